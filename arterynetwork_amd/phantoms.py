@@ -1,0 +1,127 @@
+"""Synthetic MRA-like inputs for the VRG path (numpy only, deterministic).
+
+These are the recipes SURVEY.md §8(d) fixes for BASELINE.json's configs, plus the
+small adversarial volumes the parity tests use.  Every function returns
+``(dataArray, valueMap)`` with ``valueMap`` following the reference's label
+contract (variationalRegionGrowing.py:21): 0 = seed/inside, 3 = outside, 4 = excluded.
+
+The same recipes are used by tests/golden/make_goldens.py (which runs the real
+reference on them in the build container) and by the GPU parity tests/bench, so
+goldens and live runs see byte-identical inputs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def straight_line():
+    """Reference KAT, variationalRegionGrowing.py:284-289 (inputs only)."""
+    volume = np.zeros((50, 50, 150), dtype=int)
+    volume[20:22, 20:22, 20:40] = 1
+    valueMap = np.full(volume.shape, 3)
+    valueMap[20:22, 20:22, 22:25] = 0
+    return volume, valueMap
+
+
+def sphere():
+    """Reference KAT, variationalRegionGrowing.py:300-305 (inputs only)."""
+    x, y, z = np.mgrid[:50, :50, :50]
+    volume = ((x - 25) ** 2 + (y - 25) ** 2 + (z - 25) ** 2 <= 100).astype(int)
+    valueMap = np.full(volume.shape, 3)
+    valueMap[25:27, 25:27, 25:27] = 0
+    return volume, valueMap
+
+
+def tube_phantom(shape=(128, 128, 64), radius=3.5, noise=0.1, seed=2024,
+                 seed_planes=4, amp_y=20.0, amp_z=8.0, levels=None,
+                 brain_mask=False, dtype=np.float64, noise_dtype=np.float64):
+    """Sinusoid tube along x (SURVEY.md §8(d) "Config 1" recipe when called with defaults).
+
+    centreline cy = ny/2 + amp_y*sin(2*pi*x/nx), cz = nz/2 + amp_z*cos(2*pi*x/nx);
+    tube (y-cy)^2 + (z-cz)^2 <= radius^2; I = tube + noise*N(0,1) drawn with
+    default_rng(seed).standard_normal in C order, cast through float32.
+    ``levels``: if given, quantise I to round(I*levels)/levels (integer-level volume).
+    ``brain_mask``: label 4 (excluded) outside a centred ellipsoid.
+    Seeds (label 0) = tube voxels with x < seed_planes.
+    """
+    nx, ny, nz = shape
+    x = np.arange(nx, dtype=np.float64)[:, None, None]
+    y = np.arange(ny, dtype=np.float64)[None, :, None]
+    z = np.arange(nz, dtype=np.float64)[None, None, :]
+    cy = ny / 2.0 + amp_y * np.sin(2 * np.pi * x / nx)
+    cz = nz / 2.0 + amp_z * np.cos(2 * np.pi * x / nx)
+    tube = ((y - cy) ** 2 + (z - cz) ** 2) <= radius ** 2
+    rng = np.random.default_rng(seed)
+    if noise_dtype == np.float64:   # survey recipe: float64 draw, then one cast through float32
+        I = (tube + noise * rng.standard_normal(shape)).astype(np.float32)
+    else:                           # large volumes: draw float32 directly (half the host memory)
+        I = tube.astype(np.float32) + np.float32(noise) * rng.standard_normal(shape, dtype=np.float32)
+    if levels is not None:
+        I = (np.round(I * np.float32(levels)) / np.float32(levels)).astype(np.float32)
+    valueMap = np.full(shape, 3, dtype=np.int64)
+    if brain_mask:
+        ell = (((x - (nx - 1) / 2.0) / (0.48 * nx)) ** 2 + ((y - (ny - 1) / 2.0) / (0.48 * ny)) ** 2
+               + ((z - (nz - 1) / 2.0) / (0.48 * nz)) ** 2) <= 1.0
+        valueMap[~np.broadcast_to(ell, shape)] = 4
+    seeds = tube & (np.arange(nx)[:, None, None] < seed_planes)
+    valueMap[seeds] = 0
+    return I.astype(dtype), valueMap
+
+
+def config1():
+    """BASELINE.json configs[0]: 128x128x64 tube phantom (continuous-valued, seed 2024)."""
+    return tube_phantom()
+
+
+def noise_volume(shape, seed, p_seed=0.2, p_excl=0.3, levels=None):
+    """Pure-noise adversarial volume: every voxel independently seed / excluded / outside."""
+    rng = np.random.default_rng(seed)
+    I = rng.standard_normal(shape).astype(np.float32)
+    if levels is not None:
+        I = (np.round(I * np.float32(levels)) / np.float32(levels)).astype(np.float32)
+    u = rng.random(shape)
+    valueMap = np.full(shape, 3, dtype=np.int64)
+    valueMap[u < p_seed] = 0
+    valueMap[u > 1.0 - p_excl] = 4
+    return I.astype(np.float64), valueMap
+
+
+def scattered_seeds(shape=(24, 24, 24), seed=7, n_seeds=40, p_excl=0.35):
+    """Single-voxel seeds scattered in a two-blob intensity field with excluded voxels adjacent
+    to seeds: exercises ghost outer-boundary voxels and skipped flips (SURVEY.md §8c iii)."""
+    rng = np.random.default_rng(seed)
+    nx, ny, nz = shape
+    x, y, z = np.mgrid[:nx, :ny, :nz]
+    blob = (((x - nx * 0.35) ** 2 + (y - ny * 0.4) ** 2 + (z - nz * 0.5) ** 2) <= (0.22 * nx) ** 2) | \
+           (((x - nx * 0.7) ** 2 + (y - ny * 0.65) ** 2 + (z - nz * 0.45) ** 2) <= (0.18 * nx) ** 2)
+    I = blob.astype(np.float32) + np.float32(0.35) * rng.standard_normal(shape).astype(np.float32)
+    valueMap = np.full(shape, 3, dtype=np.int64)
+    valueMap[rng.random(shape) < p_excl] = 4
+    flat = rng.choice(nx * ny * nz, size=n_seeds, replace=False)
+    valueMap.reshape(-1)[flat] = 0
+    return I.astype(np.float64), valueMap
+
+
+def shell_with_holes(n=20, seed=11, hole_frac=0.08):
+    """Ball whose seed set is a thick shell with random pin-holes and a hollow core:
+    exercises hole filling (ghost inner-boundary voxels, omitted density terms)."""
+    rng = np.random.default_rng(seed)
+    x, y, z = np.mgrid[:n, :n, :n]
+    c = (n - 1) / 2.0
+    r2 = (x - c) ** 2 + (y - c) ** 2 + (z - c) ** 2
+    ball = r2 <= (0.42 * n) ** 2
+    shell = ball & (r2 >= (0.2 * n) ** 2)
+    I = ball.astype(np.float32) + np.float32(0.25) * rng.standard_normal((n, n, n)).astype(np.float32)
+    valueMap = np.full((n, n, n), 3, dtype=np.int64)
+    seeds = shell & (rng.random((n, n, n)) > hole_frac)
+    valueMap[seeds] = 0
+    return I.astype(np.float64), valueMap
+
+
+def bench_volume(shape, seed, levels=255, radius=4.0, noise=0.1, seed_planes=3):
+    """Configs 2-4 family: helix/sinusoid tube longer than the sweep count,
+    integer-level intensities stored fp32, excluded voxels outside a centred ellipsoid."""
+    nx, ny, nz = shape
+    return tube_phantom(shape=shape, radius=radius, noise=noise, seed=seed, seed_planes=seed_planes,
+                        amp_y=0.18 * ny, amp_z=0.18 * nz, levels=levels, brain_mask=True,
+                        dtype=np.float32, noise_dtype=np.float32)
