@@ -1,0 +1,335 @@
+// vrg_engine.cpp - handle management and the C-ABI entry points (include/vrg.h) on top of a backend.
+// Compiled with hipcc into libvrg_hip.so (backend vrg_device.hip).  tests/hostmodel compiles the same
+// file with VRG_API_PREFIX=vrgm_ against the sequential test backend.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vrg.h"
+#include "vrg_backend.h"
+#include "vrg_items.h"
+
+#ifndef VRG_API_PREFIX
+#define VRG_API_PREFIX vrg_
+#endif
+#define VRG_CAT2(a, b) a##b
+#define VRG_CAT(a, b) VRG_CAT2(a, b)
+#define API(name) VRG_CAT(VRG_API_PREFIX, name)
+
+struct vrg_handle {
+    VrgCtx c;
+    std::string err;
+    std::vector<void*> owned;
+    int device = 0;
+    bool have_vol = false, have_lab = false, inited = false;
+    int variant = 0, batch = 8;
+    uint64_t band_capacity = 0;
+    VrgEvents ev{0, 0.0, 0};
+    std::chrono::steady_clock::time_point t0;
+    int64_t V = 0;
+    uint8_t* lab_base[2] = {nullptr, nullptr};
+};
+
+extern "C" void API(destroy)(vrg_handle* h);
+
+namespace {
+
+int fail(vrg_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+template <class T> T* alloc(vrg_handle* h, size_t n) {
+    void* p = be_alloc(std::max<size_t>(n, 1) * sizeof(T));
+    if (p) h->owned.push_back(p);
+    return (T*)p;
+}
+
+VrgState get_state(vrg_handle* h) { VrgState s; be_download(&s, h->c.st, sizeof(s)); return s; }
+void put_state(vrg_handle* h, const VrgState& s) { be_upload(h->c.st, &s, sizeof(s)); }
+
+void idx_to_xyz(const VrgCtx& c, uint32_t idx, int64_t* out) {
+    int x, y, z; vrg_coords(c, idx, x, y, z);
+    out[0] = x; out[1] = y; out[2] = z;
+}
+
+int check_state_error(vrg_handle* h, const VrgState& s) {
+    if (s.error == 1) return fail(h, VRG_E_CAPACITY, "band capacity exceeded; raise option band_capacity");
+    if (s.error == 2) return fail(h, VRG_E_CAPACITY, "flip capacity exceeded; raise option band_capacity");
+    if (s.error) return fail(h, VRG_E_INTERNAL, "internal consistency check failed (code " + std::to_string(s.error) + ")");
+    return VRG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out) {
+    if (!out) return VRG_E_ARG;
+    *out = nullptr;
+    if (nx < 1 || ny < 1 || nz < 1) return VRG_E_ARG;
+    int64_t PX = (nx + 2 + 15) / 16 * 16, PY = ny + 4, PZ = nz + 4;
+    if ((double)PX * (double)PY * (double)PZ >= 4294967040.0) return VRG_E_ARG;   // 32-bit voxel indices
+    if (be_set_device(device) != 0) return VRG_E_NOGPU;
+    vrg_handle* h = new vrg_handle();
+    h->device = device;
+    std::memset(&h->c, 0, sizeof(VrgCtx));
+    VrgCtx& c = h->c;
+    c.nx = (int32_t)nx; c.ny = (int32_t)ny; c.nz = (int32_t)nz;
+    c.PX = (int32_t)PX; c.PY = (int32_t)PY; c.PZ = (int32_t)PZ;
+    c.PV = (uint32_t)(PX * PY * PZ);
+    h->V = nx * ny * nz;
+    c.I = alloc<float>(h, c.PV);
+    // 16 guard bytes in front: voxel (0,0,0)'s 2-ring reaches 2 bytes before the padded array
+    h->lab_base[0] = alloc<uint8_t>(h, (size_t)c.PV + 32);
+    h->lab_base[1] = alloc<uint8_t>(h, (size_t)c.PV + 32);
+    c.lab[0] = h->lab_base[0] ? h->lab_base[0] + 16 : nullptr;
+    c.lab[1] = h->lab_base[1] ? h->lab_base[1] + 16 : nullptr;
+    c.stamp = alloc<uint64_t>(h, c.PV);
+    c.st = alloc<VrgState>(h, 1);
+    if (!c.I || !c.lab[0] || !c.lab[1] || !c.stamp || !c.st) { API(destroy)(h); return VRG_E_MEM; }
+    be_fill((void*)c.I, 0, (size_t)c.PV * 4);
+    be_fill(h->lab_base[0], VB_OOB, (size_t)c.PV + 32);
+    be_fill(h->lab_base[1], VB_OOB, (size_t)c.PV + 32);
+    be_fill(c.st, 0, sizeof(VrgState));
+    *out = h;
+    return VRG_OK;
+}
+
+void API(destroy)(vrg_handle* h) {
+    if (!h) return;
+    be_sync();
+    for (void* p : h->owned) be_free(p);
+    delete h;
+}
+
+const char* API(last_error)(const vrg_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
+    if (!h || !name) return VRG_E_ARG;
+    std::string n(name);
+    if (n == "band_capacity") { if (h->inited || value < 1) return fail(h, VRG_E_STATE, "band_capacity must be set before vrg_init"); h->band_capacity = (uint64_t)value; }
+    else if (n == "sweep_variant") h->variant = (int)value;
+    else if (n == "events") h->ev.enabled = value != 0;
+    else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
+    else return fail(h, VRG_E_ARG, "unknown option " + n);
+    return VRG_OK;
+}
+
+int API(set_volume)(vrg_handle* h, const void* data, int dtype, const int64_t st[3]) {
+    if (!h || !data || !st || dtype < VRG_U8 || dtype > VRG_F64) return fail(h, VRG_E_ARG, "set_volume: bad argument");
+    int inexact = 0;
+    int rc = be_pack_volume(h->c, (float*)h->c.I, data, dtype, st, &inexact);
+    if (rc) return fail(h, VRG_E_ARG, "set_volume: unsupported strides");
+    if (inexact) return fail(h, VRG_E_INEXACT, "set_volume: intensities are not exactly representable in fp32");
+    h->have_vol = true; h->inited = false;
+    h->c.lev = nullptr;                              // distinct-value table is rebuilt by the next vrg_init
+    return VRG_OK;
+}
+
+int API(set_labels)(vrg_handle* h, const void* labels, int dtype, const int64_t st[3]) {
+    if (!h || !labels || !st || dtype < VRG_U8 || dtype > VRG_F64) return fail(h, VRG_E_ARG, "set_labels: bad argument");
+    be_fill(h->lab_base[0], VB_OOB, (size_t)h->c.PV + 32);
+    be_fill(h->lab_base[1], VB_OOB, (size_t)h->c.PV + 32);
+    int bad = 0;
+    int rc = be_pack_labels(h->c, h->c.lab[0], labels, dtype, st, &bad);
+    if (rc) return fail(h, VRG_E_ARG, "set_labels: unsupported strides");
+    if (bad) return fail(h, VRG_E_ARG, "set_labels: valueMap must contain only 0 (seed), 3 (outside), 4 (excluded)");
+    h->have_lab = true; h->inited = false;
+    return VRG_OK;
+}
+
+int API(init)(vrg_handle* h, double H) {
+    if (!h) return VRG_E_ARG;
+    if (!h->have_vol || !h->have_lab) return fail(h, VRG_E_STATE, "vrg_init: set_volume and set_labels first");
+    if (h->inited) return fail(h, VRG_E_STATE, "vrg_init: already initialised; set_labels again to restart");
+    VrgCtx& c = h->c;
+    h->t0 = std::chrono::steady_clock::now();       // start_time (:38)
+    c.H = H;
+    c.A = std::pow(2.0 * M_PI, -0.5);               // A = (2*np.pi)**(-0.5) (:7)
+    // levels
+    double* lev = nullptr; uint32_t L = 0;
+    if (c.lev) { /* re-init on the same volume: keep */ lev = (double*)c.lev; L = c.L; }
+    else {
+        if (be_build_levels(c, &lev, &L)) return fail(h, VRG_E_MEM, "vrg_init: level table");
+        h->owned.push_back(lev);
+        c.lev = lev; c.L = L;
+        c.hin = alloc<int32_t>(h, L); c.hout = alloc<int32_t>(h, L);
+        c.dIn = alloc<uint32_t>(h, L); c.dOut = alloc<uint32_t>(h, L); c.dConv = alloc<uint32_t>(h, L);
+        c.nz_lev = alloc<uint32_t>(h, L); c.nz_val = alloc<double>(h, L);
+        c.nz_cin = alloc<uint32_t>(h, L); c.nz_cout = alloc<uint32_t>(h, L); c.nz_cconv = alloc<uint32_t>(h, L);
+        c.tabC = alloc<double>(h, 3 * (size_t)L);
+        if (!c.hin || !c.hout || !c.dIn || !c.dOut || !c.dConv || !c.nz_lev || !c.nz_val || !c.nz_cin || !c.nz_cout || !c.nz_cconv || !c.tabC)
+            return fail(h, VRG_E_MEM, "vrg_init: level arrays");
+    }
+    be_fill(c.hin, 0, (size_t)L * 4); be_fill(c.hout, 0, (size_t)L * 4);
+    be_fill(c.dIn, 0, (size_t)L * 4); be_fill(c.dOut, 0, (size_t)L * 4); be_fill(c.dConv, 0, (size_t)L * 4);
+    // band storage
+    if (!c.b_idx[0]) {
+        uint64_t V = (uint64_t)h->V;
+        uint64_t cap = h->band_capacity ? h->band_capacity : (V <= (32u << 20) ? V : std::max<uint64_t>(32u << 20, V / 8));
+        cap = std::min<uint64_t>(std::max<uint64_t>(cap, 64), V);
+        c.bcap = (uint32_t)cap; c.fcap = c.bcap;
+        for (int p = 0; p < 2; p++) {
+            c.b_idx[p] = alloc<uint32_t>(h, c.bcap); c.b_lev[p] = alloc<uint32_t>(h, c.bcap);
+            c.b_ip[p] = alloc<double>(h, c.bcap); c.b_op[p] = alloc<double>(h, c.bcap);
+            if (!c.b_idx[p] || !c.b_lev[p] || !c.b_ip[p] || !c.b_op[p]) return fail(h, VRG_E_MEM, "vrg_init: band arrays");
+        }
+        c.e_flag = alloc<uint8_t>(h, c.bcap); c.e_surv = alloc<uint8_t>(h, c.bcap);
+        c.scan = alloc<uint32_t>(h, (size_t)c.bcap + 2 * (size_t)c.fcap + 16);
+        c.f_entry = alloc<uint32_t>(h, c.fcap); c.f_idx = alloc<uint32_t>(h, c.fcap);
+        c.f_mask = alloc<uint32_t>(h, c.fcap); c.f_res = alloc<uint8_t>(h, c.fcap);
+        c.pend = alloc<uint32_t>(h, c.fcap); c.fresh = alloc<uint32_t>(h, c.bcap);
+        c.init_key = alloc<uint64_t>(h, c.bcap); c.init_idx = alloc<uint32_t>(h, c.bcap);
+        c.nstat = 4096;
+        c.st_nin = alloc<int64_t>(h, c.nstat); c.st_nout = alloc<int64_t>(h, c.nstat);
+        c.st_sin = alloc<double>(h, c.nstat); c.st_sout = alloc<double>(h, c.nstat);
+        c.trace_cap = 1u << 16;
+        c.trace = alloc<VrgTrace>(h, c.trace_cap);
+        if (!c.e_flag || !c.e_surv || !c.scan || !c.f_entry || !c.f_idx || !c.f_mask || !c.f_res || !c.pend || !c.fresh ||
+            !c.init_key || !c.init_idx || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace)
+            return fail(h, VRG_E_MEM, "vrg_init: work arrays");
+    }
+    VrgState s; std::memset(&s, 0, sizeof(s));
+    s.iterMax = 0; s.maxSegmentSize = 0;
+    put_state(h, s);
+    be_init_band(c);
+    s = get_state(h);
+    if (s.error || (uint64_t)s.ninit_in + s.ninit_out > c.bcap) return fail(h, VRG_E_CAPACITY, "vrg_init: band capacity exceeded");
+    if (s.nseed == 0) return fail(h, VRG_E_EMPTY, "vrg_init: valueMap has no seed (label 0) voxel");
+    be_init_sort(c, s.ninit_in, s.ninit_out);
+    s.ni = s.ninit_in; s.no = s.ninit_out; s.nfresh = s.ni + s.no;
+    put_state(h, s);
+    be_init_finish(c);
+    s = get_state(h);
+    int rc = check_state_error(h, s);
+    if (rc) return rc;
+    h->inited = true;
+    h->ev.ms_total = 0; h->ev.launches = 0;
+    return VRG_OK;
+}
+
+int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxSeconds, vrg_result* out) {
+    if (!h) return VRG_E_ARG;
+    if (!h->inited) return fail(h, VRG_E_STATE, "vrg_run: call vrg_init first");
+    VrgCtx& c = h->c;
+    if (iterMax < 0 || iterMax + 1 >= (int64_t)c.trace_cap) return fail(h, VRG_E_ARG, "vrg_run: iterMax out of range");
+    VrgState s = get_state(h);
+    int rc = check_state_error(h, s);
+    if (rc) return rc;
+    int32_t iter0 = s.iter;
+    s.done = 0; s.iterMax = (int32_t)iterMax; s.maxSegmentSize = maxSegmentSize;
+    put_state(h, s);
+    double ms0 = h->ev.ms_total; long long l0 = h->ev.launches;
+    auto t_begin = std::chrono::steady_clock::now();
+    for (;;) {
+        int64_t remaining = iterMax - s.iter;
+        int nb = (int)std::min<int64_t>(h->batch, std::max<int64_t>(remaining, 0) + 1);   // +1: the trip that sets the stop flag
+        for (int i = 0; i < nb; i++) be_sweep_once(c, h->variant, &h->ev);
+        s = get_state(h);
+        if (s.done || s.error) break;
+        if (maxSeconds >= 0) {                       // wall-clock cap (:97), checked between batches
+            double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->t0).count();
+            if (el >= maxSeconds) { s.done = VRG_STOP_TIME; put_state(h, s); break; }
+        }
+    }
+    be_sync();
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    rc = check_state_error(h, s);
+    if (rc) return rc;
+    if (out) {
+        out->stop_reason = s.done; out->iter_num = s.iter + 1; out->sweeps = s.iter - iter0;
+        out->nseg = s.n_in; out->n_in = s.n_in; out->n_out = s.n_out; out->ni = s.ni; out->no = s.no;
+        out->sum_in = s.sum_in; out->sum_out = s.sum_out; out->seconds = secs;
+        out->sweep_kernel_ms = h->ev.ms_total - ms0; out->sweep_launches = h->ev.launches - l0;
+    }
+    return VRG_OK;
+}
+
+int API(get_labels)(vrg_handle* h, void* outp, int dtype, const int64_t st[3]) {
+    if (!h || !outp || !st || dtype < VRG_U8 || dtype > VRG_F64) return fail(h, VRG_E_ARG, "get_labels: bad argument");
+    VrgState s = get_state(h);
+    int par = h->inited ? (s.iter & 1) : 0;
+    if (be_unpack_labels(h->c, h->c.lab[par], outp, dtype, st)) return fail(h, VRG_E_ARG, "get_labels: unsupported strides");
+    return VRG_OK;
+}
+
+int API(get_segmented)(vrg_handle* h, int64_t* coords, int64_t cap, int64_t* n) {
+    if (!h || !n) return VRG_E_ARG;
+    if (!h->inited) return fail(h, VRG_E_STATE, "get_segmented: not initialised");
+    VrgState s = get_state(h);
+    *n = s.n_in;
+    if (!coords) return VRG_OK;
+    if (cap < s.n_in) return fail(h, VRG_E_ARG, "get_segmented: buffer too small");
+    std::vector<uint64_t> stamps((size_t)s.n_in + 1);
+    std::vector<uint32_t> idxs((size_t)s.n_in + 1);
+    uint32_t got = be_collect_segmented(h->c, s.iter & 1, stamps.data(), idxs.data(), (uint32_t)s.n_in);
+    if ((int64_t)got != s.n_in) return fail(h, VRG_E_INTERNAL, "get_segmented: count mismatch");
+    std::vector<uint32_t> order(got);
+    for (uint32_t i = 0; i < got; i++) order[i] = i;
+    // list order of segmentedList: seeds in np.where order (:44), then appended per applied flip-in (:200)
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return stamps[a] < stamps[b]; });
+    for (uint32_t i = 0; i < got; i++) idx_to_xyz(h->c, idxs[order[i]], coords + 3 * (size_t)i);
+    return VRG_OK;
+}
+
+int API(get_band)(vrg_handle* h, int which, int64_t* coords, double* ip, double* op, int64_t cap, int64_t* n) {
+    if (!h || !n) return VRG_E_ARG;
+    if (!h->inited) return fail(h, VRG_E_STATE, "get_band: not initialised");
+    VrgState s = get_state(h);
+    int par = s.iter & 1;
+    uint32_t cnt = which ? s.no : s.ni, off = which ? s.ni : 0;
+    *n = cnt;
+    if (!coords && !ip && !op) return VRG_OK;
+    if (cap < cnt) return fail(h, VRG_E_ARG, "get_band: buffer too small");
+    if (coords) {
+        std::vector<uint32_t> idx(cnt + 1);
+        be_download(idx.data(), h->c.b_idx[par] + off, (size_t)cnt * 4);
+        for (uint32_t i = 0; i < cnt; i++) idx_to_xyz(h->c, idx[i], coords + 3 * (size_t)i);
+    }
+    if (ip) be_download(ip, h->c.b_ip[par] + off, (size_t)cnt * 8);
+    if (op) be_download(op, h->c.b_op[par] + off, (size_t)cnt * 8);
+    return VRG_OK;
+}
+
+int API(get_trace)(vrg_handle* h, vrg_trace_rec* outp, int64_t cap, int64_t* n) {
+    if (!h || !n) return VRG_E_ARG;
+    if (!h->inited) return fail(h, VRG_E_STATE, "get_trace: not initialised");
+    VrgState s = get_state(h);
+    *n = s.iter + 1;
+    if (!outp) return VRG_OK;
+    if (cap < *n) return fail(h, VRG_E_ARG, "get_trace: buffer too small");
+    static_assert(sizeof(vrg_trace_rec) == sizeof(VrgTrace), "trace record layout");
+    be_download(outp, h->c.trace, (size_t)(*n) * sizeof(VrgTrace));
+    return VRG_OK;
+}
+
+int API(get_levels)(vrg_handle* h, double* values, int32_t* hin, int32_t* hout, int32_t* rin, int32_t* rout,
+                    int64_t cap, int64_t* n) {
+    if (!h || !n) return VRG_E_ARG;
+    if (!h->inited) return fail(h, VRG_E_STATE, "get_levels: not initialised");
+    uint32_t L = h->c.L;
+    *n = L;
+    if (!values && !hin && !hout && !rin && !rout) return VRG_OK;
+    if (cap < L) return fail(h, VRG_E_ARG, "get_levels: buffer too small");
+    if (values) be_download(values, h->c.lev, (size_t)L * 8);
+    if (hin) be_download(hin, h->c.hin, (size_t)L * 4);
+    if (hout) be_download(hout, h->c.hout, (size_t)L * 4);
+    if (rin && rout) {
+        VrgState s = get_state(h);
+        int32_t* di = (int32_t*)be_alloc((size_t)L * 4);
+        int32_t* dout = (int32_t*)be_alloc((size_t)L * 4);
+        if (!di || !dout) return fail(h, VRG_E_MEM, "get_levels");
+        be_fill(di, 0, (size_t)L * 4); be_fill(dout, 0, (size_t)L * 4);
+        be_recount_hist(h->c, s.iter & 1, di, dout);
+        be_download(rin, di, (size_t)L * 4); be_download(rout, dout, (size_t)L * 4);
+        be_free(di); be_free(dout);
+    }
+    return VRG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,474 @@
+// vrg_items.h - per-item device functions of the VRG sweep (one band entry, one listed flip, one voxel).
+//
+// These restate variationalRegionGrowing.py's SEQUENTIAL update() (:124-261) as order-independent
+// local rules so that every item can run in parallel.  Derivation (validated against the oracle and
+// the reference goldens in tests/):
+//
+//  * flip list = concat(innerBnd, outerBnd)[mask] (:48,:88,:111): all flip-outs (label 1) precede all
+//    flip-ins (label 2); "rank" = position in that list.  Ranks only ever matter between 26-neighbours.
+//  * phase A (flip-outs, :170-196), always applied:  P: 1->2.  A label-0 neighbour becomes 1 (:194).
+//    A label-2 voxel next to a flip-out becomes 3 iff no segmented neighbour is left after all
+//    flip-outs (:186-190) - for a flipped-out voxel itself only if a flip-out neighbour of larger rank
+//    re-examines it; otherwise it stays a "ghost" 2.
+//  * phase B (flip-ins, :198-230): a flip-in whose label is still 2 after phase A is applied; one that
+//    dropped to 3 is skipped (both branches :170/:198 fail) unless an applied flip-in neighbour of
+//    smaller rank re-promoted it first (:210-213) - a monotone fix-point along rank order (P bit).
+//    Applied P: 2->1; its label-3 (or freshly included label-4) neighbours become 2; a label-1
+//    neighbour becomes 0 iff it has no non-segmented neighbour left (:223-228) - the flipped-in voxel
+//    itself only if an applied flip-in neighbour of larger rank re-examines it ("ghost" 1 otherwise).
+//  * 4->3 inclusion: 1-ring of every listed flip (:166-168) and 2-ring of every applied flip
+//    (:177-179, :206-208).
+//  * list order after the sweep (:257-258): survivors keep their order; appended in order:
+//    inner: phase-A promotions keyed (rank of first flip-out neighbour, k) then applied flip-ins by rank;
+//    outer: flip-outs still labelled 2 by rank, then phase-B promotions keyed (rank of first applied
+//    flip-in neighbour, k); k = position of the promoted voxel in get_neighbours(promoter) (:263-282).
+//  * densities (:232-255): incremental correction for entries that stayed in the band for the whole
+//    sweep, exact recomputation for entries that (re-)entered it (newInnerBndList/newOuterBndList).
+#pragma once
+#include <math.h>
+#include "vrg_types.h"
+
+// ------------------------------------------------------------------ backend shims
+#if defined(__HIP_DEVICE_COMPILE__)
+VRG_HD uint32_t vrg_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+VRG_HD int32_t vrg_atomic_add(int32_t* p, int32_t v) { return atomicAdd(p, v); }
+VRG_HD uint32_t vrg_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
+VRG_HD uint8_t vrg_load_coherent(const uint8_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#else
+VRG_HD uint32_t vrg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+VRG_HD int32_t vrg_atomic_add(int32_t* p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
+VRG_HD uint32_t vrg_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+VRG_HD uint8_t vrg_load_coherent(const uint8_t* p) { return *(const volatile uint8_t*)p; }
+#endif
+
+// OR bits into one label byte without disturbing concurrent ORs into its neighbours
+VRG_HD void vrg_or_byte(uint8_t* lab, uint32_t idx, uint8_t bits) {
+    uint32_t* w = (uint32_t*)(lab + (idx & ~3u));
+    vrg_atomic_or(w, (uint32_t)bits << (8 * (idx & 3u)));
+}
+
+// ------------------------------------------------------------------ geometry
+VRG_HD uint32_t vrg_idx(const VrgCtx& c, int x, int y, int z) {
+    return ((uint32_t)(z + 2) * (uint32_t)c.PY + (uint32_t)(y + 2)) * (uint32_t)c.PX + (uint32_t)x;
+}
+VRG_HD void vrg_coords(const VrgCtx& c, uint32_t idx, int& x, int& y, int& z) {
+    x = (int)(idx % (uint32_t)c.PX);
+    uint32_t r = idx / (uint32_t)c.PX;
+    y = (int)(r % (uint32_t)c.PY) - 2;
+    z = (int)(r / (uint32_t)c.PY) - 2;
+}
+VRG_HD uint64_t vrg_lex(const VrgCtx& c, uint32_t idx) {   // np.where order (:44): x slowest, z fastest
+    int x, y, z; vrg_coords(c, idx, x, y, z);
+    return ((uint64_t)x * (uint64_t)c.ny + (uint64_t)y) * (uint64_t)c.nz + (uint64_t)z;
+}
+// k-th offset of get_neighbours (:266-269): lexicographic in (dx,dy,dz), k = 13 is the centre
+VRG_HD int32_t vrg_off(const VrgCtx& c, int k) {
+    int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
+    return (dz * c.PY + dy) * c.PX + dx;
+}
+
+VRG_HD uint8_t vrg_enc(uint8_t ext) {     // reference label -> byte
+    return ext == 0 ? VB_S : ext == 1 ? (VB_S | VB_B) : ext == 2 ? VB_B : ext == 4 ? VB_X : 0;
+}
+VRG_HD uint8_t vrg_dec(uint8_t b) {       // byte -> reference label
+    if (b & VB_S) return (b & VB_B) ? 1 : 0;
+    if (b & VB_B) return 2;
+    return (b & VB_X) ? 4 : 3;
+}
+
+VRG_HD double vrg_kern(const VrgCtx& c, double d) { return c.A * exp(-0.5 * c.H * (d * d)); }   // :154
+
+VRG_HD uint32_t vrg_level_of(const VrgCtx& c, double v) {   // index of v in the sorted distinct values
+    uint32_t lo = 0, hi = c.L - 1;
+    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (c.lev[m] < v) lo = m + 1; else hi = m; }
+    return lo;
+}
+
+// ------------------------------------------------------------------ decide (:79-88)
+VRG_HD void vrg_item_decide(const VrgCtx& c, uint32_t e) {
+    const VrgState& s = *c.st;
+    int cur = s.iter & 1;
+    double inN = c.b_ip[cur][e] / (double)s.n_in;       // :81
+    double outN = c.b_op[cur][e] / (double)s.n_out;     // :82
+    bool ge = inN >= outN;
+    bool inner = e < s.ni;
+    uint8_t flip = (inner != ge) ? 1 : 0;               // :87 xor(segmentedMap, inner >= outer)
+    c.e_flag[e] = flip;
+    c.scan[e] = flip;
+}
+
+// after the exclusive scan of the flip flags: sizes + the stop tests in the reference's order
+VRG_HD void vrg_item_fin_decide(const VrgCtx& c, uint32_t total) {
+    VrgState& s = *c.st;
+    uint32_t n = s.ni + s.no;
+    s.nf = total;
+    s.nfo = (s.ni < n) ? c.scan[s.ni] : total;
+    s.npend = 0; s.nfresh = 0; s.fix_changed = 0;
+    if (s.iter >= s.iterMax) s.done = VRG_STOP_ITERMAX;                  // while iterNum <= iterMax (:58)
+    else if (total == 0) s.done = VRG_STOP_CONVERGED;                    // :91
+    else if (s.n_in >= s.maxSegmentSize) s.done = VRG_STOP_SIZE;         // :101 (time cap :97 is host side)
+    else if (total > c.fcap) { s.error = 2; s.done = -2; }
+}
+
+// listed flips: rank-indexed tables, L (+P for flip-outs) bits, stamp
+VRG_HD void vrg_item_mark(const VrgCtx& c, uint32_t e) {
+    if (!c.e_flag[e]) return;
+    const VrgState& s = *c.st;
+    int cur = s.iter & 1;
+    uint32_t r = c.scan[e], idx = c.b_idx[cur][e];
+    c.f_entry[r] = e; c.f_idx[r] = idx; c.f_mask[r] = 0; c.f_res[r] = 0;
+    vrg_or_byte(c.lab[cur], idx, (uint8_t)(VB_L | (e < s.ni ? VB_P : 0)));
+    c.stamp[idx] = ((uint64_t)(uint32_t)(s.iter + 1) << 32) | r;
+}
+
+// flip-ins: label after phase A (:183-190) decides whether the flip is applied at once
+VRG_HD void vrg_item_prepass(const VrgCtx& c, uint32_t j) {
+    VrgState& s = *c.st;
+    int cur = s.iter & 1;
+    uint32_t r = s.nfo + j, idx = c.f_idx[r];
+    const uint8_t* lab = c.lab[cur];
+    bool nFO = false, nSegA = false;
+    for (int k = 0; k < 27; k++) {
+        if (k == 13) continue;
+        uint8_t m = lab[(int64_t)idx + vrg_off(c, k)];
+        if (m & VB_S) { if (m & VB_L) nFO = true; else nSegA = true; }
+    }
+    if (nFO && !nSegA) c.pend[vrg_atomic_add(&s.npend, 1u)] = r;   // dropped to 3: skipped unless re-promoted
+    else vrg_or_byte(c.lab[cur], idx, VB_P);
+}
+
+// one relaxation of the skip rule: applied if an applied flip-in neighbour of smaller rank exists
+VRG_HD bool vrg_item_fix(const VrgCtx& c, uint32_t j) {
+    const VrgState& s = *c.st;
+    int cur = s.iter & 1;
+    uint32_t r = c.pend[j], idx = c.f_idx[r];
+    uint8_t* lab = c.lab[cur];
+    if (vrg_load_coherent(lab + idx) & VB_P) return false;
+    for (int k = 0; k < 27; k++) {
+        if (k == 13) continue;
+        uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
+        uint8_t mb = vrg_load_coherent(lab + m);
+        if (!(mb & VB_S) && (mb & VB_L) && (mb & VB_P) && (uint32_t)c.stamp[m] < r) {
+            vrg_or_byte(lab, idx, VB_P);
+            return true;
+        }
+    }
+    return false;
+}
+
+// scatter the "needs the stencil" mark: 1-ring of every listed flip (incl. itself), and excluded
+// voxels in the 2-ring of every applied flip.  Everything else keeps its label this sweep.
+#define VB_M 128
+VRG_HD void vrg_item_scatter_marks(const VrgCtx& c, uint32_t r) {
+    const VrgState& s = *c.st;
+    int cur = s.iter & 1;
+    uint8_t* lab = c.lab[cur];
+    uint32_t idx = c.f_idx[r];
+    bool applied = (lab[idx] & VB_P) != 0;
+    for (int dz = -2; dz <= 2; dz++)
+        for (int dy = -2; dy <= 2; dy++)
+            for (int dx = -2; dx <= 2; dx++) {
+                bool ring1 = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+                if (!ring1 && !applied) continue;
+                int64_t m = (int64_t)idx + (dz * c.PY + dy) * c.PX + dx;   // may be -1,-2 (guard bytes) at voxel (0,0,0)
+                uint8_t mb = lab[m];
+                if (mb & (VB_OOB | VB_M)) continue;
+                if (ring1 || (mb & VB_X)) vrg_or_byte(lab, (uint32_t)m, VB_M);
+            }
+}
+
+// ------------------------------------------------------------------ the relabel stencil for one voxel
+// phase-B promotion (3 -> 2, :210-213): list key (first applied flip-in neighbour, k)
+VRG_HD void vrg_promote_b(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
+    uint32_t best = 0xffffffffu; int bk = 0;
+    for (int k = 0; k < 27; k++) {
+        if (k == 13) continue;
+        uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
+        uint8_t mb = lab[m];
+        if (!(mb & VB_S) && (mb & VB_P)) {
+            uint32_t r = (uint32_t)c.stamp[m];
+            if (r < best) { best = r; bk = 26 - k; }
+        }
+    }
+    vrg_atomic_or(&c.f_mask[best], 1u << bk);
+}
+// phase-A promotion (0 -> 1, :194-196): list key (first flip-out neighbour, k)
+VRG_HD void vrg_promote_a(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
+    uint32_t best = 0xffffffffu; int bk = 0;
+    for (int k = 0; k < 27; k++) {
+        if (k == 13) continue;
+        uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
+        uint8_t mb = lab[m];
+        if ((mb & VB_S) && (mb & VB_L)) {
+            uint32_t r = (uint32_t)c.stamp[m];
+            if (r < best) { best = r; bk = 26 - k; }
+        }
+    }
+    vrg_atomic_or(&c.f_mask[best], 1u << bk);
+}
+
+// Returns the voxel's byte after the sweep.  Side effects for the rare cases: f_res (listed flips),
+// f_mask (promotions), dConv (4->3 inclusions).  `lab` = this sweep's input labels (L/P bits set).
+VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t cb) {
+    bool nSegA = false, nFO = false, nAP = false, nNonSegB = false, nListed = false;
+    for (int k = 0; k < 27; k++) {
+        if (k == 13) continue;
+        uint8_t m = lab[(int64_t)idx + vrg_off(c, k)];
+        if (m & VB_OOB) continue;                     // neighbour does not exist (:278-280)
+        bool mS = m & VB_S, mL = m & VB_L, mP = m & VB_P;
+        bool segA = mS && !mL, ap = !mS && mP;
+        nSegA |= segA; nFO |= (mS && mL); nAP |= ap; nNonSegB |= !(segA || ap); nListed |= mL;
+    }
+    if (cb & VB_S) {
+        if (cb & VB_L) {                              // flip-out (:170-175), always applied
+            uint32_t r = (uint32_t)c.stamp[idx];
+            bool to3 = false;
+            if (!nSegA)                               // re-examined by a later flip-out neighbour? (:183-190)
+                for (int k = 0; k < 27 && !to3; k++) {
+                    if (k == 13) continue;
+                    uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
+                    uint8_t mb = lab[m];
+                    if ((mb & VB_S) && (mb & VB_L) && (uint32_t)c.stamp[m] > r) to3 = true;
+                }
+            if (!to3) { c.f_res[r] = FR_WRITTEN | 2; return VB_B; }          // stays 2, carried to the outer list
+            if (nAP) {                                                      // 3 -> 2 again (:210-213): fresh
+                c.f_res[r] = FR_WRITTEN | 2 | FR_FRESH;
+                vrg_promote_b(c, lab, idx);
+                return VB_B;
+            }
+            c.f_res[r] = FR_WRITTEN | 3;
+            return 0;
+        }
+        bool is1 = (cb & VB_B) || nFO;                // label after phase A (:194)
+        if (!is1) return VB_S;
+        if (nAP && !nNonSegB) return VB_S;            // 1 -> 0 (:223-228)
+        if (!(cb & VB_B)) vrg_promote_a(c, lab, idx); // newly on the inner boundary
+        return VB_S | VB_B;
+    }
+    if (cb & VB_B) {
+        if ((cb & VB_L) && (cb & VB_P)) {             // applied flip-in (:198-204)
+            uint32_t r = (uint32_t)c.stamp[idx];
+            bool to0 = false;
+            if (!nNonSegB)                            // re-examined by a later applied flip-in nbr? (:219-228)
+                for (int k = 0; k < 27 && !to0; k++) {
+                    if (k == 13) continue;
+                    uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
+                    uint8_t mb = lab[m];
+                    if (!(mb & VB_S) && (mb & VB_P) && (uint32_t)c.stamp[m] > r) to0 = true;
+                }
+            bool fresh = nFO && !nSegA;               // had dropped to 3 in phase A: exact density (:212,:251)
+            c.f_res[r] = (uint8_t)(FR_WRITTEN | (to0 ? 0 : 1) | (fresh ? FR_FRESH : 0));
+            return to0 ? VB_S : (uint8_t)(VB_S | VB_B);
+        }
+        bool to3 = nFO && !nSegA;                     // :183-190
+        uint8_t out, res;
+        if (!to3) { out = VB_B; res = 2; }
+        else if (nAP) { out = VB_B | VB_F; res = 2 | FR_FRESH; vrg_promote_b(c, lab, idx); }
+        else { out = 0; res = 3; }
+        if (cb & VB_L) c.f_res[(uint32_t)c.stamp[idx]] = (uint8_t)(FR_WRITTEN | res);   // skipped flip-in
+        return out;
+    }
+    // labels 3 and 4
+    bool conv = false;
+    if (cb & VB_X) {
+        conv = nListed;                               // 1-ring of any listed flip (:166-168)
+        if (!conv)                                    // 2-ring of any applied flip (:177-179,:206-208)
+            for (int dz = -2; dz <= 2 && !conv; dz++)
+                for (int dy = -2; dy <= 2 && !conv; dy++)
+                    for (int dx = -2; dx <= 2; dx++) {
+                        uint8_t mb = lab[(int64_t)idx + (dz * c.PY + dy) * c.PX + dx];
+                        if ((mb & VB_P) && !(mb & VB_OOB)) { conv = true; break; }
+                    }
+        if (conv) vrg_atomic_add(&c.dConv[vrg_level_of(c, (double)c.I[idx])], 1u);   // addedPoints (:235)
+    }
+    if (nAP) { vrg_promote_b(c, lab, idx); return VB_B; }   // 3 -> 2 (:210-213)
+    return (uint8_t)(((cb & VB_X) && !conv) ? VB_X : 0);
+}
+
+// ------------------------------------------------------------------ after the sweep
+// per listed flip: density bookkeeping sets (:232-233), class histograms, rebuild counts
+VRG_HD void vrg_item_flipres(const VrgCtx& c, uint32_t r) {
+    const VrgState& s = *c.st;
+    int cur = s.iter & 1;
+    uint32_t e = c.f_entry[r];
+    uint32_t lev = c.b_lev[cur][e];
+    uint8_t res = c.f_res[r];
+    if (!(res & FR_WRITTEN)) c.st->error = 3;             // a listed flip the sweep never visited
+    uint8_t fin = res & FR_FINAL;
+    bool fresh = res & FR_FRESH;
+    if (fin == 1) vrg_atomic_add(&c.dIn[lev], 1u);        // innerAdded: listed flips labelled 1 at the end
+    else if (fin == 2) vrg_atomic_add(&c.dOut[lev], 1u);  // outerAdded: ... labelled 2
+    uint32_t n = s.ni + s.no, nfo = s.nfo, nfi = s.nf - s.nfo;
+    if (r < nfo) {                                        // flip-out: inner -> outer region
+        vrg_atomic_add(&c.hin[lev], -1); vrg_atomic_add(&c.hout[lev], 1);
+        c.scan[s.ni + r] = (uint32_t)__builtin_popcount(c.f_mask[r]);                 // seg1: A promotions
+        c.scan[n + nfo + nfi + r] = (fin == 2 && !fresh) ? 1u : 0u;                   // seg4: carried to outer
+    } else {
+        uint32_t j = r - nfo;
+        if (fin <= 1) { vrg_atomic_add(&c.hin[lev], 1); vrg_atomic_add(&c.hout[lev], -1); }   // applied
+        c.scan[s.ni + nfo + j] = (fin == 1) ? 1u : 0u;                                // seg2: joins inner list
+        c.scan[n + 2 * nfo + nfi + j] = (uint32_t)__builtin_popcount(c.f_mask[r]);    // seg5: B promotions
+    }
+}
+
+// per old band entry: does it keep its place?  (count segments seg0 / seg3)
+VRG_HD void vrg_item_survivor(const VrgCtx& c, uint32_t e) {
+    const VrgState& s = *c.st;
+    int cur = s.iter & 1;
+    uint32_t idx = c.b_idx[cur][e];
+    uint8_t* nxt = c.lab[cur ^ 1];
+    uint8_t nb = nxt[idx];
+    bool inner = e < s.ni;
+    bool surv;
+    if (inner) surv = !c.e_flag[e] && (nb & VB_LABEL) == (VB_S | VB_B);
+    else {
+        surv = !c.e_flag[e] && (nb & VB_LABEL) == VB_B && !(nb & VB_F);
+        if (nb & VB_F) nxt[idx] = (uint8_t)(nb & ~VB_F);
+    }
+    c.e_surv[e] = surv;
+    uint32_t nf = s.nf;
+    c.scan[inner ? e : e + nf] = surv ? 1u : 0u;        // seg0 = [0,ni), seg3 = [ni+nf, ni+nf+no)
+}
+
+// density correction of one intensity value (:236-247)
+VRG_HD void vrg_corrections(const VrgCtx& c, double v, double& ic, double& oc, double& ac) {
+    const VrgState& s = *c.st;
+    double a = 0, b = 0, d = 0;
+    for (uint32_t i = 0; i < s.nnz; i++) {
+        double k = vrg_kern(c, c.nz_val[i] - v);
+        a += (double)c.nz_cin[i] * k; b += (double)c.nz_cout[i] * k; d += (double)c.nz_cconv[i] * k;
+    }
+    ic = a; oc = b; ac = d;
+}
+VRG_HD void vrg_apply_correction(const VrgCtx& c, uint32_t lev, double& ip, double& op) {
+    double ic, oc, ac;
+    if (c.st->use_tab) { ic = c.tabC[3 * (size_t)lev]; oc = c.tabC[3 * (size_t)lev + 1]; ac = c.tabC[3 * (size_t)lev + 2]; }
+    else vrg_corrections(c, c.lev[lev], ic, oc, ac);
+    ip += ic; ip -= oc;             // :243-244
+    op -= ic; op += oc; op += ac;   // :245-247
+}
+
+// survivors copy themselves to their new position with the incremental correction
+VRG_HD void vrg_item_scatter_surv(const VrgCtx& c, uint32_t e) {
+    if (!c.e_surv[e]) return;
+    const VrgState& s = *c.st;
+    int cur = s.iter & 1, nx = cur ^ 1;
+    bool inner = e < s.ni;
+    uint32_t pos = c.scan[inner ? e : e + s.nf];
+    if (pos >= c.bcap) { c.st->error = 1; return; }
+    uint32_t lev = c.b_lev[cur][e];
+    double ip = c.b_ip[cur][e], op = c.b_op[cur][e];
+    vrg_apply_correction(c, lev, ip, op);
+    c.b_idx[nx][pos] = c.b_idx[cur][e]; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = ip; c.b_op[nx][pos] = op;
+}
+
+VRG_HD void vrg_new_fresh(const VrgCtx& c, int nx, uint32_t pos, uint32_t idx, uint32_t lev) {
+    if (pos >= c.bcap) { c.st->error = 1; return; }
+    c.b_idx[nx][pos] = idx; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = 0; c.b_op[nx][pos] = 0;
+    c.fresh[vrg_atomic_add(&c.st->nfresh, 1u)] = pos;
+}
+
+// per listed flip: its own new entry (carried or fresh) and the entries of the voxels it promoted
+VRG_HD void vrg_item_scatter_flip(const VrgCtx& c, uint32_t r) {
+    const VrgState& s = *c.st;
+    int cur = s.iter & 1, nx = cur ^ 1;
+    uint32_t n = s.ni + s.no, nfo = s.nfo, nfi = s.nf - s.nfo;
+    uint32_t e = c.f_entry[r], idx = c.f_idx[r];
+    uint8_t res = c.f_res[r];
+    uint8_t fin = res & FR_FINAL;
+    bool fresh = res & FR_FRESH;
+    uint32_t own, promo;
+    bool has_own;
+    if (r < nfo) { promo = s.ni + r; own = n + nfo + nfi + r; has_own = (fin == 2 && !fresh); }
+    else { uint32_t j = r - nfo; own = s.ni + nfo + j; promo = n + 2 * nfo + nfi + j; has_own = (fin == 1); }
+    if (has_own) {
+        uint32_t pos = c.scan[own];
+        uint32_t lev = c.b_lev[cur][e];
+        if (fresh) vrg_new_fresh(c, nx, pos, idx, lev);
+        else if (pos >= c.bcap) c.st->error = 1;
+        else {
+            double ip = c.b_ip[cur][e], op = c.b_op[cur][e];
+            vrg_apply_correction(c, lev, ip, op);
+            c.b_idx[nx][pos] = idx; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = ip; c.b_op[nx][pos] = op;
+        }
+    }
+    uint32_t mask = c.f_mask[r];
+    uint32_t pos = c.scan[promo];
+    for (int k = 0; k < 27; k++)
+        if (mask & (1u << k)) {
+            uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
+            vrg_new_fresh(c, nx, pos++, m, vrg_level_of(c, (double)c.I[m]));
+        }
+}
+
+// exact densities over the whole inner / outer regions (:152-155, :252-255), regrouped by level
+VRG_HD void vrg_exact_serial(const VrgCtx& c, int par, uint32_t pos) {
+    double v = c.lev[c.b_lev[par][pos]];
+    double si = 0, so = 0;
+    for (uint32_t l = 0; l < c.L; l++) {
+        int32_t a = c.hin[l], b = c.hout[l];
+        if (!(a | b)) continue;
+        double k = vrg_kern(c, c.lev[l] - v);
+        si += (double)a * k; so += (double)b * k;
+    }
+    c.b_ip[par][pos] = si; c.b_op[par][pos] = so;
+}
+
+// ------------------------------------------------------------------ init mode (:129-155)
+// labels are pure morphology (verified against the reference): seed with a non-seed neighbour -> 1,
+// non-seed next to a seed -> 2 (4 -> 3 -> 2 included), list orders: inner = seeds in np.where order,
+// outer = first-seen order keyed (lex rank of the first seed that touches it, k).
+VRG_HD void vrg_item_init_voxel(const VrgCtx& c, uint32_t idx) {
+    uint8_t* lab = c.lab[0];
+    uint8_t cb = lab[idx];
+    if (cb & VB_OOB) return;
+    VrgState& s = *c.st;
+    if (cb & VB_S) {
+        uint64_t lex = vrg_lex(c, idx);
+        c.stamp[idx] = lex;
+        vrg_atomic_add(&s.nseed, 1u);
+        bool bnd = false;
+        for (int k = 0; k < 27; k++) {
+            if (k == 13) continue;
+            uint8_t m = lab[(int64_t)idx + vrg_off(c, k)];
+            if (!(m & (VB_S | VB_OOB))) bnd = true;
+        }
+        if (bnd) {
+            uint32_t p = vrg_atomic_add(&s.ninit_in, 1u);     // inner entries staged from the bottom
+            if (p < c.bcap) { c.init_key[p] = lex; c.init_idx[p] = idx; } else s.error = 1;
+            vrg_or_byte(lab, idx, VB_B);
+        }
+        return;
+    }
+    uint64_t best = ~0ull; int bk = 0;
+    for (int k = 0; k < 27; k++) {
+        if (k == 13) continue;
+        uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
+        if (lab[m] & VB_S) {
+            uint64_t lx = vrg_lex(c, m);
+            if (lx < best) { best = lx; bk = 26 - k; }
+        }
+    }
+    if (best == ~0ull) return;
+    // outer entries are staged from the top of the init arrays downwards
+    uint32_t p = vrg_atomic_add(&s.ninit_out, 1u);
+    if (p < c.bcap) { c.init_key[c.bcap - 1 - p] = best * 27u + (uint64_t)bk; c.init_idx[c.bcap - 1 - p] = idx; }
+    else s.error = 1;
+    // B on, X off; neighbours only ever read the S bit, so a plain byte store is safe
+    lab[idx] = VB_B;
+}
+
+VRG_HD void vrg_item_init_entry(const VrgCtx& c, uint32_t e) {
+    uint32_t idx = c.b_idx[0][e];
+    c.b_lev[0][e] = vrg_level_of(c, (double)c.I[idx]);
+    c.fresh[e] = e;
+}
+
+VRG_HD void vrg_item_hist_voxel(const VrgCtx& c, uint32_t idx) {
+    uint8_t b = c.lab[0][idx];
+    if (b & (VB_OOB | VB_X)) return;
+    uint32_t lev = vrg_level_of(c, (double)c.I[idx]);
+    if (b & VB_S) vrg_atomic_add(&c.hin[lev], 1); else vrg_atomic_add(&c.hout[lev], 1);
+}

@@ -1,0 +1,107 @@
+// vrg_types.h - data layout shared by the HIP kernels, the C-ABI host code and the test host model.
+//
+// Volume layout in HBM (all dense volumes share it): x fastest, z slowest, every axis padded so
+// that stencil code never tests bounds:
+//     idx(x,y,z) = ((z+2)*PY + (y+2))*PX + x,   PX = roundup(nx+2,16), PY = ny+4, PZ = nz+4
+// Padding label bytes hold VB_OOB forever; x = -1,-2 wrap onto the previous row's padding.
+// A Z-slab (multi-GPU) is the same layout with its two halo planes per side living in the z padding.
+//
+// Label byte (internal encoding of the reference's valueMap, variationalRegionGrowing.py:21):
+//     bit0 S  segmented (labels 0,1)          bit3 L  listed in this sweep's flip list (:88)
+//     bit1 B  in the narrow band (labels 1,2)  bit4 P  flip will be applied (flip-outs always; flip-ins
+//     bit2 X  excluded (label 4)                        per the skip rule, see vrg_items.h)
+//     bit5 OOB padding / outside the volume    bit6 F  transient: outer-boundary voxel that left the band
+//                                                       and re-entered in the same sweep (fresh density)
+//     label 0 = S, 1 = S|B, 2 = B, 3 = 0, 4 = X
+#pragma once
+#include <stdint.h>
+#include "../../include/vrg.h"
+
+#if defined(__HIPCC__)
+#define VRG_HD __host__ __device__ __forceinline__
+#else
+#define VRG_HD inline
+#endif
+
+enum : uint8_t {
+    VB_S = 1, VB_B = 2, VB_X = 4, VB_L = 8, VB_P = 16, VB_OOB = 32, VB_F = 64,
+    VB_LABEL = 7
+};
+
+// stop reasons VRG_STOP_* (variationalRegionGrowing.py:91-104,118-121) come from include/vrg.h
+
+// f_res codes written by the sweep for every listed flip (indexed by flip rank)
+enum : uint8_t { FR_FINAL = 3, FR_FRESH = 4, FR_WRITTEN = 8 };
+
+struct VrgTrace {            // one record per update() call (0 = init)
+    int64_t nflip, nseg, n_in, n_out, ni, no;
+    double sum_in, sum_out;  // sum of intensities over the inner / outer regions
+};
+
+// device-resident scalars; every kernel reads them at entry (no host round trip per sweep)
+struct VrgState {
+    int32_t iter;        // incremental sweeps applied so far (= reference iterNum - 1)
+    int32_t done;        // stop reason, 0 while running
+    int32_t iterMax;
+    int32_t error;       // capacity overflow etc.
+    int64_t maxSegmentSize;
+    int64_t n_in, n_out; // region sizes (:51-52, :115-116)
+    double sum_in, sum_out;
+    uint32_t ni, no;     // band list lengths (inner list = entries [0,ni), outer = [ni,ni+no))
+    uint32_t nfo, nf;    // flip-outs, all listed flips of the sweep being processed
+    uint32_t npend;      // flip-ins waiting in the skip-rule fix-point
+    uint32_t nfresh;     // band entries needing exact densities
+    uint32_t nnz;        // distinct intensity levels touched by this sweep's density corrections
+    uint32_t ncnt;       // length of the rebuild count array
+    uint32_t ni_new, nb_new;
+    uint32_t fix_changed;
+    uint32_t ninit_in, ninit_out, nseed;
+    int32_t use_tab;     // this sweep's density corrections are memoised per intensity level (tabC)
+};
+
+struct VrgCtx {
+    int32_t nx, ny, nz;
+    int32_t PX, PY, PZ;
+    uint32_t PV;               // PX*PY*PZ
+    double H, A;               // kernel A*exp(-0.5*H*d^2) (:7,:10)
+    const float* I;            // intensities, padded layout
+    uint8_t* lab[2];           // label bytes, ping-pong by sweep parity
+    uint64_t* stamp;           // (sweep<<32 | flip rank) of a voxel's last listing; seeds: lex index
+    // intensity levels: sorted distinct values and per-class histograms (:149-150, :249-250)
+    uint32_t L;
+    const double* lev;
+    int32_t* hin;
+    int32_t* hout;
+    uint32_t* dIn;             // per-level counts of innerAdded / outerAdded / addedPoints (:232-235)
+    uint32_t* dOut;
+    uint32_t* dConv;
+    uint32_t* nz_lev;          // compacted list of touched levels ...
+    double* nz_val;            // ... their values and counts
+    uint32_t* nz_cin; uint32_t* nz_cout; uint32_t* nz_cconv;
+    double* tabC;              // per-level memo of the three corrections (3*L), see VrgState::use_tab
+    // band lists, SoA, ping-pong by sweep parity; capacity bcap entries
+    uint32_t bcap;
+    uint32_t* b_idx[2];
+    uint32_t* b_lev[2];
+    double* b_ip[2];
+    double* b_op[2];
+    uint8_t* e_flag;           // per old entry: listed flip
+    uint8_t* e_surv;           // per old entry: survives in place
+    uint32_t* scan;            // scan workspace (ranks, then rebuild positions), length >= ni+no+2*nf
+    // per listed flip (index = rank in the flip list)
+    uint32_t fcap;
+    uint32_t* f_entry;
+    uint32_t* f_idx;
+    uint32_t* f_mask;          // bit k: neighbour k (offset order of get_neighbours :263) promoted by this flip
+    uint8_t* f_res;
+    uint32_t* pend;            // flip ranks in the skip-rule fix-point
+    uint32_t* fresh;           // new-band positions needing exact densities
+    // dense statistics partials (one slot per sweep workgroup)
+    uint32_t nstat;
+    int64_t* st_nin; int64_t* st_nout; double* st_sin; double* st_sout;
+    // init scratch
+    uint64_t* init_key; uint32_t* init_idx;
+    VrgState* st;
+    VrgTrace* trace;
+    uint32_t trace_cap;
+};

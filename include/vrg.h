@@ -1,0 +1,102 @@
+/*
+ * vrg.h - C-ABI of libvrg_hip.so: the MI355X-native variational region growing sweep.
+ *
+ * The reference has no FFI layer for this path: its boundary is the Python function
+ *     variationalRegionGrowing(dataArray, valueMap, H=2.25, maxSegmentSize=5000)
+ *         -> (segmented, segmentedMap, valueMap)          Code/variationalRegionGrowing.py:10-37
+ * The Python mirror of that function (arterynetwork_amd/variationalRegionGrowing.py) binds the entry
+ * points below with ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ * Each entry point names the reference statements it replaces.
+ *
+ * Conventions: every function returns 0 on success or a negative VRG_E_* code; the message is
+ * available from vrg_last_error().  No exceptions or host-language objects cross the boundary; the
+ * library never keeps a caller pointer after a call returns.  Pointers may be host or device
+ * pointers (the copy kind is inferred).  A handle is bound to one GPU and is not thread-safe.
+ * Arrays are addressed as [x][y][z] with explicit element strides, so both numpy C order and the
+ * Fortran order nibabel returns are accepted without a host-side copy.
+ */
+#ifndef VRG_H
+#define VRG_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vrg_handle vrg_handle;
+
+enum { VRG_U8 = 0, VRG_I16 = 1, VRG_U16 = 2, VRG_I32 = 3, VRG_I64 = 4, VRG_F32 = 5, VRG_F64 = 6 };
+
+enum {
+    VRG_OK = 0,
+    VRG_E_ARG = -1,        /* bad argument (shape, dtype, strides, label outside {0,3,4}, ...) */
+    VRG_E_NOGPU = -2,      /* no usable HIP device: the product has no CPU fallback */
+    VRG_E_MEM = -3,        /* allocation failed */
+    VRG_E_STATE = -4,      /* call order (e.g. run before init) */
+    VRG_E_EMPTY = -5,      /* empty seed set: the reference raises at :48 */
+    VRG_E_INEXACT = -6,    /* intensities not exactly representable in the fp32 device volume */
+    VRG_E_CAPACITY = -7,   /* band / flip capacity exceeded (raise with vrg_set_option) */
+    VRG_E_INTERNAL = -8
+};
+
+/* stop reasons of the driver loop (variationalRegionGrowing.py:91-104, :118-121) */
+enum { VRG_RUNNING = 0, VRG_STOP_CONVERGED = 1, VRG_STOP_TIME = 2, VRG_STOP_SIZE = 3, VRG_STOP_ITERMAX = 4 };
+
+typedef struct {
+    int32_t stop_reason;      /* VRG_STOP_* (VRG_RUNNING if iterMax sweeps of this call were used up) */
+    int32_t iter_num;         /* the reference's iterNum at return: 1 + incremental sweeps applied */
+    int64_t sweeps;           /* incremental update() sweeps applied by this call */
+    int64_t nseg, n_in, n_out;/* len(segmented), innerSize, outerSize (:51-52, :115-116) */
+    int64_t ni, no;           /* len(innerBnd), len(outerBnd) */
+    double sum_in, sum_out;   /* sum of intensities over the inner / outer region */
+    double seconds;           /* wall time of this call's sweeps (device synchronised) */
+    double sweep_kernel_ms;   /* HIP-event time summed over this call's dense sweep launches (option "events") */
+    int64_t sweep_launches;
+} vrg_result;
+
+typedef struct {              /* one record per update() call; index 0 = init mode (:129-155) */
+    int64_t nflip, nseg, n_in, n_out, ni, no;
+    double sum_in, sum_out;
+} vrg_trace_rec;
+
+/* Create a handle for an nx*ny*nz volume on HIP device `device`. */
+int vrg_create(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out);
+void vrg_destroy(vrg_handle* h);
+const char* vrg_last_error(const vrg_handle* h);
+
+/* Options (before vrg_init unless noted): "band_capacity", "sweep_variant" (0 marked streaming sweep,
+ * 1 reference full-stencil sweep; any time), "events" (1: time every dense sweep launch with HIP
+ * events; any time), "batch" (sweeps enqueued between host checks of the stop flag; any time). */
+int vrg_set_option(vrg_handle* h, const char* name, int64_t value);
+
+/* dataArray (:16): any VRG_* dtype; values must be exactly representable in fp32. */
+int vrg_set_volume(vrg_handle* h, const void* data, int dtype, const int64_t strides_xyz[3]);
+/* valueMap on entry (:18-21): labels must be in {0 seed, 3 outside, 4 excluded}. */
+int vrg_set_labels(vrg_handle* h, const void* labels, int dtype, const int64_t strides_xyz[3]);
+
+/* Seeds, segmentedMap, init-mode update() and region sizes (:38-52, :129-155). */
+int vrg_init(vrg_handle* h, double H);
+
+/* The while loop (:56-117): decide flips (:79-88), stop tests (:91-104), incremental update()
+ * (:156-259), region recount (:113-116) - until a stop test fires or `iterMax` sweeps in total have
+ * been applied since vrg_init.  maxSeconds < 0 disables the wall-clock cap (:97).  May be called
+ * again with a larger iterMax to continue. */
+int vrg_run(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxSeconds, vrg_result* out);
+
+/* valueMap on return (:33-36), written with the reference's label values 0..4. */
+int vrg_get_labels(vrg_handle* h, void* out, int dtype, const int64_t strides_xyz[3]);
+/* segmentedMap (:31-32) is labels <= 1; `segmented` (:29-30) in the reference's list order. */
+int vrg_get_segmented(vrg_handle* h, int64_t* coords_xyz, int64_t cap, int64_t* n);
+/* innerBnd (which = 0) / outerBnd (1) in list order with innerProb / outerProb at those voxels. */
+int vrg_get_band(vrg_handle* h, int which, int64_t* coords_xyz, double* inner_prob, double* outer_prob,
+                 int64_t cap, int64_t* n);
+int vrg_get_trace(vrg_handle* h, vrg_trace_rec* out, int64_t cap, int64_t* n);
+/* Verification aid: class histograms over the sorted distinct intensity values, recounted densely
+ * from the labels (:149-150 / :249-250) next to the incrementally maintained ones. */
+int vrg_get_levels(vrg_handle* h, double* values, int32_t* hist_in, int32_t* hist_out,
+                   int32_t* recount_in, int32_t* recount_out, int64_t cap, int64_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

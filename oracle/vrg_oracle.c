@@ -15,7 +15,8 @@
  * Index convention: the reference indexes arrays as [x][y][z]; "lex" index here is
  * (x*ny + y)*nz + z, the order np.where returns (variationalRegionGrowing.py:44).
  *
- * density_mode 0: brute-force sums over voxels exactly as :149-155, :236-255.
+ * density_mode 0: brute-force sums over voxels exactly as :149-155, :236-255, added up with numpy's
+ *   pairwise np.sum scheme in float64 (no extended precision) so rounding follows the reference.
  * density_mode 1: the same sums regrouped by distinct intensity value (histogram over the
  *   sorted unique values); mathematically identical, rounding differs at the 1e-15 level.
  *   Used so that medium-size volumes finish in seconds; tests check mode 1 against mode 0.
@@ -71,6 +72,7 @@ typedef struct vrgo {
     int32_t *newin, *newout, *incl; int64_t nnewin, nnewout, nincl, capnew, capnewout, capincl;
     double A;
     double t0;
+    double *scr; int64_t capscr;
 } vrgo;
 
 static double now_s(void) {
@@ -173,23 +175,61 @@ static void recount_hist(vrgo *o) {
     }
 }
 
+/* np.sum of a contiguous float64 vector: numpy's pairwise summation (blocks of 128, eight
+ * running partial sums), so that rounding - and therefore exact-tie sign tests - follow the reference. */
+static double np_sum(const double *a, int64_t n) {
+    if (n < 8) {
+        double res = 0.;
+        for (int64_t i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        int64_t i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        int64_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_sum(a, n2) + np_sum(a + n2, n - n2);
+    }
+}
+
+static double *scratch(vrgo *o, int64_t n) {
+    if (n > o->capscr) {
+        o->capscr = n + 1024;
+        o->scr = (double *)realloc(o->scr, sizeof(double) * o->capscr);
+    }
+    return o->scr;
+}
+
+/* np.sum(A * np.exp(-0.5 * H * (values - v)**2))  (:154-155, :240-242, :254-255) */
+static double kern_sum(vrgo *o, const double *values, int64_t n, double v) {
+    double *t = scratch(o, n);
+    for (int64_t i = 0; i < n; i++) t[i] = kern(o, values[i] - v);
+    return np_sum(t, n);
+}
+
 /* exact densities of one point over the whole inner / outer regions (:152-155, :252-255) */
 static void exact_probs(vrgo *o, int32_t p, const double *innerValues, int64_t nin,
                         const double *outerValues, int64_t nout) {
     double v = o->data[p];
-    long double si = 0, so = 0;
     if (o->density_mode == 0) {
-        for (int64_t i = 0; i < nin; i++) si += kern(o, innerValues[i] - v);
-        for (int64_t i = 0; i < nout; i++) so += kern(o, outerValues[i] - v);
+        o->ip[p] = kern_sum(o, innerValues, nin, v);
+        o->op[p] = kern_sum(o, outerValues, nout, v);
     } else {
+        double si = 0, so = 0;
         for (int64_t l = 0; l < o->L; l++) {
             if (!o->hin[l] && !o->hout[l]) continue;
             double k = kern(o, o->lev[l] - v);
-            si += (long double)o->hin[l] * k;
-            so += (long double)o->hout[l] * k;
+            si += (double)o->hin[l] * k;
+            so += (double)o->hout[l] * k;
         }
+        o->ip[p] = si; o->op[p] = so;
     }
-    o->ip[p] = (double)si; o->op[p] = (double)so;
 }
 
 static int gather_region_values(vrgo *o, double **iv, int64_t *nin, double **ov, int64_t *nout) {
@@ -209,7 +249,7 @@ static int gather_region_values(vrgo *o, double **iv, int64_t *nin, double **ov,
 }
 
 static void recount_sizes(vrgo *o) { /* :49-52, :113-116 */
-    int64_t a = 0, b = 0; long double sa = 0, sb = 0;
+    int64_t a = 0, b = 0; double sa = 0, sb = 0;
     for (int64_t i = 0; i < o->V; i++) {
         uint8_t l = o->label[i];
         if (l <= 1) { a++; sa += o->data[i]; } else if (l <= 3) { b++; sb += o->data[i]; }
@@ -361,11 +401,9 @@ static int update_incremental(vrgo *o) {
             if (lv >= 0 && have[lv]) { ic = memo[3 * lv]; oc = memo[3 * lv + 1]; ac = memo[3 * lv + 2]; }
             else {
                 double v = o->data[p];
-                long double a = 0, b = 0, c = 0;
-                for (int64_t j = 0; j < nia; j++) a += kern(o, innerAdded[j] - v);       /* :240 */
-                for (int64_t j = 0; j < noa; j++) b += kern(o, outerAdded[j] - v);       /* :241 */
-                for (int64_t j = 0; j < o->nincl; j++) c += kern(o, addedPoints[j] - v); /* :242 */
-                ic = (double)a; oc = (double)b; ac = (double)c;
+                ic = kern_sum(o, innerAdded, nia, v);          /* :240 */
+                oc = kern_sum(o, outerAdded, noa, v);          /* :241 */
+                ac = kern_sum(o, addedPoints, o->nincl, v);    /* :242 */
                 if (lv >= 0) { memo[3 * lv] = ic; memo[3 * lv + 1] = oc; memo[3 * lv + 2] = ac; have[lv] = 1; }
             }
             o->ip[p] += ic;      /* :243 */
@@ -414,7 +452,7 @@ void vrgo_destroy(vrgo *o) {
     free(o->data); free(o->label); free(o->seg); free(o->ip); free(o->op);
     ol_free(&o->inner); ol_free(&o->outer); ol_free(&o->segl);
     free(o->lev); free(o->levidx); free(o->hin); free(o->hout);
-    free(o->trace); free(o->flips); free(o->newin); free(o->newout); free(o->incl);
+    free(o->scr); free(o->trace); free(o->flips); free(o->newin); free(o->newout); free(o->incl);
     free(o);
 }
 
