@@ -38,6 +38,9 @@ void be_init_finish(const VrgCtx& c);          // levels of entries, histograms,
 // one trip through the while-loop body (:58-117); a no-op once st->done is set
 void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev);
 
+// fold the HIP-event pairs recorded since the last call into ev (only the first n_valid were real sweeps)
+void be_events_collect(VrgEvents* ev, long long n_valid);
+
 // dense recount of the class histograms (verification aid)
 void be_recount_hist(const VrgCtx& c, int par, int32_t* rin, int32_t* rout);
 // (stamp, idx) of every segmented voxel, unordered; returns the count

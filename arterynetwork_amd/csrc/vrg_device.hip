@@ -1,0 +1,664 @@
+// vrg_device.hip - the product backend: HIP kernels for MI355X (gfx950, wave64).
+//
+// Kernel inventory (one while-loop trip of variationalRegionGrowing.py:58-117 = be_sweep_once):
+//   band kernels (O(band) work, grid-stride over device-resident counts, no host round trip):
+//     k_decide -> scan -> k_fin_decide -> k_mark -> k_prepass -> k_fix -> k_scatter_marks
+//   dense kernel (every voxel, HBM-bound: 4 B intensity + 1 B label in, 1 B label out):
+//     k_sweep<variant> : relabel + region statistics  -> k_stats_reduce
+//   band kernels: k_flipres, k_survivor, level-delta compaction, k_tab, scan, k_scatter_*, k_exact,
+//     k_finalize
+// Every kernel starts by reading the device-resident VrgState and returns at once when the stop
+// flag is set, so the host can enqueue batches of sweeps without synchronising.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "vrg_backend.h"
+#include "vrg_items.h"
+
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
+
+namespace {
+
+constexpr int TPB = 256;            // 4 waves of 64
+constexpr int ITEM_BLOCKS = 256;    // band kernels: 64 Ki threads, grid-stride
+constexpr int SCAN_BLOCKS = 256;
+constexpr int SWEEP_BLOCKS = 2048;  // 8 workgroups per CU on 256 CUs
+
+hipStream_t g_stream = nullptr;
+
+// ---- wave / block primitives (wave = 64 lanes) -------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);   // fixed butterfly: deterministic
+    return v;
+}
+__device__ __forceinline__ long long wave_sum(long long v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+    return v;
+}
+// exclusive scan of one value per thread over a 256-thread block; returns the block total in `total`
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total, uint32_t* sh /*4+*/) {
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int i = 0; i < w; i++) base += sh[i];
+    total = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+// ---- item kernels ---------------------------------------------------------------------------------
+#define ITEM_LOOP(n) for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += gridDim.x * blockDim.x)
+
+__global__ void k_decide(VrgCtx c) {
+    if (c.st->done) return;
+    ITEM_LOOP(c.st->ni + c.st->no) vrg_item_decide(c, i);
+}
+__global__ void k_fin_decide(VrgCtx c) {
+    if (c.st->done) return;
+    vrg_item_fin_decide(c, c.st->scan_total);
+}
+__global__ void k_mark(VrgCtx c) {
+    if (c.st->done) return;
+    ITEM_LOOP(c.st->ni + c.st->no) vrg_item_mark(c, i);
+}
+__global__ void k_prepass(VrgCtx c) {
+    if (c.st->done) return;
+    ITEM_LOOP(c.st->nf - c.st->nfo) vrg_item_prepass(c, i);
+}
+// skip-rule fix-point (rare): one workgroup relaxes until nothing changes
+__global__ void k_fix(VrgCtx c) {
+    if (c.st->done) return;
+    __shared__ int changed;
+    uint32_t np = c.st->npend;
+    if (np == 0) return;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < np; j += blockDim.x)
+            if (vrg_item_fix(c, j)) changed = 1;
+        __threadfence();
+        __syncthreads();
+        if (!changed) break;
+    }
+}
+__global__ void k_scatter_marks(VrgCtx c) {
+    if (c.st->done) return;
+    ITEM_LOOP(c.st->nf) vrg_item_scatter_marks(c, i);
+}
+__global__ void k_flipres(VrgCtx c) {
+    if (c.st->done) return;
+    ITEM_LOOP(c.st->nf) vrg_item_flipres(c, i);
+}
+__global__ void k_survivor(VrgCtx c) {
+    if (c.st->done) return;
+    ITEM_LOOP(c.st->ni + c.st->no) vrg_item_survivor(c, i);
+}
+__global__ void k_scatter_surv(VrgCtx c) {
+    if (c.st->done) return;
+    ITEM_LOOP(c.st->ni + c.st->no) vrg_item_scatter_surv(c, i);
+}
+__global__ void k_scatter_flip(VrgCtx c) {
+    if (c.st->done) return;
+    ITEM_LOOP(c.st->nf) vrg_item_scatter_flip(c, i);
+}
+
+// level-delta compaction (:232-235 regrouped by distinct intensity value)
+__global__ void k_delta_flag(VrgCtx c) {
+    if (c.st->done) return;
+    ITEM_LOOP(c.L) c.lscan[i] = (c.dIn[i] | c.dOut[i] | c.dConv[i]) ? 1u : 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.st->nscan = c.L;
+}
+__global__ void k_delta_scatter(VrgCtx c) {
+    if (c.st->done) return;
+    ITEM_LOOP(c.L) {
+        uint32_t a = c.dIn[i], b = c.dOut[i], d = c.dConv[i];
+        if (a | b | d) {
+            uint32_t j = c.lscan[i];
+            c.nz_lev[j] = i; c.nz_val[j] = c.lev[i]; c.nz_cin[j] = a; c.nz_cout[j] = b; c.nz_cconv[j] = d;
+            c.hout[i] += (int32_t)d;                 // included voxels join the outer region
+            c.dIn[i] = 0; c.dOut[i] = 0; c.dConv[i] = 0;
+        }
+    }
+}
+__global__ void k_post_prep(VrgCtx c) {               // after the level scan, before the rebuild scan
+    if (c.st->done) return;
+    VrgState& s = *c.st;
+    uint32_t n = s.ni + s.no;
+    s.nnz = s.scan_total;
+    s.use_tab = c.L <= n;
+    s.ncnt = n + 2 * s.nf;
+    s.nscan = s.ncnt;
+}
+// per-level memo of the three density corrections: one wave per level
+__global__ void k_tab(VrgCtx c) {
+    if (c.st->done || !c.st->use_tab) return;
+    uint32_t nnz = c.st->nnz;
+    int lane = threadIdx.x & 63;
+    uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t l = wid; l < c.L; l += nw) {
+        double v = c.lev[l], a = 0, b = 0, d = 0;
+        for (uint32_t i = lane; i < nnz; i += 64) {
+            double k = vrg_kern(c, c.nz_val[i] - v);
+            a += (double)c.nz_cin[i] * k; b += (double)c.nz_cout[i] * k; d += (double)c.nz_cconv[i] * k;
+        }
+        a = wave_sum(a); b = wave_sum(b); d = wave_sum(d);
+        if (lane == 0) { c.tabC[3 * (size_t)l] = a; c.tabC[3 * (size_t)l + 1] = b; c.tabC[3 * (size_t)l + 2] = d; }
+    }
+}
+__global__ void k_fin_scan(VrgCtx c) {
+    if (c.st->done) return;
+    VrgState& s = *c.st;
+    uint32_t tot = s.scan_total;
+    s.ni_new = (s.ni + s.nf < s.ncnt) ? c.scan[s.ni + s.nf] : tot;
+    s.nb_new = tot;
+    if (tot > c.bcap) { s.error = 1; s.done = -1; }
+}
+// exact densities (:152-155, :252-255): one wave per fresh entry, lanes stride over the levels
+__global__ void k_exact(VrgCtx c, int par_is_next) {
+    if (c.st->done) return;
+    int par = par_is_next ? ((c.st->iter & 1) ^ 1) : 0;
+    uint32_t nfresh = c.st->nfresh;
+    int lane = threadIdx.x & 63;
+    uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t f = wid; f < nfresh; f += nw) {
+        uint32_t pos = c.fresh[f];
+        double v = c.lev[c.b_lev[par][pos]], si = 0, so = 0;
+        for (uint32_t l = lane; l < c.L; l += 64) {
+            int32_t a = c.hin[l], b = c.hout[l];
+            if (!(a | b)) continue;
+            double k = vrg_kern(c, c.lev[l] - v);
+            si += (double)a * k; so += (double)b * k;
+        }
+        si = wave_sum(si); so = wave_sum(so);
+        if (lane == 0) { c.b_ip[par][pos] = si; c.b_op[par][pos] = so; }
+    }
+}
+__global__ void k_finalize(VrgCtx c) {                // iterNum += 1 (:117) + trace record
+    if (c.st->done) return;
+    VrgState& s = *c.st;
+    s.ni = s.ni_new; s.no = s.nb_new - s.ni_new; s.iter++;
+    s.nscan = s.ni + s.no;
+    if ((uint32_t)s.iter < c.trace_cap) {
+        VrgTrace& t = c.trace[s.iter];
+        t.nflip = s.nf; t.nseg = s.n_in; t.n_in = s.n_in; t.n_out = s.n_out; t.ni = s.ni; t.no = s.no;
+        t.sum_in = s.sum_in; t.sum_out = s.sum_out;
+    }
+    if (s.error) s.done = -1;
+}
+
+// ---- device-wide exclusive scan of c-array `a` (length st->nscan), total -> st->scan_total ----------
+__device__ __forceinline__ void scan_range(uint32_t n, uint32_t& lo, uint32_t& hi) {
+    uint32_t chunk = (n + SCAN_BLOCKS - 1) / SCAN_BLOCKS;
+    chunk = (chunk + TPB - 1) / TPB * TPB;
+    lo = min(n, blockIdx.x * chunk); hi = min(n, lo + chunk);
+}
+__global__ void k_scan_reduce(VrgCtx c, uint32_t* a) {
+    if (c.st->done) return;
+    __shared__ uint32_t sh[4];
+    uint32_t lo, hi; scan_range(c.st->nscan, lo, hi);
+    uint32_t s = 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += TPB) s += a[i];
+    uint32_t tot; block_excl_scan(s, tot, sh);
+    if (threadIdx.x == 0) c.bsum[blockIdx.x] = tot;
+}
+__global__ void k_scan_top(VrgCtx c) {
+    if (c.st->done) return;
+    __shared__ uint32_t sh[4];
+    uint32_t v = c.bsum[threadIdx.x], tot;
+    uint32_t ex = block_excl_scan(v, tot, sh);
+    c.bsum[threadIdx.x] = ex;
+    if (threadIdx.x == 0) c.st->scan_total = tot;
+}
+__global__ void k_scan_down(VrgCtx c, uint32_t* a) {
+    if (c.st->done) return;
+    __shared__ uint32_t sh[4];
+    uint32_t lo, hi; scan_range(c.st->nscan, lo, hi);
+    uint32_t run = c.bsum[blockIdx.x];
+    for (uint32_t base = lo; base < hi; base += TPB) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < hi ? a[i] : 0, tot;
+        uint32_t ex = block_excl_scan(v, tot, sh);
+        if (i < hi) a[i] = run + ex;
+        run += tot;
+    }
+}
+void device_scan(const VrgCtx& c, uint32_t* a) {
+    static_assert(SCAN_BLOCKS == TPB, "k_scan_top scans one value per thread");
+    k_scan_reduce<<<SCAN_BLOCKS, TPB, 0, g_stream>>>(c, a);
+    k_scan_top<<<1, SCAN_BLOCKS, 0, g_stream>>>(c);
+    k_scan_down<<<SCAN_BLOCKS, TPB, 0, g_stream>>>(c, a);
+}
+
+// ---- the dense sweep ---------------------------------------------------------------------------------
+// Streams the interior planes as 16-byte label chunks (+64 bytes of intensities): a voxel whose byte
+// carries the mark bit runs the relabel stencil (vrg_sweep_core), every other voxel keeps its label;
+// region sizes and intensity sums (:113-116) are reduced on the fly (wave butterfly -> LDS -> one
+// slot per workgroup, summed in fixed order by k_stats_reduce).
+template <int VARIANT>
+__global__ void __launch_bounds__(TPB) k_sweep(VrgCtx c) {
+    if (c.st->done) return;
+    const int cur = c.st->iter & 1;
+    const uint8_t* __restrict__ in = c.lab[cur];
+    uint8_t* __restrict__ out = c.lab[cur ^ 1];
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
+    const uint32_t first = 2u * plane;
+    const uint32_t nchunk = (uint32_t)(((uint64_t)c.nz * plane) >> 4);
+    long long nin = 0, nout = 0;
+    double sin_ = 0, sout = 0;
+    for (uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x; ch < nchunk; ch += gridDim.x * blockDim.x) {
+        const uint32_t base = first + (ch << 4);
+        uint4 w = *reinterpret_cast<const uint4*>(in + base);
+        const float4* ip = reinterpret_cast<const float4*>(c.I + base);
+        float4 f0 = ip[0], f1 = ip[1], f2 = ip[2], f3 = ip[3];
+        uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        const uint32_t need = VARIANT == 0 ? 0x80808080u : 0u;
+        bool any = VARIANT == 0 ? (((w.x | w.y | w.z | w.w) & need) != 0)
+                                : ((w.x & w.y & w.z & w.w & 0x20202020u) != 0x20202020u);
+        if (any) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t v = ws[q];
+                for (int b = 0; b < 4; b++) {
+                    uint8_t cb = (uint8_t)(v >> (8 * b));
+                    bool run = VARIANT == 0 ? (cb & VB_M) != 0 : !(cb & VB_OOB);
+                    if (run) {
+                        uint8_t nb = vrg_sweep_core(c, in, base + 4 * q + b, cb);
+                        v = (v & ~(0xffu << (8 * b))) | ((uint32_t)nb << (8 * b));
+                    }
+                }
+                ws[q] = v;
+            }
+        }
+        *reinterpret_cast<uint4*>(out + base) = make_uint4(ws[0], ws[1], ws[2], ws[3]);
+        const float fv[16] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w, f3.x, f3.y, f3.z, f3.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t v = ws[q];
+            uint32_t sbits = v & 0x01010101u;                                  // S
+            uint32_t obits = ~(v | (v >> 2) | (v >> 5)) & 0x01010101u;         // !(S|X|OOB)
+            nin += __popc(sbits); nout += __popc(obits);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                double x = (double)fv[4 * q + b];
+                sin_ += ((sbits >> (8 * b)) & 1u) ? x : 0.0;
+                sout += ((obits >> (8 * b)) & 1u) ? x : 0.0;
+            }
+        }
+    }
+    __shared__ long long sh_n[2][4];
+    __shared__ double sh_s[2][4];
+    nin = wave_sum(nin); nout = wave_sum(nout); sin_ = wave_sum(sin_); sout = wave_sum(sout);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sh_n[0][wv] = nin; sh_n[1][wv] = nout; sh_s[0][wv] = sin_; sh_s[1][wv] = sout; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c.st_nin[blockIdx.x] = sh_n[0][0] + sh_n[0][1] + sh_n[0][2] + sh_n[0][3];
+        c.st_nout[blockIdx.x] = sh_n[1][0] + sh_n[1][1] + sh_n[1][2] + sh_n[1][3];
+        c.st_sin[blockIdx.x] = ((sh_s[0][0] + sh_s[0][1]) + sh_s[0][2]) + sh_s[0][3];
+        c.st_sout[blockIdx.x] = ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3];
+    }
+}
+__global__ void k_stats_reduce(VrgCtx c, uint32_t nslots) {
+    if (c.st->done) return;
+    __shared__ long long sh_n[2][4];
+    __shared__ double sh_s[2][4];
+    long long a = 0, b = 0; double sa = 0, sb = 0;
+    for (uint32_t i = threadIdx.x; i < nslots; i += TPB) { a += c.st_nin[i]; b += c.st_nout[i]; sa += c.st_sin[i]; sb += c.st_sout[i]; }
+    a = wave_sum(a); b = wave_sum(b); sa = wave_sum(sa); sb = wave_sum(sb);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sh_n[0][wv] = a; sh_n[1][wv] = b; sh_s[0][wv] = sa; sh_s[1][wv] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        VrgState& s = *c.st;
+        s.n_in = sh_n[0][0] + sh_n[0][1] + sh_n[0][2] + sh_n[0][3];
+        s.n_out = sh_n[1][0] + sh_n[1][1] + sh_n[1][2] + sh_n[1][3];
+        s.sum_in = ((sh_s[0][0] + sh_s[0][1]) + sh_s[0][2]) + sh_s[0][3];
+        s.sum_out = ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3];
+    }
+}
+// statistics only (init): same reduction over lab[0] without relabelling
+__global__ void __launch_bounds__(TPB) k_stats_only(VrgCtx c) {
+    const uint8_t* __restrict__ in = c.lab[0];
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
+    const uint32_t first = 2u * plane;
+    const uint32_t nchunk = (uint32_t)(((uint64_t)c.nz * plane) >> 4);
+    long long nin = 0, nout = 0;
+    double sin_ = 0, sout = 0;
+    for (uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x; ch < nchunk; ch += gridDim.x * blockDim.x) {
+        const uint32_t base = first + (ch << 4);
+        for (int b = 0; b < 16; b++) {
+            uint8_t v = in[base + b];
+            double x = (double)c.I[base + b];
+            if (v & VB_S) { nin++; sin_ += x; } else if (!(v & (VB_X | VB_OOB))) { nout++; sout += x; }
+        }
+    }
+    __shared__ long long sh_n[2][4];
+    __shared__ double sh_s[2][4];
+    nin = wave_sum(nin); nout = wave_sum(nout); sin_ = wave_sum(sin_); sout = wave_sum(sout);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sh_n[0][wv] = nin; sh_n[1][wv] = nout; sh_s[0][wv] = sin_; sh_s[1][wv] = sout; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c.st_nin[blockIdx.x] = sh_n[0][0] + sh_n[0][1] + sh_n[0][2] + sh_n[0][3];
+        c.st_nout[blockIdx.x] = sh_n[1][0] + sh_n[1][1] + sh_n[1][2] + sh_n[1][3];
+        c.st_sin[blockIdx.x] = ((sh_s[0][0] + sh_s[0][1]) + sh_s[0][2]) + sh_s[0][3];
+        c.st_sout[blockIdx.x] = ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3];
+    }
+}
+
+// ---- dense helpers over the real voxels -------------------------------------------------------------
+__device__ __forceinline__ uint32_t real_idx(const VrgCtx& c, uint64_t t, int& x, int& y, int& z) {
+    x = (int)(t % (uint64_t)c.nx); uint64_t r = t / (uint64_t)c.nx;
+    y = (int)(r % (uint64_t)c.ny); z = (int)(r / (uint64_t)c.ny);
+    return vrg_idx(c, x, y, z);
+}
+#define VOXEL_LOOP(c) \
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nV_ = (uint64_t)(c).nx * (c).ny * (c).nz; \
+         t < nV_; t += (uint64_t)gridDim.x * blockDim.x)
+
+__global__ void k_init_voxel(VrgCtx c) {
+    VOXEL_LOOP(c) { int x, y, z; vrg_item_init_voxel(c, real_idx(c, t, x, y, z)); }
+}
+__global__ void k_hist_voxel(VrgCtx c) {
+    VOXEL_LOOP(c) { int x, y, z; vrg_item_hist_voxel(c, real_idx(c, t, x, y, z)); }
+}
+__global__ void k_init_entry(VrgCtx c) {
+    ITEM_LOOP(c.st->ni + c.st->no) vrg_item_init_entry(c, i);
+}
+__global__ void k_fin_init(VrgCtx c) {
+    VrgState& s = *c.st;
+    s.nfresh = 0; s.nscan = s.ni + s.no;
+    VrgTrace& t = c.trace[0];
+    t.nflip = 0; t.nseg = s.n_in; t.n_in = s.n_in; t.n_out = s.n_out; t.ni = s.ni; t.no = s.no;
+    t.sum_in = s.sum_in; t.sum_out = s.sum_out;
+}
+__global__ void k_recount(VrgCtx c, int par, int32_t* rin, int32_t* rout) {
+    VOXEL_LOOP(c) {
+        int x, y, z; uint32_t idx = real_idx(c, t, x, y, z);
+        uint8_t b = c.lab[par][idx];
+        if (b & VB_X) continue;
+        uint32_t lev = vrg_level_of(c, (double)c.I[idx]);
+        atomicAdd((b & VB_S) ? &rin[lev] : &rout[lev], 1);
+    }
+}
+__global__ void k_collect_seg(VrgCtx c, int par, uint64_t* stamps, uint32_t* idxs, uint32_t cap, uint32_t* count) {
+    VOXEL_LOOP(c) {
+        int x, y, z; uint32_t idx = real_idx(c, t, x, y, z);
+        if (c.lab[par][idx] & VB_S) {
+            uint32_t p = atomicAdd(count, 1u);
+            if (p < cap) { stamps[p] = c.stamp[idx]; idxs[p] = idx; }
+        }
+    }
+}
+__global__ void k_gather_I(VrgCtx c, float* dst) {
+    VOXEL_LOOP(c) { int x, y, z; dst[t] = c.I[real_idx(c, t, x, y, z)]; }
+}
+__global__ void k_f2d(const float* a, double* b, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) b[i] = (double)a[i];
+}
+
+// ---- repacking caller arrays ------------------------------------------------------------------------
+__device__ __forceinline__ double load_as_double(const void* p, int dtype, int64_t i) {
+    switch (dtype) {
+        case 0: return ((const uint8_t*)p)[i];
+        case 1: return ((const int16_t*)p)[i];
+        case 2: return ((const uint16_t*)p)[i];
+        case 3: return ((const int32_t*)p)[i];
+        case 4: return (double)((const int64_t*)p)[i];
+        case 5: return ((const float*)p)[i];
+        default: return ((const double*)p)[i];
+    }
+}
+__device__ __forceinline__ void store_int(void* p, int dtype, int64_t i, int v) {
+    switch (dtype) {
+        case 0: ((uint8_t*)p)[i] = (uint8_t)v; break;
+        case 1: ((int16_t*)p)[i] = (int16_t)v; break;
+        case 2: ((uint16_t*)p)[i] = (uint16_t)v; break;
+        case 3: ((int32_t*)p)[i] = v; break;
+        case 4: ((int64_t*)p)[i] = v; break;
+        case 5: ((float*)p)[i] = (float)v; break;
+        default: ((double*)p)[i] = v; break;
+    }
+}
+__global__ void k_pack_volume(VrgCtx c, float* dst, const void* src, int dtype, int64_t s0, int64_t s1, int64_t s2, int* flag) {
+    VOXEL_LOOP(c) {
+        int x, y, z; uint32_t idx = real_idx(c, t, x, y, z);
+        double v = load_as_double(src, dtype, x * s0 + y * s1 + z * s2);
+        float f = (float)v;
+        if ((double)f != v) *flag = 1;
+        dst[idx] = f;
+    }
+}
+__global__ void k_pack_labels(VrgCtx c, uint8_t* dst, const void* src, int dtype, int64_t s0, int64_t s1, int64_t s2, int* flag) {
+    VOXEL_LOOP(c) {
+        int x, y, z; uint32_t idx = real_idx(c, t, x, y, z);
+        double v = load_as_double(src, dtype, x * s0 + y * s1 + z * s2);
+        uint8_t b = 0;
+        if (v == 0) b = VB_S; else if (v == 3) b = 0; else if (v == 4) b = VB_X; else *flag = 1;
+        dst[idx] = b;
+    }
+}
+__global__ void k_unpack_labels(VrgCtx c, const uint8_t* lab, void* dst, int dtype, int64_t s0, int64_t s1, int64_t s2) {
+    VOXEL_LOOP(c) {
+        int x, y, z; uint32_t idx = real_idx(c, t, x, y, z);
+        store_int(dst, dtype, x * s0 + y * s1 + z * s2, vrg_dec(lab[idx]));
+    }
+}
+
+const size_t kElem[7] = {1, 2, 2, 4, 8, 4, 8};
+
+// strides must describe a dense permutation of the three axes (numpy C or F order)
+bool dense_strides(const VrgCtx& c, const int64_t st[3]) {
+    int64_t dim[3] = {c.nx, c.ny, c.nz};
+    int o[3] = {0, 1, 2};
+    for (int i = 0; i < 3; i++) for (int j = i + 1; j < 3; j++) if (st[o[j]] < st[o[i]]) { int t = o[i]; o[i] = o[j]; o[j] = t; }
+    int64_t expect = 1;
+    for (int i = 0; i < 3; i++) {
+        if (dim[o[i]] == 1) continue;                 // stride of a length-1 axis is irrelevant
+        if (st[o[i]] != expect) return false;
+        expect *= dim[o[i]];
+    }
+    return true;
+}
+bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+int voxel_blocks(const VrgCtx& c) {
+    uint64_t V = (uint64_t)c.nx * c.ny * c.nz;
+    return (int)std::min<uint64_t>(4096, (V + TPB - 1) / TPB);
+}
+
+struct EvPair { hipEvent_t a, b; };
+std::vector<EvPair> g_ev_pool;
+size_t g_ev_used = 0;
+
+}  // namespace
+
+// ---- backend interface ---------------------------------------------------------------------------------
+int be_set_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) { (void)hipGetLastError(); return -1; }
+    if (hipSetDevice(device) != hipSuccess) return -1;
+    return 0;
+}
+void* be_alloc(size_t bytes) { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
+void be_free(void* p) { HIP_CHECK(hipFree(p)); }
+void be_fill(void* p, int byte, size_t bytes) { HIP_CHECK(hipMemsetAsync(p, byte, bytes, g_stream)); }
+void be_upload(void* dst, const void* src, size_t bytes) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, g_stream)); HIP_CHECK(hipStreamSynchronize(g_stream)); }
+void be_download(void* dst, const void* src, size_t bytes) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, g_stream)); HIP_CHECK(hipStreamSynchronize(g_stream)); }
+void be_sync() { HIP_CHECK(hipStreamSynchronize(g_stream)); }
+
+static const void* stage_in(const VrgCtx& c, const void* src, int dtype, void** tmp) {
+    *tmp = nullptr;
+    if (is_device_ptr(src)) return src;
+    size_t bytes = (size_t)c.nx * c.ny * c.nz * kElem[dtype];
+    if (hipMalloc(tmp, bytes) != hipSuccess) return nullptr;
+    HIP_CHECK(hipMemcpyAsync(*tmp, src, bytes, hipMemcpyHostToDevice, g_stream));
+    return *tmp;
+}
+
+int be_pack_volume(const VrgCtx& c, float* dst, const void* src, int dtype, const int64_t st[3], int* inexact) {
+    if (!dense_strides(c, st)) return -1;
+    void* tmp; const void* d = stage_in(c, src, dtype, &tmp);
+    if (!d) return -1;
+    int* flag; HIP_CHECK(hipMalloc(&flag, sizeof(int))); HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), g_stream));
+    k_pack_volume<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, dst, d, dtype, st[0], st[1], st[2], flag);
+    HIP_CHECK(hipMemcpyAsync(inexact, flag, sizeof(int), hipMemcpyDeviceToHost, g_stream));
+    HIP_CHECK(hipStreamSynchronize(g_stream));
+    HIP_CHECK(hipFree(flag)); if (tmp) HIP_CHECK(hipFree(tmp));
+    return 0;
+}
+int be_pack_labels(const VrgCtx& c, uint8_t* dst, const void* src, int dtype, const int64_t st[3], int* bad) {
+    if (!dense_strides(c, st)) return -1;
+    void* tmp; const void* d = stage_in(c, src, dtype, &tmp);
+    if (!d) return -1;
+    int* flag; HIP_CHECK(hipMalloc(&flag, sizeof(int))); HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), g_stream));
+    k_pack_labels<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, dst, d, dtype, st[0], st[1], st[2], flag);
+    HIP_CHECK(hipMemcpyAsync(bad, flag, sizeof(int), hipMemcpyDeviceToHost, g_stream));
+    HIP_CHECK(hipStreamSynchronize(g_stream));
+    HIP_CHECK(hipFree(flag)); if (tmp) HIP_CHECK(hipFree(tmp));
+    return 0;
+}
+int be_unpack_labels(const VrgCtx& c, const uint8_t* lab, void* dst, int dtype, const int64_t st[3]) {
+    if (!dense_strides(c, st)) return -1;
+    bool dev = is_device_ptr(dst);
+    size_t bytes = (size_t)c.nx * c.ny * c.nz * kElem[dtype];
+    void* d = dst;
+    if (!dev && hipMalloc(&d, bytes) != hipSuccess) return -1;
+    k_unpack_labels<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, lab, d, dtype, st[0], st[1], st[2]);
+    if (!dev) { HIP_CHECK(hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, g_stream)); }
+    HIP_CHECK(hipStreamSynchronize(g_stream));
+    if (!dev) HIP_CHECK(hipFree(d));
+    return 0;
+}
+
+int be_build_levels(const VrgCtx& c, double** lev, uint32_t* L) {
+    size_t V = (size_t)c.nx * c.ny * c.nz;
+    float *a = nullptr, *b = nullptr; uint32_t* cnt = nullptr; void* tmp = nullptr; size_t tb = 0, tb2 = 0;
+    if (hipMalloc(&a, V * 4) != hipSuccess || hipMalloc(&b, V * 4) != hipSuccess || hipMalloc(&cnt, 4) != hipSuccess) return -1;
+    k_gather_I<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, a);
+    HIP_CHECK(rocprim::radix_sort_keys(nullptr, tb, a, b, V, 0, 32, g_stream));
+    HIP_CHECK(rocprim::unique(nullptr, tb2, b, a, cnt, V, rocprim::equal_to<float>(), g_stream));
+    tb = std::max(tb, tb2);
+    if (hipMalloc(&tmp, tb) != hipSuccess) return -1;
+    HIP_CHECK(rocprim::radix_sort_keys(tmp, tb, a, b, V, 0, 32, g_stream));
+    HIP_CHECK(rocprim::unique(tmp, tb, b, a, cnt, V, rocprim::equal_to<float>(), g_stream));
+    uint32_t n = 0;
+    HIP_CHECK(hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, g_stream));
+    HIP_CHECK(hipStreamSynchronize(g_stream));
+    double* out = nullptr;
+    if (hipMalloc(&out, (size_t)n * 8) != hipSuccess) return -1;
+    k_f2d<<<256, TPB, 0, g_stream>>>(a, out, n);
+    HIP_CHECK(hipStreamSynchronize(g_stream));
+    HIP_CHECK(hipFree(a)); HIP_CHECK(hipFree(b)); HIP_CHECK(hipFree(cnt)); HIP_CHECK(hipFree(tmp));
+    *lev = out; *L = n;
+    return 0;
+}
+
+void be_init_band(const VrgCtx& c) {
+    k_init_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
+}
+
+void be_init_sort(const VrgCtx& c, uint32_t n_in, uint32_t n_out) {
+    uint32_t nmax = std::max(n_in, n_out);
+    if (nmax == 0) return;
+    uint64_t* kout = nullptr; void* tmp = nullptr; size_t tb = 0;
+    HIP_CHECK(hipMalloc(&kout, (size_t)nmax * 8));
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, c.init_key, kout, c.init_idx, c.b_idx[0], nmax, 0, 64, g_stream));
+    HIP_CHECK(hipMalloc(&tmp, tb));
+    if (n_in) HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, c.init_key, kout, c.init_idx, c.b_idx[0], n_in, 0, 64, g_stream));
+    if (n_out) HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, c.init_key + (c.bcap - n_out), kout, c.init_idx + (c.bcap - n_out),
+                                                   c.b_idx[0] + n_in, n_out, 0, 64, g_stream));
+    HIP_CHECK(hipStreamSynchronize(g_stream));
+    HIP_CHECK(hipFree(kout)); HIP_CHECK(hipFree(tmp));
+}
+
+void be_init_finish(const VrgCtx& c) {
+    k_init_entry<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    k_hist_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
+    k_exact<<<1024, TPB, 0, g_stream>>>(c, 0);
+    k_stats_only<<<SWEEP_BLOCKS, TPB, 0, g_stream>>>(c);
+    k_stats_reduce<<<1, TPB, 0, g_stream>>>(c, SWEEP_BLOCKS);
+    k_fin_init<<<1, 1, 0, g_stream>>>(c);
+}
+
+void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev) {
+    k_decide<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    device_scan(c, c.scan);
+    k_fin_decide<<<1, 1, 0, g_stream>>>(c);
+    k_mark<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    k_prepass<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    k_fix<<<1, 1024, 0, g_stream>>>(c);
+    if (variant == 0) k_scatter_marks<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    EvPair* p = nullptr;
+    if (ev && ev->enabled) {
+        if (g_ev_used == g_ev_pool.size()) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); g_ev_pool.push_back(n); }
+        p = &g_ev_pool[g_ev_used++];
+        HIP_CHECK(hipEventRecord(p->a, g_stream));
+    }
+    if (variant == 0) k_sweep<0><<<SWEEP_BLOCKS, TPB, 0, g_stream>>>(c);
+    else k_sweep<1><<<SWEEP_BLOCKS, TPB, 0, g_stream>>>(c);
+    if (p) HIP_CHECK(hipEventRecord(p->b, g_stream));
+    k_stats_reduce<<<1, TPB, 0, g_stream>>>(c, SWEEP_BLOCKS);
+    k_flipres<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    k_survivor<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    k_delta_flag<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    device_scan(c, c.lscan);
+    k_post_prep<<<1, 1, 0, g_stream>>>(c);
+    k_delta_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    k_tab<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    device_scan(c, c.scan);
+    k_fin_scan<<<1, 1, 0, g_stream>>>(c);
+    k_scatter_surv<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    k_scatter_flip<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    k_exact<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c, 1);
+    k_finalize<<<1, 1, 0, g_stream>>>(c);
+}
+
+void be_events_collect(VrgEvents* ev, long long n_valid) {
+    if (!ev) return;
+    for (size_t i = 0; i < g_ev_used; i++) {
+        if ((long long)i < n_valid) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, g_ev_pool[i].a, g_ev_pool[i].b) == hipSuccess) { ev->ms_total += ms; ev->launches++; }
+            else (void)hipGetLastError();
+        }
+    }
+    g_ev_used = 0;
+}
+
+void be_recount_hist(const VrgCtx& c, int par, int32_t* rin, int32_t* rout) {
+    k_recount<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, par, rin, rout);
+    HIP_CHECK(hipStreamSynchronize(g_stream));
+}
+
+uint32_t be_collect_segmented(const VrgCtx& c, int par, uint64_t* stamps, uint32_t* idxs, uint32_t cap) {
+    uint64_t* ds = nullptr; uint32_t* di = nullptr; uint32_t* dc = nullptr;
+    HIP_CHECK(hipMalloc(&ds, (size_t)(cap + 1) * 8)); HIP_CHECK(hipMalloc(&di, (size_t)(cap + 1) * 4)); HIP_CHECK(hipMalloc(&dc, 4));
+    HIP_CHECK(hipMemsetAsync(dc, 0, 4, g_stream));
+    k_collect_seg<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, par, ds, di, cap, dc);
+    uint32_t n = 0;
+    HIP_CHECK(hipMemcpyAsync(&n, dc, 4, hipMemcpyDeviceToHost, g_stream));
+    HIP_CHECK(hipStreamSynchronize(g_stream));
+    uint32_t m = std::min(n, cap);
+    HIP_CHECK(hipMemcpy(stamps, ds, (size_t)m * 8, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(idxs, di, (size_t)m * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipFree(ds)); HIP_CHECK(hipFree(di)); HIP_CHECK(hipFree(dc));
+    return n;
+}

@@ -163,7 +163,8 @@ int API(init)(vrg_handle* h, double H) {
         c.nz_lev = alloc<uint32_t>(h, L); c.nz_val = alloc<double>(h, L);
         c.nz_cin = alloc<uint32_t>(h, L); c.nz_cout = alloc<uint32_t>(h, L); c.nz_cconv = alloc<uint32_t>(h, L);
         c.tabC = alloc<double>(h, 3 * (size_t)L);
-        if (!c.hin || !c.hout || !c.dIn || !c.dOut || !c.dConv || !c.nz_lev || !c.nz_val || !c.nz_cin || !c.nz_cout || !c.nz_cconv || !c.tabC)
+        c.lscan = alloc<uint32_t>(h, (size_t)L + 16);
+        if (!c.hin || !c.hout || !c.dIn || !c.dOut || !c.dConv || !c.nz_lev || !c.nz_val || !c.nz_cin || !c.nz_cout || !c.nz_cconv || !c.tabC || !c.lscan)
             return fail(h, VRG_E_MEM, "vrg_init: level arrays");
     }
     be_fill(c.hin, 0, (size_t)L * 4); be_fill(c.hout, 0, (size_t)L * 4);
@@ -181,6 +182,7 @@ int API(init)(vrg_handle* h, double H) {
         }
         c.e_flag = alloc<uint8_t>(h, c.bcap); c.e_surv = alloc<uint8_t>(h, c.bcap);
         c.scan = alloc<uint32_t>(h, (size_t)c.bcap + 2 * (size_t)c.fcap + 16);
+        c.bsum = alloc<uint32_t>(h, 1024);
         c.f_entry = alloc<uint32_t>(h, c.fcap); c.f_idx = alloc<uint32_t>(h, c.fcap);
         c.f_mask = alloc<uint32_t>(h, c.fcap); c.f_res = alloc<uint8_t>(h, c.fcap);
         c.pend = alloc<uint32_t>(h, c.fcap); c.fresh = alloc<uint32_t>(h, c.bcap);
@@ -190,7 +192,7 @@ int API(init)(vrg_handle* h, double H) {
         c.st_sin = alloc<double>(h, c.nstat); c.st_sout = alloc<double>(h, c.nstat);
         c.trace_cap = 1u << 16;
         c.trace = alloc<VrgTrace>(h, c.trace_cap);
-        if (!c.e_flag || !c.e_surv || !c.scan || !c.f_entry || !c.f_idx || !c.f_mask || !c.f_res || !c.pend || !c.fresh ||
+        if (!c.e_flag || !c.e_surv || !c.scan || !c.bsum || !c.f_entry || !c.f_idx || !c.f_mask || !c.f_res || !c.pend || !c.fresh ||
             !c.init_key || !c.init_idx || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace)
             return fail(h, VRG_E_MEM, "vrg_init: work arrays");
     }
@@ -229,8 +231,10 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     for (;;) {
         int64_t remaining = iterMax - s.iter;
         int nb = (int)std::min<int64_t>(h->batch, std::max<int64_t>(remaining, 0) + 1);   // +1: the trip that sets the stop flag
+        int32_t before = s.iter;
         for (int i = 0; i < nb; i++) be_sweep_once(c, h->variant, &h->ev);
         s = get_state(h);
+        be_events_collect(&h->ev, s.iter - before);
         if (s.done || s.error) break;
         if (maxSeconds >= 0) {                       // wall-clock cap (:97), checked between batches
             double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->t0).count();

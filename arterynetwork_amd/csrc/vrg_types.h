@@ -18,6 +18,7 @@
 #include "../../include/vrg.h"
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define VRG_HD __host__ __device__ __forceinline__
 #else
 #define VRG_HD inline
@@ -56,6 +57,8 @@ struct VrgState {
     uint32_t ni_new, nb_new;
     uint32_t fix_changed;
     uint32_t ninit_in, ninit_out, nseed;
+    uint32_t nscan;      // length of the array the next device-wide scan runs over
+    uint32_t scan_total; // its total
     int32_t use_tab;     // this sweep's density corrections are memoised per intensity level (tabC)
 };
 
@@ -87,6 +90,8 @@ struct VrgCtx {
     double* b_op[2];
     uint8_t* e_flag;           // per old entry: listed flip
     uint8_t* e_surv;           // per old entry: survives in place
+    uint32_t* lscan;           // per-level scan workspace (length L)
+    uint32_t* bsum;            // per-workgroup partials of the device-wide scan
     uint32_t* scan;            // scan workspace (ranks, then rebuild positions), length >= ni+no+2*nf
     // per listed flip (index = rank in the flip list)
     uint32_t fcap;

@@ -195,6 +195,8 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*) {
     if (s.error) s.done = -1;
 }
 
+void be_events_collect(VrgEvents*, long long) {}
+
 void be_recount_hist(const VrgCtx& c, int par, int32_t* rin, int32_t* rout) {
     for_real_voxels(c, [&](uint32_t idx, int, int, int) {
         uint8_t b = c.lab[par][idx];

@@ -1,0 +1,115 @@
+"""CPU checks of the HIP pipeline's logic through the sequential host model (test infrastructure).
+
+tests/hostmodel/libvrg_hostmodel.so runs the same item functions as the HIP kernels
+(arterynetwork_amd/csrc/vrg_items.h) one item at a time.  Here it is compared with the oracle after
+every sweep: labels, band list orders, `segmented` order, counts and stop reason exactly; densities
+to 1e-9.  The GPU-side twin of this file is tests/test_gpu_parity.py.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import parity
+from conftest import golden_names, ROOT
+from arterynetwork_amd._capi import VrgLib
+
+HM_DIR = os.path.join(ROOT, 'tests', 'hostmodel')
+
+
+@pytest.fixture(scope='module')
+def hm():
+    subprocess.check_call(['make', '-C', HM_DIR, '-s', 'libvrg_hostmodel.so'])
+    return VrgLib(os.path.join(HM_DIR, 'libvrg_hostmodel.so'), 'vrgm_')
+
+
+SMALL = [n for n in golden_names() if n != 'config1_tube']
+
+
+@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('name', SMALL)
+def test_hostmodel_matches_oracle_on_goldens(hm, golden_loader, name, variant):
+    g = golden_loader(name)
+    data, vmap = g.inputs()
+    iterMax = g.max_sweeps if g.max_sweeps >= 0 else 200
+    res, k = parity.run_stepwise(hm, data, vmap, g.H, g.maxSegmentSize, iterMax, density_mode=1,
+                                 check_hist=True, options={'sweep_variant': variant})
+    assert res is not None
+    assert k == g.ncalls - 1
+    assert res.nseg == int(g.z['nseg'][-1])
+
+
+def random_case(sd, lo=1, hi=13):
+    rng = np.random.default_rng(sd)
+    shape = tuple(int(x) for x in rng.integers(lo, hi, size=3))
+    p_seed = rng.choice([0.02, 0.1, 0.3, 0.6])
+    p_excl = rng.choice([0.0, 0.2, 0.5])
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        I = rng.standard_normal(shape).astype(np.float32).astype(np.float64)
+    elif kind == 1:
+        I = rng.integers(0, 3, size=shape).astype(np.float64)
+    else:
+        I = (np.round(rng.standard_normal(shape) * 3) / 3).astype(np.float32).astype(np.float64)
+    u = rng.random(shape)
+    vm = np.full(shape, 3, dtype=np.int64)
+    vm[u < p_seed] = 0
+    vm[u > 1 - p_excl] = 4
+    if not (vm == 0).any():
+        vm.reshape(-1)[0] = 0
+    H = float(rng.choice([0.3, 1.0, 2.25, 6.0]))
+    return I, vm, H, int(rng.integers(0, 2)), int(rng.integers(0, 2))
+
+
+def test_hostmodel_random_volumes(hm):
+    """300 random tiny volumes (degenerate axes, excluded voxels, ties in integer data)."""
+    sweeps = 0
+    for sd in range(300):
+        I, vm, H, variant, dmode = random_case(sd)
+        res, k = parity.run_stepwise(hm, I, vm, H, None, 40, density_mode=dmode, check_hist=True,
+                                     options={'sweep_variant': variant})
+        sweeps += k
+    assert sweeps > 1000
+
+
+def test_hostmodel_rejects_bad_inputs(hm):
+    from arterynetwork_amd._capi import Session, VrgError
+    s = Session((4, 5, 6), lib=hm)
+    with pytest.raises(VrgError):            # init before inputs
+        s.init(2.25)
+    s.set_volume(np.zeros((4, 5, 6)))
+    with pytest.raises(VrgError):            # label outside {0,3,4}
+        s.set_labels(np.full((4, 5, 6), 1))
+    s.set_labels(np.full((4, 5, 6), 3))
+    with pytest.raises(VrgError) as e:       # no seed: the reference raises at :48
+        s.init(2.25)
+    assert e.value.code == -5
+    with pytest.raises(VrgError):            # 0.1 is not an fp32 value
+        s.set_volume(np.full((4, 5, 6), 0.1))
+    s.close()
+
+
+def test_hostmodel_layouts_and_dtypes(hm):
+    """C order / Fortran order / integer dtypes give the same result (strides are part of the ABI)."""
+    from arterynetwork_amd._capi import Session
+    rng = np.random.default_rng(3)
+    shape = (7, 9, 5)
+    I = rng.integers(0, 4, size=shape)
+    vm = np.full(shape, 3, dtype=np.int64)
+    vm[rng.random(shape) < 0.2] = 0
+    outs = []
+    for data, lab in ((I.astype(np.float64), vm), (np.asfortranarray(I.astype(np.float32)), np.asfortranarray(vm.astype(np.uint8))),
+                      (I.astype(np.int16), vm.astype(np.int32))):
+        s = Session(shape, lib=hm)
+        s.set_volume(data)
+        s.set_labels(lab)
+        s.init(2.25)
+        s.run(10, 10 ** 9, None)
+        out_c = s.labels()
+        out_f = s.labels(out=np.empty(shape, dtype=np.int64, order='F'))
+        assert np.array_equal(out_c, out_f)
+        outs.append((out_c, s.segmented()))
+        s.close()
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
