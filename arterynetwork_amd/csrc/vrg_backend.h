@@ -14,7 +14,8 @@ struct VrgEvents {            // optional HIP-event timing of the dense sweep la
     long long launches;
 };
 
-int be_set_device(int device);                 // 0 ok, <0 no usable device
+int be_set_device(int device);
+void be_set_tuning(const char* name, long long value);   // kernel launch knobs ("sweep_blocks")                 // 0 ok, <0 no usable device
 void* be_alloc(size_t bytes);
 void be_free(void* p);
 void be_fill(void* p, int byte, size_t bytes);

@@ -1,12 +1,17 @@
 // vrg_device.hip - the product backend: HIP kernels for MI355X (gfx950, wave64).
 //
-// Kernel inventory (one while-loop trip of variationalRegionGrowing.py:58-117 = be_sweep_once):
-//   band kernels (O(band) work, grid-stride over device-resident counts, no host round trip):
-//     k_decide -> scan -> k_fin_decide -> k_mark -> k_prepass -> k_fix -> k_scatter_marks
-//   dense kernel (every voxel, HBM-bound: 4 B intensity + 1 B label in, 1 B label out):
-//     k_sweep<variant> : relabel + region statistics  -> k_stats_reduce
-//   band kernels: k_flipres, k_survivor, level-delta compaction, k_tab, scan, k_scatter_*, k_exact,
-//     k_finalize
+// One while-loop trip of variationalRegionGrowing.py:58-117 (be_sweep_once), two HIP streams:
+//   stream A, band kernels (O(band) work, grid-stride over device-resident counts, no host round trip):
+//     k_decide (+listing) -> k_marks_prepass (stop tests, marks, skip-rule prepass) -> k_fix
+//     -> k_relabel (3x3x3 / 5x5x5 label stencil on the marked voxels, old labels only) -> k_apply
+//     -> k_recount : the dense kernel (every voxel, HBM-bound, read-only: 4 B intensity + 1 B label per
+//        voxel): region sizes and intensity sums (:113-116, :249-250), reduced by its last workgroup
+//   stream B (forked after k_apply, high priority, runs in the shadow of k_recount):
+//     k_entry_post, level-delta compaction, k_tab, scan, k_scatter_*, k_exact;
+//   join, k_finalize closes the trip.
+// Labels are updated IN PLACE: measured on MI355X, streaming I + labels read-only runs at 5.8-6.0 TB/s
+// while the same stream with a 1 B/voxel label write-back drops to 4.8 TB/s, so unchanged labels are
+// never rewritten.  (The full-stencil check variant relabels every voxel through lab[1].)
 // Every kernel starts by reading the device-resident VrgState and returns at once when the stop
 // flag is set, so the host can enqueue batches of sweeps without synchronising.
 #include <hip/hip_runtime.h>
@@ -28,9 +33,14 @@ namespace {
 constexpr int TPB = 256;            // 4 waves of 64
 constexpr int ITEM_BLOCKS = 256;    // band kernels: 64 Ki threads, grid-stride
 constexpr int SCAN_BLOCKS = 256;
-constexpr int SWEEP_BLOCKS = 2048;  // 8 workgroups per CU on 256 CUs
+constexpr int SWEEP_BLOCKS = 512;   // 2 workgroups per CU on 256 CUs: measured best for the HBM-bound recount while
+                                    // stream B's band kernels run beside it (384-512: 0.430 ms, 1024: 0.475, 2048: 0.512)
 
-hipStream_t g_stream = nullptr;
+hipStream_t g_stream = nullptr;      // stream A: decide -> relabel -> dense recount (the critical path), copies
+hipStream_t g_stream_b = nullptr;    // stream B: band bookkeeping, runs in the shadow of the recount (high priority)
+hipEvent_t g_ev_a = nullptr, g_ev_b = nullptr;
+int g_sweep_blocks = 0;              // 0 = auto (dense_blocks)
+int g_prio_mode = 0;
 
 // ---- wave / block primitives (wave = 64 lanes) -------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
@@ -62,21 +72,23 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
 // ---- item kernels ---------------------------------------------------------------------------------
 #define ITEM_LOOP(n) for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += gridDim.x * blockDim.x)
 
-__global__ void k_decide(VrgCtx c) {
+__global__ void k_decide(VrgCtx c) {                   // decide (:79-88) + listing of the flips
     if (c.st->done) return;
     ITEM_LOOP(c.st->ni + c.st->no) vrg_item_decide(c, i);
 }
-__global__ void k_fin_decide(VrgCtx c) {
+// stop tests (:91-104) once all entries have decided, then per listed flip: 125 mark positions + prepass
+__global__ void k_marks_prepass(VrgCtx c) {
     if (c.st->done) return;
-    vrg_item_fin_decide(c, c.st->scan_total);
-}
-__global__ void k_mark(VrgCtx c) {
-    if (c.st->done) return;
-    ITEM_LOOP(c.st->ni + c.st->no) vrg_item_mark(c, i);
-}
-__global__ void k_prepass(VrgCtx c) {
-    if (c.st->done) return;
-    ITEM_LOOP(c.st->nf - c.st->nfo) vrg_item_prepass(c, i);
+    int32_t stop = vrg_stop_test(c);
+    if (stop || c.st->error) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) c.st->done = stop ? stop : -1;
+        return;
+    }
+    ITEM_LOOP(c.st->nf * 128u) {
+        uint32_t r = i >> 7, p = i & 127u;
+        if (p < 125u) vrg_item_scatter_marks(c, r, p);
+        else if (p == 125u) vrg_item_prepass(c, c.flist[r]);
+    }
 }
 // skip-rule fix-point (rare): one workgroup relaxes until nothing changes
 __global__ void k_fix(VrgCtx c) {
@@ -95,25 +107,25 @@ __global__ void k_fix(VrgCtx c) {
         if (!changed) break;
     }
 }
-__global__ void k_scatter_marks(VrgCtx c) {
+__global__ void k_relabel(VrgCtx c) {
     if (c.st->done) return;
-    ITEM_LOOP(c.st->nf) vrg_item_scatter_marks(c, i);
+    ITEM_LOOP(min(c.st->nmk, c.mcap)) vrg_item_relabel(c, i);
 }
-__global__ void k_flipres(VrgCtx c) {
+__global__ void k_apply(VrgCtx c) {
     if (c.st->done) return;
-    ITEM_LOOP(c.st->nf) vrg_item_flipres(c, i);
+    ITEM_LOOP(min(c.st->nmk, c.mcap)) vrg_item_apply(c, i);
 }
-__global__ void k_survivor(VrgCtx c) {
+__global__ void k_entry_post(VrgCtx c) {
     if (c.st->done) return;
-    ITEM_LOOP(c.st->ni + c.st->no) vrg_item_survivor(c, i);
+    ITEM_LOOP(c.st->ni + c.st->no) vrg_item_entry_post(c, i);
 }
-__global__ void k_scatter_surv(VrgCtx c) {
+__global__ void k_scatter_entry(VrgCtx c) {
     if (c.st->done) return;
-    ITEM_LOOP(c.st->ni + c.st->no) vrg_item_scatter_surv(c, i);
+    ITEM_LOOP(c.st->ni + c.st->no) vrg_item_scatter_entry(c, i);
 }
-__global__ void k_scatter_flip(VrgCtx c) {
+__global__ void k_scatter_promo(VrgCtx c) {            // item = (listed flip, neighbour k)
     if (c.st->done) return;
-    ITEM_LOOP(c.st->nf) vrg_item_scatter_flip(c, i);
+    ITEM_LOOP(c.st->nf * 32u) vrg_item_scatter_promo(c, i >> 5, i & 31u);
 }
 
 // level-delta compaction (:232-235 regrouped by distinct intensity value)
@@ -140,7 +152,7 @@ __global__ void k_post_prep(VrgCtx c) {               // after the level scan, b
     uint32_t n = s.ni + s.no;
     s.nnz = s.scan_total;
     s.use_tab = c.L <= n;
-    s.ncnt = n + 2 * s.nf;
+    s.ncnt = 3 * n;
     s.nscan = s.ncnt;
 }
 // per-level memo of the three density corrections: one wave per level
@@ -163,7 +175,8 @@ __global__ void k_fin_scan(VrgCtx c) {
     if (c.st->done) return;
     VrgState& s = *c.st;
     uint32_t tot = s.scan_total;
-    s.ni_new = (s.ni + s.nf < s.ncnt) ? c.scan[s.ni + s.nf] : tot;
+    uint32_t b0 = vrg_slot_B0(s, 0);
+    s.ni_new = (b0 < s.ncnt) ? c.scan[b0] : tot;
     s.nb_new = tot;
     if (tot > c.bcap) { s.error = 1; s.done = -1; }
 }
@@ -191,12 +204,13 @@ __global__ void k_finalize(VrgCtx c) {                // iterNum += 1 (:117) + t
     if (c.st->done) return;
     VrgState& s = *c.st;
     s.ni = s.ni_new; s.no = s.nb_new - s.ni_new; s.iter++;
-    s.nscan = s.ni + s.no;
     if ((uint32_t)s.iter < c.trace_cap) {
         VrgTrace& t = c.trace[s.iter];
-        t.nflip = s.nf; t.nseg = s.n_in; t.n_in = s.n_in; t.n_out = s.n_out; t.ni = s.ni; t.no = s.no;
-        t.sum_in = s.sum_in; t.sum_out = s.sum_out;
+        const VrgDense& d = *c.dn;
+        t.nflip = s.nf; t.nseg = d.n_in; t.n_in = d.n_in; t.n_out = d.n_out; t.ni = s.ni; t.no = s.no;
+        t.sum_in = d.sum_in; t.sum_out = d.sum_out;
     }
+    s.nf = 0; s.npend = 0; s.nmk = 0; s.nfresh = 0;
     if (s.error) s.done = -1;
 }
 
@@ -236,128 +250,140 @@ __global__ void k_scan_down(VrgCtx c, uint32_t* a) {
         run += tot;
     }
 }
-void device_scan(const VrgCtx& c, uint32_t* a) {
+void device_scan(const VrgCtx& c, uint32_t* a, hipStream_t st) {
     static_assert(SCAN_BLOCKS == TPB, "k_scan_top scans one value per thread");
-    k_scan_reduce<<<SCAN_BLOCKS, TPB, 0, g_stream>>>(c, a);
-    k_scan_top<<<1, SCAN_BLOCKS, 0, g_stream>>>(c);
-    k_scan_down<<<SCAN_BLOCKS, TPB, 0, g_stream>>>(c, a);
+    k_scan_reduce<<<SCAN_BLOCKS, TPB, 0, st>>>(c, a);
+    k_scan_top<<<1, SCAN_BLOCKS, 0, st>>>(c);
+    k_scan_down<<<SCAN_BLOCKS, TPB, 0, st>>>(c, a);
 }
 
-// ---- the dense sweep ---------------------------------------------------------------------------------
-// Streams the interior planes as 16-byte label chunks (+64 bytes of intensities): a voxel whose byte
-// carries the mark bit runs the relabel stencil (vrg_sweep_core), every other voxel keeps its label;
-// region sizes and intensity sums (:113-116) are reduced on the fly (wave butterfly -> LDS -> one
-// slot per workgroup, summed in fixed order by k_stats_reduce).
-template <int VARIANT>
-__global__ void __launch_bounds__(TPB) k_sweep(VrgCtx c) {
-    if (c.st->done) return;
-    const int cur = c.st->iter & 1;
-    const uint8_t* __restrict__ in = c.lab[cur];
-    uint8_t* __restrict__ out = c.lab[cur ^ 1];
-    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
-    const uint32_t first = 2u * plane;
-    const uint32_t nchunk = (uint32_t)(((uint64_t)c.nz * plane) >> 4);
-    long long nin = 0, nout = 0;
-    double sin_ = 0, sout = 0;
-    for (uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x; ch < nchunk; ch += gridDim.x * blockDim.x) {
-        const uint32_t base = first + (ch << 4);
-        uint4 w = *reinterpret_cast<const uint4*>(in + base);
-        const float4* ip = reinterpret_cast<const float4*>(c.I + base);
-        float4 f0 = ip[0], f1 = ip[1], f2 = ip[2], f3 = ip[3];
-        uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-        const uint32_t need = VARIANT == 0 ? 0x80808080u : 0u;
-        bool any = VARIANT == 0 ? (((w.x | w.y | w.z | w.w) & need) != 0)
-                                : ((w.x & w.y & w.z & w.w & 0x20202020u) != 0x20202020u);
-        if (any) {
+// ---- the dense pass ----------------------------------------------------------------------------------
+// Region recount (:113-116 innerSize/outerSize, :249-250 dataArray[mask]) over every voxel, every sweep.
+// Streams the interior planes [2*plane, (nz+2)*plane) of the padded volume.  A wave owns one 1-KiB unit
+// of label bytes (1024 voxels) per trip: lane l takes the four dwords at +256*j + 4*l (j = 0..3) and
+// the four float4 of intensities at the same voxel offsets, so EVERY wave instruction is one contiguous
+// 256-B (labels) or 1-KiB (intensities) request.  Sums are reduced lane -> wave butterfly -> LDS -> one
+// slot per workgroup, added in fixed slot order by the last workgroup to finish: bit-reproducible.
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+struct SweepAcc { long long nin, nout; double sin_, sout; };
+
+__device__ __forceinline__ void sweep_stats(SweepAcc& a, uint32_t v, f4v f) {
+    uint32_t sbits = v & 0x01010101u;                                  // S
+    uint32_t obits = ~(v | (v >> 2) | (v >> 5)) & 0x01010101u;         // !(S|X|OOB)
+    a.nin += __popc(sbits); a.nout += __popc(obits);
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t v = ws[q];
-                for (int b = 0; b < 4; b++) {
-                    uint8_t cb = (uint8_t)(v >> (8 * b));
-                    bool run = VARIANT == 0 ? (cb & VB_M) != 0 : !(cb & VB_OOB);
-                    if (run) {
-                        uint8_t nb = vrg_sweep_core(c, in, base + 4 * q + b, cb);
-                        v = (v & ~(0xffu << (8 * b))) | ((uint32_t)nb << (8 * b));
-                    }
-                }
-                ws[q] = v;
-            }
-        }
-        *reinterpret_cast<uint4*>(out + base) = make_uint4(ws[0], ws[1], ws[2], ws[3]);
-        const float fv[16] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w, f3.x, f3.y, f3.z, f3.w};
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t v = ws[q];
-            uint32_t sbits = v & 0x01010101u;                                  // S
-            uint32_t obits = ~(v | (v >> 2) | (v >> 5)) & 0x01010101u;         // !(S|X|OOB)
-            nin += __popc(sbits); nout += __popc(obits);
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                double x = (double)fv[4 * q + b];
-                sin_ += ((sbits >> (8 * b)) & 1u) ? x : 0.0;
-                sout += ((obits >> (8 * b)) & 1u) ? x : 0.0;
-            }
-        }
+    for (int b = 0; b < 4; b++) {
+        double x = (double)f[b];
+        a.sin_ += ((sbits >> (8 * b)) & 1u) ? x : 0.0;
+        a.sout += ((obits >> (8 * b)) & 1u) ? x : 0.0;
     }
+}
+// per-workgroup slot, then the LAST workgroup to arrive adds all slots in slot order and publishes the
+// totals (agent-scope release before the ticket, acquire after it: cdna guide, Guideline 16)
+__device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a) {
     __shared__ long long sh_n[2][4];
     __shared__ double sh_s[2][4];
-    nin = wave_sum(nin); nout = wave_sum(nout); sin_ = wave_sum(sin_); sout = wave_sum(sout);
+    __shared__ int is_last;
+    a.nin = wave_sum(a.nin); a.nout = wave_sum(a.nout); a.sin_ = wave_sum(a.sin_); a.sout = wave_sum(a.sout);
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { sh_n[0][wv] = nin; sh_n[1][wv] = nout; sh_s[0][wv] = sin_; sh_s[1][wv] = sout; }
+    if (lane == 0) { sh_n[0][wv] = a.nin; sh_n[1][wv] = a.nout; sh_s[0][wv] = a.sin_; sh_s[1][wv] = a.sout; }
     __syncthreads();
     if (threadIdx.x == 0) {
         c.st_nin[blockIdx.x] = sh_n[0][0] + sh_n[0][1] + sh_n[0][2] + sh_n[0][3];
         c.st_nout[blockIdx.x] = sh_n[1][0] + sh_n[1][1] + sh_n[1][2] + sh_n[1][3];
         c.st_sin[blockIdx.x] = ((sh_s[0][0] + sh_s[0][1]) + sh_s[0][2]) + sh_s[0][3];
         c.st_sout[blockIdx.x] = ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t t = __hip_atomic_fetch_add(&c.counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (t == gridDim.x - 1);
+        if (is_last) {
+            c.counters[0] = 0;                       // every workgroup has arrived: reset for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
-}
-__global__ void k_stats_reduce(VrgCtx c, uint32_t nslots) {
-    if (c.st->done) return;
-    __shared__ long long sh_n[2][4];
-    __shared__ double sh_s[2][4];
-    long long a = 0, b = 0; double sa = 0, sb = 0;
-    for (uint32_t i = threadIdx.x; i < nslots; i += TPB) { a += c.st_nin[i]; b += c.st_nout[i]; sa += c.st_sin[i]; sb += c.st_sout[i]; }
-    a = wave_sum(a); b = wave_sum(b); sa = wave_sum(sa); sb = wave_sum(sb);
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { sh_n[0][wv] = a; sh_n[1][wv] = b; sh_s[0][wv] = sa; sh_s[1][wv] = sb; }
+    __syncthreads();
+    if (!is_last) return;
+    long long x = 0, y = 0; double sx = 0, sy = 0;
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += TPB) { x += c.st_nin[i]; y += c.st_nout[i]; sx += c.st_sin[i]; sy += c.st_sout[i]; }
+    x = wave_sum(x); y = wave_sum(y); sx = wave_sum(sx); sy = wave_sum(sy);
+    __syncthreads();
+    if (lane == 0) { sh_n[0][wv] = x; sh_n[1][wv] = y; sh_s[0][wv] = sx; sh_s[1][wv] = sy; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        VrgState& s = *c.st;
-        s.n_in = sh_n[0][0] + sh_n[0][1] + sh_n[0][2] + sh_n[0][3];
-        s.n_out = sh_n[1][0] + sh_n[1][1] + sh_n[1][2] + sh_n[1][3];
-        s.sum_in = ((sh_s[0][0] + sh_s[0][1]) + sh_s[0][2]) + sh_s[0][3];
-        s.sum_out = ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3];
+        VrgDense& d = *c.dn;
+        d.n_in = sh_n[0][0] + sh_n[0][1] + sh_n[0][2] + sh_n[0][3];
+        d.n_out = sh_n[1][0] + sh_n[1][1] + sh_n[1][2] + sh_n[1][3];
+        d.sum_in = ((sh_s[0][0] + sh_s[0][1]) + sh_s[0][2]) + sh_s[0][3];
+        d.sum_out = ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3];
     }
 }
-// statistics only (init): same reduction over lab[0] without relabelling
-__global__ void __launch_bounds__(TPB) k_stats_only(VrgCtx c) {
+
+__global__ void __launch_bounds__(TPB) k_recount(VrgCtx c, int check_done) {
+    if (check_done && c.st->done) return;
     const uint8_t* __restrict__ in = c.lab[0];
+    const float* __restrict__ I = c.I;
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
     const uint32_t first = 2u * plane;
-    const uint32_t nchunk = (uint32_t)(((uint64_t)c.nz * plane) >> 4);
-    long long nin = 0, nout = 0;
-    double sin_ = 0, sout = 0;
-    for (uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x; ch < nchunk; ch += gridDim.x * blockDim.x) {
-        const uint32_t base = first + (ch << 4);
-        for (int b = 0; b < 16; b++) {
-            uint8_t v = in[base + b];
-            double x = (double)c.I[base + b];
-            if (v & VB_S) { nin++; sin_ += x; } else if (!(v & (VB_X | VB_OOB))) { nout++; sout += x; }
+    const uint32_t total = (uint32_t)c.nz * plane;          // interior bytes, a multiple of 16
+    const uint32_t nfull = total >> 10;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    SweepAcc acc = {0, 0, 0.0, 0.0};
+    for (uint32_t u = wave; u < nfull; u += nwaves) {
+        const uint32_t base = first + (u << 10) + (lane << 2);
+        uint32_t w[4]; f4v f[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            w[j] = *reinterpret_cast<const uint32_t*>(in + base + (j << 8));
+            f[j] = *reinterpret_cast<const f4v*>(I + base + (j << 8));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) sweep_stats(acc, w[j], f[j]);
+    }
+    if (wave == nwaves - 1 && (total & 1023u)) {            // tail unit (< 1 KiB), predicated per lane
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t off = (nfull << 10) + (j << 8) + (lane << 2);
+            if (off < total)
+                sweep_stats(acc, *reinterpret_cast<const uint32_t*>(in + first + off), *reinterpret_cast<const f4v*>(I + first + off));
         }
     }
-    __shared__ long long sh_n[2][4];
-    __shared__ double sh_s[2][4];
-    nin = wave_sum(nin); nout = wave_sum(nout); sin_ = wave_sum(sin_); sout = wave_sum(sout);
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { sh_n[0][wv] = nin; sh_n[1][wv] = nout; sh_s[0][wv] = sin_; sh_s[1][wv] = sout; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        c.st_nin[blockIdx.x] = sh_n[0][0] + sh_n[0][1] + sh_n[0][2] + sh_n[0][3];
-        c.st_nout[blockIdx.x] = sh_n[1][0] + sh_n[1][1] + sh_n[1][2] + sh_n[1][3];
-        c.st_sin[blockIdx.x] = ((sh_s[0][0] + sh_s[0][1]) + sh_s[0][2]) + sh_s[0][3];
-        c.st_sout[blockIdx.x] = ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3];
+    sweep_finish(c, acc);
+}
+
+// full-stencil check variant: every voxel runs the relabel stencil (no marks); new bytes go to lab[1]
+// and are copied back, so stencil reads only ever see pre-sweep labels.
+__global__ void __launch_bounds__(TPB) k_full_relabel(VrgCtx c) {
+    if (c.st->done) return;
+    const uint8_t* __restrict__ in = c.lab[0];
+    uint8_t* __restrict__ out = c.lab[1];
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
+    const uint32_t first = 2u * plane;
+    const uint32_t ndw = (uint32_t)(((uint64_t)c.nz * plane) >> 2);
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < ndw; d += gridDim.x * blockDim.x) {
+        const uint32_t base = first + (d << 2);
+        uint32_t v = *reinterpret_cast<const uint32_t*>(in + base);
+        if ((v & 0x20202020u) != 0x20202020u)
+            for (int b = 0; b < 4; b++) {
+                uint8_t cb = (uint8_t)(v >> (8 * b));
+                if (!(cb & VB_OOB)) {
+                    uint8_t nb = vrg_sweep_core(c, in, base + b, cb);
+                    v = (v & ~(0xffu << (8 * b))) | ((uint32_t)nb << (8 * b));
+                }
+            }
+        *reinterpret_cast<uint32_t*>(out + base) = v;
     }
+}
+__global__ void __launch_bounds__(TPB) k_copy_back(VrgCtx c) {
+    if (c.st->done) return;
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(c.lab[1] + 2u * plane);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(c.lab[0] + 2u * plane);
+    const uint32_t n16 = (uint32_t)(((uint64_t)c.nz * plane) >> 4);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 // ---- dense helpers over the real voxels -------------------------------------------------------------
@@ -381,24 +407,25 @@ __global__ void k_init_entry(VrgCtx c) {
 }
 __global__ void k_fin_init(VrgCtx c) {
     VrgState& s = *c.st;
-    s.nfresh = 0; s.nscan = s.ni + s.no;
+    s.nfresh = 0; s.nf = 0; s.npend = 0; s.nmk = 0;
+    const VrgDense& d = *c.dn;
     VrgTrace& t = c.trace[0];
-    t.nflip = 0; t.nseg = s.n_in; t.n_in = s.n_in; t.n_out = s.n_out; t.ni = s.ni; t.no = s.no;
-    t.sum_in = s.sum_in; t.sum_out = s.sum_out;
+    t.nflip = 0; t.nseg = d.n_in; t.n_in = d.n_in; t.n_out = d.n_out; t.ni = s.ni; t.no = s.no;
+    t.sum_in = d.sum_in; t.sum_out = d.sum_out;
 }
-__global__ void k_recount(VrgCtx c, int par, int32_t* rin, int32_t* rout) {
+__global__ void k_recount_hist(VrgCtx c, int32_t* rin, int32_t* rout) {
     VOXEL_LOOP(c) {
         int x, y, z; uint32_t idx = real_idx(c, t, x, y, z);
-        uint8_t b = c.lab[par][idx];
+        uint8_t b = c.lab[0][idx];
         if (b & VB_X) continue;
         uint32_t lev = vrg_level_of(c, (double)c.I[idx]);
         atomicAdd((b & VB_S) ? &rin[lev] : &rout[lev], 1);
     }
 }
-__global__ void k_collect_seg(VrgCtx c, int par, uint64_t* stamps, uint32_t* idxs, uint32_t cap, uint32_t* count) {
+__global__ void k_collect_seg(VrgCtx c, uint64_t* stamps, uint32_t* idxs, uint32_t cap, uint32_t* count) {
     VOXEL_LOOP(c) {
         int x, y, z; uint32_t idx = real_idx(c, t, x, y, z);
-        if (c.lab[par][idx] & VB_S) {
+        if (c.lab[0][idx] & VB_S) {
             uint32_t p = atomicAdd(count, 1u);
             if (p < cap) { stamps[p] = c.stamp[idx]; idxs[p] = idx; }
         }
@@ -484,6 +511,13 @@ int voxel_blocks(const VrgCtx& c) {
     return (int)std::min<uint64_t>(4096, (V + TPB - 1) / TPB);
 }
 
+// workgroups of the dense recount: >= 32 one-KiB units per wave, at most 2 workgroups per CU
+int dense_blocks(const VrgCtx& c) {
+    if (g_sweep_blocks > 0) return g_sweep_blocks;
+    uint64_t units = ((uint64_t)c.nz * c.PY * c.PX) >> 10;
+    return (int)std::min<uint64_t>(SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128));
+}
+
 struct EvPair { hipEvent_t a, b; };
 std::vector<EvPair> g_ev_pool;
 size_t g_ev_used = 0;
@@ -491,10 +525,29 @@ size_t g_ev_used = 0;
 }  // namespace
 
 // ---- backend interface ---------------------------------------------------------------------------------
+static void make_streams() {
+    int lo = 0, hi = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));      // hi = numerically lowest = highest priority
+    if (g_stream) { HIP_CHECK(hipStreamSynchronize(g_stream)); HIP_CHECK(hipStreamDestroy(g_stream)); }
+    if (g_stream_b) { HIP_CHECK(hipStreamSynchronize(g_stream_b)); HIP_CHECK(hipStreamDestroy(g_stream_b)); }
+    // prio_mode 0: equal; 1: critical stream A high; 2: bookkeeping stream B high
+    HIP_CHECK(hipStreamCreateWithPriority(&g_stream, hipStreamNonBlocking, g_prio_mode == 1 ? hi : (g_prio_mode == 2 ? lo : 0)));
+    HIP_CHECK(hipStreamCreateWithPriority(&g_stream_b, hipStreamNonBlocking, g_prio_mode == 2 ? hi : (g_prio_mode == 1 ? lo : 0)));
+}
+void be_set_tuning(const char* name, long long v) {
+    if (std::strcmp(name, "sweep_blocks") == 0 && v >= 0 && v <= 4096) g_sweep_blocks = (int)v;
+    if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != g_prio_mode) { g_prio_mode = (int)v; make_streams(); }
+}
+
 int be_set_device(int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) { (void)hipGetLastError(); return -1; }
     if (hipSetDevice(device) != hipSuccess) return -1;
+    if (!g_stream) {
+        make_streams();
+        HIP_CHECK(hipEventCreateWithFlags(&g_ev_a, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&g_ev_b, hipEventDisableTiming));
+    }
     return 0;
 }
 void* be_alloc(size_t bytes) { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
@@ -502,7 +555,7 @@ void be_free(void* p) { HIP_CHECK(hipFree(p)); }
 void be_fill(void* p, int byte, size_t bytes) { HIP_CHECK(hipMemsetAsync(p, byte, bytes, g_stream)); }
 void be_upload(void* dst, const void* src, size_t bytes) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, g_stream)); HIP_CHECK(hipStreamSynchronize(g_stream)); }
 void be_download(void* dst, const void* src, size_t bytes) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, g_stream)); HIP_CHECK(hipStreamSynchronize(g_stream)); }
-void be_sync() { HIP_CHECK(hipStreamSynchronize(g_stream)); }
+void be_sync() { HIP_CHECK(hipStreamSynchronize(g_stream)); HIP_CHECK(hipStreamSynchronize(g_stream_b)); }
 
 static const void* stage_in(const VrgCtx& c, const void* src, int dtype, void** tmp) {
     *tmp = nullptr;
@@ -593,41 +646,50 @@ void be_init_finish(const VrgCtx& c) {
     k_init_entry<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     k_hist_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
     k_exact<<<1024, TPB, 0, g_stream>>>(c, 0);
-    k_stats_only<<<SWEEP_BLOCKS, TPB, 0, g_stream>>>(c);
-    k_stats_reduce<<<1, TPB, 0, g_stream>>>(c, SWEEP_BLOCKS);
+    k_recount<<<dense_blocks(c), TPB, 0, g_stream>>>(c, 0);
     k_fin_init<<<1, 1, 0, g_stream>>>(c);
 }
 
 void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev) {
+    const bool full = variant & 1;
+    const int blocks = dense_blocks(c);
+    // stream A: decide + flip list, marks + prepass, skip-rule fix-point, sparse relabel
     k_decide<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    device_scan(c, c.scan);
-    k_fin_decide<<<1, 1, 0, g_stream>>>(c);
-    k_mark<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    k_prepass<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    k_marks_prepass<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     k_fix<<<1, 1024, 0, g_stream>>>(c);
-    if (variant == 0) k_scatter_marks<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    if (!full) {
+        k_relabel<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+        k_apply<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    } else {
+        k_full_relabel<<<2048, TPB, 0, g_stream>>>(c);
+        k_copy_back<<<2048, TPB, 0, g_stream>>>(c);
+    }
+    // fork: stream B does the band bookkeeping (new lists, densities) ...
+    HIP_CHECK(hipEventRecord(g_ev_a, g_stream));
+    HIP_CHECK(hipStreamWaitEvent(g_stream_b, g_ev_a, 0));
+    k_entry_post<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
+    k_delta_flag<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
+    device_scan(c, c.lscan, g_stream_b);
+    k_post_prep<<<1, 1, 0, g_stream_b>>>(c);
+    k_delta_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
+    k_tab<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
+    device_scan(c, c.scan, g_stream_b);
+    k_fin_scan<<<1, 1, 0, g_stream_b>>>(c);
+    k_scatter_entry<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
+    k_scatter_promo<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
+    k_exact<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c, 1);
+    HIP_CHECK(hipEventRecord(g_ev_b, g_stream_b));
+    // ... while stream A streams every voxel once: the dense recount over the new labels (read-only)
     EvPair* p = nullptr;
     if (ev && ev->enabled) {
         if (g_ev_used == g_ev_pool.size()) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); g_ev_pool.push_back(n); }
         p = &g_ev_pool[g_ev_used++];
         HIP_CHECK(hipEventRecord(p->a, g_stream));
     }
-    if (variant == 0) k_sweep<0><<<SWEEP_BLOCKS, TPB, 0, g_stream>>>(c);
-    else k_sweep<1><<<SWEEP_BLOCKS, TPB, 0, g_stream>>>(c);
+    k_recount<<<blocks, TPB, 0, g_stream>>>(c, 1);
     if (p) HIP_CHECK(hipEventRecord(p->b, g_stream));
-    k_stats_reduce<<<1, TPB, 0, g_stream>>>(c, SWEEP_BLOCKS);
-    k_flipres<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    k_survivor<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    k_delta_flag<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    device_scan(c, c.lscan);
-    k_post_prep<<<1, 1, 0, g_stream>>>(c);
-    k_delta_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    k_tab<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    device_scan(c, c.scan);
-    k_fin_scan<<<1, 1, 0, g_stream>>>(c);
-    k_scatter_surv<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    k_scatter_flip<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    k_exact<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c, 1);
+    // join
+    HIP_CHECK(hipStreamWaitEvent(g_stream, g_ev_b, 0));
     k_finalize<<<1, 1, 0, g_stream>>>(c);
 }
 
@@ -644,7 +706,7 @@ void be_events_collect(VrgEvents* ev, long long n_valid) {
 }
 
 void be_recount_hist(const VrgCtx& c, int par, int32_t* rin, int32_t* rout) {
-    k_recount<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, par, rin, rout);
+    k_recount_hist<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, rin, rout);
     HIP_CHECK(hipStreamSynchronize(g_stream));
 }
 
@@ -652,7 +714,7 @@ uint32_t be_collect_segmented(const VrgCtx& c, int par, uint64_t* stamps, uint32
     uint64_t* ds = nullptr; uint32_t* di = nullptr; uint32_t* dc = nullptr;
     HIP_CHECK(hipMalloc(&ds, (size_t)(cap + 1) * 8)); HIP_CHECK(hipMalloc(&di, (size_t)(cap + 1) * 4)); HIP_CHECK(hipMalloc(&dc, 4));
     HIP_CHECK(hipMemsetAsync(dc, 0, 4, g_stream));
-    k_collect_seg<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, par, ds, di, cap, dc);
+    k_collect_seg<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, ds, di, cap, dc);
     uint32_t n = 0;
     HIP_CHECK(hipMemcpyAsync(&n, dc, 4, hipMemcpyDeviceToHost, g_stream));
     HIP_CHECK(hipStreamSynchronize(g_stream));

@@ -49,6 +49,7 @@ template <class T> T* alloc(vrg_handle* h, size_t n) {
     return (T*)p;
 }
 
+VrgDense get_dense(vrg_handle* h) { VrgDense d; be_download(&d, h->c.dn, sizeof(d)); return d; }
 VrgState get_state(vrg_handle* h) { VrgState s; be_download(&s, h->c.st, sizeof(s)); return s; }
 void put_state(vrg_handle* h, const VrgState& s) { be_upload(h->c.st, &s, sizeof(s)); }
 
@@ -91,11 +92,15 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.lab[1] = h->lab_base[1] ? h->lab_base[1] + 16 : nullptr;
     c.stamp = alloc<uint64_t>(h, c.PV);
     c.st = alloc<VrgState>(h, 1);
-    if (!c.I || !c.lab[0] || !c.lab[1] || !c.stamp || !c.st) { API(destroy)(h); return VRG_E_MEM; }
+    c.dn = alloc<VrgDense>(h, 16);                   // own allocation: written by the dense kernel only
+    c.counters = alloc<uint32_t>(h, 64);
+    if (!c.I || !c.lab[0] || !c.lab[1] || !c.stamp || !c.st || !c.dn || !c.counters) { API(destroy)(h); return VRG_E_MEM; }
     be_fill((void*)c.I, 0, (size_t)c.PV * 4);
     be_fill(h->lab_base[0], VB_OOB, (size_t)c.PV + 32);
     be_fill(h->lab_base[1], VB_OOB, (size_t)c.PV + 32);
     be_fill(c.st, 0, sizeof(VrgState));
+    be_fill(c.dn, 0, sizeof(VrgDense));
+    be_fill(c.counters, 0, 64 * sizeof(uint32_t));
     *out = h;
     return VRG_OK;
 }
@@ -116,6 +121,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "sweep_variant") h->variant = (int)value;
     else if (n == "events") h->ev.enabled = value != 0;
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
+    else if (n == "sweep_blocks" || n == "prio_mode") be_set_tuning(name, value);
     else return fail(h, VRG_E_ARG, "unknown option " + n);
     return VRG_OK;
 }
@@ -181,19 +187,21 @@ int API(init)(vrg_handle* h, double H) {
             if (!c.b_idx[p] || !c.b_lev[p] || !c.b_ip[p] || !c.b_op[p]) return fail(h, VRG_E_MEM, "vrg_init: band arrays");
         }
         c.e_flag = alloc<uint8_t>(h, c.bcap); c.e_surv = alloc<uint8_t>(h, c.bcap);
-        c.scan = alloc<uint32_t>(h, (size_t)c.bcap + 2 * (size_t)c.fcap + 16);
+        c.e_res = alloc<uint8_t>(h, c.bcap); c.e_mask = alloc<uint32_t>(h, c.bcap);
+        c.scan = alloc<uint32_t>(h, 3 * (size_t)c.bcap + 16);
         c.bsum = alloc<uint32_t>(h, 1024);
-        c.f_entry = alloc<uint32_t>(h, c.fcap); c.f_idx = alloc<uint32_t>(h, c.fcap);
-        c.f_mask = alloc<uint32_t>(h, c.fcap); c.f_res = alloc<uint8_t>(h, c.fcap);
+        c.flist = alloc<uint32_t>(h, c.fcap);
         c.pend = alloc<uint32_t>(h, c.fcap); c.fresh = alloc<uint32_t>(h, c.bcap);
         c.init_key = alloc<uint64_t>(h, c.bcap); c.init_idx = alloc<uint32_t>(h, c.bcap);
+        c.mcap = (uint32_t)std::min<uint64_t>(V, 0xffffffffull);
+        c.mk_idx = alloc<uint32_t>(h, c.mcap); c.mk_new = alloc<uint8_t>(h, (size_t)c.mcap + 16);
         c.nstat = 4096;
         c.st_nin = alloc<int64_t>(h, c.nstat); c.st_nout = alloc<int64_t>(h, c.nstat);
         c.st_sin = alloc<double>(h, c.nstat); c.st_sout = alloc<double>(h, c.nstat);
         c.trace_cap = 1u << 16;
         c.trace = alloc<VrgTrace>(h, c.trace_cap);
-        if (!c.e_flag || !c.e_surv || !c.scan || !c.bsum || !c.f_entry || !c.f_idx || !c.f_mask || !c.f_res || !c.pend || !c.fresh ||
-            !c.init_key || !c.init_idx || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace)
+        if (!c.e_flag || !c.e_surv || !c.scan || !c.bsum || !c.e_res || !c.e_mask || !c.flist || !c.pend || !c.fresh ||
+            !c.init_key || !c.init_idx || !c.mk_idx || !c.mk_new || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace)
             return fail(h, VRG_E_MEM, "vrg_init: work arrays");
     }
     VrgState s; std::memset(&s, 0, sizeof(s));
@@ -225,6 +233,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     if (rc) return rc;
     int32_t iter0 = s.iter;
     s.done = 0; s.iterMax = (int32_t)iterMax; s.maxSegmentSize = maxSegmentSize;
+    s.nf = 0; s.npend = 0; s.nmk = 0; s.nfresh = 0;      // counters of a trip that stopped before update()
     put_state(h, s);
     double ms0 = h->ev.ms_total; long long l0 = h->ev.launches;
     auto t_begin = std::chrono::steady_clock::now();
@@ -247,8 +256,9 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     if (rc) return rc;
     if (out) {
         out->stop_reason = s.done; out->iter_num = s.iter + 1; out->sweeps = s.iter - iter0;
-        out->nseg = s.n_in; out->n_in = s.n_in; out->n_out = s.n_out; out->ni = s.ni; out->no = s.no;
-        out->sum_in = s.sum_in; out->sum_out = s.sum_out; out->seconds = secs;
+        VrgDense d = get_dense(h);
+        out->nseg = d.n_in; out->n_in = d.n_in; out->n_out = d.n_out; out->ni = s.ni; out->no = s.no;
+        out->sum_in = d.sum_in; out->sum_out = d.sum_out; out->seconds = secs;
         out->sweep_kernel_ms = h->ev.ms_total - ms0; out->sweep_launches = h->ev.launches - l0;
     }
     return VRG_OK;
@@ -256,23 +266,21 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
 
 int API(get_labels)(vrg_handle* h, void* outp, int dtype, const int64_t st[3]) {
     if (!h || !outp || !st || dtype < VRG_U8 || dtype > VRG_F64) return fail(h, VRG_E_ARG, "get_labels: bad argument");
-    VrgState s = get_state(h);
-    int par = h->inited ? (s.iter & 1) : 0;
-    if (be_unpack_labels(h->c, h->c.lab[par], outp, dtype, st)) return fail(h, VRG_E_ARG, "get_labels: unsupported strides");
+    if (be_unpack_labels(h->c, h->c.lab[0], outp, dtype, st)) return fail(h, VRG_E_ARG, "get_labels: unsupported strides");
     return VRG_OK;
 }
 
 int API(get_segmented)(vrg_handle* h, int64_t* coords, int64_t cap, int64_t* n) {
     if (!h || !n) return VRG_E_ARG;
     if (!h->inited) return fail(h, VRG_E_STATE, "get_segmented: not initialised");
-    VrgState s = get_state(h);
-    *n = s.n_in;
+    VrgDense d = get_dense(h);
+    *n = d.n_in;
     if (!coords) return VRG_OK;
-    if (cap < s.n_in) return fail(h, VRG_E_ARG, "get_segmented: buffer too small");
-    std::vector<uint64_t> stamps((size_t)s.n_in + 1);
-    std::vector<uint32_t> idxs((size_t)s.n_in + 1);
-    uint32_t got = be_collect_segmented(h->c, s.iter & 1, stamps.data(), idxs.data(), (uint32_t)s.n_in);
-    if ((int64_t)got != s.n_in) return fail(h, VRG_E_INTERNAL, "get_segmented: count mismatch");
+    if (cap < d.n_in) return fail(h, VRG_E_ARG, "get_segmented: buffer too small");
+    std::vector<uint64_t> stamps((size_t)d.n_in + 1);
+    std::vector<uint32_t> idxs((size_t)d.n_in + 1);
+    uint32_t got = be_collect_segmented(h->c, 0, stamps.data(), idxs.data(), (uint32_t)d.n_in);
+    if ((int64_t)got != d.n_in) return fail(h, VRG_E_INTERNAL, "get_segmented: count mismatch");
     std::vector<uint32_t> order(got);
     for (uint32_t i = 0; i < got; i++) order[i] = i;
     // list order of segmentedList: seeds in np.where order (:44), then appended per applied flip-in (:200)
@@ -324,12 +332,11 @@ int API(get_levels)(vrg_handle* h, double* values, int32_t* hin, int32_t* hout, 
     if (hin) be_download(hin, h->c.hin, (size_t)L * 4);
     if (hout) be_download(hout, h->c.hout, (size_t)L * 4);
     if (rin && rout) {
-        VrgState s = get_state(h);
         int32_t* di = (int32_t*)be_alloc((size_t)L * 4);
         int32_t* dout = (int32_t*)be_alloc((size_t)L * 4);
         if (!di || !dout) return fail(h, VRG_E_MEM, "get_levels");
         be_fill(di, 0, (size_t)L * 4); be_fill(dout, 0, (size_t)L * 4);
-        be_recount_hist(h->c, s.iter & 1, di, dout);
+        be_recount_hist(h->c, 0, di, dout);
         be_download(rin, di, (size_t)L * 4); be_download(rout, dout, (size_t)L * 4);
         be_free(di); be_free(dout);
     }

@@ -5,7 +5,8 @@
 // the reference goldens in tests/):
 //
 //  * flip list = concat(innerBnd, outerBnd)[mask] (:48,:88,:111): all flip-outs (label 1) precede all
-//    flip-ins (label 2); "rank" = position in that list.  Ranks only ever matter between 26-neighbours.
+//    flip-ins (label 2).  Only the ORDER of that list matters, and only between 26-neighbours, so the
+//    position e of a voxel in concat(innerBnd, outerBnd) (its band entry index) serves as its "rank".
 //  * phase A (flip-outs, :170-196), always applied:  P: 1->2.  A label-0 neighbour becomes 1 (:194).
 //    A label-2 voxel next to a flip-out becomes 3 iff no segmented neighbour is left after all
 //    flip-outs (:186-190) - for a flipped-out voxel itself only if a flip-out neighbour of larger rank
@@ -86,71 +87,64 @@ VRG_HD uint32_t vrg_level_of(const VrgCtx& c, double v) {   // index of v in the
     return lo;
 }
 
-// ------------------------------------------------------------------ decide (:79-88)
+// ------------------------------------------------------------------ decide (:79-88) + listing
+// One item per band entry.  A flip is listed at once: L bit (+P for flip-outs, which are always
+// applied), stamp = (sweep, entry index) and an unordered append to the flip list.
 VRG_HD void vrg_item_decide(const VrgCtx& c, uint32_t e) {
-    const VrgState& s = *c.st;
+    VrgState& s = *c.st;
+    if (s.iter >= s.iterMax) return;                      // while iterNum <= iterMax (:58)
     int cur = s.iter & 1;
-    double inN = c.b_ip[cur][e] / (double)s.n_in;       // :81
-    double outN = c.b_op[cur][e] / (double)s.n_out;     // :82
+    double inN = c.b_ip[cur][e] / (double)c.dn->n_in;     // :81
+    double outN = c.b_op[cur][e] / (double)c.dn->n_out;   // :82
     bool ge = inN >= outN;
     bool inner = e < s.ni;
-    uint8_t flip = (inner != ge) ? 1 : 0;               // :87 xor(segmentedMap, inner >= outer)
-    c.e_flag[e] = flip;
-    c.scan[e] = flip;
+    bool flip = inner != ge;                              // :87 xor(segmentedMap, inner >= outer)
+    c.e_flag[e] = flip ? 1 : 0; c.e_res[e] = 0; c.e_mask[e] = 0;
+    if (!flip) return;
+    uint32_t q = vrg_atomic_add(&s.nf, 1u);
+    if (c.dn->n_in >= s.maxSegmentSize) return;           // :101 fires before update(): count only
+    if (q >= c.fcap) { s.error = 2; return; }
+    c.flist[q] = e;
+    uint32_t idx = c.b_idx[cur][e];
+    vrg_or_byte(c.lab[0], idx, (uint8_t)(VB_L | (inner ? VB_P : 0)));
+    c.stamp[idx] = ((uint64_t)(uint32_t)(s.iter + 1) << 32) | e;
 }
 
-// after the exclusive scan of the flip flags: sizes + the stop tests in the reference's order
-VRG_HD void vrg_item_fin_decide(const VrgCtx& c, uint32_t total) {
-    VrgState& s = *c.st;
-    uint32_t n = s.ni + s.no;
-    s.nf = total;
-    s.nfo = (s.ni < n) ? c.scan[s.ni] : total;
-    s.npend = 0; s.nfresh = 0; s.fix_changed = 0;
-    if (s.iter >= s.iterMax) s.done = VRG_STOP_ITERMAX;                  // while iterNum <= iterMax (:58)
-    else if (total == 0) s.done = VRG_STOP_CONVERGED;                    // :91
-    else if (s.n_in >= s.maxSegmentSize) s.done = VRG_STOP_SIZE;         // :101 (time cap :97 is host side)
-    else if (total > c.fcap) { s.error = 2; s.done = -2; }
-}
-
-// listed flips: rank-indexed tables, L (+P for flip-outs) bits, stamp
-VRG_HD void vrg_item_mark(const VrgCtx& c, uint32_t e) {
-    if (!c.e_flag[e]) return;
+// the stop tests in the reference's order, once every entry has decided (time cap :97 is host side)
+VRG_HD int32_t vrg_stop_test(const VrgCtx& c) {
     const VrgState& s = *c.st;
-    int cur = s.iter & 1;
-    uint32_t r = c.scan[e], idx = c.b_idx[cur][e];
-    c.f_entry[r] = e; c.f_idx[r] = idx; c.f_mask[r] = 0; c.f_res[r] = 0;
-    vrg_or_byte(c.lab[cur], idx, (uint8_t)(VB_L | (e < s.ni ? VB_P : 0)));
-    c.stamp[idx] = ((uint64_t)(uint32_t)(s.iter + 1) << 32) | r;
+    if (s.iter >= s.iterMax) return VRG_STOP_ITERMAX;                    // :58
+    if (s.nf == 0) return VRG_STOP_CONVERGED;                            // :91
+    if (c.dn->n_in >= s.maxSegmentSize) return VRG_STOP_SIZE;            // :101
+    return 0;
 }
 
 // flip-ins: label after phase A (:183-190) decides whether the flip is applied at once
-VRG_HD void vrg_item_prepass(const VrgCtx& c, uint32_t j) {
+VRG_HD void vrg_item_prepass(const VrgCtx& c, uint32_t e) {
     VrgState& s = *c.st;
-    int cur = s.iter & 1;
-    uint32_t r = s.nfo + j, idx = c.f_idx[r];
-    const uint8_t* lab = c.lab[cur];
+    if (e < s.ni) return;
+    uint32_t idx = c.b_idx[s.iter & 1][e];
+    const uint8_t* lab = c.lab[0];
     bool nFO = false, nSegA = false;
     for (int k = 0; k < 27; k++) {
         if (k == 13) continue;
         uint8_t m = lab[(int64_t)idx + vrg_off(c, k)];
         if (m & VB_S) { if (m & VB_L) nFO = true; else nSegA = true; }
     }
-    if (nFO && !nSegA) c.pend[vrg_atomic_add(&s.npend, 1u)] = r;   // dropped to 3: skipped unless re-promoted
-    else vrg_or_byte(c.lab[cur], idx, VB_P);
+    if (nFO && !nSegA) c.pend[vrg_atomic_add(&s.npend, 1u)] = e;   // dropped to 3: skipped unless re-promoted
+    else vrg_or_byte(c.lab[0], idx, VB_P);
 }
 
 // one relaxation of the skip rule: applied if an applied flip-in neighbour of smaller rank exists
 VRG_HD bool vrg_item_fix(const VrgCtx& c, uint32_t j) {
-    const VrgState& s = *c.st;
-    int cur = s.iter & 1;
-    uint32_t r = c.pend[j], idx = c.f_idx[r];
-    uint8_t* lab = c.lab[cur];
+    uint32_t e = c.pend[j], idx = c.b_idx[c.st->iter & 1][e];
+    uint8_t* lab = c.lab[0];
     if (vrg_load_coherent(lab + idx) & VB_P) return false;
     for (int k = 0; k < 27; k++) {
         if (k == 13) continue;
         uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
         uint8_t mb = vrg_load_coherent(lab + m);
-        if (!(mb & VB_S) && (mb & VB_L) && (mb & VB_P) && (uint32_t)c.stamp[m] < r) {
+        if (!(mb & VB_S) && (mb & VB_L) && (mb & VB_P) && (uint32_t)c.stamp[m] < e) {
             vrg_or_byte(lab, idx, VB_P);
             return true;
         }
@@ -158,26 +152,37 @@ VRG_HD bool vrg_item_fix(const VrgCtx& c, uint32_t j) {
     return false;
 }
 
-// scatter the "needs the stencil" mark: 1-ring of every listed flip (incl. itself), and excluded
-// voxels in the 2-ring of every applied flip.  Everything else keeps its label this sweep.
+// scatter the "needs the stencil" mark: 1-ring of every listed flip (incl. itself) and the excluded
+// voxels of its 2-ring (needed for applied flips; harmless for a skipped flip-in, whose 2-ring voxels
+// then simply keep their label); the first marker of a voxel appends it to the marked list.
+// Everything else keeps its label this sweep.  Item = (listed flip r, position p of the 5x5x5 cube).
 #define VB_M 128
-VRG_HD void vrg_item_scatter_marks(const VrgCtx& c, uint32_t r) {
-    const VrgState& s = *c.st;
-    int cur = s.iter & 1;
-    uint8_t* lab = c.lab[cur];
-    uint32_t idx = c.f_idx[r];
-    bool applied = (lab[idx] & VB_P) != 0;
-    for (int dz = -2; dz <= 2; dz++)
-        for (int dy = -2; dy <= 2; dy++)
-            for (int dx = -2; dx <= 2; dx++) {
-                bool ring1 = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
-                if (!ring1 && !applied) continue;
-                int64_t m = (int64_t)idx + (dz * c.PY + dy) * c.PX + dx;   // may be -1,-2 (guard bytes) at voxel (0,0,0)
-                uint8_t mb = lab[m];
-                if (mb & (VB_OOB | VB_M)) continue;
-                if (ring1 || (mb & VB_X)) vrg_or_byte(lab, (uint32_t)m, VB_M);
-            }
+VRG_HD void vrg_item_scatter_marks(const VrgCtx& c, uint32_t r, uint32_t p) {
+    if (p >= 125) return;
+    uint8_t* lab = c.lab[0];
+    uint32_t idx = c.b_idx[c.st->iter & 1][c.flist[r]];
+    int dx = (int)(p % 5) - 2, dy = (int)((p / 5) % 5) - 2, dz = (int)(p / 25) - 2;
+    bool ring1 = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+    int64_t m = (int64_t)idx + (dz * c.PY + dy) * c.PX + dx;   // may be -1,-2 (guard bytes) at voxel (0,0,0)
+    uint8_t mb = lab[m];
+    if (mb & (VB_OOB | VB_M)) return;
+    if (!ring1 && !(mb & VB_X)) return;
+    uint32_t sh = 8 * ((uint32_t)m & 3u);
+    uint32_t old = vrg_atomic_or((uint32_t*)(lab + ((uint32_t)m & ~3u)), (uint32_t)VB_M << sh);
+    if (!((old >> sh) & VB_M)) {
+        uint32_t q = vrg_atomic_add(&c.st->nmk, 1u);
+        if (q < c.mcap) c.mk_idx[q] = (uint32_t)m; else c.st->error = 4;
+    }
 }
+// sparse relabel, phase 1: new byte of every marked voxel from the OLD labels (nothing is written to
+// the label volume yet, so all stencil reads see the pre-sweep state)
+VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t cb);
+VRG_HD void vrg_item_relabel(const VrgCtx& c, uint32_t i) {
+    uint32_t idx = c.mk_idx[i];
+    c.mk_new[i] = vrg_sweep_core(c, c.lab[0], idx, c.lab[0][idx]);
+}
+// phase 2: write the new bytes (this also clears the L / P / mark bits)
+VRG_HD void vrg_item_apply(const VrgCtx& c, uint32_t i) { c.lab[0][c.mk_idx[i]] = c.mk_new[i]; }
 
 // ------------------------------------------------------------------ the relabel stencil for one voxel
 // phase-B promotion (3 -> 2, :210-213): list key (first applied flip-in neighbour, k)
@@ -192,7 +197,7 @@ VRG_HD void vrg_promote_b(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
             if (r < best) { best = r; bk = 26 - k; }
         }
     }
-    vrg_atomic_or(&c.f_mask[best], 1u << bk);
+    vrg_atomic_or(&c.e_mask[best], 1u << bk);
 }
 // phase-A promotion (0 -> 1, :194-196): list key (first flip-out neighbour, k)
 VRG_HD void vrg_promote_a(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
@@ -206,11 +211,11 @@ VRG_HD void vrg_promote_a(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
             if (r < best) { best = r; bk = 26 - k; }
         }
     }
-    vrg_atomic_or(&c.f_mask[best], 1u << bk);
+    vrg_atomic_or(&c.e_mask[best], 1u << bk);
 }
 
-// Returns the voxel's byte after the sweep.  Side effects for the rare cases: f_res (listed flips),
-// f_mask (promotions), dConv (4->3 inclusions).  `lab` = this sweep's input labels (L/P bits set).
+// Returns the voxel's byte after the sweep.  Side effects for the rare cases: e_res (listed flips),
+// e_mask (promotions), dConv (4->3 inclusions).  Ranks (low stamp word) are band entry indices.  `lab` = this sweep's input labels (L/P bits set).
 VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t cb) {
     bool nSegA = false, nFO = false, nAP = false, nNonSegB = false, nListed = false;
     for (int k = 0; k < 27; k++) {
@@ -232,13 +237,13 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
                     uint8_t mb = lab[m];
                     if ((mb & VB_S) && (mb & VB_L) && (uint32_t)c.stamp[m] > r) to3 = true;
                 }
-            if (!to3) { c.f_res[r] = FR_WRITTEN | 2; return VB_B; }          // stays 2, carried to the outer list
+            if (!to3) { c.e_res[r] = FR_WRITTEN | 2; return VB_B; }          // stays 2, carried to the outer list
             if (nAP) {                                                      // 3 -> 2 again (:210-213): fresh
-                c.f_res[r] = FR_WRITTEN | 2 | FR_FRESH;
+                c.e_res[r] = FR_WRITTEN | 2 | FR_FRESH;
                 vrg_promote_b(c, lab, idx);
                 return VB_B;
             }
-            c.f_res[r] = FR_WRITTEN | 3;
+            c.e_res[r] = FR_WRITTEN | 3;
             return 0;
         }
         bool is1 = (cb & VB_B) || nFO;                // label after phase A (:194)
@@ -259,7 +264,7 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
                     if (!(mb & VB_S) && (mb & VB_P) && (uint32_t)c.stamp[m] > r) to0 = true;
                 }
             bool fresh = nFO && !nSegA;               // had dropped to 3 in phase A: exact density (:212,:251)
-            c.f_res[r] = (uint8_t)(FR_WRITTEN | (to0 ? 0 : 1) | (fresh ? FR_FRESH : 0));
+            c.e_res[r] = (uint8_t)(FR_WRITTEN | (to0 ? 0 : 1) | (fresh ? FR_FRESH : 0));
             return to0 ? VB_S : (uint8_t)(VB_S | VB_B);
         }
         bool to3 = nFO && !nSegA;                     // :183-190
@@ -267,7 +272,7 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
         if (!to3) { out = VB_B; res = 2; }
         else if (nAP) { out = VB_B | VB_F; res = 2 | FR_FRESH; vrg_promote_b(c, lab, idx); }
         else { out = 0; res = 3; }
-        if (cb & VB_L) c.f_res[(uint32_t)c.stamp[idx]] = (uint8_t)(FR_WRITTEN | res);   // skipped flip-in
+        if (cb & VB_L) c.e_res[(uint32_t)c.stamp[idx]] = (uint8_t)(FR_WRITTEN | res);   // skipped flip-in
         return out;
     }
     // labels 3 and 4
@@ -287,49 +292,54 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
     return (uint8_t)(((cb & VB_X) && !conv) ? VB_X : 0);
 }
 
-// ------------------------------------------------------------------ after the sweep
-// per listed flip: density bookkeeping sets (:232-233), class histograms, rebuild counts
-VRG_HD void vrg_item_flipres(const VrgCtx& c, uint32_t r) {
-    const VrgState& s = *c.st;
-    int cur = s.iter & 1;
-    uint32_t e = c.f_entry[r];
-    uint32_t lev = c.b_lev[cur][e];
-    uint8_t res = c.f_res[r];
-    if (!(res & FR_WRITTEN)) c.st->error = 3;             // a listed flip the sweep never visited
-    uint8_t fin = res & FR_FINAL;
-    bool fresh = res & FR_FRESH;
-    if (fin == 1) vrg_atomic_add(&c.dIn[lev], 1u);        // innerAdded: listed flips labelled 1 at the end
-    else if (fin == 2) vrg_atomic_add(&c.dOut[lev], 1u);  // outerAdded: ... labelled 2
-    uint32_t n = s.ni + s.no, nfo = s.nfo, nfi = s.nf - s.nfo;
-    if (r < nfo) {                                        // flip-out: inner -> outer region
-        vrg_atomic_add(&c.hin[lev], -1); vrg_atomic_add(&c.hout[lev], 1);
-        c.scan[s.ni + r] = (uint32_t)__builtin_popcount(c.f_mask[r]);                 // seg1: A promotions
-        c.scan[n + nfo + nfi + r] = (fin == 2 && !fresh) ? 1u : 0u;                   // seg4: carried to outer
-    } else {
-        uint32_t j = r - nfo;
-        if (fin <= 1) { vrg_atomic_add(&c.hin[lev], 1); vrg_atomic_add(&c.hout[lev], -1); }   // applied
-        c.scan[s.ni + nfo + j] = (fin == 1) ? 1u : 0u;                                // seg2: joins inner list
-        c.scan[n + 2 * nfo + nfi + j] = (uint32_t)__builtin_popcount(c.f_mask[r]);    // seg5: B promotions
-    }
-}
+// ------------------------------------------------------------------ after the relabel
+// Rebuild count array (length 3n, exclusive-scanned into new list positions), n = ni + no, j = e - ni:
+//   A0[e]  inner survivors          A1[e]  voxels promoted to 1 by flip-out e     A2[j]  flip-ins now labelled 1
+//   B0[j]  outer survivors          B1[e]  flip-outs still labelled 2 (carried)   B2[j]  voxels promoted to 2 by flip-in j
+// laid out [A0|A1|A2|B0|B1|B2]: exactly the append order of innerBndList / outerBndList (:257-258).
+VRG_HD uint32_t vrg_slot_A0(const VrgState&, uint32_t e) { return e; }
+VRG_HD uint32_t vrg_slot_A1(const VrgState& s, uint32_t e) { return s.ni + e; }
+VRG_HD uint32_t vrg_slot_A2(const VrgState& s, uint32_t j) { return 2 * s.ni + j; }
+VRG_HD uint32_t vrg_slot_B0(const VrgState& s, uint32_t j) { return 2 * s.ni + s.no + j; }
+VRG_HD uint32_t vrg_slot_B1(const VrgState& s, uint32_t e) { return 2 * s.ni + 2 * s.no + e; }
+VRG_HD uint32_t vrg_slot_B2(const VrgState& s, uint32_t j) { return 3 * s.ni + 2 * s.no + j; }
 
-// per old band entry: does it keep its place?  (count segments seg0 / seg3)
-VRG_HD void vrg_item_survivor(const VrgCtx& c, uint32_t e) {
+// per old band entry: survivor test, and for listed flips the density bookkeeping sets (:232-233) and
+// the class histograms
+VRG_HD void vrg_item_entry_post(const VrgCtx& c, uint32_t e) {
     const VrgState& s = *c.st;
     int cur = s.iter & 1;
     uint32_t idx = c.b_idx[cur][e];
-    uint8_t* nxt = c.lab[cur ^ 1];
-    uint8_t nb = nxt[idx];
-    bool inner = e < s.ni;
+    uint8_t* lab = c.lab[0];
+    uint8_t nb = lab[idx];
+    bool inner = e < s.ni, flag = c.e_flag[e] != 0;
+    uint8_t res = c.e_res[e];
+    uint8_t fin = res & FR_FINAL;
+    bool fresh = res & FR_FRESH;
+    uint32_t mask = flag ? c.e_mask[e] : 0u;
+    if (flag) {
+        uint32_t lev = c.b_lev[cur][e];
+        if (!(res & FR_WRITTEN)) c.st->error = 3;             // a listed flip the relabel never visited
+        if (fin == 1) vrg_atomic_add(&c.dIn[lev], 1u);        // innerAdded: listed flips labelled 1 at the end
+        else if (fin == 2) vrg_atomic_add(&c.dOut[lev], 1u);  // outerAdded: ... labelled 2
+        if (inner) { vrg_atomic_add(&c.hin[lev], -1); vrg_atomic_add(&c.hout[lev], 1); }             // flip-out
+        else if (fin <= 1) { vrg_atomic_add(&c.hin[lev], 1); vrg_atomic_add(&c.hout[lev], -1); }     // applied flip-in
+    }
     bool surv;
-    if (inner) surv = !c.e_flag[e] && (nb & VB_LABEL) == (VB_S | VB_B);
-    else {
-        surv = !c.e_flag[e] && (nb & VB_LABEL) == VB_B && !(nb & VB_F);
-        if (nb & VB_F) nxt[idx] = (uint8_t)(nb & ~VB_F);
+    if (inner) {
+        surv = !flag && (nb & VB_LABEL) == (VB_S | VB_B);
+        c.scan[vrg_slot_A0(s, e)] = surv ? 1u : 0u;
+        c.scan[vrg_slot_A1(s, e)] = (uint32_t)__builtin_popcount(mask);
+        c.scan[vrg_slot_B1(s, e)] = (flag && fin == 2 && !fresh) ? 1u : 0u;
+    } else {
+        uint32_t j = e - s.ni;
+        surv = !flag && (nb & VB_LABEL) == VB_B && !(nb & VB_F);
+        if (nb & VB_F) lab[idx] = (uint8_t)(nb & ~VB_F);      // only the S/X/OOB bits are read concurrently (recount)
+        c.scan[vrg_slot_B0(s, j)] = surv ? 1u : 0u;
+        c.scan[vrg_slot_A2(s, j)] = (flag && fin == 1) ? 1u : 0u;
+        c.scan[vrg_slot_B2(s, j)] = (uint32_t)__builtin_popcount(mask);
     }
     c.e_surv[e] = surv;
-    uint32_t nf = s.nf;
-    c.scan[inner ? e : e + nf] = surv ? 1u : 0u;        // seg0 = [0,ni), seg3 = [ni+nf, ni+nf+no)
 }
 
 // density correction of one intensity value (:236-247)
@@ -350,57 +360,49 @@ VRG_HD void vrg_apply_correction(const VrgCtx& c, uint32_t lev, double& ip, doub
     op -= ic; op += oc; op += ac;   // :245-247
 }
 
-// survivors copy themselves to their new position with the incremental correction
-VRG_HD void vrg_item_scatter_surv(const VrgCtx& c, uint32_t e) {
-    if (!c.e_surv[e]) return;
-    const VrgState& s = *c.st;
-    int cur = s.iter & 1, nx = cur ^ 1;
-    bool inner = e < s.ni;
-    uint32_t pos = c.scan[inner ? e : e + s.nf];
-    if (pos >= c.bcap) { c.st->error = 1; return; }
-    uint32_t lev = c.b_lev[cur][e];
-    double ip = c.b_ip[cur][e], op = c.b_op[cur][e];
-    vrg_apply_correction(c, lev, ip, op);
-    c.b_idx[nx][pos] = c.b_idx[cur][e]; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = ip; c.b_op[nx][pos] = op;
-}
-
 VRG_HD void vrg_new_fresh(const VrgCtx& c, int nx, uint32_t pos, uint32_t idx, uint32_t lev) {
     if (pos >= c.bcap) { c.st->error = 1; return; }
     c.b_idx[nx][pos] = idx; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = 0; c.b_op[nx][pos] = 0;
     c.fresh[vrg_atomic_add(&c.st->nfresh, 1u)] = pos;
 }
 
-// per listed flip: its own new entry (carried or fresh) and the entries of the voxels it promoted
-VRG_HD void vrg_item_scatter_flip(const VrgCtx& c, uint32_t r) {
+// per old band entry: survivors and carried flips copy themselves to their new position with the
+// incremental correction; a flip that left the band during the sweep re-enters as a fresh entry
+VRG_HD void vrg_item_scatter_entry(const VrgCtx& c, uint32_t e) {
     const VrgState& s = *c.st;
     int cur = s.iter & 1, nx = cur ^ 1;
-    uint32_t n = s.ni + s.no, nfo = s.nfo, nfi = s.nf - s.nfo;
-    uint32_t e = c.f_entry[r], idx = c.f_idx[r];
-    uint8_t res = c.f_res[r];
-    uint8_t fin = res & FR_FINAL;
-    bool fresh = res & FR_FRESH;
-    uint32_t own, promo;
-    bool has_own;
-    if (r < nfo) { promo = s.ni + r; own = n + nfo + nfi + r; has_own = (fin == 2 && !fresh); }
-    else { uint32_t j = r - nfo; own = s.ni + nfo + j; promo = n + 2 * nfo + nfi + j; has_own = (fin == 1); }
-    if (has_own) {
-        uint32_t pos = c.scan[own];
-        uint32_t lev = c.b_lev[cur][e];
-        if (fresh) vrg_new_fresh(c, nx, pos, idx, lev);
-        else if (pos >= c.bcap) c.st->error = 1;
-        else {
-            double ip = c.b_ip[cur][e], op = c.b_op[cur][e];
-            vrg_apply_correction(c, lev, ip, op);
-            c.b_idx[nx][pos] = idx; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = ip; c.b_op[nx][pos] = op;
-        }
-    }
-    uint32_t mask = c.f_mask[r];
-    uint32_t pos = c.scan[promo];
-    for (int k = 0; k < 27; k++)
-        if (mask & (1u << k)) {
-            uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
-            vrg_new_fresh(c, nx, pos++, m, vrg_level_of(c, (double)c.I[m]));
-        }
+    bool inner = e < s.ni;
+    uint32_t j = e - s.ni;
+    uint32_t pos;
+    bool fresh = false;
+    if (c.e_surv[e]) pos = c.scan[inner ? vrg_slot_A0(s, e) : vrg_slot_B0(s, j)];
+    else if (c.e_flag[e]) {
+        uint8_t res = c.e_res[e];
+        uint8_t fin = res & FR_FINAL;
+        fresh = res & FR_FRESH;
+        if (inner) { if (!(fin == 2 && !fresh)) return; pos = c.scan[vrg_slot_B1(s, e)]; }
+        else { if (fin != 1) return; pos = c.scan[vrg_slot_A2(s, j)]; }
+    } else return;
+    uint32_t lev = c.b_lev[cur][e];
+    if (fresh) { vrg_new_fresh(c, nx, pos, c.b_idx[cur][e], lev); return; }
+    if (pos >= c.bcap) { c.st->error = 1; return; }
+    double ip = c.b_ip[cur][e], op = c.b_op[cur][e];
+    vrg_apply_correction(c, lev, ip, op);
+    c.b_idx[nx][pos] = c.b_idx[cur][e]; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = ip; c.b_op[nx][pos] = op;
+}
+
+// the voxels a listed flip promoted (item k = neighbour k of the flip, :263-282 order): fresh entries
+VRG_HD void vrg_item_scatter_promo(const VrgCtx& c, uint32_t r, uint32_t k) {
+    if (k >= 27) return;
+    const VrgState& s = *c.st;
+    int cur = s.iter & 1, nx = cur ^ 1;
+    uint32_t e = c.flist[r];
+    uint32_t mask = c.e_mask[e];
+    if (!(mask & (1u << k))) return;
+    uint32_t slot = e < s.ni ? vrg_slot_A1(s, e) : vrg_slot_B2(s, e - s.ni);
+    uint32_t pos = c.scan[slot] + (uint32_t)__builtin_popcount(mask & ((1u << k) - 1u));
+    uint32_t m = (uint32_t)((int64_t)c.b_idx[cur][e] + vrg_off(c, (int)k));
+    vrg_new_fresh(c, nx, pos, m, vrg_level_of(c, (double)c.I[m]));
 }
 
 // exact densities over the whole inner / outer regions (:152-155, :252-255), regrouped by level

@@ -31,7 +31,7 @@ enum : uint8_t {
 
 // stop reasons VRG_STOP_* (variationalRegionGrowing.py:91-104,118-121) come from include/vrg.h
 
-// f_res codes written by the sweep for every listed flip (indexed by flip rank)
+// e_res codes written by the relabel for every listed flip
 enum : uint8_t { FR_FINAL = 3, FR_FRESH = 4, FR_WRITTEN = 8 };
 
 struct VrgTrace {            // one record per update() call (0 = init)
@@ -46,12 +46,11 @@ struct VrgState {
     int32_t iterMax;
     int32_t error;       // capacity overflow etc.
     int64_t maxSegmentSize;
-    int64_t n_in, n_out; // region sizes (:51-52, :115-116)
-    double sum_in, sum_out;
     uint32_t ni, no;     // band list lengths (inner list = entries [0,ni), outer = [ni,ni+no))
-    uint32_t nfo, nf;    // flip-outs, all listed flips of the sweep being processed
+    uint32_t nf;         // listed flips of the sweep being processed (atomic count)
     uint32_t npend;      // flip-ins waiting in the skip-rule fix-point
     uint32_t nfresh;     // band entries needing exact densities
+    uint32_t nmk;        // voxels marked for the relabel stencil this sweep
     uint32_t nnz;        // distinct intensity levels touched by this sweep's density corrections
     uint32_t ncnt;       // length of the rebuild count array
     uint32_t ni_new, nb_new;
@@ -62,13 +61,22 @@ struct VrgState {
     int32_t use_tab;     // this sweep's density corrections are memoised per intensity level (tabC)
 };
 
+// results of the dense recount; written by the dense stream only (own allocation, own cache lines)
+struct VrgDense {
+    int64_t n_in, n_out;     // region sizes (:51-52, :115-116)
+    double sum_in, sum_out;  // sums of intensities over the two regions
+};
+
 struct VrgCtx {
     int32_t nx, ny, nz;
     int32_t PX, PY, PZ;
     uint32_t PV;               // PX*PY*PZ
     double H, A;               // kernel A*exp(-0.5*H*d^2) (:7,:10)
     const float* I;            // intensities, padded layout
-    uint8_t* lab[2];           // label bytes, ping-pong by sweep parity
+    uint8_t* lab[2];           // lab[0]: label bytes, updated in place; lab[1]: scratch of the full-stencil check variant
+    uint32_t mcap;             // marked-voxel list: index and new byte
+    uint32_t* mk_idx;
+    uint8_t* mk_new;
     uint64_t* stamp;           // (sweep<<32 | flip rank) of a voxel's last listing; seeds: lex index
     // intensity levels: sorted distinct values and per-class histograms (:149-150, :249-250)
     uint32_t L;
@@ -90,16 +98,14 @@ struct VrgCtx {
     double* b_op[2];
     uint8_t* e_flag;           // per old entry: listed flip
     uint8_t* e_surv;           // per old entry: survives in place
+    uint8_t* e_res;            // per old entry: FR_* result of a listed flip
+    uint32_t* e_mask;          // per old entry: bit k = neighbour k (offset order of get_neighbours :263) promoted by this flip
     uint32_t* lscan;           // per-level scan workspace (length L)
     uint32_t* bsum;            // per-workgroup partials of the device-wide scan
-    uint32_t* scan;            // scan workspace (ranks, then rebuild positions), length >= ni+no+2*nf
-    // per listed flip (index = rank in the flip list)
+    uint32_t* scan;            // rebuild count array / positions, length 3*(ni+no)
     uint32_t fcap;
-    uint32_t* f_entry;
-    uint32_t* f_idx;
-    uint32_t* f_mask;          // bit k: neighbour k (offset order of get_neighbours :263) promoted by this flip
-    uint8_t* f_res;
-    uint32_t* pend;            // flip ranks in the skip-rule fix-point
+    uint32_t* flist;           // entry indices of the listed flips, unordered
+    uint32_t* pend;            // entry indices of the flip-ins in the skip-rule fix-point
     uint32_t* fresh;           // new-band positions needing exact densities
     // dense statistics partials (one slot per sweep workgroup)
     uint32_t nstat;
@@ -107,6 +113,8 @@ struct VrgCtx {
     // init scratch
     uint64_t* init_key; uint32_t* init_idx;
     VrgState* st;
+    VrgDense* dn;
+    uint32_t* counters;        // arrival tickets of the last-workgroup reductions (zero between launches)
     VrgTrace* trace;
     uint32_t trace_cap;
 };

@@ -104,6 +104,8 @@ def main():
     ap.add_argument('--H', type=float, default=2.25)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--variant', type=int, default=0)
+    ap.add_argument('--sweep-blocks', type=int, default=0)
+    ap.add_argument('--prio-mode', type=int, default=-1)
     args = ap.parse_args()
     shape = tuple(int(s) for s in args.shape.lower().split('x'))
     assert len(shape) == 3
@@ -138,6 +140,10 @@ def main():
     V = shape[0] * shape[1] * shape[2]
     s = Session(shape, device=local_rank)
     s.set_option('sweep_variant', args.variant)
+    if args.sweep_blocks:
+        s.set_option('sweep_blocks', args.sweep_blocks)
+    if args.prio_mode >= 0:
+        s.set_option('prio_mode', args.prio_mode)
     s.set_option('events', 1)
     s.set_option('batch', 64)
     s.set_volume_ptr(I.data_ptr(), np.float32, [st for st in I.stride()])

@@ -15,6 +15,7 @@
 #include "../../arterynetwork_amd/csrc/vrg_items.h"
 
 int be_set_device(int) { return 0; }
+void be_set_tuning(const char*, long long) {}
 void* be_alloc(size_t bytes) { return std::malloc(bytes); }
 void be_free(void* p) { std::free(p); }
 void be_fill(void* p, int byte, size_t bytes) { std::memset(p, byte, bytes); }
@@ -117,8 +118,8 @@ static void dense_stats(const VrgCtx& c, const uint8_t* lab) {
         if (o & VB_S) { a++; sa += (double)c.I[idx]; }
         else if (!(o & VB_X)) { b++; sb += (double)c.I[idx]; }
     });
-    VrgState& s = *c.st;
-    s.n_in = a; s.n_out = b; s.sum_in = sa; s.sum_out = sb;
+    VrgDense& d = *c.dn;
+    d.n_in = a; d.n_out = b; d.sum_in = sa; d.sum_out = sb;
 }
 
 void be_init_finish(const VrgCtx& c) {
@@ -129,41 +130,41 @@ void be_init_finish(const VrgCtx& c) {
     for (uint32_t i = 0; i < n; i++) vrg_exact_serial(c, 0, c.fresh[i]);
     dense_stats(c, c.lab[0]);
     s.nfresh = 0;
+    const VrgDense& d = *c.dn;
     VrgTrace& t = c.trace[0];
-    t.nflip = 0; t.nseg = s.n_in; t.n_in = s.n_in; t.n_out = s.n_out; t.ni = s.ni; t.no = s.no;
-    t.sum_in = s.sum_in; t.sum_out = s.sum_out;
+    t.nflip = 0; t.nseg = d.n_in; t.n_in = d.n_in; t.n_out = d.n_out; t.ni = s.ni; t.no = s.no;
+    t.sum_in = d.sum_in; t.sum_out = d.sum_out;
 }
 
 void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*) {
     VrgState& s = *c.st;
     if (s.done) return;
-    int cur = s.iter & 1, nxt = cur ^ 1;
+    int nxt = (s.iter & 1) ^ 1;
     uint32_t n = s.ni + s.no;
     for (uint32_t e = 0; e < n; e++) vrg_item_decide(c, e);
-    uint32_t total = exclusive_scan(c.scan, n);
-    vrg_item_fin_decide(c, total);
-    if (s.done) return;
-    for (uint32_t e = 0; e < n; e++) vrg_item_mark(c, e);
-    for (uint32_t j = 0; j < s.nf - s.nfo; j++) vrg_item_prepass(c, j);
+    if (int32_t stop = vrg_stop_test(c)) { s.done = stop; return; }
+    if (s.error) { s.done = -1; return; }
+    for (uint32_t r = 0; r < s.nf; r++) vrg_item_prepass(c, c.flist[r]);
     for (bool changed = true; changed;) {
         changed = false;
         for (uint32_t j = 0; j < s.npend; j++) changed |= vrg_item_fix(c, j);
     }
-    for (uint32_t r = 0; r < s.nf; r++)
-        if (c.f_idx[r] >= c.PV || (c.lab[cur][c.f_idx[r]] & VB_OOB)) { std::fprintf(stderr, "bad f_idx r=%u idx=%u nf=%u nfo=%u iter=%d ni=%u no=%u\n", r, c.f_idx[r], s.nf, s.nfo, s.iter, s.ni, s.no); std::abort(); }
-    if (variant == 0) for (uint32_t r = 0; r < s.nf; r++) vrg_item_scatter_marks(c, r);
-    // dense sweep: relabel + region statistics
-    const uint8_t* in = c.lab[cur];
-    uint8_t* out = c.lab[nxt];
-    for_real_voxels(c, [&](uint32_t idx, int, int, int) {
-        uint8_t cb = in[idx];
-        bool run = variant == 0 ? (cb & VB_M) != 0 : true;
-        out[idx] = run ? vrg_sweep_core(c, in, idx, cb) : cb;
-    });
-    dense_stats(c, out);
+    const bool full = variant & 1;
+    uint8_t* lab = c.lab[0];
+    if (!full) {
+        // marks -> sparse two-phase relabel, in place
+        for (uint32_t r = 0; r < s.nf; r++) for (uint32_t p = 0; p < 125; p++) vrg_item_scatter_marks(c, r, p);
+        if (s.nmk > c.mcap) { s.error = 4; s.done = -1; return; }
+        for (uint32_t i = 0; i < s.nmk; i++) vrg_item_relabel(c, i);
+        for (uint32_t i = 0; i < s.nmk; i++) vrg_item_apply(c, i);
+    } else {
+        // full-stencil check variant: every voxel, through the scratch volume
+        for_real_voxels(c, [&](uint32_t idx, int, int, int) { c.lab[1][idx] = vrg_sweep_core(c, lab, idx, lab[idx]); });
+        for_real_voxels(c, [&](uint32_t idx, int, int, int) { lab[idx] = c.lab[1][idx]; });
+    }
+    dense_stats(c, lab);          // the dense recount (:113-116)
     // band bookkeeping
-    for (uint32_t r = 0; r < s.nf; r++) vrg_item_flipres(c, r);
-    for (uint32_t e = 0; e < n; e++) vrg_item_survivor(c, e);
+    for (uint32_t e = 0; e < n; e++) vrg_item_entry_post(c, e);
     s.nnz = 0;
     for (uint32_t l = 0; l < c.L; l++) {
         uint32_t a = c.dIn[l], b = c.dOut[l], d = c.dConv[l];
@@ -177,21 +178,24 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*) {
     s.use_tab = c.L <= n;
     if (s.use_tab)
         for (uint32_t l = 0; l < c.L; l++) vrg_corrections(c, c.lev[l], c.tabC[3 * (size_t)l], c.tabC[3 * (size_t)l + 1], c.tabC[3 * (size_t)l + 2]);
-    s.ncnt = n + 2 * s.nf;
+    s.ncnt = 3 * n;
     uint32_t tot = exclusive_scan(c.scan, s.ncnt);
-    s.ni_new = (s.ni + s.nf < s.ncnt) ? c.scan[s.ni + s.nf] : tot;
+    uint32_t b0 = vrg_slot_B0(s, 0);
+    s.ni_new = (b0 < s.ncnt) ? c.scan[b0] : tot;
     s.nb_new = tot;
     if (tot > c.bcap) { s.error = 1; s.done = -1; return; }
-    for (uint32_t e = 0; e < n; e++) vrg_item_scatter_surv(c, e);
-    for (uint32_t r = 0; r < s.nf; r++) vrg_item_scatter_flip(c, r);
+    for (uint32_t e = 0; e < n; e++) vrg_item_scatter_entry(c, e);
+    for (uint32_t r = 0; r < s.nf; r++) for (uint32_t k = 0; k < 27; k++) vrg_item_scatter_promo(c, r, k);
     for (uint32_t i = 0; i < s.nfresh; i++) vrg_exact_serial(c, nxt, c.fresh[i]);
     // iterNum += 1 (:117) and the trace record of this update() call
     s.ni = s.ni_new; s.no = s.nb_new - s.ni_new; s.iter++;
     if ((uint32_t)s.iter < c.trace_cap) {
+        const VrgDense& d = *c.dn;
         VrgTrace& t = c.trace[s.iter];
-        t.nflip = s.nf; t.nseg = s.n_in; t.n_in = s.n_in; t.n_out = s.n_out; t.ni = s.ni; t.no = s.no;
-        t.sum_in = s.sum_in; t.sum_out = s.sum_out;
+        t.nflip = s.nf; t.nseg = d.n_in; t.n_in = d.n_in; t.n_out = d.n_out; t.ni = s.ni; t.no = s.no;
+        t.sum_in = d.sum_in; t.sum_out = d.sum_out;
     }
+    s.nf = 0; s.npend = 0; s.nmk = 0; s.nfresh = 0;
     if (s.error) s.done = -1;
 }
 
@@ -199,7 +203,7 @@ void be_events_collect(VrgEvents*, long long) {}
 
 void be_recount_hist(const VrgCtx& c, int par, int32_t* rin, int32_t* rout) {
     for_real_voxels(c, [&](uint32_t idx, int, int, int) {
-        uint8_t b = c.lab[par][idx];
+        uint8_t b = c.lab[0][idx];
         if (b & VB_X) return;
         uint32_t lev = vrg_level_of(c, (double)c.I[idx]);
         if (b & VB_S) rin[lev]++; else rout[lev]++;
@@ -209,7 +213,7 @@ void be_recount_hist(const VrgCtx& c, int par, int32_t* rin, int32_t* rout) {
 uint32_t be_collect_segmented(const VrgCtx& c, int par, uint64_t* stamps, uint32_t* idxs, uint32_t cap) {
     uint32_t n = 0;
     for_real_voxels(c, [&](uint32_t idx, int, int, int) {
-        if (c.lab[par][idx] & VB_S) { if (n < cap) { stamps[n] = c.stamp[idx]; idxs[n] = idx; } n++; }
+        if (c.lab[0][idx] & VB_S) { if (n < cap) { stamps[n] = c.stamp[idx]; idxs[n] = idx; } n++; }
     });
     return n;
 }
