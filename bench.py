@@ -94,6 +94,21 @@ def load_traffic(shape, n_gpus):
     return None
 
 
+def roofline(V_per_launch, kern_ms, launches, traffic):
+    """Dominant kernel = k_recount (dense region recount, one launch per sweep).  `achieved` uses the
+    ALGORITHMIC 6 B/voxel-iter of SURVEY.md 8(d); the kernel itself moves ~5 B/voxel (labels are updated
+    in place, so the 1 B/voxel label write-back is elided) - `traffic` is the rocprofv3 PMC figure."""
+    achieved = BYTES_PER_VOXEL_ITER * V_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
+    out = {'bound': 'hbm', 'kernel': 'k_recount', 'achieved': round(achieved, 1) if achieved else None,
+           'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+           'kernel_ms_avg': round(kern_ms, 4), 'launches': launches,
+           'algorithmic_bytes_per_launch': BYTES_PER_VOXEL_ITER * V_per_launch, 'traffic': traffic}
+    if traffic and kern_ms > 0:
+        out['traffic_gbs'] = round(traffic / (kern_ms * 1e-3) / 1e9, 1)
+        out['traffic_frac_of_peak'] = round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -163,7 +178,6 @@ def main():
     ms_per_step = dt / max(1, r.sweeps) * 1e3
     value = V * r.sweeps / dt / 1e6
     kern_ms = r.sweep_kernel_ms / max(1, r.sweep_launches)
-    achieved = BYTES_PER_VOXEL_ITER * V / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
     tr = s.trace()
     out = {
         'metric': 'Mvoxel-iters/sec, VRG sweep, {} volume'.format(args.shape), 'value': round(value, 1),
@@ -178,12 +192,7 @@ def main():
                    'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
                    'flips_per_sweep_mean': round(float(tr['nflip'][args.warmup + 1:].mean()), 1),
                    'hbm_gbs_whole_step': round(BYTES_PER_VOXEL_ITER * V / (ms_per_step * 1e-3) / 1e9, 1)},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_sweep<{}>'.format(args.variant),
-                     'achieved': round(achieved, 1) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                     'kernel_ms_avg': round(kern_ms, 4), 'launches': int(r.sweep_launches),
-                     'algorithmic_bytes_per_launch': BYTES_PER_VOXEL_ITER * V,
-                     'traffic': load_traffic(shape, 1)},
+        'roofline': roofline(V, kern_ms, int(r.sweep_launches), load_traffic(shape, 1)),
     }
     if not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(I, vm, args.H)
