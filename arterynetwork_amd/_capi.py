@@ -35,6 +35,9 @@ TRACE_DTYPE = np.dtype([('nflip', 'i8'), ('nseg', 'i8'), ('n_in', 'i8'), ('n_out
                         ('ni', 'i8'), ('no', 'i8'), ('sum_in', 'f8'), ('sum_out', 'f8')])
 
 
+REDUCE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_void_p)
+
+
 class VrgError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__('{} ({}): {}'.format(ERRORS.get(code, 'error'), code, msg))
@@ -69,6 +72,10 @@ class VrgLib:
         self.get_band = fn('get_band', [p, C.c_int, p, p, p, C.c_int64, i64p])
         self.get_trace = fn('get_trace', [p, p, C.c_int64, i64p])
         self.get_levels = fn('get_levels', [p, p, p, p, p, p, C.c_int64, i64p])
+        self.set_slab = fn('set_slab', [p, C.c_int64, C.c_int64])
+        self.comm_unique_id = fn('comm_unique_id', [p])
+        self.comm_init = fn('comm_init', [p, C.c_int, C.c_int, p])
+        self.set_reduce_callback = fn('set_reduce_callback', [p, REDUCE_FN, p])
 
 
 _product = None
@@ -160,6 +167,28 @@ class Session:
     def set_labels_ptr(self, ptr, dtype, strides_elems):
         self._check(self.lib.set_labels(self._h, C.c_void_p(ptr), DTYPE_CODES[np.dtype(dtype)],
                                         (C.c_int64 * 3)(*strides_elems)))
+
+    # ---- multi-GPU ------------------------------------------------------------------------------
+    def set_slab(self, z0, z1):
+        self._check(self.lib.set_slab(self._h, int(z0), int(z1)))
+
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        self._check(self.lib.comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, nranks, rank, id128):
+        buf = C.create_string_buffer(bytes(id128), 128)
+        self._check(self.lib.comm_init(self._h, int(nranks), int(rank), buf))
+
+    def set_reduce_callback(self, fn):
+        """fn(list_of_4_floats) -> list_of_4_floats (global totals); kept alive by the session."""
+        def thunk(ptr, _user):
+            out = fn([ptr[0], ptr[1], ptr[2], ptr[3]])
+            for i in range(4):
+                ptr[i] = float(out[i])
+        self._reduce_thunk = REDUCE_FN(thunk)
+        self._check(self.lib.set_reduce_callback(self._h, self._reduce_thunk, None))
 
     def init(self, H=2.25):
         self._check(self.lib.init(self._h, float(H)))

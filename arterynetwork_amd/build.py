@@ -22,7 +22,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB] + SOURCES
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB] + SOURCES + ['-L/opt/rocm/lib', '-lrccl']
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

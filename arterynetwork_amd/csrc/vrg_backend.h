@@ -34,10 +34,15 @@ int be_build_levels(const VrgCtx& c, double** lev, uint32_t* L);
 // init mode (:129-155): labels by morphology + staged band entries; then order them and finish
 void be_init_band(const VrgCtx& c);
 void be_init_sort(const VrgCtx& c, uint32_t n_in, uint32_t n_out);   // keys -> b_idx[0] in list order
-void be_init_finish(const VrgCtx& c);          // levels of entries, histograms, exact densities, region stats
+typedef void (*be_reduce_fn)(double v[4], void* user);
+void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user);   // levels of entries, histograms, exact densities, region stats
 
 // one trip through the while-loop body (:58-117); a no-op once st->done is set
-void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev);
+void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb, void* user);
+
+// RCCL communicator for the per-sweep all-reduce of the slab statistics (device backend only)
+int be_comm_unique_id(void* id128);
+int be_comm_init(int nranks, int rank, const void* id128);
 
 // fold the HIP-event pairs recorded since the last call into ev (only the first n_valid were real sweeps)
 void be_events_collect(VrgEvents* ev, long long n_valid);

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
+#include <rccl/rccl.h>
 
 #include "vrg_backend.h"
 #include "vrg_items.h"
@@ -41,6 +42,7 @@ hipStream_t g_stream_b = nullptr;    // stream B: band bookkeeping, runs in the 
 hipEvent_t g_ev_a = nullptr, g_ev_b = nullptr;
 int g_sweep_blocks = 0;              // 0 = auto (dense_blocks)
 int g_prio_mode = 0;
+ncclComm_t g_comm = nullptr;          // per-sweep all-reduce of the slab statistics (multi-GPU)
 
 // ---- wave / block primitives (wave = 64 lanes) -------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
@@ -207,7 +209,7 @@ __global__ void k_finalize(VrgCtx c) {                // iterNum += 1 (:117) + t
     if ((uint32_t)s.iter < c.trace_cap) {
         VrgTrace& t = c.trace[s.iter];
         const VrgDense& d = *c.dn;
-        t.nflip = s.nf; t.nseg = d.n_in; t.n_in = d.n_in; t.n_out = d.n_out; t.ni = s.ni; t.no = s.no;
+        t.nflip = s.nf; t.nseg = (int64_t)d.n_in; t.n_in = (int64_t)d.n_in; t.n_out = (int64_t)d.n_out; t.ni = s.ni; t.no = s.no;
         t.sum_in = d.sum_in; t.sum_out = d.sum_out;
     }
     s.nf = 0; s.npend = 0; s.nmk = 0; s.nfresh = 0;
@@ -313,11 +315,13 @@ __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a) {
     if (lane == 0) { sh_n[0][wv] = x; sh_n[1][wv] = y; sh_s[0][wv] = sx; sh_s[1][wv] = sy; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        VrgDense& d = *c.dn;
-        d.n_in = sh_n[0][0] + sh_n[0][1] + sh_n[0][2] + sh_n[0][3];
-        d.n_out = sh_n[1][0] + sh_n[1][1] + sh_n[1][2] + sh_n[1][3];
+        VrgDense d;
+        d.n_in = (double)(sh_n[0][0] + sh_n[0][1] + sh_n[0][2] + sh_n[0][3]);
+        d.n_out = (double)(sh_n[1][0] + sh_n[1][1] + sh_n[1][2] + sh_n[1][3]);
         d.sum_in = ((sh_s[0][0] + sh_s[0][1]) + sh_s[0][2]) + sh_s[0][3];
         d.sum_out = ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3];
+        *c.dn_part = d;                              // slab partials: input of the all-reduce
+        if (c.world == 1) *c.dn = d;
     }
 }
 
@@ -326,8 +330,8 @@ __global__ void __launch_bounds__(TPB) k_recount(VrgCtx c, int check_done) {
     const uint8_t* __restrict__ in = c.lab[0];
     const float* __restrict__ I = c.I;
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
-    const uint32_t first = 2u * plane;
-    const uint32_t total = (uint32_t)c.nz * plane;          // interior bytes, a multiple of 16
+    const uint32_t first = (2u + (uint32_t)c.z0) * plane;   // this device's Z-slab [z0, z1)
+    const uint32_t total = (uint32_t)(c.z1 - c.z0) * plane; // bytes, a multiple of 16
     const uint32_t nfull = total >> 10;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -410,7 +414,7 @@ __global__ void k_fin_init(VrgCtx c) {
     s.nfresh = 0; s.nf = 0; s.npend = 0; s.nmk = 0;
     const VrgDense& d = *c.dn;
     VrgTrace& t = c.trace[0];
-    t.nflip = 0; t.nseg = d.n_in; t.n_in = d.n_in; t.n_out = d.n_out; t.ni = s.ni; t.no = s.no;
+    t.nflip = 0; t.nseg = (int64_t)d.n_in; t.n_in = (int64_t)d.n_in; t.n_out = (int64_t)d.n_out; t.ni = s.ni; t.no = s.no;
     t.sum_in = d.sum_in; t.sum_out = d.sum_out;
 }
 __global__ void k_recount_hist(VrgCtx c, int32_t* rin, int32_t* rout) {
@@ -514,7 +518,7 @@ int voxel_blocks(const VrgCtx& c) {
 // workgroups of the dense recount: >= 32 one-KiB units per wave, at most 2 workgroups per CU
 int dense_blocks(const VrgCtx& c) {
     if (g_sweep_blocks > 0) return g_sweep_blocks;
-    uint64_t units = ((uint64_t)c.nz * c.PY * c.PX) >> 10;
+    uint64_t units = ((uint64_t)(c.z1 - c.z0) * c.PY * c.PX) >> 10;
     return (int)std::min<uint64_t>(SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128));
 }
 
@@ -642,15 +646,41 @@ void be_init_sort(const VrgCtx& c, uint32_t n_in, uint32_t n_out) {
     HIP_CHECK(hipFree(kout)); HIP_CHECK(hipFree(tmp));
 }
 
-void be_init_finish(const VrgCtx& c) {
+// sum the slab statistics over the ranks: RCCL on the stream, or the host callback (synchronises)
+static void reduce_dense(const VrgCtx& c, be_reduce_fn cb, void* user) {
+    if (g_comm) {
+        ncclResult_t r = ncclAllReduce(c.dn_part, c.dn, 4, ncclDouble, ncclSum, g_comm, g_stream);
+        if (r != ncclSuccess) std::fprintf(stderr, "RCCL all-reduce failed: %s\n", ncclGetErrorString(r));
+    } else if (cb) {
+        double v[4];
+        HIP_CHECK(hipMemcpyAsync(v, c.dn_part, sizeof(v), hipMemcpyDeviceToHost, g_stream));
+        HIP_CHECK(hipStreamSynchronize(g_stream));
+        cb(v, user);
+        HIP_CHECK(hipMemcpyAsync(c.dn, v, sizeof(v), hipMemcpyHostToDevice, g_stream));
+        HIP_CHECK(hipStreamSynchronize(g_stream));
+    }
+}
+
+int be_comm_unique_id(void* id128) {
+    static_assert(sizeof(ncclUniqueId) == 128, "id size");
+    return ncclGetUniqueId((ncclUniqueId*)id128) == ncclSuccess ? 0 : -1;
+}
+int be_comm_init(int nranks, int rank, const void* id128) {
+    if (g_comm) { ncclCommDestroy(g_comm); g_comm = nullptr; }
+    ncclUniqueId id; std::memcpy(&id, id128, sizeof(id));
+    return ncclCommInitRank(&g_comm, nranks, id, rank) == ncclSuccess ? 0 : -1;
+}
+
+void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
     k_init_entry<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     k_hist_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
     k_exact<<<1024, TPB, 0, g_stream>>>(c, 0);
     k_recount<<<dense_blocks(c), TPB, 0, g_stream>>>(c, 0);
+    reduce_dense(c, cb, user);
     k_fin_init<<<1, 1, 0, g_stream>>>(c);
 }
 
-void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev) {
+void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb, void* user) {
     const bool full = variant & 1;
     const int blocks = dense_blocks(c);
     // stream A: decide + flip list, marks + prepass, skip-rule fix-point, sparse relabel
@@ -688,6 +718,7 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev) {
     }
     k_recount<<<blocks, TPB, 0, g_stream>>>(c, 1);
     if (p) HIP_CHECK(hipEventRecord(p->b, g_stream));
+    reduce_dense(c, cb, user);
     // join
     HIP_CHECK(hipStreamWaitEvent(g_stream, g_ev_b, 0));
     k_finalize<<<1, 1, 0, g_stream>>>(c);

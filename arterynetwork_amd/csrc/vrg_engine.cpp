@@ -32,6 +32,8 @@ struct vrg_handle {
     std::chrono::steady_clock::time_point t0;
     int64_t V = 0;
     uint8_t* lab_base[2] = {nullptr, nullptr};
+    vrg_reduce_fn reduce_fn = nullptr;
+    void* reduce_user = nullptr;
 };
 
 extern "C" void API(destroy)(vrg_handle* h);
@@ -83,6 +85,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.nx = (int32_t)nx; c.ny = (int32_t)ny; c.nz = (int32_t)nz;
     c.PX = (int32_t)PX; c.PY = (int32_t)PY; c.PZ = (int32_t)PZ;
     c.PV = (uint32_t)(PX * PY * PZ);
+    c.z0 = 0; c.z1 = (int32_t)nz;
     h->V = nx * ny * nz;
     c.I = alloc<float>(h, c.PV);
     // 16 guard bytes in front: voxel (0,0,0)'s 2-ring reaches 2 bytes before the padded array
@@ -94,12 +97,15 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.st = alloc<VrgState>(h, 1);
     c.dn = alloc<VrgDense>(h, 16);                   // own allocation: written by the dense kernel only
     c.counters = alloc<uint32_t>(h, 64);
-    if (!c.I || !c.lab[0] || !c.lab[1] || !c.stamp || !c.st || !c.dn || !c.counters) { API(destroy)(h); return VRG_E_MEM; }
+    c.dn_part = alloc<VrgDense>(h, 16);
+    c.world = 1;
+    if (!c.I || !c.lab[0] || !c.lab[1] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part) { API(destroy)(h); return VRG_E_MEM; }
     be_fill((void*)c.I, 0, (size_t)c.PV * 4);
     be_fill(h->lab_base[0], VB_OOB, (size_t)c.PV + 32);
     be_fill(h->lab_base[1], VB_OOB, (size_t)c.PV + 32);
     be_fill(c.st, 0, sizeof(VrgState));
     be_fill(c.dn, 0, sizeof(VrgDense));
+    be_fill(c.dn_part, 0, sizeof(VrgDense));
     be_fill(c.counters, 0, 64 * sizeof(uint32_t));
     *out = h;
     return VRG_OK;
@@ -214,7 +220,7 @@ int API(init)(vrg_handle* h, double H) {
     be_init_sort(c, s.ninit_in, s.ninit_out);
     s.ni = s.ninit_in; s.no = s.ninit_out; s.nfresh = s.ni + s.no;
     put_state(h, s);
-    be_init_finish(c);
+    be_init_finish(c, h->reduce_fn, h->reduce_user);
     s = get_state(h);
     int rc = check_state_error(h, s);
     if (rc) return rc;
@@ -241,7 +247,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
         int64_t remaining = iterMax - s.iter;
         int nb = (int)std::min<int64_t>(h->batch, std::max<int64_t>(remaining, 0) + 1);   // +1: the trip that sets the stop flag
         int32_t before = s.iter;
-        for (int i = 0; i < nb; i++) be_sweep_once(c, h->variant, &h->ev);
+        for (int i = 0; i < nb; i++) be_sweep_once(c, h->variant, &h->ev, h->reduce_fn, h->reduce_user);
         s = get_state(h);
         be_events_collect(&h->ev, s.iter - before);
         if (s.done || s.error) break;
@@ -257,7 +263,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     if (out) {
         out->stop_reason = s.done; out->iter_num = s.iter + 1; out->sweeps = s.iter - iter0;
         VrgDense d = get_dense(h);
-        out->nseg = d.n_in; out->n_in = d.n_in; out->n_out = d.n_out; out->ni = s.ni; out->no = s.no;
+        out->nseg = (int64_t)d.n_in; out->n_in = (int64_t)d.n_in; out->n_out = (int64_t)d.n_out; out->ni = s.ni; out->no = s.no;
         out->sum_in = d.sum_in; out->sum_out = d.sum_out; out->seconds = secs;
         out->sweep_kernel_ms = h->ev.ms_total - ms0; out->sweep_launches = h->ev.launches - l0;
     }
@@ -273,14 +279,14 @@ int API(get_labels)(vrg_handle* h, void* outp, int dtype, const int64_t st[3]) {
 int API(get_segmented)(vrg_handle* h, int64_t* coords, int64_t cap, int64_t* n) {
     if (!h || !n) return VRG_E_ARG;
     if (!h->inited) return fail(h, VRG_E_STATE, "get_segmented: not initialised");
-    VrgDense d = get_dense(h);
-    *n = d.n_in;
+    int64_t nseg = (int64_t)get_dense(h).n_in;
+    *n = nseg;
     if (!coords) return VRG_OK;
-    if (cap < d.n_in) return fail(h, VRG_E_ARG, "get_segmented: buffer too small");
-    std::vector<uint64_t> stamps((size_t)d.n_in + 1);
-    std::vector<uint32_t> idxs((size_t)d.n_in + 1);
-    uint32_t got = be_collect_segmented(h->c, 0, stamps.data(), idxs.data(), (uint32_t)d.n_in);
-    if ((int64_t)got != d.n_in) return fail(h, VRG_E_INTERNAL, "get_segmented: count mismatch");
+    if (cap < nseg) return fail(h, VRG_E_ARG, "get_segmented: buffer too small");
+    std::vector<uint64_t> stamps((size_t)nseg + 1);
+    std::vector<uint32_t> idxs((size_t)nseg + 1);
+    uint32_t got = be_collect_segmented(h->c, 0, stamps.data(), idxs.data(), (uint32_t)nseg);
+    if ((int64_t)got != nseg) return fail(h, VRG_E_INTERNAL, "get_segmented: count mismatch");
     std::vector<uint32_t> order(got);
     for (uint32_t i = 0; i < got; i++) order[i] = i;
     // list order of segmentedList: seeds in np.where order (:44), then appended per applied flip-in (:200)
@@ -340,6 +346,30 @@ int API(get_levels)(vrg_handle* h, double* values, int32_t* hin, int32_t* hout, 
         be_download(rin, di, (size_t)L * 4); be_download(rout, dout, (size_t)L * 4);
         be_free(di); be_free(dout);
     }
+    return VRG_OK;
+}
+
+int API(set_slab)(vrg_handle* h, int64_t z0, int64_t z1) {
+    if (!h) return VRG_E_ARG;
+    if (z0 < 0 || z1 > h->c.nz || z0 >= z1) return fail(h, VRG_E_ARG, "set_slab: need 0 <= z0 < z1 <= nz");
+    if (h->inited) return fail(h, VRG_E_STATE, "set_slab: call before vrg_init");
+    h->c.z0 = (int32_t)z0; h->c.z1 = (int32_t)z1;
+    return VRG_OK;
+}
+
+int API(comm_unique_id)(void* id128) { return (id128 && be_comm_unique_id(id128) == 0) ? VRG_OK : VRG_E_INTERNAL; }
+
+int API(comm_init)(vrg_handle* h, int nranks, int rank, const void* id128) {
+    if (!h || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, VRG_E_ARG, "comm_init: bad argument");
+    if (be_comm_init(nranks, rank, id128) != 0) return fail(h, VRG_E_INTERNAL, "comm_init: RCCL communicator could not be created");
+    h->c.world = nranks;
+    return VRG_OK;
+}
+
+int API(set_reduce_callback)(vrg_handle* h, vrg_reduce_fn fn, void* user) {
+    if (!h) return VRG_E_ARG;
+    h->reduce_fn = fn; h->reduce_user = user;
+    if (fn) h->c.world = 2;                          // partials go through the reduction (any value > 1)
     return VRG_OK;
 }
 

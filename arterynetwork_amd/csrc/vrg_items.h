@@ -94,15 +94,15 @@ VRG_HD void vrg_item_decide(const VrgCtx& c, uint32_t e) {
     VrgState& s = *c.st;
     if (s.iter >= s.iterMax) return;                      // while iterNum <= iterMax (:58)
     int cur = s.iter & 1;
-    double inN = c.b_ip[cur][e] / (double)c.dn->n_in;     // :81
-    double outN = c.b_op[cur][e] / (double)c.dn->n_out;   // :82
+    double inN = c.b_ip[cur][e] / c.dn->n_in;             // :81
+    double outN = c.b_op[cur][e] / c.dn->n_out;           // :82
     bool ge = inN >= outN;
     bool inner = e < s.ni;
     bool flip = inner != ge;                              // :87 xor(segmentedMap, inner >= outer)
     c.e_flag[e] = flip ? 1 : 0; c.e_res[e] = 0; c.e_mask[e] = 0;
     if (!flip) return;
     uint32_t q = vrg_atomic_add(&s.nf, 1u);
-    if (c.dn->n_in >= s.maxSegmentSize) return;           // :101 fires before update(): count only
+    if (c.dn->n_in >= (double)s.maxSegmentSize) return;   // :101 fires before update(): count only
     if (q >= c.fcap) { s.error = 2; return; }
     c.flist[q] = e;
     uint32_t idx = c.b_idx[cur][e];
@@ -115,7 +115,7 @@ VRG_HD int32_t vrg_stop_test(const VrgCtx& c) {
     const VrgState& s = *c.st;
     if (s.iter >= s.iterMax) return VRG_STOP_ITERMAX;                    // :58
     if (s.nf == 0) return VRG_STOP_CONVERGED;                            // :91
-    if (c.dn->n_in >= s.maxSegmentSize) return VRG_STOP_SIZE;            // :101
+    if (c.dn->n_in >= (double)s.maxSegmentSize) return VRG_STOP_SIZE;    // :101
     return 0;
 }
 

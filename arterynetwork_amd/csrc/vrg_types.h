@@ -62,14 +62,15 @@ struct VrgState {
 };
 
 // results of the dense recount; written by the dense stream only (own allocation, own cache lines)
-struct VrgDense {
-    int64_t n_in, n_out;     // region sizes (:51-52, :115-116)
+struct VrgDense {            // all four as double so one all-reduce sums them over the Z-slabs (counts < 2^53: exact)
+    double n_in, n_out;      // region sizes (:51-52, :115-116)
     double sum_in, sum_out;  // sums of intensities over the two regions
 };
 
 struct VrgCtx {
     int32_t nx, ny, nz;
     int32_t PX, PY, PZ;
+    int32_t z0, z1;            // Z-slab [z0, z1) this device recounts (whole volume on one GPU)
     uint32_t PV;               // PX*PY*PZ
     double H, A;               // kernel A*exp(-0.5*H*d^2) (:7,:10)
     const float* I;            // intensities, padded layout
@@ -113,7 +114,9 @@ struct VrgCtx {
     // init scratch
     uint64_t* init_key; uint32_t* init_idx;
     VrgState* st;
-    VrgDense* dn;
+    VrgDense* dn;              // global region statistics (sum over all Z-slabs)
+    VrgDense* dn_part;         // this device's slab partials (input of the all-reduce)
+    int32_t world;             // number of slabs / ranks (1: dn is written directly)
     uint32_t* counters;        // arrival tickets of the last-workgroup reductions (zero between launches)
     VrgTrace* trace;
     uint32_t trace_cap;

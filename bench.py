@@ -121,6 +121,7 @@ def main():
     ap.add_argument('--variant', type=int, default=0)
     ap.add_argument('--sweep-blocks', type=int, default=0)
     ap.add_argument('--prio-mode', type=int, default=-1)
+    ap.add_argument('--force-dist', action='store_true', help='use the N>1 code path (RCCL comm) even with one rank')
     args = ap.parse_args()
     shape = tuple(int(s) for s in args.shape.lower().split('x'))
     assert len(shape) == 3
@@ -138,9 +139,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         from arterynetwork_amd import slabs
+        if 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=dev)
         out = slabs.bench_slabs(shape, args, dev, rank, world)
         if rank == 0:

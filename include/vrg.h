@@ -96,6 +96,21 @@ int vrg_get_trace(vrg_handle* h, vrg_trace_rec* out, int64_t cap, int64_t* n);
 int vrg_get_levels(vrg_handle* h, double* values, int32_t* hist_in, int32_t* hist_out,
                    int32_t* recount_in, int32_t* recount_out, int64_t cap, int64_t* n);
 
+/* ---- multi-GPU (one process per GPU) --------------------------------------------------
+ * Every rank holds the label volume and applies the O(band) relabel identically (it is deterministic),
+ * so no label halo has to travel; the O(V) per-sweep work - the dense region recount - is cut into
+ * Z-slabs: this handle recounts planes [z0, z1) only and the partial region statistics are summed over
+ * the ranks once per sweep, either by RCCL on the device stream (vrg_comm_init) or by a host callback. */
+int vrg_set_slab(vrg_handle* h, int64_t z0, int64_t z1);
+/* RCCL: rank 0 obtains a 128-byte id and the caller broadcasts it (e.g. torch.distributed); every rank
+ * then calls vrg_comm_init (collective). */
+int vrg_comm_unique_id(void* id128);
+int vrg_comm_init(vrg_handle* h, int nranks, int rank, const void* id128);
+/* Host-side alternative: fn turns the local partials {n_in, n_out, sum_in, sum_out} into global totals
+ * in place; called once per sweep (and once by vrg_init).  Costs a host synchronisation per sweep. */
+typedef void (*vrg_reduce_fn)(double partial_to_total[4], void* user);
+int vrg_set_reduce_callback(vrg_handle* h, vrg_reduce_fn fn, void* user);
+
 #ifdef __cplusplus
 }
 #endif

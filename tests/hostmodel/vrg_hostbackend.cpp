@@ -111,32 +111,39 @@ void be_init_sort(const VrgCtx& c, uint32_t n_in, uint32_t n_out) {
     for (uint32_t i = 0; i < n_out; i++) c.b_idx[0][n_in + i] = b[i].second;
 }
 
-static void dense_stats(const VrgCtx& c, const uint8_t* lab) {
+// the dense recount over this handle's Z-slab, then the sum over the slabs (callback) if there are several
+static void dense_stats(const VrgCtx& c, const uint8_t* lab, be_reduce_fn cb, void* user) {
     int64_t a = 0, b = 0; double sa = 0, sb = 0;
-    for_real_voxels(c, [&](uint32_t idx, int, int, int) {
+    for_real_voxels(c, [&](uint32_t idx, int, int, int z) {
+        if (z < c.z0 || z >= c.z1) return;
         uint8_t o = lab[idx];
         if (o & VB_S) { a++; sa += (double)c.I[idx]; }
         else if (!(o & VB_X)) { b++; sb += (double)c.I[idx]; }
     });
-    VrgDense& d = *c.dn;
-    d.n_in = a; d.n_out = b; d.sum_in = sa; d.sum_out = sb;
+    VrgDense& p = *c.dn_part;
+    p.n_in = (double)a; p.n_out = (double)b; p.sum_in = sa; p.sum_out = sb;
+    *c.dn = p;
+    if (cb) cb(&c.dn->n_in, user);
 }
 
-void be_init_finish(const VrgCtx& c) {
+void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
     VrgState& s = *c.st;
     uint32_t n = s.ni + s.no;
     for (uint32_t e = 0; e < n; e++) vrg_item_init_entry(c, e);
     for_real_voxels(c, [&](uint32_t idx, int, int, int) { vrg_item_hist_voxel(c, idx); });
     for (uint32_t i = 0; i < n; i++) vrg_exact_serial(c, 0, c.fresh[i]);
-    dense_stats(c, c.lab[0]);
+    dense_stats(c, c.lab[0], cb, user);
     s.nfresh = 0;
     const VrgDense& d = *c.dn;
     VrgTrace& t = c.trace[0];
-    t.nflip = 0; t.nseg = d.n_in; t.n_in = d.n_in; t.n_out = d.n_out; t.ni = s.ni; t.no = s.no;
+    t.nflip = 0; t.nseg = (int64_t)d.n_in; t.n_in = (int64_t)d.n_in; t.n_out = (int64_t)d.n_out; t.ni = s.ni; t.no = s.no;
     t.sum_in = d.sum_in; t.sum_out = d.sum_out;
 }
 
-void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*) {
+int be_comm_unique_id(void*) { return -1; }
+int be_comm_init(int, int, const void*) { return -1; }
+
+void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*, be_reduce_fn cb, void* user) {
     VrgState& s = *c.st;
     if (s.done) return;
     int nxt = (s.iter & 1) ^ 1;
@@ -162,7 +169,7 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*) {
         for_real_voxels(c, [&](uint32_t idx, int, int, int) { c.lab[1][idx] = vrg_sweep_core(c, lab, idx, lab[idx]); });
         for_real_voxels(c, [&](uint32_t idx, int, int, int) { lab[idx] = c.lab[1][idx]; });
     }
-    dense_stats(c, lab);          // the dense recount (:113-116)
+    dense_stats(c, lab, cb, user);          // the dense recount (:113-116)
     // band bookkeeping
     for (uint32_t e = 0; e < n; e++) vrg_item_entry_post(c, e);
     s.nnz = 0;
@@ -192,7 +199,7 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*) {
     if ((uint32_t)s.iter < c.trace_cap) {
         const VrgDense& d = *c.dn;
         VrgTrace& t = c.trace[s.iter];
-        t.nflip = s.nf; t.nseg = d.n_in; t.n_in = d.n_in; t.n_out = d.n_out; t.ni = s.ni; t.no = s.no;
+        t.nflip = s.nf; t.nseg = (int64_t)d.n_in; t.n_in = (int64_t)d.n_in; t.n_out = (int64_t)d.n_out; t.ni = s.ni; t.no = s.no;
         t.sum_in = d.sum_in; t.sum_out = d.sum_out;
     }
     s.nf = 0; s.npend = 0; s.nmk = 0; s.nfresh = 0;

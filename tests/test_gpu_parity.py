@@ -200,3 +200,62 @@ def test_config2_size_properties(lib):
         for x, y in zip(s.band(w), s2.band(w)):
             assert np.array_equal(x, y)
     s.close(); s2.close()
+
+
+def _gpu_slab_worker(rank, world, port, sweeps, outdir):
+    import os, sys
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from arterynetwork_amd import slabs, phantoms
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    data, vmap = phantoms.tube_phantom(shape=(96, 64, 40), radius=3.0, seed=4, seed_planes=3, amp_y=10.0, amp_z=5.0,
+                                       levels=32, brain_mask=True)
+    s = slabs.make_slab_session(data.shape, rank, world, device=0, reduce='callback')   # both ranks share GPU 0
+    s.set_volume(data); s.set_labels(vmap); s.init(2.25)
+    s.run(sweeps, 10 ** 9, None)
+    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), labels=s.labels(), seg=s.segmented(), tr=s.trace())
+    s.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zslabs_two_processes_one_gpu(lib, tmp_path):
+    """Z-slab driver with two ranks (sharing the one GPU of the box; host-callback reduction over gloo)."""
+    import torch.multiprocessing as mp
+    from test_slabs_gloo import free_port
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session
+    sweeps = 25
+    data, vmap = phantoms.tube_phantom(shape=(96, 64, 40), radius=3.0, seed=4, seed_planes=3, amp_y=10.0, amp_z=5.0,
+                                       levels=32, brain_mask=True)
+    s = Session(data.shape, lib=lib)
+    s.set_volume(data); s.set_labels(vmap); s.init(2.25)
+    s.run(sweeps, 10 ** 9, None)
+    ref = (s.labels(), s.segmented(), s.trace())
+    s.close()
+    mp.spawn(_gpu_slab_worker, args=(2, free_port(), sweeps, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        z = np.load(str(tmp_path / ('rank%d.npz' % r)))
+        assert np.array_equal(z['labels'], ref[0]) and np.array_equal(z['seg'], ref[1])
+        for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no'):
+            assert np.array_equal(z['tr'][f], ref[2][f]), f
+
+
+def test_rccl_single_rank_comm(lib):
+    """The RCCL path (communicator + on-stream all-reduce) with a one-rank communicator."""
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session
+    data, vmap = phantoms.scattered_seeds()
+    outs = []
+    for use_comm in (False, True):
+        s = Session(data.shape, lib=lib)
+        if use_comm:
+            s.comm_init(1, 0, s.comm_unique_id())
+        s.set_volume(data); s.set_labels(vmap); s.init(2.25)
+        s.run(12, 10 ** 9, None)
+        outs.append((s.labels(), s.segmented(), s.trace()))
+        s.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2].tobytes() == outs[1][2].tobytes()
