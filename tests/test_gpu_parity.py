@@ -259,3 +259,25 @@ def test_rccl_single_rank_comm(lib):
         s.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert outs[0][2].tobytes() == outs[1][2].tobytes()
+
+
+def test_refine_nifti_in_nifti_out(tmp_path):
+    """File-level drop-in: stage-1 NIfTI files in, refined uint8 mask out, equal to the oracle's segmentedMap."""
+    from arterynetwork_amd import nifti, phantoms
+    from arterynetwork_amd.refine import refine, build_value_map
+    from oracle import vrg_oracle as O
+    data, vmap = phantoms.tube_phantom(shape=(64, 48, 32), radius=3.0, seed=6, seed_planes=4, amp_y=8.0, amp_z=4.0,
+                                       levels=32, brain_mask=True, dtype=np.float32)
+    aff = np.array([[0.4, 0, 0, -20.0], [0, 0.4, 0, -15.0], [0, 0, 0.5, 3.0], [0, 0, 0, 1.0]])
+    nifti.saveVolume(data, aff, str(tmp_path / 'brainVolume.nii.gz'), astype=np.float32)
+    nifti.saveVolume(vmap == 0, aff, str(tmp_path / 'vesselVolumeMask.nii.gz'))
+    nifti.saveVolume(vmap != 4, aff, str(tmp_path / 'brainVolumeMask.nii.gz'))
+    seg, segMap, vm = refine(str(tmp_path), iterMax=30, quiet=True)
+    out, aff2 = nifti.loadVolume(str(tmp_path), 'vesselVolumeMaskRefined.nii.gz')
+    assert out.dtype == np.uint8 and np.allclose(aff2, aff, atol=1e-6)
+    vm_o = build_value_map(data, vmap == 0, vmap != 4).astype(np.int64)
+    assert np.array_equal(vm_o, vmap)
+    seg_o, segMap_o, _ = O.variationalRegionGrowing(data.astype(np.float64), vm_o, maxSegmentSize=data.size + 1,
+                                                    iterMax=30, maxTime=-1.0, density_mode=1, quiet=True)
+    assert np.array_equal(out, segMap_o) and np.array_equal(seg, seg_o) and np.array_equal(vm, vm_o)
+    assert out.sum() > (vmap == 0).sum()
