@@ -406,6 +406,39 @@ __global__ void k_init_voxel(VrgCtx c) {
 __global__ void k_hist_voxel(VrgCtx c) {
     VOXEL_LOOP(c) { int x, y, z; vrg_item_hist_voxel(c, real_idx(c, t, x, y, z)); }
 }
+// same, for level tables that fit LDS: per-workgroup private histograms (the level values too), streamed
+// over the padded interior 16 bytes per lane, flushed with one global atomic per non-zero bin.
+constexpr uint32_t HIST_LDS_LEVELS = 4096;
+__global__ void __launch_bounds__(TPB) k_hist_lds(VrgCtx c) {
+    __shared__ float s_lev[HIST_LDS_LEVELS];
+    __shared__ uint32_t s_h[2][HIST_LDS_LEVELS];
+    const uint32_t L = c.L;
+    for (uint32_t i = threadIdx.x; i < L; i += TPB) { s_lev[i] = (float)c.lev[i]; s_h[0][i] = 0; s_h[1][i] = 0; }
+    __syncthreads();
+    const uint8_t* __restrict__ in = c.lab[0];
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX, first = 2u * plane;
+    const uint32_t ndw = (uint32_t)(((uint64_t)c.nz * plane) >> 2);
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < ndw; d += gridDim.x * blockDim.x) {
+        const uint32_t base = first + (d << 2);
+        uint32_t v = *reinterpret_cast<const uint32_t*>(in + base);
+        if ((v & 0x24242424u) == 0x24242424u) continue;          // all four excluded or padding
+        const float4 f = *reinterpret_cast<const float4*>(c.I + base);
+        const float fv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            uint8_t cb = (uint8_t)(v >> (8 * b));
+            if (cb & (VB_OOB | VB_X)) continue;
+            uint32_t lo = 0, hi = L - 1;
+            while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (s_lev[m] < fv[b]) lo = m + 1; else hi = m; }
+            atomicAdd(&s_h[(cb & VB_S) ? 0 : 1][lo], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < L; i += TPB) {
+        if (s_h[0][i]) atomicAdd(&c.hin[i], (int32_t)s_h[0][i]);
+        if (s_h[1][i]) atomicAdd(&c.hout[i], (int32_t)s_h[1][i]);
+    }
+}
 __global__ void k_init_entry(VrgCtx c) {
     ITEM_LOOP(c.st->ni + c.st->no) vrg_item_init_entry(c, i);
 }
@@ -673,7 +706,8 @@ int be_comm_init(int nranks, int rank, const void* id128) {
 
 void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
     k_init_entry<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    k_hist_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
+    if (c.L <= HIST_LDS_LEVELS) k_hist_lds<<<1024, TPB, 0, g_stream>>>(c);
+    else k_hist_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
     k_exact<<<1024, TPB, 0, g_stream>>>(c, 0);
     k_recount<<<dense_blocks(c), TPB, 0, g_stream>>>(c, 0);
     reduce_dense(c, cb, user);
