@@ -238,7 +238,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     int rc = check_state_error(h, s);
     if (rc) return rc;
     int32_t iter0 = s.iter;
-    s.done = 0; s.iterMax = (int32_t)iterMax; s.maxSegmentSize = maxSegmentSize;
+    s.done = 0; s.time_up = 0; s.iterMax = (int32_t)iterMax; s.maxSegmentSize = maxSegmentSize;
     s.nf = 0; s.npend = 0; s.nmk = 0; s.nfresh = 0;      // counters of a trip that stopped before update()
     put_state(h, s);
     double ms0 = h->ev.ms_total; long long l0 = h->ev.launches;
@@ -246,15 +246,15 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     for (;;) {
         int64_t remaining = iterMax - s.iter;
         int nb = (int)std::min<int64_t>(h->batch, std::max<int64_t>(remaining, 0) + 1);   // +1: the trip that sets the stop flag
+        if (maxSeconds >= 0 && s.iter < iterMax) {   // wall-clock cap (:97): tested after the no-flip test, before update()
+            double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->t0).count();
+            if (el >= maxSeconds) { s.time_up = 1; put_state(h, s); nb = 1; }
+        }
         int32_t before = s.iter;
         for (int i = 0; i < nb; i++) be_sweep_once(c, h->variant, &h->ev, h->reduce_fn, h->reduce_user);
         s = get_state(h);
         be_events_collect(&h->ev, s.iter - before);
         if (s.done || s.error) break;
-        if (maxSeconds >= 0) {                       // wall-clock cap (:97), checked between batches
-            double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->t0).count();
-            if (el >= maxSeconds) { s.done = VRG_STOP_TIME; put_state(h, s); break; }
-        }
     }
     be_sync();
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();

@@ -102,7 +102,7 @@ VRG_HD void vrg_item_decide(const VrgCtx& c, uint32_t e) {
     c.e_flag[e] = flip ? 1 : 0; c.e_res[e] = 0; c.e_mask[e] = 0;
     if (!flip) return;
     uint32_t q = vrg_atomic_add(&s.nf, 1u);
-    if (c.dn->n_in >= (double)s.maxSegmentSize) return;   // :101 fires before update(): count only
+    if (s.time_up || c.dn->n_in >= (double)s.maxSegmentSize) return;   // :97 / :101 fire before update(): count only
     if (q >= c.fcap) { s.error = 2; return; }
     c.flist[q] = e;
     uint32_t idx = c.b_idx[cur][e];
@@ -110,11 +110,12 @@ VRG_HD void vrg_item_decide(const VrgCtx& c, uint32_t e) {
     c.stamp[idx] = ((uint64_t)(uint32_t)(s.iter + 1) << 32) | e;
 }
 
-// the stop tests in the reference's order, once every entry has decided (time cap :97 is host side)
+// the stop tests in the reference's order, once every entry has decided (the host raises time_up)
 VRG_HD int32_t vrg_stop_test(const VrgCtx& c) {
     const VrgState& s = *c.st;
     if (s.iter >= s.iterMax) return VRG_STOP_ITERMAX;                    // :58
     if (s.nf == 0) return VRG_STOP_CONVERGED;                            // :91
+    if (s.time_up) return VRG_STOP_TIME;                                 // :97
     if (c.dn->n_in >= (double)s.maxSegmentSize) return VRG_STOP_SIZE;    // :101
     return 0;
 }

@@ -45,6 +45,7 @@ struct VrgState {
     int32_t done;        // stop reason, 0 while running
     int32_t iterMax;
     int32_t error;       // capacity overflow etc.
+    int32_t time_up;     // host: wall-clock cap reached (:97) - the next trip only decides and stops
     int64_t maxSegmentSize;
     uint32_t ni, no;     // band list lengths (inner list = entries [0,ni), outer = [ni,ni+no))
     uint32_t nf;         // listed flips of the sweep being processed (atomic count)

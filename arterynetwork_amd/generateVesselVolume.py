@@ -1,0 +1,122 @@
+"""MI355X-native counterparts of the voxel passes in the reference's Code/generateVesselVolume.py
+(stage 1: vessel mask generation) - SURVEY.md section 8 row f2, plus the EDT that
+manualCorrectionGUI.py:248 uses for vessel radii (row f4).
+
+Same function names and return conventions as the reference where it has functions
+(`labelVolume`, `maskVolume`, `loadVolume`, `saveVolume`); the body of its `main()` (:177-199) is
+exposed as `vesselVolumeMask(...)`.  The work runs in HIP kernels behind include/vmask.h; no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._capi import product_lib, VrgError
+from .nifti import loadVolume, saveVolume  # noqa: F401  (same names as the reference module exports)
+
+_bound = None
+
+
+def _lib():
+    global _bound
+    if _bound is None:
+        dll = product_lib().dll
+        p, i64 = C.c_void_p, C.c_int64
+        dll.vmask_edt.argtypes = [C.c_int, p, i64, i64, i64, p]
+        dll.vmask_label.argtypes = [C.c_int, p, i64, i64, i64, C.c_int, p, p, i64, C.POINTER(i64)]
+        dll.vmask_vessel_mask.argtypes = [C.c_int, p, p, C.c_int, i64, i64, i64, C.c_double, C.c_double, C.c_double,
+                                          i64, p, C.POINTER(i64)]
+        dll.vmask_last_error.restype = C.c_char_p
+        _bound = dll
+    return _bound
+
+
+def _check(rc):
+    if rc != 0:
+        raise VrgError(rc, _lib().vmask_last_error().decode())
+
+
+def _u8c(a):
+    a = np.asarray(a)
+    if a.ndim != 3:
+        raise ValueError('expected a 3-D volume')
+    return np.ascontiguousarray(a != 0, dtype=np.uint8)
+
+
+def distance_transform_edt(mask, device=0):
+    """scipy.ndimage.distance_transform_edt(mask) with unit sampling (generateVesselVolume.py:183,
+    manualCorrectionGUI.py:248): float64 distance of every non-zero voxel to the nearest zero voxel."""
+    m = _u8c(mask)
+    out = np.empty(m.shape, np.float64)
+    _check(_lib().vmask_edt(device, m.ctypes.data, *m.shape, out.ctypes.data))
+    return out
+
+
+def labelVolume(volume, minSize=1, maxHop=3, device=0):
+    """
+    Partition the volume into connected components and attach labels (generateVesselVolume.py:107-136).
+
+    Returns
+    -------
+    labeled : ndarray
+        0 = background, components 1..n numbered in raster order of their first voxel (as
+        skimage.measure.label(volume, connectivity=maxHop) numbers them).
+    labelResult : list
+        [(label, size), ...] for every label present, background included, exactly like
+        np.bincount(labeled.ravel()) filtered to non-zero counts (:131-134).  `minSize` is accepted and
+        unused, as in the reference.
+    """
+    v = _u8c(volume)
+    labeled = np.empty(v.shape, np.int32)
+    n = C.c_int64()
+    cap = max(1, v.size // 2 + 1)
+    sizes = np.empty(cap, np.int64)
+    _check(_lib().vmask_label(device, v.ctypes.data, *v.shape, int(maxHop), labeled.ctypes.data, sizes.ctypes.data,
+                              cap, C.byref(n)))
+    ncomp = n.value
+    labelResult = []
+    nbg = int(v.size - sizes[:ncomp].sum())
+    if nbg:
+        labelResult.append((0, nbg))
+    labelResult.extend((k + 1, int(sizes[k])) for k in range(ncomp))
+    return labeled.astype(np.int64), labelResult
+
+
+def maskVolume(volume, mask):
+    """Apply the given volume mask to the given volume (generateVesselVolume.py:86-105)."""
+    newVolume = np.array(volume, copy=True)
+    newVolume[np.asarray(mask) == 0] = 0
+    return newVolume
+
+
+def vesselVolumeMask(brainVolumeMask, vesselnessVolume, edtMax=10, frac1=0.8, frac2=0.7, minSize=150, device=0):
+    """The body of the reference's main() between loading and saving (generateVesselVolume.py:177-199):
+    suppress weak vesselness near the brain-mask boundary (EDT <= 10 and <= min + 0.8*range), threshold at
+    min + 0.7*range, binarise, drop 26-connected components of <= 150 voxels.  Returns the uint8 mask."""
+    ves = np.ascontiguousarray(vesselnessVolume)
+    if ves.dtype not in (np.float32, np.float64):
+        ves = ves.astype(np.float64)
+    b = _u8c(brainVolumeMask)
+    if b.shape != ves.shape:
+        raise ValueError('brainVolumeMask and vesselnessVolume must have the same shape')
+    out = np.empty(ves.shape, np.uint8)
+    kept = C.c_int64()
+    _check(_lib().vmask_vessel_mask(device, b.ctypes.data, ves.ctypes.data, 5 if ves.dtype == np.float32 else 6,
+                                    *ves.shape, float(edtMax), float(frac1), float(frac2), int(minSize),
+                                    out.ctypes.data, C.byref(kept)))
+    print('Number of voxels in segmentation: {}'.format(kept.value))          # :211
+    return out
+
+
+def main(baseFolder=None, rawVolumeName='401 3D MRA BRAIN.nii.gz'):
+    """File-level equivalent of the reference's main() (:138-228) for a folder holding the same files."""
+    if baseFolder is None:
+        baseFolder = os.getcwd()
+    _, rawVolumeAffine = loadVolume(baseFolder, rawVolumeName)
+    brainVolumeMask, _ = loadVolume(baseFolder, 'brainVolumeMask.nii.gz')
+    vesselnessVolume, _ = loadVolume(baseFolder, 'vesselnessFiltered.nii.gz')
+    mask = vesselVolumeMask(brainVolumeMask, vesselnessVolume)
+    saveVolume(mask, rawVolumeAffine, os.path.join(baseFolder, 'vesselVolumeMask.nii.gz'), astype=np.uint8)   # :213-216
+    return mask

@@ -281,3 +281,44 @@ def test_refine_nifti_in_nifti_out(tmp_path):
                                                     iterMax=30, maxTime=-1.0, density_mode=1, quiet=True)
     assert np.array_equal(out, segMap_o) and np.array_equal(seg, seg_o) and np.array_equal(vm, vm_o)
     assert out.sum() > (vmap == 0).sum()
+
+
+def test_layouts_dtypes_and_stop_order(lib):
+    """C / Fortran order and integer dtypes through the device repack kernels; stop-test order :91 > :97 > :101."""
+    from arterynetwork_amd._capi import Session
+    from arterynetwork_amd import variationalRegionGrowing, phantoms
+    rng = np.random.default_rng(3)
+    shape = (37, 29, 23)
+    I = rng.integers(0, 6, size=shape)
+    vm = np.full(shape, 3, dtype=np.int64)
+    vm[rng.random(shape) < 0.15] = 0
+    vm[rng.random(shape) < 0.1] = 4
+    if not (vm == 0).any():
+        vm[0, 0, 0] = 0
+    outs = []
+    for data, lab in ((I.astype(np.float64), vm), (np.asfortranarray(I.astype(np.float32)), np.asfortranarray(vm.astype(np.uint8))),
+                      (I.astype(np.int16), vm.astype(np.int32)), (I.astype(np.uint16), np.asfortranarray(vm))):
+        s = Session(shape, lib=lib)
+        s.set_volume(data); s.set_labels(lab); s.init(2.25)
+        s.run(8, 10 ** 9, None)
+        out_c = s.labels()
+        assert np.array_equal(out_c, s.labels(out=np.empty(shape, dtype=np.int64, order='F')))
+        outs.append((out_c, s.segmented()))
+        s.close()
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+    # in-place write-back keeps the caller's dtype and memory order
+    vmf = np.asfortranarray(vm.astype(np.uint8))
+    seg, segMap, back = variationalRegionGrowing(I.astype(np.int16), vmf, iterMax=8, maxSegmentSize=10 ** 9, quiet=True)
+    assert back is vmf and vmf.dtype == np.uint8 and np.array_equal(vmf, outs[0][0])
+    # stop order
+    data, vmap = phantoms.shell_with_holes()
+    s = Session(data.shape, lib=lib)
+    s.set_volume(data); s.set_labels(vmap); s.init(2.25)
+    before = s.labels()
+    r = s.run(200, 1, 0.0)
+    assert r.stop_reason == 2 and r.sweeps == 0 and np.array_equal(s.labels(), before)
+    assert s.run(200, 1, None).stop_reason == 3
+    assert s.run(200, 10 ** 9, None).stop_reason == 1
+    assert s.run(200, 1, 0.0).stop_reason == 1
+    s.close()

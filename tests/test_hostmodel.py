@@ -113,3 +113,23 @@ def test_hostmodel_layouts_and_dtypes(hm):
         s.close()
     for o in outs[1:]:
         assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+
+
+def test_hostmodel_time_cap_order(hm):
+    """:91 no flips beats :97 time beats :101 size, all before update() is applied."""
+    from arterynetwork_amd._capi import Session
+    from arterynetwork_amd import phantoms
+    data, vmap = phantoms.shell_with_holes()
+    s = Session(data.shape, lib=hm)
+    s.set_volume(data); s.set_labels(vmap); s.init(2.25)
+    before = s.labels()
+    r = s.run(200, 1, 0.0)                       # time cap already reached and size cap reached: time wins
+    assert r.stop_reason == 2 and r.iter_num == 1 and r.sweeps == 0
+    assert np.array_equal(s.labels(), before)
+    r = s.run(200, 1, None)                      # no time cap: size stop
+    assert r.stop_reason == 3 and r.sweeps == 0
+    r = s.run(200, 10 ** 9, None)                # runs to convergence; afterwards "no flips" beats an expired timer
+    assert r.stop_reason == 1
+    r = s.run(200, 1, 0.0)
+    assert r.stop_reason == 1 and r.sweeps == 0
+    s.close()

@@ -1,0 +1,106 @@
+"""Stage-1 voxel passes: GPU EDT / component labelling / vessel-mask pipeline / skeletoniser
+export against the CPU oracle (oracle/mask_oracle.py: scipy.ndimage, the reference's own dependency)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mask_oracle as MO
+
+
+def _volumes(seed, shape):
+    rng = np.random.default_rng(seed)
+    x, y, z = np.meshgrid(*[np.arange(n) for n in shape], indexing='ij')
+    c = [(n - 1) / 2.0 for n in shape]
+    brain = (((x - c[0]) / (0.45 * shape[0])) ** 2 + ((y - c[1]) / (0.45 * shape[1])) ** 2
+             + ((z - c[2]) / (0.45 * shape[2])) ** 2) <= 1.0
+    tube = ((y - c[1] - 0.2 * shape[1] * np.sin(2 * np.pi * x / shape[0])) ** 2 + (z - c[2]) ** 2) <= 6.0
+    tube2 = ((x - 0.3 * shape[0]) ** 2 + (y - 0.6 * shape[1]) ** 2) <= 4.0
+    ves = (tube | tube2).astype(np.float32) + 0.25 * rng.random(shape).astype(np.float32)
+    ves[rng.random(shape) < 0.002] = 1.2          # specks: small components to be dropped
+    return brain.astype(np.uint8), ves
+
+
+# ------------------------------------------------------------------ CPU: the oracle itself
+def test_oracle_pipeline_properties():
+    brain, ves = _volumes(0, (40, 36, 30))
+    m = MO.vesselVolumeMask(brain, ves)
+    assert m.dtype == np.uint8 and set(np.unique(m)) <= {0, 1} and 50 < m.sum() < m.size // 4
+    lab, res = MO.labelVolume(m)
+    assert all(size > 150 for label, size in res if label != 0)      # :197-199
+    assert res[0][0] == 0 and sum(s for _, s in res) == m.size       # bincount includes the background (:131-134)
+    edt = MO.distance_transform_edt(brain)
+    assert edt[brain == 0].max() == 0 and edt.max() > 5
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(40, 36, 30), (17, 64, 9), (1, 50, 33), (96, 80, 72)])
+def test_edt_bit_exact(shape):
+    from arterynetwork_amd.generateVesselVolume import distance_transform_edt
+    brain, _ = _volumes(1, shape)
+    rng = np.random.default_rng(2)
+    for mask in (brain, (rng.random(shape) < 0.97).astype(np.uint8), np.ones(shape, np.uint8) * (np.arange(shape[1])[None, :, None] > 0)):
+        got = distance_transform_edt(mask)
+        ref = MO.distance_transform_edt(mask)
+        assert got.dtype == np.float64 and np.array_equal(got, ref)      # sqrt of the exact integer squared distance
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('maxHop', [1, 2, 3])
+def test_label_volume_matches_raster_numbering(maxHop):
+    from arterynetwork_amd.generateVesselVolume import labelVolume
+    rng = np.random.default_rng(3)
+    for shape, p in (((30, 28, 26), 0.25), ((9, 70, 5), 0.45), ((64, 64, 48), 0.12)):
+        vol = (rng.random(shape) < p).astype(int)
+        lab, res = labelVolume(vol, maxHop=maxHop)
+        olab, ores = MO.labelVolume(vol, maxHop=maxHop)
+        assert np.array_equal(lab, olab)
+        assert res == ores
+    lab, res = labelVolume(np.zeros((4, 5, 6), int))
+    assert lab.max() == 0 and res == [(0, 120)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_vessel_mask_pipeline(dtype, capsys):
+    from arterynetwork_amd.generateVesselVolume import vesselVolumeMask
+    for seed, shape in ((0, (40, 36, 30)), (5, (72, 64, 56))):
+        brain, ves = _volumes(seed, shape)
+        ves = ves.astype(dtype)
+        got = vesselVolumeMask(brain * 7, ves)            # any non-zero value means "inside the brain"
+        ref = MO.vesselVolumeMask(brain, ves)
+        assert got.dtype == np.uint8 and np.array_equal(got, ref)
+        assert 'Number of voxels in segmentation: {}'.format(int(ref.sum())) in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+def test_skeletoniser_export(tmp_path):
+    from arterynetwork_amd.skeletonization import analyze_export
+    brain, ves = _volumes(0, (40, 36, 30))
+    mask = MO.vesselVolumeMask(brain, ves) * 255
+    d = analyze_export(mask, str(tmp_path))
+    sw = np.swapaxes((mask != 0).astype(np.uint8), 0, 2)
+    assert open(os.path.join(d, 'BB.txt')).read() == '1\n0 0 0\n{} {} {}'.format(*sw.shape)
+    lines = open(os.path.join(d, 'xyz.txt')).read().splitlines()
+    coords = np.array(np.where(sw)).T
+    assert int(lines[0]) == len(coords) == len(lines) - 1
+    assert lines[1] == '{} {} {}'.format(*coords[0]) and lines[-1] == '{} {} {}'.format(*coords[-1])
+    z = np.load(os.path.join(d, 'vesselVolumeMaskLabelInfo.npz'))
+    olab, ores = MO.labelVolume(sw)
+    assert np.array_equal(z['vesselVolumeMaskLabeled'], olab)
+    assert [tuple(r) for r in z['vesselVolumeMaskLabelResult']] == ores
+
+
+@pytest.mark.gpu
+def test_nifti_main_round_trip(tmp_path):
+    from arterynetwork_amd import nifti, generateVesselVolume as G
+    brain, ves = _volumes(7, (48, 40, 32))
+    aff = np.diag([0.4, 0.4, 0.6, 1.0])
+    nifti.saveVolume(ves * 100, aff, str(tmp_path / '401 3D MRA BRAIN.nii.gz'), astype=np.float32)
+    nifti.saveVolume(brain, aff, str(tmp_path / 'brainVolumeMask.nii.gz'))
+    nifti.saveVolume(ves, aff, str(tmp_path / 'vesselnessFiltered.nii.gz'), astype=np.float32)
+    m = G.main(str(tmp_path))
+    out, aff2 = nifti.loadVolume(str(tmp_path), 'vesselVolumeMask.nii.gz')
+    assert out.dtype == np.uint8 and np.array_equal(out, m) and np.allclose(aff2, aff)
+    assert np.array_equal(m, MO.vesselVolumeMask(brain, ves))
