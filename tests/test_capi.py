@@ -17,14 +17,18 @@ def product():
 
 
 def header_symbols():
-    txt = open(os.path.join(ROOT, 'include', 'vrg.h')).read()
-    return sorted(set(re.findall(r'\b(vrg_[a-z_]+)\s*\(', txt)))
+    import glob
+    syms = set()
+    for h in glob.glob(os.path.join(ROOT, 'include', '*.h')):
+        txt = re.sub(r'/\*.*?\*/', '', open(h).read(), flags=re.S)        # declarations only, not comments
+        syms |= set(re.findall(r'\b((?:vrg|vmask)_[a-z_0-9]+)\s*\(', txt))
+    return sorted(syms)
 
 
 def test_library_exports_header_symbols(product):
     dll = ctypes.CDLL(product)
     syms = header_symbols()
-    assert len(syms) >= 12
+    assert len(syms) >= 20 and 'vmask_edt' in syms and 'vrg_comm_init' in syms
     for name in syms:
         assert hasattr(dll, name), name
 
