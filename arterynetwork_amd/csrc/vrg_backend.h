@@ -31,6 +31,9 @@ int be_unpack_labels(const VrgCtx& c, const uint8_t* lab, void* dst, int dtype, 
 // sorted distinct intensity values; allocates *lev (backend memory), returns the count in *L
 int be_build_levels(const VrgCtx& c, double** lev, uint32_t* L);
 
+// 16-bit storage: level index of every voxel (after be_build_levels), padded layout
+void be_build_lev16(const VrgCtx& c, uint16_t* dst);
+
 // init mode (:129-155): labels by morphology + staged band entries; then order them and finish
 void be_init_band(const VrgCtx& c);
 void be_init_sort(const VrgCtx& c, uint32_t n_in, uint32_t n_out);   // keys -> b_idx[0] in list order

@@ -358,6 +358,51 @@ __global__ void __launch_bounds__(TPB) k_recount(VrgCtx c, int check_done) {
     sweep_finish(c, acc);
 }
 
+// 16-bit storage variant: 2 B level index + 1 B label per voxel; the level values sit in LDS (<= 16384 x f32).
+// Same unit / lane mapping, so the sums are added in the same order as in k_recount (bit-identical results).
+constexpr uint32_t LEV16_MAX = 16384;
+__global__ void __launch_bounds__(TPB) k_recount16(VrgCtx c, int check_done) {
+    if (check_done && c.st->done) return;
+    __shared__ float s_val[LEV16_MAX];
+    for (uint32_t i = threadIdx.x; i < c.L; i += TPB) s_val[i] = (float)c.lev[i];
+    __syncthreads();
+    const uint8_t* __restrict__ in = c.lab[0];
+    const uint16_t* __restrict__ lv = c.lev16;
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
+    const uint32_t first = (2u + (uint32_t)c.z0) * plane;
+    const uint32_t total = (uint32_t)(c.z1 - c.z0) * plane;
+    const uint32_t nfull = total >> 10;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    SweepAcc acc = {0, 0, 0.0, 0.0};
+    for (uint32_t u = wave; u < nfull; u += nwaves) {
+        const uint32_t base = first + (u << 10) + (lane << 2);
+        uint32_t w[4]; uint2 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            w[j] = *reinterpret_cast<const uint32_t*>(in + base + (j << 8));
+            q[j] = *reinterpret_cast<const uint2*>(lv + base + (j << 8));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f4v f = {s_val[q[j].x & 0xffffu], s_val[q[j].x >> 16], s_val[q[j].y & 0xffffu], s_val[q[j].y >> 16]};
+            sweep_stats(acc, w[j], f);
+        }
+    }
+    if (wave == nwaves - 1 && (total & 1023u)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t off = (nfull << 10) + (j << 8) + (lane << 2);
+            if (off < total) {
+                uint2 q = *reinterpret_cast<const uint2*>(lv + first + off);
+                f4v f = {s_val[q.x & 0xffffu], s_val[q.x >> 16], s_val[q.y & 0xffffu], s_val[q.y >> 16]};
+                sweep_stats(acc, *reinterpret_cast<const uint32_t*>(in + first + off), f);
+            }
+        }
+    }
+    sweep_finish(c, acc);
+}
+
 // full-stencil check variant: every voxel runs the relabel stencil (no marks); new bytes go to lab[1]
 // and are copied back, so stencil reads only ever see pre-sweep labels.
 __global__ void __launch_bounds__(TPB) k_full_relabel(VrgCtx c) {
@@ -429,7 +474,8 @@ __global__ void __launch_bounds__(TPB) k_hist_lds(VrgCtx c) {
             uint8_t cb = (uint8_t)(v >> (8 * b));
             if (cb & (VB_OOB | VB_X)) continue;
             uint32_t lo = 0, hi = L - 1;
-            while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (s_lev[m] < fv[b]) lo = m + 1; else hi = m; }
+            if (c.lev16) lo = c.lev16[base + b];
+            else while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (s_lev[m] < fv[b]) lo = m + 1; else hi = m; }
             atomicAdd(&s_h[(cb & VB_S) ? 0 : 1][lo], 1u);
         }
     }
@@ -661,6 +707,14 @@ int be_build_levels(const VrgCtx& c, double** lev, uint32_t* L) {
     return 0;
 }
 
+__global__ void k_build_lev16(VrgCtx c, uint16_t* dst) {
+    VOXEL_LOOP(c) { int x, y, z; uint32_t idx = real_idx(c, t, x, y, z); dst[idx] = (uint16_t)vrg_level_of(c, (double)c.I[idx]); }
+}
+void be_build_lev16(const VrgCtx& c, uint16_t* dst) {
+    HIP_CHECK(hipMemsetAsync(dst, 0, (size_t)c.PV * 2, g_stream));
+    k_build_lev16<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, dst);
+}
+
 void be_init_band(const VrgCtx& c) {
     k_init_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
 }
@@ -709,7 +763,8 @@ void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
     if (c.L <= HIST_LDS_LEVELS) k_hist_lds<<<1024, TPB, 0, g_stream>>>(c);
     else k_hist_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
     k_exact<<<1024, TPB, 0, g_stream>>>(c, 0);
-    k_recount<<<dense_blocks(c), TPB, 0, g_stream>>>(c, 0);
+    if (c.lev16) k_recount16<<<dense_blocks(c), TPB, 0, g_stream>>>(c, 0);
+    else k_recount<<<dense_blocks(c), TPB, 0, g_stream>>>(c, 0);
     reduce_dense(c, cb, user);
     k_fin_init<<<1, 1, 0, g_stream>>>(c);
 }
@@ -750,7 +805,8 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb,
         p = &g_ev_pool[g_ev_used++];
         HIP_CHECK(hipEventRecord(p->a, g_stream));
     }
-    k_recount<<<blocks, TPB, 0, g_stream>>>(c, 1);
+    if (c.lev16) k_recount16<<<blocks, TPB, 0, g_stream>>>(c, 1);
+    else k_recount<<<blocks, TPB, 0, g_stream>>>(c, 1);
     if (p) HIP_CHECK(hipEventRecord(p->b, g_stream));
     reduce_dense(c, cb, user);
     // join

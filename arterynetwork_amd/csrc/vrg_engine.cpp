@@ -26,7 +26,8 @@ struct vrg_handle {
     std::vector<void*> owned;
     int device = 0;
     bool have_vol = false, have_lab = false, inited = false;
-    int variant = 0, batch = 8;
+    int variant = 0, batch = 8, storage16 = 0;
+    uint16_t* lev16_buf = nullptr;
     uint64_t band_capacity = 0;
     VrgEvents ev{0, 0.0, 0};
     std::chrono::steady_clock::time_point t0;
@@ -128,6 +129,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "events") h->ev.enabled = value != 0;
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
     else if (n == "sweep_blocks" || n == "prio_mode") be_set_tuning(name, value);
+    else if (n == "storage16") { if (h->inited) return fail(h, VRG_E_STATE, "storage16 must be set before vrg_init"); h->storage16 = value != 0; }
     else return fail(h, VRG_E_ARG, "unknown option " + n);
     return VRG_OK;
 }
@@ -178,6 +180,14 @@ int API(init)(vrg_handle* h, double H) {
         c.lscan = alloc<uint32_t>(h, (size_t)L + 16);
         if (!c.hin || !c.hout || !c.dIn || !c.dOut || !c.dConv || !c.nz_lev || !c.nz_val || !c.nz_cin || !c.nz_cout || !c.nz_cconv || !c.tabC || !c.lscan)
             return fail(h, VRG_E_MEM, "vrg_init: level arrays");
+    }
+    c.lev16 = nullptr;
+    if (h->storage16) {                             // 16-bit intensity storage: level indices + LDS value table
+        if (L > 16384) return fail(h, VRG_E_ARG, "storage16: more than 16384 distinct intensity values");
+        if (!h->lev16_buf) h->lev16_buf = alloc<uint16_t>(h, c.PV);
+        if (!h->lev16_buf) return fail(h, VRG_E_MEM, "vrg_init: 16-bit level volume");
+        be_build_lev16(c, h->lev16_buf);
+        c.lev16 = h->lev16_buf;
     }
     be_fill(c.hin, 0, (size_t)L * 4); be_fill(c.hout, 0, (size_t)L * 4);
     be_fill(c.dIn, 0, (size_t)L * 4); be_fill(c.dOut, 0, (size_t)L * 4); be_fill(c.dConv, 0, (size_t)L * 4);

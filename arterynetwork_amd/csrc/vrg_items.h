@@ -87,6 +87,11 @@ VRG_HD uint32_t vrg_level_of(const VrgCtx& c, double v) {   // index of v in the
     return lo;
 }
 
+// level index of a voxel's intensity: stored (16-bit mode) or looked up in the sorted level table
+VRG_HD uint32_t vrg_voxel_level(const VrgCtx& c, uint32_t idx) {
+    return c.lev16 ? (uint32_t)c.lev16[idx] : vrg_level_of(c, (double)c.I[idx]);
+}
+
 // ------------------------------------------------------------------ decide (:79-88) + listing
 // One item per band entry.  A flip is listed at once: L bit (+P for flip-outs, which are always
 // applied), stamp = (sweep, entry index) and an unordered append to the flip list.
@@ -287,7 +292,7 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
                         uint8_t mb = lab[(int64_t)idx + (dz * c.PY + dy) * c.PX + dx];
                         if ((mb & VB_P) && !(mb & VB_OOB)) { conv = true; break; }
                     }
-        if (conv) vrg_atomic_add(&c.dConv[vrg_level_of(c, (double)c.I[idx])], 1u);   // addedPoints (:235)
+        if (conv) vrg_atomic_add(&c.dConv[vrg_voxel_level(c, idx)], 1u);   // addedPoints (:235)
     }
     if (nAP) { vrg_promote_b(c, lab, idx); return VB_B; }   // 3 -> 2 (:210-213)
     return (uint8_t)(((cb & VB_X) && !conv) ? VB_X : 0);
@@ -403,7 +408,7 @@ VRG_HD void vrg_item_scatter_promo(const VrgCtx& c, uint32_t r, uint32_t k) {
     uint32_t slot = e < s.ni ? vrg_slot_A1(s, e) : vrg_slot_B2(s, e - s.ni);
     uint32_t pos = c.scan[slot] + (uint32_t)__builtin_popcount(mask & ((1u << k) - 1u));
     uint32_t m = (uint32_t)((int64_t)c.b_idx[cur][e] + vrg_off(c, (int)k));
-    vrg_new_fresh(c, nx, pos, m, vrg_level_of(c, (double)c.I[m]));
+    vrg_new_fresh(c, nx, pos, m, vrg_voxel_level(c, m));
 }
 
 // exact densities over the whole inner / outer regions (:152-155, :252-255), regrouped by level
@@ -465,13 +470,13 @@ VRG_HD void vrg_item_init_voxel(const VrgCtx& c, uint32_t idx) {
 
 VRG_HD void vrg_item_init_entry(const VrgCtx& c, uint32_t e) {
     uint32_t idx = c.b_idx[0][e];
-    c.b_lev[0][e] = vrg_level_of(c, (double)c.I[idx]);
+    c.b_lev[0][e] = vrg_voxel_level(c, idx);
     c.fresh[e] = e;
 }
 
 VRG_HD void vrg_item_hist_voxel(const VrgCtx& c, uint32_t idx) {
     uint8_t b = c.lab[0][idx];
     if (b & (VB_OOB | VB_X)) return;
-    uint32_t lev = vrg_level_of(c, (double)c.I[idx]);
+    uint32_t lev = vrg_voxel_level(c, idx);
     if (b & VB_S) vrg_atomic_add(&c.hin[lev], 1); else vrg_atomic_add(&c.hout[lev], 1);
 }

@@ -75,6 +75,8 @@ struct VrgCtx {
     uint32_t PV;               // PX*PY*PZ
     double H, A;               // kernel A*exp(-0.5*H*d^2) (:7,:10)
     const float* I;            // intensities, padded layout
+    const uint16_t* lev16;     // optional 16-bit storage: level index per voxel (same layout); the dense pass then
+                               // streams 2 B instead of 4 B of intensity per voxel (values come from an LDS table)
     uint8_t* lab[2];           // lab[0]: label bytes, updated in place; lab[1]: scratch of the full-stencil check variant
     uint32_t mcap;             // marked-voxel list: index and new byte
     uint32_t* mk_idx;

@@ -94,15 +94,15 @@ def load_traffic(shape, n_gpus):
     return None
 
 
-def roofline(V_per_launch, kern_ms, launches, traffic):
+def roofline(V_per_launch, kern_ms, launches, traffic, bytes_per_voxel=BYTES_PER_VOXEL_ITER):
     """Dominant kernel = k_recount (dense region recount, one launch per sweep).  `achieved` uses the
     ALGORITHMIC 6 B/voxel-iter of SURVEY.md 8(d); the kernel itself moves ~5 B/voxel (labels are updated
     in place, so the 1 B/voxel label write-back is elided) - `traffic` is the rocprofv3 PMC figure."""
-    achieved = BYTES_PER_VOXEL_ITER * V_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
-    out = {'bound': 'hbm', 'kernel': 'k_recount', 'achieved': round(achieved, 1) if achieved else None,
+    achieved = bytes_per_voxel * V_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
+    out = {'bound': 'hbm', 'kernel': 'k_recount16' if bytes_per_voxel == 4 else 'k_recount', 'achieved': round(achieved, 1) if achieved else None,
            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
            'kernel_ms_avg': round(kern_ms, 4), 'launches': launches,
-           'algorithmic_bytes_per_launch': BYTES_PER_VOXEL_ITER * V_per_launch, 'traffic': traffic}
+           'algorithmic_bytes_per_launch': bytes_per_voxel * V_per_launch, 'traffic': traffic}
     if traffic and kern_ms > 0:
         out['traffic_gbs'] = round(traffic / (kern_ms * 1e-3) / 1e9, 1)
         out['traffic_frac_of_peak'] = round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -121,6 +121,7 @@ def main():
     ap.add_argument('--variant', type=int, default=0)
     ap.add_argument('--sweep-blocks', type=int, default=0)
     ap.add_argument('--prio-mode', type=int, default=-1)
+    ap.add_argument('--storage16', action='store_true', help='16-bit intensity storage (level indices): config 5 style; 4 B/voxel-iter algorithmic')
     ap.add_argument('--force-dist', action='store_true', help='use the N>1 code path (RCCL comm) even with one rank')
     args = ap.parse_args()
     shape = tuple(int(s) for s in args.shape.lower().split('x'))
@@ -162,6 +163,8 @@ def main():
         s.set_option('sweep_blocks', args.sweep_blocks)
     if args.prio_mode >= 0:
         s.set_option('prio_mode', args.prio_mode)
+    if args.storage16:
+        s.set_option('storage16', 1)
     s.set_option('events', 1)
     s.set_option('batch', 64)
     s.set_volume_ptr(I.data_ptr(), np.float32, [st for st in I.stride()])
@@ -188,14 +191,17 @@ def main():
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'u8 labels + f32 intensities (f64 region sums / densities)',
         'data': 'synthetic', 'valid': bool(valid),
-        'config': {'workload': '{} synthetic MRA tube volume ({} intensity levels stored fp32, brain-mask excluded '
-                               'voxels), H={}, {} incremental VRG sweeps'.format(args.shape, args.levels, args.H, r.sweeps),
+        'config': {'workload': '{} synthetic MRA tube volume ({} intensity levels stored {}, brain-mask excluded '
+                               'voxels), H={}, {} incremental VRG sweeps'.format(
+                                   args.shape, args.levels, 'as u16 level indices' if args.storage16 else 'fp32', args.H, r.sweeps),
                    'parallelism': 'single GPU', 'sweep_variant': args.variant,
+                   'intensity_storage': 'u16 level index (2 B/voxel)' if args.storage16 else 'fp32 (4 B/voxel)',
                    'init_seconds': round(t_init, 3), 'nseg_start': int(tr['nseg'][args.warmup]),
                    'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
                    'flips_per_sweep_mean': round(float(tr['nflip'][args.warmup + 1:].mean()), 1),
                    'hbm_gbs_whole_step': round(BYTES_PER_VOXEL_ITER * V / (ms_per_step * 1e-3) / 1e9, 1)},
-        'roofline': roofline(V, kern_ms, int(r.sweep_launches), load_traffic(shape, 1)),
+        'roofline': roofline(V, kern_ms, int(r.sweep_launches), None if args.storage16 else load_traffic(shape, 1),
+                             4 if args.storage16 else BYTES_PER_VOXEL_ITER),
     }
     if not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(I, vm, args.H)

@@ -97,6 +97,11 @@ int be_build_levels(const VrgCtx& c, double** lev, uint32_t* L) {
     return 0;
 }
 
+void be_build_lev16(const VrgCtx& c, uint16_t* dst) {
+    std::memset(dst, 0, (size_t)c.PV * 2);
+    for_real_voxels(c, [&](uint32_t idx, int, int, int) { dst[idx] = (uint16_t)vrg_level_of(c, (double)c.I[idx]); });
+}
+
 void be_init_band(const VrgCtx& c) {
     for_real_voxels(c, [&](uint32_t idx, int, int, int) { vrg_item_init_voxel(c, idx); });
 }
@@ -117,8 +122,9 @@ static void dense_stats(const VrgCtx& c, const uint8_t* lab, be_reduce_fn cb, vo
     for_real_voxels(c, [&](uint32_t idx, int, int, int z) {
         if (z < c.z0 || z >= c.z1) return;
         uint8_t o = lab[idx];
-        if (o & VB_S) { a++; sa += (double)c.I[idx]; }
-        else if (!(o & VB_X)) { b++; sb += (double)c.I[idx]; }
+        double v = c.lev16 ? (double)(float)c.lev[c.lev16[idx]] : (double)c.I[idx];
+        if (o & VB_S) { a++; sa += v; }
+        else if (!(o & VB_X)) { b++; sb += v; }
     });
     VrgDense& p = *c.dn_part;
     p.n_in = (double)a; p.n_out = (double)b; p.sum_in = sa; p.sum_out = sb;

@@ -322,3 +322,38 @@ def test_layouts_dtypes_and_stop_order(lib):
     assert s.run(200, 10 ** 9, None).stop_reason == 1
     assert s.run(200, 1, 0.0).stop_reason == 1
     s.close()
+
+
+def test_16bit_storage_identical(lib, golden_loader):
+    """storage16: the dense pass streams 2 B level indices (values from an LDS table) - same results and sums."""
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session, VrgError
+    for name in ('adv_noise_q', 'adv_scattered_q', 'tube_q_small', 'kat_sphere'):
+        g = golden_loader(name)
+        data, vmap = g.inputs()
+        iterMax = g.max_sweeps if g.max_sweeps >= 0 else 200
+        res, k = parity.run_stepwise(lib, data, vmap, g.H, g.maxSegmentSize, iterMax, density_mode=1, check_hist=True,
+                                     options={'storage16': 1})
+        assert res is not None and k == g.ncalls - 1
+    data, vmap = phantoms.bench_volume((256, 192, 96), seed=4)
+    outs = []
+    for st in (0, 1):
+        s = Session(data.shape, lib=lib)
+        s.set_option('storage16', st)
+        s.set_volume(data); s.set_labels(vmap.astype(np.uint8)); s.init(2.25)
+        s.run(40, 10 ** 9, None)
+        outs.append((s.labels(), s.segmented(), s.trace(), s.band(0), s.band(1)))
+        s.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2].tobytes() == outs[1][2].tobytes()          # trace incl. the f64 intensity sums: bit-identical
+    for w in (3, 4):
+        for x, y in zip(outs[0][w], outs[1][w]):
+            assert np.array_equal(x, y)
+    # continuous-valued data has too many distinct values for 16-bit storage: loud error, no silent fallback
+    d2, v2 = phantoms.config1()
+    s = Session(d2.shape, lib=lib)
+    s.set_option('storage16', 1)
+    s.set_volume(d2); s.set_labels(v2)
+    with pytest.raises(VrgError):
+        s.init(2.25)
+    s.close()

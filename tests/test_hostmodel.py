@@ -133,3 +133,14 @@ def test_hostmodel_time_cap_order(hm):
     r = s.run(200, 1, 0.0)
     assert r.stop_reason == 1 and r.sweeps == 0
     s.close()
+
+
+@pytest.mark.parametrize('name', ['adv_noise_q', 'adv_scattered_q', 'tube_q_small', 'kat_sphere'])
+def test_hostmodel_16bit_storage(hm, golden_loader, name):
+    """storage16 (level index per voxel instead of the fp32 intensity) gives the same result, bit for bit."""
+    g = golden_loader(name)
+    data, vmap = g.inputs()
+    iterMax = g.max_sweeps if g.max_sweeps >= 0 else 200
+    res, k = parity.run_stepwise(hm, data, vmap, g.H, g.maxSegmentSize, iterMax, density_mode=1, check_hist=True,
+                                 options={'storage16': 1})
+    assert res is not None and k == g.ncalls - 1
