@@ -62,9 +62,11 @@ __device__ __forceinline__ long long floordiv(long long a, long long b) {   // b
     return (a % b != 0 && a < 0) ? q - 1 : q;
 }
 
-// Meijster phase 2 along one axis: Gout(u) = min_i (u-i)^2 + Gin(i); S,T = per-line stacks (same indexing)
-__global__ void k_edt_envelope(const int32_t* __restrict__ Gin, int32_t* __restrict__ Gout, int32_t* __restrict__ S,
-                               int32_t* __restrict__ T, Dims d, int axis) {
+// Meijster phase 2 along one axis: Gout(u) = min_i (u-i)^2 + Gin(i).  The lower envelope is a per-line stack
+// kept in global memory (ST = site | start << 16, GS = Gin at the site; same indexing as the data) with its
+// TOP cached in registers, so the forward scan touches the stack only on pops (no dependent gathers otherwise).
+__global__ void k_edt_envelope(const int32_t* __restrict__ Gin, int32_t* __restrict__ Gout, uint32_t* __restrict__ ST,
+                               int32_t* __restrict__ GS, Dims d, int axis) {
     const uint32_t nlines = axis == 1 ? (uint32_t)d.n0 * d.n2 : (uint32_t)d.n0 * d.n1;
     const int32_t m = axis == 1 ? d.n1 : d.n2;
     const size_t stride = axis == 1 ? (size_t)d.n2 : 1;
@@ -72,27 +74,29 @@ __global__ void k_edt_envelope(const int32_t* __restrict__ Gin, int32_t* __restr
         size_t base = axis == 1 ? (size_t)(line / d.n2) * d.n1 * d.n2 + (line % d.n2) : (size_t)line * d.n2;
 #define AT(u) (base + (size_t)(u) * stride)
         int32_t q = 0;
-        S[AT(0)] = 0; T[AT(0)] = 0;
+        long long ts = 0, tt = 0, tg = Gin[AT(0)];               // top of the stack: site, start, G(site)
+        ST[AT(0)] = 0; GS[AT(0)] = (int32_t)tg;
         for (int32_t u = 1; u < m; u++) {
             const long long Gu = Gin[AT(u)];
             while (q >= 0) {
-                long long sq = S[AT(q)], tq = T[AT(q)];
-                long long f1 = (tq - sq) * (tq - sq) + Gin[AT(sq)];
-                long long f2 = (tq - u) * (tq - u) + Gu;
-                if (f1 > f2) q--; else break;
+                long long f1 = (tt - ts) * (tt - ts) + tg;
+                long long f2 = (tt - u) * (tt - u) + Gu;
+                if (f1 <= f2) break;
+                if (--q >= 0) { uint32_t p = ST[AT(q)]; ts = p & 0xffffu; tt = p >> 16; tg = GS[AT(q)]; }
             }
-            if (q < 0) { q = 0; S[AT(0)] = u; }
+            if (q < 0) { q = 0; ts = u; tt = 0; tg = Gu; ST[AT(0)] = (uint32_t)u; GS[AT(0)] = (int32_t)Gu; }
             else {
-                long long i = S[AT(q)];
-                long long w = 1 + floordiv((long long)u * u - i * i + Gu - Gin[AT(i)], 2 * (u - i));
-                if (w < m) { q++; S[AT(q)] = u; T[AT(q)] = (int32_t)w; }
+                long long w = 1 + floordiv((long long)u * u - ts * ts + Gu - tg, 2 * (u - ts));
+                if (w < m) {                                      // w >= 1 here: the top still wins at its own start
+                    q++; ts = u; tt = w; tg = Gu;
+                    ST[AT(q)] = (uint32_t)u | ((uint32_t)w << 16); GS[AT(q)] = (int32_t)Gu;
+                }
             }
         }
         for (int32_t u = m - 1; u >= 0; u--) {
-            long long sq = S[AT(q)];
-            long long v = (u - sq) * (u - sq) + Gin[AT(sq)];
+            long long v = (u - ts) * (u - ts) + tg;
             Gout[AT(u)] = v >= EDT_INF ? EDT_INF : (int32_t)v;
-            if (u == T[AT(q)]) q--;
+            if (u == tt && --q >= 0) { uint32_t p = ST[AT(q)]; ts = p & 0xffffu; tt = p >> 16; tg = GS[AT(q)]; }
         }
 #undef AT
     }
@@ -106,8 +110,8 @@ __global__ void k_edt_sqrt(const int32_t* __restrict__ G, double* __restrict__ o
 int edt_squared(const uint8_t* dmask, Dims d, int32_t* G, int32_t* G2, int32_t* S, int32_t* T) {
     size_t V = (size_t)d.n0 * d.n1 * d.n2;
     k_edt_axis0<<<grid_for((uint64_t)d.n1 * d.n2), TPB>>>(dmask, G, d);
-    k_edt_envelope<<<grid_for((uint64_t)d.n0 * d.n2), TPB>>>(G, G2, S, T, d, 1);
-    k_edt_envelope<<<grid_for((uint64_t)d.n0 * d.n1), TPB>>>(G2, G, S, T, d, 2);
+    k_edt_envelope<<<grid_for((uint64_t)d.n0 * d.n2), TPB>>>(G, G2, (uint32_t*)S, T, d, 1);
+    k_edt_envelope<<<grid_for((uint64_t)d.n0 * d.n1), TPB>>>(G2, G, (uint32_t*)S, T, d, 2);
     (void)V;
     VM_TRY(hipGetLastError());
     return VRG_OK;

@@ -22,6 +22,7 @@ void be_fill(void* p, int byte, size_t bytes);
 void be_upload(void* dst, const void* src, size_t bytes);     // src may be host or device memory
 void be_download(void* dst, const void* src, size_t bytes);   // dst may be host or device memory
 void be_sync();
+const char* be_last_error();                   // first backend (HIP) failure since start-up, or nullptr
 
 // repack caller arrays ([x][y][z] with element strides) into / out of the padded device layout
 int be_pack_volume(const VrgCtx& c, float* dstI, const void* src, int dtype, const int64_t st[3], int* inexact);

@@ -27,7 +27,12 @@
 #include "vrg_backend.h"
 #include "vrg_items.h"
 
-#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
+// a failed HIP call is remembered (first one wins) and reported by be_last_error(); the engine turns it into
+// VRG_E_INTERNAL at its next synchronisation point
+static char g_hip_error[256] = "";
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess && !g_hip_error[0]) { \
+    std::snprintf(g_hip_error, sizeof(g_hip_error), "HIP error '%s' in %s (%s:%d)", hipGetErrorString(e_), #x, __FILE__, __LINE__); \
+    std::fprintf(stderr, "%s\n", g_hip_error); } } while (0)
 
 namespace {
 
@@ -638,6 +643,10 @@ void be_free(void* p) { HIP_CHECK(hipFree(p)); }
 void be_fill(void* p, int byte, size_t bytes) { HIP_CHECK(hipMemsetAsync(p, byte, bytes, g_stream)); }
 void be_upload(void* dst, const void* src, size_t bytes) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, g_stream)); HIP_CHECK(hipStreamSynchronize(g_stream)); }
 void be_download(void* dst, const void* src, size_t bytes) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, g_stream)); HIP_CHECK(hipStreamSynchronize(g_stream)); }
+const char* be_last_error() {
+    if (!g_hip_error[0]) { hipError_t e = hipGetLastError(); if (e != hipSuccess) std::snprintf(g_hip_error, sizeof(g_hip_error), "HIP error '%s' (asynchronous)", hipGetErrorString(e)); }
+    return g_hip_error[0] ? g_hip_error : nullptr;
+}
 void be_sync() { HIP_CHECK(hipStreamSynchronize(g_stream)); HIP_CHECK(hipStreamSynchronize(g_stream_b)); }
 
 static const void* stage_in(const VrgCtx& c, const void* src, int dtype, void** tmp) {

@@ -62,6 +62,7 @@ void idx_to_xyz(const VrgCtx& c, uint32_t idx, int64_t* out) {
 }
 
 int check_state_error(vrg_handle* h, const VrgState& s) {
+    if (const char* be = be_last_error()) return fail(h, VRG_E_INTERNAL, be);
     if (s.error == 1) return fail(h, VRG_E_CAPACITY, "band capacity exceeded; raise option band_capacity");
     if (s.error == 2) return fail(h, VRG_E_CAPACITY, "flip capacity exceeded; raise option band_capacity");
     if (s.error) return fail(h, VRG_E_INTERNAL, "internal consistency check failed (code " + std::to_string(s.error) + ")");

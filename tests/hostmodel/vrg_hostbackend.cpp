@@ -22,6 +22,7 @@ void be_fill(void* p, int byte, size_t bytes) { std::memset(p, byte, bytes); }
 void be_upload(void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
 void be_download(void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
 void be_sync() {}
+const char* be_last_error() { return nullptr; }
 
 namespace {
 double load_as_double(const void* p, int dtype, int64_t i) {
