@@ -7,7 +7,7 @@
 //     -> k_recount : the dense kernel (every voxel, HBM-bound, read-only: 4 B intensity + 1 B label per
 //        voxel): region sizes and intensity sums (:113-116, :249-250), reduced by its last workgroup
 //   stream B (forked after k_apply, high priority, runs in the shadow of k_recount):
-//     k_entry_post, level-delta compaction, k_tab, scan, k_scatter_*, k_exact;
+//     k_entry_post, k_levels_small (level-delta compaction), k_tab, rebuild scan, k_scatter, k_exact;
 //   join, k_finalize closes the trip.
 // Labels are updated IN PLACE: measured on MI355X, streaming I + labels read-only runs at 5.8-6.0 TB/s
 // while the same stream with a 1 B/voxel label write-back drops to 4.8 TB/s, so unchanged labels are
@@ -126,13 +126,13 @@ __global__ void k_entry_post(VrgCtx c) {
     if (c.st->done) return;
     ITEM_LOOP(c.st->ni + c.st->no) vrg_item_entry_post(c, i);
 }
-__global__ void k_scatter_entry(VrgCtx c) {
+__global__ void k_scatter(VrgCtx c) {                  // items: every old entry, then (listed flip, neighbour k)
     if (c.st->done) return;
-    ITEM_LOOP(c.st->ni + c.st->no) vrg_item_scatter_entry(c, i);
-}
-__global__ void k_scatter_promo(VrgCtx c) {            // item = (listed flip, neighbour k)
-    if (c.st->done) return;
-    ITEM_LOOP(c.st->nf * 32u) vrg_item_scatter_promo(c, i >> 5, i & 31u);
+    const uint32_t n = c.st->ni + c.st->no;
+    ITEM_LOOP(n + c.st->nf * 32u) {
+        if (i < n) vrg_item_scatter_entry(c, i);
+        else { uint32_t j = i - n; vrg_item_scatter_promo(c, j >> 5, j & 31u); }
+    }
 }
 
 // level-delta compaction (:232-235 regrouped by distinct intensity value)
@@ -162,6 +162,45 @@ __global__ void k_post_prep(VrgCtx c) {               // after the level scan, b
     s.ncnt = 3 * n;
     s.nscan = s.ncnt;
 }
+// the four kernels above in ONE workgroup when the level table is small (the common, quantised case):
+// ordered compaction of the touched levels by tiles of 1024 + the k_post_prep bookkeeping
+constexpr uint32_t LEVELS_ONEBLOCK = 32768;
+__global__ void __launch_bounds__(1024) k_levels_small(VrgCtx c) {
+    if (c.st->done) return;
+    __shared__ uint32_t sh[16];
+    __shared__ uint32_t sh_run;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sh_run = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < c.L; base += 1024) {
+        uint32_t l = base + threadIdx.x;
+        uint32_t a = 0, b = 0, d = 0;
+        if (l < c.L) { a = c.dIn[l]; b = c.dOut[l]; d = c.dConv[l]; }
+        uint32_t f = (a | b | d) ? 1u : 0u;
+        uint32_t inc = wave_incl_scan(f);
+        if (lane == 63) sh[w] = inc;
+        __syncthreads();
+        uint32_t off = sh_run, tot = 0;
+        for (int i = 0; i < 16; i++) { if (i < w) off += sh[i]; tot += sh[i]; }
+        if (f) {
+            uint32_t j = off + inc - 1;
+            c.nz_lev[j] = l; c.nz_val[j] = c.lev[l]; c.nz_cin[j] = a; c.nz_cout[j] = b; c.nz_cconv[j] = d;
+            c.hout[l] += (int32_t)d;                 // included voxels join the outer region
+            c.dIn[l] = 0; c.dOut[l] = 0; c.dConv[l] = 0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) sh_run += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        VrgState& s = *c.st;
+        uint32_t n = s.ni + s.no;
+        s.nnz = sh_run;
+        s.use_tab = c.L <= n;
+        s.ncnt = 3 * n;
+        s.nscan = s.ncnt;
+    }
+}
 // per-level memo of the three density corrections: one wave per level
 __global__ void k_tab(VrgCtx c) {
     if (c.st->done || !c.st->use_tab) return;
@@ -177,15 +216,6 @@ __global__ void k_tab(VrgCtx c) {
         a = wave_sum(a); b = wave_sum(b); d = wave_sum(d);
         if (lane == 0) { c.tabC[3 * (size_t)l] = a; c.tabC[3 * (size_t)l + 1] = b; c.tabC[3 * (size_t)l + 2] = d; }
     }
-}
-__global__ void k_fin_scan(VrgCtx c) {
-    if (c.st->done) return;
-    VrgState& s = *c.st;
-    uint32_t tot = s.scan_total;
-    uint32_t b0 = vrg_slot_B0(s, 0);
-    s.ni_new = (b0 < s.ncnt) ? c.scan[b0] : tot;
-    s.nb_new = tot;
-    if (tot > c.bcap) { s.error = 1; s.done = -1; }
 }
 // exact densities (:152-155, :252-255): one wave per fresh entry, lanes stride over the levels
 __global__ void k_exact(VrgCtx c, int par_is_next) {
@@ -236,13 +266,31 @@ __global__ void k_scan_reduce(VrgCtx c, uint32_t* a) {
     uint32_t tot; block_excl_scan(s, tot, sh);
     if (threadIdx.x == 0) c.bsum[blockIdx.x] = tot;
 }
-__global__ void k_scan_top(VrgCtx c) {
+// fin != 0: this is the rebuild scan - also derive the new list lengths (what k_fin_scan does)
+__global__ void k_scan_top(VrgCtx c, uint32_t* a, int fin) {
     if (c.st->done) return;
     __shared__ uint32_t sh[4];
     uint32_t v = c.bsum[threadIdx.x], tot;
     uint32_t ex = block_excl_scan(v, tot, sh);
     c.bsum[threadIdx.x] = ex;
     if (threadIdx.x == 0) c.st->scan_total = tot;
+    if (!fin) return;
+    // start of segment B0 = number of entries of the new inner list: block offset + partial sum inside its chunk
+    __shared__ uint32_t sh_part[4];
+    VrgState& s = *c.st;
+    const uint32_t n = s.nscan, b0 = vrg_slot_B0(s, 0);
+    uint32_t chunk = (n + SCAN_BLOCKS - 1) / SCAN_BLOCKS;
+    chunk = (chunk + TPB - 1) / TPB * TPB;
+    uint32_t blk = chunk ? b0 / chunk : 0, lo = blk * chunk;
+    __syncthreads();
+    uint32_t part = 0;
+    for (uint32_t i = lo + threadIdx.x; i < b0 && i < n; i += TPB) part += a[i];
+    uint32_t ptot; block_excl_scan(part, ptot, sh_part);
+    if (threadIdx.x == 0) {
+        s.ni_new = (b0 < n) ? c.bsum[blk] + ptot : tot;
+        s.nb_new = tot;
+        if (tot > c.bcap) { s.error = 1; s.done = -1; }
+    }
 }
 __global__ void k_scan_down(VrgCtx c, uint32_t* a) {
     if (c.st->done) return;
@@ -257,10 +305,10 @@ __global__ void k_scan_down(VrgCtx c, uint32_t* a) {
         run += tot;
     }
 }
-void device_scan(const VrgCtx& c, uint32_t* a, hipStream_t st) {
+void device_scan(const VrgCtx& c, uint32_t* a, hipStream_t st, int fin) {
     static_assert(SCAN_BLOCKS == TPB, "k_scan_top scans one value per thread");
     k_scan_reduce<<<SCAN_BLOCKS, TPB, 0, st>>>(c, a);
-    k_scan_top<<<1, SCAN_BLOCKS, 0, st>>>(c);
+    k_scan_top<<<1, SCAN_BLOCKS, 0, st>>>(c, a, fin);
     k_scan_down<<<SCAN_BLOCKS, TPB, 0, st>>>(c, a);
 }
 
@@ -792,22 +840,10 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb,
         k_full_relabel<<<2048, TPB, 0, g_stream>>>(c);
         k_copy_back<<<2048, TPB, 0, g_stream>>>(c);
     }
-    // fork: stream B does the band bookkeeping (new lists, densities) ...
+    // fork point: labels are final for this sweep
     HIP_CHECK(hipEventRecord(g_ev_a, g_stream));
-    HIP_CHECK(hipStreamWaitEvent(g_stream_b, g_ev_a, 0));
-    k_entry_post<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
-    k_delta_flag<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
-    device_scan(c, c.lscan, g_stream_b);
-    k_post_prep<<<1, 1, 0, g_stream_b>>>(c);
-    k_delta_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
-    k_tab<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
-    device_scan(c, c.scan, g_stream_b);
-    k_fin_scan<<<1, 1, 0, g_stream_b>>>(c);
-    k_scatter_entry<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
-    k_scatter_promo<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
-    k_exact<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c, 1);
-    HIP_CHECK(hipEventRecord(g_ev_b, g_stream_b));
-    // ... while stream A streams every voxel once: the dense recount over the new labels (read-only)
+    // stream A streams every voxel once: the dense recount over the new labels (read-only).  It is enqueued
+    // BEFORE the bookkeeping chain so that its dispatch never waits for the host to issue those launches.
     EvPair* p = nullptr;
     if (ev && ev->enabled) {
         if (g_ev_used == g_ev_pool.size()) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); g_ev_pool.push_back(n); }
@@ -818,6 +854,21 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb,
     else k_recount<<<blocks, TPB, 0, g_stream>>>(c, 1);
     if (p) HIP_CHECK(hipEventRecord(p->b, g_stream));
     reduce_dense(c, cb, user);
+    // stream B, in the shadow of the recount: the band bookkeeping (new lists, densities)
+    HIP_CHECK(hipStreamWaitEvent(g_stream_b, g_ev_a, 0));
+    k_entry_post<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
+    if (c.L <= LEVELS_ONEBLOCK) k_levels_small<<<1, 1024, 0, g_stream_b>>>(c);
+    else {
+        k_delta_flag<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
+        device_scan(c, c.lscan, g_stream_b, 0);
+        k_post_prep<<<1, 1, 0, g_stream_b>>>(c);
+        k_delta_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
+    }
+    k_tab<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
+    device_scan(c, c.scan, g_stream_b, 1);
+    k_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
+    k_exact<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c, 1);
+    HIP_CHECK(hipEventRecord(g_ev_b, g_stream_b));
     // join
     HIP_CHECK(hipStreamWaitEvent(g_stream, g_ev_b, 0));
     k_finalize<<<1, 1, 0, g_stream>>>(c);
