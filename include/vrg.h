@@ -64,9 +64,15 @@ int vrg_create(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out)
 void vrg_destroy(vrg_handle* h);
 const char* vrg_last_error(const vrg_handle* h);
 
-/* Options (before vrg_init unless noted): "band_capacity", "sweep_variant" (0 marked streaming sweep,
- * 1 reference full-stencil sweep; any time), "events" (1: time every dense sweep launch with HIP
- * events; any time), "batch" (sweeps enqueued between host checks of the stop flag; any time). */
+/* Options (value 0/1 unless noted; before vrg_init unless "any time"):
+ *   "band_capacity"  entries reserved for the narrow band (default: all voxels up to 32 Mi, else max(32 Mi, V/8))
+ *   "storage16"      keep intensities as 16-bit level indices (needs <= 16384 distinct values): the dense
+ *                    pass streams 2 B instead of 4 B per voxel; results are bit-identical
+ *   "sweep_variant"  any time; 0 = relabel only the marked voxels (default), 1 = check variant that runs the
+ *                    label stencil on every voxel (slow; must give the same state)
+ *   "events"         any time; time every dense-pass launch with HIP events (vrg_result.sweep_kernel_ms)
+ *   "batch"          any time; sweeps enqueued between host checks of the stop flag (default 8)
+ *   "sweep_blocks", "prio_mode"   any time; launch tuning knobs of the dense pass / the two streams */
 int vrg_set_option(vrg_handle* h, const char* name, int64_t value);
 
 /* dataArray (:16): any VRG_* dtype; values must be exactly representable in fp32. */
