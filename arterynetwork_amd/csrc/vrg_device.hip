@@ -47,6 +47,7 @@ hipStream_t g_stream_b = nullptr;    // stream B: band bookkeeping, runs in the 
 hipEvent_t g_ev_a = nullptr, g_ev_b = nullptr;
 int g_sweep_blocks = 0;              // 0 = auto (dense_blocks)
 int g_prio_mode = 0;
+int g_use_graph_req = 0;
 ncclComm_t g_comm = nullptr;          // per-sweep all-reduce of the slab statistics (multi-GPU)
 
 // ---- wave / block primitives (wave = 64 lanes) -------------------------------------------------
@@ -672,6 +673,7 @@ static void make_streams() {
 }
 void be_set_tuning(const char* name, long long v) {
     if (std::strcmp(name, "sweep_blocks") == 0 && v >= 0 && v <= 4096) g_sweep_blocks = (int)v;
+    if (std::strcmp(name, "graph") == 0) g_use_graph_req = v != 0;
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != g_prio_mode) { g_prio_mode = (int)v; make_streams(); }
 }
 
@@ -826,7 +828,7 @@ void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
     k_fin_init<<<1, 1, 0, g_stream>>>(c);
 }
 
-void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb, void* user) {
+static void enqueue_sweep(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb, void* user) {
     const bool full = variant & 1;
     const int blocks = dense_blocks(c);
     // stream A: decide + flip list, marks + prepass, skip-rule fix-point, sparse relabel
@@ -872,6 +874,38 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb,
     // join
     HIP_CHECK(hipStreamWaitEvent(g_stream, g_ev_b, 0));
     k_finalize<<<1, 1, 0, g_stream>>>(c);
+}
+
+// One trip = ~15 dependent launches on two streams.  With option "graph" the trip is captured once into a
+// hipGraph (fork/join included) and replayed with a single host call per sweep.
+struct GraphCache { hipGraphExec_t exec = nullptr; VrgCtx key; int variant = -1; bool valid = false; };
+static GraphCache g_graph;
+#define g_use_graph g_use_graph_req
+
+void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb, void* user) {
+    const bool can_graph = g_use_graph && !(ev && ev->enabled) && !cb;
+    if (!can_graph) { enqueue_sweep(c, variant, ev, cb, user); return; }
+    if (!g_graph.valid || g_graph.variant != variant || std::memcmp(&g_graph.key, &c, sizeof(VrgCtx)) != 0) {
+        if (g_graph.exec) { (void)hipGraphExecDestroy(g_graph.exec); g_graph.exec = nullptr; }
+        g_graph.valid = false;
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(g_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+            enqueue_sweep(c, variant, nullptr, nullptr, nullptr);
+            ok = hipStreamEndCapture(g_stream, &graph) == hipSuccess && graph != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&g_graph.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) {                                   // capture not possible here: stay with eager launches
+            (void)hipGetLastError();
+            g_use_graph = 0;
+            std::fprintf(stderr, "vrg: hipGraph capture failed, falling back to eager launches\n");
+            enqueue_sweep(c, variant, ev, cb, user);
+            return;
+        }
+        std::memcpy(&g_graph.key, &c, sizeof(VrgCtx)); g_graph.variant = variant; g_graph.valid = true;
+    }
+    HIP_CHECK(hipGraphLaunch(g_graph.exec, g_stream));
 }
 
 void be_events_collect(VrgEvents* ev, long long n_valid) {

@@ -72,6 +72,8 @@ const char* vrg_last_error(const vrg_handle* h);
  *                    label stencil on every voxel (slow; must give the same state)
  *   "events"         any time; time every dense-pass launch with HIP events (vrg_result.sweep_kernel_ms)
  *   "batch"          any time; sweeps enqueued between host checks of the stop flag (default 8)
+ *   "graph"          any time; replay each sweep from one captured hipGraph (one host call per sweep; no
+ *                    per-launch events then)
  *   "sweep_blocks", "prio_mode"   any time; launch tuning knobs of the dense pass / the two streams */
 int vrg_set_option(vrg_handle* h, const char* name, int64_t value);
 

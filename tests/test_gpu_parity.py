@@ -357,3 +357,23 @@ def test_16bit_storage_identical(lib, golden_loader):
     with pytest.raises(VrgError):
         s.init(2.25)
     s.close()
+
+
+def test_graph_replay_identical(lib, golden_loader):
+    """Option "graph": each sweep replayed from one captured hipGraph (both streams) - same results."""
+    from arterynetwork_amd._capi import Session
+    g = golden_loader('adv_scattered')
+    data, vmap = g.inputs()
+    res, k = parity.run_stepwise(lib, data, vmap, g.H, g.maxSegmentSize, 200, density_mode=1, check_hist=True,
+                                 options={'graph': 1})
+    assert res is not None and k == g.ncalls - 1
+    g2 = golden_loader('config1_tube')
+    d2, v2 = g2.inputs()
+    s = Session(g2.shape, lib=lib)
+    s.set_option('graph', 1); s.set_option('batch', 16)
+    s.set_volume(d2); s.set_labels(v2); s.init(g2.H)
+    s.run(50, g2.maxSegmentSize, None)
+    assert np.array_equal(s.labels(), g2.z['final_labels'])
+    assert np.array_equal(parity.lex_of(s.segmented(), g2.shape), g2.z['final_segmented'])
+    s.set_option('graph', 0)
+    s.close()

@@ -13,5 +13,6 @@ for v in variants:
             print('variant', v, 'blocks', b, 'FAILED', out.stderr[-300:])
             continue
         d = json.loads(line[-1])
+        r = d['roofline']
         print('variant %3d blocks %5d  ms/step %.4f  kernel_ms %.4f  GB/s %7.1f  frac %.3f  value %.0f valid %s' % (
-            v, b, d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['achieved'], d['roofline']['frac'], d['value'], d['valid']), flush=True)
+            v, b, d['ms_per_step'], r['kernel_ms_avg'], r['achieved'] or 0, r['frac'] or 0, d['value'], d['valid']), flush=True)
