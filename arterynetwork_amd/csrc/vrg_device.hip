@@ -828,7 +828,8 @@ void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
     k_fin_init<<<1, 1, 0, g_stream>>>(c);
 }
 
-static void enqueue_sweep(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb, void* user) {
+// everything of one trip up to the join of the two streams (capturable: no collective, no host callback)
+static void enqueue_sweep(const VrgCtx& c, int variant, VrgEvents* ev) {
     const bool full = variant & 1;
     const int blocks = dense_blocks(c);
     // stream A: decide + flip list, marks + prepass, skip-rule fix-point, sparse relabel
@@ -855,7 +856,6 @@ static void enqueue_sweep(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce
     if (c.lev16) k_recount16<<<blocks, TPB, 0, g_stream>>>(c, 1);
     else k_recount<<<blocks, TPB, 0, g_stream>>>(c, 1);
     if (p) HIP_CHECK(hipEventRecord(p->b, g_stream));
-    reduce_dense(c, cb, user);
     // stream B, in the shadow of the recount: the band bookkeeping (new lists, densities)
     HIP_CHECK(hipStreamWaitEvent(g_stream_b, g_ev_a, 0));
     k_entry_post<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
@@ -873,39 +873,41 @@ static void enqueue_sweep(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce
     HIP_CHECK(hipEventRecord(g_ev_b, g_stream_b));
     // join
     HIP_CHECK(hipStreamWaitEvent(g_stream, g_ev_b, 0));
-    k_finalize<<<1, 1, 0, g_stream>>>(c);
 }
 
-// One trip = ~15 dependent launches on two streams.  With option "graph" the trip is captured once into a
-// hipGraph (fork/join included) and replayed with a single host call per sweep.
+// One trip = ~15 dependent launches on two streams.  With option "graph" everything up to the join is captured
+// once into a hipGraph (fork/join included) and replayed with a single host call; the slab all-reduce and
+// k_finalize follow eagerly, so nothing depends on RCCL supporting stream capture.
 struct GraphCache { hipGraphExec_t exec = nullptr; VrgCtx key; int variant = -1; bool valid = false; };
 static GraphCache g_graph;
 #define g_use_graph g_use_graph_req
 
 void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb, void* user) {
-    const bool can_graph = g_use_graph && !(ev && ev->enabled) && !cb;
-    if (!can_graph) { enqueue_sweep(c, variant, ev, cb, user); return; }
-    if (!g_graph.valid || g_graph.variant != variant || std::memcmp(&g_graph.key, &c, sizeof(VrgCtx)) != 0) {
-        if (g_graph.exec) { (void)hipGraphExecDestroy(g_graph.exec); g_graph.exec = nullptr; }
-        g_graph.valid = false;
-        hipGraph_t graph = nullptr;
-        bool ok = hipStreamBeginCapture(g_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
-        if (ok) {
-            enqueue_sweep(c, variant, nullptr, nullptr, nullptr);
-            ok = hipStreamEndCapture(g_stream, &graph) == hipSuccess && graph != nullptr;
+    bool replayed = false;
+    if (g_use_graph && !(ev && ev->enabled)) {
+        if (!g_graph.valid || g_graph.variant != variant || std::memcmp(&g_graph.key, &c, sizeof(VrgCtx)) != 0) {
+            if (g_graph.exec) { (void)hipGraphExecDestroy(g_graph.exec); g_graph.exec = nullptr; }
+            g_graph.valid = false;
+            hipGraph_t graph = nullptr;
+            bool ok = hipStreamBeginCapture(g_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+            if (ok) {
+                enqueue_sweep(c, variant, nullptr);
+                ok = hipStreamEndCapture(g_stream, &graph) == hipSuccess && graph != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&g_graph.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (ok) { std::memcpy(&g_graph.key, &c, sizeof(VrgCtx)); g_graph.variant = variant; g_graph.valid = true; }
+            else {                                   // capture not possible here: stay with eager launches
+                (void)hipGetLastError();
+                g_use_graph = 0;
+                std::fprintf(stderr, "vrg: hipGraph capture failed, falling back to eager launches\n");
+            }
         }
-        if (ok) ok = hipGraphInstantiate(&g_graph.exec, graph, nullptr, nullptr, 0) == hipSuccess;
-        if (graph) (void)hipGraphDestroy(graph);
-        if (!ok) {                                   // capture not possible here: stay with eager launches
-            (void)hipGetLastError();
-            g_use_graph = 0;
-            std::fprintf(stderr, "vrg: hipGraph capture failed, falling back to eager launches\n");
-            enqueue_sweep(c, variant, ev, cb, user);
-            return;
-        }
-        std::memcpy(&g_graph.key, &c, sizeof(VrgCtx)); g_graph.variant = variant; g_graph.valid = true;
+        if (g_graph.valid) { HIP_CHECK(hipGraphLaunch(g_graph.exec, g_stream)); replayed = true; }
     }
-    HIP_CHECK(hipGraphLaunch(g_graph.exec, g_stream));
+    if (!replayed) enqueue_sweep(c, variant, ev);
+    reduce_dense(c, cb, user);                       // sum over the Z-slabs (RCCL on the stream / host callback / nothing)
+    k_finalize<<<1, 1, 0, g_stream>>>(c);
 }
 
 void be_events_collect(VrgEvents* ev, long long n_valid) {
