@@ -11,5 +11,7 @@ t0 = int(rows[i0]['Start_Timestamp'])
 for r in rows[i0:i1 + 1]:
     s = int(r['Start_Timestamp']) - t0
     e = int(r['End_Timestamp']) - t0
-    name = r['Kernel_Name'].split('(')[0].split('::')[-1]
+    import re
+    m = re.search(r'(k_\w+|nccl\w*|rccl\w*)', r['Kernel_Name'])
+    name = m.group(1) if m else r['Kernel_Name'][:40]
     print('%8.1f %8.1f dur %7.1f  q=%s %s' % (s / 1e3, e / 1e3, (e - s) / 1e3, r.get('Queue_Id', '?'), name))
