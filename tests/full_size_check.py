@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Full-size (880x880x640) property check of the HIP path; run by tests/test_gpu_parity.py in its own process."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import torch                      # before the HIP library: see INTEGRATION.md (one ROCm runtime per process)
+import bench as B
+from arterynetwork_amd._capi import Session
+
+
+def check_invariants(labels):
+    seg = labels <= 1
+    pad = np.pad(labels, 1, constant_values=255)
+    nx, ny, nz = labels.shape
+    bad = 0
+    any_nonseg = np.zeros(labels.shape, bool)
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                if dx == dy == dz == 0:
+                    continue
+                nb = pad[1 + dx:1 + dx + nx, 1 + dy:1 + dy + ny, 1 + dz:1 + dz + nz]
+                bad += int(np.count_nonzero(seg & ((nb == 3) | (nb == 4))))
+                any_nonseg |= (nb >= 2) & (nb <= 4)
+    assert bad == 0
+    assert not np.any((labels == 0) & any_nonseg)
+
+
+def main():
+    shape = (880, 880, 640)
+    dev = torch.device('cuda', 0)
+    I, vm = B.make_volume_torch(shape, dev)
+    torch.cuda.synchronize()
+    s = Session(shape)
+    s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
+    s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
+    s.init(2.25)
+    r = s.run(60, 10 ** 12, None)
+    assert r.sweeps == 60 and r.stop_reason == 4
+    tr = s.trace()
+    assert np.all(np.diff(tr['nseg']) >= 0) and tr['nseg'][-1] > 2 * tr['nseg'][0]
+    vals, hin, hout, rin, rout = s.levels()
+    assert np.array_equal(hin, rin) and np.array_equal(hout, rout)        # incremental histograms == dense recount
+    assert int(hin.sum()) == tr['n_in'][-1] and int(hout.sum()) == tr['n_out'][-1]
+    lab = torch.empty((shape[2], shape[1], shape[0]), dtype=torch.uint8, device=dev).permute(2, 1, 0)
+    s._check(s.lib.get_labels(s._h, lab.data_ptr(), 0, (ctypes.c_int64 * 3)(*lab.stride())))
+    assert int((lab <= 1).sum()) == tr['n_in'][-1] == len(s.segmented())
+    assert int(((lab == 2) | (lab == 3)).sum()) == tr['n_out'][-1]
+    assert int((lab == 1).sum()) == tr['ni'][-1] and int((lab == 2).sum()) == tr['no'][-1]
+    assert abs(float(I[lab <= 1].double().sum()) - tr['sum_in'][-1]) <= 1e-9 * abs(tr['sum_in'][-1])
+    seg = s.segmented()
+    lo = np.maximum(seg.min(0) - 3, 0)
+    hi = np.minimum(seg.max(0) + 4, shape)
+    crop = lab[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].contiguous().cpu().numpy()
+    check_invariants(crop)
+    s.close()
+    print('FULL SIZE OK: nseg %d -> %d in 60 sweeps, band %d' % (tr['nseg'][0], tr['nseg'][-1], tr['ni'][-1] + tr['no'][-1]))
+
+
+if __name__ == '__main__':
+    main()

@@ -5,6 +5,7 @@ iteration number.  Floating point (band densities innerProb/outerProb, region in
 relative 1e-9 (north_star allows 1e-5).  Exact mathematical ties of the sign test (:87) are outside
 parity - the reference decides them by np.sum's rounding - and are detected and skipped.
 """
+import ctypes
 import io
 import contextlib
 
@@ -377,3 +378,13 @@ def test_graph_replay_identical(lib, golden_loader):
     assert np.array_equal(parity.lex_of(s.segmented(), g2.shape), g2.z['final_segmented'])
     s.set_option('graph', 0)
     s.close()
+
+
+def test_config3_full_size_properties():
+    """880x880x640 (the headline size), same torch-generated volume as bench.py: size-independent properties after
+    60 sweeps.  Runs tests/full_size_check.py in a fresh process that imports torch BEFORE the HIP library (torch
+    bundles its own ROCm runtime; whichever is loaded first serves both - see INTEGRATION.md)."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'full_size_check.py')], capture_output=True, text=True)
+    assert out.returncode == 0 and 'FULL SIZE OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
