@@ -6,6 +6,8 @@ is deterministic, so all ranks hold identical labels without exchanging halo pla
 per-sweep exchange is a 32-byte all-reduce of the region statistics {n_in, n_out, sum_in, sum_out},
 issued by the library on its own HIP stream through RCCL (vrg_comm_init) - or, for CPU tests and other
 transports, through a host callback (`reduce='callback'`, here torch.distributed.all_reduce).
+All ranks must make the same sequence of calls with the same arguments; use maxTime=None (a wall-clock cap
+would let ranks stop at different sweeps).
 """
 from __future__ import annotations
 
