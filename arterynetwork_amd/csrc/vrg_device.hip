@@ -79,6 +79,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
 
 // ---- item kernels ---------------------------------------------------------------------------------
 #define ITEM_LOOP(n) for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += gridDim.x * blockDim.x)
+// same with a 64-bit item index: (listed flips) x (positions) can exceed 2^32 on adversarial volumes
+#define ITEM_LOOP64(n) for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += (uint64_t)gridDim.x * blockDim.x)
 
 __global__ void k_decide(VrgCtx c) {                   // decide (:79-88) + listing of the flips
     if (c.st->done) return;
@@ -92,8 +94,8 @@ __global__ void k_marks_prepass(VrgCtx c) {
         if (blockIdx.x == 0 && threadIdx.x == 0) c.st->done = stop ? stop : -1;
         return;
     }
-    ITEM_LOOP(c.st->nf * 128u) {
-        uint32_t r = i >> 7, p = i & 127u;
+    ITEM_LOOP64((uint64_t)c.st->nf * 128u) {
+        uint32_t r = (uint32_t)(i >> 7), p = (uint32_t)(i & 127u);
         if (p < 125u) vrg_item_scatter_marks(c, r, p);
         else if (p == 125u) vrg_item_prepass(c, c.flist[r]);
     }
@@ -130,9 +132,9 @@ __global__ void k_entry_post(VrgCtx c) {
 __global__ void k_scatter(VrgCtx c) {                  // items: every old entry, then (listed flip, neighbour k)
     if (c.st->done) return;
     const uint32_t n = c.st->ni + c.st->no;
-    ITEM_LOOP(n + c.st->nf * 32u) {
-        if (i < n) vrg_item_scatter_entry(c, i);
-        else { uint32_t j = i - n; vrg_item_scatter_promo(c, j >> 5, j & 31u); }
+    ITEM_LOOP64((uint64_t)n + (uint64_t)c.st->nf * 32u) {
+        if (i < n) vrg_item_scatter_entry(c, (uint32_t)i);
+        else { uint64_t j = i - n; vrg_item_scatter_promo(c, (uint32_t)(j >> 5), (uint32_t)(j & 31u)); }
     }
 }
 
