@@ -388,3 +388,28 @@ def test_config3_full_size_properties():
     from conftest import ROOT
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'full_size_check.py')], capture_output=True, text=True)
     assert out.returncode == 0 and 'FULL SIZE OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_drop_in_messages_and_trace(golden_loader, capsys):
+    """Every exit path of the reference prints its own message (:94-104, :118-120); the wrapper prints the same."""
+    from arterynetwork_amd import variationalRegionGrowing
+    from oracle import vrg_oracle as O
+    # size stop: the reference's recorded stdout
+    g = golden_loader('border_size_stop')
+    data, vmap = g.inputs()
+    vm = vmap.copy()
+    seg, segMap, out = variationalRegionGrowing(data, vm, maxSegmentSize=g.maxSegmentSize)
+    assert capsys.readouterr().out == str(g.z['stdout'])
+    assert np.array_equal(out, g.z['final_labels']) and len(seg) == int(g.z['nseg'][-1])
+    # iteration cap: same text as the oracle's restatement of :118-120, and the trace hook
+    g = golden_loader('adv_shell')
+    data, vmap = g.inputs()
+    tr = []
+    vm1, vm2 = vmap.copy(), vmap.copy()
+    seg, _, _ = variationalRegionGrowing(data, vm1, maxSegmentSize=10 ** 9, iterMax=2, trace=tr)
+    mine = capsys.readouterr().out
+    O.variationalRegionGrowing(data, vm2, maxSegmentSize=10 ** 9, iterMax=2, maxTime=-1.0)
+    theirs = capsys.readouterr().out
+    assert mine == theirs and 'Max iteration reached! Finished at iteration 3' in mine
+    assert np.array_equal(vm1, vm2)
+    assert [t['nflip'] for t in tr] == [int(v) for v in g.z['nflip'][:3]] and tr[2]['nseg'] == int(g.z['nseg'][2])
