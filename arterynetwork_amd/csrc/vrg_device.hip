@@ -39,14 +39,17 @@ namespace {
 constexpr int TPB = 256;            // 4 waves of 64
 constexpr int ITEM_BLOCKS = 256;    // band kernels: 64 Ki threads, grid-stride
 constexpr int SCAN_BLOCKS = 256;
-constexpr int SWEEP_BLOCKS = 512;   // 2 workgroups per CU on 256 CUs: measured best for the HBM-bound recount while
-                                    // stream B's band kernels run beside it (384-512: 0.430 ms, 1024: 0.475, 2048: 0.512)
+constexpr int SWEEP_BLOCKS = 256;   // 1 workgroup (4 waves) per CU, each wave with 3 KiB of labels + 12 KiB of intensities in
+                                    // flight: measured best for the HBM-bound recount while stream B's band kernels run beside
+                                    // it (880x880x640: 256 -> 0.38 ms, 192/384 -> 0.42-0.43, 320 -> 0.49, 512 -> 0.40, 1024 -> 0.44)
 
 hipStream_t g_stream = nullptr;      // stream A: decide -> relabel -> dense recount (the critical path), copies
 hipStream_t g_stream_b = nullptr;    // stream B: band bookkeeping, runs in the shadow of the recount (high priority)
 hipEvent_t g_ev_a = nullptr, g_ev_b = nullptr;
 int g_sweep_blocks = 0;              // 0 = auto (dense_blocks)
 int g_prio_mode = 0;
+int g_recount_mode = 5;              // dense recount shape: 0 = 1 unit/trip, plain loads; 1 = 1 unit nt; 2 = 2 units;
+                                     // 3 = 2 units nt; 4 = 4 units nt; 5 = 3 units nt (default, fastest measured)
 int g_use_graph_req = 0;
 ncclComm_t g_comm = nullptr;          // per-sweep all-reduce of the slab statistics (multi-GPU)
 
@@ -323,6 +326,7 @@ void device_scan(const VrgCtx& c, uint32_t* a, hipStream_t st, int fin) {
 // 256-B (labels) or 1-KiB (intensities) request.  Sums are reduced lane -> wave butterfly -> LDS -> one
 // slot per workgroup, added in fixed slot order by the last workgroup to finish: bit-reproducible.
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 
 struct SweepAcc { long long nin, nout; double sin_, sout; };
 
@@ -381,6 +385,9 @@ __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a) {
     }
 }
 
+// UNITS = 1-KiB units a wave loads per trip (bytes in flight), NT = non-temporal loads: the volume is read
+// once per sweep and is far larger than the 256-MiB Infinity Cache, so nothing is worth keeping.
+template <int UNITS, bool NT>
 __global__ void __launch_bounds__(TPB) k_recount(VrgCtx c, int check_done) {
     if (check_done && c.st->done) return;
     const uint8_t* __restrict__ in = c.lab[0];
@@ -392,21 +399,28 @@ __global__ void __launch_bounds__(TPB) k_recount(VrgCtx c, int check_done) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     SweepAcc acc = {0, 0, 0.0, 0.0};
-    for (uint32_t u = wave; u < nfull; u += nwaves) {
-        const uint32_t base = first + (u << 10) + (lane << 2);
-        uint32_t w[4]; f4v f[4];
+    uint32_t u = wave * UNITS;
+    for (; u + UNITS <= nfull; u += nwaves * UNITS) {
+        uint32_t w[4 * UNITS]; f4v f[4 * UNITS];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            w[j] = *reinterpret_cast<const uint32_t*>(in + base + (j << 8));
-            f[j] = *reinterpret_cast<const f4v*>(I + base + (j << 8));
+        for (int q = 0; q < UNITS; q++) {
+            const uint32_t base = first + ((u + q) << 10) + (lane << 2);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t* pl = reinterpret_cast<const uint32_t*>(in + base + (j << 8));
+                const f4v* pi = reinterpret_cast<const f4v*>(I + base + (j << 8));
+                w[4 * q + j] = NT ? __builtin_nontemporal_load(pl) : *pl;
+                f[4 * q + j] = NT ? __builtin_nontemporal_load(pi) : *pi;
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) sweep_stats(acc, w[j], f[j]);
+        for (int j = 0; j < 4 * UNITS; j++) sweep_stats(acc, w[j], f[j]);
     }
-    if (wave == nwaves - 1 && (total & 1023u)) {            // tail unit (< 1 KiB), predicated per lane
+    // remainder: whole units left over by the UNITS-stride (at most UNITS-1 per wave) and the tail unit (< 1 KiB)
+    for (; u < nfull + ((total & 1023u) ? 1u : 0u); u++) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            uint32_t off = (nfull << 10) + (j << 8) + (lane << 2);
+            uint32_t off = (u << 10) + (j << 8) + (lane << 2);
             if (off < total)
                 sweep_stats(acc, *reinterpret_cast<const uint32_t*>(in + first + off), *reinterpret_cast<const f4v*>(I + first + off));
         }
@@ -417,6 +431,7 @@ __global__ void __launch_bounds__(TPB) k_recount(VrgCtx c, int check_done) {
 // 16-bit storage variant: 2 B level index + 1 B label per voxel; the level values sit in LDS (<= 16384 x f32).
 // Same unit / lane mapping, so the sums are added in the same order as in k_recount (bit-identical results).
 constexpr uint32_t LEV16_MAX = 16384;
+template <int UNITS, bool NT>
 __global__ void __launch_bounds__(TPB) k_recount16(VrgCtx c, int check_done) {
     if (check_done && c.st->done) return;
     __shared__ float s_val[LEV16_MAX];
@@ -431,26 +446,32 @@ __global__ void __launch_bounds__(TPB) k_recount16(VrgCtx c, int check_done) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     SweepAcc acc = {0, 0, 0.0, 0.0};
-    for (uint32_t u = wave; u < nfull; u += nwaves) {
-        const uint32_t base = first + (u << 10) + (lane << 2);
-        uint32_t w[4]; uint2 q[4];
+    uint32_t u = wave * UNITS;
+    for (; u + UNITS <= nfull; u += nwaves * UNITS) {
+        uint32_t w[4 * UNITS]; u2v q[4 * UNITS];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            w[j] = *reinterpret_cast<const uint32_t*>(in + base + (j << 8));
-            q[j] = *reinterpret_cast<const uint2*>(lv + base + (j << 8));
+        for (int k = 0; k < UNITS; k++) {
+            const uint32_t base = first + ((u + k) << 10) + (lane << 2);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t* pl = reinterpret_cast<const uint32_t*>(in + base + (j << 8));
+                const u2v* pq = reinterpret_cast<const u2v*>(lv + base + (j << 8));
+                w[4 * k + j] = NT ? __builtin_nontemporal_load(pl) : *pl;
+                q[4 * k + j] = NT ? __builtin_nontemporal_load(pq) : *pq;
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < 4 * UNITS; j++) {
             f4v f = {s_val[q[j].x & 0xffffu], s_val[q[j].x >> 16], s_val[q[j].y & 0xffffu], s_val[q[j].y >> 16]};
             sweep_stats(acc, w[j], f);
         }
     }
-    if (wave == nwaves - 1 && (total & 1023u)) {
+    for (; u < nfull + ((total & 1023u) ? 1u : 0u); u++) {     // leftover whole units of this wave + the tail unit
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            uint32_t off = (nfull << 10) + (j << 8) + (lane << 2);
+            uint32_t off = (u << 10) + (j << 8) + (lane << 2);
             if (off < total) {
-                uint2 q = *reinterpret_cast<const uint2*>(lv + first + off);
+                u2v q = *reinterpret_cast<const u2v*>(lv + first + off);
                 f4v f = {s_val[q.x & 0xffffu], s_val[q.x >> 16], s_val[q.y & 0xffffu], s_val[q.y >> 16]};
                 sweep_stats(acc, *reinterpret_cast<const uint32_t*>(in + first + off), f);
             }
@@ -650,11 +671,12 @@ int voxel_blocks(const VrgCtx& c) {
     return (int)std::min<uint64_t>(4096, (V + TPB - 1) / TPB);
 }
 
-// workgroups of the dense recount: >= 32 one-KiB units per wave, at most 2 workgroups per CU
+// workgroups of the dense recount: >= 32 one-KiB units per wave, at most 1 workgroup per CU
 int dense_blocks(const VrgCtx& c) {
     if (g_sweep_blocks > 0) return g_sweep_blocks;
     uint64_t units = ((uint64_t)(c.z1 - c.z0) * c.PY * c.PX) >> 10;
-    return (int)std::min<uint64_t>(SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128));
+    // the 16-bit variant spends issue slots on LDS table look-ups and wants twice the waves (512: 0.275 ms, 256: 0.335)
+    return (int)std::min<uint64_t>(c.lev16 ? 2 * SWEEP_BLOCKS : SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128));
 }
 
 struct EvPair { hipEvent_t a, b; };
@@ -676,6 +698,7 @@ static void make_streams() {
 void be_set_tuning(const char* name, long long v) {
     if (std::strcmp(name, "sweep_blocks") == 0 && v >= 0 && v <= 4096) g_sweep_blocks = (int)v;
     if (std::strcmp(name, "graph") == 0) g_use_graph_req = v != 0;
+    if (std::strcmp(name, "recount_mode") == 0 && v >= 0 && v <= 5) g_recount_mode = (int)v;
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != g_prio_mode) { g_prio_mode = (int)v; make_streams(); }
 }
 
@@ -819,13 +842,28 @@ int be_comm_init(int nranks, int rank, const void* id128) {
     return ncclCommInitRank(&g_comm, nranks, id, rank) == ncclSuccess ? 0 : -1;
 }
 
+static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t st) {
+    if (c.lev16) {
+        if (g_recount_mode == 0) k_recount16<1, false><<<blocks, TPB, 0, st>>>(c, check);
+        else k_recount16<3, true><<<blocks, TPB, 0, st>>>(c, check);
+        return;
+    }
+    switch (g_recount_mode) {
+        case 1: k_recount<1, true><<<blocks, TPB, 0, st>>>(c, check); break;
+        case 2: k_recount<2, false><<<blocks, TPB, 0, st>>>(c, check); break;
+        case 3: k_recount<2, true><<<blocks, TPB, 0, st>>>(c, check); break;
+        case 4: k_recount<4, true><<<blocks, TPB, 0, st>>>(c, check); break;
+        case 5: k_recount<3, true><<<blocks, TPB, 0, st>>>(c, check); break;
+        default: k_recount<1, false><<<blocks, TPB, 0, st>>>(c, check); break;
+    }
+}
+
 void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
     k_init_entry<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     if (c.L <= HIST_LDS_LEVELS) k_hist_lds<<<1024, TPB, 0, g_stream>>>(c);
     else k_hist_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
     k_exact<<<1024, TPB, 0, g_stream>>>(c, 0);
-    if (c.lev16) k_recount16<<<dense_blocks(c), TPB, 0, g_stream>>>(c, 0);
-    else k_recount<<<dense_blocks(c), TPB, 0, g_stream>>>(c, 0);
+    launch_recount(c, dense_blocks(c), 0, g_stream);
     reduce_dense(c, cb, user);
     k_fin_init<<<1, 1, 0, g_stream>>>(c);
 }
@@ -855,8 +893,7 @@ static void enqueue_sweep(const VrgCtx& c, int variant, VrgEvents* ev) {
         p = &g_ev_pool[g_ev_used++];
         HIP_CHECK(hipEventRecord(p->a, g_stream));
     }
-    if (c.lev16) k_recount16<<<blocks, TPB, 0, g_stream>>>(c, 1);
-    else k_recount<<<blocks, TPB, 0, g_stream>>>(c, 1);
+    launch_recount(c, blocks, 1, g_stream);
     if (p) HIP_CHECK(hipEventRecord(p->b, g_stream));
     // stream B, in the shadow of the recount: the band bookkeeping (new lists, densities)
     HIP_CHECK(hipStreamWaitEvent(g_stream_b, g_ev_a, 0));

@@ -121,6 +121,7 @@ def main():
     ap.add_argument('--variant', type=int, default=0)
     ap.add_argument('--sweep-blocks', type=int, default=0)
     ap.add_argument('--prio-mode', type=int, default=-1)
+    ap.add_argument('--recount-mode', type=int, default=-1)
     ap.add_argument('--graph', type=int, default=0, help='replay each sweep from a captured hipGraph (no per-launch HIP events then)')
     ap.add_argument('--storage16', action='store_true', help='16-bit intensity storage (level indices): config 5 style; 4 B/voxel-iter algorithmic')
     ap.add_argument('--force-dist', action='store_true', help='use the N>1 code path (RCCL comm) even with one rank')
@@ -164,6 +165,8 @@ def main():
         s.set_option('sweep_blocks', args.sweep_blocks)
     if args.prio_mode >= 0:
         s.set_option('prio_mode', args.prio_mode)
+    if args.recount_mode >= 0:
+        s.set_option('recount_mode', args.recount_mode)
     if args.storage16:
         s.set_option('storage16', 1)
     s.set_option('events', 0 if args.graph else 1)
