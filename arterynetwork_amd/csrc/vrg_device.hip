@@ -126,8 +126,10 @@ __global__ void k_relabel(VrgCtx c) {
 }
 __global__ void k_apply(VrgCtx c) {
     if (c.st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) vrg_request_dense(c);
     ITEM_LOOP(min(c.st->nmk, c.mcap)) vrg_item_apply(c, i);
 }
+__global__ void k_dense_fin(VrgCtx c) { vrg_dense_fin(c); }
 __global__ void k_entry_post(VrgCtx c) {
     if (c.st->done) return;
     ITEM_LOOP(c.st->ni + c.st->no) vrg_item_entry_post(c, i);
@@ -248,10 +250,8 @@ __global__ void k_finalize(VrgCtx c) {                // iterNum += 1 (:117) + t
     VrgState& s = *c.st;
     s.ni = s.ni_new; s.no = s.nb_new - s.ni_new; s.iter++;
     if ((uint32_t)s.iter < c.trace_cap) {
-        VrgTrace& t = c.trace[s.iter];
-        const VrgDense& d = *c.dn;
-        t.nflip = s.nf; t.nseg = (int64_t)d.n_in; t.n_in = (int64_t)d.n_in; t.n_out = (int64_t)d.n_out; t.ni = s.ni; t.no = s.no;
-        t.sum_in = d.sum_in; t.sum_out = d.sum_out;
+        VrgTrace& t = c.trace[s.iter];                    // the intensity sums are filed by the dense pass (vrg_dense_fin)
+        t.nflip = s.nf; t.nseg = c.inc[VC_NIN]; t.n_in = c.inc[VC_NIN]; t.n_out = c.inc[VC_NOUT]; t.ni = s.ni; t.no = s.no;
     }
     s.nf = 0; s.npend = 0; s.nmk = 0; s.nfresh = 0;
     if (s.error) s.done = -1;
@@ -382,6 +382,7 @@ __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a) {
         d.sum_out = ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3];
         *c.dn_part = d;                              // slab partials: input of the all-reduce
         if (c.world == 1) *c.dn = d;
+        c.dctl[VD_NIN] = c.inc[VC_NIN]; c.dctl[VD_NOUT] = c.inc[VC_NOUT];   // the sizes these totals must reproduce
     }
 }
 
@@ -389,7 +390,7 @@ __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a) {
 // once per sweep and is far larger than the 256-MiB Infinity Cache, so nothing is worth keeping.
 template <int UNITS, bool NT>
 __global__ void __launch_bounds__(TPB) k_recount(VrgCtx c, int check_done) {
-    if (check_done && c.st->done) return;
+    if (check_done && !vrg_dense_due(c)) return;     // no sweep was applied since the last pass (stop flag)
     const uint8_t* __restrict__ in = c.lab[0];
     const float* __restrict__ I = c.I;
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
@@ -433,7 +434,7 @@ __global__ void __launch_bounds__(TPB) k_recount(VrgCtx c, int check_done) {
 constexpr uint32_t LEV16_MAX = 16384;
 template <int UNITS, bool NT>
 __global__ void __launch_bounds__(TPB) k_recount16(VrgCtx c, int check_done) {
-    if (check_done && c.st->done) return;
+    if (check_done && !vrg_dense_due(c)) return;     // no sweep was applied since the last pass (stop flag)
     __shared__ float s_val[LEV16_MAX];
     for (uint32_t i = threadIdx.x; i < c.L; i += TPB) s_val[i] = (float)c.lev[i];
     __syncthreads();
@@ -509,7 +510,15 @@ __global__ void __launch_bounds__(TPB) k_copy_back(VrgCtx c) {
     const uint4* __restrict__ src = reinterpret_cast<const uint4*>(c.lab[1] + 2u * plane);
     uint4* __restrict__ dst = reinterpret_cast<uint4*>(c.lab[0] + 2u * plane);
     const uint32_t n16 = (uint32_t)(((uint64_t)c.nz * plane) >> 4);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) vrg_request_dense(c);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) {
+        uint4 a = src[i], b = dst[i];
+        if (a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w) {
+            const uint32_t nw[4] = {a.x, a.y, a.z, a.w}, od[4] = {b.x, b.y, b.z, b.w};
+            for (int k = 0; k < 16; k++) vrg_count_change(c, (uint8_t)(od[k >> 2] >> (8 * (k & 3))), (uint8_t)(nw[k >> 2] >> (8 * (k & 3))));
+            dst[i] = a;
+        }
+    }
 }
 
 // ---- dense helpers over the real voxels -------------------------------------------------------------
@@ -568,6 +577,7 @@ __global__ void k_init_entry(VrgCtx c) {
 __global__ void k_fin_init(VrgCtx c) {
     VrgState& s = *c.st;
     s.nfresh = 0; s.nf = 0; s.npend = 0; s.nmk = 0;
+    vrg_init_counts(c);
     const VrgDense& d = *c.dn;
     VrgTrace& t = c.trace[0];
     t.nflip = 0; t.nseg = (int64_t)d.n_in; t.n_in = (int64_t)d.n_in; t.n_out = (int64_t)d.n_out; t.ni = s.ni; t.no = s.no;
@@ -946,6 +956,7 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb,
     }
     if (!replayed) enqueue_sweep(c, variant, ev);
     reduce_dense(c, cb, user);                       // sum over the Z-slabs (RCCL on the stream / host callback / nothing)
+    k_dense_fin<<<1, 1, 0, g_stream>>>(c);
     k_finalize<<<1, 1, 0, g_stream>>>(c);
 }
 

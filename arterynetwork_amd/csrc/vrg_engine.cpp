@@ -52,7 +52,12 @@ template <class T> T* alloc(vrg_handle* h, size_t n) {
     return (T*)p;
 }
 
-VrgDense get_dense(vrg_handle* h) { VrgDense d; be_download(&d, h->c.dn, sizeof(d)); return d; }
+VrgDense get_dense(vrg_handle* h) {     // region sizes as the band side keeps them + the sums of the last dense pass
+    VrgDense d; be_download(&d, h->c.dn, sizeof(d));
+    int64_t n[2]; be_download(n, h->c.inc, sizeof(n));
+    d.n_in = (double)n[0]; d.n_out = (double)n[1];
+    return d;
+}
 VrgState get_state(vrg_handle* h) { VrgState s; be_download(&s, h->c.st, sizeof(s)); return s; }
 void put_state(vrg_handle* h, const VrgState& s) { be_upload(h->c.st, &s, sizeof(s)); }
 
@@ -100,8 +105,10 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.dn = alloc<VrgDense>(h, 16);                   // own allocation: written by the dense kernel only
     c.counters = alloc<uint32_t>(h, 64);
     c.dn_part = alloc<VrgDense>(h, 16);
+    c.inc = alloc<int64_t>(h, 32); c.dctl = alloc<int64_t>(h, 32);   // one allocation each: written from different streams
     c.world = 1;
-    if (!c.I || !c.lab[0] || !c.lab[1] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part) { API(destroy)(h); return VRG_E_MEM; }
+    if (!c.I || !c.lab[0] || !c.lab[1] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.inc || !c.dctl) { API(destroy)(h); return VRG_E_MEM; }
+    be_fill(c.inc, 0, 32 * sizeof(int64_t)); be_fill(c.dctl, 0, 32 * sizeof(int64_t));
     be_fill((void*)c.I, 0, (size_t)c.PV * 4);
     be_fill(h->lab_base[0], VB_OOB, (size_t)c.PV + 32);
     be_fill(h->lab_base[1], VB_OOB, (size_t)c.PV + 32);
@@ -269,6 +276,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     }
     be_sync();
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    s = get_state(h);                                // the dense stream may have raised its cross-check error last
     rc = check_state_error(h, s);
     if (rc) return rc;
     if (out) {

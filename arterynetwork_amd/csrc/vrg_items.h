@@ -34,6 +34,7 @@
 VRG_HD uint32_t vrg_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 VRG_HD int32_t vrg_atomic_add(int32_t* p, int32_t v) { return atomicAdd(p, v); }
 VRG_HD uint32_t vrg_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
+VRG_HD void vrg_atomic_add64(int64_t* p, int64_t v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 VRG_HD uint8_t vrg_load_coherent(const uint8_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -41,6 +42,7 @@ VRG_HD uint8_t vrg_load_coherent(const uint8_t* p) {
 VRG_HD uint32_t vrg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 VRG_HD int32_t vrg_atomic_add(int32_t* p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
 VRG_HD uint32_t vrg_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+VRG_HD void vrg_atomic_add64(int64_t* p, int64_t v) { *p += v; }
 VRG_HD uint8_t vrg_load_coherent(const uint8_t* p) { return *(const volatile uint8_t*)p; }
 #endif
 
@@ -99,15 +101,15 @@ VRG_HD void vrg_item_decide(const VrgCtx& c, uint32_t e) {
     VrgState& s = *c.st;
     if (s.iter >= s.iterMax) return;                      // while iterNum <= iterMax (:58)
     int cur = s.iter & 1;
-    double inN = c.b_ip[cur][e] / c.dn->n_in;             // :81
-    double outN = c.b_op[cur][e] / c.dn->n_out;           // :82
+    double inN = c.b_ip[cur][e] / (double)c.inc[VC_NIN];  // :81
+    double outN = c.b_op[cur][e] / (double)c.inc[VC_NOUT];// :82
     bool ge = inN >= outN;
     bool inner = e < s.ni;
     bool flip = inner != ge;                              // :87 xor(segmentedMap, inner >= outer)
     c.e_flag[e] = flip ? 1 : 0; c.e_res[e] = 0; c.e_mask[e] = 0;
     if (!flip) return;
     uint32_t q = vrg_atomic_add(&s.nf, 1u);
-    if (s.time_up || c.dn->n_in >= (double)s.maxSegmentSize) return;   // :97 / :101 fire before update(): count only
+    if (s.time_up || c.inc[VC_NIN] >= s.maxSegmentSize) return;   // :97 / :101 fire before update(): count only
     if (q >= c.fcap) { s.error = 2; return; }
     c.flist[q] = e;
     uint32_t idx = c.b_idx[cur][e];
@@ -121,7 +123,7 @@ VRG_HD int32_t vrg_stop_test(const VrgCtx& c) {
     if (s.iter >= s.iterMax) return VRG_STOP_ITERMAX;                    // :58
     if (s.nf == 0) return VRG_STOP_CONVERGED;                            // :91
     if (s.time_up) return VRG_STOP_TIME;                                 // :97
-    if (c.dn->n_in >= (double)s.maxSegmentSize) return VRG_STOP_SIZE;    // :101
+    if (c.inc[VC_NIN] >= s.maxSegmentSize) return VRG_STOP_SIZE;           // :101
     return 0;
 }
 
@@ -188,7 +190,36 @@ VRG_HD void vrg_item_relabel(const VrgCtx& c, uint32_t i) {
     c.mk_new[i] = vrg_sweep_core(c, c.lab[0], idx, c.lab[0][idx]);
 }
 // phase 2: write the new bytes (this also clears the L / P / mark bits)
-VRG_HD void vrg_item_apply(const VrgCtx& c, uint32_t i) { c.lab[0][c.mk_idx[i]] = c.mk_new[i]; }
+// ... and keep the region sizes (:113-116) in step: inner = S, outer = neither S nor excluded
+VRG_HD void vrg_count_change(const VrgCtx& c, uint8_t old, uint8_t nw) {
+    int din = (int)((nw & VB_S) != 0) - (int)((old & VB_S) != 0);
+    int dout = (int)((nw & (VB_S | VB_X | VB_OOB)) == 0) - (int)((old & (VB_S | VB_X | VB_OOB)) == 0);
+    if (din) vrg_atomic_add64(&c.inc[VC_NIN], din);
+    if (dout) vrg_atomic_add64(&c.inc[VC_NOUT], dout);
+}
+VRG_HD void vrg_item_apply(const VrgCtx& c, uint32_t i) {
+    uint32_t idx = c.mk_idx[i];
+    uint8_t old = c.lab[0][idx], nw = c.mk_new[i];
+    c.lab[0][idx] = nw;
+    vrg_count_change(c, old, nw);
+}
+// one caller per applied sweep: the labels of sweep iter+1 are in place, a dense pass over them is due
+VRG_HD void vrg_request_dense(const VrgCtx& c) { c.inc[VC_REQ] = (int64_t)c.st->iter + 1; }
+VRG_HD bool vrg_dense_due(const VrgCtx& c) { return c.inc[VC_REQ] > c.dctl[VD_SEQ]; }
+// the dense pass has the totals in c.dn: cross-check the sizes it had to reproduce, file the sums, close the pass
+VRG_HD void vrg_dense_fin(const VrgCtx& c) {
+    if (!vrg_dense_due(c)) return;
+    int64_t seq = c.dctl[VD_SEQ] + 1;
+    const VrgDense& d = *c.dn;
+    if ((int64_t)d.n_in != c.dctl[VD_NIN] || (int64_t)d.n_out != c.dctl[VD_NOUT]) c.st->error = 5;
+    if ((uint64_t)seq < c.trace_cap) { c.trace[seq].sum_in = d.sum_in; c.trace[seq].sum_out = d.sum_out; }
+    c.dctl[VD_SEQ] = seq;
+}
+// init: the dense pass founds the incremental sizes
+VRG_HD void vrg_init_counts(const VrgCtx& c) {
+    c.inc[VC_NIN] = (int64_t)c.dn->n_in; c.inc[VC_NOUT] = (int64_t)c.dn->n_out; c.inc[VC_REQ] = 0;
+    c.dctl[VD_SEQ] = 0; c.dctl[VD_NIN] = c.inc[VC_NIN]; c.dctl[VD_NOUT] = c.inc[VC_NOUT];
+}
 
 // ------------------------------------------------------------------ the relabel stencil for one voxel
 // phase-B promotion (3 -> 2, :210-213): list key (first applied flip-in neighbour, k)

@@ -62,11 +62,18 @@ struct VrgState {
     int32_t use_tab;     // this sweep's density corrections are memoised per intensity level (tabC)
 };
 
-// results of the dense recount; written by the dense stream only (own allocation, own cache lines)
+// results of the dense recount; written by the dense stream only (own allocation, own cache lines).
+// The dense pass of sweep k runs on its own stream while the band kernels already prepare sweep k+1: the region
+// SIZES the next decisions need (:81-82, :101) are integers and follow exactly from the labels the sparse relabel
+// changed (VrgCtx::inc); the dense pass recounts them from all voxels, must agree (else error 5), and supplies the
+// intensity sums.
 struct VrgDense {            // all four as double so one all-reduce sums them over the Z-slabs (counts < 2^53: exact)
     double n_in, n_out;      // region sizes (:51-52, :115-116)
     double sum_in, sum_out;  // sums of intensities over the two regions
 };
+
+enum { VC_NIN = 0, VC_NOUT = 1, VC_REQ = 2 };     // VrgCtx::inc
+enum { VD_SEQ = 0, VD_NIN = 1, VD_NOUT = 2 };     // VrgCtx::dctl
 
 struct VrgCtx {
     int32_t nx, ny, nz;
@@ -119,6 +126,10 @@ struct VrgCtx {
     VrgState* st;
     VrgDense* dn;              // global region statistics (sum over all Z-slabs)
     VrgDense* dn_part;         // this device's slab partials (input of the all-reduce)
+    int64_t* inc;              // band side (own cache line): region sizes kept by increments as labels are applied -
+                               // what the decisions and stop tests read - and the sweep number of the last apply
+    int64_t* dctl;             // dense side (own cache line): dense passes closed since init, and the region sizes
+                               // the pass in flight has to reproduce
     int32_t world;             // number of slabs / ranks (1: dn is written directly)
     uint32_t* counters;        // arrival tickets of the last-workgroup reductions (zero between launches)
     VrgTrace* trace;

@@ -131,6 +131,7 @@ static void dense_stats(const VrgCtx& c, const uint8_t* lab, be_reduce_fn cb, vo
     p.n_in = (double)a; p.n_out = (double)b; p.sum_in = sa; p.sum_out = sb;
     *c.dn = p;
     if (cb) cb(&c.dn->n_in, user);
+    c.dctl[VD_NIN] = c.inc[VC_NIN]; c.dctl[VD_NOUT] = c.inc[VC_NOUT];
 }
 
 void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
@@ -141,6 +142,7 @@ void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
     for (uint32_t i = 0; i < n; i++) vrg_exact_serial(c, 0, c.fresh[i]);
     dense_stats(c, c.lab[0], cb, user);
     s.nfresh = 0;
+    vrg_init_counts(c);
     const VrgDense& d = *c.dn;
     VrgTrace& t = c.trace[0];
     t.nflip = 0; t.nseg = (int64_t)d.n_in; t.n_in = (int64_t)d.n_in; t.n_out = (int64_t)d.n_out; t.ni = s.ni; t.no = s.no;
@@ -174,9 +176,11 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*, be_reduce_fn cb, vo
     } else {
         // full-stencil check variant: every voxel, through the scratch volume
         for_real_voxels(c, [&](uint32_t idx, int, int, int) { c.lab[1][idx] = vrg_sweep_core(c, lab, idx, lab[idx]); });
-        for_real_voxels(c, [&](uint32_t idx, int, int, int) { lab[idx] = c.lab[1][idx]; });
+        for_real_voxels(c, [&](uint32_t idx, int, int, int) { vrg_count_change(c, lab[idx], c.lab[1][idx]); lab[idx] = c.lab[1][idx]; });
     }
-    dense_stats(c, lab, cb, user);          // the dense recount (:113-116)
+    vrg_request_dense(c);
+    dense_stats(c, lab, cb, user);          // the dense recount (:113-116) ...
+    vrg_dense_fin(c);                       // ... cross-checks the incremental sizes and files the sums
     // band bookkeeping
     for (uint32_t e = 0; e < n; e++) vrg_item_entry_post(c, e);
     s.nnz = 0;
@@ -204,10 +208,8 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*, be_reduce_fn cb, vo
     // iterNum += 1 (:117) and the trace record of this update() call
     s.ni = s.ni_new; s.no = s.nb_new - s.ni_new; s.iter++;
     if ((uint32_t)s.iter < c.trace_cap) {
-        const VrgDense& d = *c.dn;
         VrgTrace& t = c.trace[s.iter];
-        t.nflip = s.nf; t.nseg = (int64_t)d.n_in; t.n_in = (int64_t)d.n_in; t.n_out = (int64_t)d.n_out; t.ni = s.ni; t.no = s.no;
-        t.sum_in = d.sum_in; t.sum_out = d.sum_out;
+        t.nflip = s.nf; t.nseg = c.inc[VC_NIN]; t.n_in = c.inc[VC_NIN]; t.n_out = c.inc[VC_NOUT]; t.ni = s.ni; t.no = s.no;
     }
     s.nf = 0; s.npend = 0; s.nmk = 0; s.nfresh = 0;
     if (s.error) s.done = -1;
