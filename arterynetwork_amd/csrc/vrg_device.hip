@@ -3,12 +3,16 @@
 // One while-loop trip of variationalRegionGrowing.py:58-117 (be_sweep_once), two HIP streams:
 //   stream A, band kernels (O(band) work, grid-stride over device-resident counts, no host round trip):
 //     k_decide (+listing) -> k_marks_prepass (stop tests, marks, skip-rule prepass) -> k_fix
-//     -> k_relabel (3x3x3 / 5x5x5 label stencil on the marked voxels, old labels only) -> k_apply
-//     -> k_recount : the dense kernel (every voxel, HBM-bound, read-only: 4 B intensity + 1 B label per
-//        voxel): region sizes and intensity sums (:113-116, :249-250), reduced by its last workgroup
-//   stream B (forked after k_apply, high priority, runs in the shadow of k_recount):
-//     k_entry_post, k_levels_small (level-delta compaction), k_tab, rebuild scan, k_scatter, k_exact;
-//   join, k_finalize closes the trip.
+//     -> k_relabel (3x3x3 / 5x5x5 label stencil on the marked voxels, old labels only)
+//     -> k_apply (writes the new labels, keeps the region sizes in step)
+//     -> k_entry_post, k_levels_small (level-delta compaction), k_tab, rebuild scan, k_scatter, k_exact
+//     -> k_finalize closes the trip;
+//   stream B, the dense pass, forked after k_apply:
+//     k_recount : the dense kernel (every voxel, HBM-bound, read-only: 4 B intensity + 1 B label per voxel):
+//        region sizes and intensity sums (:113-116, :249-250), reduced by its last workgroup
+//     -> slab all-reduce (multi-GPU) -> k_dense_fin (cross-check against the incremental sizes, trace sums).
+//   Stream A does not join: it goes on with the next trip up to k_relabel and only k_apply waits for the
+//   recount of the previous trip (see be_sweep_once).
 // Labels are updated IN PLACE: measured on MI355X, streaming I + labels read-only runs at 5.8-6.0 TB/s
 // while the same stream with a 1 B/voxel label write-back drops to 4.8 TB/s, so unchanged labels are
 // never rewritten.  (The full-stencil check variant relabels every voxel through lab[1].)
@@ -43,9 +47,12 @@ constexpr int SWEEP_BLOCKS = 256;   // 1 workgroup (4 waves) per CU, each wave w
                                     // flight: measured best for the HBM-bound recount while stream B's band kernels run beside
                                     // it (880x880x640: 256 -> 0.38 ms, 192/384 -> 0.42-0.43, 320 -> 0.49, 512 -> 0.40, 1024 -> 0.44)
 
-hipStream_t g_stream = nullptr;      // stream A: decide -> relabel -> dense recount (the critical path), copies
-hipStream_t g_stream_b = nullptr;    // stream B: band bookkeeping, runs in the shadow of the recount (high priority)
-hipEvent_t g_ev_a = nullptr, g_ev_b = nullptr;
+hipStream_t g_stream = nullptr;      // stream A: the band kernels of every trip in program order, copies
+hipStream_t g_stream_b = nullptr;    // stream B: the dense pass (recount, slab all-reduce, k_dense_fin); trails stream A by up to one sweep
+hipEvent_t g_ev_a = nullptr, g_ev_d = nullptr;   // labels applied (A -> B) / labels read by the dense pass (B -> A)
+hipEvent_t g_last_read = nullptr;                // the "labels read" event of the latest dense pass
+hipEvent_t g_ev_r = nullptr;                     // new labels computed (A -> B), when stream B applies them
+int g_apply_stream = 0;              // 0: by slab size; 1: k_apply on stream A; 2: on stream B
 int g_sweep_blocks = 0;              // 0 = auto (dense_blocks)
 int g_prio_mode = 0;
 int g_recount_mode = 5;              // dense recount shape: 0 = 1 unit/trip, plain loads; 1 = 1 unit nt; 2 = 2 units;
@@ -343,7 +350,7 @@ __device__ __forceinline__ void sweep_stats(SweepAcc& a, uint32_t v, f4v f) {
 }
 // per-workgroup slot, then the LAST workgroup to arrive adds all slots in slot order and publishes the
 // totals (agent-scope release before the ticket, acquire after it: cdna guide, Guideline 16)
-__device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a) {
+__device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a, int fin) {
     __shared__ long long sh_n[2][4];
     __shared__ double sh_s[2][4];
     __shared__ int is_last;
@@ -383,6 +390,7 @@ __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a) {
         *c.dn_part = d;                              // slab partials: input of the all-reduce
         if (c.world == 1) *c.dn = d;
         c.dctl[VD_NIN] = c.inc[VC_NIN]; c.dctl[VD_NOUT] = c.inc[VC_NOUT];   // the sizes these totals must reproduce
+        if (fin && c.world == 1) vrg_dense_fin(c);
     }
 }
 
@@ -426,7 +434,7 @@ __global__ void __launch_bounds__(TPB) k_recount(VrgCtx c, int check_done) {
                 sweep_stats(acc, *reinterpret_cast<const uint32_t*>(in + first + off), *reinterpret_cast<const f4v*>(I + first + off));
         }
     }
-    sweep_finish(c, acc);
+    sweep_finish(c, acc, check_done);
 }
 
 // 16-bit storage variant: 2 B level index + 1 B label per voxel; the level values sit in LDS (<= 16384 x f32).
@@ -478,7 +486,7 @@ __global__ void __launch_bounds__(TPB) k_recount16(VrgCtx c, int check_done) {
             }
         }
     }
-    sweep_finish(c, acc);
+    sweep_finish(c, acc, check_done);
 }
 
 // full-stencil check variant: every voxel runs the relabel stencil (no marks); new bytes go to lab[1]
@@ -708,6 +716,7 @@ static void make_streams() {
 void be_set_tuning(const char* name, long long v) {
     if (std::strcmp(name, "sweep_blocks") == 0 && v >= 0 && v <= 4096) g_sweep_blocks = (int)v;
     if (std::strcmp(name, "graph") == 0) g_use_graph_req = v != 0;
+    if (std::strcmp(name, "apply_stream") == 0 && v >= 0 && v <= 2) g_apply_stream = (int)v;
     if (std::strcmp(name, "recount_mode") == 0 && v >= 0 && v <= 5) g_recount_mode = (int)v;
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != g_prio_mode) { g_prio_mode = (int)v; make_streams(); }
 }
@@ -719,7 +728,8 @@ int be_set_device(int device) {
     if (!g_stream) {
         make_streams();
         HIP_CHECK(hipEventCreateWithFlags(&g_ev_a, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&g_ev_b, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&g_ev_d, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&g_ev_r, hipEventDisableTiming));
     }
     return 0;
 }
@@ -828,7 +838,7 @@ void be_init_sort(const VrgCtx& c, uint32_t n_in, uint32_t n_out) {
 }
 
 // sum the slab statistics over the ranks: RCCL on the stream, or the host callback (synchronises)
-static void reduce_dense(const VrgCtx& c, be_reduce_fn cb, void* user) {
+static void reduce_dense(const VrgCtx& c, be_reduce_fn cb, void* user, hipStream_t g_stream) {
     if (g_comm) {
         ncclResult_t r = ncclAllReduce(c.dn_part, c.dn, 4, ncclDouble, ncclSum, g_comm, g_stream);
         if (r != ncclSuccess) std::fprintf(stderr, "RCCL all-reduce failed: %s\n", ncclGetErrorString(r));
@@ -874,94 +884,123 @@ void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
     else k_hist_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
     k_exact<<<1024, TPB, 0, g_stream>>>(c, 0);
     launch_recount(c, dense_blocks(c), 0, g_stream);
-    reduce_dense(c, cb, user);
+    reduce_dense(c, cb, user, g_stream);
     k_fin_init<<<1, 1, 0, g_stream>>>(c);
 }
 
-// everything of one trip up to the join of the two streams (capturable: no collective, no host callback)
-static void enqueue_sweep(const VrgCtx& c, int variant, VrgEvents* ev) {
-    const bool full = variant & 1;
-    const int blocks = dense_blocks(c);
-    // stream A: decide + flip list, marks + prepass, skip-rule fix-point, sparse relabel
+// ---- one sweep ------------------------------------------------------------------------------------------
+// Stream A ("band") carries every sparse kernel in program order; stream B ("dense") carries the recount, the
+// slab all-reduce and k_dense_fin.  The only edges between them:
+//   apply(k)   waits for recount(k-1)   (g_ev_d: the dense pass has finished reading the labels apply(k) rewrites)
+//   recount(k) waits for apply(k)       (g_ev_a)
+// so while the dense pass of sweep k streams the volume, stream A already runs the bookkeeping of sweep k and
+// decide .. relabel of sweep k+1 (these read the labels and OR the L/P/M bits only - never S or X, which is all
+// the recount looks at; the region sizes they need come from VrgCtx::inc).
+static void enqueue_pre(const VrgCtx& c, int variant) {         // decide + flip list, marks + prepass, fix-point, relabel
     k_decide<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     k_marks_prepass<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     k_fix<<<1, 1024, 0, g_stream>>>(c);
-    if (!full) {
-        k_relabel<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-        k_apply<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    } else {
-        k_full_relabel<<<2048, TPB, 0, g_stream>>>(c);
-        k_copy_back<<<2048, TPB, 0, g_stream>>>(c);
-    }
-    // fork point: labels are final for this sweep
-    HIP_CHECK(hipEventRecord(g_ev_a, g_stream));
-    // stream A streams every voxel once: the dense recount over the new labels (read-only).  It is enqueued
-    // BEFORE the bookkeeping chain so that its dispatch never waits for the host to issue those launches.
-    EvPair* p = nullptr;
-    if (ev && ev->enabled) {
-        if (g_ev_used == g_ev_pool.size()) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); g_ev_pool.push_back(n); }
-        p = &g_ev_pool[g_ev_used++];
-        HIP_CHECK(hipEventRecord(p->a, g_stream));
-    }
-    launch_recount(c, blocks, 1, g_stream);
-    if (p) HIP_CHECK(hipEventRecord(p->b, g_stream));
-    // stream B, in the shadow of the recount: the band bookkeeping (new lists, densities)
-    HIP_CHECK(hipStreamWaitEvent(g_stream_b, g_ev_a, 0));
-    k_entry_post<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
-    if (c.L <= LEVELS_ONEBLOCK) k_levels_small<<<1, 1024, 0, g_stream_b>>>(c);
+    if (!(variant & 1)) k_relabel<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    else k_full_relabel<<<2048, TPB, 0, g_stream>>>(c);
+}
+static void enqueue_post(const VrgCtx& c) {                     // band bookkeeping (new lists, densities), iterNum += 1
+    k_entry_post<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    if (c.L <= LEVELS_ONEBLOCK) k_levels_small<<<1, 1024, 0, g_stream>>>(c);
     else {
-        k_delta_flag<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
-        device_scan(c, c.lscan, g_stream_b, 0);
-        k_post_prep<<<1, 1, 0, g_stream_b>>>(c);
-        k_delta_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
+        k_delta_flag<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+        device_scan(c, c.lscan, g_stream, 0);
+        k_post_prep<<<1, 1, 0, g_stream>>>(c);
+        k_delta_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     }
-    k_tab<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
-    device_scan(c, c.scan, g_stream_b, 1);
-    k_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c);
-    k_exact<<<ITEM_BLOCKS, TPB, 0, g_stream_b>>>(c, 1);
-    HIP_CHECK(hipEventRecord(g_ev_b, g_stream_b));
-    // join
-    HIP_CHECK(hipStreamWaitEvent(g_stream, g_ev_b, 0));
+    k_tab<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    device_scan(c, c.scan, g_stream, 1);
+    k_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    k_exact<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c, 1);
+    k_finalize<<<1, 1, 0, g_stream>>>(c);
 }
 
-// One trip = ~15 dependent launches on two streams.  With option "graph" everything up to the join is captured
-// once into a hipGraph (fork/join included) and replayed with a single host call; the slab all-reduce and
-// k_finalize follow eagerly, so nothing depends on RCCL supporting stream capture.
+// With option "graph" the two runs of band kernels are replayed from captured hipGraphs (one host call each);
+// apply, the event edges, the recount and the collective stay eager, so nothing depends on RCCL supporting
+// stream capture and the per-launch HIP-event timing of the recount keeps working.
 struct GraphCache { hipGraphExec_t exec = nullptr; VrgCtx key; int variant = -1; bool valid = false; };
-static GraphCache g_graph;
+static GraphCache g_graph_pre, g_graph_post;
 #define g_use_graph g_use_graph_req
 
-void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb, void* user) {
-    bool replayed = false;
-    if (g_use_graph && !(ev && ev->enabled)) {
-        if (!g_graph.valid || g_graph.variant != variant || std::memcmp(&g_graph.key, &c, sizeof(VrgCtx)) != 0) {
-            if (g_graph.exec) { (void)hipGraphExecDestroy(g_graph.exec); g_graph.exec = nullptr; }
-            g_graph.valid = false;
+template <class F> static void run_band(GraphCache& g, const VrgCtx& c, int variant, F&& enqueue) {
+    if (g_use_graph) {
+        if (!g.valid || g.variant != variant || std::memcmp(&g.key, &c, sizeof(VrgCtx)) != 0) {
+            if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+            g.valid = false;
             hipGraph_t graph = nullptr;
             bool ok = hipStreamBeginCapture(g_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
             if (ok) {
-                enqueue_sweep(c, variant, nullptr);
+                enqueue();
                 ok = hipStreamEndCapture(g_stream, &graph) == hipSuccess && graph != nullptr;
             }
-            if (ok) ok = hipGraphInstantiate(&g_graph.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (ok) ok = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess;
             if (graph) (void)hipGraphDestroy(graph);
-            if (ok) { std::memcpy(&g_graph.key, &c, sizeof(VrgCtx)); g_graph.variant = variant; g_graph.valid = true; }
+            if (ok) { std::memcpy(&g.key, &c, sizeof(VrgCtx)); g.variant = variant; g.valid = true; }
             else {                                   // capture not possible here: stay with eager launches
                 (void)hipGetLastError();
                 g_use_graph = 0;
                 std::fprintf(stderr, "vrg: hipGraph capture failed, falling back to eager launches\n");
             }
         }
-        if (g_graph.valid) { HIP_CHECK(hipGraphLaunch(g_graph.exec, g_stream)); replayed = true; }
+        if (g.valid) { HIP_CHECK(hipGraphLaunch(g.exec, g_stream)); return; }
     }
-    if (!replayed) enqueue_sweep(c, variant, ev);
-    reduce_dense(c, cb, user);                       // sum over the Z-slabs (RCCL on the stream / host callback / nothing)
-    k_dense_fin<<<1, 1, 0, g_stream>>>(c);
-    k_finalize<<<1, 1, 0, g_stream>>>(c);
+    enqueue();
+}
+
+// Which stream applies the labels decides where the two cross-stream hops (an event wait costs ~15 us here) fall:
+//   dense-bound (one GPU, big volume): k_apply runs on stream B between two recounts, so B never waits - its
+//     edge from A (k_relabel done) was satisfied long ago - and A takes both hops inside its slack;
+//   band-bound (small slab per GPU): k_apply stays on stream A, which then never waits for B in practice.
+static bool apply_on_dense_stream(const VrgCtx& c) {
+    if (g_apply_stream) return g_apply_stream == 2;
+    return (uint64_t)(c.z1 - c.z0) * c.PY * c.PX >= (160ull << 20);   // recount ~ as long as the band chain (~0.11 ms)
+}
+
+void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb, void* user) {
+    const bool on_b = apply_on_dense_stream(c);
+    hipStream_t sa = on_b ? g_stream_b : g_stream;
+    // every event record / wait is a barrier packet of a few us on its stream: the two timing events of the recount
+    // double as the edges "labels applied" and "labels read"
+    hipEvent_t e_applied = g_ev_a, e_read = g_ev_d, e_start = nullptr;
+    if (ev && ev->enabled) {
+        if (g_ev_used == g_ev_pool.size()) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); g_ev_pool.push_back(n); }
+        EvPair& p = g_ev_pool[g_ev_used++];
+        e_read = p.b;
+        if (on_b) e_applied = p.a; else e_start = p.a;
+    }
+    run_band(g_graph_pre, c, variant, [&] { enqueue_pre(c, variant); });
+    if (on_b) {
+        HIP_CHECK(hipEventRecord(g_ev_r, g_stream));
+        HIP_CHECK(hipStreamWaitEvent(g_stream_b, g_ev_r, 0));
+    } else if (g_last_read) {
+        // the labels change now: the previous dense pass must have read them
+        HIP_CHECK(hipStreamWaitEvent(g_stream, g_last_read, 0));
+    }
+    if (!(variant & 1)) k_apply<<<ITEM_BLOCKS, TPB, 0, sa>>>(c);
+    else k_copy_back<<<2048, TPB, 0, sa>>>(c);
+    HIP_CHECK(hipEventRecord(e_applied, sa));
+    // dense stream: every voxel once, read-only.  Enqueued before the bookkeeping so that its dispatch never waits
+    // for the host to issue those launches.
+    if (!on_b) HIP_CHECK(hipStreamWaitEvent(g_stream_b, e_applied, 0));
+    if (e_start) HIP_CHECK(hipEventRecord(e_start, g_stream_b));
+    launch_recount(c, dense_blocks(c), 1, g_stream_b);
+    HIP_CHECK(hipEventRecord(e_read, g_stream_b));
+    g_last_read = e_read;
+    if (c.world > 1) {                               // one GPU: the last workgroup of the recount closes the pass itself
+        reduce_dense(c, cb, user, g_stream_b);       // sum over the Z-slabs (RCCL on the stream / host callback)
+        k_dense_fin<<<1, 1, 0, g_stream_b>>>(c);
+    }
+    if (on_b) HIP_CHECK(hipStreamWaitEvent(g_stream, e_applied, 0));
+    run_band(g_graph_post, c, 0, [&] { enqueue_post(c); });
 }
 
 void be_events_collect(VrgEvents* ev, long long n_valid) {
     if (!ev) return;
+    if (g_ev_used) HIP_CHECK(hipStreamSynchronize(g_stream_b));   // the dense stream may trail the band stream by one pass
     for (size_t i = 0; i < g_ev_used; i++) {
         if ((long long)i < n_valid) {
             float ms = 0;

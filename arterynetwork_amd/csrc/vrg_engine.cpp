@@ -136,7 +136,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "sweep_variant") h->variant = (int)value;
     else if (n == "events") h->ev.enabled = value != 0;
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
-    else if (n == "sweep_blocks" || n == "prio_mode" || n == "graph" || n == "recount_mode") be_set_tuning(name, value);
+    else if (n == "sweep_blocks" || n == "prio_mode" || n == "graph" || n == "recount_mode" || n == "apply_stream") be_set_tuning(name, value);
     else if (n == "storage16") { if (h->inited) return fail(h, VRG_E_STATE, "storage16 must be set before vrg_init"); h->storage16 = value != 0; }
     else return fail(h, VRG_E_ARG, "unknown option " + n);
     return VRG_OK;

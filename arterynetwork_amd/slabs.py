@@ -82,9 +82,11 @@ def bench_slabs(shape, args, dev, rank, world):
     if args.sweep_blocks:
         s.set_option('sweep_blocks', args.sweep_blocks)
     use_graph = int(getattr(args, 'graph', 1) or (world > 1))
-    s.set_option('events', 0 if use_graph else 1)
-    s.set_option('graph', use_graph)           # one host call per sweep: at 8 ranks the step is ~0.1 ms, close to the
-    s.set_option('batch', 64)                  # cost of issuing its ~25 launches one by one
+    s.set_option('events', 1)
+    s.set_option('graph', use_graph)           # band kernels replayed from two hipGraphs: at 8 ranks the step is ~0.1 ms,
+    s.set_option('batch', 64)                  # close to the cost of issuing its ~25 launches one by one
+    if getattr(args, 'apply_stream', -1) >= 0:
+        s.set_option('apply_stream', args.apply_stream)
     s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
     s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
     s.init(args.H)
@@ -97,12 +99,7 @@ def bench_slabs(shape, args, dev, rank, world):
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
-    if use_graph:                              # graph replay carries no per-launch events: time the dense kernel on the
-        s.set_option('graph', 0)               # next 50 sweeps, launched eagerly with HIP events
-        s.set_option('events', 1)
-        rk = s.run(args.warmup + args.steps + 50, big, None)
-    else:
-        rk = r
+    rk = r
     t = torch.tensor([dt, rk.sweep_kernel_ms / max(1, rk.sweep_launches)], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max, kern_ms = float(t[0]), float(t[1])
@@ -120,7 +117,7 @@ def bench_slabs(shape, args, dev, rank, world):
                                'voxels), H={}, {} incremental VRG sweeps'.format(args.shape, args.levels, args.H, r.sweeps),
                    'parallelism': 'zslab{} (dense recount sharded into {} Z-slabs, band relabel replicated, one '
                                   '32-byte RCCL all-reduce per sweep)'.format(world, world),
-                   'reduction': s.reduce_mode, 'launch': 'hipGraph replay (kernel_ms from the 50 eager sweeps after the timed region)' if use_graph else 'eager', 'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1])},
+                   'reduction': s.reduce_mode, 'launch': 'band kernels from hipGraph replay' if use_graph else 'eager', 'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1])},
         'roofline': B.roofline(slab_vox, kern_ms, int(rk.sweep_launches), None),
     }
     s.close()
