@@ -54,7 +54,7 @@ hipEvent_t g_last_read = nullptr;                // the "labels read" event of t
 hipEvent_t g_ev_r = nullptr;                     // new labels computed (A -> B), when stream B applies them
 int g_apply_stream = 0;              // 0: by slab size; 1: k_apply on stream A; 2: on stream B
 int g_sweep_blocks = 0;              // 0 = auto (dense_blocks)
-int g_prio_mode = 0;
+int g_prio_mode = 2;                 // the dense stream gets the higher priority (measured: -1..2 % step time)
 int g_recount_mode = 5;              // dense recount shape: 0 = 1 unit/trip, plain loads; 1 = 1 unit nt; 2 = 2 units;
                                      // 3 = 2 units nt; 4 = 4 units nt; 5 = 3 units nt (default, fastest measured)
 int g_use_graph_req = 0;
@@ -390,7 +390,7 @@ __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a, int fi
         *c.dn_part = d;                              // slab partials: input of the all-reduce
         if (c.world == 1) *c.dn = d;
         c.dctl[VD_NIN] = c.inc[VC_NIN]; c.dctl[VD_NOUT] = c.inc[VC_NOUT];   // the sizes these totals must reproduce
-        if (fin && c.world == 1) vrg_dense_fin(c);
+        if (fin == 2) vrg_dense_fin(c);              // nothing to sum over ranks: close the pass here
     }
 }
 
@@ -987,10 +987,11 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb,
     // for the host to issue those launches.
     if (!on_b) HIP_CHECK(hipStreamWaitEvent(g_stream_b, e_applied, 0));
     if (e_start) HIP_CHECK(hipEventRecord(e_start, g_stream_b));
-    launch_recount(c, dense_blocks(c), 1, g_stream_b);
+    const bool ranks = c.world > 1 || g_comm || cb;
+    launch_recount(c, dense_blocks(c), ranks ? 1 : 2, g_stream_b);
     HIP_CHECK(hipEventRecord(e_read, g_stream_b));
     g_last_read = e_read;
-    if (c.world > 1) {                               // one GPU: the last workgroup of the recount closes the pass itself
+    if (ranks) {                                     // one GPU: the last workgroup of the recount closes the pass itself
         reduce_dense(c, cb, user, g_stream_b);       // sum over the Z-slabs (RCCL on the stream / host callback)
         k_dense_fin<<<1, 1, 0, g_stream_b>>>(c);
     }

@@ -81,7 +81,7 @@ def bench_slabs(shape, args, dev, rank, world):
     s = make_slab_session(shape, rank, world, device=dev.index, reduce='rccl-always')
     if args.sweep_blocks:
         s.set_option('sweep_blocks', args.sweep_blocks)
-    use_graph = int(getattr(args, 'graph', 1) or (world > 1))
+    use_graph = int(getattr(args, 'graph', 0))
     s.set_option('events', 1)
     s.set_option('graph', use_graph)           # band kernels replayed from two hipGraphs: at 8 ranks the step is ~0.1 ms,
     s.set_option('batch', 64)                  # close to the cost of issuing its ~25 launches one by one

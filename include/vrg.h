@@ -72,9 +72,9 @@ const char* vrg_last_error(const vrg_handle* h);
  *                    label stencil on every voxel (slow; must give the same state)
  *   "events"         any time; time every dense-pass launch with HIP events (vrg_result.sweep_kernel_ms)
  *   "batch"          any time; sweeps enqueued between host checks of the stop flag (default 8)
- *   "graph"          any time; replay each sweep from one captured hipGraph (one host call per sweep; no
- *                    per-launch events then)
- *   "sweep_blocks", "prio_mode"   any time; launch tuning knobs of the dense pass / the two streams */
+ *   "graph"          any time; replay the band kernels of each sweep from two captured hipGraphs
+ *   "sweep_blocks", "recount_mode", "prio_mode", "apply_stream"
+ *                    any time; launch tuning knobs of the dense pass / the two streams (0 = automatic) */
 int vrg_set_option(vrg_handle* h, const char* name, int64_t value);
 
 /* dataArray (:16): any VRG_* dtype; values must be exactly representable in fp32. */
@@ -108,7 +108,9 @@ int vrg_get_levels(vrg_handle* h, double* values, int32_t* hist_in, int32_t* his
  * Every rank holds the label volume and applies the O(band) relabel identically (it is deterministic),
  * so no label halo has to travel; the O(V) per-sweep work - the dense region recount - is cut into
  * Z-slabs: this handle recounts planes [z0, z1) only and the partial region statistics are summed over
- * the ranks once per sweep, either by RCCL on the device stream (vrg_comm_init) or by a host callback. */
+ * the ranks once per sweep, either by RCCL on the dense stream (vrg_comm_init) or by a host callback.  The
+ * decisions never wait for that sum: region sizes are kept by increments on every rank and the summed recount
+ * only has to reproduce them (a mismatch surfaces as VRG_E_INTERNAL). */
 int vrg_set_slab(vrg_handle* h, int64_t z0, int64_t z1);
 /* RCCL: rank 0 obtains a 128-byte id and the caller broadcasts it (e.g. torch.distributed); every rank
  * then calls vrg_comm_init (collective). */

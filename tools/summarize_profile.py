@@ -13,7 +13,7 @@ def short(name):
         return 'torch elementwise (synthetic volume generation)'
     return name.replace('(anonymous namespace)::', '').replace('void ', '')
 
-st = glob.glob(src + '/trace/*/*kernel_stats.csv')[0]
+st = max(glob.glob(src + '/trace/*/*kernel_stats.csv'), key=os.path.getmtime)   # gpurun merges runs: newest wins
 agg = {}
 for r in csv.DictReader(open(st)):
     k = short(r['Name'])
@@ -27,7 +27,7 @@ with open('profiles/%s_kernel_stats.csv' % tag, 'w') as f:
         f.write('"%s",%d,%d,%.1f,%.3f\n' % (k, a[0], a[1], a[1] / a[0], 100.0 * a[1] / tot))
 
 def pmc(dirname, counter):
-    f = glob.glob(src + '/' + dirname + '/*/*counter_collection.csv')[0]
+    f = max(glob.glob(src + '/' + dirname + '/*/*counter_collection.csv'), key=os.path.getmtime)
     vals = []
     for r in csv.DictReader(open(f)):
         if 'k_recount' in r['Kernel_Name'] and r['Counter_Name'] == counter:
