@@ -55,7 +55,7 @@ hipEvent_t g_ev_r = nullptr;                     // new labels computed (A -> B)
 int g_apply_stream = 0;              // 0: by slab size; 1: k_apply on stream A; 2: on stream B
 int g_sweep_blocks = 0;              // 0 = auto (dense_blocks)
 int g_prio_mode = 2;                 // the dense stream gets the higher priority (measured: -1..2 % step time)
-int g_recount_mode = 5;              // dense recount shape: 0 = 1 unit/trip, plain loads; 1 = 1 unit nt; 2 = 2 units;
+int g_recount_mode = 6;              // dense recount shape: 0 = 1 unit/trip, plain loads; 1 = 1 unit nt; 2 = 2 units;
                                      // 3 = 2 units nt; 4 = 4 units nt; 5 = 3 units nt (default, fastest measured)
 int g_use_graph_req = 0;
 ncclComm_t g_comm = nullptr;          // per-sweep all-reduce of the slab statistics (multi-GPU)
@@ -489,6 +489,89 @@ __global__ void __launch_bounds__(TPB) k_recount16(VrgCtx c, int check_done) {
     sweep_finish(c, acc, check_done);
 }
 
+// Class-bit variants (the default): the recount needs two facts per voxel - inner / outer - so it streams the
+// 2-bit class volume (VrgCtx::cls, 0.25 B/voxel) instead of the label bytes: 4.25 B (fp32 storage) or 2.25 B
+// (16-bit storage) per voxel.  Units are 1024-voxel aligned in the absolute voxel index; lane l owns class dword l
+// of a unit and the 4 x 4 intensities at 256*j + 4*l, i.e. one 256-B + four 1-KiB (or 512-B) requests per wave
+// and unit.  A slab edge that cuts a unit is handled by masking (first / last wave); padding planes are class 0.
+__device__ __forceinline__ void stats_bits(SweepAcc& a, uint32_t w, const f4v* f) {
+    a.nin += __popc(w & 0x55555555u); a.nout += __popc(w & 0xAAAAAAAAu);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            uint32_t t = w >> (2 * (4 * j + b));
+            double x = (double)f[j][b];
+            a.sin_ += (t & 1u) ? x : 0.0;
+            a.sout += (t & 2u) ? x : 0.0;
+        }
+}
+template <bool L16, bool NT>
+__device__ __forceinline__ void load_unit(const VrgCtx& c, const float* s_val, uint32_t u, uint32_t lane, uint32_t& w, f4v* f) {
+    const uint32_t* pc = c.cls + ((size_t)u << 6) + lane;
+    w = NT ? __builtin_nontemporal_load(pc) : *pc;
+    const uint32_t base = (u << 10) + (lane << 2);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (L16) {
+            const u2v* pq = reinterpret_cast<const u2v*>(c.lev16 + base + (j << 8));
+            u2v q = NT ? __builtin_nontemporal_load(pq) : *pq;
+            f[j] = f4v{s_val[q.x & 0xffffu], s_val[q.x >> 16], s_val[q.y & 0xffffu], s_val[q.y >> 16]};
+        } else {
+            const f4v* pi = reinterpret_cast<const f4v*>(c.I + base + (j << 8));
+            f[j] = NT ? __builtin_nontemporal_load(pi) : *pi;
+        }
+    }
+}
+template <int UNITS, bool NT, bool L16>
+__global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) {
+    if (check_done && !vrg_dense_due(c)) return;     // no sweep was applied since the last pass (stop flag)
+    __shared__ float s_val[L16 ? LEV16_MAX : 1];
+    if (L16) {
+        for (uint32_t i = threadIdx.x; i < c.L; i += TPB) s_val[i] = (float)c.lev[i];
+        __syncthreads();
+    }
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
+    const uint32_t lo = (2u + (uint32_t)c.z0) * plane;         // this device's Z-slab [z0, z1) as a voxel range
+    const uint32_t hi = (2u + (uint32_t)c.z1) * plane;
+    uint32_t f_lo = (lo + 1023u) >> 10, f_hi = hi >> 10;       // units wholly inside it
+    if (f_hi < f_lo) f_hi = f_lo;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    SweepAcc acc = {0, 0, 0.0, 0.0};
+    uint32_t u = f_lo + wave * UNITS;
+    for (; u + UNITS <= f_hi; u += nwaves * UNITS) {
+        uint32_t w[UNITS]; f4v f[UNITS][4];
+#pragma unroll
+        for (int q = 0; q < UNITS; q++) load_unit<L16, NT>(c, s_val, u + q, lane, w[q], f[q]);
+#pragma unroll
+        for (int q = 0; q < UNITS; q++) stats_bits(acc, w[q], f[q]);
+    }
+    for (; u < f_hi; u++) {                                    // whole units left over by the UNITS-stride
+        uint32_t w; f4v f[4];
+        load_unit<L16, false>(c, s_val, u, lane, w, f);
+        stats_bits(acc, w, f);
+    }
+    // units the slab edges cut: the first and the last unit touching [lo, hi), masked to the slab
+    const uint32_t e0 = lo >> 10, e1 = (hi - 1u) >> 10;
+    const uint32_t edge = wave == 0 ? e0 : (wave == nwaves - 1 && e1 != e0 ? e1 : 0xffffffffu);
+    if (edge != 0xffffffffu && !(edge >= f_lo && edge < f_hi)) {
+        uint32_t w; f4v f[4];
+        load_unit<L16, false>(c, s_val, edge, lane, w, f);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t v = (edge << 10) + (j << 8) + (lane << 2);        // groups of 4 voxels never straddle a plane
+            if (v < lo || v >= hi) w &= ~(0xffu << (8 * j));
+        }
+        stats_bits(acc, w, f);
+    }
+    sweep_finish(c, acc, check_done);
+}
+__global__ void k_cls_build(VrgCtx c) {
+    const uint32_t nd = ((c.PV + 1023u) >> 10) << 6;
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < nd; d += gridDim.x * blockDim.x) vrg_item_cls_build(c, d);
+}
+
 // full-stencil check variant: every voxel runs the relabel stencil (no marks); new bytes go to lab[1]
 // and are copied back, so stencil reads only ever see pre-sweep labels.
 __global__ void __launch_bounds__(TPB) k_full_relabel(VrgCtx c) {
@@ -523,7 +606,7 @@ __global__ void __launch_bounds__(TPB) k_copy_back(VrgCtx c) {
         uint4 a = src[i], b = dst[i];
         if (a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w) {
             const uint32_t nw[4] = {a.x, a.y, a.z, a.w}, od[4] = {b.x, b.y, b.z, b.w};
-            for (int k = 0; k < 16; k++) vrg_count_change(c, (uint8_t)(od[k >> 2] >> (8 * (k & 3))), (uint8_t)(nw[k >> 2] >> (8 * (k & 3))));
+            for (int k = 0; k < 16; k++) vrg_count_change(c, 2u * plane + 16u * i + (uint32_t)k, (uint8_t)(od[k >> 2] >> (8 * (k & 3))), (uint8_t)(nw[k >> 2] >> (8 * (k & 3))));
             dst[i] = a;
         }
     }
@@ -717,7 +800,7 @@ void be_set_tuning(const char* name, long long v) {
     if (std::strcmp(name, "sweep_blocks") == 0 && v >= 0 && v <= 4096) g_sweep_blocks = (int)v;
     if (std::strcmp(name, "graph") == 0) g_use_graph_req = v != 0;
     if (std::strcmp(name, "apply_stream") == 0 && v >= 0 && v <= 2) g_apply_stream = (int)v;
-    if (std::strcmp(name, "recount_mode") == 0 && v >= 0 && v <= 5) g_recount_mode = (int)v;
+    if (std::strcmp(name, "recount_mode") == 0 && v >= 0 && v <= 6) g_recount_mode = (int)v;
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != g_prio_mode) { g_prio_mode = (int)v; make_streams(); }
 }
 
@@ -815,7 +898,7 @@ __global__ void k_build_lev16(VrgCtx c, uint16_t* dst) {
     VOXEL_LOOP(c) { int x, y, z; uint32_t idx = real_idx(c, t, x, y, z); dst[idx] = (uint16_t)vrg_level_of(c, (double)c.I[idx]); }
 }
 void be_build_lev16(const VrgCtx& c, uint16_t* dst) {
-    HIP_CHECK(hipMemsetAsync(dst, 0, (size_t)c.PV * 2, g_stream));
+    HIP_CHECK(hipMemsetAsync(dst, 0, ((size_t)c.PV + 1023) / 1024 * 1024 * 2, g_stream));
     k_build_lev16<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, dst);
 }
 
@@ -863,6 +946,11 @@ int be_comm_init(int nranks, int rank, const void* id128) {
 }
 
 static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t st) {
+    if (g_recount_mode == 6) {
+        if (c.lev16) k_recount_bits<3, true, true><<<blocks, TPB, 0, st>>>(c, check);
+        else k_recount_bits<3, true, false><<<blocks, TPB, 0, st>>>(c, check);
+        return;
+    }
     if (c.lev16) {
         if (g_recount_mode == 0) k_recount16<1, false><<<blocks, TPB, 0, st>>>(c, check);
         else k_recount16<3, true><<<blocks, TPB, 0, st>>>(c, check);
@@ -883,6 +971,7 @@ void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
     if (c.L <= HIST_LDS_LEVELS) k_hist_lds<<<1024, TPB, 0, g_stream>>>(c);
     else k_hist_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
     k_exact<<<1024, TPB, 0, g_stream>>>(c, 0);
+    k_cls_build<<<2048, TPB, 0, g_stream>>>(c);
     launch_recount(c, dense_blocks(c), 0, g_stream);
     reduce_dense(c, cb, user, g_stream);
     k_fin_init<<<1, 1, 0, g_stream>>>(c);

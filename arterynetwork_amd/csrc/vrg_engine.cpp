@@ -94,7 +94,9 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.PV = (uint32_t)(PX * PY * PZ);
     c.z0 = 0; c.z1 = (int32_t)nz;
     h->V = nx * ny * nz;
-    c.I = alloc<float>(h, c.PV);
+    const size_t PVu = ((size_t)c.PV + 1023) / 1024 * 1024;   // dense arrays end on a whole 1024-voxel unit
+    c.I = alloc<float>(h, PVu);
+    c.cls = alloc<uint32_t>(h, PVu / 16);
     // 16 guard bytes in front: voxel (0,0,0)'s 2-ring reaches 2 bytes before the padded array
     h->lab_base[0] = alloc<uint8_t>(h, (size_t)c.PV + 32);
     h->lab_base[1] = alloc<uint8_t>(h, (size_t)c.PV + 32);
@@ -107,9 +109,10 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.dn_part = alloc<VrgDense>(h, 16);
     c.inc = alloc<int64_t>(h, 32); c.dctl = alloc<int64_t>(h, 32);   // one allocation each: written from different streams
     c.world = 1;
-    if (!c.I || !c.lab[0] || !c.lab[1] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.inc || !c.dctl) { API(destroy)(h); return VRG_E_MEM; }
+    if (!c.I || !c.lab[0] || !c.lab[1] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.inc || !c.dctl || !c.cls) { API(destroy)(h); return VRG_E_MEM; }
     be_fill(c.inc, 0, 32 * sizeof(int64_t)); be_fill(c.dctl, 0, 32 * sizeof(int64_t));
-    be_fill((void*)c.I, 0, (size_t)c.PV * 4);
+    be_fill((void*)c.I, 0, PVu * 4);
+    if (c.cls) be_fill(c.cls, 0, PVu / 4);
     be_fill(h->lab_base[0], VB_OOB, (size_t)c.PV + 32);
     be_fill(h->lab_base[1], VB_OOB, (size_t)c.PV + 32);
     be_fill(c.st, 0, sizeof(VrgState));
@@ -192,7 +195,7 @@ int API(init)(vrg_handle* h, double H) {
     c.lev16 = nullptr;
     if (h->storage16) {                             // 16-bit intensity storage: level indices + LDS value table
         if (L > 16384) return fail(h, VRG_E_ARG, "storage16: more than 16384 distinct intensity values");
-        if (!h->lev16_buf) h->lev16_buf = alloc<uint16_t>(h, c.PV);
+        if (!h->lev16_buf) h->lev16_buf = alloc<uint16_t>(h, ((size_t)c.PV + 1023) / 1024 * 1024);
         if (!h->lev16_buf) return fail(h, VRG_E_MEM, "vrg_init: 16-bit level volume");
         be_build_lev16(c, h->lev16_buf);
         c.lev16 = h->lev16_buf;

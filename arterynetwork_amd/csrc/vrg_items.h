@@ -35,6 +35,7 @@ VRG_HD uint32_t vrg_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v)
 VRG_HD int32_t vrg_atomic_add(int32_t* p, int32_t v) { return atomicAdd(p, v); }
 VRG_HD uint32_t vrg_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 VRG_HD void vrg_atomic_add64(int64_t* p, int64_t v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
+VRG_HD void vrg_atomic_xor(uint32_t* p, uint32_t v) { atomicXor(p, v); }
 VRG_HD uint8_t vrg_load_coherent(const uint8_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -43,6 +44,7 @@ VRG_HD uint32_t vrg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = 
 VRG_HD int32_t vrg_atomic_add(int32_t* p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
 VRG_HD uint32_t vrg_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 VRG_HD void vrg_atomic_add64(int64_t* p, int64_t v) { *p += v; }
+VRG_HD void vrg_atomic_xor(uint32_t* p, uint32_t v) { *p ^= v; }
 VRG_HD uint8_t vrg_load_coherent(const uint8_t* p) { return *(const volatile uint8_t*)p; }
 #endif
 
@@ -190,10 +192,21 @@ VRG_HD void vrg_item_relabel(const VrgCtx& c, uint32_t i) {
     c.mk_new[i] = vrg_sweep_core(c, c.lab[0], idx, c.lab[0][idx]);
 }
 // phase 2: write the new bytes (this also clears the L / P / mark bits)
-// ... and keep the region sizes (:113-116) in step: inner = S, outer = neither S nor excluded
-VRG_HD void vrg_count_change(const VrgCtx& c, uint8_t old, uint8_t nw) {
-    int din = (int)((nw & VB_S) != 0) - (int)((old & VB_S) != 0);
-    int dout = (int)((nw & (VB_S | VB_X | VB_OOB)) == 0) - (int)((old & (VB_S | VB_X | VB_OOB)) == 0);
+// class of a label for the region statistics (:113-116): 1 inner (S), 2 outer (neither S nor excluded), 0 neither
+VRG_HD uint32_t vrg_cls_of(uint8_t b) { return (b & VB_S) ? 1u : ((b & (VB_X | VB_OOB)) ? 0u : 2u); }
+// where voxel idx keeps its two class bits (layout: VrgCtx::cls)
+VRG_HD void vrg_cls_pos(uint32_t idx, uint32_t& dw, uint32_t& sh) {
+    uint32_t o = idx & 1023u;
+    dw = ((idx >> 10) << 6) | ((o & 255u) >> 2);
+    sh = 2u * (((o >> 8) << 2) | (o & 3u));
+}
+// a label byte changes: keep the class bits and the region sizes in step
+VRG_HD void vrg_count_change(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t nw) {
+    uint32_t a = vrg_cls_of(old), b = vrg_cls_of(nw);
+    if (a == b) return;
+    uint32_t dw, sh; vrg_cls_pos(idx, dw, sh);
+    vrg_atomic_xor(&c.cls[dw], (a ^ b) << sh);
+    int din = (int)(b == 1u) - (int)(a == 1u), dout = (int)(b == 2u) - (int)(a == 2u);
     if (din) vrg_atomic_add64(&c.inc[VC_NIN], din);
     if (dout) vrg_atomic_add64(&c.inc[VC_NOUT], dout);
 }
@@ -201,7 +214,17 @@ VRG_HD void vrg_item_apply(const VrgCtx& c, uint32_t i) {
     uint32_t idx = c.mk_idx[i];
     uint8_t old = c.lab[0][idx], nw = c.mk_new[i];
     c.lab[0][idx] = nw;
-    vrg_count_change(c, old, nw);
+    vrg_count_change(c, idx, old, nw);
+}
+// init: class dword d from the labels (16 voxels)
+VRG_HD void vrg_item_cls_build(const VrgCtx& c, uint32_t d) {
+    uint32_t base = ((d >> 6) << 10) | ((d & 63u) << 2), w = 0;
+    for (uint32_t j = 0; j < 4; j++)
+        for (uint32_t b = 0; b < 4; b++) {
+            uint32_t idx = base + 256u * j + b;
+            if (idx < c.PV) w |= vrg_cls_of(c.lab[0][idx]) << (2u * (4u * j + b));
+        }
+    c.cls[d] = w;
 }
 // one caller per applied sweep: the labels of sweep iter+1 are in place, a dense pass over them is due
 VRG_HD void vrg_request_dense(const VrgCtx& c) { c.inc[VC_REQ] = (int64_t)c.st->iter + 1; }

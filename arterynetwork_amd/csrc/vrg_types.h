@@ -85,6 +85,9 @@ struct VrgCtx {
     const uint16_t* lev16;     // optional 16-bit storage: level index per voxel (same layout); the dense pass then
                                // streams 2 B instead of 4 B of intensity per voxel (values come from an LDS table)
     uint8_t* lab[2];           // lab[0]: label bytes, updated in place; lab[1]: scratch of the full-stencil check variant
+    uint32_t* cls;             // class bits: what the dense pass needs of a label - inner (S) / outer (not S, not excluded) -
+                               // 2 bits per voxel, kept in step by every label write; lane l of a wave owns dword l of each
+                               // 1024-voxel unit (its 16 voxels 256*j + 4*l + b), so a unit is one coalesced 256-B request
     uint32_t mcap;             // marked-voxel list: index and new byte
     uint32_t* mk_idx;
     uint8_t* mk_new;

@@ -95,11 +95,13 @@ def load_traffic(shape, n_gpus):
 
 
 def roofline(V_per_launch, kern_ms, launches, traffic, bytes_per_voxel=BYTES_PER_VOXEL_ITER):
-    """Dominant kernel = k_recount (dense region recount, one launch per sweep).  `achieved` uses the
-    ALGORITHMIC 6 B/voxel-iter of SURVEY.md 8(d); the kernel itself moves ~5 B/voxel (labels are updated
-    in place, so the 1 B/voxel label write-back is elided) - `traffic` is the rocprofv3 PMC figure."""
+    """Dominant kernel = k_recount_bits (dense region recount, one launch per sweep).  `achieved` uses the
+    ALGORITHMIC 6 B/voxel-iter of SURVEY.md 8(d).  The kernel itself moves 4.25 B/voxel: labels are updated in
+    place (no 1 B/voxel write-back) and the recount reads a 2-bit class volume instead of the label bytes, so
+    `achieved` can exceed the HBM peak; `traffic` is the rocprofv3 PMC figure of what really crossed the bus and
+    `traffic_frac_of_peak` the fraction of the HBM peak the kernel sustains."""
     achieved = bytes_per_voxel * V_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
-    out = {'bound': 'hbm', 'kernel': 'k_recount16' if bytes_per_voxel == 4 else 'k_recount', 'achieved': round(achieved, 1) if achieved else None,
+    out = {'bound': 'hbm', 'kernel': 'k_recount_bits<3,true,true>' if bytes_per_voxel == 4 else 'k_recount_bits<3,true,false>', 'achieved': round(achieved, 1) if achieved else None,
            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
            'kernel_ms_avg': round(kern_ms, 4), 'launches': launches,
            'algorithmic_bytes_per_launch': bytes_per_voxel * V_per_launch, 'traffic': traffic}

@@ -122,10 +122,12 @@ static void dense_stats(const VrgCtx& c, const uint8_t* lab, be_reduce_fn cb, vo
     int64_t a = 0, b = 0; double sa = 0, sb = 0;
     for_real_voxels(c, [&](uint32_t idx, int, int, int z) {
         if (z < c.z0 || z >= c.z1) return;
-        uint8_t o = lab[idx];
+        uint32_t dw, sh; vrg_cls_pos(idx, dw, sh);
+        uint32_t k = (c.cls[dw] >> sh) & 3u;                 // the dense pass reads the class bits ...
+        if (k != vrg_cls_of(lab[idx])) c.st->error = 6;      // ... which every label write must have kept in step
         double v = c.lev16 ? (double)(float)c.lev[c.lev16[idx]] : (double)c.I[idx];
-        if (o & VB_S) { a++; sa += v; }
-        else if (!(o & VB_X)) { b++; sb += v; }
+        if (k == 1u) { a++; sa += v; }
+        else if (k == 2u) { b++; sb += v; }
     });
     VrgDense& p = *c.dn_part;
     p.n_in = (double)a; p.n_out = (double)b; p.sum_in = sa; p.sum_out = sb;
@@ -140,6 +142,7 @@ void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
     for (uint32_t e = 0; e < n; e++) vrg_item_init_entry(c, e);
     for_real_voxels(c, [&](uint32_t idx, int, int, int) { vrg_item_hist_voxel(c, idx); });
     for (uint32_t i = 0; i < n; i++) vrg_exact_serial(c, 0, c.fresh[i]);
+    for (uint32_t d = 0; d < (((c.PV + 1023u) >> 10) << 6); d++) vrg_item_cls_build(c, d);
     dense_stats(c, c.lab[0], cb, user);
     s.nfresh = 0;
     vrg_init_counts(c);
@@ -176,7 +179,7 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*, be_reduce_fn cb, vo
     } else {
         // full-stencil check variant: every voxel, through the scratch volume
         for_real_voxels(c, [&](uint32_t idx, int, int, int) { c.lab[1][idx] = vrg_sweep_core(c, lab, idx, lab[idx]); });
-        for_real_voxels(c, [&](uint32_t idx, int, int, int) { vrg_count_change(c, lab[idx], c.lab[1][idx]); lab[idx] = c.lab[1][idx]; });
+        for_real_voxels(c, [&](uint32_t idx, int, int, int) { vrg_count_change(c, idx, lab[idx], c.lab[1][idx]); lab[idx] = c.lab[1][idx]; });
     }
     vrg_request_dense(c);
     dense_stats(c, lab, cb, user);          // the dense recount (:113-116) ...
