@@ -24,4 +24,12 @@ for sd in range(200000, 200000 + n_med):
         sweeps += k; amb += res is None
     except Exception as e:
         fails += 1; print('FAIL medium', sd, type(e).__name__, str(e)[:200].replace('\n', ' '))
+for sd in range(300000, 300000 + n_small):
+    I, vm, H, variant, dmode = random_case(sd)
+    try:
+        res, k = parity.run_batched(lib, I, vm, H, None, 40, density_mode=dmode,
+                                    options={'sweep_variant': variant, 'batch': 1 + sd % 7, 'apply_stream': sd % 3, 'graph': (sd // 3) % 2})
+        sweeps += k; amb += res is None
+    except Exception as e:
+        fails += 1; print('FAIL batched', sd, type(e).__name__, str(e)[:200].replace('\n', ' '))
 print('fuzz: %d small + %d medium cases, %d sweeps compared, %d tie-ambiguous, %d FAILED, %.0f s' % (n_small, n_med, sweeps, amb, fails, time.time() - t))

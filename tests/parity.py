@@ -96,3 +96,45 @@ def run_stepwise(lib, data, vmap, H=2.25, maxSegmentSize=None, iterMax=200, dens
     s.close()
     o.close()
     return res, k
+
+
+def run_batched(lib, data, vmap, H=2.25, maxSegmentSize=None, iterMax=200, density_mode=1, rtol=1e-9,
+                options=None, device=0, tie_tol=1e-11):
+    """Oracle sweep by sweep to its stop; the implementation in ONE vrg_run call (sweeps enqueued in batches, the
+    dense pass trailing the band kernels); compare final state, list orders and the whole trace.
+    Returns (result, sweeps) or (None, k) when the oracle met an exact tie."""
+    shape = data.shape
+    if maxSegmentSize is None:
+        maxSegmentSize = data.size + 1
+    o = O.Oracle(data, vmap, H, density_mode)
+    o.init()
+    k = 0
+    while True:
+        if decision_margin(o) < tie_tol:
+            o.close()
+            return None, k
+        rc = o.step(iterMax, maxSegmentSize, -1.0)
+        if rc != 0:
+            break
+        k += 1
+    s = Session(shape, device=device, lib=lib)
+    for kk, v in (options or {}).items():
+        s.set_option(kk, v)
+    s.set_volume(data)
+    s.set_labels(vmap)
+    s.init(H)
+    res = s.run(iterMax, maxSegmentSize, None)
+    assert res.stop_reason == rc and res.iter_num == o.iterNum and res.sweeps == k, (res.stop_reason, rc, res.sweeps, k)
+    compare_state(s, o, shape, rtol, 'final (batched)')
+    assert np.array_equal(lex_of(s.segmented(), shape), o.segmented_lex()), 'segmented order differs'
+    tr, otr = s.trace(), o.trace()
+    assert len(tr) == len(otr)
+    for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no'):
+        assert np.array_equal(tr[f], otr[f]), f
+    np.testing.assert_allclose(tr['sum_in'], otr['sum_in'], rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(tr['sum_out'], otr['sum_out'], rtol=1e-9, atol=1e-6)
+    vals, hin, hout, rin, rout = s.levels()
+    assert np.array_equal(hin, rin) and np.array_equal(hout, rout), 'incremental class histograms drifted'
+    s.close()
+    o.close()
+    return res, k
