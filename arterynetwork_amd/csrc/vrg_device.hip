@@ -49,14 +49,11 @@ constexpr int SWEEP_BLOCKS = 256;   // 1 workgroup (4 waves) per CU, each wave w
 
 hipStream_t g_stream = nullptr;      // stream A: the band kernels of every trip in program order, copies
 hipStream_t g_stream_b = nullptr;    // stream B: the dense pass (recount, slab all-reduce, k_dense_fin); trails stream A by up to one sweep
-hipEvent_t g_ev_a = nullptr, g_ev_d = nullptr;   // labels applied (A -> B) / labels read by the dense pass (B -> A)
-hipEvent_t g_last_read = nullptr;                // the "labels read" event of the latest dense pass
-hipEvent_t g_ev_r = nullptr;                     // new labels computed (A -> B), when stream B applies them
-int g_apply_stream = 0;              // 0: by slab size; 1: k_apply on stream A; 2: on stream B
+hipEvent_t g_ev_a = nullptr, g_ev_d[2] = {nullptr, nullptr};   // labels applied (A -> B) / class copy read by the dense pass (B -> A)
+hipEvent_t g_read[2] = {nullptr, nullptr};       // the "class copy read" events of the last two dense passes, by trip parity
+unsigned long long g_trip = 0;
 int g_sweep_blocks = 0;              // 0 = auto (dense_blocks)
 int g_prio_mode = 2;                 // the dense stream gets the higher priority (measured: -1..2 % step time)
-int g_recount_mode = 6;              // dense recount shape: 0 = 1 unit/trip, plain loads; 1 = 1 unit nt; 2 = 2 units;
-                                     // 3 = 2 units nt; 4 = 4 units nt; 5 = 3 units nt (default, fastest measured)
 int g_use_graph_req = 0;
 ncclComm_t g_comm = nullptr;          // per-sweep all-reduce of the slab statistics (multi-GPU)
 
@@ -131,14 +128,16 @@ __global__ void k_relabel(VrgCtx c) {
     if (c.st->done) return;
     ITEM_LOOP(min(c.st->nmk, c.mcap)) vrg_item_relabel(c, i);
 }
-__global__ void k_apply(VrgCtx c) {
+__global__ void k_apply(VrgCtx c) {                    // + the class changes of the sweep before (see VrgCtx::clsb)
     if (c.st->done) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) vrg_request_dense(c);
-    ITEM_LOOP(min(c.st->nmk, c.mcap)) vrg_item_apply(c, i);
+    const uint32_t nm = min(c.st->nmk, c.mcap);
+    ITEM_LOOP(nm + vrg_catchup_count(c)) { if (i < nm) vrg_item_apply(c, i); else vrg_item_catchup(c, i - nm); }
 }
 __global__ void k_dense_fin(VrgCtx c) { vrg_dense_fin(c); }
 __global__ void k_entry_post(VrgCtx c) {
     if (c.st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) vrg_post_apply(c);
     ITEM_LOOP(c.st->ni + c.st->no) vrg_item_entry_post(c, i);
 }
 __global__ void k_scatter(VrgCtx c) {                  // items: every old entry, then (listed flip, neighbour k)
@@ -279,50 +278,44 @@ __global__ void k_scan_reduce(VrgCtx c, uint32_t* a) {
     uint32_t tot; block_excl_scan(s, tot, sh);
     if (threadIdx.x == 0) c.bsum[blockIdx.x] = tot;
 }
-// fin != 0: this is the rebuild scan - also derive the new list lengths (what k_fin_scan does)
-__global__ void k_scan_top(VrgCtx c, uint32_t* a, int fin) {
+// second pass: every workgroup adds up the partials before its own (256 values: one per thread), scans its chunk;
+// fin != 0: this is the rebuild scan - also derive the new list lengths (ni_new = scan value at the start of
+// segment B0 = number of entries of the new inner list)
+__global__ void k_scan_down(VrgCtx c, uint32_t* a, int fin) {
     if (c.st->done) return;
     __shared__ uint32_t sh[4];
-    uint32_t v = c.bsum[threadIdx.x], tot;
-    uint32_t ex = block_excl_scan(v, tot, sh);
-    c.bsum[threadIdx.x] = ex;
-    if (threadIdx.x == 0) c.st->scan_total = tot;
-    if (!fin) return;
-    // start of segment B0 = number of entries of the new inner list: block offset + partial sum inside its chunk
-    __shared__ uint32_t sh_part[4];
+    __shared__ uint32_t sh_off;
     VrgState& s = *c.st;
-    const uint32_t n = s.nscan, b0 = vrg_slot_B0(s, 0);
-    uint32_t chunk = (n + SCAN_BLOCKS - 1) / SCAN_BLOCKS;
-    chunk = (chunk + TPB - 1) / TPB * TPB;
-    uint32_t blk = chunk ? b0 / chunk : 0, lo = blk * chunk;
+    const uint32_t n = s.nscan;
+    uint32_t lo, hi; scan_range(n, lo, hi);
+    uint32_t gtot, gex = block_excl_scan(c.bsum[threadIdx.x], gtot, sh);
+    if (threadIdx.x == blockIdx.x) sh_off = gex;
     __syncthreads();
-    uint32_t part = 0;
-    for (uint32_t i = lo + threadIdx.x; i < b0 && i < n; i += TPB) part += a[i];
-    uint32_t ptot; block_excl_scan(part, ptot, sh_part);
-    if (threadIdx.x == 0) {
-        s.ni_new = (b0 < n) ? c.bsum[blk] + ptot : tot;
-        s.nb_new = tot;
-        if (tot > c.bcap) { s.error = 1; s.done = -1; }
-    }
-}
-__global__ void k_scan_down(VrgCtx c, uint32_t* a) {
-    if (c.st->done) return;
-    __shared__ uint32_t sh[4];
-    uint32_t lo, hi; scan_range(c.st->nscan, lo, hi);
-    uint32_t run = c.bsum[blockIdx.x];
+    uint32_t run = sh_off;
+    const uint32_t b0 = fin ? vrg_slot_B0(s, 0) : 0xffffffffu;
     for (uint32_t base = lo; base < hi; base += TPB) {
         uint32_t i = base + threadIdx.x;
         uint32_t v = i < hi ? a[i] : 0, tot;
         uint32_t ex = block_excl_scan(v, tot, sh);
-        if (i < hi) a[i] = run + ex;
+        if (i < hi) {
+            a[i] = run + ex;
+            if (i == b0) s.ni_new = run + ex;
+        }
         run += tot;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        s.scan_total = gtot;
+        if (fin) {
+            if (b0 >= n) s.ni_new = gtot;
+            s.nb_new = gtot;
+            if (gtot > c.bcap) { s.error = 1; s.done = -1; }
+        }
     }
 }
 void device_scan(const VrgCtx& c, uint32_t* a, hipStream_t st, int fin) {
-    static_assert(SCAN_BLOCKS == TPB, "k_scan_top scans one value per thread");
+    static_assert(SCAN_BLOCKS == TPB, "k_scan_down adds up one partial per thread");
     k_scan_reduce<<<SCAN_BLOCKS, TPB, 0, st>>>(c, a);
-    k_scan_top<<<1, SCAN_BLOCKS, 0, st>>>(c, a, fin);
-    k_scan_down<<<SCAN_BLOCKS, TPB, 0, st>>>(c, a);
+    k_scan_down<<<SCAN_BLOCKS, TPB, 0, st>>>(c, a, fin);
 }
 
 // ---- the dense pass ----------------------------------------------------------------------------------
@@ -389,111 +382,20 @@ __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a, int fi
         d.sum_out = ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3];
         *c.dn_part = d;                              // slab partials: input of the all-reduce
         if (c.world == 1) *c.dn = d;
-        c.dctl[VD_NIN] = c.inc[VC_NIN]; c.dctl[VD_NOUT] = c.inc[VC_NOUT];   // the sizes these totals must reproduce
         if (fin == 2) vrg_dense_fin(c);              // nothing to sum over ranks: close the pass here
     }
 }
 
-// UNITS = 1-KiB units a wave loads per trip (bytes in flight), NT = non-temporal loads: the volume is read
-// once per sweep and is far larger than the 256-MiB Infinity Cache, so nothing is worth keeping.
-template <int UNITS, bool NT>
-__global__ void __launch_bounds__(TPB) k_recount(VrgCtx c, int check_done) {
-    if (check_done && !vrg_dense_due(c)) return;     // no sweep was applied since the last pass (stop flag)
-    const uint8_t* __restrict__ in = c.lab[0];
-    const float* __restrict__ I = c.I;
-    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
-    const uint32_t first = (2u + (uint32_t)c.z0) * plane;   // this device's Z-slab [z0, z1)
-    const uint32_t total = (uint32_t)(c.z1 - c.z0) * plane; // bytes, a multiple of 16
-    const uint32_t nfull = total >> 10;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    SweepAcc acc = {0, 0, 0.0, 0.0};
-    uint32_t u = wave * UNITS;
-    for (; u + UNITS <= nfull; u += nwaves * UNITS) {
-        uint32_t w[4 * UNITS]; f4v f[4 * UNITS];
-#pragma unroll
-        for (int q = 0; q < UNITS; q++) {
-            const uint32_t base = first + ((u + q) << 10) + (lane << 2);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t* pl = reinterpret_cast<const uint32_t*>(in + base + (j << 8));
-                const f4v* pi = reinterpret_cast<const f4v*>(I + base + (j << 8));
-                w[4 * q + j] = NT ? __builtin_nontemporal_load(pl) : *pl;
-                f[4 * q + j] = NT ? __builtin_nontemporal_load(pi) : *pi;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4 * UNITS; j++) sweep_stats(acc, w[j], f[j]);
-    }
-    // remainder: whole units left over by the UNITS-stride (at most UNITS-1 per wave) and the tail unit (< 1 KiB)
-    for (; u < nfull + ((total & 1023u) ? 1u : 0u); u++) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t off = (u << 10) + (j << 8) + (lane << 2);
-            if (off < total)
-                sweep_stats(acc, *reinterpret_cast<const uint32_t*>(in + first + off), *reinterpret_cast<const f4v*>(I + first + off));
-        }
-    }
-    sweep_finish(c, acc, check_done);
-}
+constexpr uint32_t LEV16_MAX = 16384;   // 16-bit storage: the level values sit in LDS (<= 16384 x f32)
 
-// 16-bit storage variant: 2 B level index + 1 B label per voxel; the level values sit in LDS (<= 16384 x f32).
-// Same unit / lane mapping, so the sums are added in the same order as in k_recount (bit-identical results).
-constexpr uint32_t LEV16_MAX = 16384;
-template <int UNITS, bool NT>
-__global__ void __launch_bounds__(TPB) k_recount16(VrgCtx c, int check_done) {
-    if (check_done && !vrg_dense_due(c)) return;     // no sweep was applied since the last pass (stop flag)
-    __shared__ float s_val[LEV16_MAX];
-    for (uint32_t i = threadIdx.x; i < c.L; i += TPB) s_val[i] = (float)c.lev[i];
-    __syncthreads();
-    const uint8_t* __restrict__ in = c.lab[0];
-    const uint16_t* __restrict__ lv = c.lev16;
-    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
-    const uint32_t first = (2u + (uint32_t)c.z0) * plane;
-    const uint32_t total = (uint32_t)(c.z1 - c.z0) * plane;
-    const uint32_t nfull = total >> 10;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    SweepAcc acc = {0, 0, 0.0, 0.0};
-    uint32_t u = wave * UNITS;
-    for (; u + UNITS <= nfull; u += nwaves * UNITS) {
-        uint32_t w[4 * UNITS]; u2v q[4 * UNITS];
-#pragma unroll
-        for (int k = 0; k < UNITS; k++) {
-            const uint32_t base = first + ((u + k) << 10) + (lane << 2);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t* pl = reinterpret_cast<const uint32_t*>(in + base + (j << 8));
-                const u2v* pq = reinterpret_cast<const u2v*>(lv + base + (j << 8));
-                w[4 * k + j] = NT ? __builtin_nontemporal_load(pl) : *pl;
-                q[4 * k + j] = NT ? __builtin_nontemporal_load(pq) : *pq;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4 * UNITS; j++) {
-            f4v f = {s_val[q[j].x & 0xffffu], s_val[q[j].x >> 16], s_val[q[j].y & 0xffffu], s_val[q[j].y >> 16]};
-            sweep_stats(acc, w[j], f);
-        }
-    }
-    for (; u < nfull + ((total & 1023u) ? 1u : 0u); u++) {     // leftover whole units of this wave + the tail unit
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t off = (u << 10) + (j << 8) + (lane << 2);
-            if (off < total) {
-                u2v q = *reinterpret_cast<const u2v*>(lv + first + off);
-                f4v f = {s_val[q.x & 0xffffu], s_val[q.x >> 16], s_val[q.y & 0xffffu], s_val[q.y >> 16]};
-                sweep_stats(acc, *reinterpret_cast<const uint32_t*>(in + first + off), f);
-            }
-        }
-    }
-    sweep_finish(c, acc, check_done);
-}
-
-// Class-bit variants (the default): the recount needs two facts per voxel - inner / outer - so it streams the
-// 2-bit class volume (VrgCtx::cls, 0.25 B/voxel) instead of the label bytes: 4.25 B (fp32 storage) or 2.25 B
+// The recount needs two facts per voxel - inner / outer - so it streams the
+// 2-bit class volume (VrgCtx::clsb, 0.25 B/voxel) instead of the label bytes: 4.25 B (fp32 storage) or 2.25 B
 // (16-bit storage) per voxel.  Units are 1024-voxel aligned in the absolute voxel index; lane l owns class dword l
 // of a unit and the 4 x 4 intensities at 256*j + 4*l, i.e. one 256-B + four 1-KiB (or 512-B) requests per wave
 // and unit.  A slab edge that cuts a unit is handled by masking (first / last wave); padding planes are class 0.
+// UNITS = units a wave loads per trip (bytes in flight); NT = non-temporal loads: the volume is read once per
+// sweep and is far larger than the 256-MiB Infinity Cache, so nothing is worth keeping.
+// Dense pass number seq (= passes closed + 1) reads copy seq & 1 of the class bits.
 __device__ __forceinline__ void stats_bits(SweepAcc& a, uint32_t w, const f4v* f) {
     a.nin += __popc(w & 0x55555555u); a.nout += __popc(w & 0xAAAAAAAAu);
 #pragma unroll
@@ -507,8 +409,8 @@ __device__ __forceinline__ void stats_bits(SweepAcc& a, uint32_t w, const f4v* f
         }
 }
 template <bool L16, bool NT>
-__device__ __forceinline__ void load_unit(const VrgCtx& c, const float* s_val, uint32_t u, uint32_t lane, uint32_t& w, f4v* f) {
-    const uint32_t* pc = c.cls + ((size_t)u << 6) + lane;
+__device__ __forceinline__ void load_unit(const VrgCtx& c, const uint32_t* cls, const float* s_val, uint32_t u, uint32_t lane, uint32_t& w, f4v* f) {
+    const uint32_t* pc = cls + ((size_t)u << 6) + lane;
     w = NT ? __builtin_nontemporal_load(pc) : *pc;
     const uint32_t base = (u << 10) + (lane << 2);
 #pragma unroll
@@ -531,6 +433,7 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
         for (uint32_t i = threadIdx.x; i < c.L; i += TPB) s_val[i] = (float)c.lev[i];
         __syncthreads();
     }
+    const uint32_t* __restrict__ cls = c.clsb[(c.dctl[VD_SEQ] + 1) & 1];
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
     const uint32_t lo = (2u + (uint32_t)c.z0) * plane;         // this device's Z-slab [z0, z1) as a voxel range
     const uint32_t hi = (2u + (uint32_t)c.z1) * plane;
@@ -543,13 +446,13 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
     for (; u + UNITS <= f_hi; u += nwaves * UNITS) {
         uint32_t w[UNITS]; f4v f[UNITS][4];
 #pragma unroll
-        for (int q = 0; q < UNITS; q++) load_unit<L16, NT>(c, s_val, u + q, lane, w[q], f[q]);
+        for (int q = 0; q < UNITS; q++) load_unit<L16, NT>(c, cls, s_val, u + q, lane, w[q], f[q]);
 #pragma unroll
         for (int q = 0; q < UNITS; q++) stats_bits(acc, w[q], f[q]);
     }
     for (; u < f_hi; u++) {                                    // whole units left over by the UNITS-stride
         uint32_t w; f4v f[4];
-        load_unit<L16, false>(c, s_val, u, lane, w, f);
+        load_unit<L16, false>(c, cls, s_val, u, lane, w, f);
         stats_bits(acc, w, f);
     }
     // units the slab edges cut: the first and the last unit touching [lo, hi), masked to the slab
@@ -557,7 +460,7 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
     const uint32_t edge = wave == 0 ? e0 : (wave == nwaves - 1 && e1 != e0 ? e1 : 0xffffffffu);
     if (edge != 0xffffffffu && !(edge >= f_lo && edge < f_hi)) {
         uint32_t w; f4v f[4];
-        load_unit<L16, false>(c, s_val, edge, lane, w, f);
+        load_unit<L16, false>(c, cls, s_val, edge, lane, w, f);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             uint32_t v = (edge << 10) + (j << 8) + (lane << 2);        // groups of 4 voxels never straddle a plane
@@ -602,6 +505,7 @@ __global__ void __launch_bounds__(TPB) k_copy_back(VrgCtx c) {
     uint4* __restrict__ dst = reinterpret_cast<uint4*>(c.lab[0] + 2u * plane);
     const uint32_t n16 = (uint32_t)(((uint64_t)c.nz * plane) >> 4);
     if (blockIdx.x == 0 && threadIdx.x == 0) vrg_request_dense(c);
+    ITEM_LOOP(vrg_catchup_count(c)) vrg_item_catchup(c, i);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) {
         uint4 a = src[i], b = dst[i];
         if (a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w) {
@@ -799,8 +703,6 @@ static void make_streams() {
 void be_set_tuning(const char* name, long long v) {
     if (std::strcmp(name, "sweep_blocks") == 0 && v >= 0 && v <= 4096) g_sweep_blocks = (int)v;
     if (std::strcmp(name, "graph") == 0) g_use_graph_req = v != 0;
-    if (std::strcmp(name, "apply_stream") == 0 && v >= 0 && v <= 2) g_apply_stream = (int)v;
-    if (std::strcmp(name, "recount_mode") == 0 && v >= 0 && v <= 6) g_recount_mode = (int)v;
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != g_prio_mode) { g_prio_mode = (int)v; make_streams(); }
 }
 
@@ -811,8 +713,8 @@ int be_set_device(int device) {
     if (!g_stream) {
         make_streams();
         HIP_CHECK(hipEventCreateWithFlags(&g_ev_a, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&g_ev_d, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&g_ev_r, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&g_ev_d[0], hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&g_ev_d[1], hipEventDisableTiming));
     }
     return 0;
 }
@@ -946,27 +848,12 @@ int be_comm_init(int nranks, int rank, const void* id128) {
 }
 
 static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t st) {
-    if (g_recount_mode == 6) {
-        if (c.lev16) k_recount_bits<3, true, true><<<blocks, TPB, 0, st>>>(c, check);
-        else k_recount_bits<3, true, false><<<blocks, TPB, 0, st>>>(c, check);
-        return;
-    }
-    if (c.lev16) {
-        if (g_recount_mode == 0) k_recount16<1, false><<<blocks, TPB, 0, st>>>(c, check);
-        else k_recount16<3, true><<<blocks, TPB, 0, st>>>(c, check);
-        return;
-    }
-    switch (g_recount_mode) {
-        case 1: k_recount<1, true><<<blocks, TPB, 0, st>>>(c, check); break;
-        case 2: k_recount<2, false><<<blocks, TPB, 0, st>>>(c, check); break;
-        case 3: k_recount<2, true><<<blocks, TPB, 0, st>>>(c, check); break;
-        case 4: k_recount<4, true><<<blocks, TPB, 0, st>>>(c, check); break;
-        case 5: k_recount<3, true><<<blocks, TPB, 0, st>>>(c, check); break;
-        default: k_recount<1, false><<<blocks, TPB, 0, st>>>(c, check); break;
-    }
+    if (c.lev16) k_recount_bits<3, true, true><<<blocks, TPB, 0, st>>>(c, check);
+    else k_recount_bits<3, true, false><<<blocks, TPB, 0, st>>>(c, check);
 }
 
 void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
+    HIP_CHECK(hipStreamSynchronize(g_stream_b));     // both class copies are rebuilt: no dense pass may be in flight
     k_init_entry<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     if (c.L <= HIST_LDS_LEVELS) k_hist_lds<<<1024, TPB, 0, g_stream>>>(c);
     else k_hist_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
@@ -978,13 +865,13 @@ void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
 }
 
 // ---- one sweep ------------------------------------------------------------------------------------------
-// Stream A ("band") carries every sparse kernel in program order; stream B ("dense") carries the recount, the
-// slab all-reduce and k_dense_fin.  The only edges between them:
-//   apply(k)   waits for recount(k-1)   (g_ev_d: the dense pass has finished reading the labels apply(k) rewrites)
-//   recount(k) waits for apply(k)       (g_ev_a)
-// so while the dense pass of sweep k streams the volume, stream A already runs the bookkeeping of sweep k and
-// decide .. relabel of sweep k+1 (these read the labels and OR the L/P/M bits only - never S or X, which is all
-// the recount looks at; the region sizes they need come from VrgCtx::inc).
+// Stream A ("band") carries every sparse kernel in program order; stream B ("dense") carries the recounts (+ the
+// slab all-reduce and k_dense_fin on several GPUs).  The only edges between them:
+//   recount(k) waits for apply(k) + entry_post(k)    (labels of sweep k in class copy k & 1, expected sizes filed)
+//   apply(k)   waits for recount(k-2)                (it rewrites class copy k & 1, which pass k-2 was reading)
+// Neither wait blocks in steady state: on one big volume stream A is a sweep ahead and stream B runs its recounts
+// back to back; on small slabs stream B is idle most of the time and stream A never finds pass k-2 unfinished.
+// The band kernels read and write the label BYTES only; the dense pass reads the class bits only.
 static void enqueue_pre(const VrgCtx& c, int variant) {         // decide + flip list, marks + prepass, fix-point, relabel
     k_decide<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     k_marks_prepass<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
@@ -992,8 +879,7 @@ static void enqueue_pre(const VrgCtx& c, int variant) {         // decide + flip
     if (!(variant & 1)) k_relabel<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     else k_full_relabel<<<2048, TPB, 0, g_stream>>>(c);
 }
-static void enqueue_post(const VrgCtx& c) {                     // band bookkeeping (new lists, densities), iterNum += 1
-    k_entry_post<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+static void enqueue_post(const VrgCtx& c) {                     // rest of the band bookkeeping (new lists, densities), iterNum += 1
     if (c.L <= LEVELS_ONEBLOCK) k_levels_small<<<1, 1024, 0, g_stream>>>(c);
     else {
         k_delta_flag<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
@@ -1009,8 +895,8 @@ static void enqueue_post(const VrgCtx& c) {                     // band bookkeep
 }
 
 // With option "graph" the two runs of band kernels are replayed from captured hipGraphs (one host call each);
-// apply, the event edges, the recount and the collective stay eager, so nothing depends on RCCL supporting
-// stream capture and the per-launch HIP-event timing of the recount keeps working.
+// apply, entry_post, the event edges, the recount and the collective stay eager, so nothing depends on RCCL
+// supporting stream capture and the per-launch HIP-event timing of the recount keeps working.
 struct GraphCache { hipGraphExec_t exec = nullptr; VrgCtx key; int variant = -1; bool valid = false; };
 static GraphCache g_graph_pre, g_graph_post;
 #define g_use_graph g_use_graph_req
@@ -1040,51 +926,35 @@ template <class F> static void run_band(GraphCache& g, const VrgCtx& c, int vari
     enqueue();
 }
 
-// Which stream applies the labels decides where the two cross-stream hops (an event wait costs ~15 us here) fall:
-//   dense-bound (one GPU, big volume): k_apply runs on stream B between two recounts, so B never waits - its
-//     edge from A (k_relabel done) was satisfied long ago - and A takes both hops inside its slack;
-//   band-bound (small slab per GPU): k_apply stays on stream A, which then never waits for B in practice.
-static bool apply_on_dense_stream(const VrgCtx& c) {
-    if (g_apply_stream) return g_apply_stream == 2;
-    return (uint64_t)(c.z1 - c.z0) * c.PY * c.PX >= (160ull << 20);   // recount ~ as long as the band chain (~0.11 ms)
-}
-
 void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb, void* user) {
-    const bool on_b = apply_on_dense_stream(c);
-    hipStream_t sa = on_b ? g_stream_b : g_stream;
-    // every event record / wait is a barrier packet of a few us on its stream: the two timing events of the recount
-    // double as the edges "labels applied" and "labels read"
-    hipEvent_t e_applied = g_ev_a, e_read = g_ev_d, e_start = nullptr;
+    // every event record / wait is a barrier packet of a few us on its stream: the end-of-recount timing event
+    // doubles as the edge "class copy read"
+    hipEvent_t e_start = nullptr, e_read = g_ev_d[g_trip & 1];
     if (ev && ev->enabled) {
         if (g_ev_used == g_ev_pool.size()) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); g_ev_pool.push_back(n); }
         EvPair& p = g_ev_pool[g_ev_used++];
-        e_read = p.b;
-        if (on_b) e_applied = p.a; else e_start = p.a;
+        e_start = p.a; e_read = p.b;
     }
     run_band(g_graph_pre, c, variant, [&] { enqueue_pre(c, variant); });
-    if (on_b) {
-        HIP_CHECK(hipEventRecord(g_ev_r, g_stream));
-        HIP_CHECK(hipStreamWaitEvent(g_stream_b, g_ev_r, 0));
-    } else if (g_last_read) {
-        // the labels change now: the previous dense pass must have read them
-        HIP_CHECK(hipStreamWaitEvent(g_stream, g_last_read, 0));
-    }
-    if (!(variant & 1)) k_apply<<<ITEM_BLOCKS, TPB, 0, sa>>>(c);
-    else k_copy_back<<<2048, TPB, 0, sa>>>(c);
-    HIP_CHECK(hipEventRecord(e_applied, sa));
-    // dense stream: every voxel once, read-only.  Enqueued before the bookkeeping so that its dispatch never waits
-    // for the host to issue those launches.
-    if (!on_b) HIP_CHECK(hipStreamWaitEvent(g_stream_b, e_applied, 0));
+    // the labels change now, in the class copy the dense pass of two sweeps ago was reading
+    if (g_read[g_trip & 1]) HIP_CHECK(hipStreamWaitEvent(g_stream, g_read[g_trip & 1], 0));
+    if (!(variant & 1)) k_apply<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    else k_copy_back<<<2048, TPB, 0, g_stream>>>(c);
+    k_entry_post<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    HIP_CHECK(hipEventRecord(g_ev_a, g_stream));
+    // dense stream: every voxel once, read-only.  Enqueued before the rest of the bookkeeping so that its dispatch
+    // never waits for the host to issue those launches.
+    HIP_CHECK(hipStreamWaitEvent(g_stream_b, g_ev_a, 0));
     if (e_start) HIP_CHECK(hipEventRecord(e_start, g_stream_b));
     const bool ranks = c.world > 1 || g_comm || cb;
     launch_recount(c, dense_blocks(c), ranks ? 1 : 2, g_stream_b);
     HIP_CHECK(hipEventRecord(e_read, g_stream_b));
-    g_last_read = e_read;
+    g_read[g_trip & 1] = e_read;
+    g_trip++;
     if (ranks) {                                     // one GPU: the last workgroup of the recount closes the pass itself
         reduce_dense(c, cb, user, g_stream_b);       // sum over the Z-slabs (RCCL on the stream / host callback)
         k_dense_fin<<<1, 1, 0, g_stream_b>>>(c);
     }
-    if (on_b) HIP_CHECK(hipStreamWaitEvent(g_stream, e_applied, 0));
     run_band(g_graph_post, c, 0, [&] { enqueue_post(c); });
 }
 

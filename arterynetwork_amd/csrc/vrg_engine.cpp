@@ -70,6 +70,7 @@ int check_state_error(vrg_handle* h, const VrgState& s) {
     if (const char* be = be_last_error()) return fail(h, VRG_E_INTERNAL, be);
     if (s.error == 1) return fail(h, VRG_E_CAPACITY, "band capacity exceeded; raise option band_capacity");
     if (s.error == 2) return fail(h, VRG_E_CAPACITY, "flip capacity exceeded; raise option band_capacity");
+    if (s.error == 7) return fail(h, VRG_E_CAPACITY, "class-change list capacity exceeded; raise option band_capacity");
     if (s.error) return fail(h, VRG_E_INTERNAL, "internal consistency check failed (code " + std::to_string(s.error) + ")");
     return VRG_OK;
 }
@@ -96,7 +97,8 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     h->V = nx * ny * nz;
     const size_t PVu = ((size_t)c.PV + 1023) / 1024 * 1024;   // dense arrays end on a whole 1024-voxel unit
     c.I = alloc<float>(h, PVu);
-    c.cls = alloc<uint32_t>(h, PVu / 16);
+    c.clsb[0] = alloc<uint32_t>(h, PVu / 16); c.clsb[1] = alloc<uint32_t>(h, PVu / 16);
+    c.nchg = alloc<uint32_t>(h, 32);
     // 16 guard bytes in front: voxel (0,0,0)'s 2-ring reaches 2 bytes before the padded array
     h->lab_base[0] = alloc<uint8_t>(h, (size_t)c.PV + 32);
     h->lab_base[1] = alloc<uint8_t>(h, (size_t)c.PV + 32);
@@ -109,10 +111,12 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.dn_part = alloc<VrgDense>(h, 16);
     c.inc = alloc<int64_t>(h, 32); c.dctl = alloc<int64_t>(h, 32);   // one allocation each: written from different streams
     c.world = 1;
-    if (!c.I || !c.lab[0] || !c.lab[1] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.inc || !c.dctl || !c.cls) { API(destroy)(h); return VRG_E_MEM; }
+    if (!c.I || !c.lab[0] || !c.lab[1] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] || !c.nchg) { API(destroy)(h); return VRG_E_MEM; }
     be_fill(c.inc, 0, 32 * sizeof(int64_t)); be_fill(c.dctl, 0, 32 * sizeof(int64_t));
     be_fill((void*)c.I, 0, PVu * 4);
-    if (c.cls) be_fill(c.cls, 0, PVu / 4);
+    if (c.clsb[0]) be_fill(c.clsb[0], 0, PVu / 4);
+    if (c.clsb[1]) be_fill(c.clsb[1], 0, PVu / 4);
+    if (c.nchg) be_fill(c.nchg, 0, 32 * sizeof(uint32_t));
     be_fill(h->lab_base[0], VB_OOB, (size_t)c.PV + 32);
     be_fill(h->lab_base[1], VB_OOB, (size_t)c.PV + 32);
     be_fill(c.st, 0, sizeof(VrgState));
@@ -139,7 +143,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "sweep_variant") h->variant = (int)value;
     else if (n == "events") h->ev.enabled = value != 0;
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
-    else if (n == "sweep_blocks" || n == "prio_mode" || n == "graph" || n == "recount_mode" || n == "apply_stream") be_set_tuning(name, value);
+    else if (n == "sweep_blocks" || n == "prio_mode" || n == "graph") be_set_tuning(name, value);
     else if (n == "storage16") { if (h->inited) return fail(h, VRG_E_STATE, "storage16 must be set before vrg_init"); h->storage16 = value != 0; }
     else return fail(h, VRG_E_ARG, "unknown option " + n);
     return VRG_OK;
@@ -222,6 +226,12 @@ int API(init)(vrg_handle* h, double H) {
         c.init_key = alloc<uint64_t>(h, c.bcap); c.init_idx = alloc<uint32_t>(h, c.bcap);
         c.mcap = (uint32_t)std::min<uint64_t>(V, 0xffffffffull);
         c.mk_idx = alloc<uint32_t>(h, c.mcap); c.mk_new = alloc<uint8_t>(h, (size_t)c.mcap + 16);
+        // class changes of one sweep: its flips (<= band) + excluded voxels it includes; 2 x band covers what the band does
+        c.ccap = (uint32_t)std::min<uint64_t>(V, 2 * (uint64_t)c.bcap);
+        for (int p = 0; p < 2; p++) {
+            c.chg_dw[p] = alloc<uint32_t>(h, c.ccap); c.chg_x[p] = alloc<uint32_t>(h, c.ccap);
+            if (!c.chg_dw[p] || !c.chg_x[p]) return fail(h, VRG_E_MEM, "vrg_init: class-change lists");
+        }
         c.nstat = 4096;
         c.st_nin = alloc<int64_t>(h, c.nstat); c.st_nout = alloc<int64_t>(h, c.nstat);
         c.st_sin = alloc<double>(h, c.nstat); c.st_sout = alloc<double>(h, c.nstat);

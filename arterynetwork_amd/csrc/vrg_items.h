@@ -200,23 +200,41 @@ VRG_HD void vrg_cls_pos(uint32_t idx, uint32_t& dw, uint32_t& sh) {
     dw = ((idx >> 10) << 6) | ((o & 255u) >> 2);
     sh = 2u * (((o >> 8) << 2) | (o & 3u));
 }
-// a label byte changes: keep the class bits and the region sizes in step
+// a label byte changes during sweep iter+1: keep the region sizes and that sweep's copy of the class bits in step,
+// and note the change for the other copy
 VRG_HD void vrg_count_change(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t nw) {
     uint32_t a = vrg_cls_of(old), b = vrg_cls_of(nw);
     if (a == b) return;
+    const int p = (c.st->iter + 1) & 1;
     uint32_t dw, sh; vrg_cls_pos(idx, dw, sh);
-    vrg_atomic_xor(&c.cls[dw], (a ^ b) << sh);
+    const uint32_t x = (a ^ b) << sh;
+    vrg_atomic_xor(&c.clsb[p][dw], x);
+    uint32_t q = vrg_atomic_add(&c.nchg[p], 1u);
+    if (q < c.ccap) { c.chg_dw[p][q] = dw; c.chg_x[p][q] = x; } else c.st->error = 7;
     int din = (int)(b == 1u) - (int)(a == 1u), dout = (int)(b == 2u) - (int)(a == 2u);
     if (din) vrg_atomic_add64(&c.inc[VC_NIN], din);
     if (dout) vrg_atomic_add64(&c.inc[VC_NOUT], dout);
 }
+// change i of the sweep before: this sweep's copy of the class bits sat that sweep out
+VRG_HD void vrg_item_catchup(const VrgCtx& c, uint32_t i) {
+    const int p = (c.st->iter + 1) & 1;
+    vrg_atomic_xor(&c.clsb[p][c.chg_dw[p ^ 1][i]], c.chg_x[p ^ 1][i]);
+}
+VRG_HD uint32_t vrg_catchup_count(const VrgCtx& c) { uint32_t n = c.nchg[((c.st->iter + 1) & 1) ^ 1]; return n < c.ccap ? n : c.ccap; }
 VRG_HD void vrg_item_apply(const VrgCtx& c, uint32_t i) {
     uint32_t idx = c.mk_idx[i];
     uint8_t old = c.lab[0][idx], nw = c.mk_new[i];
     c.lab[0][idx] = nw;
     vrg_count_change(c, idx, old, nw);
 }
-// init: class dword d from the labels (16 voxels)
+// one caller, after every label of sweep iter+1 is written and before anything of the next sweep: file the sizes
+// that sweep's dense pass has to reproduce; the change list just consumed becomes the next sweep's
+VRG_HD void vrg_post_apply(const VrgCtx& c) {
+    const int64_t k = (int64_t)c.st->iter + 1;
+    c.inc[VC_EXP + 2 * (k & 3)] = c.inc[VC_NIN]; c.inc[VC_EXP + 2 * (k & 3) + 1] = c.inc[VC_NOUT];
+    c.nchg[(k & 1) ^ 1] = 0;
+}
+// init: class dword d from the labels (16 voxels), both copies
 VRG_HD void vrg_item_cls_build(const VrgCtx& c, uint32_t d) {
     uint32_t base = ((d >> 6) << 10) | ((d & 63u) << 2), w = 0;
     for (uint32_t j = 0; j < 4; j++)
@@ -224,24 +242,25 @@ VRG_HD void vrg_item_cls_build(const VrgCtx& c, uint32_t d) {
             uint32_t idx = base + 256u * j + b;
             if (idx < c.PV) w |= vrg_cls_of(c.lab[0][idx]) << (2u * (4u * j + b));
         }
-    c.cls[d] = w;
+    c.clsb[0][d] = w; c.clsb[1][d] = w;
 }
 // one caller per applied sweep: the labels of sweep iter+1 are in place, a dense pass over them is due
 VRG_HD void vrg_request_dense(const VrgCtx& c) { c.inc[VC_REQ] = (int64_t)c.st->iter + 1; }
 VRG_HD bool vrg_dense_due(const VrgCtx& c) { return c.inc[VC_REQ] > c.dctl[VD_SEQ]; }
-// the dense pass has the totals in c.dn: cross-check the sizes it had to reproduce, file the sums, close the pass
+// the dense pass (number seq = passes closed + 1, reading clsb[seq & 1]) has the totals in c.dn: cross-check the sizes
+// it had to reproduce, file the sums, close the pass
 VRG_HD void vrg_dense_fin(const VrgCtx& c) {
     if (!vrg_dense_due(c)) return;
     int64_t seq = c.dctl[VD_SEQ] + 1;
     const VrgDense& d = *c.dn;
-    if ((int64_t)d.n_in != c.dctl[VD_NIN] || (int64_t)d.n_out != c.dctl[VD_NOUT]) c.st->error = 5;
+    if ((int64_t)d.n_in != c.inc[VC_EXP + 2 * (seq & 3)] || (int64_t)d.n_out != c.inc[VC_EXP + 2 * (seq & 3) + 1]) c.st->error = 5;
     if ((uint64_t)seq < c.trace_cap) { c.trace[seq].sum_in = d.sum_in; c.trace[seq].sum_out = d.sum_out; }
     c.dctl[VD_SEQ] = seq;
 }
 // init: the dense pass founds the incremental sizes
 VRG_HD void vrg_init_counts(const VrgCtx& c) {
     c.inc[VC_NIN] = (int64_t)c.dn->n_in; c.inc[VC_NOUT] = (int64_t)c.dn->n_out; c.inc[VC_REQ] = 0;
-    c.dctl[VD_SEQ] = 0; c.dctl[VD_NIN] = c.inc[VC_NIN]; c.dctl[VD_NOUT] = c.inc[VC_NOUT];
+    c.dctl[VD_SEQ] = 0; c.nchg[0] = 0; c.nchg[1] = 0;
 }
 
 // ------------------------------------------------------------------ the relabel stencil for one voxel

@@ -72,8 +72,9 @@ struct VrgDense {            // all four as double so one all-reduce sums them o
     double sum_in, sum_out;  // sums of intensities over the two regions
 };
 
-enum { VC_NIN = 0, VC_NOUT = 1, VC_REQ = 2 };     // VrgCtx::inc
-enum { VD_SEQ = 0, VD_NIN = 1, VD_NOUT = 2 };     // VrgCtx::dctl
+enum { VC_NIN = 0, VC_NOUT = 1, VC_REQ = 2, VC_EXP = 8 };   // VrgCtx::inc; VC_EXP: ring of 4 x {n_in, n_out}, the sizes
+                                                            // after sweep k at slot k & 3 (what dense pass k must reproduce)
+enum { VD_SEQ = 0 };                              // VrgCtx::dctl
 
 struct VrgCtx {
     int32_t nx, ny, nz;
@@ -85,9 +86,16 @@ struct VrgCtx {
     const uint16_t* lev16;     // optional 16-bit storage: level index per voxel (same layout); the dense pass then
                                // streams 2 B instead of 4 B of intensity per voxel (values come from an LDS table)
     uint8_t* lab[2];           // lab[0]: label bytes, updated in place; lab[1]: scratch of the full-stencil check variant
-    uint32_t* cls;             // class bits: what the dense pass needs of a label - inner (S) / outer (not S, not excluded) -
-                               // 2 bits per voxel, kept in step by every label write; lane l of a wave owns dword l of each
-                               // 1024-voxel unit (its 16 voxels 256*j + 4*l + b), so a unit is one coalesced 256-B request
+    // class bits: what the dense pass needs of a label - inner (S) / outer (not S, not excluded) - 2 bits per voxel;
+    // lane l of a wave owns dword l of each 1024-voxel unit (its 16 voxels 256*j + 4*l + b), so a unit is one coalesced
+    // 256-B request.  TWO copies: the dense pass of sweep k reads clsb[k & 1] while k_apply of sweep k+1 already
+    // writes clsb[(k+1) & 1]; each copy therefore receives the class changes of two sweeps at a time - its own and,
+    // from the change list of the sweep before (chg_*[(k-1) & 1]), the one it sat out.
+    uint32_t* clsb[2];
+    uint32_t ccap;             // capacity of the class-change lists
+    uint32_t* chg_dw[2];       // per sweep parity: dword index ...
+    uint32_t* chg_x[2];        // ... and xor mask of every class change that sweep made
+    uint32_t* nchg;            // their lengths (2 counters, own allocation)
     uint32_t mcap;             // marked-voxel list: index and new byte
     uint32_t* mk_idx;
     uint8_t* mk_new;
@@ -131,8 +139,7 @@ struct VrgCtx {
     VrgDense* dn_part;         // this device's slab partials (input of the all-reduce)
     int64_t* inc;              // band side (own cache line): region sizes kept by increments as labels are applied -
                                // what the decisions and stop tests read - and the sweep number of the last apply
-    int64_t* dctl;             // dense side (own cache line): dense passes closed since init, and the region sizes
-                               // the pass in flight has to reproduce
+    int64_t* dctl;             // dense side (own cache line): dense passes closed since init
     int32_t world;             // number of slabs / ranks (1: dn is written directly)
     uint32_t* counters;        // arrival tickets of the last-workgroup reductions (zero between launches)
     VrgTrace* trace;

@@ -85,8 +85,6 @@ def bench_slabs(shape, args, dev, rank, world):
     s.set_option('events', 1)
     s.set_option('graph', use_graph)           # band kernels replayed from two hipGraphs: at 8 ranks the step is ~0.1 ms,
     s.set_option('batch', 64)                  # close to the cost of issuing its ~25 launches one by one
-    if getattr(args, 'apply_stream', -1) >= 0:
-        s.set_option('apply_stream', args.apply_stream)
     s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
     s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
     s.init(args.H)

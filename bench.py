@@ -123,8 +123,6 @@ def main():
     ap.add_argument('--variant', type=int, default=0)
     ap.add_argument('--sweep-blocks', type=int, default=0)
     ap.add_argument('--prio-mode', type=int, default=-1)
-    ap.add_argument('--recount-mode', type=int, default=-1)
-    ap.add_argument('--apply-stream', type=int, default=-1)
     ap.add_argument('--events', type=int, default=1, help='0: no HIP events around the dense launches (no roofline then)')
     ap.add_argument('--graph', type=int, default=0, help='replay the band kernels of each sweep from captured hipGraphs')
     ap.add_argument('--storage16', action='store_true', help='16-bit intensity storage (level indices): config 5 style; 4 B/voxel-iter algorithmic')
@@ -169,10 +167,6 @@ def main():
         s.set_option('sweep_blocks', args.sweep_blocks)
     if args.prio_mode >= 0:
         s.set_option('prio_mode', args.prio_mode)
-    if args.recount_mode >= 0:
-        s.set_option('recount_mode', args.recount_mode)
-    if args.apply_stream >= 0:
-        s.set_option('apply_stream', args.apply_stream)
     if args.storage16:
         s.set_option('storage16', 1)
     s.set_option('events', args.events)

@@ -73,7 +73,7 @@ const char* vrg_last_error(const vrg_handle* h);
  *   "events"         any time; time every dense-pass launch with HIP events (vrg_result.sweep_kernel_ms)
  *   "batch"          any time; sweeps enqueued between host checks of the stop flag (default 8)
  *   "graph"          any time; replay the band kernels of each sweep from two captured hipGraphs
- *   "sweep_blocks", "recount_mode", "prio_mode", "apply_stream"
+ *   "sweep_blocks", "prio_mode"
  *                    any time; launch tuning knobs of the dense pass / the two streams (0 = automatic) */
 int vrg_set_option(vrg_handle* h, const char* name, int64_t value);
 

@@ -28,7 +28,7 @@ for sd in range(300000, 300000 + n_small):
     I, vm, H, variant, dmode = random_case(sd)
     try:
         res, k = parity.run_batched(lib, I, vm, H, None, 40, density_mode=dmode,
-                                    options={'sweep_variant': variant, 'batch': 1 + sd % 7, 'apply_stream': sd % 3, 'graph': (sd // 3) % 2})
+                                    options={'sweep_variant': variant, 'batch': 1 + sd % 7, 'graph': (sd // 3) % 2})
         sweeps += k; amb += res is None
     except Exception as e:
         fails += 1; print('FAIL batched', sd, type(e).__name__, str(e)[:200].replace('\n', ' '))

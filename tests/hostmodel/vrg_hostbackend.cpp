@@ -120,10 +120,11 @@ void be_init_sort(const VrgCtx& c, uint32_t n_in, uint32_t n_out) {
 // the dense recount over this handle's Z-slab, then the sum over the slabs (callback) if there are several
 static void dense_stats(const VrgCtx& c, const uint8_t* lab, be_reduce_fn cb, void* user) {
     int64_t a = 0, b = 0; double sa = 0, sb = 0;
+    const uint32_t* cls = c.clsb[(c.dctl[VD_SEQ] + 1) & 1];
     for_real_voxels(c, [&](uint32_t idx, int, int, int z) {
         if (z < c.z0 || z >= c.z1) return;
         uint32_t dw, sh; vrg_cls_pos(idx, dw, sh);
-        uint32_t k = (c.cls[dw] >> sh) & 3u;                 // the dense pass reads the class bits ...
+        uint32_t k = (cls[dw] >> sh) & 3u;                   // the dense pass reads its copy of the class bits ...
         if (k != vrg_cls_of(lab[idx])) c.st->error = 6;      // ... which every label write must have kept in step
         double v = c.lev16 ? (double)(float)c.lev[c.lev16[idx]] : (double)c.I[idx];
         if (k == 1u) { a++; sa += v; }
@@ -133,7 +134,6 @@ static void dense_stats(const VrgCtx& c, const uint8_t* lab, be_reduce_fn cb, vo
     p.n_in = (double)a; p.n_out = (double)b; p.sum_in = sa; p.sum_out = sb;
     *c.dn = p;
     if (cb) cb(&c.dn->n_in, user);
-    c.dctl[VD_NIN] = c.inc[VC_NIN]; c.dctl[VD_NOUT] = c.inc[VC_NOUT];
 }
 
 void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
@@ -176,12 +176,15 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*, be_reduce_fn cb, vo
         if (s.nmk > c.mcap) { s.error = 4; s.done = -1; return; }
         for (uint32_t i = 0; i < s.nmk; i++) vrg_item_relabel(c, i);
         for (uint32_t i = 0; i < s.nmk; i++) vrg_item_apply(c, i);
+        for (uint32_t i = 0, nc = vrg_catchup_count(c); i < nc; i++) vrg_item_catchup(c, i);
     } else {
         // full-stencil check variant: every voxel, through the scratch volume
         for_real_voxels(c, [&](uint32_t idx, int, int, int) { c.lab[1][idx] = vrg_sweep_core(c, lab, idx, lab[idx]); });
         for_real_voxels(c, [&](uint32_t idx, int, int, int) { vrg_count_change(c, idx, lab[idx], c.lab[1][idx]); lab[idx] = c.lab[1][idx]; });
+        for (uint32_t i = 0, nc = vrg_catchup_count(c); i < nc; i++) vrg_item_catchup(c, i);
     }
     vrg_request_dense(c);
+    vrg_post_apply(c);
     dense_stats(c, lab, cb, user);          // the dense recount (:113-116) ...
     vrg_dense_fin(c);                       // ... cross-checks the incremental sizes and files the sums
     // band bookkeeping

@@ -119,12 +119,12 @@ def test_random_volumes_in_one_call(lib):
     for sd in range(300, 400):
         I, vm, H, variant, dmode = random_case(sd)
         res, k = parity.run_batched(lib, I, vm, H, None, 40, density_mode=dmode,
-                                    options={'sweep_variant': variant, 'batch': 1 + sd % 7, 'apply_stream': sd % 3})
+                                    options={'sweep_variant': variant, 'batch': 1 + sd % 7})
         sweeps += k
     for sd in range(6000, 6020):
         I, vm, H, variant, dmode = random_case(sd, 8, 26)
         res, k = parity.run_batched(lib, I, vm, H, None, 30, density_mode=1,
-                                    options={'sweep_variant': variant, 'batch': 8, 'apply_stream': sd % 3,
+                                    options={'sweep_variant': variant, 'batch': 8,
                                              'storage16': sd % 2, 'graph': (sd // 2) % 2})
         sweeps += k
     assert sweeps > 400
@@ -137,7 +137,7 @@ def test_medium_tube_vs_oracle(lib):
                                        amp_z=9.0, levels=64, brain_mask=True)
     res, k = parity.run_stepwise(lib, data, vmap, 2.25, None, 60, density_mode=1, every=10, check_hist=True)
     assert res is not None and k == 60 and res.nseg > 1000
-    for opts in ({'apply_stream': 1}, {'apply_stream': 2}, {'apply_stream': 2, 'storage16': 1, 'graph': 1}):
+    for opts in ({'batch': 3}, {'storage16': 1, 'graph': 1}):
         res, k = parity.run_batched(lib, data, vmap, 2.25, None, 60, density_mode=1, options=opts)
         assert res is not None and k == 60
 
