@@ -4,15 +4,16 @@
 //   stream A, band kernels (O(band) work, grid-stride over device-resident counts, no host round trip):
 //     k_decide (+listing) -> k_marks_prepass (stop tests, marks, skip-rule prepass) -> k_fix
 //     -> k_relabel (3x3x3 / 5x5x5 label stencil on the marked voxels, old labels only)
-//     -> k_apply (writes the new labels, keeps the region sizes in step)
+//     -> k_apply (writes the new label bytes, keeps the region sizes and the class bits in step)
 //     -> k_entry_post, k_levels_small (level-delta compaction), k_tab, rebuild scan, k_scatter, k_exact
 //     -> k_finalize closes the trip;
-//   stream B, the dense pass, forked after k_apply:
-//     k_recount : the dense kernel (every voxel, HBM-bound, read-only: 4 B intensity + 1 B label per voxel):
-//        region sizes and intensity sums (:113-116, :249-250), reduced by its last workgroup
-//     -> slab all-reduce (multi-GPU) -> k_dense_fin (cross-check against the incremental sizes, trace sums).
-//   Stream A does not join: it goes on with the next trip up to k_relabel and only k_apply waits for the
-//   recount of the previous trip (see be_sweep_once).
+//   stream B, the dense pass, forked after k_entry_post:
+//     k_recount_bits : the dense kernel (every voxel, HBM-bound, read-only: 4 B intensity + 2 class bits per
+//        voxel): region sizes and intensity sums (:113-116, :249-250), reduced by its last workgroup, checked
+//        against the sizes the band side keeps by increments
+//     -> on several GPUs: slab all-reduce -> k_dense_fin (the same check on the totals, trace sums).
+//   Stream A does not join: it runs up to two sweeps ahead of the dense pass (two copies of the class bits; see
+//   be_sweep_once).
 // Labels are updated IN PLACE: measured on MI355X, streaming I + labels read-only runs at 5.8-6.0 TB/s
 // while the same stream with a 1 B/voxel label write-back drops to 4.8 TB/s, so unchanged labels are
 // never rewritten.  (The full-stencil check variant relabels every voxel through lab[1].)
