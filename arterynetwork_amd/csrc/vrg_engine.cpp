@@ -226,8 +226,9 @@ int API(init)(vrg_handle* h, double H) {
         c.init_key = alloc<uint64_t>(h, c.bcap); c.init_idx = alloc<uint32_t>(h, c.bcap);
         c.mcap = (uint32_t)std::min<uint64_t>(V, 0xffffffffull);
         c.mk_idx = alloc<uint32_t>(h, c.mcap); c.mk_new = alloc<uint8_t>(h, (size_t)c.mcap + 16);
-        // class changes of one sweep: its flips (<= band) + excluded voxels it includes; 2 x band covers what the band does
-        c.ccap = (uint32_t)std::min<uint64_t>(V, 2 * (uint64_t)c.bcap);
+        // class changes of one sweep: its flips + the excluded voxels it includes - a small fraction of the band in
+        // practice; everything for small volumes, 2 x band when the caller sized the band explicitly
+        c.ccap = (uint32_t)std::min<uint64_t>(V, h->band_capacity ? 2 * (uint64_t)c.bcap : std::max<uint64_t>(4u << 20, c.bcap / 4));
         for (int p = 0; p < 2; p++) {
             c.chg_dw[p] = alloc<uint32_t>(h, c.ccap); c.chg_x[p] = alloc<uint32_t>(h, c.ccap);
             if (!c.chg_dw[p] || !c.chg_x[p]) return fail(h, VRG_E_MEM, "vrg_init: class-change lists");

@@ -1,6 +1,6 @@
 """Z-slab multi-GPU driver: one process per GPU, torch.distributed for rendezvous, RCCL for the data path.
 
-What is sharded: the dense per-sweep recount (every voxel: 4 B intensity + 1 B label), cut into
+What is sharded: the dense per-sweep recount (every voxel: 4 B intensity + 2 class bits), cut into
 contiguous Z-slabs, one per rank.  What is replicated: the label volume and the O(band) relabel, which
 is deterministic, so all ranks hold identical labels without exchanging halo planes.  The only
 per-sweep exchange is a 32-byte all-reduce of the region statistics {n_in, n_out, sum_in, sum_out},
