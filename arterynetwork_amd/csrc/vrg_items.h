@@ -73,6 +73,14 @@ VRG_HD int32_t vrg_off(const VrgCtx& c, int k) {
     int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
     return (dz * c.PY + dy) * c.PX + dx;
 }
+// the 27 label bytes around idx in one go: straight-line loads, so that the device issues them back to back and
+// waits once (a loop with tests between the loads waits for every byte: 26 dependent L2 round trips)
+VRG_HD void vrg_load_nbrs(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t nb[27]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 27; k++) nb[k] = lab[(int64_t)idx + vrg_off(c, k)];
+}
 
 VRG_HD uint8_t vrg_enc(uint8_t ext) {     // reference label -> byte
     return ext == 0 ? VB_S : ext == 1 ? (VB_S | VB_B) : ext == 2 ? VB_B : ext == 4 ? VB_X : 0;
@@ -100,21 +108,23 @@ VRG_HD uint32_t vrg_voxel_level(const VrgCtx& c, uint32_t idx) {
 // One item per band entry.  A flip is listed at once: L bit (+P for flip-outs, which are always
 // applied), stamp = (sweep, entry index) and an unordered append to the flip list.
 VRG_HD void vrg_item_decide(const VrgCtx& c, uint32_t e) {
-    VrgState& s = *c.st;
+    const VrgState s = *c.st;                             // a copy (nf is only ever bumped atomically below)
     if (s.iter >= s.iterMax) return;                      // while iterNum <= iterMax (:58)
     int cur = s.iter & 1;
-    double inN = c.b_ip[cur][e] / (double)c.inc[VC_NIN];  // :81
-    double outN = c.b_op[cur][e] / (double)c.inc[VC_NOUT];// :82
+    const double ip = c.b_ip[cur][e], op = c.b_op[cur][e];
+    const uint32_t idx = c.b_idx[cur][e];
+    const int64_t n_in = c.inc[VC_NIN], n_out = c.inc[VC_NOUT];
+    double inN = ip / (double)n_in;                       // :81
+    double outN = op / (double)n_out;                     // :82
     bool ge = inN >= outN;
     bool inner = e < s.ni;
     bool flip = inner != ge;                              // :87 xor(segmentedMap, inner >= outer)
     c.e_flag[e] = flip ? 1 : 0; c.e_res[e] = 0; c.e_mask[e] = 0;
     if (!flip) return;
-    uint32_t q = vrg_atomic_add(&s.nf, 1u);
-    if (s.time_up || c.inc[VC_NIN] >= s.maxSegmentSize) return;   // :97 / :101 fire before update(): count only
-    if (q >= c.fcap) { s.error = 2; return; }
+    uint32_t q = vrg_atomic_add(&c.st->nf, 1u);
+    if (s.time_up || n_in >= s.maxSegmentSize) return;    // :97 / :101 fire before update(): count only
+    if (q >= c.fcap) { c.st->error = 2; return; }
     c.flist[q] = e;
-    uint32_t idx = c.b_idx[cur][e];
     vrg_or_byte(c.lab[0], idx, (uint8_t)(VB_L | (inner ? VB_P : 0)));
     c.stamp[idx] = ((uint64_t)(uint32_t)(s.iter + 1) << 32) | e;
 }
@@ -136,9 +146,10 @@ VRG_HD void vrg_item_prepass(const VrgCtx& c, uint32_t e) {
     uint32_t idx = c.b_idx[s.iter & 1][e];
     const uint8_t* lab = c.lab[0];
     bool nFO = false, nSegA = false;
+    uint8_t nb[27]; vrg_load_nbrs(c, lab, idx, nb);
     for (int k = 0; k < 27; k++) {
         if (k == 13) continue;
-        uint8_t m = lab[(int64_t)idx + vrg_off(c, k)];
+        uint8_t m = nb[k];
         if (m & VB_S) { if (m & VB_L) nFO = true; else nSegA = true; }
     }
     if (nFO && !nSegA) c.pend[vrg_atomic_add(&s.npend, 1u)] = e;   // dropped to 3: skipped unless re-promoted
@@ -265,12 +276,12 @@ VRG_HD void vrg_init_counts(const VrgCtx& c) {
 
 // ------------------------------------------------------------------ the relabel stencil for one voxel
 // phase-B promotion (3 -> 2, :210-213): list key (first applied flip-in neighbour, k)
-VRG_HD void vrg_promote_b(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
+VRG_HD void vrg_promote_b(const VrgCtx& c, const uint8_t* nb, uint32_t idx) {
     uint32_t best = 0xffffffffu; int bk = 0;
     for (int k = 0; k < 27; k++) {
         if (k == 13) continue;
         uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
-        uint8_t mb = lab[m];
+        uint8_t mb = nb[k];
         if (!(mb & VB_S) && (mb & VB_P)) {
             uint32_t r = (uint32_t)c.stamp[m];
             if (r < best) { best = r; bk = 26 - k; }
@@ -279,12 +290,12 @@ VRG_HD void vrg_promote_b(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
     vrg_atomic_or(&c.e_mask[best], 1u << bk);
 }
 // phase-A promotion (0 -> 1, :194-196): list key (first flip-out neighbour, k)
-VRG_HD void vrg_promote_a(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
+VRG_HD void vrg_promote_a(const VrgCtx& c, const uint8_t* nb, uint32_t idx) {
     uint32_t best = 0xffffffffu; int bk = 0;
     for (int k = 0; k < 27; k++) {
         if (k == 13) continue;
         uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
-        uint8_t mb = lab[m];
+        uint8_t mb = nb[k];
         if ((mb & VB_S) && (mb & VB_L)) {
             uint32_t r = (uint32_t)c.stamp[m];
             if (r < best) { best = r; bk = 26 - k; }
@@ -297,9 +308,10 @@ VRG_HD void vrg_promote_a(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
 // e_mask (promotions), dConv (4->3 inclusions).  Ranks (low stamp word) are band entry indices.  `lab` = this sweep's input labels (L/P bits set).
 VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t cb) {
     bool nSegA = false, nFO = false, nAP = false, nNonSegB = false, nListed = false;
+    uint8_t nb[27]; vrg_load_nbrs(c, lab, idx, nb);
     for (int k = 0; k < 27; k++) {
         if (k == 13) continue;
-        uint8_t m = lab[(int64_t)idx + vrg_off(c, k)];
+        uint8_t m = nb[k];
         if (m & VB_OOB) continue;                     // neighbour does not exist (:278-280)
         bool mS = m & VB_S, mL = m & VB_L, mP = m & VB_P;
         bool segA = mS && !mL, ap = !mS && mP;
@@ -313,13 +325,13 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
                 for (int k = 0; k < 27 && !to3; k++) {
                     if (k == 13) continue;
                     uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
-                    uint8_t mb = lab[m];
+                    uint8_t mb = nb[k];
                     if ((mb & VB_S) && (mb & VB_L) && (uint32_t)c.stamp[m] > r) to3 = true;
                 }
             if (!to3) { c.e_res[r] = FR_WRITTEN | 2; return VB_B; }          // stays 2, carried to the outer list
             if (nAP) {                                                      // 3 -> 2 again (:210-213): fresh
                 c.e_res[r] = FR_WRITTEN | 2 | FR_FRESH;
-                vrg_promote_b(c, lab, idx);
+                vrg_promote_b(c, nb, idx);
                 return VB_B;
             }
             c.e_res[r] = FR_WRITTEN | 3;
@@ -328,7 +340,7 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
         bool is1 = (cb & VB_B) || nFO;                // label after phase A (:194)
         if (!is1) return VB_S;
         if (nAP && !nNonSegB) return VB_S;            // 1 -> 0 (:223-228)
-        if (!(cb & VB_B)) vrg_promote_a(c, lab, idx); // newly on the inner boundary
+        if (!(cb & VB_B)) vrg_promote_a(c, nb, idx); // newly on the inner boundary
         return VB_S | VB_B;
     }
     if (cb & VB_B) {
@@ -339,7 +351,7 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
                 for (int k = 0; k < 27 && !to0; k++) {
                     if (k == 13) continue;
                     uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
-                    uint8_t mb = lab[m];
+                    uint8_t mb = nb[k];
                     if (!(mb & VB_S) && (mb & VB_P) && (uint32_t)c.stamp[m] > r) to0 = true;
                 }
             bool fresh = nFO && !nSegA;               // had dropped to 3 in phase A: exact density (:212,:251)
@@ -349,7 +361,7 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
         bool to3 = nFO && !nSegA;                     // :183-190
         uint8_t out, res;
         if (!to3) { out = VB_B; res = 2; }
-        else if (nAP) { out = VB_B | VB_F; res = 2 | FR_FRESH; vrg_promote_b(c, lab, idx); }
+        else if (nAP) { out = VB_B | VB_F; res = 2 | FR_FRESH; vrg_promote_b(c, nb, idx); }
         else { out = 0; res = 3; }
         if (cb & VB_L) c.e_res[(uint32_t)c.stamp[idx]] = (uint8_t)(FR_WRITTEN | res);   // skipped flip-in
         return out;
@@ -367,7 +379,7 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
                     }
         if (conv) vrg_atomic_add(&c.dConv[vrg_voxel_level(c, idx)], 1u);   // addedPoints (:235)
     }
-    if (nAP) { vrg_promote_b(c, lab, idx); return VB_B; }   // 3 -> 2 (:210-213)
+    if (nAP) { vrg_promote_b(c, nb, idx); return VB_B; }   // 3 -> 2 (:210-213)
     return (uint8_t)(((cb & VB_X) && !conv) ? VB_X : 0);
 }
 
@@ -386,18 +398,18 @@ VRG_HD uint32_t vrg_slot_B2(const VrgState& s, uint32_t j) { return 3 * s.ni + 2
 // per old band entry: survivor test, and for listed flips the density bookkeeping sets (:232-233) and
 // the class histograms
 VRG_HD void vrg_item_entry_post(const VrgCtx& c, uint32_t e) {
-    const VrgState& s = *c.st;
+    const VrgState s = *c.st;                                 // a copy: no reloads after the stores below
     int cur = s.iter & 1;
-    uint32_t idx = c.b_idx[cur][e];
     uint8_t* lab = c.lab[0];
-    uint8_t nb = lab[idx];
-    bool inner = e < s.ni, flag = c.e_flag[e] != 0;
+    // independent loads first (one round trip), then the one that depends on idx
+    uint32_t idx = c.b_idx[cur][e], lev = c.b_lev[cur][e], mask = c.e_mask[e];
     uint8_t res = c.e_res[e];
+    bool inner = e < s.ni, flag = c.e_flag[e] != 0;
+    uint8_t nb = lab[idx];
     uint8_t fin = res & FR_FINAL;
     bool fresh = res & FR_FRESH;
-    uint32_t mask = flag ? c.e_mask[e] : 0u;
+    if (!flag) mask = 0u;
     if (flag) {
-        uint32_t lev = c.b_lev[cur][e];
         if (!(res & FR_WRITTEN)) c.st->error = 3;             // a listed flip the relabel never visited
         if (fin == 1) vrg_atomic_add(&c.dIn[lev], 1u);        // innerAdded: listed flips labelled 1 at the end
         else if (fin == 2) vrg_atomic_add(&c.dOut[lev], 1u);  // outerAdded: ... labelled 2
@@ -448,26 +460,27 @@ VRG_HD void vrg_new_fresh(const VrgCtx& c, int nx, uint32_t pos, uint32_t idx, u
 // per old band entry: survivors and carried flips copy themselves to their new position with the
 // incremental correction; a flip that left the band during the sweep re-enters as a fresh entry
 VRG_HD void vrg_item_scatter_entry(const VrgCtx& c, uint32_t e) {
-    const VrgState& s = *c.st;
+    const VrgState s = *c.st;                                 // a copy: no reloads after the stores below
     int cur = s.iter & 1, nx = cur ^ 1;
     bool inner = e < s.ni;
     uint32_t j = e - s.ni;
-    uint32_t pos;
+    // independent loads first (one round trip); the survivor's slot is known without looking anything up
+    const uint8_t surv = c.e_surv[e], flag = c.e_flag[e], res = c.e_res[e];
+    const uint32_t lev = c.b_lev[cur][e], idx = c.b_idx[cur][e];
+    double ip = c.b_ip[cur][e], op = c.b_op[cur][e];
+    uint32_t pos = c.scan[inner ? vrg_slot_A0(s, e) : vrg_slot_B0(s, j)];
     bool fresh = false;
-    if (c.e_surv[e]) pos = c.scan[inner ? vrg_slot_A0(s, e) : vrg_slot_B0(s, j)];
-    else if (c.e_flag[e]) {
-        uint8_t res = c.e_res[e];
+    if (!surv) {
+        if (!flag) return;
         uint8_t fin = res & FR_FINAL;
         fresh = res & FR_FRESH;
         if (inner) { if (!(fin == 2 && !fresh)) return; pos = c.scan[vrg_slot_B1(s, e)]; }
         else { if (fin != 1) return; pos = c.scan[vrg_slot_A2(s, j)]; }
-    } else return;
-    uint32_t lev = c.b_lev[cur][e];
-    if (fresh) { vrg_new_fresh(c, nx, pos, c.b_idx[cur][e], lev); return; }
+    }
+    if (fresh) { vrg_new_fresh(c, nx, pos, idx, lev); return; }
     if (pos >= c.bcap) { c.st->error = 1; return; }
-    double ip = c.b_ip[cur][e], op = c.b_op[cur][e];
     vrg_apply_correction(c, lev, ip, op);
-    c.b_idx[nx][pos] = c.b_idx[cur][e]; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = ip; c.b_op[nx][pos] = op;
+    c.b_idx[nx][pos] = idx; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = ip; c.b_op[nx][pos] = op;
 }
 
 // the voxels a listed flip promoted (item k = neighbour k of the flip, :263-282 order): fresh entries
