@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-PRODUCT_LIB = os.path.join(HERE, 'csrc', 'libvrg_hip.so')
+PRODUCT_LIB = os.environ.get('VRG_HIP_LIB') or os.path.join(HERE, 'csrc', 'libvrg_hip.so')   # env: A/B another build
 
 DTYPE_CODES = {np.dtype(np.uint8): 0, np.dtype(np.int16): 1, np.dtype(np.uint16): 2, np.dtype(np.int32): 3,
                np.dtype(np.int64): 4, np.dtype(np.float32): 5, np.dtype(np.float64): 6}

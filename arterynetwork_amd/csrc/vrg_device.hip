@@ -105,7 +105,7 @@ __global__ void k_marks_prepass(VrgCtx c) {
     ITEM_LOOP64((uint64_t)c.st->nf * 128u) {
         uint32_t r = (uint32_t)(i >> 7), p = (uint32_t)(i & 127u);
         if (p < 125u) vrg_item_scatter_marks(c, r, p);
-        else if (p == 125u) vrg_item_prepass(c, c.flist[r]);
+        else if (p == 125u) vrg_item_prepass(c, r);
     }
 }
 // skip-rule fix-point (rare): one workgroup relaxes until nothing changes
@@ -232,17 +232,33 @@ __global__ void k_tab(VrgCtx c) {
         if (lane == 0) { c.tabC[3 * (size_t)l] = a; c.tabC[3 * (size_t)l + 1] = b; c.tabC[3 * (size_t)l + 2] = d; }
     }
 }
-// exact densities (:152-155, :252-255): one wave per fresh entry, lanes stride over the levels
+// exact densities (:152-155, :252-255): one wave per fresh entry, lanes stride over the levels.  The level table
+// (the same for every entry) is fetched first, four levels per lane at a time, so that it travels together with
+// the entry's own look-ups instead of behind them.
 __global__ void k_exact(VrgCtx c, int par_is_next) {
     if (c.st->done) return;
     int par = par_is_next ? ((c.st->iter & 1) ^ 1) : 0;
     uint32_t nfresh = c.st->nfresh;
     int lane = threadIdx.x & 63;
     uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    if (wid >= nfresh) return;
+    int32_t ha[4], hb[4]; double lv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t l = lane + 64u * q;
+        bool in = l < c.L;
+        ha[q] = in ? c.hin[l] : 0; hb[q] = in ? c.hout[l] : 0; lv[q] = in ? c.lev[l] : 0.0;
+    }
     for (uint32_t f = wid; f < nfresh; f += nw) {
         uint32_t pos = c.fresh[f];
         double v = c.lev[c.b_lev[par][pos]], si = 0, so = 0;
-        for (uint32_t l = lane; l < c.L; l += 64) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (!(ha[q] | hb[q])) continue;
+            double k = vrg_kern(c, lv[q] - v);
+            si += (double)ha[q] * k; so += (double)hb[q] * k;
+        }
+        for (uint32_t l = lane + 256u; l < c.L; l += 64) {
             int32_t a = c.hin[l], b = c.hout[l];
             if (!(a | b)) continue;
             double k = vrg_kern(c, c.lev[l] - v);
@@ -253,15 +269,17 @@ __global__ void k_exact(VrgCtx c, int par_is_next) {
     }
 }
 __global__ void k_finalize(VrgCtx c) {                // iterNum += 1 (:117) + trace record
-    if (c.st->done) return;
-    VrgState& s = *c.st;
+    VrgState s = *c.st;                               // one round trip for the whole state, one to write it back
+    if (s.done) return;
+    const int64_t n_in = c.inc[VC_NIN], n_out = c.inc[VC_NOUT];
     s.ni = s.ni_new; s.no = s.nb_new - s.ni_new; s.iter++;
     if ((uint32_t)s.iter < c.trace_cap) {
-        VrgTrace& t = c.trace[s.iter];                    // the intensity sums are filed by the dense pass (vrg_dense_fin)
-        t.nflip = s.nf; t.nseg = c.inc[VC_NIN]; t.n_in = c.inc[VC_NIN]; t.n_out = c.inc[VC_NOUT]; t.ni = s.ni; t.no = s.no;
+        VrgTrace& t = c.trace[s.iter];                // the intensity sums are filed by the dense pass (vrg_dense_fin)
+        t.nflip = s.nf; t.nseg = n_in; t.n_in = n_in; t.n_out = n_out; t.ni = s.ni; t.no = s.no;
     }
     s.nf = 0; s.npend = 0; s.nmk = 0; s.nfresh = 0;
     if (s.error) s.done = -1;
+    *c.st = s;
 }
 
 // ---- device-wide exclusive scan of c-array `a` (length st->nscan), total -> st->scan_total ----------

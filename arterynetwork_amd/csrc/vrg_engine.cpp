@@ -221,7 +221,7 @@ int API(init)(vrg_handle* h, double H) {
         c.e_res = alloc<uint8_t>(h, c.bcap); c.e_mask = alloc<uint32_t>(h, c.bcap);
         c.scan = alloc<uint32_t>(h, 3 * (size_t)c.bcap + 16);
         c.bsum = alloc<uint32_t>(h, 1024);
-        c.flist = alloc<uint32_t>(h, c.fcap);
+        c.flist = alloc<uint32_t>(h, c.fcap); c.fidx = alloc<uint32_t>(h, c.fcap);
         c.pend = alloc<uint32_t>(h, c.fcap); c.fresh = alloc<uint32_t>(h, c.bcap);
         c.init_key = alloc<uint64_t>(h, c.bcap); c.init_idx = alloc<uint32_t>(h, c.bcap);
         c.mcap = (uint32_t)std::min<uint64_t>(V, 0xffffffffull);
@@ -238,7 +238,7 @@ int API(init)(vrg_handle* h, double H) {
         c.st_sin = alloc<double>(h, c.nstat); c.st_sout = alloc<double>(h, c.nstat);
         c.trace_cap = 1u << 16;
         c.trace = alloc<VrgTrace>(h, c.trace_cap);
-        if (!c.e_flag || !c.e_surv || !c.scan || !c.bsum || !c.e_res || !c.e_mask || !c.flist || !c.pend || !c.fresh ||
+        if (!c.e_flag || !c.e_surv || !c.scan || !c.bsum || !c.e_res || !c.e_mask || !c.flist || !c.fidx || !c.pend || !c.fresh ||
             !c.init_key || !c.init_idx || !c.mk_idx || !c.mk_new || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace)
             return fail(h, VRG_E_MEM, "vrg_init: work arrays");
     }
@@ -290,7 +290,9 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     }
     be_sync();
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-    s = get_state(h);                                // the dense stream may have raised its cross-check error last
+    int64_t dense_err = 0;                           // raised by the dense stream, possibly after the band side stopped
+    be_download(&dense_err, c.dctl + VD_ERR, sizeof(dense_err));
+    if (dense_err) s.error = (int32_t)dense_err;
     rc = check_state_error(h, s);
     if (rc) return rc;
     if (out) {

@@ -124,7 +124,7 @@ VRG_HD void vrg_item_decide(const VrgCtx& c, uint32_t e) {
     uint32_t q = vrg_atomic_add(&c.st->nf, 1u);
     if (s.time_up || n_in >= s.maxSegmentSize) return;    // :97 / :101 fire before update(): count only
     if (q >= c.fcap) { c.st->error = 2; return; }
-    c.flist[q] = e;
+    c.flist[q] = e; c.fidx[q] = idx;
     vrg_or_byte(c.lab[0], idx, (uint8_t)(VB_L | (inner ? VB_P : 0)));
     c.stamp[idx] = ((uint64_t)(uint32_t)(s.iter + 1) << 32) | e;
 }
@@ -140,10 +140,10 @@ VRG_HD int32_t vrg_stop_test(const VrgCtx& c) {
 }
 
 // flip-ins: label after phase A (:183-190) decides whether the flip is applied at once
-VRG_HD void vrg_item_prepass(const VrgCtx& c, uint32_t e) {
+VRG_HD void vrg_item_prepass(const VrgCtx& c, uint32_t r) {
     VrgState& s = *c.st;
+    const uint32_t e = c.flist[r], idx = c.fidx[r];
     if (e < s.ni) return;
-    uint32_t idx = c.b_idx[s.iter & 1][e];
     const uint8_t* lab = c.lab[0];
     bool nFO = false, nSegA = false;
     uint8_t nb[27]; vrg_load_nbrs(c, lab, idx, nb);
@@ -181,7 +181,7 @@ VRG_HD bool vrg_item_fix(const VrgCtx& c, uint32_t j) {
 VRG_HD void vrg_item_scatter_marks(const VrgCtx& c, uint32_t r, uint32_t p) {
     if (p >= 125) return;
     uint8_t* lab = c.lab[0];
-    uint32_t idx = c.b_idx[c.st->iter & 1][c.flist[r]];
+    uint32_t idx = c.fidx[r];
     int dx = (int)(p % 5) - 2, dy = (int)((p / 5) % 5) - 2, dz = (int)(p / 25) - 2;
     bool ring1 = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
     int64_t m = (int64_t)idx + (dz * c.PY + dy) * c.PX + dx;   // may be -1,-2 (guard bytes) at voxel (0,0,0)
@@ -264,14 +264,14 @@ VRG_HD void vrg_dense_fin(const VrgCtx& c) {
     if (!vrg_dense_due(c)) return;
     int64_t seq = c.dctl[VD_SEQ] + 1;
     const VrgDense& d = *c.dn;
-    if ((int64_t)d.n_in != c.inc[VC_EXP + 2 * (seq & 3)] || (int64_t)d.n_out != c.inc[VC_EXP + 2 * (seq & 3) + 1]) c.st->error = 5;
+    if ((int64_t)d.n_in != c.inc[VC_EXP + 2 * (seq & 3)] || (int64_t)d.n_out != c.inc[VC_EXP + 2 * (seq & 3) + 1]) c.dctl[VD_ERR] = 5;
     if ((uint64_t)seq < c.trace_cap) { c.trace[seq].sum_in = d.sum_in; c.trace[seq].sum_out = d.sum_out; }
     c.dctl[VD_SEQ] = seq;
 }
 // init: the dense pass founds the incremental sizes
 VRG_HD void vrg_init_counts(const VrgCtx& c) {
     c.inc[VC_NIN] = (int64_t)c.dn->n_in; c.inc[VC_NOUT] = (int64_t)c.dn->n_out; c.inc[VC_REQ] = 0;
-    c.dctl[VD_SEQ] = 0; c.nchg[0] = 0; c.nchg[1] = 0;
+    c.dctl[VD_SEQ] = 0; c.dctl[VD_ERR] = 0; c.nchg[0] = 0; c.nchg[1] = 0;
 }
 
 // ------------------------------------------------------------------ the relabel stencil for one voxel
@@ -488,12 +488,12 @@ VRG_HD void vrg_item_scatter_promo(const VrgCtx& c, uint32_t r, uint32_t k) {
     if (k >= 27) return;
     const VrgState& s = *c.st;
     int cur = s.iter & 1, nx = cur ^ 1;
-    uint32_t e = c.flist[r];
+    uint32_t e = c.flist[r], fi = c.fidx[r];
     uint32_t mask = c.e_mask[e];
     if (!(mask & (1u << k))) return;
     uint32_t slot = e < s.ni ? vrg_slot_A1(s, e) : vrg_slot_B2(s, e - s.ni);
     uint32_t pos = c.scan[slot] + (uint32_t)__builtin_popcount(mask & ((1u << k) - 1u));
-    uint32_t m = (uint32_t)((int64_t)c.b_idx[cur][e] + vrg_off(c, (int)k));
+    uint32_t m = (uint32_t)((int64_t)fi + vrg_off(c, (int)k));
     vrg_new_fresh(c, nx, pos, m, vrg_voxel_level(c, m));
 }
 

@@ -74,7 +74,7 @@ struct VrgDense {            // all four as double so one all-reduce sums them o
 
 enum { VC_NIN = 0, VC_NOUT = 1, VC_REQ = 2, VC_EXP = 8 };   // VrgCtx::inc; VC_EXP: ring of 4 x {n_in, n_out}, the sizes
                                                             // after sweep k at slot k & 3 (what dense pass k must reproduce)
-enum { VD_SEQ = 0 };                              // VrgCtx::dctl
+enum { VD_SEQ = 0, VD_ERR = 1 };                  // VrgCtx::dctl (VD_ERR: the dense pass disagreed with the incremental sizes)
 
 struct VrgCtx {
     int32_t nx, ny, nz;
@@ -127,6 +127,7 @@ struct VrgCtx {
     uint32_t* scan;            // rebuild count array / positions, length 3*(ni+no)
     uint32_t fcap;
     uint32_t* flist;           // entry indices of the listed flips, unordered
+    uint32_t* fidx;            // ... and their voxel indices (saves the dependent b_idx look-up in every flip item)
     uint32_t* pend;            // entry indices of the flip-ins in the skip-rule fix-point
     uint32_t* fresh;           // new-band positions needing exact densities
     // dense statistics partials (one slot per sweep workgroup)

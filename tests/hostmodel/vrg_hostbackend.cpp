@@ -163,7 +163,7 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*, be_reduce_fn cb, vo
     for (uint32_t e = 0; e < n; e++) vrg_item_decide(c, e);
     if (int32_t stop = vrg_stop_test(c)) { s.done = stop; return; }
     if (s.error) { s.done = -1; return; }
-    for (uint32_t r = 0; r < s.nf; r++) vrg_item_prepass(c, c.flist[r]);
+    for (uint32_t r = 0; r < s.nf; r++) vrg_item_prepass(c, r);
     for (bool changed = true; changed;) {
         changed = false;
         for (uint32_t j = 0; j < s.npend; j++) changed |= vrg_item_fix(c, j);
