@@ -243,8 +243,11 @@ def _gpu_slab_worker(rank, world, port, sweeps, outdir):
     dist.destroy_process_group()
 
 
-def test_zslabs_two_processes_one_gpu(lib, tmp_path):
-    """Z-slab driver with two ranks (sharing the one GPU of the box; host-callback reduction over gloo)."""
+@pytest.mark.parametrize('world', [2, 3])
+def test_zslabs_processes_one_gpu(lib, tmp_path, world):
+    """Z-slab driver with two / three ranks (sharing the one GPU of the box; host-callback reduction over gloo).
+    The slab faces cut the 1024-voxel units of the dense pass (plane = 112 x 68 voxels), so its edge masking is
+    exercised; the summed recount has to reproduce the incremental region sizes every sweep."""
     import torch.multiprocessing as mp
     from test_slabs_gloo import free_port
     from arterynetwork_amd import phantoms
@@ -257,8 +260,8 @@ def test_zslabs_two_processes_one_gpu(lib, tmp_path):
     s.run(sweeps, 10 ** 9, None)
     ref = (s.labels(), s.segmented(), s.trace())
     s.close()
-    mp.spawn(_gpu_slab_worker, args=(2, free_port(), sweeps, str(tmp_path)), nprocs=2, join=True)
-    for r in range(2):
+    mp.spawn(_gpu_slab_worker, args=(world, free_port(), sweeps, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
         z = np.load(str(tmp_path / ('rank%d.npz' % r)))
         assert np.array_equal(z['labels'], ref[0]) and np.array_equal(z['seg'], ref[1])
         for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no'):
