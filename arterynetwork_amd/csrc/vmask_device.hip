@@ -6,8 +6,8 @@
 // EDT: Meijster's exact integer algorithm (the squared distance is an integer, so any exact method -
 //   scipy uses a Voronoi feature transform - yields the same value; out = sqrt in float64).
 //   Phase 1 along axis 0 (two scans), then the lower-envelope pass along axis 1 and along axis 2,
-//   one thread per line; lines of axes 0/1 are coalesced across the wave, axis-2 lines are L2-resident.
-//   HBM-bound: ~9 volume passes of 4 B/voxel.
+//   one thread per line with the wave's lanes on neighbouring lines (coalesced); for axis 2 the volume is
+//   transposed i1 <-> i2 in 64 x 64 LDS tiles before and after.  HBM-bound: ~13 volume passes of 4 B/voxel.
 // Labelling: union-find with compare-and-swap linking (root = smallest raster index of the component), one
 //   union pass over the 3/9/13 forward neighbours, path flattening, component sizes by atomics, and
 //   raster-order numbering = exclusive scan of the root flags (what skimage / scipy number by).
@@ -106,13 +106,41 @@ __global__ void k_edt_sqrt(const int32_t* __restrict__ G, double* __restrict__ o
         out[i] = sqrt((double)G[i]);
 }
 
-// squared EDT of a device-resident mask into G (device); tmp: three more int32 volumes
+// out[i0][b][a] = in[i0][a][b] for every i0-slab (na x nb -> nb x na), 64 x 64 tiles through LDS: both sides coalesced
+__global__ void __launch_bounds__(256) k_transpose12(const int32_t* __restrict__ in, int32_t* __restrict__ out, int32_t n0, int32_t na, int32_t nb) {
+    __shared__ int32_t tile[64][65];
+    const uint32_t ta = (na + 63) / 64, tb = (nb + 63) / 64;
+    const uint64_t ntiles = (uint64_t)n0 * ta * tb;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 64 x 4
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint32_t i0 = (uint32_t)(t / ((uint64_t)ta * tb)), r = (uint32_t)(t % ((uint64_t)ta * tb));
+        const int a0 = (int)(r / tb) * 64, b0 = (int)(r % tb) * 64;
+        const size_t slab = (size_t)i0 * na * nb;
+        for (int j = ty; j < 64; j += 4) {
+            int a = a0 + j, b = b0 + tx;
+            if (a < na && b < nb) tile[j][tx] = in[slab + (size_t)a * nb + b];
+        }
+        __syncthreads();
+        for (int j = ty; j < 64; j += 4) {
+            int b = b0 + j, a = a0 + tx;
+            if (a < na && b < nb) out[slab + (size_t)b * na + a] = tile[tx][j];
+        }
+        __syncthreads();
+    }
+}
+
+// squared EDT of a device-resident mask into G (device); tmp: three more int32 volumes.
+// The lower-envelope pass runs one thread per line with the lanes of a wave on neighbouring lines, which is
+// coalesced only when the lines are NOT along the fastest axis: the axis-2 pass therefore runs on the i1 <-> i2
+// transposed volume (two tiled transposes, ~4 GB of traffic each at 880x880x640, instead of a 20x slower pass).
 int edt_squared(const uint8_t* dmask, Dims d, int32_t* G, int32_t* G2, int32_t* S, int32_t* T) {
-    size_t V = (size_t)d.n0 * d.n1 * d.n2;
     k_edt_axis0<<<grid_for((uint64_t)d.n1 * d.n2), TPB>>>(dmask, G, d);
     k_edt_envelope<<<grid_for((uint64_t)d.n0 * d.n2), TPB>>>(G, G2, (uint32_t*)S, T, d, 1);
-    k_edt_envelope<<<grid_for((uint64_t)d.n0 * d.n1), TPB>>>(G2, G, (uint32_t*)S, T, d, 2);
-    (void)V;
+    const int tgrid = (int)std::min<uint64_t>(65535u * 4u, (uint64_t)d.n0 * ((d.n1 + 63) / 64) * ((d.n2 + 63) / 64));
+    k_transpose12<<<tgrid, 256>>>(G2, G, d.n0, d.n1, d.n2);                 // G = [n0][n2][n1]
+    Dims dt = {d.n0, d.n2, d.n1};
+    k_edt_envelope<<<grid_for((uint64_t)d.n0 * d.n1), TPB>>>(G, G2, (uint32_t*)S, T, dt, 1);
+    k_transpose12<<<tgrid, 256>>>(G2, G, d.n0, d.n2, d.n1);                 // back to [n0][n1][n2]
     VM_TRY(hipGetLastError());
     return VRG_OK;
 }
