@@ -962,8 +962,7 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb,
     if (g_read[g_trip & 1]) HIP_CHECK(hipStreamWaitEvent(g_stream, g_read[g_trip & 1], 0));
     if (!(variant & 1)) k_apply<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     else k_copy_back<<<2048, TPB, 0, g_stream>>>(c);
-    k_entry_post<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    HIP_CHECK(hipEventRecord(g_ev_a, g_stream));
+    hipExtLaunchKernelGGL(k_entry_post, dim3(ITEM_BLOCKS), dim3(TPB), 0, g_stream, nullptr, g_ev_a, 0, c);   // g_ev_a rides on the dispatch
     // dense stream: every voxel once, read-only.  Enqueued before the rest of the bookkeeping so that its dispatch
     // never waits for the host to issue those launches.
     HIP_CHECK(hipStreamWaitEvent(g_stream_b, g_ev_a, 0));
