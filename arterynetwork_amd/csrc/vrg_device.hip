@@ -2,8 +2,8 @@
 //
 // One while-loop trip of variationalRegionGrowing.py:58-117 (be_sweep_once), two HIP streams:
 //   stream A, band kernels (O(band) work, grid-stride over device-resident counts, no host round trip):
-//     k_decide (+listing) -> k_marks_prepass (stop tests, marks, skip-rule prepass) -> k_fix
-//     -> k_relabel (3x3x3 / 5x5x5 label stencil on the marked voxels, old labels only)
+//     k_decide (+listing) -> k_marks_prepass (stop tests, marks, skip-rule prepass)
+//     -> k_relabel (skip-rule fix-point; 3x3x3 / 5x5x5 label stencil on the marked voxels, old labels only)
 //     -> k_apply (writes the new label bytes, keeps the region sizes and the class bits in step)
 //     -> k_entry_post, k_levels_small (level-delta compaction), k_tab, rebuild scan, k_scatter, k_exact
 //     -> k_finalize closes the trip;
@@ -109,7 +109,7 @@ __global__ void k_marks_prepass(VrgCtx c) {
         else if (p == 125u) vrg_item_prepass(c, r);
     }
 }
-// skip-rule fix-point (rare): one workgroup relaxes until nothing changes
+// skip-rule fix-point as a kernel of its own (one workgroup): only the full-stencil check variant launches it
 __global__ void k_fix(VrgCtx c) {
     if (c.st->done) return;
     __shared__ int changed;
@@ -126,8 +126,27 @@ __global__ void k_fix(VrgCtx c) {
         if (!changed) break;
     }
 }
+// Skip-rule fix-point first (rare: only when a flip-in dropped to 3 in phase A, npend > 0).  It is a monotone
+// closure (P bits are only ever set) over facts the previous kernel left behind, so EVERY workgroup computes all
+// of it by itself - the same bits, set with atomic ORs - instead of one workgroup in a kernel of its own that the
+// common case (npend == 0) would pay a launch for.  Then the relabel stencil of the marked voxels.
 __global__ void k_relabel(VrgCtx c) {
     if (c.st->done) return;
+    const uint32_t np = c.st->npend;
+    if (np) {
+        __shared__ int changed;
+        for (;;) {
+            __syncthreads();
+            if (threadIdx.x == 0) changed = 0;
+            __syncthreads();
+            for (uint32_t j = threadIdx.x; j < np; j += blockDim.x)
+                if (vrg_item_fix(c, j)) changed = 1;
+            __threadfence();
+            __syncthreads();
+            if (!changed) break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // the stencil below reads the P bits with plain loads
+    }
     ITEM_LOOP(min(c.st->nmk, c.mcap)) vrg_item_relabel(c, i);
 }
 __global__ void k_apply(VrgCtx c) {                    // + the class changes of the sweep before (see VrgCtx::clsb)
@@ -897,9 +916,8 @@ void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
 static void enqueue_pre(const VrgCtx& c, int variant) {         // decide + flip list, marks + prepass, fix-point, relabel
     k_decide<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     k_marks_prepass<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    k_fix<<<1, 1024, 0, g_stream>>>(c);
-    if (!(variant & 1)) k_relabel<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    else k_full_relabel<<<2048, TPB, 0, g_stream>>>(c);
+    if (!(variant & 1)) k_relabel<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);     // + the skip-rule fix-point
+    else { k_fix<<<1, 1024, 0, g_stream>>>(c); k_full_relabel<<<2048, TPB, 0, g_stream>>>(c); }
 }
 static void enqueue_post(const VrgCtx& c) {                     // rest of the band bookkeeping (new lists, densities), iterNum += 1
     if (c.L <= LEVELS_ONEBLOCK) k_levels_small<<<1, 1024, 0, g_stream>>>(c);
