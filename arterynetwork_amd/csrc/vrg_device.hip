@@ -173,18 +173,20 @@ __global__ void k_scatter(VrgCtx c) {                  // items: every old entry
 // level-delta compaction (:232-235 regrouped by distinct intensity value)
 __global__ void k_delta_flag(VrgCtx c) {
     if (c.st->done) return;
-    ITEM_LOOP(c.L) c.lscan[i] = (c.dIn[i] | c.dOut[i] | c.dConv[i]) ? 1u : 0u;
+    const uint32_t off = vrg_delta_off(c);
+    ITEM_LOOP(c.L) c.lscan[i] = (c.dIn[off + i] | c.dOut[off + i] | c.dConv[off + i]) ? 1u : 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) c.st->nscan = c.L;
 }
 __global__ void k_delta_scatter(VrgCtx c) {
     if (c.st->done) return;
+    const uint32_t off = vrg_delta_off(c);
     ITEM_LOOP(c.L) {
-        uint32_t a = c.dIn[i], b = c.dOut[i], d = c.dConv[i];
+        uint32_t a = c.dIn[off + i], b = c.dOut[off + i], d = c.dConv[off + i];
         if (a | b | d) {
             uint32_t j = c.lscan[i];
             c.nz_lev[j] = i; c.nz_val[j] = c.lev[i]; c.nz_cin[j] = a; c.nz_cout[j] = b; c.nz_cconv[j] = d;
             c.hout[i] += (int32_t)d;                 // included voxels join the outer region
-            c.dIn[i] = 0; c.dOut[i] = 0; c.dConv[i] = 0;
+            c.dIn[off + i] = 0; c.dOut[off + i] = 0; c.dConv[off + i] = 0;
         }
     }
 }
@@ -205,23 +207,24 @@ __global__ void __launch_bounds__(1024) k_levels_small(VrgCtx c) {
     __shared__ uint32_t sh[16];
     __shared__ uint32_t sh_run;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t off = vrg_delta_off(c);
     if (threadIdx.x == 0) sh_run = 0;
     __syncthreads();
     for (uint32_t base = 0; base < c.L; base += 1024) {
         uint32_t l = base + threadIdx.x;
         uint32_t a = 0, b = 0, d = 0;
-        if (l < c.L) { a = c.dIn[l]; b = c.dOut[l]; d = c.dConv[l]; }
+        if (l < c.L) { a = c.dIn[off + l]; b = c.dOut[off + l]; d = c.dConv[off + l]; }
         uint32_t f = (a | b | d) ? 1u : 0u;
         uint32_t inc = wave_incl_scan(f);
         if (lane == 63) sh[w] = inc;
         __syncthreads();
-        uint32_t off = sh_run, tot = 0;
-        for (int i = 0; i < 16; i++) { if (i < w) off += sh[i]; tot += sh[i]; }
+        uint32_t pos = sh_run, tot = 0;
+        for (int i = 0; i < 16; i++) { if (i < w) pos += sh[i]; tot += sh[i]; }
         if (f) {
-            uint32_t j = off + inc - 1;
+            uint32_t j = pos + inc - 1;
             c.nz_lev[j] = l; c.nz_val[j] = c.lev[l]; c.nz_cin[j] = a; c.nz_cout[j] = b; c.nz_cconv[j] = d;
             c.hout[l] += (int32_t)d;                 // included voxels join the outer region
-            c.dIn[l] = 0; c.dOut[l] = 0; c.dConv[l] = 0;
+            c.dIn[off + l] = 0; c.dOut[off + l] = 0; c.dConv[off + l] = 0;
         }
         __syncthreads();
         if (threadIdx.x == 0) sh_run += tot;
@@ -355,6 +358,82 @@ void device_scan(const VrgCtx& c, uint32_t* a, hipStream_t st, int fin) {
     static_assert(SCAN_BLOCKS == TPB, "k_scan_down adds up one partial per thread");
     k_scan_reduce<<<SCAN_BLOCKS, TPB, 0, st>>>(c, a);
     k_scan_down<<<SCAN_BLOCKS, TPB, 0, st>>>(c, a, fin);
+}
+
+// k_levels_small + k_tab + the first pass of the rebuild scan in ONE launch, for level tables up to LT_MAX:
+//  * workgroups [0, ITEM_BLOCKS): each compacts the touched levels into LDS for itself (same ordered compaction,
+//    a few hundred levels), then its waves fill their share of the per-level correction memo from LDS; workgroup 0
+//    also publishes the compacted list, folds the included voxels into the outer histogram, sets the bookkeeping
+//    scalars and clears the delta counters of the OTHER parity (this sweep's are still being read by the rest);
+//  * workgroups [ITEM_BLOCKS, ITEM_BLOCKS + SCAN_BLOCKS): k_scan_reduce of the rebuild count array (3 n entries).
+// Two dependent launches fewer on the band chain.
+constexpr uint32_t LT_MAX = 2048;
+__global__ void __launch_bounds__(TPB) k_levels_tab_scan(VrgCtx c) {
+    if (c.st->done) return;
+    const uint32_t n = c.st->ni + c.st->no;
+    __shared__ uint32_t sh[4];
+    if (blockIdx.x >= ITEM_BLOCKS) {
+        const uint32_t b = blockIdx.x - ITEM_BLOCKS, n3 = 3u * n;
+        uint32_t chunk = (n3 + SCAN_BLOCKS - 1) / SCAN_BLOCKS;
+        chunk = (chunk + TPB - 1) / TPB * TPB;
+        const uint32_t lo = min(n3, b * chunk), hi = min(n3, lo + chunk);
+        uint32_t sum = 0;
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += TPB) sum += c.scan[i];
+        uint32_t tot; block_excl_scan(sum, tot, sh);
+        if (threadIdx.x == 0) c.bsum[b] = tot;
+        return;
+    }
+    __shared__ double s_val[LT_MAX];
+    __shared__ uint32_t s_lev[LT_MAX], s_cin[LT_MAX], s_cout[LT_MAX], s_cconv[LT_MAX];
+    __shared__ uint32_t sh_run;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t off = vrg_delta_off(c);
+    if (threadIdx.x == 0) sh_run = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < c.L; base += TPB) {
+        const uint32_t l = base + threadIdx.x;
+        uint32_t a = 0, bb = 0, d = 0;
+        if (l < c.L) { a = c.dIn[off + l]; bb = c.dOut[off + l]; d = c.dConv[off + l]; }
+        const uint32_t f = (a | bb | d) ? 1u : 0u;
+        const uint32_t inc = wave_incl_scan(f);
+        if (lane == 63) sh[w] = inc;
+        __syncthreads();
+        uint32_t pos = sh_run, tot = 0;
+        for (int i = 0; i < 4; i++) { if (i < w) pos += sh[i]; tot += sh[i]; }
+        if (f) {
+            const uint32_t j = pos + inc - 1;
+            s_lev[j] = l; s_val[j] = c.lev[l]; s_cin[j] = a; s_cout[j] = bb; s_cconv[j] = d;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) sh_run += tot;
+        __syncthreads();
+    }
+    const uint32_t nnz = sh_run;
+    const bool use_tab = c.L <= n;
+    if (blockIdx.x == 0) {
+        for (uint32_t j = threadIdx.x; j < nnz; j += TPB) {
+            const uint32_t l = s_lev[j];
+            c.nz_lev[j] = l; c.nz_val[j] = s_val[j]; c.nz_cin[j] = s_cin[j]; c.nz_cout[j] = s_cout[j]; c.nz_cconv[j] = s_cconv[j];
+            c.hout[l] += (int32_t)s_cconv[j];        // included voxels join the outer region
+        }
+        const uint32_t other = off ? 0u : c.L;       // next sweep's counters: nobody touches them during this kernel
+        for (uint32_t l = threadIdx.x; l < c.L; l += TPB) { c.dIn[other + l] = 0; c.dOut[other + l] = 0; c.dConv[other + l] = 0; }
+        if (threadIdx.x == 0) {
+            VrgState& s = *c.st;
+            s.nnz = nnz; s.use_tab = use_tab; s.ncnt = 3 * n; s.nscan = 3 * n;
+        }
+    }
+    if (!use_tab) return;
+    const uint32_t wid = (blockIdx.x * TPB + threadIdx.x) >> 6, nw = (ITEM_BLOCKS * TPB) >> 6;
+    for (uint32_t l = wid; l < c.L; l += nw) {
+        double v = c.lev[l], a = 0, b = 0, d = 0;
+        for (uint32_t i = lane; i < nnz; i += 64) {
+            double k = vrg_kern(c, s_val[i] - v);
+            a += (double)s_cin[i] * k; b += (double)s_cout[i] * k; d += (double)s_cconv[i] * k;
+        }
+        a = wave_sum(a); b = wave_sum(b); d = wave_sum(d);
+        if (lane == 0) { c.tabC[3 * (size_t)l] = a; c.tabC[3 * (size_t)l + 1] = b; c.tabC[3 * (size_t)l + 2] = d; }
+    }
 }
 
 // ---- the dense pass ----------------------------------------------------------------------------------
@@ -920,15 +999,20 @@ static void enqueue_pre(const VrgCtx& c, int variant) {         // decide + flip
     else { k_fix<<<1, 1024, 0, g_stream>>>(c); k_full_relabel<<<2048, TPB, 0, g_stream>>>(c); }
 }
 static void enqueue_post(const VrgCtx& c) {                     // rest of the band bookkeeping (new lists, densities), iterNum += 1
-    if (c.L <= LEVELS_ONEBLOCK) k_levels_small<<<1, 1024, 0, g_stream>>>(c);
-    else {
-        k_delta_flag<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-        device_scan(c, c.lscan, g_stream, 0);
-        k_post_prep<<<1, 1, 0, g_stream>>>(c);
-        k_delta_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    if (c.L <= LT_MAX) {
+        k_levels_tab_scan<<<ITEM_BLOCKS + SCAN_BLOCKS, TPB, 0, g_stream>>>(c);
+        k_scan_down<<<SCAN_BLOCKS, TPB, 0, g_stream>>>(c, c.scan, 1);
+    } else {
+        if (c.L <= LEVELS_ONEBLOCK) k_levels_small<<<1, 1024, 0, g_stream>>>(c);
+        else {
+            k_delta_flag<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+            device_scan(c, c.lscan, g_stream, 0);
+            k_post_prep<<<1, 1, 0, g_stream>>>(c);
+            k_delta_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+        }
+        k_tab<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+        device_scan(c, c.scan, g_stream, 1);
     }
-    k_tab<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    device_scan(c, c.scan, g_stream, 1);
     k_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     k_exact<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c, 1);
     k_finalize<<<1, 1, 0, g_stream>>>(c);

@@ -188,7 +188,7 @@ int API(init)(vrg_handle* h, double H) {
         h->owned.push_back(lev);
         c.lev = lev; c.L = L;
         c.hin = alloc<int32_t>(h, L); c.hout = alloc<int32_t>(h, L);
-        c.dIn = alloc<uint32_t>(h, L); c.dOut = alloc<uint32_t>(h, L); c.dConv = alloc<uint32_t>(h, L);
+        c.dIn = alloc<uint32_t>(h, 2 * (size_t)L); c.dOut = alloc<uint32_t>(h, 2 * (size_t)L); c.dConv = alloc<uint32_t>(h, 2 * (size_t)L);
         c.nz_lev = alloc<uint32_t>(h, L); c.nz_val = alloc<double>(h, L);
         c.nz_cin = alloc<uint32_t>(h, L); c.nz_cout = alloc<uint32_t>(h, L); c.nz_cconv = alloc<uint32_t>(h, L);
         c.tabC = alloc<double>(h, 3 * (size_t)L);
@@ -205,7 +205,7 @@ int API(init)(vrg_handle* h, double H) {
         c.lev16 = h->lev16_buf;
     }
     be_fill(c.hin, 0, (size_t)L * 4); be_fill(c.hout, 0, (size_t)L * 4);
-    be_fill(c.dIn, 0, (size_t)L * 4); be_fill(c.dOut, 0, (size_t)L * 4); be_fill(c.dConv, 0, (size_t)L * 4);
+    be_fill(c.dIn, 0, (size_t)L * 8); be_fill(c.dOut, 0, (size_t)L * 8); be_fill(c.dConv, 0, (size_t)L * 8);
     // band storage
     if (!c.b_idx[0]) {
         uint64_t V = (uint64_t)h->V;

@@ -99,6 +99,9 @@ VRG_HD uint32_t vrg_level_of(const VrgCtx& c, double v) {   // index of v in the
     return lo;
 }
 
+// the per-level delta counters (dIn, dOut, dConv) exist twice: sweep iter+1 counts into the copy of parity iter & 1,
+// so that the kernel that consumes them can leave clearing to the sweep after (see k_levels_tab_scan)
+VRG_HD uint32_t vrg_delta_off(const VrgCtx& c) { return (c.st->iter & 1) ? c.L : 0u; }
 // level index of a voxel's intensity: stored (16-bit mode) or looked up in the sorted level table
 VRG_HD uint32_t vrg_voxel_level(const VrgCtx& c, uint32_t idx) {
     return c.lev16 ? (uint32_t)c.lev16[idx] : vrg_level_of(c, (double)c.I[idx]);
@@ -377,7 +380,7 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
                         uint8_t mb = lab[(int64_t)idx + (dz * c.PY + dy) * c.PX + dx];
                         if ((mb & VB_P) && !(mb & VB_OOB)) { conv = true; break; }
                     }
-        if (conv) vrg_atomic_add(&c.dConv[vrg_voxel_level(c, idx)], 1u);   // addedPoints (:235)
+        if (conv) vrg_atomic_add(&c.dConv[vrg_delta_off(c) + vrg_voxel_level(c, idx)], 1u);   // addedPoints (:235)
     }
     if (nAP) { vrg_promote_b(c, nb, idx); return VB_B; }   // 3 -> 2 (:210-213)
     return (uint8_t)(((cb & VB_X) && !conv) ? VB_X : 0);
@@ -411,8 +414,8 @@ VRG_HD void vrg_item_entry_post(const VrgCtx& c, uint32_t e) {
     if (!flag) mask = 0u;
     if (flag) {
         if (!(res & FR_WRITTEN)) c.st->error = 3;             // a listed flip the relabel never visited
-        if (fin == 1) vrg_atomic_add(&c.dIn[lev], 1u);        // innerAdded: listed flips labelled 1 at the end
-        else if (fin == 2) vrg_atomic_add(&c.dOut[lev], 1u);  // outerAdded: ... labelled 2
+        if (fin == 1) vrg_atomic_add(&c.dIn[vrg_delta_off(c) + lev], 1u);        // innerAdded: listed flips labelled 1 at the end
+        else if (fin == 2) vrg_atomic_add(&c.dOut[vrg_delta_off(c) + lev], 1u);  // outerAdded: ... labelled 2
         if (inner) { vrg_atomic_add(&c.hin[lev], -1); vrg_atomic_add(&c.hout[lev], 1); }             // flip-out
         else if (fin <= 1) { vrg_atomic_add(&c.hin[lev], 1); vrg_atomic_add(&c.hout[lev], -1); }     // applied flip-in
     }

@@ -191,12 +191,13 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*, be_reduce_fn cb, vo
     for (uint32_t e = 0; e < n; e++) vrg_item_entry_post(c, e);
     s.nnz = 0;
     for (uint32_t l = 0; l < c.L; l++) {
-        uint32_t a = c.dIn[l], b = c.dOut[l], d = c.dConv[l];
+        const uint32_t o = vrg_delta_off(c) + l;
+        uint32_t a = c.dIn[o], b = c.dOut[o], d = c.dConv[o];
         if (a | b | d) {
             uint32_t i = s.nnz++;
             c.nz_lev[i] = l; c.nz_val[i] = c.lev[l]; c.nz_cin[i] = a; c.nz_cout[i] = b; c.nz_cconv[i] = d;
             c.hout[l] += (int32_t)d;                    // included voxels join the outer region
-            c.dIn[l] = c.dOut[l] = c.dConv[l] = 0;
+            c.dIn[o] = c.dOut[o] = c.dConv[o] = 0;
         }
     }
     s.use_tab = c.L <= n;
