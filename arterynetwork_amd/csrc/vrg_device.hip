@@ -88,16 +88,27 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
 
 // ---- item kernels ---------------------------------------------------------------------------------
 #define ITEM_LOOP(n) for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += gridDim.x * blockDim.x)
+// the same over the first `g` workgroups of a grid whose other workgroups do something else
+#define ITEM_LOOP_G(n, g) for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += (g) * blockDim.x)
 // same with a 64-bit item index: (listed flips) x (positions) can exceed 2^32 on adversarial volumes
 #define ITEM_LOOP64(n) for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += (uint64_t)gridDim.x * blockDim.x)
 
-__global__ void k_decide(VrgCtx c) {                   // decide (:79-88) + listing of the flips
+__device__ void exact_wave(const VrgCtx& c, int par, uint32_t nfresh, uint32_t wid, uint32_t nw, bool then_decide);
+// decide (:79-88) + listing of the flips - and, in the second half of the grid, the exact densities of the entries
+// that (re-)entered the band in the sweep just closed (:252-255), one wave per entry, each of which is decided by
+// that wave as soon as its densities exist (the first half skips entries whose densities are still pending).
+// The closed sweep's k_exact launch is gone from the chain.
+__global__ void k_decide_exact(VrgCtx c) {
     if (c.st->done) return;
-    ITEM_LOOP(c.st->ni + c.st->no) vrg_item_decide(c, i);
+    if (blockIdx.x < ITEM_BLOCKS) { ITEM_LOOP_G(c.st->ni + c.st->no, ITEM_BLOCKS) vrg_item_decide(c, i, c.st->nfx != 0); return; }
+    const uint32_t nfx = c.st->nfx;
+    const uint32_t wid = ((blockIdx.x - ITEM_BLOCKS) * blockDim.x + threadIdx.x) >> 6, nw = (ITEM_BLOCKS * blockDim.x) >> 6;
+    exact_wave(c, c.st->iter & 1, nfx, wid, nw, true);
 }
 // stop tests (:91-104) once all entries have decided, then per listed flip: 125 mark positions + prepass
 __global__ void k_marks_prepass(VrgCtx c) {
     if (c.st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.st->nfx = 0;     // k_decide_exact has computed them
     int32_t stop = vrg_stop_test(c);
     if (stop || c.st->error) {
         if (blockIdx.x == 0 && threadIdx.x == 0) c.st->done = stop ? stop : -1;
@@ -258,12 +269,8 @@ __global__ void k_tab(VrgCtx c) {
 // exact densities (:152-155, :252-255): one wave per fresh entry, lanes stride over the levels.  The level table
 // (the same for every entry) is fetched first, four levels per lane at a time, so that it travels together with
 // the entry's own look-ups instead of behind them.
-__global__ void k_exact(VrgCtx c, int par_is_next) {
-    if (c.st->done) return;
-    int par = par_is_next ? ((c.st->iter & 1) ^ 1) : 0;
-    uint32_t nfresh = c.st->nfresh;
-    int lane = threadIdx.x & 63;
-    uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+__device__ void exact_wave(const VrgCtx& c, int par, uint32_t nfresh, uint32_t wid, uint32_t nw, bool then_decide) {
+    const int lane = threadIdx.x & 63;
     if (wid >= nfresh) return;
     int32_t ha[4], hb[4]; double lv[4];
 #pragma unroll
@@ -288,8 +295,18 @@ __global__ void k_exact(VrgCtx c, int par_is_next) {
             si += (double)a * k; so += (double)b * k;
         }
         si = wave_sum(si); so = wave_sum(so);
-        if (lane == 0) { c.b_ip[par][pos] = si; c.b_op[par][pos] = so; }
+        if (lane == 0) {
+            c.b_ip[par][pos] = si; c.b_op[par][pos] = so;
+            if (then_decide) {
+                const VrgState s = *c.st;
+                if (s.iter < s.iterMax) vrg_decide_core(c, s, pos, si, so);   // while iterNum <= iterMax (:58)
+            }
+        }
     }
+}
+__global__ void k_exact(VrgCtx c) {                   // init mode (:152-155): every band entry
+    const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    exact_wave(c, 0, c.st->nfresh, wid, nw, false);
 }
 __global__ void k_finalize(VrgCtx c) {                // iterNum += 1 (:117) + trace record
     VrgState s = *c.st;                               // one round trip for the whole state, one to write it back
@@ -300,7 +317,8 @@ __global__ void k_finalize(VrgCtx c) {                // iterNum += 1 (:117) + t
         VrgTrace& t = c.trace[s.iter];                // the intensity sums are filed by the dense pass (vrg_dense_fin)
         t.nflip = s.nf; t.nseg = n_in; t.n_in = n_in; t.n_out = n_out; t.ni = s.ni; t.no = s.no;
     }
-    s.nf = 0; s.npend = 0; s.nmk = 0; s.nfresh = 0;
+    s.nf = 0; s.npend = 0; s.nmk = 0;
+    s.nfx = s.nfresh; s.nfresh = 0;                   // exact densities of the new entries: first thing next trip
     if (s.error) s.done = -1;
     *c.st = s;
 }
@@ -977,7 +995,7 @@ void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
     k_init_entry<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     if (c.L <= HIST_LDS_LEVELS) k_hist_lds<<<1024, TPB, 0, g_stream>>>(c);
     else k_hist_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
-    k_exact<<<1024, TPB, 0, g_stream>>>(c, 0);
+    k_exact<<<1024, TPB, 0, g_stream>>>(c);
     k_cls_build<<<2048, TPB, 0, g_stream>>>(c);
     launch_recount(c, dense_blocks(c), 0, g_stream);
     reduce_dense(c, cb, user, g_stream);
@@ -993,7 +1011,7 @@ void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
 // back to back; on small slabs stream B is idle most of the time and stream A never finds pass k-2 unfinished.
 // The band kernels read and write the label BYTES only; the dense pass reads the class bits only.
 static void enqueue_pre(const VrgCtx& c, int variant) {         // decide + flip list, marks + prepass, fix-point, relabel
-    k_decide<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    k_decide_exact<<<2 * ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     k_marks_prepass<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
     if (!(variant & 1)) k_relabel<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);     // + the skip-rule fix-point
     else { k_fix<<<1, 1024, 0, g_stream>>>(c); k_full_relabel<<<2048, TPB, 0, g_stream>>>(c); }
@@ -1014,8 +1032,7 @@ static void enqueue_post(const VrgCtx& c) {                     // rest of the b
         device_scan(c, c.scan, g_stream, 1);
     }
     k_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    k_exact<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c, 1);
-    k_finalize<<<1, 1, 0, g_stream>>>(c);
+    k_finalize<<<1, 1, 0, g_stream>>>(c);             // the new entries' exact densities: k_decide_exact of the next trip
 }
 
 // With option "graph" the two runs of band kernels are replayed from captured hipGraphs (one host call each);

@@ -214,8 +214,9 @@ int API(init)(vrg_handle* h, double H) {
         c.bcap = (uint32_t)cap; c.fcap = c.bcap;
         for (int p = 0; p < 2; p++) {
             c.b_idx[p] = alloc<uint32_t>(h, c.bcap); c.b_lev[p] = alloc<uint32_t>(h, c.bcap);
-            c.b_ip[p] = alloc<double>(h, c.bcap); c.b_op[p] = alloc<double>(h, c.bcap);
-            if (!c.b_idx[p] || !c.b_lev[p] || !c.b_ip[p] || !c.b_op[p]) return fail(h, VRG_E_MEM, "vrg_init: band arrays");
+            c.b_ip[p] = alloc<double>(h, c.bcap); c.b_op[p] = alloc<double>(h, c.bcap); c.b_pend[p] = alloc<uint8_t>(h, c.bcap);
+            if (c.b_pend[p]) be_fill(c.b_pend[p], 0, c.bcap);
+            if (!c.b_idx[p] || !c.b_lev[p] || !c.b_ip[p] || !c.b_op[p] || !c.b_pend[p]) return fail(h, VRG_E_MEM, "vrg_init: band arrays");
         }
         c.e_flag = alloc<uint8_t>(h, c.bcap); c.e_surv = alloc<uint8_t>(h, c.bcap);
         c.e_res = alloc<uint8_t>(h, c.bcap); c.e_mask = alloc<uint32_t>(h, c.bcap);

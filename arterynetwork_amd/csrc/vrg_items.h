@@ -110,11 +110,8 @@ VRG_HD uint32_t vrg_voxel_level(const VrgCtx& c, uint32_t idx) {
 // ------------------------------------------------------------------ decide (:79-88) + listing
 // One item per band entry.  A flip is listed at once: L bit (+P for flip-outs, which are always
 // applied), stamp = (sweep, entry index) and an unordered append to the flip list.
-VRG_HD void vrg_item_decide(const VrgCtx& c, uint32_t e) {
-    const VrgState s = *c.st;                             // a copy (nf is only ever bumped atomically below)
-    if (s.iter >= s.iterMax) return;                      // while iterNum <= iterMax (:58)
+VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, uint32_t e, double ip, double op) {
     int cur = s.iter & 1;
-    const double ip = c.b_ip[cur][e], op = c.b_op[cur][e];
     const uint32_t idx = c.b_idx[cur][e];
     const int64_t n_in = c.inc[VC_NIN], n_out = c.inc[VC_NOUT];
     double inN = ip / (double)n_in;                       // :81
@@ -130,6 +127,15 @@ VRG_HD void vrg_item_decide(const VrgCtx& c, uint32_t e) {
     c.flist[q] = e; c.fidx[q] = idx;
     vrg_or_byte(c.lab[0], idx, (uint8_t)(VB_L | (inner ? VB_P : 0)));
     c.stamp[idx] = ((uint64_t)(uint32_t)(s.iter + 1) << 32) | e;
+}
+// skip_pending (device): an entry whose densities are still to be computed exactly is decided by the wave that
+// computes them (exact half of k_decide_exact), not here
+VRG_HD void vrg_item_decide(const VrgCtx& c, uint32_t e, bool skip_pending) {
+    const VrgState s = *c.st;                             // a copy (nf is only ever bumped atomically)
+    if (s.iter >= s.iterMax) return;                      // while iterNum <= iterMax (:58)
+    const double ip = c.b_ip[s.iter & 1][e], op = c.b_op[s.iter & 1][e];
+    if (skip_pending && c.b_pend[s.iter & 1][e]) return;
+    vrg_decide_core(c, s, e, ip, op);
 }
 
 // the stop tests in the reference's order, once every entry has decided (the host raises time_up)
@@ -456,7 +462,7 @@ VRG_HD void vrg_apply_correction(const VrgCtx& c, uint32_t lev, double& ip, doub
 
 VRG_HD void vrg_new_fresh(const VrgCtx& c, int nx, uint32_t pos, uint32_t idx, uint32_t lev) {
     if (pos >= c.bcap) { c.st->error = 1; return; }
-    c.b_idx[nx][pos] = idx; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = 0; c.b_op[nx][pos] = 0;
+    c.b_idx[nx][pos] = idx; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = 0; c.b_op[nx][pos] = 0; c.b_pend[nx][pos] = 1;
     c.fresh[vrg_atomic_add(&c.st->nfresh, 1u)] = pos;
 }
 
@@ -483,7 +489,7 @@ VRG_HD void vrg_item_scatter_entry(const VrgCtx& c, uint32_t e) {
     if (fresh) { vrg_new_fresh(c, nx, pos, idx, lev); return; }
     if (pos >= c.bcap) { c.st->error = 1; return; }
     vrg_apply_correction(c, lev, ip, op);
-    c.b_idx[nx][pos] = idx; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = ip; c.b_op[nx][pos] = op;
+    c.b_idx[nx][pos] = idx; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = ip; c.b_op[nx][pos] = op; c.b_pend[nx][pos] = 0;
 }
 
 // the voxels a listed flip promoted (item k = neighbour k of the flip, :263-282 order): fresh entries

@@ -51,6 +51,7 @@ struct VrgState {
     uint32_t nf;         // listed flips of the sweep being processed (atomic count)
     uint32_t npend;      // flip-ins waiting in the skip-rule fix-point
     uint32_t nfresh;     // band entries needing exact densities
+    uint32_t nfx;        // device: ... of the sweep just closed, computed by the next trip's first kernel (k_decide_exact)
     uint32_t nmk;        // voxels marked for the relabel stencil this sweep
     uint32_t nnz;        // distinct intensity levels touched by this sweep's density corrections
     uint32_t ncnt;       // length of the rebuild count array
@@ -118,6 +119,7 @@ struct VrgCtx {
     uint32_t* b_lev[2];
     double* b_ip[2];
     double* b_op[2];
+    uint8_t* b_pend[2];        // 1: densities still to be computed exactly (entry (re-)entered the band in the sweep that built the list)
     uint8_t* e_flag;           // per old entry: listed flip
     uint8_t* e_surv;           // per old entry: survives in place
     uint8_t* e_res;            // per old entry: FR_* result of a listed flip

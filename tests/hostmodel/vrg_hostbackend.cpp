@@ -160,7 +160,7 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*, be_reduce_fn cb, vo
     if (s.done) return;
     int nxt = (s.iter & 1) ^ 1;
     uint32_t n = s.ni + s.no;
-    for (uint32_t e = 0; e < n; e++) vrg_item_decide(c, e);
+    for (uint32_t e = 0; e < n; e++) vrg_item_decide(c, e, false);
     if (int32_t stop = vrg_stop_test(c)) { s.done = stop; return; }
     if (s.error) { s.done = -1; return; }
     for (uint32_t r = 0; r < s.nf; r++) vrg_item_prepass(c, r);
