@@ -2,11 +2,12 @@
 //
 // One while-loop trip of variationalRegionGrowing.py:58-117 (be_sweep_once), two HIP streams:
 //   stream A, band kernels (O(band) work, grid-stride over device-resident counts, no host round trip):
-//     k_decide (+listing) -> k_marks_prepass (stop tests, marks, skip-rule prepass)
+//     k_decide_exact (decide + listing; its second half: exact densities of the entries the previous sweep
+//        added, which it then decides) -> k_marks_prepass (stop tests, marks, skip-rule prepass)
 //     -> k_relabel (skip-rule fix-point; 3x3x3 / 5x5x5 label stencil on the marked voxels, old labels only)
 //     -> k_apply (writes the new label bytes, keeps the region sizes and the class bits in step)
-//     -> k_entry_post, k_levels_small (level-delta compaction), k_tab, rebuild scan, k_scatter, k_exact
-//     -> k_finalize closes the trip;
+//     -> k_entry_post -> k_levels_tab_scan (level-delta compaction, correction memo, first pass of the rebuild
+//        scan) -> k_scan_down -> k_scatter -> k_finalize closes the trip                        (9 launches);
 //   stream B, the dense pass, forked after k_entry_post:
 //     k_recount_bits : the dense kernel (every voxel, HBM-bound, read-only: 4 B intensity + 2 class bits per
 //        voxel): region sizes and intensity sums (:113-116, :249-250), reduced by its last workgroup, checked
