@@ -5,10 +5,11 @@
 //     k_decide_exact (decide + listing; its second half: exact densities of the entries the previous sweep
 //        added, which it then decides) -> k_marks_prepass (stop tests, marks, skip-rule prepass)
 //     -> k_relabel (skip-rule fix-point; 3x3x3 / 5x5x5 label stencil on the marked voxels, old labels only)
-//     -> k_apply (writes the new label bytes, keeps the region sizes and the class bits in step)
-//     -> k_entry_post -> k_levels_tab_scan (level-delta compaction, correction memo, first pass of the rebuild
-//        scan) -> k_scan_down -> k_scatter -> k_finalize closes the trip                        (9 launches);
-//   stream B, the dense pass, forked after k_entry_post:
+//     -> k_apply_entry_post (writes the new label bytes, keeps the region sizes and the class bits in step; its
+//        second half: per-entry survivor test and flip bookkeeping, fed by the relabel's per-entry result)
+//     -> k_levels_tab_scan (level-delta compaction, correction memo, first pass of the rebuild scan)
+//     -> k_scan_down -> k_scatter -> k_finalize closes the trip                                  (8 launches);
+//   stream B, the dense pass, forked after k_levels_tab_scan:
 //     k_recount_bits : the dense kernel (every voxel, HBM-bound, read-only: 4 B intensity + 2 class bits per
 //        voxel): region sizes and intensity sums (:113-116, :249-250), reduced by its last workgroup, checked
 //        against the sizes the band side keeps by increments
@@ -161,16 +162,24 @@ __global__ void k_relabel(VrgCtx c) {
     }
     ITEM_LOOP(min(c.st->nmk, c.mcap)) vrg_item_relabel(c, i);
 }
-__global__ void k_apply(VrgCtx c) {                    // + the class changes of the sweep before (see VrgCtx::clsb)
+// k_apply + k_entry_post in one launch: the survivor test of an entry takes its voxel's new byte from the relabel
+// (e_new) or, for a voxel the relabel did not visit, from the label it keeps - so it does not wait for the bytes
+// being written.  First half of the grid: write the new label bytes (+ the class changes of the sweep before into
+// this sweep's class copy, see VrgCtx::clsb); second half: per old band entry, survivor test and flip bookkeeping.
+__global__ void k_apply_entry_post(VrgCtx c) {
     if (c.st->done) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) vrg_request_dense(c);
-    const uint32_t nm = min(c.st->nmk, c.mcap);
-    ITEM_LOOP(nm + vrg_catchup_count(c)) { if (i < nm) vrg_item_apply(c, i); else vrg_item_catchup(c, i - nm); }
+    if (blockIdx.x < ITEM_BLOCKS) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) vrg_request_dense(c);
+        const uint32_t nm = min(c.st->nmk, c.mcap);
+        ITEM_LOOP_G(nm + vrg_catchup_count(c), ITEM_BLOCKS) { if (i < nm) vrg_item_apply(c, i); else vrg_item_catchup(c, i - nm); }
+        return;
+    }
+    for (uint32_t i = (blockIdx.x - ITEM_BLOCKS) * blockDim.x + threadIdx.x, n = c.st->ni + c.st->no; i < n; i += ITEM_BLOCKS * blockDim.x)
+        vrg_item_entry_post(c, i);
 }
 __global__ void k_dense_fin(VrgCtx c) { vrg_dense_fin(c); }
-__global__ void k_entry_post(VrgCtx c) {
+__global__ void k_entry_post(VrgCtx c) {               // full-stencil check variant: after k_copy_back
     if (c.st->done) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) vrg_post_apply(c);
     ITEM_LOOP(c.st->ni + c.st->no) vrg_item_entry_post(c, i);
 }
 __global__ void k_scatter(VrgCtx c) {                  // items: every old entry, then (listed flip, neighbour k)
@@ -185,6 +194,7 @@ __global__ void k_scatter(VrgCtx c) {                  // items: every old entry
 // level-delta compaction (:232-235 regrouped by distinct intensity value)
 __global__ void k_delta_flag(VrgCtx c) {
     if (c.st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) vrg_post_apply(c);
     const uint32_t off = vrg_delta_off(c);
     ITEM_LOOP(c.L) c.lscan[i] = (c.dIn[off + i] | c.dOut[off + i] | c.dConv[off + i]) ? 1u : 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) c.st->nscan = c.L;
@@ -216,6 +226,7 @@ __global__ void k_post_prep(VrgCtx c) {               // after the level scan, b
 constexpr uint32_t LEVELS_ONEBLOCK = 32768;
 __global__ void __launch_bounds__(1024) k_levels_small(VrgCtx c) {
     if (c.st->done) return;
+    if (threadIdx.x == 0) vrg_post_apply(c);
     __shared__ uint32_t sh[16];
     __shared__ uint32_t sh_run;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -389,6 +400,7 @@ void device_scan(const VrgCtx& c, uint32_t* a, hipStream_t st, int fin) {
 constexpr uint32_t LT_MAX = 2048;
 __global__ void __launch_bounds__(TPB) k_levels_tab_scan(VrgCtx c) {
     if (c.st->done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) vrg_post_apply(c);     // first kernel after the labels are applied
     const uint32_t n = c.st->ni + c.st->no;
     __shared__ uint32_t sh[4];
     if (blockIdx.x >= ITEM_BLOCKS) {
@@ -629,6 +641,7 @@ __global__ void __launch_bounds__(TPB) k_full_relabel(VrgCtx c) {
                 uint8_t cb = (uint8_t)(v >> (8 * b));
                 if (!(cb & VB_OOB)) {
                     uint8_t nb = vrg_sweep_core(c, in, base + b, cb);
+                    if (cb & VB_B) c.e_new[c.vent[base + b]] = (uint8_t)(nb | VE_VALID);
                     v = (v & ~(0xffu << (8 * b))) | ((uint32_t)nb << (8 * b));
                 }
             }
@@ -648,6 +661,7 @@ __global__ void __launch_bounds__(TPB) k_copy_back(VrgCtx c) {
         if (a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w) {
             const uint32_t nw[4] = {a.x, a.y, a.z, a.w}, od[4] = {b.x, b.y, b.z, b.w};
             for (int k = 0; k < 16; k++) vrg_count_change(c, 2u * plane + 16u * i + (uint32_t)k, (uint8_t)(od[k >> 2] >> (8 * (k & 3))), (uint8_t)(nw[k >> 2] >> (8 * (k & 3))));
+            a.x &= ~0x40404040u; a.y &= ~0x40404040u; a.z &= ~0x40404040u; a.w &= ~0x40404040u;   // F: see vrg_item_apply
             dst[i] = a;
         }
     }
@@ -1017,14 +1031,22 @@ static void enqueue_pre(const VrgCtx& c, int variant) {         // decide + flip
     if (!(variant & 1)) k_relabel<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);     // + the skip-rule fix-point
     else { k_fix<<<1, 1024, 0, g_stream>>>(c); k_full_relabel<<<2048, TPB, 0, g_stream>>>(c); }
 }
+// first kernel(s) after the labels are applied (level deltas; files the expected sizes): launched eagerly, the event
+// that releases the dense pass rides on the dispatch (small level tables) or follows it
+static void launch_levels(const VrgCtx& c, hipEvent_t ev) {
+    if (c.L <= LT_MAX) {
+        hipExtLaunchKernelGGL(k_levels_tab_scan, dim3(ITEM_BLOCKS + SCAN_BLOCKS), dim3(TPB), 0, g_stream, nullptr, ev, 0, c);
+        return;
+    }
+    if (c.L <= LEVELS_ONEBLOCK) k_levels_small<<<1, 1024, 0, g_stream>>>(c);
+    else k_delta_flag<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    HIP_CHECK(hipEventRecord(ev, g_stream));
+}
 static void enqueue_post(const VrgCtx& c) {                     // rest of the band bookkeeping (new lists, densities), iterNum += 1
     if (c.L <= LT_MAX) {
-        k_levels_tab_scan<<<ITEM_BLOCKS + SCAN_BLOCKS, TPB, 0, g_stream>>>(c);
         k_scan_down<<<SCAN_BLOCKS, TPB, 0, g_stream>>>(c, c.scan, 1);
     } else {
-        if (c.L <= LEVELS_ONEBLOCK) k_levels_small<<<1, 1024, 0, g_stream>>>(c);
-        else {
-            k_delta_flag<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+        if (c.L > LEVELS_ONEBLOCK) {
             device_scan(c, c.lscan, g_stream, 0);
             k_post_prep<<<1, 1, 0, g_stream>>>(c);
             k_delta_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
@@ -1080,9 +1102,9 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb,
     run_band(g_graph_pre, c, variant, [&] { enqueue_pre(c, variant); });
     // the labels change now, in the class copy the dense pass of two sweeps ago was reading
     if (g_read[g_trip & 1]) HIP_CHECK(hipStreamWaitEvent(g_stream, g_read[g_trip & 1], 0));
-    if (!(variant & 1)) k_apply<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    else k_copy_back<<<2048, TPB, 0, g_stream>>>(c);
-    hipExtLaunchKernelGGL(k_entry_post, dim3(ITEM_BLOCKS), dim3(TPB), 0, g_stream, nullptr, g_ev_a, 0, c);   // g_ev_a rides on the dispatch
+    if (!(variant & 1)) k_apply_entry_post<<<2 * ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
+    else { k_copy_back<<<2048, TPB, 0, g_stream>>>(c); k_entry_post<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c); }
+    launch_levels(c, g_ev_a);                        // files the sizes the dense pass must reproduce; g_ev_a on its dispatch
     // dense stream: every voxel once, read-only.  Enqueued before the rest of the bookkeeping so that its dispatch
     // never waits for the host to issue those launches.
     HIP_CHECK(hipStreamWaitEvent(g_stream_b, g_ev_a, 0));

@@ -99,6 +99,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.I = alloc<float>(h, PVu);
     c.clsb[0] = alloc<uint32_t>(h, PVu / 16); c.clsb[1] = alloc<uint32_t>(h, PVu / 16);
     c.nchg = alloc<uint32_t>(h, 32);
+    c.vent = alloc<uint32_t>(h, PVu);
     // 16 guard bytes in front: voxel (0,0,0)'s 2-ring reaches 2 bytes before the padded array
     h->lab_base[0] = alloc<uint8_t>(h, (size_t)c.PV + 32);
     h->lab_base[1] = alloc<uint8_t>(h, (size_t)c.PV + 32);
@@ -111,7 +112,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.dn_part = alloc<VrgDense>(h, 16);
     c.inc = alloc<int64_t>(h, 32); c.dctl = alloc<int64_t>(h, 32);   // one allocation each: written from different streams
     c.world = 1;
-    if (!c.I || !c.lab[0] || !c.lab[1] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] || !c.nchg) { API(destroy)(h); return VRG_E_MEM; }
+    if (!c.I || !c.lab[0] || !c.lab[1] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] || !c.nchg || !c.vent) { API(destroy)(h); return VRG_E_MEM; }
     be_fill(c.inc, 0, 32 * sizeof(int64_t)); be_fill(c.dctl, 0, 32 * sizeof(int64_t));
     be_fill((void*)c.I, 0, PVu * 4);
     if (c.clsb[0]) be_fill(c.clsb[0], 0, PVu / 4);
@@ -218,7 +219,7 @@ int API(init)(vrg_handle* h, double H) {
             if (c.b_pend[p]) be_fill(c.b_pend[p], 0, c.bcap);
             if (!c.b_idx[p] || !c.b_lev[p] || !c.b_ip[p] || !c.b_op[p] || !c.b_pend[p]) return fail(h, VRG_E_MEM, "vrg_init: band arrays");
         }
-        c.e_flag = alloc<uint8_t>(h, c.bcap); c.e_surv = alloc<uint8_t>(h, c.bcap);
+        c.e_flag = alloc<uint8_t>(h, c.bcap); c.e_surv = alloc<uint8_t>(h, c.bcap); c.e_new = alloc<uint8_t>(h, c.bcap);
         c.e_res = alloc<uint8_t>(h, c.bcap); c.e_mask = alloc<uint32_t>(h, c.bcap);
         c.scan = alloc<uint32_t>(h, 3 * (size_t)c.bcap + 16);
         c.bsum = alloc<uint32_t>(h, 1024);
@@ -239,7 +240,7 @@ int API(init)(vrg_handle* h, double H) {
         c.st_sin = alloc<double>(h, c.nstat); c.st_sout = alloc<double>(h, c.nstat);
         c.trace_cap = 1u << 16;
         c.trace = alloc<VrgTrace>(h, c.trace_cap);
-        if (!c.e_flag || !c.e_surv || !c.scan || !c.bsum || !c.e_res || !c.e_mask || !c.flist || !c.fidx || !c.pend || !c.fresh ||
+        if (!c.e_flag || !c.e_surv || !c.e_new || !c.scan || !c.bsum || !c.e_res || !c.e_mask || !c.flist || !c.fidx || !c.pend || !c.fresh ||
             !c.init_key || !c.init_idx || !c.mk_idx || !c.mk_new || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace)
             return fail(h, VRG_E_MEM, "vrg_init: work arrays");
     }

@@ -119,7 +119,7 @@ VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, uint32_t e, doub
     bool ge = inN >= outN;
     bool inner = e < s.ni;
     bool flip = inner != ge;                              // :87 xor(segmentedMap, inner >= outer)
-    c.e_flag[e] = flip ? 1 : 0; c.e_res[e] = 0; c.e_mask[e] = 0;
+    c.e_flag[e] = flip ? 1 : 0; c.e_res[e] = 0; c.e_mask[e] = 0; c.e_new[e] = 0;
     if (!flip) return;
     uint32_t q = vrg_atomic_add(&c.st->nf, 1u);
     if (s.time_up || n_in >= s.maxSegmentSize) return;    // :97 / :101 fire before update(): count only
@@ -207,9 +207,14 @@ VRG_HD void vrg_item_scatter_marks(const VrgCtx& c, uint32_t r, uint32_t p) {
 // sparse relabel, phase 1: new byte of every marked voxel from the OLD labels (nothing is written to
 // the label volume yet, so all stencil reads see the pre-sweep state)
 VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t cb);
+#define VE_VALID 0x80          // e_new: the relabel visited the entry's voxel (new bytes never carry bit 7 = VB_M)
 VRG_HD void vrg_item_relabel(const VrgCtx& c, uint32_t i) {
     uint32_t idx = c.mk_idx[i];
-    c.mk_new[i] = vrg_sweep_core(c, c.lab[0], idx, c.lab[0][idx]);
+    const uint32_t e = c.vent[idx];                        // meaningful only for a band voxel (B bit)
+    const uint8_t cb = c.lab[0][idx];
+    const uint8_t nw = vrg_sweep_core(c, c.lab[0], idx, cb);
+    c.mk_new[i] = nw;
+    if (cb & VB_B) c.e_new[e] = (uint8_t)(nw | VE_VALID);  // the entry's survivor test need not wait for k_apply
 }
 // phase 2: write the new bytes (this also clears the L / P / mark bits)
 // class of a label for the region statistics (:113-116): 1 inner (S), 2 outer (neither S nor excluded), 0 neither
@@ -244,7 +249,7 @@ VRG_HD uint32_t vrg_catchup_count(const VrgCtx& c) { uint32_t n = c.nchg[((c.st-
 VRG_HD void vrg_item_apply(const VrgCtx& c, uint32_t i) {
     uint32_t idx = c.mk_idx[i];
     uint8_t old = c.lab[0][idx], nw = c.mk_new[i];
-    c.lab[0][idx] = nw;
+    c.lab[0][idx] = (uint8_t)(nw & ~VB_F);                 // F is a note to the entry's survivor test (e_new), not a label bit
     vrg_count_change(c, idx, old, nw);
 }
 // one caller, after every label of sweep iter+1 is written and before anything of the next sweep: file the sizes
@@ -409,12 +414,14 @@ VRG_HD uint32_t vrg_slot_B2(const VrgState& s, uint32_t j) { return 3 * s.ni + 2
 VRG_HD void vrg_item_entry_post(const VrgCtx& c, uint32_t e) {
     const VrgState s = *c.st;                                 // a copy: no reloads after the stores below
     int cur = s.iter & 1;
-    uint8_t* lab = c.lab[0];
+    const uint8_t* lab = c.lab[0];
     // independent loads first (one round trip), then the one that depends on idx
     uint32_t idx = c.b_idx[cur][e], lev = c.b_lev[cur][e], mask = c.e_mask[e];
-    uint8_t res = c.e_res[e];
+    uint8_t res = c.e_res[e], en = c.e_new[e];
     bool inner = e < s.ni, flag = c.e_flag[e] != 0;
-    uint8_t nb = lab[idx];
+    // the voxel's byte after the sweep: from the relabel if it visited the voxel, else the label it kept (k_apply,
+    // which may run beside this kernel, only rewrites visited voxels)
+    uint8_t nb = (en & VE_VALID) ? (uint8_t)(en & ~VE_VALID) : lab[idx];
     uint8_t fin = res & FR_FINAL;
     bool fresh = res & FR_FRESH;
     if (!flag) mask = 0u;
@@ -434,7 +441,6 @@ VRG_HD void vrg_item_entry_post(const VrgCtx& c, uint32_t e) {
     } else {
         uint32_t j = e - s.ni;
         surv = !flag && (nb & VB_LABEL) == VB_B && !(nb & VB_F);
-        if (nb & VB_F) lab[idx] = (uint8_t)(nb & ~VB_F);      // only the S/X/OOB bits are read concurrently (recount)
         c.scan[vrg_slot_B0(s, j)] = surv ? 1u : 0u;
         c.scan[vrg_slot_A2(s, j)] = (flag && fin == 1) ? 1u : 0u;
         c.scan[vrg_slot_B2(s, j)] = (uint32_t)__builtin_popcount(mask);
@@ -463,6 +469,7 @@ VRG_HD void vrg_apply_correction(const VrgCtx& c, uint32_t lev, double& ip, doub
 VRG_HD void vrg_new_fresh(const VrgCtx& c, int nx, uint32_t pos, uint32_t idx, uint32_t lev) {
     if (pos >= c.bcap) { c.st->error = 1; return; }
     c.b_idx[nx][pos] = idx; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = 0; c.b_op[nx][pos] = 0; c.b_pend[nx][pos] = 1;
+    c.vent[idx] = pos;
     c.fresh[vrg_atomic_add(&c.st->nfresh, 1u)] = pos;
 }
 
@@ -490,6 +497,7 @@ VRG_HD void vrg_item_scatter_entry(const VrgCtx& c, uint32_t e) {
     if (pos >= c.bcap) { c.st->error = 1; return; }
     vrg_apply_correction(c, lev, ip, op);
     c.b_idx[nx][pos] = idx; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = ip; c.b_op[nx][pos] = op; c.b_pend[nx][pos] = 0;
+    c.vent[idx] = pos;
 }
 
 // the voxels a listed flip promoted (item k = neighbour k of the flip, :263-282 order): fresh entries
@@ -567,6 +575,7 @@ VRG_HD void vrg_item_init_entry(const VrgCtx& c, uint32_t e) {
     uint32_t idx = c.b_idx[0][e];
     c.b_lev[0][e] = vrg_voxel_level(c, idx);
     c.fresh[e] = e;
+    c.vent[idx] = e;
 }
 
 VRG_HD void vrg_item_hist_voxel(const VrgCtx& c, uint32_t idx) {

@@ -121,6 +121,8 @@ struct VrgCtx {
     double* b_op[2];
     uint8_t* b_pend[2];        // 1: densities still to be computed exactly (entry (re-)entered the band in the sweep that built the list)
     uint8_t* e_flag;           // per old entry: listed flip
+    uint8_t* e_new;            // per entry: 0x80 | its voxel's byte after this sweep, when the relabel visited that voxel (else 0)
+    uint32_t* vent;            // per voxel: list position of the band entry sitting there (valid while the B bit is set)
     uint8_t* e_surv;           // per old entry: survives in place
     uint8_t* e_res;            // per old entry: FR_* result of a listed flip
     uint32_t* e_mask;          // per old entry: bit k = neighbour k (offset order of get_neighbours :263) promoted by this flip

@@ -179,8 +179,12 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*, be_reduce_fn cb, vo
         for (uint32_t i = 0, nc = vrg_catchup_count(c); i < nc; i++) vrg_item_catchup(c, i);
     } else {
         // full-stencil check variant: every voxel, through the scratch volume
-        for_real_voxels(c, [&](uint32_t idx, int, int, int) { c.lab[1][idx] = vrg_sweep_core(c, lab, idx, lab[idx]); });
-        for_real_voxels(c, [&](uint32_t idx, int, int, int) { vrg_count_change(c, idx, lab[idx], c.lab[1][idx]); lab[idx] = c.lab[1][idx]; });
+        for_real_voxels(c, [&](uint32_t idx, int, int, int) {
+            uint8_t nb = vrg_sweep_core(c, lab, idx, lab[idx]);
+            if (lab[idx] & VB_B) c.e_new[c.vent[idx]] = (uint8_t)(nb | VE_VALID);
+            c.lab[1][idx] = nb;
+        });
+        for_real_voxels(c, [&](uint32_t idx, int, int, int) { vrg_count_change(c, idx, lab[idx], c.lab[1][idx]); lab[idx] = (uint8_t)(c.lab[1][idx] & ~VB_F); });
         for (uint32_t i = 0, nc = vrg_catchup_count(c); i < nc; i++) vrg_item_catchup(c, i);
     }
     vrg_request_dense(c);
