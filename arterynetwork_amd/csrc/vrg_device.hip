@@ -133,7 +133,7 @@ __global__ void k_fix(VrgCtx c) {
         if (threadIdx.x == 0) changed = 0;
         __syncthreads();
         for (uint32_t j = threadIdx.x; j < np; j += blockDim.x)
-            if (vrg_item_fix(c, j)) changed = 1;
+            if (vrg_item_fix(c, j) == 2) changed = 1;
         __threadfence();
         __syncthreads();
         if (!changed) break;
@@ -142,18 +142,27 @@ __global__ void k_fix(VrgCtx c) {
 // Skip-rule fix-point first (rare: only when a flip-in dropped to 3 in phase A, npend > 0).  It is a monotone
 // closure (P bits are only ever set) over facts the previous kernel left behind, so EVERY workgroup computes all
 // of it by itself - the same bits, set with atomic ORs - instead of one workgroup in a kernel of its own that the
-// common case (npend == 0) would pay a launch for.  Then the relabel stencil of the marked voxels.
+// common case (npend == 0) would pay a launch for.  A workgroup is done after a pass in which it neither applied
+// anything NOR saw a bit that it had not seen the pass before (another workgroup may set an entry between this
+// one's look at a dependent entry and its look at the entry itself; the per-thread count of set entries catches
+// that).  Then the relabel stencil of the marked voxels.
 __global__ void k_relabel(VrgCtx c) {
     if (c.st->done) return;
     const uint32_t np = c.st->npend;
     if (np) {
         __shared__ int changed;
+        uint32_t seen_before = 0;
         for (;;) {
             __syncthreads();
             if (threadIdx.x == 0) changed = 0;
             __syncthreads();
-            for (uint32_t j = threadIdx.x; j < np; j += blockDim.x)
-                if (vrg_item_fix(c, j)) changed = 1;
+            uint32_t seen = 0; bool mine = false;
+            for (uint32_t j = threadIdx.x; j < np; j += blockDim.x) {
+                const int r = vrg_item_fix(c, j);
+                seen += r != 0; mine |= r == 2;
+            }
+            if (mine || seen != seen_before) changed = 1;
+            seen_before = seen;
             __threadfence();
             __syncthreads();
             if (!changed) break;

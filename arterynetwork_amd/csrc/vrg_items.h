@@ -166,20 +166,21 @@ VRG_HD void vrg_item_prepass(const VrgCtx& c, uint32_t r) {
 }
 
 // one relaxation of the skip rule: applied if an applied flip-in neighbour of smaller rank exists
-VRG_HD bool vrg_item_fix(const VrgCtx& c, uint32_t j) {
+// returns 0: still skipped, 1: found applied (by whoever), 2: applied by this call
+VRG_HD int vrg_item_fix(const VrgCtx& c, uint32_t j) {
     uint32_t e = c.pend[j], idx = c.b_idx[c.st->iter & 1][e];
     uint8_t* lab = c.lab[0];
-    if (vrg_load_coherent(lab + idx) & VB_P) return false;
+    if (vrg_load_coherent(lab + idx) & VB_P) return 1;
     for (int k = 0; k < 27; k++) {
         if (k == 13) continue;
         uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
         uint8_t mb = vrg_load_coherent(lab + m);
         if (!(mb & VB_S) && (mb & VB_L) && (mb & VB_P) && (uint32_t)c.stamp[m] < e) {
             vrg_or_byte(lab, idx, VB_P);
-            return true;
+            return 2;
         }
     }
-    return false;
+    return 0;
 }
 
 // scatter the "needs the stencil" mark: 1-ring of every listed flip (incl. itself) and the excluded

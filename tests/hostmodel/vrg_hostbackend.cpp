@@ -166,7 +166,7 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*, be_reduce_fn cb, vo
     for (uint32_t r = 0; r < s.nf; r++) vrg_item_prepass(c, r);
     for (bool changed = true; changed;) {
         changed = false;
-        for (uint32_t j = 0; j < s.npend; j++) changed |= vrg_item_fix(c, j);
+        for (uint32_t j = 0; j < s.npend; j++) changed |= vrg_item_fix(c, j) == 2;
     }
     const bool full = variant & 1;
     uint8_t* lab = c.lab[0];
