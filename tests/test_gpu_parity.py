@@ -130,6 +130,16 @@ def test_random_volumes_in_one_call(lib):
     assert sweeps > 400
 
 
+def test_skip_rule_closure_is_race_free(lib):
+    """Regression: the skip-rule fix-point is computed by every workgroup of k_relabel for itself.  With a wrong
+    termination test one workgroup could stop before another one's write became visible; this case then failed in
+    6 % of its runs (labels of sweep 1).  300 repetitions."""
+    I, vm, H, variant, dmode = random_case(200041, 10, 40)
+    for _ in range(300):
+        res, k = parity.run_stepwise(lib, I, vm, H, None, 2, density_mode=1, options={'sweep_variant': 0})
+        assert k == 2
+
+
 def test_medium_tube_vs_oracle(lib):
     """A 160x96x64 integer-level tube with a brain mask, 60 sweeps: the oracle (level mode) takes seconds."""
     from arterynetwork_amd import phantoms
