@@ -42,8 +42,10 @@ def decision_margin(o):
     m = np.inf
     for which in (0, 1):
         _, ip, op = o.band(which)
-        if len(ip) == 0 or nin == 0 or nout == 0:
+        if len(ip) == 0:
             continue
+        if nin == 0 or nout == 0:      # a region vanished: x / 0 with x a rounding residue of the incremental corrections -
+            return 0.0                 # its SIGN (+-1e-16 -> +-inf) decides in the reference: summation-order dependent
         a, b = ip / nin, op / nout
         rel = np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-300)
         m = min(m, float(rel.min()))
