@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Repeat one random case in whole-run mode (development tool: hunting rare races). args: seed reps graph batch"""
+"""Repeat one random case in whole-run mode (development tool: hunting rare races). args: seed reps graph batch [lo hi]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -9,7 +9,9 @@ from test_hostmodel import random_case
 from arterynetwork_amd._capi import product_lib
 lib = product_lib()
 sd, reps, graph, batch = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-I, vm, H, variant, dmode = random_case(sd)
+lo, hi = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (1, 13)
+I, vm, H, variant, dmode = random_case(sd, lo, hi)
+if max(I.shape) > 16: dmode = 1
 print('seed', sd, 'shape', I.shape, 'variant', variant, 'levels', len(np.unique(I)), 'dmode', dmode, flush=True)
 fails = 0
 for r in range(reps):
