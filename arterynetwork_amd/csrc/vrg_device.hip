@@ -478,27 +478,14 @@ __global__ void __launch_bounds__(TPB) k_levels_tab_scan(VrgCtx c) {
 
 // ---- the dense pass ----------------------------------------------------------------------------------
 // Region recount (:113-116 innerSize/outerSize, :249-250 dataArray[mask]) over every voxel, every sweep.
-// Streams the interior planes [2*plane, (nz+2)*plane) of the padded volume.  A wave owns one 1-KiB unit
-// of label bytes (1024 voxels) per trip: lane l takes the four dwords at +256*j + 4*l (j = 0..3) and
-// the four float4 of intensities at the same voxel offsets, so EVERY wave instruction is one contiguous
-// 256-B (labels) or 1-KiB (intensities) request.  Sums are reduced lane -> wave butterfly -> LDS -> one
-// slot per workgroup, added in fixed slot order by the last workgroup to finish: bit-reproducible.
+// Streams the interior planes of the padded volume in units of 1024 voxels (k_recount_bits below).  Sums are
+// reduced lane -> wave butterfly -> LDS -> one slot per workgroup, added in fixed slot order by the last workgroup
+// to finish: bit-reproducible.
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 
 struct SweepAcc { long long nin, nout; double sin_, sout; };
 
-__device__ __forceinline__ void sweep_stats(SweepAcc& a, uint32_t v, f4v f) {
-    uint32_t sbits = v & 0x01010101u;                                  // S
-    uint32_t obits = ~(v | (v >> 2) | (v >> 5)) & 0x01010101u;         // !(S|X|OOB)
-    a.nin += __popc(sbits); a.nout += __popc(obits);
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        double x = (double)f[b];
-        a.sin_ += ((sbits >> (8 * b)) & 1u) ? x : 0.0;
-        a.sout += ((obits >> (8 * b)) & 1u) ? x : 0.0;
-    }
-}
 // per-workgroup slot, then the LAST workgroup to arrive adds all slots in slot order and publishes the
 // totals (agent-scope release before the ticket, acquire after it: cdna guide, Guideline 16)
 __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a, int fin) {
