@@ -140,6 +140,21 @@ def test_skip_rule_closure_is_race_free(lib):
         assert k == 2
 
 
+def test_level_table_paths(lib):
+    """The three ways the per-level bookkeeping is launched: fused kernel (<= 2048 distinct intensities), one-workgroup
+    compaction (<= 32768), device-wide scan (more).  Float noise volumes, stepwise and in one call."""
+    for shape, sd in (((12, 13, 11), 1), ((30, 31, 29), 2), ((34, 33, 32), 3)):
+        rng = np.random.default_rng(sd)
+        I = rng.standard_normal(shape).astype(np.float32).astype(np.float64)
+        u = rng.random(shape)
+        vm = np.full(shape, 3, dtype=np.int64); vm[u < 0.1] = 0; vm[u > 0.8] = 4
+        assert len(np.unique(I)) > 0.99 * I.size
+        res, k = parity.run_stepwise(lib, I, vm, 2.25, None, 4, density_mode=1, check_hist=True)
+        assert res is not None and k >= 3
+        res, k = parity.run_batched(lib, I, vm, 2.25, None, 4, density_mode=1, options={'batch': 3})
+        assert res is not None
+
+
 def test_medium_tube_vs_oracle(lib):
     """A 160x96x64 integer-level tube with a brain mask, 60 sweeps: the oracle (level mode) takes seconds."""
     from arterynetwork_amd import phantoms
