@@ -140,6 +140,15 @@ def test_skip_rule_closure_is_race_free(lib):
         assert k == 2
 
 
+def test_whole_run_is_repeatable(lib):
+    """The same medium case 100 times in one call each (sweeps batched, kernels of consecutive sweeps back to back,
+    dense pass trailing): every run has to reproduce the oracle - a cheap trap for rare intra-kernel races."""
+    I, vm, H, variant, dmode = random_case(200041, 10, 40)
+    for rep in range(100):
+        res, k = parity.run_batched(lib, I, vm, H, None, 6, density_mode=1, options={'sweep_variant': 0, 'batch': 1 + rep % 4})
+        assert res is not None
+
+
 def test_level_table_paths(lib):
     """The three ways the per-level bookkeeping is launched: fused kernel (<= 2048 distinct intensities), one-workgroup
     compaction (<= 32768), device-wide scan (more).  Float noise volumes, stepwise and in one call."""
