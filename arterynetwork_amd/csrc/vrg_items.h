@@ -371,7 +371,7 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
                 }
             bool fresh = nFO && !nSegA;               // had dropped to 3 in phase A: exact density (:212,:251)
             c.e_res[r] = (uint8_t)(FR_WRITTEN | (to0 ? 0 : 1) | (fresh ? FR_FRESH : 0));
-            return to0 ? VB_S : (uint8_t)(VB_S | VB_B);
+            return to0 ? (uint8_t)VB_S : (uint8_t)(VB_S | VB_B);
         }
         bool to3 = nFO && !nSegA;                     // :183-190
         uint8_t out, res;
