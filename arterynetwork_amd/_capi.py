@@ -237,6 +237,31 @@ class Session:
         self._check(self.lib.get_trace(self._h, out.ctypes.data, n.value, C.byref(n)))
         return out
 
+    def nlevels(self):
+        """Number of distinct intensity values of the volume (after init)."""
+        n = C.c_int64()
+        self._check(self.lib.get_levels(self._h, None, None, None, None, None, 0, C.byref(n)))
+        return n.value
+
+    def chain_timing(self, H=2.25, sweeps=100):
+        """Measurement aid for bench.py: the band chain of a sweep timed ALONE (option dense_off: the dense recount
+        is not launched), `sweeps` more sweeps from the current state.  The session has to be re-initialised
+        afterwards.  Returns {} when nothing could be measured (run stopped)."""
+        import time
+        try:
+            self.set_option('events', 0)
+            self.set_option('dense_off', 1)
+        except VrgError:
+            return {}
+        it0 = len(self.trace()) - 1
+        t0 = time.perf_counter()
+        r = self.run(it0 + sweeps, 10 ** 15, None)
+        dt = time.perf_counter() - t0
+        if r.sweeps <= 0:
+            return {}
+        return {'band_chain_ms': round(dt / r.sweeps * 1e3, 4), 'band_chain_sweeps': int(r.sweeps),
+                'band_chain_note': 'stream A alone (dense recount not launched), wall time per sweep incl. host enqueue'}
+
     def levels(self, recount=True):
         n = C.c_int64()
         self._check(self.lib.get_levels(self._h, None, None, None, None, None, 0, C.byref(n)))

@@ -973,7 +973,10 @@ void be_init_sort(const VrgCtx& c, uint32_t n_in, uint32_t n_out) {
 static void reduce_dense(const VrgCtx& c, be_reduce_fn cb, void* user, hipStream_t g_stream) {
     if (g_comm) {
         ncclResult_t r = ncclAllReduce(c.dn_part, c.dn, 4, ncclDouble, ncclSum, g_comm, g_stream);
-        if (r != ncclSuccess) std::fprintf(stderr, "RCCL all-reduce failed: %s\n", ncclGetErrorString(r));
+        if (r != ncclSuccess && !g_hip_error[0]) {   // sticky: the engine turns it into VRG_E_INTERNAL at its next synchronisation point
+            std::snprintf(g_hip_error, sizeof(g_hip_error), "RCCL all-reduce of the slab statistics failed: %s", ncclGetErrorString(r));
+            std::fprintf(stderr, "%s\n", g_hip_error);
+        }
     } else if (cb) {
         double v[4];
         HIP_CHECK(hipMemcpyAsync(v, c.dn_part, sizeof(v), hipMemcpyDeviceToHost, g_stream));
@@ -991,7 +994,9 @@ int be_comm_unique_id(void* id128) {
 int be_comm_init(int nranks, int rank, const void* id128) {
     if (g_comm) { ncclCommDestroy(g_comm); g_comm = nullptr; }
     ncclUniqueId id; std::memcpy(&id, id128, sizeof(id));
-    return ncclCommInitRank(&g_comm, nranks, id, rank) == ncclSuccess ? 0 : -1;
+    ncclResult_t r = ncclCommInitRank(&g_comm, nranks, id, rank);
+    if (r != ncclSuccess) { std::fprintf(stderr, "ncclCommInitRank failed: %s\n", ncclGetErrorString(r)); g_comm = nullptr; return -1; }
+    return 0;
 }
 
 // The start / stop events ride on the dispatch itself (hipExtLaunchKernel): no separate event packets in the stream,
@@ -1095,7 +1100,7 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb,
         EvPair& p = g_ev_pool[g_ev_used++];
         e_start = p.a; e_read = p.b;
     }
-    run_band(g_graph_pre, c, variant, [&] { enqueue_pre(c, variant); });
+    run_band(g_graph_pre, c, variant & 3, [&] { enqueue_pre(c, variant & 3); });
     // the labels change now, in the class copy the dense pass of two sweeps ago was reading
     if (g_read[g_trip & 1]) HIP_CHECK(hipStreamWaitEvent(g_stream, g_read[g_trip & 1], 0));
     if (!(variant & 1)) k_apply_entry_post<<<2 * ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
@@ -1103,6 +1108,7 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb,
     launch_levels(c, g_ev_a);                        // files the sizes the dense pass must reproduce; g_ev_a on its dispatch
     // dense stream: every voxel once, read-only.  Enqueued before the rest of the bookkeeping so that its dispatch
     // never waits for the host to issue those launches.
+    if (!(variant & 4)) {                            // (variant & 4: measurement aid, the band chain alone)
     HIP_CHECK(hipStreamWaitEvent(g_stream_b, g_ev_a, 0));
     const bool ranks = c.world > 1 || g_comm || cb;
     launch_recount(c, dense_blocks(c), ranks ? 1 : 2, g_stream_b, e_start, e_read);
@@ -1111,6 +1117,7 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb,
     if (ranks) {                                     // one GPU: the last workgroup of the recount closes the pass itself
         reduce_dense(c, cb, user, g_stream_b);       // sum over the Z-slabs (RCCL on the stream / host callback)
         k_dense_fin<<<1, 1, 0, g_stream_b>>>(c);
+    }
     }
     run_band(g_graph_post, c, 0, [&] { enqueue_post(c); });
 }

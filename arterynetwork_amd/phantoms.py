@@ -125,3 +125,30 @@ def bench_volume(shape, seed, levels=255, radius=4.0, noise=0.1, seed_planes=3):
     return tube_phantom(shape=shape, radius=radius, noise=noise, seed=seed, seed_planes=seed_planes,
                         amp_y=0.18 * ny, amp_z=0.18 * nz, levels=levels, brain_mask=True,
                         dtype=np.float32, noise_dtype=np.float32)
+
+
+def bench_volume_torch(shape, device, seed=3, levels=255, radius=4.0, noise=0.1, seed_planes=3):
+    """The configs 2-4 recipe generated directly in HBM with torch (plumbing only), x-fastest
+    layout.  Returns (I, vm) as torch tensors of logical shape (nx,ny,nz) with element strides (1,nx,nx*ny).
+    ``levels=None`` keeps the continuous float32 noise (one distinct value per voxel, nearly)."""
+    import math
+    import torch
+    nx, ny, nz = shape
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    xs = torch.arange(nx, device=device, dtype=torch.float32)[None, None, :]
+    ys = torch.arange(ny, device=device, dtype=torch.float32)[None, :, None]
+    zs = torch.arange(nz, device=device, dtype=torch.float32)[:, None, None]
+    cy = ny / 2.0 + 0.18 * ny * torch.sin(2 * math.pi * xs / nx)
+    cz = nz / 2.0 + 0.18 * nz * torch.cos(2 * math.pi * xs / nx)
+    tube = ((ys - cy) ** 2 + (zs - cz) ** 2) <= radius ** 2            # (nz,ny,nx)
+    I = torch.randn((nz, ny, nx), generator=g, device=device, dtype=torch.float32)
+    I.mul_(noise).add_(tube.to(torch.float32))
+    if levels:
+        I = torch.round(I * levels) / levels
+    ell = (((xs - (nx - 1) / 2.0) / (0.48 * nx)) ** 2 + ((ys - (ny - 1) / 2.0) / (0.48 * ny)) ** 2
+           + ((zs - (nz - 1) / 2.0) / (0.48 * nz)) ** 2) <= 1.0
+    vm = torch.full((nz, ny, nx), 3, dtype=torch.uint8, device=device)
+    vm[~ell.expand(nz, ny, nx)] = 4
+    vm[tube & (xs < seed_planes)] = 0
+    return I.permute(2, 1, 0), vm.permute(2, 1, 0)

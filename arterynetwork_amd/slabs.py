@@ -39,7 +39,11 @@ def make_slab_session(shape, rank, world, device=0, lib=None, reduce='rccl', gro
     s = Session(shape, device=device, lib=lib)
     z0, z1 = partition(shape[2], world)[rank]
     s.set_slab(z0, z1)
+    s.slab = (z0, z1)
     s.reduce_mode = 'none'
+    s.comm_ranks = 0
+    if reduce == 'none':
+        return s
     if world > 1 or reduce == 'rccl-always':
         ok = False
         if reduce in ('rccl', 'rccl-always'):
@@ -47,6 +51,7 @@ def make_slab_session(shape, rank, world, device=0, lib=None, reduce='rccl', gro
             dist.broadcast_object_list(ident, src=0, group=group)
             try:
                 s.comm_init(world, rank, ident[0])
+                s.comm_ranks = world
                 ok = True
             except VrgError:
                 ok = False
@@ -69,22 +74,30 @@ def make_slab_session(shape, rank, world, device=0, lib=None, reduce='rccl', gro
     return s
 
 
-def bench_slabs(shape, args, dev, rank, world):
+def bench_slabs(shape, args, dev, rank, world, roofline):
     """bench.py body for N > 1 ranks: every rank generates the same synthetic volume in its HBM, recounts
-    its own Z-slab; barrier + synchronize around exactly K sweeps; MAX over ranks; whole-job throughput."""
+    its own Z-slab; barrier + synchronize around exactly K sweeps; MAX over ranks; whole-job throughput.
+    `roofline` is bench.py's roofline(shape, planes, kernel_ms, launches, traffic, storage16)."""
     import torch
     import torch.distributed as dist
-    import bench as B
-    I, vm = B.make_volume_torch(shape, dev, levels=args.levels, H=args.H)
+    from . import phantoms
+    I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels)
     torch.cuda.synchronize()
     V = shape[0] * shape[1] * shape[2]
-    s = make_slab_session(shape, rank, world, device=dev.index, reduce='rccl-always')
+    slab_of = int(getattr(args, 'slab_of', 0) or 0)
+    if slab_of > 1 and world == 1:
+        # one GPU standing in for one of `slab_of` ranks: recount the first of that many Z-slabs (projection runs)
+        s = make_slab_session(shape, 0, slab_of, device=dev.index, reduce='none')
+        s.comm_init(1, 0, s.comm_unique_id())
+        s.reduce_mode = 'rccl (1-rank communicator)'
+    else:
+        s = make_slab_session(shape, rank, world, device=dev.index, reduce='rccl-always')
     if args.sweep_blocks:
         s.set_option('sweep_blocks', args.sweep_blocks)
     use_graph = int(getattr(args, 'graph', 0))
     s.set_option('events', 1)
-    s.set_option('graph', use_graph)           # band kernels replayed from two hipGraphs: at 8 ranks the step is ~0.1 ms,
-    s.set_option('batch', 64)                  # close to the cost of issuing its ~25 launches one by one
+    s.set_option('graph', use_graph)
+    s.set_option('batch', 64)
     s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
     s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
     s.init(args.H)
@@ -97,14 +110,17 @@ def bench_slabs(shape, args, dev, rank, world):
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
-    rk = r
-    t = torch.tensor([dt, rk.sweep_kernel_ms / max(1, rk.sweep_launches)], dtype=torch.float64, device=dev)
+    dense_ms = r.sweep_kernel_ms / max(1, r.sweep_launches)
+    t = torch.tensor([dt, dense_ms], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max, kern_ms = float(t[0]), float(t[1])
+    per_rank = [None] * world
+    chain = s.chain_timing(args.H) if getattr(s, 'reduce_mode', '') else {}
+    dist.all_gather_object(per_rank, {'rank': rank, 'slab': list(s.slab), 'dense_ms': round(dense_ms, 4),
+                                      'band_chain_ms': chain.get('band_chain_ms'), 'seconds': round(dt, 4)})
     valid = (r.sweeps == args.steps) and (r0.sweeps == args.warmup)
     tr = s.trace()
     z0, z1 = s.slab
-    slab_vox = shape[0] * shape[1] * (z1 - z0)
     out = {
         'metric': 'Mvoxel-iters/sec, VRG sweep, {} volume'.format(args.shape),
         'value': round(V * r.sweeps / dt_max / 1e6, 1), 'unit': 'Mvoxel-iter/s', 'n_gpus': world,
@@ -114,9 +130,13 @@ def bench_slabs(shape, args, dev, rank, world):
         'config': {'workload': '{} synthetic MRA tube volume ({} intensity levels stored fp32, brain-mask excluded '
                                'voxels), H={}, {} incremental VRG sweeps'.format(args.shape, args.levels, args.H, r.sweeps),
                    'parallelism': 'zslab{} (dense recount sharded into {} Z-slabs, band relabel replicated, one '
-                                  '32-byte RCCL all-reduce per sweep)'.format(world, world),
-                   'reduction': s.reduce_mode, 'launch': 'band kernels from hipGraph replay' if use_graph else 'eager', 'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1])},
-        'roofline': B.roofline(slab_vox, kern_ms, int(rk.sweep_launches), None),
+                                  '32-byte RCCL all-reduce per sweep)'.format(slab_of or world, slab_of or world),
+                   'reduction': s.reduce_mode, 'rccl_ranks': s.comm_ranks, 'launch': 'band kernels from hipGraph replay' if use_graph else 'eager',
+                   'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
+                   'dense_ms': round(kern_ms, 4), 'band_chain_ms': chain.get('band_chain_ms'), 'ranks': per_rank},
+        'roofline': roofline(shape, z1 - z0, kern_ms, int(r.sweep_launches), None),
     }
+    if slab_of > 1 and world == 1:
+        out['config']['note'] = 'ONE GPU doing the work of rank 0 of {} (projection run, not a scaling measurement)'.format(slab_of)
     s.close()
     return out

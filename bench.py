@@ -7,15 +7,18 @@ generated on the GPU with torch (plumbing only) and are resident in HBM before t
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--shape 880x880x640]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU): the volume is cut into Z-slabs with a
-per-sweep halo exchange (arterynetwork_amd/slabs.py).  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU.  Under a launcher (torch.distributed.run sets WORLD_SIZE) this process is one
+rank; started plainly with --gpus N it starts the N ranks itself (a child `python -m torch.distributed.run`,
+before anything here touches the GPU) and passes their JSON line through.  The dense recount is cut into
+Z-slabs (arterynetwork_amd/slabs.py).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
-import math
 import os
+import subprocess
 import sys
 import time
 
@@ -26,89 +29,145 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-BYTES_PER_VOXEL_ITER = 6     # 4 B fp32 intensity + 1 B label read + 1 B label write (SURVEY.md §8d)
+BYTES_PER_VOXEL_ITER = 6     # SURVEY.md §8d: 4 B fp32 intensity + 1 B label read + 1 B label write
+REFERENCE_ITSELF = {'value': 2.43, 'unit': 'Mvoxel-iter/s', 'cores': 1, 'config': '128x128x64 tube, 50 sweeps (BASELINE configs[0])',
+                    'source': 'the reference imported in the build container (SURVEY.md §6; it cannot run the larger configs)'}
 
 
-def make_volume_torch(shape, device, seed=3, levels=255, radius=4.0, noise=0.1, seed_planes=3, H=2.25):
-    """Configs 2-4 recipe generated directly in HBM, x-fastest layout.
-    Returns (I, vm) as torch tensors of logical shape (nx,ny,nz) with element strides (1,nx,nx*ny)."""
-    import torch
-    nx, ny, nz = shape
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    xs = torch.arange(nx, device=device, dtype=torch.float32)[None, None, :]
-    ys = torch.arange(ny, device=device, dtype=torch.float32)[None, :, None]
-    zs = torch.arange(nz, device=device, dtype=torch.float32)[:, None, None]
-    cy = ny / 2.0 + 0.18 * ny * torch.sin(2 * math.pi * xs / nx)
-    cz = nz / 2.0 + 0.18 * nz * torch.cos(2 * math.pi * xs / nx)
-    tube = ((ys - cy) ** 2 + (zs - cz) ** 2) <= radius ** 2            # (nz,ny,nx)
-    I = torch.randn((nz, ny, nx), generator=g, device=device, dtype=torch.float32)
-    I.mul_(noise).add_(tube.to(torch.float32))
-    I = torch.round(I * levels) / levels
-    ell = (((xs - (nx - 1) / 2.0) / (0.48 * nx)) ** 2 + ((ys - (ny - 1) / 2.0) / (0.48 * ny)) ** 2
-           + ((zs - (nz - 1) / 2.0) / (0.48 * nz)) ** 2) <= 1.0
-    vm = torch.full((nz, ny, nx), 3, dtype=torch.uint8, device=device)
-    vm[~ell.expand(nz, ny, nx)] = 4
-    vm[tube & (xs < seed_planes)] = 0
-    return I.permute(2, 1, 0), vm.permute(2, 1, 0)
+def device_source_sha():
+    """Identifies the kernel sources a committed PMC traffic figure belongs to."""
+    h = hashlib.sha256()
+    for f in ('vrg_device.hip', 'vrg_items.h', 'vrg_types.h'):
+        with open(os.path.join(ROOT, 'arterynetwork_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
-def cpu_baseline(I_t, vm_t, H, budget_s=20.0):
-    """Time the oracle (a scalar C port of the reference, density_mode 1) on this host's cores, on a
-    bounded crop of the same volume around the seeds. Returns the cpu_baseline JSON object."""
-    from oracle import vrg_oracle as O
-    nx, ny, nz = I_t.shape
-    cx, cyy, czz = min(nx, 448), min(ny, 448), min(nz, 320)
-    y0 = max(0, min(ny - cyy, ny // 2 - cyy // 2))
-    z0 = max(0, min(nz - czz, int(nz / 2.0 + 0.18 * nz) - czz // 2))
-    I = I_t[:cx, y0:y0 + cyy, z0:z0 + czz].contiguous().cpu().numpy().astype(np.float64)
-    vm = vm_t[:cx, y0:y0 + cyy, z0:z0 + czz].contiguous().cpu().numpy()
-    if not (vm == 0).any():
-        return None
-    o = O.Oracle(I, vm, H, density_mode=1)
-    o.init()
-    t0 = time.perf_counter()
-    sweeps = 0
-    while time.perf_counter() - t0 < budget_s and sweeps < 300:
-        if o.step(10 ** 6, 10 ** 12, -1.0) != 0:
-            break
-        sweeps += 1
-    dt = time.perf_counter() - t0
-    o.close()
-    if sweeps == 0:
-        return None
-    return {'value': round(I.size * sweeps / dt / 1e6, 3), 'unit': 'Mvoxel-iter/s', 'cores': 1, 'kind': 'port',
-            'sample': '{} sweeps of the oracle (oracle/vrg_oracle.c, level-histogram mode) on the {}x{}x{} crop '
-                      'around the seeds of the same volume, {:.1f} s'.format(sweeps, cx, cyy, czz, dt)}
-
-
-def load_traffic(shape, n_gpus):
-    """HBM bytes per sweep launch from the committed rocprofv3 PMC passes (profiles/traffic.json)."""
-    p = os.path.join(ROOT, 'profiles', 'traffic.json')
+def load_traffic(shape, n_gpus, storage16):
+    """HBM bytes per dense launch from the committed rocprofv3 PMC passes (profiles/traffic.json) - only when that
+    file was measured on these very kernel sources (src_sha) and workload; None otherwise (never a stale figure)."""
     try:
-        t = json.load(open(p))
-        if t.get('shape') == list(shape) and t.get('n_gpus', 1) == n_gpus:
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+        if (t.get('shape') == list(shape) and t.get('n_gpus', 1) == n_gpus and bool(t.get('storage16', False)) == bool(storage16)
+                and t.get('src_sha') == device_source_sha()):
             return t.get('hbm_bytes_per_launch')
     except Exception:
         pass
     return None
 
 
-def roofline(V_per_launch, kern_ms, launches, traffic, bytes_per_voxel=BYTES_PER_VOXEL_ITER):
-    """Dominant kernel = k_recount_bits (dense region recount, one launch per sweep).  `achieved` uses the
-    ALGORITHMIC 6 B/voxel-iter of SURVEY.md 8(d).  The kernel itself moves 4.25 B/voxel: labels are updated in
-    place (no 1 B/voxel write-back) and the recount reads a 2-bit class volume instead of the label bytes, so
-    `achieved` can exceed the HBM peak; `traffic` is the rocprofv3 PMC figure of what really crossed the bus and
-    `traffic_frac_of_peak` the fraction of the HBM peak the kernel sustains."""
-    achieved = bytes_per_voxel * V_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
-    out = {'bound': 'hbm', 'kernel': 'k_recount_bits<3,true,true>' if bytes_per_voxel == 4 else 'k_recount_bits<3,true,false>', 'achieved': round(achieved, 1) if achieved else None,
-           'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+def padded_slab_voxels(shape, planes):
+    """Voxels the dense pass addresses for `planes` Z planes: padded rows (PX = roundup(nx+2,16)) x (ny+4) rows."""
+    nx, ny, _ = shape
+    return ((nx + 2 + 15) // 16 * 16) * (ny + 4) * planes
+
+
+def roofline(shape, planes, kern_ms, launches, traffic, storage16=False):
+    """Dominant kernel = k_recount_bits (dense region recount, one launch per sweep), HBM-bound.
+    `achieved` = the bytes the kernel has to move by its own design - 4 B fp32 intensity (2 B level index with
+    16-bit storage) + 2 class bits per voxel of the padded slab it streams - divided by the HIP-event time of the
+    launch; `frac` = achieved / 8 TB/s.  The label bytes are NOT streamed (labels are updated in place at the
+    ~10^3 marked voxels), so this is below SURVEY.md §8(d)'s 6 B/voxel-iteration accounting,
+    which is kept as `algorithmic_equiv_gbs` (what a kernel moving 6 B/voxel would need to match the time)."""
+    bpv = 2.25 if storage16 else 4.25
+    design = bpv * padded_slab_voxels(shape, planes)
+    V = shape[0] * shape[1] * planes
+    achieved = design / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
+    out = {'bound': 'hbm', 'kernel': 'k_recount_bits<3,true,{}>'.format('true' if storage16 else 'false'),
+           'achieved': round(achieved, 1) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+           'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
            'kernel_ms_avg': round(kern_ms, 4), 'launches': launches,
-           'algorithmic_bytes_per_launch': bytes_per_voxel * V_per_launch, 'traffic': traffic}
+           'bytes_per_launch': int(design), 'bytes_per_voxel': bpv,
+           'algorithmic_equiv_gbs': round((4 if storage16 else BYTES_PER_VOXEL_ITER) * V / (kern_ms * 1e-3) / 1e9, 1) if kern_ms > 0 else None,
+           'traffic': traffic}
     if traffic and kern_ms > 0:
         out['traffic_gbs'] = round(traffic / (kern_ms * 1e-3) / 1e9, 1)
         out['traffic_frac_of_peak'] = round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     return out
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(I_t, vm_t, H, levels_note, budget_s=(8.0, 12.0), max_vox=70e6):
+    """The oracle (oracle/vrg_oracle.c, a C port of the reference; level-histogram mode) timed on this host, with one
+    thread and with all cores (OpenMP build of the same file), on the workload's own volume when it is small enough
+    (config 2) and otherwise on a crop around the seeds.  The sweeps it made are then repeated by the HIP path on the
+    same sample and compared (labels, segmented order, integer trace): `parity`.  Outside the timed region."""
+    from oracle import vrg_oracle as O
+    from arterynetwork_amd._capi import Session
+    nx, ny, nz = I_t.shape
+    if nx * ny * nz <= max_vox:
+        cx, cyy, czz, y0, z0 = nx, ny, nz, 0, 0
+        what = 'the whole {}x{}x{} volume'.format(nx, ny, nz)
+    else:
+        cx, cyy, czz = min(nx, 448), min(ny, 448), min(nz, 320)
+        y0 = max(0, min(ny - cyy, ny // 2 - cyy // 2))
+        z0 = max(0, min(nz - czz, int(nz / 2.0 + 0.18 * nz) - czz // 2))
+        what = 'the {}x{}x{} crop around the seeds of the same volume'.format(cx, cyy, czz)
+    Ic = I_t[:cx, y0:y0 + cyy, z0:z0 + czz].contiguous().cpu().numpy()
+    vm = vm_t[:cx, y0:y0 + cyy, z0:z0 + czz].contiguous().cpu().numpy()
+    if not (vm == 0).any():
+        return None
+    o = O.Oracle(Ic.astype(np.float64), vm, H, density_mode=1, omp=True)
+    ncores = os.cpu_count() or 1
+    o.init()
+    timings = []
+    sweeps = 0
+    for threads, budget, cap in ((1, budget_s[0], 40), (ncores, budget_s[1], 400)):
+        got = o.set_threads(threads)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < budget and n < cap:
+            if o.step(10 ** 6, 10 ** 12, -1.0) != 0:
+                break
+            n += 1
+        dt = time.perf_counter() - t0
+        sweeps += n
+        timings.append((got, n, dt))
+    if sweeps == 0 or timings[1][1] == 0:
+        o.close()
+        return None
+    # the same sweeps by the HIP path on the same sample
+    s = Session(Ic.shape)
+    s.set_volume(Ic)
+    s.set_labels(vm)
+    s.init(H)
+    r = s.run(sweeps, 10 ** 15, None)
+    tr, otr = s.trace(), o.trace()
+    parity = bool(r.sweeps == sweeps and np.array_equal(s.labels(), o.labels())
+                  and np.array_equal((lambda c: (c[:, 0] * Ic.shape[1] + c[:, 1]) * Ic.shape[2] + c[:, 2])(s.segmented()), o.segmented_lex())
+                  and all(np.array_equal(tr[f], otr[f]) for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no')))
+    s.close()
+    o.close()
+    (t1, n1, d1), (tn, nn, dn) = timings
+    return {'value': round(Ic.size * nn / dn / 1e6, 1), 'unit': 'Mvoxel-iter/s', 'cores': tn, 'kind': 'port',
+            'single_core': {'value': round(Ic.size * n1 / d1 / 1e6, 1) if n1 else None, 'cores': 1, 'sweeps': n1, 'seconds': round(d1, 1)},
+            'cpu': cpu_model(), 'parity': parity, 'parity_sweeps': sweeps,
+            'sample': '{} sweeps with 1 thread ({:.1f} s) then {} sweeps with {} threads ({:.1f} s) of the oracle (C port of the '
+                      'reference, level-histogram mode, OpenMP build) on {} ({}); the HIP path repeated the {} sweeps on the same '
+                      'sample and was compared with it'.format(n1, d1, nn, tn, dn, what, levels_note, sweeps),
+            'reference_itself': REFERENCE_ITSELF}
+
+
+def spawn_ranks(args_list, n):
+    """--gpus N without a launcher: start the N ranks as a child torch.distributed.run (this process has not touched the
+    GPU), pass the child's output through, exit with its code."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + args_list
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -117,7 +176,7 @@ def main():
     ap.add_argument('--steps', type=int, default=500)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--shape', default='880x880x640')
-    ap.add_argument('--levels', type=int, default=255)
+    ap.add_argument('--levels', type=int, default=255, help='intensity levels of the synthetic volume; 0 = continuous float32 noise')
     ap.add_argument('--H', type=float, default=2.25)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--variant', type=int, default=0)
@@ -127,22 +186,25 @@ def main():
     ap.add_argument('--graph', type=int, default=0, help='replay the band kernels of each sweep from captured hipGraphs')
     ap.add_argument('--storage16', action='store_true', help='16-bit intensity storage (level indices): config 5 style; 4 B/voxel-iter algorithmic')
     ap.add_argument('--force-dist', action='store_true', help='use the N>1 code path (RCCL comm) even with one rank')
+    ap.add_argument('--slab-of', type=int, default=0, help='with --force-dist on one GPU: recount only the first of this many Z-slabs (what one of N ranks does)')
     args = ap.parse_args()
     shape = tuple(int(s) for s in args.shape.lower().split('x'))
     assert len(shape) == 3
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(sys.argv[1:], args.gpus))
 
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
-                             '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
+        raise SystemExit('--gpus {} but the launcher started {} ranks'.format(args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU path)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    from arterynetwork_amd import phantoms
 
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -150,15 +212,15 @@ def main():
         if 'MASTER_ADDR' not in os.environ:
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=dev)
-        out = slabs.bench_slabs(shape, args, dev, rank, world)
+        out = slabs.bench_slabs(shape, args, dev, rank, world, roofline)
         if rank == 0:
-            print(json.dumps(out))
+            print(json.dumps(out), flush=True)
         dist.barrier()
         dist.destroy_process_group()
         return
 
     from arterynetwork_amd._capi import Session
-    I, vm = make_volume_torch(shape, dev, levels=args.levels, H=args.H)
+    I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels)
     torch.cuda.synchronize()
     V = shape[0] * shape[1] * shape[2]
     s = Session(shape, device=local_rank)
@@ -191,28 +253,30 @@ def main():
     value = V * r.sweeps / dt / 1e6
     kern_ms = r.sweep_kernel_ms / max(1, r.sweep_launches)
     tr = s.trace()
+    nlev = s.nlevels()
+    lev_note = '{} distinct intensities'.format(nlev)
     out = {
         'metric': 'Mvoxel-iters/sec, VRG sweep, {} volume'.format(args.shape), 'value': round(value, 1),
         'unit': 'Mvoxel-iter/s', 'n_gpus': 1, 'steps': int(r.sweeps), 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'u8 labels + f32 intensities (f64 region sums / densities)',
         'data': 'synthetic', 'valid': bool(valid),
-        'config': {'workload': '{} synthetic MRA tube volume ({} intensity levels stored {}, brain-mask excluded '
+        'config': {'workload': '{} synthetic MRA tube volume ({} stored {}, brain-mask excluded '
                                'voxels), H={}, {} incremental VRG sweeps'.format(
-                                   args.shape, args.levels, 'as u16 level indices' if args.storage16 else 'fp32', args.H, r.sweeps),
+                                   args.shape, lev_note, 'as u16 level indices' if args.storage16 else 'fp32', args.H, r.sweeps),
                    'parallelism': 'single GPU', 'sweep_variant': args.variant,
                    'intensity_storage': 'u16 level index (2 B/voxel)' if args.storage16 else 'fp32 (4 B/voxel)',
                    'init_seconds': round(t_init, 3), 'nseg_start': int(tr['nseg'][args.warmup]),
                    'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
                    'flips_per_sweep_mean': round(float(tr['nflip'][args.warmup + 1:].mean()), 1),
-                   'hbm_gbs_whole_step': round(BYTES_PER_VOXEL_ITER * V / (ms_per_step * 1e-3) / 1e9, 1)},
-        'roofline': roofline(V, kern_ms, int(r.sweep_launches), None if args.storage16 else load_traffic(shape, 1),
-                             4 if args.storage16 else BYTES_PER_VOXEL_ITER),
+                   'dense_ms': round(kern_ms, 4)},
+        'roofline': roofline(shape, shape[2], kern_ms, int(r.sweep_launches), load_traffic(shape, 1, args.storage16), args.storage16),
     }
-    if not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(I, vm, args.H)
+    out['config'].update(s.chain_timing(args.H))
     s.close()
-    print(json.dumps(out))
+    if not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(I, vm, args.H, lev_note)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -27,6 +27,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define VRGO_OK 0
 #define VRGO_STOP_CONVERGED 1   /* :91-96  no flipped points          */
@@ -155,6 +158,9 @@ static int build_levels(vrgo *o) {
     o->levidx = (int32_t *)malloc(sizeof(int32_t) * o->V);
     o->hin = (int64_t *)calloc(L, sizeof(int64_t));
     o->hout = (int64_t *)calloc(L, sizeof(int64_t));
+#ifdef _OPENMP
+    #pragma omp parallel for schedule(static)
+#endif
     for (int64_t i = 0; i < o->V; i++) {
         int64_t lo = 0, hi = L - 1; double v = o->data[i];
         while (lo < hi) { int64_t m = (lo + hi) / 2; if (o->lev[m] < v) lo = m + 1; else hi = m; }
@@ -168,11 +174,29 @@ static int build_levels(vrgo *o) {
 static void recount_hist(vrgo *o) {
     memset(o->hin, 0, sizeof(int64_t) * o->L);
     memset(o->hout, 0, sizeof(int64_t) * o->L);
+#ifdef _OPENMP
+    /* all-cores build (libvrg_oracle_omp.so, bench.py's cpu_baseline): private histograms per thread,
+     * added up afterwards - integer counts, so the result is the serial one */
+    #pragma omp parallel
+    {
+        int64_t *hi = (int64_t *)calloc((size_t)o->L * 2, sizeof(int64_t)), *ho = hi + o->L;
+        #pragma omp for schedule(static) nowait
+        for (int64_t i = 0; i < o->V; i++) {
+            uint8_t l = o->label[i];
+            if (l <= 1) hi[o->levidx[i]]++;
+            else if (l <= 3) ho[o->levidx[i]]++;
+        }
+        #pragma omp critical
+        for (int64_t l = 0; l < o->L; l++) { o->hin[l] += hi[l]; o->hout[l] += ho[l]; }
+        free(hi);
+    }
+#else
     for (int64_t i = 0; i < o->V; i++) {
         uint8_t l = o->label[i];
         if (l <= 1) o->hin[o->levidx[i]]++;
         else if (l <= 3) o->hout[o->levidx[i]]++;
     }
+#endif
 }
 
 /* np.sum of a contiguous float64 vector: numpy's pairwise summation (blocks of 128, eight
@@ -250,10 +274,27 @@ static int gather_region_values(vrgo *o, double **iv, int64_t *nin, double **ov,
 
 static void recount_sizes(vrgo *o) { /* :49-52, :113-116 */
     int64_t a = 0, b = 0; double sa = 0, sb = 0;
+#ifdef _OPENMP
+    /* all-cores build: 256 fixed chunks, each summed in voxel order, added up in chunk order - the intensity
+     * sums then do not depend on the thread count (they differ from the serial build's by rounding only) */
+    enum { NCH = 256 };
+    int64_t ca[NCH], cb[NCH]; double csa[NCH], csb[NCH];
+    #pragma omp parallel for schedule(static)
+    for (int c = 0; c < NCH; c++) {
+        int64_t lo = o->V * c / NCH, hi = o->V * (c + 1) / NCH, x = 0, y = 0; double sx = 0, sy = 0;
+        for (int64_t i = lo; i < hi; i++) {
+            uint8_t l = o->label[i];
+            if (l <= 1) { x++; sx += o->data[i]; } else if (l <= 3) { y++; sy += o->data[i]; }
+        }
+        ca[c] = x; cb[c] = y; csa[c] = sx; csb[c] = sy;
+    }
+    for (int c = 0; c < NCH; c++) { a += ca[c]; b += cb[c]; sa += csa[c]; sb += csb[c]; }
+#else
     for (int64_t i = 0; i < o->V; i++) {
         uint8_t l = o->label[i];
         if (l <= 1) { a++; sa += o->data[i]; } else if (l <= 3) { b++; sb += o->data[i]; }
     }
+#endif
     o->innerSize = a; o->outerSize = b;
     if (o->ntrace == o->captrace) {
         o->captrace = o->captrace ? o->captrace * 2 : 64;
@@ -505,6 +546,15 @@ int vrgo_run(vrgo *o, int64_t iterMax, int64_t maxSegmentSize, double maxSeconds
     for (;;) { int rc = vrgo_step(o, iterMax, maxSegmentSize, maxSeconds); if (rc) return rc; }
 }
 
+/* all-cores build only: threads used by the dense loops (returns what is in effect; 1 in the serial build) */
+int vrgo_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n; return 1;
+#endif
+}
 int64_t vrgo_iter_num(const vrgo *o) { return o->iterNum; }
 int64_t vrgo_nseg(const vrgo *o) { return o->segl.n; }
 int64_t vrgo_ninner(const vrgo *o) { return o->inner.n; }

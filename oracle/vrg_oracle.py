@@ -17,6 +17,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, 'libvrg_oracle.so')
+LIB_OMP = os.path.join(HERE, 'libvrg_oracle_omp.so')     # same source built with -fopenmp (dense loops on all cores)
 
 STOP_NAMES = {1: 'converged', 2: 'time', 3: 'size', 4: 'itermax'}
 
@@ -26,21 +27,21 @@ class Trace(C.Structure):
                 ('ni', C.c_int64), ('no', C.c_int64), ('sum_in', C.c_double), ('sum_out', C.c_double)]
 
 
-def build(force=False):
+def build(force=False, omp=False):
     src = os.path.join(HERE, 'vrg_oracle.c')
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        subprocess.check_call(['make', '-C', HERE, '-s', 'libvrg_oracle.so'])
-    return LIB
+    out = LIB_OMP if omp else LIB
+    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', HERE, '-s', os.path.basename(out)])
+    return out
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
+def lib(omp=False):
+    _lib = _libs.get(bool(omp))
     if _lib is None:
-        build()
-        L = C.CDLL(LIB)
+        L = C.CDLL(build(omp=omp))
         L.vrgo_create.restype = C.c_void_p
         L.vrgo_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int]
         L.vrgo_destroy.argtypes = [C.c_void_p]
@@ -55,7 +56,9 @@ def lib():
         L.vrgo_get_segmented.argtypes = [C.c_void_p, C.c_void_p]
         L.vrgo_get_band.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vrgo_get_trace.argtypes = [C.c_void_p, C.c_void_p]
-        _lib = L
+        L.vrgo_set_threads.argtypes = [C.c_int]
+        L.vrgo_set_threads.restype = C.c_int
+        _lib = _libs[bool(omp)] = L
     return _lib
 
 
@@ -63,11 +66,11 @@ class Oracle:
     """Stateful handle: init() then step()/run(); arrays are exchanged in the reference's
     [x][y][z] C order ("lex" indices)."""
 
-    def __init__(self, dataArray, valueMap, H=2.25, density_mode=0):
+    def __init__(self, dataArray, valueMap, H=2.25, density_mode=0, omp=False):
         self.shape = tuple(int(s) for s in dataArray.shape)
         data = np.ascontiguousarray(dataArray, dtype=np.float64)
         lab = np.ascontiguousarray(valueMap, dtype=np.uint8)
-        self._L = lib()
+        self._L = lib(omp)
         self._h = self._L.vrgo_create(*self.shape, data.ctypes.data, lab.ctypes.data, float(H), int(density_mode))
         if not self._h:
             raise MemoryError('vrgo_create failed')
@@ -79,6 +82,10 @@ class Oracle:
             self._h = None
 
     __del__ = close
+
+    def set_threads(self, n):
+        """Threads of the dense loops (all-cores build, omp=True); returns the number in effect."""
+        return self._L.vrgo_set_threads(int(n))
 
     def init(self):
         rc = self._L.vrgo_init(self._h)

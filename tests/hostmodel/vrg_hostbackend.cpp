@@ -189,8 +189,10 @@ void be_sweep_once(const VrgCtx& c, int variant, VrgEvents*, be_reduce_fn cb, vo
     }
     vrg_request_dense(c);
     vrg_post_apply(c);
-    dense_stats(c, lab, cb, user);          // the dense recount (:113-116) ...
-    vrg_dense_fin(c);                       // ... cross-checks the incremental sizes and files the sums
+    if (!(variant & 4)) {
+        dense_stats(c, lab, cb, user);      // the dense recount (:113-116) ...
+        vrg_dense_fin(c);                   // ... cross-checks the incremental sizes and files the sums
+    }
     // band bookkeeping
     for (uint32_t e = 0; e < n; e++) vrg_item_entry_post(c, e);
     s.nnz = 0;

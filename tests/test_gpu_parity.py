@@ -98,36 +98,42 @@ def test_config1_against_reference_trace(lib, golden_loader):
 
 
 def test_random_volumes(lib):
-    sweeps = 0
+    sweeps = done = 0
     for sd in range(120):
         I, vm, H, variant, dmode = random_case(sd)
         res, k = parity.run_stepwise(lib, I, vm, H, None, 40, density_mode=dmode, check_hist=True,
                                      options={'sweep_variant': variant})
         sweeps += k
+        done += res is not None
     for sd in range(5000, 5030):
         I, vm, H, variant, dmode = random_case(sd, 8, 26)
         res, k = parity.run_stepwise(lib, I, vm, H, None, 30, density_mode=1, check_hist=True,
                                      options={'sweep_variant': variant})
         sweeps += k
+        done += res is not None
     assert sweeps > 500
+    assert done >= 140, 'too many cases cut short by an exact tie: {} of 150 completed'.format(done)
 
 
 def test_random_volumes_in_one_call(lib):
     """Same cases, but the whole run in ONE vrg_run call: sweeps are enqueued in batches without host
     synchronisation and the dense pass of sweep k overlaps the band kernels of sweep k+1."""
-    sweeps = 0
+    sweeps = done = 0
     for sd in range(300, 400):
         I, vm, H, variant, dmode = random_case(sd)
         res, k = parity.run_batched(lib, I, vm, H, None, 40, density_mode=dmode,
                                     options={'sweep_variant': variant, 'batch': 1 + sd % 7})
         sweeps += k
+        done += res is not None
     for sd in range(6000, 6020):
         I, vm, H, variant, dmode = random_case(sd, 8, 26)
         res, k = parity.run_batched(lib, I, vm, H, None, 30, density_mode=1,
                                     options={'sweep_variant': variant, 'batch': 8,
                                              'storage16': sd % 2, 'graph': (sd // 2) % 2})
         sweeps += k
+        done += res is not None
     assert sweeps > 400
+    assert done >= 110, 'too many cases cut short by an exact tie: {} of 120 completed'.format(done)
 
 
 def test_skip_rule_closure_is_race_free(lib):
@@ -256,6 +262,27 @@ def test_config2_size_properties(lib):
         for x, y in zip(s.band(w), s2.band(w)):
             assert np.array_equal(x, y)
     s.close(); s2.close()
+
+
+def test_config2_full_size_vs_oracle(lib):
+    """BASELINE configs[1] at FULL size: 512x512x170, 200 sweeps in ONE vrg_run call against the oracle (level mode,
+    ~1 min of CPU): final labels, both band list orders and densities, `segmented` order, the whole trace and the
+    incremental class histograms."""
+    from arterynetwork_amd import phantoms
+    data, vmap = phantoms.bench_volume((512, 512, 170), seed=2)
+    res, k = parity.run_batched(lib, data, vmap.astype(np.uint8), 2.25, None, 200, density_mode=1, options={'batch': 64})
+    assert res is not None and k == 200 and res.stop_reason == 4
+    assert res.nseg > 5000
+
+
+def test_config5_size_storage16():
+    """BASELINE configs[4] on the one GPU of the box: 1024^3 with 16-bit intensity storage.  Runs
+    tests/full_size_check.py --config5 in a fresh process: properties after 40 sweeps and bit-identity of labels,
+    `segmented` and trace with fp32 storage of the same volume."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'full_size_check.py'), '--config5'], capture_output=True, text=True)
+    assert out.returncode == 0 and 'CONFIG5 OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def _gpu_slab_worker(rank, world, port, sweeps, outdir):
