@@ -72,6 +72,7 @@ class VrgLib:
         self.get_band = fn('get_band', [p, C.c_int, p, p, p, C.c_int64, i64p])
         self.get_trace = fn('get_trace', [p, p, C.c_int64, i64p])
         self.get_levels = fn('get_levels', [p, p, p, p, p, p, C.c_int64, i64p])
+        self.get_stats = fn('get_stats', [p, i64p, C.c_int64])
         self.set_slab = fn('set_slab', [p, C.c_int64, C.c_int64])
         self.comm_unique_id = fn('comm_unique_id', [p])
         self.comm_init = fn('comm_init', [p, C.c_int, C.c_int, p])
@@ -236,6 +237,13 @@ class Session:
         out = np.zeros(n.value, TRACE_DTYPE)
         self._check(self.lib.get_trace(self._h, out.ctypes.data, n.value, C.byref(n)))
         return out
+
+    def stats(self):
+        """Diagnostics: how often a trip was handed back to the host and why, array capacities."""
+        a = (C.c_int64 * 8)()
+        self._check(self.lib.get_stats(self._h, a, 8))
+        return {'bail_flips': a[1], 'grow_marks': a[2], 'grow_pool': a[3], 'host_driven_trips': a[4],
+                'pool_capacity': a[5], 'mark_capacity': a[6], 'pool_slots': a[7]}
 
     def nlevels(self):
         """Number of distinct intensity values of the volume (after init)."""

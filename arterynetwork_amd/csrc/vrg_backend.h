@@ -4,9 +4,14 @@
 // same interface with sequential loops over the very same item functions (vrg_items.h) so that the
 // parallel restatement of the reference's sequential update() can be checked against the oracle
 // without a GPU; that model is test infrastructure and is never linked into the product library.
+//
+// Everything a backend keeps between calls - device, streams, events, RCCL communicator, first error - lives
+// in its VrgBackend object, one per handle: two handles (two volumes, two devices, two host threads) share nothing.
 #pragma once
 #include <stddef.h>
 #include "vrg_types.h"
+
+struct VrgBackend;             // opaque: defined by the backend
 
 struct VrgEvents {            // optional HIP-event timing of the dense sweep launches
     int enabled;
@@ -14,44 +19,57 @@ struct VrgEvents {            // optional HIP-event timing of the dense sweep la
     long long launches;
 };
 
-int be_set_device(int device);
-void be_set_tuning(const char* name, long long value);   // kernel launch knobs ("sweep_blocks")                 // 0 ok, <0 no usable device
-void* be_alloc(size_t bytes);
-void be_free(void* p);
-void be_fill(void* p, int byte, size_t bytes);
-void be_upload(void* dst, const void* src, size_t bytes);     // src may be host or device memory
-void be_download(void* dst, const void* src, size_t bytes);   // dst may be host or device memory
-void be_sync();
-const char* be_last_error();                   // first backend (HIP) failure since start-up, or nullptr
+VrgBackend* be_create(int device);                             // nullptr: no usable device
+void be_destroy(VrgBackend* b);
+void be_set_tuning(VrgBackend* b, const char* name, long long value);   // kernel launch knobs ("sweep_blocks", "prio_mode")
+void* be_alloc(VrgBackend* b, size_t bytes);
+void be_free(VrgBackend* b, void* p);
+void be_fill(VrgBackend* b, void* p, int byte, size_t bytes);
+void be_upload(VrgBackend* b, void* dst, const void* src, size_t bytes);     // src may be host or device memory
+void be_download(VrgBackend* b, void* dst, const void* src, size_t bytes);   // dst may be host or device memory
+void be_copy(VrgBackend* b, void* dst, const void* src, size_t bytes);       // device to device, stream-ordered
+void be_sync(VrgBackend* b);
+const char* be_last_error(VrgBackend* b);      // first backend (HIP / RCCL) failure of this handle, or nullptr
+void be_clear_error(VrgBackend* b);
 
-// repack caller arrays ([x][y][z] with element strides) into / out of the padded device layout
-int be_pack_volume(const VrgCtx& c, float* dstI, const void* src, int dtype, const int64_t st[3], int* inexact);
-int be_pack_labels(const VrgCtx& c, uint8_t* dst, const void* src, int dtype, const int64_t st[3], int* bad);
-int be_unpack_labels(const VrgCtx& c, const uint8_t* lab, void* dst, int dtype, const int64_t st[3]);
+// repack caller arrays ([x][y][z] with element strides) into / out of the padded device layout; dstI (fp32) or dstI64
+// *inexact: some value is not representable in fp32 (only written when dstI is given)
+int be_pack_volume(VrgBackend* b, const VrgCtx& c, float* dstI, double* dstI64, const void* src, int dtype, const int64_t st[3], int* inexact);
+int be_pack_labels(VrgBackend* b, const VrgCtx& c, uint8_t* dst, const void* src, int dtype, const int64_t st[3], int* bad);
+int be_unpack_labels(VrgBackend* b, const VrgCtx& c, const uint8_t* lab, void* dst, int dtype, const int64_t st[3]);
 
 // sorted distinct intensity values; allocates *lev (backend memory), returns the count in *L
-int be_build_levels(const VrgCtx& c, double** lev, uint32_t* L);
+int be_build_levels(VrgBackend* b, const VrgCtx& c, double** lev, uint32_t* L);
 
 // 16-bit storage: level index of every voxel (after be_build_levels), padded layout
-void be_build_lev16(const VrgCtx& c, uint16_t* dst);
+void be_build_lev16(VrgBackend* b, const VrgCtx& c, uint16_t* dst);
 
 // init mode (:129-155): labels by morphology + staged band entries; then order them and finish
-void be_init_band(const VrgCtx& c);
-void be_init_sort(const VrgCtx& c, uint32_t n_in, uint32_t n_out);   // keys -> b_idx[0] in list order
+void be_init_band(VrgBackend* b, const VrgCtx& c);
+void be_init_sort(VrgBackend* b, const VrgCtx& c, uint32_t n_in, uint32_t n_out);   // keys -> p_idx in list order
 typedef void (*be_reduce_fn)(double v[4], void* user);
-void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user);   // levels of entries, histograms, exact densities, region stats
+void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user);   // levels of entries, histograms, exact densities, region stats
 
-// one trip through the while-loop body (:58-117); a no-op once st->done is set
-void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb, void* user);
+// One trip through the while-loop body (:58-117); a no-op once st->done or st->bail is set.
+//   flags: VRG_SWEEP_FULL   the relabel stencil runs over every voxel instead of the marked ones (check variant)
+//          VRG_SWEEP_NODENSE  the dense recount is not launched (measurement aid)
+//          VRG_SWEEP_SYNC   host-driven trip: the backend synchronises after the decisions, may grow nothing itself,
+//                           but runs update() with device-wide kernels and sorts - any number of flips
+// Without VRG_SWEEP_SYNC the trip is two launches (k_band, k_sweep) and is enqueued without synchronising; k_sweep
+// hands a trip it cannot do in one workgroup back through st->bail.
+enum { VRG_SWEEP_FULL = 1, VRG_SWEEP_NODENSE = 4, VRG_SWEEP_SYNC = 8 };
+void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_reduce_fn cb, void* user);
+// flips one workgroup takes on (k_sweep); more -> VBAIL_FLIPS
+uint32_t be_small_flip_limit(VrgBackend* b);
 
 // RCCL communicator for the per-sweep all-reduce of the slab statistics (device backend only)
 int be_comm_unique_id(void* id128);
-int be_comm_init(int nranks, int rank, const void* id128);
+int be_comm_init(VrgBackend* b, int nranks, int rank, const void* id128);
 
 // fold the HIP-event pairs recorded since the last call into ev (only the first n_valid were real sweeps)
-void be_events_collect(VrgEvents* ev, long long n_valid);
+void be_events_collect(VrgBackend* b, VrgEvents* ev, long long n_valid);
 
 // dense recount of the class histograms (verification aid)
-void be_recount_hist(const VrgCtx& c, int par, int32_t* rin, int32_t* rout);
+void be_recount_hist(VrgBackend* b, const VrgCtx& c, int32_t* rin, int32_t* rout);
 // (stamp, idx) of every segmented voxel, unordered; returns the count
-uint32_t be_collect_segmented(const VrgCtx& c, int par, uint64_t* stamps, uint32_t* idxs, uint32_t cap);
+uint32_t be_collect_segmented(VrgBackend* b, const VrgCtx& c, uint64_t* stamps, uint32_t* idxs, uint32_t cap);

@@ -1,31 +1,33 @@
 // vrg_device.hip - the product backend: HIP kernels for MI355X (gfx950, wave64).
 //
-// One while-loop trip of variationalRegionGrowing.py:58-117 (be_sweep_once), two HIP streams:
-//   stream A, band kernels (O(band) work, grid-stride over device-resident counts, no host round trip):
-//     k_decide_exact (decide + listing; its second half: exact densities of the entries the previous sweep
-//        added, which it then decides) -> k_marks_prepass (stop tests, marks, skip-rule prepass)
-//     -> k_relabel (skip-rule fix-point; 3x3x3 / 5x5x5 label stencil on the marked voxels, old labels only)
-//     -> k_apply_entry_post (writes the new label bytes, keeps the region sizes and the class bits in step; its
-//        second half: per-entry survivor test and flip bookkeeping, fed by the relabel's per-entry result)
-//     -> k_levels_tab_scan (level-delta compaction, correction memo, first pass of the rebuild scan)
-//     -> k_scan_down -> k_scatter -> k_finalize closes the trip                                  (8 launches);
-//   stream B, the dense pass, forked after k_levels_tab_scan:
+// One while-loop trip of variationalRegionGrowing.py:58-117 (be_sweep_once) is FOUR launches on stream A (k_band, then
+// update() as k_order / k_mark_relabel / k_close, see there) plus the dense pass on stream B:
+//   k_band  (many workgroups, one thread per band-pool slot): adds the density corrections of the sweep before
+//           (:236-247) to the surviving entries, decides every entry (:79-88) and appends the flips to an unordered
+//           list; extra workgroups compute the exact densities (:252-255) of the entries the sweep before added
+//           (one wave per entry) and decide those.
+//   k_order -> k_mark_relabel -> k_close: update() (:156-259); a sweep with more flips than one workgroup should
+//           order in LDS (or one that needs larger arrays) is handed back untouched (VrgState::bail); the engine then
+//           drives such trips from the host (be_sweep_once with VRG_SWEEP_SYNC: the same item functions as
+//           device-wide kernels, rocPRIM sorts).
+//   stream B, the dense pass, forked after k_close:
 //     k_recount_bits : the dense kernel (every voxel, HBM-bound, read-only: 4 B intensity + 2 class bits per
 //        voxel): region sizes and intensity sums (:113-116, :249-250), reduced by its last workgroup, checked
 //        against the sizes the band side keeps by increments
 //     -> on several GPUs: slab all-reduce -> k_dense_fin (the same check on the totals, trace sums).
-//   Stream A does not join: it runs up to two sweeps ahead of the dense pass (two copies of the class bits; see
-//   be_sweep_once).
+//   Stream A does not join: it runs up to two sweeps ahead of the dense pass (two copies of the class bits).
 // Labels are updated IN PLACE: measured on MI355X, streaming I + labels read-only runs at 5.8-6.0 TB/s
 // while the same stream with a 1 B/voxel label write-back drops to 4.8 TB/s, so unchanged labels are
 // never rewritten.  (The full-stencil check variant relabels every voxel through lab[1].)
 // Every kernel starts by reading the device-resident VrgState and returns at once when the stop
 // flag is set, so the host can enqueue batches of sweeps without synchronising.
+// All state of the backend (device, streams, events, communicator, first error) lives in VrgBackend: one per handle.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -35,31 +37,38 @@
 #include "vrg_backend.h"
 #include "vrg_items.h"
 
-// a failed HIP call is remembered (first one wins) and reported by be_last_error(); the engine turns it into
-// VRG_E_INTERNAL at its next synchronisation point
-static char g_hip_error[256] = "";
-#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess && !g_hip_error[0]) { \
-    std::snprintf(g_hip_error, sizeof(g_hip_error), "HIP error '%s' in %s (%s:%d)", hipGetErrorString(e_), #x, __FILE__, __LINE__); \
-    std::fprintf(stderr, "%s\n", g_hip_error); } } while (0)
+struct EvPair { hipEvent_t a, b; };
+
+struct VrgBackend {
+    int device = 0;
+    hipStream_t sa = nullptr;            // stream A: the band kernels of every trip in program order, copies
+    hipStream_t sb = nullptr;            // stream B: the dense pass (recount, slab all-reduce, k_dense_fin); trails stream A by up to one sweep
+    int sweep_blocks = 0;                // 0 = auto (dense_blocks)
+    int prio_mode = 2;                   // the dense stream gets the higher priority (measured: -1..2 % step time)
+    uint32_t small_flips = 4096;         // flips per sweep k_order takes on (<= NF_SMALL)
+    ncclComm_t comm = nullptr;           // per-sweep all-reduce of the slab statistics (multi-GPU)
+    char err[256] = "";                  // first HIP / RCCL failure; the engine turns it into VRG_E_INTERNAL
+    std::vector<EvPair> ev_pool;
+    size_t ev_used = 0;
+    void* tmp = nullptr; size_t tmp_bytes = 0;        // scratch of the host-driven sorts
+    uint64_t* keys2 = nullptr; size_t keys2_n = 0;
+};
+
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess && !b->err[0]) { \
+    std::snprintf(b->err, sizeof(b->err), "HIP error '%s' in %s (%s:%d)", hipGetErrorString(e_), #x, __FILE__, __LINE__); \
+    std::fprintf(stderr, "%s\n", b->err); } } while (0)
 
 namespace {
 
 constexpr int TPB = 256;            // 4 waves of 64
-constexpr int ITEM_BLOCKS = 256;    // band kernels: 64 Ki threads, grid-stride
-constexpr int SCAN_BLOCKS = 256;
+constexpr int ITEM_BLOCKS = 256;    // item kernels: 64 Ki threads, grid-stride
+constexpr int EXACT_BLOCKS = 128;   // k_band: workgroups for the exact densities (512 waves)
 constexpr int SWEEP_BLOCKS = 256;   // 1 workgroup (4 waves) per CU, each wave with 3 KiB of labels + 12 KiB of intensities in
                                     // flight: measured best for the HBM-bound recount while stream B's band kernels run beside
                                     // it (880x880x640: 256 -> 0.38 ms, 192/384 -> 0.42-0.43, 320 -> 0.49, 512 -> 0.40, 1024 -> 0.44)
-
-hipStream_t g_stream = nullptr;      // stream A: the band kernels of every trip in program order, copies
-hipStream_t g_stream_b = nullptr;    // stream B: the dense pass (recount, slab all-reduce, k_dense_fin); trails stream A by up to one sweep
-hipEvent_t g_ev_a = nullptr, g_ev_d[2] = {nullptr, nullptr};   // labels applied (A -> B) / class copy read by the dense pass (B -> A)
-hipEvent_t g_read[2] = {nullptr, nullptr};       // the "class copy read" events of the last two dense passes, by trip parity
-unsigned long long g_trip = 0;
-int g_sweep_blocks = 0;              // 0 = auto (dense_blocks)
-int g_prio_mode = 2;                 // the dense stream gets the higher priority (measured: -1..2 % step time)
-int g_use_graph_req = 0;
-ncclComm_t g_comm = nullptr;          // per-sweep all-reduce of the slab statistics (multi-GPU)
+constexpr uint32_t NF_SMALL = 4096; // flips one workgroup sorts in LDS
+constexpr uint32_t NZ_LDS = 1024;   // touched levels k_band keeps in LDS
+constexpr int KS_THREADS = 1024;    // k_close, k_fix: one big workgroup
 
 // ---- wave / block primitives (wave = 64 lanes) -------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
@@ -88,209 +97,16 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
     return base + inc - v;
 }
 
-// ---- item kernels ---------------------------------------------------------------------------------
+
 #define ITEM_LOOP(n) for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += gridDim.x * blockDim.x)
-// the same over the first `g` workgroups of a grid whose other workgroups do something else
-#define ITEM_LOOP_G(n, g) for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += (g) * blockDim.x)
 // same with a 64-bit item index: (listed flips) x (positions) can exceed 2^32 on adversarial volumes
 #define ITEM_LOOP64(n) for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += (uint64_t)gridDim.x * blockDim.x)
 
-__device__ void exact_wave(const VrgCtx& c, int par, uint32_t nfresh, uint32_t wid, uint32_t nw, bool then_decide);
-// decide (:79-88) + listing of the flips - and, in the second half of the grid, the exact densities of the entries
-// that (re-)entered the band in the sweep just closed (:252-255), one wave per entry, each of which is decided by
-// that wave as soon as its densities exist (the first half skips entries whose densities are still pending).
-// The closed sweep's k_exact launch is gone from the chain.
-__global__ void k_decide_exact(VrgCtx c) {
-    if (c.st->done) return;
-    if (blockIdx.x < ITEM_BLOCKS) { ITEM_LOOP_G(c.st->ni + c.st->no, ITEM_BLOCKS) vrg_item_decide(c, i, c.st->nfx != 0); return; }
-    const uint32_t nfx = c.st->nfx;
-    const uint32_t wid = ((blockIdx.x - ITEM_BLOCKS) * blockDim.x + threadIdx.x) >> 6, nw = (ITEM_BLOCKS * blockDim.x) >> 6;
-    exact_wave(c, c.st->iter & 1, nfx, wid, nw, true);
-}
-// stop tests (:91-104) once all entries have decided, then per listed flip: 125 mark positions + prepass
-__global__ void k_marks_prepass(VrgCtx c) {
-    if (c.st->done) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) c.st->nfx = 0;     // k_decide_exact has computed them
-    int32_t stop = vrg_stop_test(c);
-    if (stop || c.st->error) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) c.st->done = stop ? stop : -1;
-        return;
-    }
-    ITEM_LOOP64((uint64_t)c.st->nf * 128u) {
-        uint32_t r = (uint32_t)(i >> 7), p = (uint32_t)(i & 127u);
-        if (p < 125u) vrg_item_scatter_marks(c, r, p);
-        else if (p == 125u) vrg_item_prepass(c, r);
-    }
-}
-// skip-rule fix-point as a kernel of its own (one workgroup): only the full-stencil check variant launches it
-__global__ void k_fix(VrgCtx c) {
-    if (c.st->done) return;
-    __shared__ int changed;
-    uint32_t np = c.st->npend;
-    if (np == 0) return;
-    for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) changed = 0;
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < np; j += blockDim.x)
-            if (vrg_item_fix(c, j) == 2) changed = 1;
-        __threadfence();
-        __syncthreads();
-        if (!changed) break;
-    }
-}
-// Skip-rule fix-point first (rare: only when a flip-in dropped to 3 in phase A, npend > 0).  It is a monotone
-// closure (P bits are only ever set) over facts the previous kernel left behind, so EVERY workgroup computes all
-// of it by itself - the same bits, set with atomic ORs - instead of one workgroup in a kernel of its own that the
-// common case (npend == 0) would pay a launch for.  A workgroup is done after a pass in which it neither applied
-// anything NOR saw a bit that it had not seen the pass before (another workgroup may set an entry between this
-// one's look at a dependent entry and its look at the entry itself; the per-thread count of set entries catches
-// that).  Then the relabel stencil of the marked voxels.
-__global__ void k_relabel(VrgCtx c) {
-    if (c.st->done) return;
-    const uint32_t np = c.st->npend;
-    if (np) {
-        __shared__ int changed;
-        uint32_t seen_before = 0;
-        for (;;) {
-            __syncthreads();
-            if (threadIdx.x == 0) changed = 0;
-            __syncthreads();
-            uint32_t seen = 0; bool mine = false;
-            for (uint32_t j = threadIdx.x; j < np; j += blockDim.x) {
-                const int r = vrg_item_fix(c, j);
-                seen += r != 0; mine |= r == 2;
-            }
-            if (mine || seen != seen_before) changed = 1;
-            seen_before = seen;
-            __threadfence();
-            __syncthreads();
-            if (!changed) break;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // the stencil below reads the P bits with plain loads
-    }
-    ITEM_LOOP(min(c.st->nmk, c.mcap)) vrg_item_relabel(c, i);
-}
-// k_apply + k_entry_post in one launch: the survivor test of an entry takes its voxel's new byte from the relabel
-// (e_new) or, for a voxel the relabel did not visit, from the label it keeps - so it does not wait for the bytes
-// being written.  First half of the grid: write the new label bytes (+ the class changes of the sweep before into
-// this sweep's class copy, see VrgCtx::clsb); second half: per old band entry, survivor test and flip bookkeeping.
-__global__ void k_apply_entry_post(VrgCtx c) {
-    if (c.st->done) return;
-    if (blockIdx.x < ITEM_BLOCKS) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) vrg_request_dense(c);
-        const uint32_t nm = min(c.st->nmk, c.mcap);
-        ITEM_LOOP_G(nm + vrg_catchup_count(c), ITEM_BLOCKS) { if (i < nm) vrg_item_apply(c, i); else vrg_item_catchup(c, i - nm); }
-        return;
-    }
-    for (uint32_t i = (blockIdx.x - ITEM_BLOCKS) * blockDim.x + threadIdx.x, n = c.st->ni + c.st->no; i < n; i += ITEM_BLOCKS * blockDim.x)
-        vrg_item_entry_post(c, i);
-}
-__global__ void k_dense_fin(VrgCtx c) { vrg_dense_fin(c); }
-__global__ void k_entry_post(VrgCtx c) {               // full-stencil check variant: after k_copy_back
-    if (c.st->done) return;
-    ITEM_LOOP(c.st->ni + c.st->no) vrg_item_entry_post(c, i);
-}
-__global__ void k_scatter(VrgCtx c) {                  // items: every old entry, then (listed flip, neighbour k)
-    if (c.st->done) return;
-    const uint32_t n = c.st->ni + c.st->no;
-    ITEM_LOOP64((uint64_t)n + (uint64_t)c.st->nf * 32u) {
-        if (i < n) vrg_item_scatter_entry(c, (uint32_t)i);
-        else { uint64_t j = i - n; vrg_item_scatter_promo(c, (uint32_t)(j >> 5), (uint32_t)(j & 31u)); }
-    }
-}
-
-// level-delta compaction (:232-235 regrouped by distinct intensity value)
-__global__ void k_delta_flag(VrgCtx c) {
-    if (c.st->done) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) vrg_post_apply(c);
-    const uint32_t off = vrg_delta_off(c);
-    ITEM_LOOP(c.L) c.lscan[i] = (c.dIn[off + i] | c.dOut[off + i] | c.dConv[off + i]) ? 1u : 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) c.st->nscan = c.L;
-}
-__global__ void k_delta_scatter(VrgCtx c) {
-    if (c.st->done) return;
-    const uint32_t off = vrg_delta_off(c);
-    ITEM_LOOP(c.L) {
-        uint32_t a = c.dIn[off + i], b = c.dOut[off + i], d = c.dConv[off + i];
-        if (a | b | d) {
-            uint32_t j = c.lscan[i];
-            c.nz_lev[j] = i; c.nz_val[j] = c.lev[i]; c.nz_cin[j] = a; c.nz_cout[j] = b; c.nz_cconv[j] = d;
-            c.hout[i] += (int32_t)d;                 // included voxels join the outer region
-            c.dIn[off + i] = 0; c.dOut[off + i] = 0; c.dConv[off + i] = 0;
-        }
-    }
-}
-__global__ void k_post_prep(VrgCtx c) {               // after the level scan, before the rebuild scan
-    if (c.st->done) return;
-    VrgState& s = *c.st;
-    uint32_t n = s.ni + s.no;
-    s.nnz = s.scan_total;
-    s.use_tab = c.L <= n;
-    s.ncnt = 3 * n;
-    s.nscan = s.ncnt;
-}
-// the four kernels above in ONE workgroup when the level table is small (the common, quantised case):
-// ordered compaction of the touched levels by tiles of 1024 + the k_post_prep bookkeeping
-constexpr uint32_t LEVELS_ONEBLOCK = 32768;
-__global__ void __launch_bounds__(1024) k_levels_small(VrgCtx c) {
-    if (c.st->done) return;
-    if (threadIdx.x == 0) vrg_post_apply(c);
-    __shared__ uint32_t sh[16];
-    __shared__ uint32_t sh_run;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t off = vrg_delta_off(c);
-    if (threadIdx.x == 0) sh_run = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < c.L; base += 1024) {
-        uint32_t l = base + threadIdx.x;
-        uint32_t a = 0, b = 0, d = 0;
-        if (l < c.L) { a = c.dIn[off + l]; b = c.dOut[off + l]; d = c.dConv[off + l]; }
-        uint32_t f = (a | b | d) ? 1u : 0u;
-        uint32_t inc = wave_incl_scan(f);
-        if (lane == 63) sh[w] = inc;
-        __syncthreads();
-        uint32_t pos = sh_run, tot = 0;
-        for (int i = 0; i < 16; i++) { if (i < w) pos += sh[i]; tot += sh[i]; }
-        if (f) {
-            uint32_t j = pos + inc - 1;
-            c.nz_lev[j] = l; c.nz_val[j] = c.lev[l]; c.nz_cin[j] = a; c.nz_cout[j] = b; c.nz_cconv[j] = d;
-            c.hout[l] += (int32_t)d;                 // included voxels join the outer region
-            c.dIn[off + l] = 0; c.dOut[off + l] = 0; c.dConv[off + l] = 0;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) sh_run += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        VrgState& s = *c.st;
-        uint32_t n = s.ni + s.no;
-        s.nnz = sh_run;
-        s.use_tab = c.L <= n;
-        s.ncnt = 3 * n;
-        s.nscan = s.ncnt;
-    }
-}
-// per-level memo of the three density corrections: one wave per level
-__global__ void k_tab(VrgCtx c) {
-    if (c.st->done || !c.st->use_tab) return;
-    uint32_t nnz = c.st->nnz;
-    int lane = threadIdx.x & 63;
-    uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t l = wid; l < c.L; l += nw) {
-        double v = c.lev[l], a = 0, b = 0, d = 0;
-        for (uint32_t i = lane; i < nnz; i += 64) {
-            double k = vrg_kern(c, c.nz_val[i] - v);
-            a += (double)c.nz_cin[i] * k; b += (double)c.nz_cout[i] * k; d += (double)c.nz_cconv[i] * k;
-        }
-        a = wave_sum(a); b = wave_sum(b); d = wave_sum(d);
-        if (lane == 0) { c.tabC[3 * (size_t)l] = a; c.tabC[3 * (size_t)l + 1] = b; c.tabC[3 * (size_t)l + 2] = d; }
-    }
-}
-// exact densities (:152-155, :252-255): one wave per fresh entry, lanes stride over the levels.  The level table
+// ---- k_band -----------------------------------------------------------------------------------------------
+// exact densities (:152-155, :252-255): one wave per pending slot, lanes stride over the levels.  The level table
 // (the same for every entry) is fetched first, four levels per lane at a time, so that it travels together with
-// the entry's own look-ups instead of behind them.
-__device__ void exact_wave(const VrgCtx& c, int par, uint32_t nfresh, uint32_t wid, uint32_t nw, bool then_decide) {
+// the entry's own look-ups instead of behind them.  The wave that computed an entry's densities decides it.
+__device__ void exact_wave(const VrgCtx& c, const VrgState& s, uint32_t nfresh, uint32_t wid, uint32_t nw, bool then_decide) {
     const int lane = threadIdx.x & 63;
     if (wid >= nfresh) return;
     int32_t ha[4], hb[4]; double lv[4];
@@ -301,8 +117,8 @@ __device__ void exact_wave(const VrgCtx& c, int par, uint32_t nfresh, uint32_t w
         ha[q] = in ? c.hin[l] : 0; hb[q] = in ? c.hout[l] : 0; lv[q] = in ? c.lev[l] : 0.0;
     }
     for (uint32_t f = wid; f < nfresh; f += nw) {
-        uint32_t pos = c.fresh[f];
-        double v = c.lev[c.b_lev[par][pos]], si = 0, so = 0;
+        const uint32_t slot = c.fresh[f];
+        double v = c.lev[c.p_lev[slot]], si = 0, so = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (!(ha[q] | hb[q])) continue;
@@ -310,169 +126,433 @@ __device__ void exact_wave(const VrgCtx& c, int par, uint32_t nfresh, uint32_t w
             si += (double)ha[q] * k; so += (double)hb[q] * k;
         }
         for (uint32_t l = lane + 256u; l < c.L; l += 64) {
-            int32_t a = c.hin[l], b = c.hout[l];
-            if (!(a | b)) continue;
+            int32_t a = c.hin[l], bb = c.hout[l];
+            if (!(a | bb)) continue;
             double k = vrg_kern(c, c.lev[l] - v);
-            si += (double)a * k; so += (double)b * k;
+            si += (double)a * k; so += (double)bb * k;
         }
         si = wave_sum(si); so = wave_sum(so);
         if (lane == 0) {
-            c.b_ip[par][pos] = si; c.b_op[par][pos] = so;
-            if (then_decide) {
-                const VrgState s = *c.st;
-                if (s.iter < s.iterMax) vrg_decide_core(c, s, pos, si, so);   // while iterNum <= iterMax (:58)
+            c.p_ip[slot] = si; c.p_op[slot] = so;        // (the pending flag is cleared by the slot's own thread in the other half)
+            if (then_decide && s.iter < s.iterMax) vrg_decide_core(c, s, slot, c.p_flag[slot] & PF_INNER, si, so);   // while iterNum <= iterMax (:58)
+        }
+    }
+}
+// First kernel of a trip.  Workgroups [0, BAND_BLOCKS): the pool slots - correction of the sweep before, then the sign
+// test; a flip is appended to the unordered flip list.  When the correction is evaluated entry by entry from the
+// touched-level list (staged in LDS when it fits), LPE lanes share one slot: each sums every LPE-th level (nnz f64
+// exp per entry is what this kernel costs), a fixed butterfly adds the partial sums.  With the per-level memo (or
+// nothing to correct) it is one thread per slot.  Workgroups [BAND_BLOCKS, +EXACT_BLOCKS): the exact densities of the
+// slots that (re-)entered the band in the sweep before, then their sign tests.
+constexpr int BAND_BLOCKS = 1024;
+constexpr int LPE = 8;
+__global__ void __launch_bounds__(TPB) k_band(VrgCtx c) {
+    const VrgState s = *c.st;                             // a copy (nf is only ever bumped atomically)
+    if (s.done || s.bail) return;
+    if (blockIdx.x >= BAND_BLOCKS) {
+        const uint32_t wid = ((blockIdx.x - BAND_BLOCKS) * TPB + threadIdx.x) >> 6, nw = (EXACT_BLOCKS * TPB) >> 6;
+        exact_wave(c, s, s.nfx, wid, nw, true);
+        return;
+    }
+    const bool direct = s.corr && !s.use_tab;
+    if (!direct) {
+        for (uint32_t slot = blockIdx.x * TPB + threadIdx.x; slot < s.np; slot += BAND_BLOCKS * TPB)
+            vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv);
+        return;
+    }
+    __shared__ double s_val[NZ_LDS];
+    __shared__ uint32_t s_cin[NZ_LDS], s_cout[NZ_LDS], s_cconv[NZ_LDS];
+    const double* nzv = c.nz_val; const uint32_t* nzi = c.nz_cin; const uint32_t* nzo = c.nz_cout; const uint32_t* nzc = c.nz_cconv;
+    if (s.nnz <= NZ_LDS) {
+        for (uint32_t j = threadIdx.x; j < s.nnz; j += TPB) { s_val[j] = c.nz_val[j]; s_cin[j] = c.nz_cin[j]; s_cout[j] = c.nz_cout[j]; s_cconv[j] = c.nz_cconv[j]; }
+        __syncthreads();
+        nzv = s_val; nzi = s_cin; nzo = s_cout; nzc = s_cconv;
+    }
+    const uint32_t sub = threadIdx.x & (LPE - 1);
+    const uint32_t np_pad = (s.np + (TPB / LPE) - 1) / (TPB / LPE) * (TPB / LPE);      // whole waves stay in the loop together
+    for (uint32_t slot = (blockIdx.x * TPB + threadIdx.x) / LPE; slot < np_pad; slot += BAND_BLOCKS * TPB / LPE) {
+        uint8_t fl = 0; double ip = 0, op = 0, v = 0;
+        const bool live = slot < s.np;
+        if (live) fl = c.p_flag[slot];
+        const bool work = live && (fl & PF_ALIVE) && !(fl & PF_PEND);
+        if (work) { ip = c.p_ip[slot]; op = c.p_op[slot]; v = c.lev[c.p_lev[slot]]; }
+        double a = 0, bb = 0, d = 0;
+        if (work)
+            for (uint32_t j = sub; j < s.nnz; j += LPE) {
+                const double k = vrg_kern(c, nzv[j] - v);
+                a += (double)nzi[j] * k; bb += (double)nzo[j] * k; d += (double)nzc[j] * k;
+            }
+#pragma unroll
+        for (int o = LPE / 2; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); bb += __shfl_xor(bb, o, 64); d += __shfl_xor(d, o, 64); }
+        if (sub == 0 && live) {
+            if ((fl & PF_ALIVE) && (fl & PF_PEND)) c.p_flag[slot] = (uint8_t)(fl & ~PF_PEND);   // decided by the exact half
+            else if (work) {
+                vrg_add_correction(a, bb, d, ip, op);
+                c.p_ip[slot] = ip; c.p_op[slot] = op;
+                if (s.iter < s.iterMax) vrg_decide_core(c, s, slot, fl & PF_INNER, ip, op);   // while iterNum <= iterMax (:58)
             }
         }
     }
 }
-__global__ void k_exact(VrgCtx c) {                   // init mode (:152-155): every band entry
-    const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-    exact_wave(c, 0, c.st->nfresh, wid, nw, false);
-}
-__global__ void k_finalize(VrgCtx c) {                // iterNum += 1 (:117) + trace record
-    VrgState s = *c.st;                               // one round trip for the whole state, one to write it back
-    if (s.done) return;
-    const int64_t n_in = c.inc[VC_NIN], n_out = c.inc[VC_NOUT];
-    s.ni = s.ni_new; s.no = s.nb_new - s.ni_new; s.iter++;
-    if ((uint32_t)s.iter < c.trace_cap) {
-        VrgTrace& t = c.trace[s.iter];                // the intensity sums are filed by the dense pass (vrg_dense_fin)
-        t.nflip = s.nf; t.nseg = n_in; t.n_in = n_in; t.n_out = n_out; t.ni = s.ni; t.no = s.no;
-    }
-    s.nf = 0; s.npend = 0; s.nmk = 0;
-    s.nfx = s.nfresh; s.nfresh = 0;                   // exact densities of the new entries: first thing next trip
-    if (s.error) s.done = -1;
-    *c.st = s;
-}
 
-// ---- device-wide exclusive scan of c-array `a` (length st->nscan), total -> st->scan_total ----------
-__device__ __forceinline__ void scan_range(uint32_t n, uint32_t& lo, uint32_t& hi) {
-    uint32_t chunk = (n + SCAN_BLOCKS - 1) / SCAN_BLOCKS;
-    chunk = (chunk + TPB - 1) / TPB * TPB;
-    lo = min(n, blockIdx.x * chunk); hi = min(n, lo + chunk);
-}
-__global__ void k_scan_reduce(VrgCtx c, uint32_t* a) {
-    if (c.st->done) return;
-    __shared__ uint32_t sh[4];
-    uint32_t lo, hi; scan_range(c.st->nscan, lo, hi);
-    uint32_t s = 0;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += TPB) s += a[i];
-    uint32_t tot; block_excl_scan(s, tot, sh);
-    if (threadIdx.x == 0) c.bsum[blockIdx.x] = tot;
-}
-// second pass: every workgroup adds up the partials before its own (256 values: one per thread), scans its chunk;
-// fin != 0: this is the rebuild scan - also derive the new list lengths (ni_new = scan value at the start of
-// segment B0 = number of entries of the new inner list)
-__global__ void k_scan_down(VrgCtx c, uint32_t* a, int fin) {
-    if (c.st->done) return;
-    __shared__ uint32_t sh[4];
-    __shared__ uint32_t sh_off;
-    VrgState& s = *c.st;
-    const uint32_t n = s.nscan;
-    uint32_t lo, hi; scan_range(n, lo, hi);
-    uint32_t gtot, gex = block_excl_scan(c.bsum[threadIdx.x], gtot, sh);
-    if (threadIdx.x == blockIdx.x) sh_off = gex;
-    __syncthreads();
-    uint32_t run = sh_off;
-    const uint32_t b0 = fin ? vrg_slot_B0(s, 0) : 0xffffffffu;
-    for (uint32_t base = lo; base < hi; base += TPB) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < hi ? a[i] : 0, tot;
-        uint32_t ex = block_excl_scan(v, tot, sh);
-        if (i < hi) {
-            a[i] = run + ex;
-            if (i == b0) s.ni_new = run + ex;
+// ---- sorting inside one workgroup -------------------------------------------------------------------------
+// ascending sort of n (key, value) pairs, keys distinct; n <= capacity of the arrays rounded up to a power of two
+// (LDS arrays, or global ones for the rare long list).  All threads of the workgroup call it.
+template <class K, class V>
+__device__ void wg_sort_pairs(K* key, V* val, uint32_t n, bool has_val) {
+    const uint32_t t = threadIdx.x, nt = blockDim.x;
+    if (n <= 128u) {                                      // by counting: rank = number of smaller keys; two barriers
+        K k = 0; V v = 0; uint32_t r = 0;
+        if (t < n) {
+            k = key[t]; if (has_val) v = val[t];
+            for (uint32_t j = 0; j < n; j++) r += key[j] < k;
         }
-        run += tot;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        s.scan_total = gtot;
-        if (fin) {
-            if (b0 >= n) s.ni_new = gtot;
-            s.nb_new = gtot;
-            if (gtot > c.bcap) { s.error = 1; s.done = -1; }
-        }
-    }
-}
-void device_scan(const VrgCtx& c, uint32_t* a, hipStream_t st, int fin) {
-    static_assert(SCAN_BLOCKS == TPB, "k_scan_down adds up one partial per thread");
-    k_scan_reduce<<<SCAN_BLOCKS, TPB, 0, st>>>(c, a);
-    k_scan_down<<<SCAN_BLOCKS, TPB, 0, st>>>(c, a, fin);
-}
-
-// k_levels_small + k_tab + the first pass of the rebuild scan in ONE launch, for level tables up to LT_MAX:
-//  * workgroups [0, ITEM_BLOCKS): each compacts the touched levels into LDS for itself (same ordered compaction,
-//    a few hundred levels), then its waves fill their share of the per-level correction memo from LDS; workgroup 0
-//    also publishes the compacted list, folds the included voxels into the outer histogram, sets the bookkeeping
-//    scalars and clears the delta counters of the OTHER parity (this sweep's are still being read by the rest);
-//  * workgroups [ITEM_BLOCKS, ITEM_BLOCKS + SCAN_BLOCKS): k_scan_reduce of the rebuild count array (3 n entries).
-// Two dependent launches fewer on the band chain.
-constexpr uint32_t LT_MAX = 2048;
-__global__ void __launch_bounds__(TPB) k_levels_tab_scan(VrgCtx c) {
-    if (c.st->done) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) vrg_post_apply(c);     // first kernel after the labels are applied
-    const uint32_t n = c.st->ni + c.st->no;
-    __shared__ uint32_t sh[4];
-    if (blockIdx.x >= ITEM_BLOCKS) {
-        const uint32_t b = blockIdx.x - ITEM_BLOCKS, n3 = 3u * n;
-        uint32_t chunk = (n3 + SCAN_BLOCKS - 1) / SCAN_BLOCKS;
-        chunk = (chunk + TPB - 1) / TPB * TPB;
-        const uint32_t lo = min(n3, b * chunk), hi = min(n3, lo + chunk);
-        uint32_t sum = 0;
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += TPB) sum += c.scan[i];
-        uint32_t tot; block_excl_scan(sum, tot, sh);
-        if (threadIdx.x == 0) c.bsum[b] = tot;
+        __syncthreads();
+        if (t < n) { key[r] = k; if (has_val) val[r] = v; }
+        __syncthreads();
         return;
     }
-    __shared__ double s_val[LT_MAX];
-    __shared__ uint32_t s_lev[LT_MAX], s_cin[LT_MAX], s_cout[LT_MAX], s_cconv[LT_MAX];
-    __shared__ uint32_t sh_run;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t off = vrg_delta_off(c);
-    if (threadIdx.x == 0) sh_run = 0;
+    uint32_t n2 = 1; while (n2 < n) n2 <<= 1;
+    for (uint32_t i = n + t; i < n2; i += nt) key[i] = ~(K)0;
     __syncthreads();
-    for (uint32_t base = 0; base < c.L; base += TPB) {
-        const uint32_t l = base + threadIdx.x;
-        uint32_t a = 0, bb = 0, d = 0;
-        if (l < c.L) { a = c.dIn[off + l]; bb = c.dOut[off + l]; d = c.dConv[off + l]; }
-        const uint32_t f = (a | bb | d) ? 1u : 0u;
-        const uint32_t inc = wave_incl_scan(f);
-        if (lane == 63) sh[w] = inc;
+    for (uint32_t k = 2; k <= n2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = t; i < n2; i += nt) {
+                const uint32_t x = i ^ j;
+                if (x > i) {
+                    const K a = key[i], bb = key[x];
+                    if ((a > bb) == ((i & k) == 0)) {
+                        key[i] = bb; key[x] = a;
+                        if (has_val) { const V va = val[i]; val[i] = val[x]; val[x] = va; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// ---- update() as three launches -----------------------------------------------------------------------------
+// What was measured on MI355X and shapes this (tools/latbench.hip, tools/icbench.hip, in-kernel phase stamps): a
+// dependent kernel boundary costs 2.3 us; a dependent global load 0.1 us (L2) to 0.4 us (HBM); code that runs once per
+// launch is fetched cold at ~30 ns per 64-B line; and ONE workgroup has four SIMDs - a whole update() inside one
+// workgroup took 67 us, nearly all of it instruction issue (the label stencil of ~1600 marked voxels on 4 SIMDs).  So the
+// per-voxel stencil runs on the whole chip, and only the steps that need to see every flip / every result - ordering
+// the flips, closing the sweep - are single workgroups with compact code:
+//   k_order        (1 workgroup)  stop tests (:91-104), flips sorted by list key in LDS = the reference's flip order
+//                                 (:88), L/P bits + stamps, skip-rule prepass and fix-point
+//   k_mark_relabel (chip-wide)    item = (flip, position of its 5x5x5 cube): the first marker of a voxel runs the label
+//                                 stencil for it from the OLD labels and appends (voxel, new byte) to the marked list;
+//                                 the stencil also files what the change means for the band pool, the class histograms
+//                                 and the sweep's level deltas
+//   k_close        (workgroup 0)  new label bytes in place (+ class bits, region sizes), dead slots onto the free list,
+//                                 touched levels sorted, iterNum += 1, trace record;
+//                  (workgroups 1..) per-level memo of the density corrections for the next k_band, one wave per level
+// ---- the two edges between the streams, kept on the device -------------------------------------------------
+// (a host event wait / record is a barrier packet of several microseconds in the stream; both conditions are almost
+// always true already, so one thread looks at a word instead.)  Spins are bounded: a wait that does not end within
+// SPIN_LIMIT raises an error instead of hanging the queue.
+constexpr unsigned long long SPIN_LIMIT = 300000000ull;    // wall_clock64 ticks (100 MHz): 3 s
+// band side, before the labels of sweep k are written into class copy k & 1: the dense pass k-2 has read that copy
+__device__ __forceinline__ void wait_dense_read(const VrgCtx& c) {
+    const int64_t need = (int64_t)c.st->iter + 1 - 2;
+    if (need <= 0 || vrg_load_i64(&c.dctl[VD_SEQ]) >= need) return;
+    const unsigned long long t0 = wall_clock64();
+    while (vrg_load_i64(&c.dctl[VD_SEQ]) < need) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > SPIN_LIMIT) { c.st->error = 9; return; }
+    }
+}
+// dense side, in front of every recount: a sweep has been applied since the last pass (or the run has stopped)
+__global__ void k_gate(VrgCtx c) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        if (vrg_load_i64(&c.inc[VC_REQ]) > vrg_load_i64(&c.dctl[VD_SEQ])) return;
+        if (vrg_load_i32(&c.st->done) || vrg_load_i32(&c.st->bail) || vrg_load_i32(&c.st->error)) {
+            (void)vrg_load_i64(&c.inc[VC_REQ]);     // (the last applied sweep's request is older than the stop flag: the recount itself re-checks)
+            return;
+        }
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > SPIN_LIMIT) { c.dctl[VD_ERR] = 10; return; }
+    }
+}
+__global__ void k_wait_dense(VrgCtx c) { if (threadIdx.x == 0) wait_dense_read(c); }
+
+constexpr int KO_THREADS = 256;
+constexpr int TAB_BLOCKS = 64;
+constexpr uint32_t NZ_SORT = 2048;  // touched levels one workgroup sorts in LDS
+
+__global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_limit) {
+
+    __shared__ uint64_t s_key[NF_SMALL];
+    __shared__ uint32_t s_slot[NF_SMALL];
+    __shared__ int s_go, s_changed;
+    constexpr uint32_t T = KO_THREADS;
+    const uint32_t t = threadIdx.x;
+    if (c.st->done || c.st->bail) return;
+    if (t == 0) {
+        int go = 1;
+        const int32_t stop = vrg_stop_test(c);                           // :91-104, in the reference's order
+        if (stop || c.st->error) { c.st->done = stop ? stop : -1; vrg_close_without_update(c); go = 0; }
+        else {
+            const uint32_t nf = c.st->nf;
+            const int32_t bail = nf > small_limit ? (int32_t)VBAIL_FLIPS : vrg_capacity_test(c, nf);
+            if (bail) { c.st->bail = bail; vrg_close_without_update(c); go = 0; }
+        }
+        s_go = go;
+    }
+    __syncthreads();
+    if (!s_go) return;
+    const uint32_t nf = c.st->nf;
+    for (uint32_t j = t, n = c.st->nnz; j < n; j += T) vrg_item_level_clear(c, j);   // level counters of the sweep before
+    for (uint32_t q = t; q < nf; q += T) { const uint32_t slot = c.flist[q]; s_key[q] = vrg_flip_key(c, slot); s_slot[q] = slot; }
+    __syncthreads();
+    if (t == 0) vrg_open_update(c);
+    wg_sort_pairs(s_key, s_slot, nf, true);
+    for (uint32_t r = t; r < nf; r += T) { c.f_slot[r] = s_slot[r]; vrg_item_list(c, r); }   // L (+P) bits, stamps
+    __syncthreads();
+    for (uint32_t r = t; r < nf; r += T) vrg_item_prepass(c, r);         // phase-A label of the flip-ins
+    __syncthreads();
+    const uint32_t np_ = vrg_load_u32(&c.st->npend);
+    if (np_) {                                                           // skip-rule fix-point (rare)
+        for (;;) {
+            __syncthreads();
+            if (t == 0) s_changed = 0;
+            __syncthreads();
+            for (uint32_t j = t; j < np_; j += T) if (vrg_item_fix(c, j) == 2) s_changed = 1;
+            __syncthreads();
+            if (!s_changed) break;
+        }
+    }
+}
+
+constexpr uint32_t LEV_LDS = 2048;  // level values a workgroup of k_mark_relabel keeps in LDS
+__global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
+    if (cg.st->done || cg.st->bail) return;
+    const uint32_t nf = cg.st->nf, lane = threadIdx.x & 63;
+    const uint64_t n = (uint64_t)nf * 128u;
+    if ((uint64_t)blockIdx.x * TPB >= n) return;                          // (no item for this workgroup)
+    // a voxel that enters the band needs the level index of its intensity: a binary search, i.e. log2(L) DEPENDENT loads -
+    // from LDS when the table fits
+    __shared__ double s_lev[LEV_LDS];
+    __shared__ uint32_t s_n[3], s_base[3];                                // this workgroup's new / dead / pending events
+    __shared__ int32_t s_d[2];                                            // ... and list length changes
+    VrgCtx c = cg;
+    if (cg.L <= LEV_LDS && !cg.lev16) {
+        for (uint32_t l = threadIdx.x; l < cg.L; l += TPB) s_lev[l] = cg.lev[l];
+        c.lev = s_lev;
+    }
+    uint8_t* lab = c.lab[0];
+    // (every thread of the workgroup makes the same number of trips: the commit below needs its barriers)
+    for (uint64_t base = (uint64_t)blockIdx.x * TPB; base < n; base += (uint64_t)gridDim.x * TPB) {
+        if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
+        if (threadIdx.x < 2) s_d[threadIdx.x] = 0;
         __syncthreads();
-        uint32_t pos = sh_run, tot = 0;
-        for (int i = 0; i < 4; i++) { if (i < w) pos += sh[i]; tot += sh[i]; }
-        if (f) {
-            const uint32_t j = pos + inc - 1;
-            s_lev[j] = l; s_val[j] = c.lev[l]; s_cin[j] = a; s_cout[j] = bb; s_cconv[j] = d;
+        const uint64_t i = base + threadIdx.x;
+        const uint32_t r = (uint32_t)(i >> 7), p = (uint32_t)(i & 127u);
+        int64_t m = 0; uint8_t mb = VB_OOB;
+        if (i < n && p < 125u) { m = vrg_mark_pos(c, c.f_idx[r], p); mb = lab[m]; }
+        const bool first = vrg_mark_wanted(p, mb) && vrg_mark_set(c, m);
+        // one reservation in the marked list per wave (every first marker of the chip bumping the same word would
+        // serialise in L2)
+        const unsigned long long fm = __ballot(first);
+        uint32_t q = 0;
+        if (fm) {
+            const int leader = __ffsll((long long)fm) - 1;
+            uint32_t b0 = 0;
+            if ((int)lane == leader) b0 = vrg_atomic_add(&c.st->nmk, (uint32_t)__popcll(fm));
+            q = __shfl(b0, leader, 64) + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+        }
+        VrgEvent ev; ev.kind = VE_NONE; ev.pend = 0;
+        uint32_t rn = 0, rd = 0, rf = 0;
+        if (first) {
+            const uint8_t nw = vrg_sweep_core(c, lab, (uint32_t)m, mb, ev);   // (L / P bits date from k_order: mb is current)
+            if (q < c.mcap) { c.mk_idx[q] = (uint32_t)m; c.mk_new[q] = nw; } else c.st->error = 4;
+            // its event takes a number inside the workgroup ...
+            if (ev.kind == VE_NEW) rn = atomicAdd(&s_n[0], 1u);
+            if (ev.kind == VE_DIE) rd = atomicAdd(&s_n[1], 1u);
+            if (ev.kind != VE_NONE && ev.kind != VE_DIE && ev.pend) rf = atomicAdd(&s_n[2], 1u);
+            const int di = vrg_ev_dni(ev), dq = vrg_ev_dno(ev);
+            if (di) atomicAdd(&s_d[0], di);
+            if (dq) atomicAdd(&s_d[1], dq);
         }
         __syncthreads();
-        if (threadIdx.x == 0) sh_run += tot;
+        // ... the workgroup reserves its stretch of every list with ONE atomic each ...
+        if (threadIdx.x < 3 && s_n[threadIdx.x])
+            s_base[threadIdx.x] = vrg_atomic_add(threadIdx.x == 0 ? &c.st->nalloc : threadIdx.x == 1 ? &c.st->ndead : &c.st->nfresh, s_n[threadIdx.x]);
+        if (threadIdx.x >= 4 && threadIdx.x < 6 && s_d[threadIdx.x - 4]) vrg_atomic_add(threadIdx.x == 4 ? &c.st->d_ni : &c.st->d_no, s_d[threadIdx.x - 4]);
+        __syncthreads();
+        // ... and every event is written at its place
+        if (ev.kind != VE_NONE) vrg_ev_write(c, (uint32_t)m, ev, s_base[0] + rn, s_base[1] + rd, s_base[2] + rf);
         __syncthreads();
     }
-    const uint32_t nnz = sh_run;
-    const bool use_tab = c.L <= n;
-    if (blockIdx.x == 0) {
-        for (uint32_t j = threadIdx.x; j < nnz; j += TPB) {
-            const uint32_t l = s_lev[j];
-            c.nz_lev[j] = l; c.nz_val[j] = s_val[j]; c.nz_cin[j] = s_cin[j]; c.nz_cout[j] = s_cout[j]; c.nz_cconv[j] = s_cconv[j];
-            c.hout[l] += (int32_t)s_cconv[j];        // included voxels join the outer region
+}
+
+__global__ void __launch_bounds__(KS_THREADS) k_close(VrgCtx c, int dense_on) {
+    if (c.st->done || c.st->bail) return;
+    constexpr uint32_t T = KS_THREADS;
+    const uint32_t t = threadIdx.x;
+    __shared__ uint64_t s_key[NZ_SORT];
+    __shared__ double s_val[NZ_SORT];
+    __shared__ uint32_t s_cin[NZ_SORT], s_cout[NZ_SORT], s_cconv[NZ_SORT];
+    // (only fields that workgroup 0's vrg_finalize leaves alone are read here: late workgroups may start after it)
+    const uint32_t nnz = min(c.st->nnz, c.zcap);
+    const bool use_tab = nnz <= NZ_SORT && c.st->tab_ok;                 // fewer levels than entries: memoise per level
+    if (blockIdx.x > 0 && !use_tab) return;
+    // every workgroup: this sweep's touched levels in ascending order (a fixed summation order), with their counts
+    if (nnz <= NZ_SORT) {
+        for (uint32_t j = t; j < nnz; j += T) s_key[j] = c.nz_key[j];
+        __syncthreads();
+        wg_sort_pairs(s_key, (uint32_t*)nullptr, nnz, false);
+        for (uint32_t j = t; j < nnz; j += T) {
+            const uint32_t l = (uint32_t)s_key[j];
+            s_val[j] = c.lev[l]; s_cin[j] = c.dIn[l]; s_cout[j] = c.dOut[l]; s_cconv[j] = c.dConv[l];
         }
-        const uint32_t other = off ? 0u : c.L;       // next sweep's counters: nobody touches them during this kernel
-        for (uint32_t l = threadIdx.x; l < c.L; l += TPB) { c.dIn[other + l] = 0; c.dOut[other + l] = 0; c.dConv[other + l] = 0; }
-        if (threadIdx.x == 0) {
-            VrgState& s = *c.st;
-            s.nnz = nnz; s.use_tab = use_tab; s.ncnt = 3 * n; s.nscan = 3 * n;
-        }
+        __syncthreads();
     }
-    if (!use_tab) return;
-    const uint32_t wid = (blockIdx.x * TPB + threadIdx.x) >> 6, nw = (ITEM_BLOCKS * TPB) >> 6;
+    if (blockIdx.x > 0) {                                                // the memo: one wave per level
+        const uint32_t lane = t & 63, wid = ((blockIdx.x - 1) * T + t) >> 6, nw = (TAB_BLOCKS * T) >> 6;
+        for (uint32_t l = wid; l < c.L; l += nw) {
+            const double v = c.lev[l];
+            double a = 0, bb = 0, d = 0;
+            for (uint32_t j = lane; j < nnz; j += 64) {
+                const double k = vrg_kern(c, s_val[j] - v);
+                a += (double)s_cin[j] * k; bb += (double)s_cout[j] * k; d += (double)s_cconv[j] * k;
+            }
+            a = wave_sum(a); bb = wave_sum(bb); d = wave_sum(d);
+            if (lane == 0) { c.tabC[3 * (size_t)l] = a; c.tabC[3 * (size_t)l + 1] = bb; c.tabC[3 * (size_t)l + 2] = d; }
+        }
+        return;
+    }
+    // workgroup 0: new label bytes in place (+ class bits, region sizes, the class changes of the sweep before)
+    if (t == 0 && dense_on) wait_dense_read(c);
+    __syncthreads();
+    const uint32_t nmk = min(c.st->nmk, c.mcap), nf = c.st->nf;
+    for (uint32_t i = t; i < nmk; i += T) vrg_item_apply(c, i);
+    for (uint32_t i = t, nc = vrg_catchup_count(c); i < nc; i += T) vrg_item_catchup(c, i);
+    for (uint32_t r = t; r < nf; r += T) vrg_item_check_flip(c, r);
+    for (uint32_t j = t, nd = c.st->ndead; j < nd; j += T) vrg_item_free(c, j);
+    if (nnz <= NZ_SORT) {                                                // the ordered level list, for an entry-by-entry k_band
+        // (nz_key itself stays as it is: the other workgroups may still be reading it, and only the set matters later)
+        for (uint32_t j = t; j < nnz; j += T) { c.nz_val[j] = s_val[j]; c.nz_cin[j] = s_cin[j]; c.nz_cout[j] = s_cout[j]; c.nz_cconv[j] = s_cconv[j]; }
+    } else {                                                             // (rare: a long list is sorted in place in global memory)
+        __syncthreads();
+        wg_sort_pairs(c.nz_key, (uint32_t*)nullptr, nnz, false);
+        __syncthreads();
+        for (uint32_t j = t; j < nnz; j += T) vrg_item_level(c, j, false);
+    }
+    __syncthreads();
+    if (t == 0) { vrg_post_apply(c); vrg_request_dense(c); vrg_finalize(c, use_tab); }
+}
+
+// ---- the same update() as device-wide kernels (host-driven trips: any number of flips) ------------------------
+__global__ void __launch_bounds__(TPB) k_trip_open(VrgCtx c) {   // stop tests and capacity test; opens update() (one workgroup)
+    __shared__ int s_go;
+    if (c.st->done || c.st->bail) return;
+    if (threadIdx.x == 0) {
+        int go = 1;
+        const int32_t stop = vrg_stop_test(c);
+        if (stop || c.st->error) { c.st->done = stop ? stop : -1; vrg_close_without_update(c); go = 0; }
+        else {
+            const int32_t bail = vrg_capacity_test(c, c.st->nf);
+            if (bail) { c.st->bail = bail; vrg_close_without_update(c); go = 0; }
+        }
+        s_go = go;
+    }
+    __syncthreads();
+    if (!s_go) return;
+    for (uint32_t j = threadIdx.x, n = c.st->nnz; j < n; j += TPB) vrg_item_level_clear(c, j);   // level counters of the sweep before
+    __syncthreads();
+    if (threadIdx.x == 0) vrg_open_update(c);
+}
+__global__ void k_flip_keys(VrgCtx c, uint32_t nf) { ITEM_LOOP(nf) c.f_key[i] = vrg_flip_key(c, c.flist[i]); }
+__global__ void k_list(VrgCtx c, uint32_t nf) { ITEM_LOOP(nf) vrg_item_list(c, i); }
+__global__ void k_marks_prepass(VrgCtx c, uint32_t nf) {
+    ITEM_LOOP64((uint64_t)nf * 128u) {
+        uint32_t r = (uint32_t)(i >> 7), p = (uint32_t)(i & 127u);
+        if (p < 125u) vrg_item_scatter_marks(c, r, p);
+        else if (p == 125u) vrg_item_prepass(c, r);
+    }
+}
+__global__ void k_prepass(VrgCtx c, uint32_t nf) { ITEM_LOOP(nf) vrg_item_prepass(c, i); }
+__global__ void __launch_bounds__(KS_THREADS) k_fix(VrgCtx c) {   // skip-rule fix-point, one workgroup
+    __shared__ int changed;
+    const uint32_t np_ = c.st->npend;
+    if (np_ == 0) return;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < np_; j += blockDim.x)
+            if (vrg_item_fix(c, j) == 2) changed = 1;
+        __syncthreads();
+        if (!changed) break;
+    }
+}
+__global__ void k_relabel(VrgCtx c) { ITEM_LOOP(min(c.st->nmk, c.mcap)) vrg_item_relabel(c, i); }
+__global__ void k_apply(VrgCtx c) {
+    const uint32_t nm = min(c.st->nmk, c.mcap);
+    ITEM_LOOP(nm + vrg_catchup_count(c)) { if (i < nm) vrg_item_apply(c, i); else vrg_item_catchup(c, i - nm); }
+}
+__global__ void k_close(VrgCtx c, uint32_t nf) {
+    ITEM_LOOP(nf) vrg_item_check_flip(c, i);
+    ITEM_LOOP(c.st->ndead) vrg_item_free(c, i);
+}
+__global__ void k_levels(VrgCtx c, uint32_t nnz) { ITEM_LOOP(nnz) vrg_item_level(c, i, false); }
+// per-level memo of the three density corrections: one wave per level
+__global__ void k_tab(VrgCtx c, uint32_t nnz) {
+    int lane = threadIdx.x & 63;
+    uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t l = wid; l < c.L; l += nw) {
-        double v = c.lev[l], a = 0, b = 0, d = 0;
+        double v = c.lev[l], a = 0, bb = 0, d = 0;
         for (uint32_t i = lane; i < nnz; i += 64) {
-            double k = vrg_kern(c, s_val[i] - v);
-            a += (double)s_cin[i] * k; b += (double)s_cout[i] * k; d += (double)s_cconv[i] * k;
+            double k = vrg_kern(c, c.nz_val[i] - v);
+            a += (double)c.nz_cin[i] * k; bb += (double)c.nz_cout[i] * k; d += (double)c.nz_cconv[i] * k;
         }
-        a = wave_sum(a); b = wave_sum(b); d = wave_sum(d);
-        if (lane == 0) { c.tabC[3 * (size_t)l] = a; c.tabC[3 * (size_t)l + 1] = b; c.tabC[3 * (size_t)l + 2] = d; }
+        a = wave_sum(a); bb = wave_sum(bb); d = wave_sum(d);
+        if (lane == 0) { c.tabC[3 * (size_t)l] = a; c.tabC[3 * (size_t)l + 1] = bb; c.tabC[3 * (size_t)l + 2] = d; }
+    }
+}
+__global__ void k_finalize(VrgCtx c, int use_tab) { vrg_post_apply(c); vrg_request_dense(c); vrg_finalize(c, use_tab != 0); }
+__global__ void k_dense_fin(VrgCtx c) { vrg_dense_fin(c); }
+
+// full-stencil check variant: every voxel runs the relabel stencil (no marks); new bytes go to lab[1]
+// and are copied back, so stencil reads only ever see pre-sweep labels.
+__global__ void __launch_bounds__(TPB) k_full_relabel(VrgCtx c) {
+    const uint8_t* __restrict__ in = c.lab[0];
+    uint8_t* __restrict__ out = c.lab[1];
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
+    const uint32_t first = 2u * plane;
+    const uint32_t ndw = (uint32_t)(((uint64_t)c.nz * plane) >> 2);
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < ndw; d += gridDim.x * blockDim.x) {
+        const uint32_t base = first + (d << 2);
+        uint32_t v = *reinterpret_cast<const uint32_t*>(in + base);
+        if ((v & 0x20202020u) != 0x20202020u)
+            for (int bb = 0; bb < 4; bb++) {
+                uint8_t cb = (uint8_t)(v >> (8 * bb));
+                if (!(cb & VB_OOB)) {
+                    VrgEvent ev;
+                    uint8_t nb = vrg_sweep_core(c, in, base + bb, cb, ev);
+                    vrg_commit_event(c, base + bb, ev);
+                    v = (v & ~(0xffu << (8 * bb))) | ((uint32_t)nb << (8 * bb));
+                }
+            }
+        *reinterpret_cast<uint32_t*>(out + base) = v;
+    }
+}
+__global__ void __launch_bounds__(TPB) k_copy_back(VrgCtx c) {
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(c.lab[1] + 2u * plane);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(c.lab[0] + 2u * plane);
+    const uint32_t n16 = (uint32_t)(((uint64_t)c.nz * plane) >> 4);
+    ITEM_LOOP(vrg_catchup_count(c)) vrg_item_catchup(c, i);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) {
+        uint4 a = src[i], bq = dst[i];
+        if (a.x != bq.x || a.y != bq.y || a.z != bq.z || a.w != bq.w) {
+            const uint32_t nw[4] = {a.x, a.y, a.z, a.w}, od[4] = {bq.x, bq.y, bq.z, bq.w};
+            for (int k = 0; k < 16; k++) vrg_count_change(c, 2u * plane + 16u * i + (uint32_t)k, (uint8_t)(od[k >> 2] >> (8 * (k & 3))), (uint8_t)(nw[k >> 2] >> (8 * (k & 3))));
+            dst[i] = a;
+        }
     }
 }
 
@@ -482,6 +562,7 @@ __global__ void __launch_bounds__(TPB) k_levels_tab_scan(VrgCtx c) {
 // reduced lane -> wave butterfly -> LDS -> one slot per workgroup, added in fixed slot order by the last workgroup
 // to finish: bit-reproducible.
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef double d2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 
 struct SweepAcc { long long nin, nout; double sin_, sout; };
@@ -534,47 +615,57 @@ __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a, int fi
 constexpr uint32_t LEV16_MAX = 16384;   // 16-bit storage: the level values sit in LDS (<= 16384 x f32)
 
 // The recount needs two facts per voxel - inner / outer - so it streams the
-// 2-bit class volume (VrgCtx::clsb, 0.25 B/voxel) instead of the label bytes: 4.25 B (fp32 storage) or 2.25 B
-// (16-bit storage) per voxel.  Units are 1024-voxel aligned in the absolute voxel index; lane l owns class dword l
-// of a unit and the 4 x 4 intensities at 256*j + 4*l, i.e. one 256-B + four 1-KiB (or 512-B) requests per wave
-// and unit.  A slab edge that cuts a unit is handled by masking (first / last wave); padding planes are class 0.
+// 2-bit class volume (VrgCtx::clsb, 0.25 B/voxel) instead of the label bytes: 4.25 B (fp32 storage), 2.25 B
+// (16-bit storage) or 8.25 B (float64 storage) per voxel.  Units are 1024-voxel aligned in the absolute voxel
+// index; lane l owns class dword l of a unit and the 4 x 4 intensities at 256*j + 4*l, i.e. one 256-B + four 1-KiB
+// (or 512-B / 2-KiB) requests per wave and unit.  A slab edge that cuts a unit is handled by masking (first / last
+// wave); padding planes are class 0.
 // UNITS = units a wave loads per trip (bytes in flight); NT = non-temporal loads: the volume is read once per
 // sweep and is far larger than the 256-MiB Infinity Cache, so nothing is worth keeping.
+// MODE 0: fp32 intensities, 1: 16-bit level indices + LDS value table, 2: float64 intensities.
 // Dense pass number seq (= passes closed + 1) reads copy seq & 1 of the class bits.
-__device__ __forceinline__ void stats_bits(SweepAcc& a, uint32_t w, const f4v* f) {
+template <int MODE> struct UnitVals { f4v f[4]; };
+template <> struct UnitVals<2> { d2v f[4][2]; };
+template <int MODE>
+__device__ __forceinline__ void stats_bits(SweepAcc& a, uint32_t w, const UnitVals<MODE>& u) {
     a.nin += __popc(w & 0x55555555u); a.nout += __popc(w & 0xAAAAAAAAu);
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            uint32_t t = w >> (2 * (4 * j + b));
-            double x = (double)f[j][b];
+        for (int bb = 0; bb < 4; bb++) {
+            uint32_t t = w >> (2 * (4 * j + bb));
+            double x;
+            if constexpr (MODE == 2) x = u.f[j][bb >> 1][bb & 1]; else x = (double)u.f[j][bb];
             a.sin_ += (t & 1u) ? x : 0.0;
             a.sout += (t & 2u) ? x : 0.0;
         }
 }
-template <bool L16, bool NT>
-__device__ __forceinline__ void load_unit(const VrgCtx& c, const uint32_t* cls, const float* s_val, uint32_t u, uint32_t lane, uint32_t& w, f4v* f) {
+template <int MODE, bool NT>
+__device__ __forceinline__ void load_unit(const VrgCtx& c, const uint32_t* cls, const float* s_val, uint32_t u, uint32_t lane, uint32_t& w, UnitVals<MODE>& o) {
     const uint32_t* pc = cls + ((size_t)u << 6) + lane;
     w = NT ? __builtin_nontemporal_load(pc) : *pc;
     const uint32_t base = (u << 10) + (lane << 2);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        if (L16) {
+        if constexpr (MODE == 1) {
             const u2v* pq = reinterpret_cast<const u2v*>(c.lev16 + base + (j << 8));
             u2v q = NT ? __builtin_nontemporal_load(pq) : *pq;
-            f[j] = f4v{s_val[q.x & 0xffffu], s_val[q.x >> 16], s_val[q.y & 0xffffu], s_val[q.y >> 16]};
+            o.f[j] = f4v{s_val[q.x & 0xffffu], s_val[q.x >> 16], s_val[q.y & 0xffffu], s_val[q.y >> 16]};
+        } else if constexpr (MODE == 2) {
+            const d2v* pd = reinterpret_cast<const d2v*>(c.I64 + base + (j << 8));
+            o.f[j][0] = NT ? __builtin_nontemporal_load(pd) : pd[0];
+            o.f[j][1] = NT ? __builtin_nontemporal_load(pd + 1) : pd[1];
         } else {
             const f4v* pi = reinterpret_cast<const f4v*>(c.I + base + (j << 8));
-            f[j] = NT ? __builtin_nontemporal_load(pi) : *pi;
+            o.f[j] = NT ? __builtin_nontemporal_load(pi) : *pi;
         }
     }
 }
-template <int UNITS, bool NT, bool L16>
+template <int UNITS, bool NT, int MODE>
 __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) {
     if (check_done && !vrg_dense_due(c)) return;     // no sweep was applied since the last pass (stop flag)
-    __shared__ float s_val[L16 ? LEV16_MAX : 1];
-    if (L16) {
+    __shared__ float s_val[MODE == 1 ? LEV16_MAX : 1];
+    if (MODE == 1) {
         for (uint32_t i = threadIdx.x; i < c.L; i += TPB) s_val[i] = (float)c.lev[i];
         __syncthreads();
     }
@@ -582,85 +673,42 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
     const uint32_t lo = (2u + (uint32_t)c.z0) * plane;         // this device's Z-slab [z0, z1) as a voxel range
     const uint32_t hi = (2u + (uint32_t)c.z1) * plane;
-    uint32_t f_lo = (lo + 1023u) >> 10, f_hi = hi >> 10;       // units wholly inside it
+    uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10;       // units wholly inside it
     if (f_hi < f_lo) f_hi = f_lo;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     SweepAcc acc = {0, 0, 0.0, 0.0};
     uint32_t u = f_lo + wave * UNITS;
     for (; u + UNITS <= f_hi; u += nwaves * UNITS) {
-        uint32_t w[UNITS]; f4v f[UNITS][4];
+        uint32_t w[UNITS]; UnitVals<MODE> f[UNITS];
 #pragma unroll
-        for (int q = 0; q < UNITS; q++) load_unit<L16, NT>(c, cls, s_val, u + q, lane, w[q], f[q]);
+        for (int q = 0; q < UNITS; q++) load_unit<MODE, NT>(c, cls, s_val, u + q, lane, w[q], f[q]);
 #pragma unroll
-        for (int q = 0; q < UNITS; q++) stats_bits(acc, w[q], f[q]);
+        for (int q = 0; q < UNITS; q++) stats_bits<MODE>(acc, w[q], f[q]);
     }
     for (; u < f_hi; u++) {                                    // whole units left over by the UNITS-stride
-        uint32_t w; f4v f[4];
-        load_unit<L16, false>(c, cls, s_val, u, lane, w, f);
-        stats_bits(acc, w, f);
+        uint32_t w; UnitVals<MODE> f;
+        load_unit<MODE, false>(c, cls, s_val, u, lane, w, f);
+        stats_bits<MODE>(acc, w, f);
     }
     // units the slab edges cut: the first and the last unit touching [lo, hi), masked to the slab
     const uint32_t e0 = lo >> 10, e1 = (hi - 1u) >> 10;
     const uint32_t edge = wave == 0 ? e0 : (wave == nwaves - 1 && e1 != e0 ? e1 : 0xffffffffu);
     if (edge != 0xffffffffu && !(edge >= f_lo && edge < f_hi)) {
-        uint32_t w; f4v f[4];
-        load_unit<L16, false>(c, cls, s_val, edge, lane, w, f);
+        uint32_t w; UnitVals<MODE> f;
+        load_unit<MODE, false>(c, cls, s_val, edge, lane, w, f);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             uint32_t v = (edge << 10) + (j << 8) + (lane << 2);        // groups of 4 voxels never straddle a plane
             if (v < lo || v >= hi) w &= ~(0xffu << (8 * j));
         }
-        stats_bits(acc, w, f);
+        stats_bits<MODE>(acc, w, f);
     }
     sweep_finish(c, acc, check_done);
 }
 __global__ void k_cls_build(VrgCtx c) {
-    const uint32_t nd = ((c.PV + 1023u) >> 10) << 6;
+    const uint32_t nd = (uint32_t)((((uint64_t)c.PV + 1023u) >> 10) << 6);
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < nd; d += gridDim.x * blockDim.x) vrg_item_cls_build(c, d);
-}
-
-// full-stencil check variant: every voxel runs the relabel stencil (no marks); new bytes go to lab[1]
-// and are copied back, so stencil reads only ever see pre-sweep labels.
-__global__ void __launch_bounds__(TPB) k_full_relabel(VrgCtx c) {
-    if (c.st->done) return;
-    const uint8_t* __restrict__ in = c.lab[0];
-    uint8_t* __restrict__ out = c.lab[1];
-    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
-    const uint32_t first = 2u * plane;
-    const uint32_t ndw = (uint32_t)(((uint64_t)c.nz * plane) >> 2);
-    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < ndw; d += gridDim.x * blockDim.x) {
-        const uint32_t base = first + (d << 2);
-        uint32_t v = *reinterpret_cast<const uint32_t*>(in + base);
-        if ((v & 0x20202020u) != 0x20202020u)
-            for (int b = 0; b < 4; b++) {
-                uint8_t cb = (uint8_t)(v >> (8 * b));
-                if (!(cb & VB_OOB)) {
-                    uint8_t nb = vrg_sweep_core(c, in, base + b, cb);
-                    if (cb & VB_B) c.e_new[c.vent[base + b]] = (uint8_t)(nb | VE_VALID);
-                    v = (v & ~(0xffu << (8 * b))) | ((uint32_t)nb << (8 * b));
-                }
-            }
-        *reinterpret_cast<uint32_t*>(out + base) = v;
-    }
-}
-__global__ void __launch_bounds__(TPB) k_copy_back(VrgCtx c) {
-    if (c.st->done) return;
-    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
-    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(c.lab[1] + 2u * plane);
-    uint4* __restrict__ dst = reinterpret_cast<uint4*>(c.lab[0] + 2u * plane);
-    const uint32_t n16 = (uint32_t)(((uint64_t)c.nz * plane) >> 4);
-    if (blockIdx.x == 0 && threadIdx.x == 0) vrg_request_dense(c);
-    ITEM_LOOP(vrg_catchup_count(c)) vrg_item_catchup(c, i);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) {
-        uint4 a = src[i], b = dst[i];
-        if (a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w) {
-            const uint32_t nw[4] = {a.x, a.y, a.z, a.w}, od[4] = {b.x, b.y, b.z, b.w};
-            for (int k = 0; k < 16; k++) vrg_count_change(c, 2u * plane + 16u * i + (uint32_t)k, (uint8_t)(od[k >> 2] >> (8 * (k & 3))), (uint8_t)(nw[k >> 2] >> (8 * (k & 3))));
-            a.x &= ~0x40404040u; a.y &= ~0x40404040u; a.z &= ~0x40404040u; a.w &= ~0x40404040u;   // F: see vrg_item_apply
-            dst[i] = a;
-        }
-    }
 }
 
 // ---- dense helpers over the real voxels -------------------------------------------------------------
@@ -679,8 +727,8 @@ __global__ void k_init_voxel(VrgCtx c) {
 __global__ void k_hist_voxel(VrgCtx c) {
     VOXEL_LOOP(c) { int x, y, z; vrg_item_hist_voxel(c, real_idx(c, t, x, y, z)); }
 }
-// same, for level tables that fit LDS: per-workgroup private histograms (the level values too), streamed
-// over the padded interior 16 bytes per lane, flushed with one global atomic per non-zero bin.
+// same, for level tables that fit LDS (fp32 storage): per-workgroup private histograms (the level values too),
+// streamed over the padded interior 16 bytes per lane, flushed with one global atomic per non-zero bin.
 constexpr uint32_t HIST_LDS_LEVELS = 4096;
 __global__ void __launch_bounds__(TPB) k_hist_lds(VrgCtx c) {
     __shared__ float s_lev[HIST_LDS_LEVELS];
@@ -698,12 +746,12 @@ __global__ void __launch_bounds__(TPB) k_hist_lds(VrgCtx c) {
         const float4 f = *reinterpret_cast<const float4*>(c.I + base);
         const float fv[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            uint8_t cb = (uint8_t)(v >> (8 * b));
+        for (int bb = 0; bb < 4; bb++) {
+            uint8_t cb = (uint8_t)(v >> (8 * bb));
             if (cb & (VB_OOB | VB_X)) continue;
             uint32_t lo = 0, hi = L - 1;
-            if (c.lev16) lo = c.lev16[base + b];
-            else while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (s_lev[m] < fv[b]) lo = m + 1; else hi = m; }
+            if (c.lev16) lo = c.lev16[base + bb];
+            else while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (s_lev[m] < fv[bb]) lo = m + 1; else hi = m; }
             atomicAdd(&s_h[(cb & VB_S) ? 0 : 1][lo], 1u);
         }
     }
@@ -716,9 +764,15 @@ __global__ void __launch_bounds__(TPB) k_hist_lds(VrgCtx c) {
 __global__ void k_init_entry(VrgCtx c) {
     ITEM_LOOP(c.st->ni + c.st->no) vrg_item_init_entry(c, i);
 }
+__global__ void k_exact_init(VrgCtx c) {               // init mode (:152-155): every band entry
+    const VrgState s = *c.st;
+    const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    exact_wave(c, s, s.nfresh, wid, nw, false);
+}
 __global__ void k_fin_init(VrgCtx c) {
     VrgState& s = *c.st;
-    s.nfresh = 0; s.nf = 0; s.npend = 0; s.nmk = 0;
+    s.np = s.ni + s.no; s.nfree = 0; s.nfresh = 0; s.nfx = 0; s.nf = 0; s.last_nf = 0; s.npend = 0; s.nmk = 0; s.nnz = 0;
+    s.nalloc = 0; s.ndead = 0; s.d_ni = 0; s.d_no = 0; s.corr = 0; s.use_tab = 0; s.bail = 0;
     vrg_init_counts(c);
     const VrgDense& d = *c.dn;
     VrgTrace& t = c.trace[0];
@@ -728,10 +782,10 @@ __global__ void k_fin_init(VrgCtx c) {
 __global__ void k_recount_hist(VrgCtx c, int32_t* rin, int32_t* rout) {
     VOXEL_LOOP(c) {
         int x, y, z; uint32_t idx = real_idx(c, t, x, y, z);
-        uint8_t b = c.lab[0][idx];
-        if (b & VB_X) continue;
-        uint32_t lev = vrg_level_of(c, (double)c.I[idx]);
-        atomicAdd((b & VB_S) ? &rin[lev] : &rout[lev], 1);
+        uint8_t bb = c.lab[0][idx];
+        if (bb & VB_X) continue;
+        uint32_t lev = vrg_level_of(c, vrg_voxel_value(c, idx));
+        atomicAdd((bb & VB_S) ? &rin[lev] : &rout[lev], 1);
     }
 }
 __global__ void k_collect_seg(VrgCtx c, uint64_t* stamps, uint32_t* idxs, uint32_t cap, uint32_t* count) {
@@ -743,8 +797,8 @@ __global__ void k_collect_seg(VrgCtx c, uint64_t* stamps, uint32_t* idxs, uint32
         }
     }
 }
-__global__ void k_gather_I(VrgCtx c, float* dst) {
-    VOXEL_LOOP(c) { int x, y, z; dst[t] = c.I[real_idx(c, t, x, y, z)]; }
+template <class T> __global__ void k_gather_I(VrgCtx c, T* dst) {
+    VOXEL_LOOP(c) { int x, y, z; uint32_t idx = real_idx(c, t, x, y, z); dst[t] = c.I ? (T)c.I[idx] : (T)c.I64[idx]; }
 }
 __global__ void k_f2d(const float* a, double* b, uint32_t n) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) b[i] = (double)a[i];
@@ -773,10 +827,11 @@ __device__ __forceinline__ void store_int(void* p, int dtype, int64_t i, int v) 
         default: ((double*)p)[i] = v; break;
     }
 }
-__global__ void k_pack_volume(VrgCtx c, float* dst, const void* src, int dtype, int64_t s0, int64_t s1, int64_t s2, int* flag) {
+__global__ void k_pack_volume(VrgCtx c, float* dst, double* dst64, const void* src, int dtype, int64_t s0, int64_t s1, int64_t s2, int* flag) {
     VOXEL_LOOP(c) {
         int x, y, z; uint32_t idx = real_idx(c, t, x, y, z);
         double v = load_as_double(src, dtype, x * s0 + y * s1 + z * s2);
+        if (dst64) { dst64[idx] = v; continue; }
         float f = (float)v;
         if ((double)f != v) *flag = 1;
         dst[idx] = f;
@@ -786,9 +841,9 @@ __global__ void k_pack_labels(VrgCtx c, uint8_t* dst, const void* src, int dtype
     VOXEL_LOOP(c) {
         int x, y, z; uint32_t idx = real_idx(c, t, x, y, z);
         double v = load_as_double(src, dtype, x * s0 + y * s1 + z * s2);
-        uint8_t b = 0;
-        if (v == 0) b = VB_S; else if (v == 3) b = 0; else if (v == 4) b = VB_X; else *flag = 1;
-        dst[idx] = b;
+        uint8_t bb = 0;
+        if (v == 0) bb = VB_S; else if (v == 3) bb = 0; else if (v == 4) bb = VB_X; else *flag = 1;
+        dst[idx] = bb;
     }
 }
 __global__ void k_unpack_labels(VrgCtx c, const uint8_t* lab, void* dst, int dtype, int64_t s0, int64_t s1, int64_t s2) {
@@ -796,6 +851,9 @@ __global__ void k_unpack_labels(VrgCtx c, const uint8_t* lab, void* dst, int dty
         int x, y, z; uint32_t idx = real_idx(c, t, x, y, z);
         store_int(dst, dtype, x * s0 + y * s1 + z * s2, vrg_dec(lab[idx]));
     }
+}
+__global__ void k_build_lev16(VrgCtx c, uint16_t* dst) {
+    VOXEL_LOOP(c) { int x, y, z; uint32_t idx = real_idx(c, t, x, y, z); dst[idx] = (uint16_t)vrg_level_of(c, vrg_voxel_value(c, idx)); }
 }
 
 const size_t kElem[7] = {1, 2, 2, 4, 8, 4, 8};
@@ -824,166 +882,213 @@ int voxel_blocks(const VrgCtx& c) {
 }
 
 // workgroups of the dense recount: >= 32 one-KiB units per wave, at most 1 workgroup per CU
-int dense_blocks(const VrgCtx& c) {
-    if (g_sweep_blocks > 0) return g_sweep_blocks;
+int dense_blocks(const VrgBackend* b, const VrgCtx& c) {
+    if (b->sweep_blocks > 0) return b->sweep_blocks;
     uint64_t units = ((uint64_t)(c.z1 - c.z0) * c.PY * c.PX) >> 10;
     // the 16-bit variant spends issue slots on LDS table look-ups and wants twice the waves (512: 0.275 ms, 256: 0.335)
     return (int)std::min<uint64_t>(c.lev16 ? 2 * SWEEP_BLOCKS : SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128));
 }
 
-struct EvPair { hipEvent_t a, b; };
-std::vector<EvPair> g_ev_pool;
-size_t g_ev_used = 0;
+void use_device(VrgBackend* b) { HIP_CHECK(hipSetDevice(b->device)); }
+
+void make_streams(VrgBackend* b) {
+    int lo = 0, hi = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));      // hi = numerically lowest = highest priority
+    if (b->sa) { HIP_CHECK(hipStreamSynchronize(b->sa)); HIP_CHECK(hipStreamDestroy(b->sa)); }
+    if (b->sb) { HIP_CHECK(hipStreamSynchronize(b->sb)); HIP_CHECK(hipStreamDestroy(b->sb)); }
+    // prio_mode 0: equal; 1: band stream A high; 2: dense stream B high
+    HIP_CHECK(hipStreamCreateWithPriority(&b->sa, hipStreamNonBlocking, b->prio_mode == 1 ? hi : (b->prio_mode == 2 ? lo : 0)));
+    HIP_CHECK(hipStreamCreateWithPriority(&b->sb, hipStreamNonBlocking, b->prio_mode == 2 ? hi : (b->prio_mode == 1 ? lo : 0)));
+}
+
+// scratch for the host-driven sorts, grown on demand
+bool need_tmp(VrgBackend* b, size_t bytes) {
+    if (bytes <= b->tmp_bytes) return true;
+    if (b->tmp) HIP_CHECK(hipFree(b->tmp));
+    b->tmp = nullptr; b->tmp_bytes = 0;
+    if (hipMalloc(&b->tmp, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+    b->tmp_bytes = bytes;
+    return true;
+}
+bool need_keys2(VrgBackend* b, size_t n) {
+    if (n <= b->keys2_n) return true;
+    if (b->keys2) HIP_CHECK(hipFree(b->keys2));
+    b->keys2 = nullptr; b->keys2_n = 0;
+    if (hipMalloc(&b->keys2, n * 8) != hipSuccess) { (void)hipGetLastError(); return false; }
+    b->keys2_n = n;
+    return true;
+}
 
 }  // namespace
 
 // ---- backend interface ---------------------------------------------------------------------------------
-static void make_streams() {
-    int lo = 0, hi = 0;
-    HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));      // hi = numerically lowest = highest priority
-    if (g_stream) { HIP_CHECK(hipStreamSynchronize(g_stream)); HIP_CHECK(hipStreamDestroy(g_stream)); }
-    if (g_stream_b) { HIP_CHECK(hipStreamSynchronize(g_stream_b)); HIP_CHECK(hipStreamDestroy(g_stream_b)); }
-    // prio_mode 0: equal; 1: critical stream A high; 2: bookkeeping stream B high
-    HIP_CHECK(hipStreamCreateWithPriority(&g_stream, hipStreamNonBlocking, g_prio_mode == 1 ? hi : (g_prio_mode == 2 ? lo : 0)));
-    HIP_CHECK(hipStreamCreateWithPriority(&g_stream_b, hipStreamNonBlocking, g_prio_mode == 2 ? hi : (g_prio_mode == 1 ? lo : 0)));
-}
-void be_set_tuning(const char* name, long long v) {
-    if (std::strcmp(name, "sweep_blocks") == 0 && v >= 0 && v <= 4096) g_sweep_blocks = (int)v;
-    if (std::strcmp(name, "graph") == 0) g_use_graph_req = v != 0;
-    if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != g_prio_mode) { g_prio_mode = (int)v; make_streams(); }
-}
-
-int be_set_device(int device) {
+VrgBackend* be_create(int device) {
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) { (void)hipGetLastError(); return -1; }
-    if (hipSetDevice(device) != hipSuccess) return -1;
-    if (!g_stream) {
-        make_streams();
-        HIP_CHECK(hipEventCreateWithFlags(&g_ev_a, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&g_ev_d[0], hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&g_ev_d[1], hipEventDisableTiming));
-    }
-    return 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) { (void)hipGetLastError(); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    VrgBackend* b = new VrgBackend();
+    b->device = device;
+    make_streams(b);
+    if (b->err[0]) { be_destroy(b); return nullptr; }
+    return b;
 }
-void* be_alloc(size_t bytes) { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
-void be_free(void* p) { HIP_CHECK(hipFree(p)); }
-void be_fill(void* p, int byte, size_t bytes) { HIP_CHECK(hipMemsetAsync(p, byte, bytes, g_stream)); }
-void be_upload(void* dst, const void* src, size_t bytes) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, g_stream)); HIP_CHECK(hipStreamSynchronize(g_stream)); }
-void be_download(void* dst, const void* src, size_t bytes) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, g_stream)); HIP_CHECK(hipStreamSynchronize(g_stream)); }
-const char* be_last_error() {
-    if (!g_hip_error[0]) { hipError_t e = hipGetLastError(); if (e != hipSuccess) std::snprintf(g_hip_error, sizeof(g_hip_error), "HIP error '%s' (asynchronous)", hipGetErrorString(e)); }
-    return g_hip_error[0] ? g_hip_error : nullptr;
+void be_destroy(VrgBackend* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->sa) (void)hipStreamSynchronize(b->sa);
+    if (b->sb) (void)hipStreamSynchronize(b->sb);
+    if (b->comm) { ncclCommDestroy(b->comm); b->comm = nullptr; }
+    for (auto& p : b->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (b->tmp) (void)hipFree(b->tmp);
+    if (b->keys2) (void)hipFree(b->keys2);
+    if (b->sa) (void)hipStreamDestroy(b->sa);
+    if (b->sb) (void)hipStreamDestroy(b->sb);
+    delete b;
 }
-void be_sync() { HIP_CHECK(hipStreamSynchronize(g_stream)); HIP_CHECK(hipStreamSynchronize(g_stream_b)); }
+void be_set_tuning(VrgBackend* b, const char* name, long long v) {
+    use_device(b);
+    if (std::strcmp(name, "sweep_blocks") == 0 && v >= 0 && v <= 4096) b->sweep_blocks = (int)v;
+    if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)std::min<long long>(v, NF_SMALL);
+    if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != b->prio_mode) { b->prio_mode = (int)v; make_streams(b); }
+}
+uint32_t be_small_flip_limit(VrgBackend* b) { return b->small_flips; }
 
-static const void* stage_in(const VrgCtx& c, const void* src, int dtype, void** tmp) {
+void* be_alloc(VrgBackend* b, size_t bytes) { use_device(b); void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
+void be_free(VrgBackend* b, void* p) { use_device(b); HIP_CHECK(hipFree(p)); }
+void be_fill(VrgBackend* b, void* p, int byte, size_t bytes) { use_device(b); HIP_CHECK(hipMemsetAsync(p, byte, bytes, b->sa)); }
+void be_upload(VrgBackend* b, void* dst, const void* src, size_t bytes) { use_device(b); HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, b->sa)); HIP_CHECK(hipStreamSynchronize(b->sa)); }
+void be_download(VrgBackend* b, void* dst, const void* src, size_t bytes) { use_device(b); HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, b->sa)); HIP_CHECK(hipStreamSynchronize(b->sa)); }
+void be_copy(VrgBackend* b, void* dst, const void* src, size_t bytes) { use_device(b); HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, b->sa)); }
+const char* be_last_error(VrgBackend* b) {
+    if (!b->err[0]) { (void)hipSetDevice(b->device); hipError_t e = hipGetLastError(); if (e != hipSuccess) std::snprintf(b->err, sizeof(b->err), "HIP error '%s' (asynchronous)", hipGetErrorString(e)); }
+    return b->err[0] ? b->err : nullptr;
+}
+void be_clear_error(VrgBackend* b) { b->err[0] = 0; }
+void be_sync(VrgBackend* b) { use_device(b); HIP_CHECK(hipStreamSynchronize(b->sa)); HIP_CHECK(hipStreamSynchronize(b->sb)); }
+
+// A device-resident input is read on the library's own stream: the caller's producer must have finished (vrg.h).
+static const void* stage_in(VrgBackend* b, const VrgCtx& c, const void* src, int dtype, void** tmp) {
     *tmp = nullptr;
     if (is_device_ptr(src)) return src;
     size_t bytes = (size_t)c.nx * c.ny * c.nz * kElem[dtype];
-    if (hipMalloc(tmp, bytes) != hipSuccess) return nullptr;
-    HIP_CHECK(hipMemcpyAsync(*tmp, src, bytes, hipMemcpyHostToDevice, g_stream));
+    if (hipMalloc(tmp, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    HIP_CHECK(hipMemcpyAsync(*tmp, src, bytes, hipMemcpyHostToDevice, b->sa));
     return *tmp;
 }
 
-int be_pack_volume(const VrgCtx& c, float* dst, const void* src, int dtype, const int64_t st[3], int* inexact) {
+int be_pack_volume(VrgBackend* b, const VrgCtx& c, float* dst, double* dst64, const void* src, int dtype, const int64_t st[3], int* inexact) {
+    use_device(b);
     if (!dense_strides(c, st)) return -1;
-    void* tmp; const void* d = stage_in(c, src, dtype, &tmp);
+    void* tmp; const void* d = stage_in(b, c, src, dtype, &tmp);
     if (!d) return -1;
-    int* flag; HIP_CHECK(hipMalloc(&flag, sizeof(int))); HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), g_stream));
-    k_pack_volume<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, dst, d, dtype, st[0], st[1], st[2], flag);
-    HIP_CHECK(hipMemcpyAsync(inexact, flag, sizeof(int), hipMemcpyDeviceToHost, g_stream));
-    HIP_CHECK(hipStreamSynchronize(g_stream));
+    int* flag; HIP_CHECK(hipMalloc(&flag, sizeof(int))); HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), b->sa));
+    k_pack_volume<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, dst, dst64, d, dtype, st[0], st[1], st[2], flag);
+    HIP_CHECK(hipMemcpyAsync(inexact, flag, sizeof(int), hipMemcpyDeviceToHost, b->sa));
+    HIP_CHECK(hipStreamSynchronize(b->sa));
     HIP_CHECK(hipFree(flag)); if (tmp) HIP_CHECK(hipFree(tmp));
     return 0;
 }
-int be_pack_labels(const VrgCtx& c, uint8_t* dst, const void* src, int dtype, const int64_t st[3], int* bad) {
+int be_pack_labels(VrgBackend* b, const VrgCtx& c, uint8_t* dst, const void* src, int dtype, const int64_t st[3], int* bad) {
+    use_device(b);
     if (!dense_strides(c, st)) return -1;
-    void* tmp; const void* d = stage_in(c, src, dtype, &tmp);
+    void* tmp; const void* d = stage_in(b, c, src, dtype, &tmp);
     if (!d) return -1;
-    int* flag; HIP_CHECK(hipMalloc(&flag, sizeof(int))); HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), g_stream));
-    k_pack_labels<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, dst, d, dtype, st[0], st[1], st[2], flag);
-    HIP_CHECK(hipMemcpyAsync(bad, flag, sizeof(int), hipMemcpyDeviceToHost, g_stream));
-    HIP_CHECK(hipStreamSynchronize(g_stream));
+    int* flag; HIP_CHECK(hipMalloc(&flag, sizeof(int))); HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), b->sa));
+    k_pack_labels<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, dst, d, dtype, st[0], st[1], st[2], flag);
+    HIP_CHECK(hipMemcpyAsync(bad, flag, sizeof(int), hipMemcpyDeviceToHost, b->sa));
+    HIP_CHECK(hipStreamSynchronize(b->sa));
     HIP_CHECK(hipFree(flag)); if (tmp) HIP_CHECK(hipFree(tmp));
     return 0;
 }
-int be_unpack_labels(const VrgCtx& c, const uint8_t* lab, void* dst, int dtype, const int64_t st[3]) {
+int be_unpack_labels(VrgBackend* b, const VrgCtx& c, const uint8_t* lab, void* dst, int dtype, const int64_t st[3]) {
+    use_device(b);
     if (!dense_strides(c, st)) return -1;
     bool dev = is_device_ptr(dst);
     size_t bytes = (size_t)c.nx * c.ny * c.nz * kElem[dtype];
     void* d = dst;
-    if (!dev && hipMalloc(&d, bytes) != hipSuccess) return -1;
-    k_unpack_labels<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, lab, d, dtype, st[0], st[1], st[2]);
-    if (!dev) { HIP_CHECK(hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, g_stream)); }
-    HIP_CHECK(hipStreamSynchronize(g_stream));
+    if (!dev && hipMalloc(&d, bytes) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    k_unpack_labels<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, lab, d, dtype, st[0], st[1], st[2]);
+    if (!dev) { HIP_CHECK(hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, b->sa)); }
+    HIP_CHECK(hipStreamSynchronize(b->sa));
     if (!dev) HIP_CHECK(hipFree(d));
     return 0;
 }
 
-int be_build_levels(const VrgCtx& c, double** lev, uint32_t* L) {
+// sorted distinct intensity values (rocPRIM radix sort + unique), as float64
+template <class T> static int build_levels_t(VrgBackend* b, const VrgCtx& c, double** lev, uint32_t* L) {
     size_t V = (size_t)c.nx * c.ny * c.nz;
-    float *a = nullptr, *b = nullptr; uint32_t* cnt = nullptr; void* tmp = nullptr; size_t tb = 0, tb2 = 0;
-    if (hipMalloc(&a, V * 4) != hipSuccess || hipMalloc(&b, V * 4) != hipSuccess || hipMalloc(&cnt, 4) != hipSuccess) return -1;
-    k_gather_I<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, a);
-    HIP_CHECK(rocprim::radix_sort_keys(nullptr, tb, a, b, V, 0, 32, g_stream));
-    HIP_CHECK(rocprim::unique(nullptr, tb2, b, a, cnt, V, rocprim::equal_to<float>(), g_stream));
-    tb = std::max(tb, tb2);
-    if (hipMalloc(&tmp, tb) != hipSuccess) return -1;
-    HIP_CHECK(rocprim::radix_sort_keys(tmp, tb, a, b, V, 0, 32, g_stream));
-    HIP_CHECK(rocprim::unique(tmp, tb, b, a, cnt, V, rocprim::equal_to<float>(), g_stream));
-    uint32_t n = 0;
-    HIP_CHECK(hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, g_stream));
-    HIP_CHECK(hipStreamSynchronize(g_stream));
+    T *a = nullptr, *bb = nullptr; uint32_t* cnt = nullptr; void* tmp = nullptr; size_t tb = 0, tb2 = 0;
+    int rc = -1;
     double* out = nullptr;
-    if (hipMalloc(&out, (size_t)n * 8) != hipSuccess) return -1;
-    k_f2d<<<256, TPB, 0, g_stream>>>(a, out, n);
-    HIP_CHECK(hipStreamSynchronize(g_stream));
-    HIP_CHECK(hipFree(a)); HIP_CHECK(hipFree(b)); HIP_CHECK(hipFree(cnt)); HIP_CHECK(hipFree(tmp));
-    *lev = out; *L = n;
-    return 0;
+    if (hipMalloc(&a, V * sizeof(T)) == hipSuccess && hipMalloc(&bb, V * sizeof(T)) == hipSuccess && hipMalloc(&cnt, 4) == hipSuccess) {
+        k_gather_I<T><<<voxel_blocks(c), TPB, 0, b->sa>>>(c, a);
+        HIP_CHECK(rocprim::radix_sort_keys(nullptr, tb, a, bb, V, 0, 8 * sizeof(T), b->sa));
+        HIP_CHECK(rocprim::unique(nullptr, tb2, bb, a, cnt, V, rocprim::equal_to<T>(), b->sa));
+        tb = std::max(tb, tb2);
+        if (hipMalloc(&tmp, tb) == hipSuccess) {
+            HIP_CHECK(rocprim::radix_sort_keys(tmp, tb, a, bb, V, 0, 8 * sizeof(T), b->sa));
+            HIP_CHECK(rocprim::unique(tmp, tb, bb, a, cnt, V, rocprim::equal_to<T>(), b->sa));
+            uint32_t n = 0;
+            HIP_CHECK(hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, b->sa));
+            HIP_CHECK(hipStreamSynchronize(b->sa));
+            if (n && hipMalloc(&out, (size_t)n * 8) == hipSuccess) {
+                if (sizeof(T) == 4) k_f2d<<<256, TPB, 0, b->sa>>>((const float*)a, out, n);
+                else HIP_CHECK(hipMemcpyAsync(out, a, (size_t)n * 8, hipMemcpyDeviceToDevice, b->sa));
+                HIP_CHECK(hipStreamSynchronize(b->sa));
+                *lev = out; *L = n; rc = 0;
+            }
+        }
+    }
+    (void)hipGetLastError();
+    if (a) HIP_CHECK(hipFree(a)); if (bb) HIP_CHECK(hipFree(bb)); if (cnt) HIP_CHECK(hipFree(cnt)); if (tmp) HIP_CHECK(hipFree(tmp));
+    return rc;
+}
+int be_build_levels(VrgBackend* b, const VrgCtx& c, double** lev, uint32_t* L) {
+    use_device(b);
+    return c.I ? build_levels_t<float>(b, c, lev, L) : build_levels_t<double>(b, c, lev, L);
 }
 
-__global__ void k_build_lev16(VrgCtx c, uint16_t* dst) {
-    VOXEL_LOOP(c) { int x, y, z; uint32_t idx = real_idx(c, t, x, y, z); dst[idx] = (uint16_t)vrg_level_of(c, (double)c.I[idx]); }
-}
-void be_build_lev16(const VrgCtx& c, uint16_t* dst) {
-    HIP_CHECK(hipMemsetAsync(dst, 0, ((size_t)c.PV + 1023) / 1024 * 1024 * 2, g_stream));
-    k_build_lev16<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, dst);
+void be_build_lev16(VrgBackend* b, const VrgCtx& c, uint16_t* dst) {
+    use_device(b);
+    HIP_CHECK(hipMemsetAsync(dst, 0, ((size_t)c.PV + 1023) / 1024 * 1024 * 2, b->sa));
+    k_build_lev16<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, dst);
 }
 
-void be_init_band(const VrgCtx& c) {
-    k_init_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
+void be_init_band(VrgBackend* b, const VrgCtx& c) {
+    use_device(b);
+    k_init_voxel<<<voxel_blocks(c), TPB, 0, b->sa>>>(c);
 }
 
-void be_init_sort(const VrgCtx& c, uint32_t n_in, uint32_t n_out) {
+void be_init_sort(VrgBackend* b, const VrgCtx& c, uint32_t n_in, uint32_t n_out) {
+    use_device(b);
     uint32_t nmax = std::max(n_in, n_out);
     if (nmax == 0) return;
     uint64_t* kout = nullptr; void* tmp = nullptr; size_t tb = 0;
     HIP_CHECK(hipMalloc(&kout, (size_t)nmax * 8));
-    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, c.init_key, kout, c.init_idx, c.b_idx[0], nmax, 0, 64, g_stream));
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, c.init_key, kout, c.init_idx, c.p_idx, nmax, 0, 64, b->sa));
     HIP_CHECK(hipMalloc(&tmp, tb));
-    if (n_in) HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, c.init_key, kout, c.init_idx, c.b_idx[0], n_in, 0, 64, g_stream));
+    if (n_in) HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, c.init_key, kout, c.init_idx, c.p_idx, n_in, 0, 64, b->sa));
     if (n_out) HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, c.init_key + (c.bcap - n_out), kout, c.init_idx + (c.bcap - n_out),
-                                                   c.b_idx[0] + n_in, n_out, 0, 64, g_stream));
-    HIP_CHECK(hipStreamSynchronize(g_stream));
+                                                   c.p_idx + n_in, n_out, 0, 64, b->sa));
+    HIP_CHECK(hipStreamSynchronize(b->sa));
     HIP_CHECK(hipFree(kout)); HIP_CHECK(hipFree(tmp));
 }
 
 // sum the slab statistics over the ranks: RCCL on the stream, or the host callback (synchronises)
-static void reduce_dense(const VrgCtx& c, be_reduce_fn cb, void* user, hipStream_t g_stream) {
-    if (g_comm) {
-        ncclResult_t r = ncclAllReduce(c.dn_part, c.dn, 4, ncclDouble, ncclSum, g_comm, g_stream);
-        if (r != ncclSuccess && !g_hip_error[0]) {   // sticky: the engine turns it into VRG_E_INTERNAL at its next synchronisation point
-            std::snprintf(g_hip_error, sizeof(g_hip_error), "RCCL all-reduce of the slab statistics failed: %s", ncclGetErrorString(r));
-            std::fprintf(stderr, "%s\n", g_hip_error);
+static void reduce_dense(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user, hipStream_t st) {
+    if (b->comm) {
+        ncclResult_t r = ncclAllReduce(c.dn_part, c.dn, 4, ncclDouble, ncclSum, b->comm, st);
+        if (r != ncclSuccess && !b->err[0]) {        // sticky: the engine turns it into VRG_E_INTERNAL at its next synchronisation point
+            std::snprintf(b->err, sizeof(b->err), "RCCL all-reduce of the slab statistics failed: %s", ncclGetErrorString(r));
+            std::fprintf(stderr, "%s\n", b->err);
         }
     } else if (cb) {
         double v[4];
-        HIP_CHECK(hipMemcpyAsync(v, c.dn_part, sizeof(v), hipMemcpyDeviceToHost, g_stream));
-        HIP_CHECK(hipStreamSynchronize(g_stream));
+        HIP_CHECK(hipMemcpyAsync(v, c.dn_part, sizeof(v), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
         cb(v, user);
-        HIP_CHECK(hipMemcpyAsync(c.dn, v, sizeof(v), hipMemcpyHostToDevice, g_stream));
-        HIP_CHECK(hipStreamSynchronize(g_stream));
+        HIP_CHECK(hipMemcpyAsync(c.dn, v, sizeof(v), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
     }
 }
 
@@ -991,163 +1096,161 @@ int be_comm_unique_id(void* id128) {
     static_assert(sizeof(ncclUniqueId) == 128, "id size");
     return ncclGetUniqueId((ncclUniqueId*)id128) == ncclSuccess ? 0 : -1;
 }
-int be_comm_init(int nranks, int rank, const void* id128) {
-    if (g_comm) { ncclCommDestroy(g_comm); g_comm = nullptr; }
+int be_comm_init(VrgBackend* b, int nranks, int rank, const void* id128) {
+    use_device(b);
+    if (b->comm) { ncclCommDestroy(b->comm); b->comm = nullptr; }
     ncclUniqueId id; std::memcpy(&id, id128, sizeof(id));
-    ncclResult_t r = ncclCommInitRank(&g_comm, nranks, id, rank);
-    if (r != ncclSuccess) { std::fprintf(stderr, "ncclCommInitRank failed: %s\n", ncclGetErrorString(r)); g_comm = nullptr; return -1; }
+    ncclResult_t r = ncclCommInitRank(&b->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        b->comm = nullptr;
+        if (!b->err[0]) std::snprintf(b->err, sizeof(b->err), "ncclCommInitRank(%d ranks, rank %d) failed: %s", nranks, rank, ncclGetErrorString(r));
+        return -1;
+    }
     return 0;
 }
 
 // The start / stop events ride on the dispatch itself (hipExtLaunchKernel): no separate event packets in the stream,
 // which cost ~4 us each between two back-to-back recounts.
 static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t st, hipEvent_t e_start = nullptr, hipEvent_t e_stop = nullptr) {
-    if (c.lev16) hipExtLaunchKernelGGL((k_recount_bits<3, true, true>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
-    else hipExtLaunchKernelGGL((k_recount_bits<3, true, false>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
+    if (c.lev16) hipExtLaunchKernelGGL((k_recount_bits<3, true, 1>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
+    else if (c.I) hipExtLaunchKernelGGL((k_recount_bits<3, true, 0>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
+    else hipExtLaunchKernelGGL((k_recount_bits<2, true, 2>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
 }
 
-void be_init_finish(const VrgCtx& c, be_reduce_fn cb, void* user) {
-    HIP_CHECK(hipStreamSynchronize(g_stream_b));     // both class copies are rebuilt: no dense pass may be in flight
-    k_init_entry<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    if (c.L <= HIST_LDS_LEVELS) k_hist_lds<<<1024, TPB, 0, g_stream>>>(c);
-    else k_hist_voxel<<<voxel_blocks(c), TPB, 0, g_stream>>>(c);
-    k_exact<<<1024, TPB, 0, g_stream>>>(c);
-    k_cls_build<<<2048, TPB, 0, g_stream>>>(c);
-    launch_recount(c, dense_blocks(c), 0, g_stream);
-    reduce_dense(c, cb, user, g_stream);
-    k_fin_init<<<1, 1, 0, g_stream>>>(c);
+void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
+    use_device(b);
+    HIP_CHECK(hipStreamSynchronize(b->sb));     // both class copies are rebuilt: no dense pass may be in flight
+    k_init_entry<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c);
+    if (c.I && c.L <= HIST_LDS_LEVELS) k_hist_lds<<<1024, TPB, 0, b->sa>>>(c);
+    else k_hist_voxel<<<voxel_blocks(c), TPB, 0, b->sa>>>(c);
+    k_exact_init<<<1024, TPB, 0, b->sa>>>(c);
+    k_cls_build<<<2048, TPB, 0, b->sa>>>(c);
+    launch_recount(c, dense_blocks(b, c), 0, b->sa);
+    reduce_dense(b, c, cb, user, b->sa);
+    k_fin_init<<<1, 1, 0, b->sa>>>(c);
 }
 
-// ---- one sweep ------------------------------------------------------------------------------------------
-// Stream A ("band") carries every sparse kernel in program order; stream B ("dense") carries the recounts (+ the
-// slab all-reduce and k_dense_fin on several GPUs).  The only edges between them:
-//   recount(k) waits for apply(k) + entry_post(k)    (labels of sweep k in class copy k & 1, expected sizes filed)
-//   apply(k)   waits for recount(k-2)                (it rewrites class copy k & 1, which pass k-2 was reading)
+// ---- one trip ---------------------------------------------------------------------------------------------
+// Stream A ("band") carries k_band and the update() kernels of every trip in program order; stream B ("dense") carries the recounts
+// (+ the slab all-reduce and k_dense_fin on several GPUs).  The only edges between them:
+//   recount(k) waits for k_close(k)        (labels of sweep k in class copy k & 1, expected sizes filed)
+//   k_close(k) waits for recount(k-2)      (it rewrites class copy k & 1, which pass k-2 was reading)
 // Neither wait blocks in steady state: on one big volume stream A is a sweep ahead and stream B runs its recounts
 // back to back; on small slabs stream B is idle most of the time and stream A never finds pass k-2 unfinished.
 // The band kernels read and write the label BYTES only; the dense pass reads the class bits only.
-static void enqueue_pre(const VrgCtx& c, int variant) {         // decide + flip list, marks + prepass, fix-point, relabel
-    k_decide_exact<<<2 * ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    k_marks_prepass<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    if (!(variant & 1)) k_relabel<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);     // + the skip-rule fix-point
-    else { k_fix<<<1, 1024, 0, g_stream>>>(c); k_full_relabel<<<2048, TPB, 0, g_stream>>>(c); }
-}
-// first kernel(s) after the labels are applied (level deltas; files the expected sizes): launched eagerly, the event
-// that releases the dense pass rides on the dispatch (small level tables) or follows it
-static void launch_levels(const VrgCtx& c, hipEvent_t ev) {
-    if (c.L <= LT_MAX) {
-        hipExtLaunchKernelGGL(k_levels_tab_scan, dim3(ITEM_BLOCKS + SCAN_BLOCKS), dim3(TPB), 0, g_stream, nullptr, ev, 0, c);
-        return;
-    }
-    if (c.L <= LEVELS_ONEBLOCK) k_levels_small<<<1, 1024, 0, g_stream>>>(c);
-    else k_delta_flag<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    HIP_CHECK(hipEventRecord(ev, g_stream));
-}
-static void enqueue_post(const VrgCtx& c) {                     // rest of the band bookkeeping (new lists, densities), iterNum += 1
-    if (c.L <= LT_MAX) {
-        k_scan_down<<<SCAN_BLOCKS, TPB, 0, g_stream>>>(c, c.scan, 1);
-    } else {
-        if (c.L > LEVELS_ONEBLOCK) {
-            device_scan(c, c.lscan, g_stream, 0);
-            k_post_prep<<<1, 1, 0, g_stream>>>(c);
-            k_delta_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-        }
-        k_tab<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-        device_scan(c, c.scan, g_stream, 1);
-    }
-    k_scatter<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    k_finalize<<<1, 1, 0, g_stream>>>(c);             // the new entries' exact densities: k_decide_exact of the next trip
-}
 
-// With option "graph" the two runs of band kernels are replayed from captured hipGraphs (one host call each);
-// apply, entry_post, the event edges, the recount and the collective stay eager, so nothing depends on RCCL
-// supporting stream capture and the per-launch HIP-event timing of the recount keeps working.
-struct GraphCache { hipGraphExec_t exec = nullptr; VrgCtx key; int variant = -1; bool valid = false; };
-static GraphCache g_graph_pre, g_graph_post;
-#define g_use_graph g_use_graph_req
-
-template <class F> static void run_band(GraphCache& g, const VrgCtx& c, int variant, F&& enqueue) {
-    if (g_use_graph) {
-        if (!g.valid || g.variant != variant || std::memcmp(&g.key, &c, sizeof(VrgCtx)) != 0) {
-            if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-            g.valid = false;
-            hipGraph_t graph = nullptr;
-            bool ok = hipStreamBeginCapture(g_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
-            if (ok) {
-                enqueue();
-                ok = hipStreamEndCapture(g_stream, &graph) == hipSuccess && graph != nullptr;
-            }
-            if (ok) ok = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess;
-            if (graph) (void)hipGraphDestroy(graph);
-            if (ok) { std::memcpy(&g.key, &c, sizeof(VrgCtx)); g.variant = variant; g.valid = true; }
-            else {                                   // capture not possible here: stay with eager launches
-                (void)hipGetLastError();
-                g_use_graph = 0;
-                std::fprintf(stderr, "vrg: hipGraph capture failed, falling back to eager launches\n");
-            }
-        }
-        if (g.valid) { HIP_CHECK(hipGraphLaunch(g.exec, g_stream)); return; }
-    }
-    enqueue();
-}
-
-void be_sweep_once(const VrgCtx& c, int variant, VrgEvents* ev, be_reduce_fn cb, void* user) {
-    // every event record / wait is a barrier packet of a few us on its stream: the end-of-recount timing event
-    // doubles as the edge "class copy read"
-    hipEvent_t e_start = nullptr, e_read = g_ev_d[g_trip & 1];
-    if (ev && ev->enabled) {
-        if (g_ev_used == g_ev_pool.size()) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); g_ev_pool.push_back(n); }
-        EvPair& p = g_ev_pool[g_ev_used++];
-        e_start = p.a; e_read = p.b;
-    }
-    run_band(g_graph_pre, c, variant & 3, [&] { enqueue_pre(c, variant & 3); });
+// update() driven from the host: any number of flips.  Returns after the band side of the trip is enqueued.
+static void host_driven_update(VrgBackend* b, const VrgCtx& c, int flags) {
+    k_trip_open<<<1, TPB, 0, b->sa>>>(c);
+    VrgState s;
+    HIP_CHECK(hipMemcpyAsync(&s, c.st, sizeof(s), hipMemcpyDeviceToHost, b->sa));
+    HIP_CHECK(hipStreamSynchronize(b->sa));
+    if (s.done || s.bail || b->err[0]) return;
+    const uint32_t nf = s.nf;
+    // the flip list in the reference's order: device-wide sort by (list, key)
+    size_t tb = 0;
+    if (!need_keys2(b, nf)) { std::snprintf(b->err, sizeof(b->err), "out of device memory (flip sort)"); return; }
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, c.f_key, b->keys2, c.flist, c.f_slot, nf, 0, 64, b->sa));
+    if (!need_tmp(b, tb)) { std::snprintf(b->err, sizeof(b->err), "out of device memory (flip sort)"); return; }
+    k_flip_keys<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nf);
+    HIP_CHECK(rocprim::radix_sort_pairs(b->tmp, tb, c.f_key, b->keys2, c.flist, c.f_slot, nf, 0, 64, b->sa));
+    k_list<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nf);
+    if (flags & VRG_SWEEP_FULL) k_prepass<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nf);
+    else k_marks_prepass<<<4 * ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nf);
+    k_fix<<<1, KS_THREADS, 0, b->sa>>>(c);
+    if (flags & VRG_SWEEP_FULL) k_full_relabel<<<2048, TPB, 0, b->sa>>>(c);
+    else k_relabel<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c);
     // the labels change now, in the class copy the dense pass of two sweeps ago was reading
-    if (g_read[g_trip & 1]) HIP_CHECK(hipStreamWaitEvent(g_stream, g_read[g_trip & 1], 0));
-    if (!(variant & 1)) k_apply_entry_post<<<2 * ITEM_BLOCKS, TPB, 0, g_stream>>>(c);
-    else { k_copy_back<<<2048, TPB, 0, g_stream>>>(c); k_entry_post<<<ITEM_BLOCKS, TPB, 0, g_stream>>>(c); }
-    launch_levels(c, g_ev_a);                        // files the sizes the dense pass must reproduce; g_ev_a on its dispatch
-    // dense stream: every voxel once, read-only.  Enqueued before the rest of the bookkeeping so that its dispatch
-    // never waits for the host to issue those launches.
-    if (!(variant & 4)) {                            // (variant & 4: measurement aid, the band chain alone)
-    HIP_CHECK(hipStreamWaitEvent(g_stream_b, g_ev_a, 0));
-    const bool ranks = c.world > 1 || g_comm || cb;
-    launch_recount(c, dense_blocks(c), ranks ? 1 : 2, g_stream_b, e_start, e_read);
-    g_read[g_trip & 1] = e_read;
-    g_trip++;
-    if (ranks) {                                     // one GPU: the last workgroup of the recount closes the pass itself
-        reduce_dense(c, cb, user, g_stream_b);       // sum over the Z-slabs (RCCL on the stream / host callback)
-        k_dense_fin<<<1, 1, 0, g_stream_b>>>(c);
+    if (!(flags & VRG_SWEEP_NODENSE)) k_wait_dense<<<1, 64, 0, b->sa>>>(c);
+    if (flags & VRG_SWEEP_FULL) k_copy_back<<<2048, TPB, 0, b->sa>>>(c);
+    else k_apply<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c);
+    k_close<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nf);
+    HIP_CHECK(hipMemcpyAsync(&s, c.st, sizeof(s), hipMemcpyDeviceToHost, b->sa));
+    HIP_CHECK(hipStreamSynchronize(b->sa));
+    const uint32_t nnz = std::min(s.nnz, c.zcap);
+    if (nnz > 1) {                                   // touched levels in ascending order
+        if (!need_keys2(b, nnz)) { std::snprintf(b->err, sizeof(b->err), "out of device memory (level sort)"); return; }
+        HIP_CHECK(rocprim::radix_sort_keys(nullptr, tb, c.nz_key, b->keys2, nnz, 0, 32, b->sa));
+        if (!need_tmp(b, tb)) { std::snprintf(b->err, sizeof(b->err), "out of device memory (level sort)"); return; }
+        HIP_CHECK(rocprim::radix_sort_keys(b->tmp, tb, c.nz_key, b->keys2, nnz, 0, 32, b->sa));
+        HIP_CHECK(hipMemcpyAsync(c.nz_key, b->keys2, (size_t)nnz * 8, hipMemcpyDeviceToDevice, b->sa));
     }
-    }
-    run_band(g_graph_post, c, 0, [&] { enqueue_post(c); });
+    k_levels<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nnz);
+    // memoise the corrections per level when there are far fewer levels than band entries
+    const uint64_t band = (uint64_t)((int64_t)s.ni + s.d_ni) + (uint64_t)((int64_t)s.no + s.d_no);
+    const int use_tab = (uint64_t)c.L * 8u <= band;
+    if (use_tab) k_tab<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nnz);
+    k_finalize<<<1, 1, 0, b->sa>>>(c, use_tab);
 }
 
-void be_events_collect(VrgEvents* ev, long long n_valid) {
+// update() for a sweep with few flips: three launches, nothing from the host in between
+static void small_update(VrgBackend* b, const VrgCtx& c, bool dense) {
+    k_order<<<1, KO_THREADS, 0, b->sa>>>(c, b->small_flips);
+    k_mark_relabel<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c);
+    k_close<<<1 + TAB_BLOCKS, KS_THREADS, 0, b->sa>>>(c, dense ? 1 : 0);   // (waits on the device for the dense pass of two sweeps ago)
+}
+
+void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_reduce_fn cb, void* user) {
+    use_device(b);
+    hipEvent_t e_start = nullptr, e_stop = nullptr;
+    const bool dense = !(flags & VRG_SWEEP_NODENSE);
+    if (dense && ev && ev->enabled) {
+        if (b->ev_used == b->ev_pool.size()) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); b->ev_pool.push_back(n); }
+        EvPair& p = b->ev_pool[b->ev_used++];
+        e_start = p.a; e_stop = p.b;
+    }
+    k_band<<<BAND_BLOCKS + EXACT_BLOCKS, TPB, 0, b->sa>>>(c);
+    if (flags & VRG_SWEEP_SYNC) {
+        VrgState s;
+        HIP_CHECK(hipMemcpyAsync(&s, c.st, sizeof(s), hipMemcpyDeviceToHost, b->sa));
+        HIP_CHECK(hipStreamSynchronize(b->sa));
+        if (s.done || s.bail) return;
+        if (s.nf > b->small_flips || (flags & VRG_SWEEP_FULL)) host_driven_update(b, c, flags);
+        else small_update(b, c, dense);
+    } else {
+        small_update(b, c, dense);
+    }
+    if (!dense) return;
+    // dense stream: every voxel once, read-only; the gate holds it until the sweep's labels are in place
+    const bool ranks = c.world > 1 || b->comm || cb;
+    k_gate<<<1, 64, 0, b->sb>>>(c);
+    launch_recount(c, dense_blocks(b, c), ranks ? 1 : 2, b->sb, e_start, e_stop);
+    if (ranks) {                                     // one GPU: the last workgroup of the recount closes the pass itself
+        reduce_dense(b, c, cb, user, b->sb);         // sum over the Z-slabs (RCCL on the stream / host callback)
+        k_dense_fin<<<1, 1, 0, b->sb>>>(c);
+    }
+}
+
+void be_events_collect(VrgBackend* b, VrgEvents* ev, long long n_valid) {
     if (!ev) return;
-    if (g_ev_used) HIP_CHECK(hipStreamSynchronize(g_stream_b));   // the dense stream may trail the band stream by one pass
-    for (size_t i = 0; i < g_ev_used; i++) {
+    use_device(b);
+    if (b->ev_used) HIP_CHECK(hipStreamSynchronize(b->sb));   // the dense stream may trail the band stream by one pass
+    for (size_t i = 0; i < b->ev_used; i++) {
         if ((long long)i < n_valid) {
             float ms = 0;
-            if (hipEventElapsedTime(&ms, g_ev_pool[i].a, g_ev_pool[i].b) == hipSuccess) { ev->ms_total += ms; ev->launches++; }
+            if (hipEventElapsedTime(&ms, b->ev_pool[i].a, b->ev_pool[i].b) == hipSuccess) { ev->ms_total += ms; ev->launches++; }
             else (void)hipGetLastError();
         }
     }
-    g_ev_used = 0;
+    b->ev_used = 0;
 }
 
-void be_recount_hist(const VrgCtx& c, int par, int32_t* rin, int32_t* rout) {
-    k_recount_hist<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, rin, rout);
-    HIP_CHECK(hipStreamSynchronize(g_stream));
+void be_recount_hist(VrgBackend* b, const VrgCtx& c, int32_t* rin, int32_t* rout) {
+    use_device(b);
+    k_recount_hist<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, rin, rout);
+    HIP_CHECK(hipStreamSynchronize(b->sa));
 }
 
-uint32_t be_collect_segmented(const VrgCtx& c, int par, uint64_t* stamps, uint32_t* idxs, uint32_t cap) {
+uint32_t be_collect_segmented(VrgBackend* b, const VrgCtx& c, uint64_t* stamps, uint32_t* idxs, uint32_t cap) {
+    use_device(b);
     uint64_t* ds = nullptr; uint32_t* di = nullptr; uint32_t* dc = nullptr;
     HIP_CHECK(hipMalloc(&ds, (size_t)(cap + 1) * 8)); HIP_CHECK(hipMalloc(&di, (size_t)(cap + 1) * 4)); HIP_CHECK(hipMalloc(&dc, 4));
-    HIP_CHECK(hipMemsetAsync(dc, 0, 4, g_stream));
-    k_collect_seg<<<voxel_blocks(c), TPB, 0, g_stream>>>(c, ds, di, cap, dc);
+    if (!ds || !di || !dc) { if (ds) (void)hipFree(ds); if (di) (void)hipFree(di); if (dc) (void)hipFree(dc); return 0xffffffffu; }
+    HIP_CHECK(hipMemsetAsync(dc, 0, 4, b->sa));
+    k_collect_seg<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, ds, di, cap, dc);
     uint32_t n = 0;
-    HIP_CHECK(hipMemcpyAsync(&n, dc, 4, hipMemcpyDeviceToHost, g_stream));
-    HIP_CHECK(hipStreamSynchronize(g_stream));
+    HIP_CHECK(hipMemcpyAsync(&n, dc, 4, hipMemcpyDeviceToHost, b->sa));
+    HIP_CHECK(hipStreamSynchronize(b->sa));
     uint32_t m = std::min(n, cap);
     HIP_CHECK(hipMemcpy(stamps, ds, (size_t)m * 8, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(idxs, di, (size_t)m * 4, hipMemcpyDeviceToHost));

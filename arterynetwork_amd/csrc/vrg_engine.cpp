@@ -22,19 +22,26 @@
 
 struct vrg_handle {
     VrgCtx c;
+    VrgBackend* be = nullptr;
     std::string err;
     std::vector<void*> owned;
     int device = 0;
     bool have_vol = false, have_lab = false, inited = false;
+    bool sync_mode = false;              // trips are driven one at a time from the host (many flips per sweep)
     int variant = 0, batch = 8, storage16 = 0, dense_off = 0;
     uint16_t* lev16_buf = nullptr;
+    float* I32 = nullptr; double* I64 = nullptr;
     uint64_t band_capacity = 0;
+    uint64_t cap_floor = 1u << 16;       // smallest pool / marked-list capacity (tests lower it to exercise the growth paths)
     VrgEvents ev{0, 0.0, 0};
     std::chrono::steady_clock::time_point t0;
     int64_t V = 0;
+    size_t PVu = 0;
     uint8_t* lab_base[2] = {nullptr, nullptr};
     vrg_reduce_fn reduce_fn = nullptr;
     void* reduce_user = nullptr;
+    long long bails[4] = {0, 0, 0, 0};   // how often a trip came back, by VBAIL_* reason
+    long long sync_trips = 0;
 };
 
 extern "C" void API(destroy)(vrg_handle* h);
@@ -47,19 +54,36 @@ int fail(vrg_handle* h, int code, const std::string& msg) {
 }
 
 template <class T> T* alloc(vrg_handle* h, size_t n) {
-    void* p = be_alloc(std::max<size_t>(n, 1) * sizeof(T));
+    void* p = be_alloc(h->be, std::max<size_t>(n, 1) * sizeof(T));
     if (p) h->owned.push_back(p);
     return (T*)p;
 }
+void release(vrg_handle* h, void* p) {
+    if (!p) return;
+    auto it = std::find(h->owned.begin(), h->owned.end(), p);
+    if (it != h->owned.end()) h->owned.erase(it);
+    be_free(h->be, p);
+}
+// a larger array with the first `keep` elements carried over; false: out of memory (the old array stays)
+template <class T> bool grow(vrg_handle* h, T*& p, size_t keep, size_t n) {
+    T* q = alloc<T>(h, n);
+    if (!q) return false;
+    if (p && keep) be_copy(h->be, q, p, keep * sizeof(T));
+    be_sync(h->be);
+    release(h, p);
+    p = q;
+    return true;
+}
+uint64_t pow2_at_least(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
 
 VrgDense get_dense(vrg_handle* h) {     // region sizes as the band side keeps them + the sums of the last dense pass
-    VrgDense d; be_download(&d, h->c.dn, sizeof(d));
-    int64_t n[2]; be_download(n, h->c.inc, sizeof(n));
+    VrgDense d; be_download(h->be, &d, h->c.dn, sizeof(d));
+    int64_t n[2]; be_download(h->be, n, h->c.inc, sizeof(n));
     d.n_in = (double)n[0]; d.n_out = (double)n[1];
     return d;
 }
-VrgState get_state(vrg_handle* h) { VrgState s; be_download(&s, h->c.st, sizeof(s)); return s; }
-void put_state(vrg_handle* h, const VrgState& s) { be_upload(h->c.st, &s, sizeof(s)); }
+VrgState get_state(vrg_handle* h) { VrgState s; be_download(h->be, &s, h->c.st, sizeof(s)); return s; }
+void put_state(vrg_handle* h, const VrgState& s) { be_upload(h->be, h->c.st, &s, sizeof(s)); }
 
 void idx_to_xyz(const VrgCtx& c, uint32_t idx, int64_t* out) {
     int x, y, z; vrg_coords(c, idx, x, y, z);
@@ -67,12 +91,41 @@ void idx_to_xyz(const VrgCtx& c, uint32_t idx, int64_t* out) {
 }
 
 int check_state_error(vrg_handle* h, const VrgState& s) {
-    if (const char* be = be_last_error()) return fail(h, VRG_E_INTERNAL, be);
-    if (s.error == 1) return fail(h, VRG_E_CAPACITY, "band capacity exceeded; raise option band_capacity");
-    if (s.error == 2) return fail(h, VRG_E_CAPACITY, "flip capacity exceeded; raise option band_capacity");
-    if (s.error == 7) return fail(h, VRG_E_CAPACITY, "class-change list capacity exceeded; raise option band_capacity");
+    if (const char* be = be_last_error(h->be)) { std::string m = be; be_clear_error(h->be); return fail(h, VRG_E_INTERNAL, m); }
+    if (s.error == 1) return fail(h, VRG_E_CAPACITY, "band pool capacity exceeded");
+    if (s.error == 2) return fail(h, VRG_E_CAPACITY, "flip list capacity exceeded");
+    if (s.error == 4 || s.error == 7) return fail(h, VRG_E_CAPACITY, "marked-voxel list capacity exceeded");
     if (s.error) return fail(h, VRG_E_INTERNAL, "internal consistency check failed (code " + std::to_string(s.error) + ")");
     return VRG_OK;
+}
+
+// ---- arrays sized by demand ------------------------------------------------------------------------------
+// band pool + flip arrays (capacity bcap = fcap, a power of two); contents of the first `keep` slots survive
+bool size_pool(vrg_handle* h, uint64_t want, uint32_t keep, uint32_t keep_free) {
+    VrgCtx& c = h->c;
+    uint64_t cap = pow2_at_least(std::max<uint64_t>(want, h->cap_floor));
+    if (cap > 0x80000000ull) return false;
+    bool ok = grow(h, c.p_idx, keep, cap) && grow(h, c.p_lev, keep, cap) && grow(h, c.p_ip, keep, cap) && grow(h, c.p_op, keep, cap) &&
+              grow(h, c.p_key, keep, cap) && grow(h, c.p_flag, keep, cap) && grow(h, c.freel, keep_free, cap) &&
+              grow(h, c.flist, 0, cap) && grow(h, c.f_key, 0, cap) && grow(h, c.f_slot, 0, cap) && grow(h, c.f_idx, 0, cap) &&
+              grow(h, c.f_res, 0, cap) && grow(h, c.pend, 0, cap) && grow(h, c.fresh, keep, cap) &&
+              grow(h, c.init_key, 0, cap) && grow(h, c.init_idx, 0, cap);
+    if (!ok) return false;
+    if (cap > keep) be_fill(h->be, c.p_flag + keep, 0, cap - keep);
+    c.bcap = (uint32_t)cap; c.fcap = c.bcap;
+    return true;
+}
+// marked-voxel list, class-change lists, dead list (capacity mcap); the change lists' contents survive
+bool size_marks(vrg_handle* h, uint64_t want, bool keep) {
+    VrgCtx& c = h->c;
+    uint64_t cap = pow2_at_least(std::max<uint64_t>(want, h->cap_floor));
+    if (cap > 0x80000000ull) return false;
+    const size_t k = keep ? c.mcap : 0;
+    bool ok = grow(h, c.mk_idx, 0, cap) && grow(h, c.mk_new, 0, cap + 16) && grow(h, c.dead, 0, cap);
+    for (int p = 0; p < 2 && ok; p++) ok = grow(h, c.chg_dw[p], k, cap) && grow(h, c.chg_x[p], k, cap);
+    if (!ok) return false;
+    c.mcap = (uint32_t)cap;
+    return true;
 }
 
 }  // namespace
@@ -84,9 +137,11 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     *out = nullptr;
     if (nx < 1 || ny < 1 || nz < 1) return VRG_E_ARG;
     int64_t PX = (nx + 2 + 15) / 16 * 16, PY = ny + 4, PZ = nz + 4;
-    if ((double)PX * (double)PY * (double)PZ >= 4294967040.0) return VRG_E_ARG;   // 32-bit voxel indices
-    if (be_set_device(device) != 0) return VRG_E_NOGPU;
+    if ((double)PX * (double)PY * (double)PZ >= 4294960000.0) return VRG_E_ARG;   // 32-bit voxel indices, with room to round up
+    VrgBackend* be = be_create(device);
+    if (!be) return VRG_E_NOGPU;
     vrg_handle* h = new vrg_handle();
+    h->be = be;
     h->device = device;
     std::memset(&h->c, 0, sizeof(VrgCtx));
     VrgCtx& c = h->c;
@@ -96,42 +151,44 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.z0 = 0; c.z1 = (int32_t)nz;
     h->V = nx * ny * nz;
     const size_t PVu = ((size_t)c.PV + 1023) / 1024 * 1024;   // dense arrays end on a whole 1024-voxel unit
-    c.I = alloc<float>(h, PVu);
+    h->PVu = PVu;
     c.clsb[0] = alloc<uint32_t>(h, PVu / 16); c.clsb[1] = alloc<uint32_t>(h, PVu / 16);
     c.nchg = alloc<uint32_t>(h, 32);
     c.vent = alloc<uint32_t>(h, PVu);
     // 16 guard bytes in front: voxel (0,0,0)'s 2-ring reaches 2 bytes before the padded array
     h->lab_base[0] = alloc<uint8_t>(h, (size_t)c.PV + 32);
-    h->lab_base[1] = alloc<uint8_t>(h, (size_t)c.PV + 32);
     c.lab[0] = h->lab_base[0] ? h->lab_base[0] + 16 : nullptr;
-    c.lab[1] = h->lab_base[1] ? h->lab_base[1] + 16 : nullptr;
     c.stamp = alloc<uint64_t>(h, c.PV);
     c.st = alloc<VrgState>(h, 1);
     c.dn = alloc<VrgDense>(h, 16);                   // own allocation: written by the dense kernel only
     c.counters = alloc<uint32_t>(h, 64);
     c.dn_part = alloc<VrgDense>(h, 16);
     c.inc = alloc<int64_t>(h, 32); c.dctl = alloc<int64_t>(h, 32);   // one allocation each: written from different streams
+    c.nstat = 4096;
+    c.st_nin = alloc<int64_t>(h, c.nstat); c.st_nout = alloc<int64_t>(h, c.nstat);
+    c.st_sin = alloc<double>(h, c.nstat); c.st_sout = alloc<double>(h, c.nstat);
+    c.trace_cap = 1u << 16;
+    c.trace = alloc<VrgTrace>(h, c.trace_cap);
     c.world = 1;
-    if (!c.I || !c.lab[0] || !c.lab[1] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] || !c.nchg || !c.vent) { API(destroy)(h); return VRG_E_MEM; }
-    be_fill(c.inc, 0, 32 * sizeof(int64_t)); be_fill(c.dctl, 0, 32 * sizeof(int64_t));
-    be_fill((void*)c.I, 0, PVu * 4);
-    if (c.clsb[0]) be_fill(c.clsb[0], 0, PVu / 4);
-    if (c.clsb[1]) be_fill(c.clsb[1], 0, PVu / 4);
-    if (c.nchg) be_fill(c.nchg, 0, 32 * sizeof(uint32_t));
-    be_fill(h->lab_base[0], VB_OOB, (size_t)c.PV + 32);
-    be_fill(h->lab_base[1], VB_OOB, (size_t)c.PV + 32);
-    be_fill(c.st, 0, sizeof(VrgState));
-    be_fill(c.dn, 0, sizeof(VrgDense));
-    be_fill(c.dn_part, 0, sizeof(VrgDense));
-    be_fill(c.counters, 0, 64 * sizeof(uint32_t));
+    if (!c.lab[0] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
+        !c.nchg || !c.vent || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace) { API(destroy)(h); return VRG_E_MEM; }
+    be_fill(be, c.inc, 0, 32 * sizeof(int64_t)); be_fill(be, c.dctl, 0, 32 * sizeof(int64_t));
+    be_fill(be, c.clsb[0], 0, PVu / 4); be_fill(be, c.clsb[1], 0, PVu / 4);
+    be_fill(be, c.nchg, 0, 32 * sizeof(uint32_t));
+    be_fill(be, h->lab_base[0], VB_OOB, (size_t)c.PV + 32);
+    be_fill(be, c.st, 0, sizeof(VrgState));
+    be_fill(be, c.dn, 0, sizeof(VrgDense));
+    be_fill(be, c.dn_part, 0, sizeof(VrgDense));
+    be_fill(be, c.counters, 0, 64 * sizeof(uint32_t));
     *out = h;
     return VRG_OK;
 }
 
 void API(destroy)(vrg_handle* h) {
     if (!h) return;
-    be_sync();
-    for (void* p : h->owned) be_free(p);
+    be_sync(h->be);
+    for (void* p : h->owned) be_free(h->be, p);
+    be_destroy(h->be);
     delete h;
 }
 
@@ -141,11 +198,12 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     if (!h || !name) return VRG_E_ARG;
     std::string n(name);
     if (n == "band_capacity") { if (h->inited || value < 1) return fail(h, VRG_E_STATE, "band_capacity must be set before vrg_init"); h->band_capacity = (uint64_t)value; }
-    else if (n == "sweep_variant") h->variant = (int)value;
+    else if (n == "capacity_floor") { if (h->c.p_idx || value < 1) return fail(h, VRG_E_STATE, "capacity_floor must be set before the first vrg_init"); h->cap_floor = (uint64_t)value; }
+    else if (n == "sweep_variant") { if (h->inited) return fail(h, VRG_E_STATE, "sweep_variant must be set before vrg_init"); h->variant = (int)value; }
     else if (n == "events") h->ev.enabled = value != 0;
     else if (n == "dense_off") h->dense_off = value != 0;   // measurement aid: band chain alone; re-initialise afterwards
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
-    else if (n == "sweep_blocks" || n == "prio_mode" || n == "graph") be_set_tuning(name, value);
+    else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips") be_set_tuning(h->be, name, value);
     else if (n == "storage16") { if (h->inited) return fail(h, VRG_E_STATE, "storage16 must be set before vrg_init"); h->storage16 = value != 0; }
     else return fail(h, VRG_E_ARG, "unknown option " + n);
     return VRG_OK;
@@ -153,21 +211,36 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
 
 int API(set_volume)(vrg_handle* h, const void* data, int dtype, const int64_t st[3]) {
     if (!h || !data || !st || dtype < VRG_U8 || dtype > VRG_F64) return fail(h, VRG_E_ARG, "set_volume: bad argument");
+    VrgCtx& c = h->c;
+    // fp32 storage whenever every value is exactly representable (integer dtypes up to 16 bit, float32, and float64 /
+    // wider integers that happen to be); float64 storage otherwise (the dense pass then streams 8 B per voxel)
+    if (!h->I32) { h->I32 = alloc<float>(h, h->PVu); if (!h->I32) return fail(h, VRG_E_MEM, "set_volume: intensity volume"); be_fill(h->be, h->I32, 0, h->PVu * 4); }
     int inexact = 0;
-    int rc = be_pack_volume(h->c, (float*)h->c.I, data, dtype, st, &inexact);
+    int rc = be_pack_volume(h->be, c, h->I32, nullptr, data, dtype, st, &inexact);
     if (rc) return fail(h, VRG_E_ARG, "set_volume: unsupported strides");
-    if (inexact) return fail(h, VRG_E_INEXACT, "set_volume: intensities are not exactly representable in fp32");
+    if (inexact) {
+        if (!h->I64) { h->I64 = alloc<double>(h, h->PVu); if (!h->I64) return fail(h, VRG_E_MEM, "set_volume: float64 intensity volume"); be_fill(h->be, h->I64, 0, h->PVu * 8); }
+        rc = be_pack_volume(h->be, c, nullptr, h->I64, data, dtype, st, &inexact);
+        if (rc) return fail(h, VRG_E_ARG, "set_volume: unsupported strides");
+        c.I = nullptr; c.I64 = h->I64;
+    } else { c.I = h->I32; c.I64 = nullptr; }
     h->have_vol = true; h->inited = false;
-    h->c.lev = nullptr;                              // distinct-value table is rebuilt by the next vrg_init
+    if (c.lev) {                                     // distinct-value table and its arrays are rebuilt by the next vrg_init
+        release(h, (void*)c.lev); c.lev = nullptr;
+        release(h, c.hin); release(h, c.hout); release(h, c.dIn); release(h, c.dOut); release(h, c.dConv); release(h, c.ltouch);
+        release(h, c.nz_key); release(h, c.nz_val); release(h, c.nz_cin); release(h, c.nz_cout); release(h, c.nz_cconv); release(h, c.tabC);
+        c.hin = c.hout = nullptr; c.dIn = c.dOut = c.dConv = c.ltouch = nullptr; c.nz_key = nullptr; c.nz_val = nullptr;
+        c.nz_cin = c.nz_cout = c.nz_cconv = nullptr; c.tabC = nullptr; c.L = 0;
+    }
     return VRG_OK;
 }
 
 int API(set_labels)(vrg_handle* h, const void* labels, int dtype, const int64_t st[3]) {
     if (!h || !labels || !st || dtype < VRG_U8 || dtype > VRG_F64) return fail(h, VRG_E_ARG, "set_labels: bad argument");
-    be_fill(h->lab_base[0], VB_OOB, (size_t)h->c.PV + 32);
-    be_fill(h->lab_base[1], VB_OOB, (size_t)h->c.PV + 32);
+    be_sync(h->be);
+    be_fill(h->be, h->lab_base[0], VB_OOB, (size_t)h->c.PV + 32);
     int bad = 0;
-    int rc = be_pack_labels(h->c, h->c.lab[0], labels, dtype, st, &bad);
+    int rc = be_pack_labels(h->be, h->c, h->c.lab[0], labels, dtype, st, &bad);
     if (rc) return fail(h, VRG_E_ARG, "set_labels: unsupported strides");
     if (bad) return fail(h, VRG_E_ARG, "set_labels: valueMap must contain only 0 (seed), 3 (outside), 4 (excluded)");
     h->have_lab = true; h->inited = false;
@@ -179,87 +252,73 @@ int API(init)(vrg_handle* h, double H) {
     if (!h->have_vol || !h->have_lab) return fail(h, VRG_E_STATE, "vrg_init: set_volume and set_labels first");
     if (h->inited) return fail(h, VRG_E_STATE, "vrg_init: already initialised; set_labels again to restart");
     VrgCtx& c = h->c;
+    VrgBackend* be = h->be;
     h->t0 = std::chrono::steady_clock::now();       // start_time (:38)
     c.H = H;
     c.A = std::pow(2.0 * M_PI, -0.5);               // A = (2*np.pi)**(-0.5) (:7)
     // levels
-    double* lev = nullptr; uint32_t L = 0;
-    if (c.lev) { /* re-init on the same volume: keep */ lev = (double*)c.lev; L = c.L; }
-    else {
-        if (be_build_levels(c, &lev, &L)) return fail(h, VRG_E_MEM, "vrg_init: level table");
+    if (!c.lev) {
+        double* lev = nullptr; uint32_t L = 0;
+        if (be_build_levels(be, c, &lev, &L)) return fail(h, VRG_E_MEM, "vrg_init: level table");
         h->owned.push_back(lev);
-        c.lev = lev; c.L = L;
-        c.hin = alloc<int32_t>(h, L); c.hout = alloc<int32_t>(h, L);
-        c.dIn = alloc<uint32_t>(h, 2 * (size_t)L); c.dOut = alloc<uint32_t>(h, 2 * (size_t)L); c.dConv = alloc<uint32_t>(h, 2 * (size_t)L);
-        c.nz_lev = alloc<uint32_t>(h, L); c.nz_val = alloc<double>(h, L);
-        c.nz_cin = alloc<uint32_t>(h, L); c.nz_cout = alloc<uint32_t>(h, L); c.nz_cconv = alloc<uint32_t>(h, L);
-        c.tabC = alloc<double>(h, 3 * (size_t)L);
-        c.lscan = alloc<uint32_t>(h, (size_t)L + 16);
-        if (!c.hin || !c.hout || !c.dIn || !c.dOut || !c.dConv || !c.nz_lev || !c.nz_val || !c.nz_cin || !c.nz_cout || !c.nz_cconv || !c.tabC || !c.lscan)
+        const uint32_t zcap = (uint32_t)pow2_at_least(L);
+        int32_t* hin = alloc<int32_t>(h, L); int32_t* hout = alloc<int32_t>(h, L);
+        uint32_t* dIn = alloc<uint32_t>(h, L); uint32_t* dOut = alloc<uint32_t>(h, L); uint32_t* dConv = alloc<uint32_t>(h, L);
+        uint32_t* ltouch = alloc<uint32_t>(h, L);
+        uint64_t* nz_key = alloc<uint64_t>(h, zcap); double* nz_val = alloc<double>(h, zcap);
+        uint32_t* nz_cin = alloc<uint32_t>(h, zcap); uint32_t* nz_cout = alloc<uint32_t>(h, zcap); uint32_t* nz_cconv = alloc<uint32_t>(h, zcap);
+        double* tabC = alloc<double>(h, 3 * (size_t)L);
+        c.hin = hin; c.hout = hout; c.dIn = dIn; c.dOut = dOut; c.dConv = dConv; c.ltouch = ltouch;
+        c.nz_key = nz_key; c.nz_val = nz_val; c.nz_cin = nz_cin; c.nz_cout = nz_cout; c.nz_cconv = nz_cconv; c.tabC = tabC;
+        c.zcap = zcap; c.L = L;
+        if (!hin || !hout || !dIn || !dOut || !dConv || !ltouch || !nz_key || !nz_val || !nz_cin || !nz_cout || !nz_cconv || !tabC) {
+            release(h, lev);                         // c.lev stays null: the next vrg_init starts over
             return fail(h, VRG_E_MEM, "vrg_init: level arrays");
+        }
+        c.lev = lev;
     }
+    const uint32_t L = c.L;
     c.lev16 = nullptr;
     if (h->storage16) {                             // 16-bit intensity storage: level indices + LDS value table
         if (L > 16384) return fail(h, VRG_E_ARG, "storage16: more than 16384 distinct intensity values");
-        if (!h->lev16_buf) h->lev16_buf = alloc<uint16_t>(h, ((size_t)c.PV + 1023) / 1024 * 1024);
+        if (!h->lev16_buf) h->lev16_buf = alloc<uint16_t>(h, h->PVu);
         if (!h->lev16_buf) return fail(h, VRG_E_MEM, "vrg_init: 16-bit level volume");
-        be_build_lev16(c, h->lev16_buf);
+        be_build_lev16(be, c, h->lev16_buf);
         c.lev16 = h->lev16_buf;
     }
-    be_fill(c.hin, 0, (size_t)L * 4); be_fill(c.hout, 0, (size_t)L * 4);
-    be_fill(c.dIn, 0, (size_t)L * 8); be_fill(c.dOut, 0, (size_t)L * 8); be_fill(c.dConv, 0, (size_t)L * 8);
-    // band storage
-    if (!c.b_idx[0]) {
-        uint64_t V = (uint64_t)h->V;
-        uint64_t cap = h->band_capacity ? h->band_capacity : (V <= (32u << 20) ? V : std::max<uint64_t>(32u << 20, V / 8));
-        cap = std::min<uint64_t>(std::max<uint64_t>(cap, 64), V);
-        c.bcap = (uint32_t)cap; c.fcap = c.bcap;
-        for (int p = 0; p < 2; p++) {
-            c.b_idx[p] = alloc<uint32_t>(h, c.bcap); c.b_lev[p] = alloc<uint32_t>(h, c.bcap);
-            c.b_ip[p] = alloc<double>(h, c.bcap); c.b_op[p] = alloc<double>(h, c.bcap); c.b_pend[p] = alloc<uint8_t>(h, c.bcap);
-            if (c.b_pend[p]) be_fill(c.b_pend[p], 0, c.bcap);
-            if (!c.b_idx[p] || !c.b_lev[p] || !c.b_ip[p] || !c.b_op[p] || !c.b_pend[p]) return fail(h, VRG_E_MEM, "vrg_init: band arrays");
-        }
-        c.e_flag = alloc<uint8_t>(h, c.bcap); c.e_surv = alloc<uint8_t>(h, c.bcap); c.e_new = alloc<uint8_t>(h, c.bcap);
-        c.e_res = alloc<uint8_t>(h, c.bcap); c.e_mask = alloc<uint32_t>(h, c.bcap);
-        c.scan = alloc<uint32_t>(h, 3 * (size_t)c.bcap + 16);
-        c.bsum = alloc<uint32_t>(h, 1024);
-        c.flist = alloc<uint32_t>(h, c.fcap); c.fidx = alloc<uint32_t>(h, c.fcap);
-        c.pend = alloc<uint32_t>(h, c.fcap); c.fresh = alloc<uint32_t>(h, c.bcap);
-        c.init_key = alloc<uint64_t>(h, c.bcap); c.init_idx = alloc<uint32_t>(h, c.bcap);
-        c.mcap = (uint32_t)std::min<uint64_t>(V, 0xffffffffull);
-        c.mk_idx = alloc<uint32_t>(h, c.mcap); c.mk_new = alloc<uint8_t>(h, (size_t)c.mcap + 16);
-        // class changes of one sweep: its flips + the excluded voxels it includes - a small fraction of the band in
-        // practice; everything for small volumes, 2 x band when the caller sized the band explicitly
-        c.ccap = (uint32_t)std::min<uint64_t>(V, h->band_capacity ? 2 * (uint64_t)c.bcap : std::max<uint64_t>(4u << 20, c.bcap / 4));
-        for (int p = 0; p < 2; p++) {
-            c.chg_dw[p] = alloc<uint32_t>(h, c.ccap); c.chg_x[p] = alloc<uint32_t>(h, c.ccap);
-            if (!c.chg_dw[p] || !c.chg_x[p]) return fail(h, VRG_E_MEM, "vrg_init: class-change lists");
-        }
-        c.nstat = 4096;
-        c.st_nin = alloc<int64_t>(h, c.nstat); c.st_nout = alloc<int64_t>(h, c.nstat);
-        c.st_sin = alloc<double>(h, c.nstat); c.st_sout = alloc<double>(h, c.nstat);
-        c.trace_cap = 1u << 16;
-        c.trace = alloc<VrgTrace>(h, c.trace_cap);
-        if (!c.e_flag || !c.e_surv || !c.e_new || !c.scan || !c.bsum || !c.e_res || !c.e_mask || !c.flist || !c.fidx || !c.pend || !c.fresh ||
-            !c.init_key || !c.init_idx || !c.mk_idx || !c.mk_new || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace)
-            return fail(h, VRG_E_MEM, "vrg_init: work arrays");
+    c.lab[1] = nullptr;
+    if (h->variant & 1) {                           // full-stencil check variant: scratch label volume
+        if (!h->lab_base[1]) { h->lab_base[1] = alloc<uint8_t>(h, (size_t)c.PV + 32); if (!h->lab_base[1]) return fail(h, VRG_E_MEM, "vrg_init: scratch labels"); }
+        c.lab[1] = h->lab_base[1] + 16;
+        be_fill(be, h->lab_base[1], VB_OOB, (size_t)c.PV + 32);
     }
-    VrgState s; std::memset(&s, 0, sizeof(s));
-    s.iterMax = 0; s.maxSegmentSize = 0;
-    put_state(h, s);
-    be_init_band(c);
-    s = get_state(h);
-    if (s.error || (uint64_t)s.ninit_in + s.ninit_out > c.bcap) return fail(h, VRG_E_CAPACITY, "vrg_init: band capacity exceeded");
+    be_fill(be, c.hin, 0, (size_t)L * 4); be_fill(be, c.hout, 0, (size_t)L * 4);
+    be_fill(be, c.dIn, 0, (size_t)L * 4); be_fill(be, c.dOut, 0, (size_t)L * 4); be_fill(be, c.dConv, 0, (size_t)L * 4);
+    be_fill(be, c.ltouch, 0, (size_t)L * 4);
+    // band pool and work arrays: sized by demand (they grow when a trip reports that it needs more)
+    if (!c.p_idx && !size_pool(h, h->band_capacity, 0, 0)) return fail(h, VRG_E_MEM, "vrg_init: band arrays");
+    if (!c.mk_idx && !size_marks(h, 0, false)) return fail(h, VRG_E_MEM, "vrg_init: work arrays");
+    VrgState s;
+    for (int attempt = 0;; attempt++) {
+        std::memset(&s, 0, sizeof(s));
+        put_state(h, s);
+        be_init_band(be, c);
+        s = get_state(h);
+        const uint64_t need = (uint64_t)s.ninit_in + s.ninit_out;
+        if (need <= c.bcap) break;
+        // staging overflowed: the label pass is idempotent, so size the pool for what it counted and stage again
+        if (attempt || !size_pool(h, 2 * need, 0, 0)) return fail(h, VRG_E_MEM, "vrg_init: band arrays");
+    }
     if (s.nseed == 0) return fail(h, VRG_E_EMPTY, "vrg_init: valueMap has no seed (label 0) voxel");
-    be_init_sort(c, s.ninit_in, s.ninit_out);
-    s.ni = s.ninit_in; s.no = s.ninit_out; s.nfresh = s.ni + s.no;
+    be_init_sort(be, c, s.ninit_in, s.ninit_out);
+    s.ni = s.ninit_in; s.no = s.ninit_out; s.nfresh = s.ni + s.no; s.error = 0;
     put_state(h, s);
-    be_init_finish(c, h->reduce_fn, h->reduce_user);
+    be_fill(be, c.p_flag, 0, c.bcap);
+    be_init_finish(be, c, h->reduce_fn, h->reduce_user);
     s = get_state(h);
     int rc = check_state_error(h, s);
     if (rc) return rc;
-    h->inited = true;
+    h->inited = true; h->sync_mode = false;
     h->ev.ms_total = 0; h->ev.launches = 0;
     return VRG_OK;
 }
@@ -268,33 +327,52 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     if (!h) return VRG_E_ARG;
     if (!h->inited) return fail(h, VRG_E_STATE, "vrg_run: call vrg_init first");
     VrgCtx& c = h->c;
+    VrgBackend* be = h->be;
     if (iterMax < 0 || iterMax + 1 >= (int64_t)c.trace_cap) return fail(h, VRG_E_ARG, "vrg_run: iterMax out of range");
     VrgState s = get_state(h);
     int rc = check_state_error(h, s);
     if (rc) return rc;
     int32_t iter0 = s.iter;
-    s.done = 0; s.time_up = 0; s.iterMax = (int32_t)iterMax; s.maxSegmentSize = maxSegmentSize;
-    s.nf = 0; s.npend = 0; s.nmk = 0; s.nfresh = 0;      // counters of a trip that stopped before update()
+    s.done = 0; s.time_up = 0; s.bail = 0; s.iterMax = (int32_t)iterMax; s.maxSegmentSize = maxSegmentSize;
+    s.nf = 0; s.npend = 0; s.nmk = 0;                    // counters of a trip that stopped before update()
     put_state(h, s);
     double ms0 = h->ev.ms_total; long long l0 = h->ev.launches;
     auto t_begin = std::chrono::steady_clock::now();
+    const int base_flags = ((h->variant & 1) ? VRG_SWEEP_FULL : 0) | (h->dense_off ? VRG_SWEEP_NODENSE : 0);
+    const uint32_t small = be_small_flip_limit(be);
     for (;;) {
+        const bool sync = h->sync_mode || (base_flags & VRG_SWEEP_FULL);
         int64_t remaining = iterMax - s.iter;
-        int nb = (int)std::min<int64_t>(h->batch, std::max<int64_t>(remaining, 0) + 1);   // +1: the trip that sets the stop flag
+        int nb = sync ? 1 : (int)std::min<int64_t>(h->batch, std::max<int64_t>(remaining, 0) + 1);   // +1: the trip that sets the stop flag
         if (maxSeconds >= 0 && s.iter < iterMax) {   // wall-clock cap (:97): tested after the no-flip test, before update()
             double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->t0).count();
             if (el >= maxSeconds) { s.time_up = 1; put_state(h, s); nb = 1; }
         }
         int32_t before = s.iter;
-        for (int i = 0; i < nb; i++) be_sweep_once(c, h->variant | (h->dense_off ? 4 : 0), &h->ev, h->reduce_fn, h->reduce_user);
+        for (int i = 0; i < nb; i++) be_sweep_once(be, c, base_flags | (sync ? VRG_SWEEP_SYNC : 0), &h->ev, h->reduce_fn, h->reduce_user);
+        if (sync) h->sync_trips++;
         s = get_state(h);
-        be_events_collect(&h->ev, s.iter - before);
+        be_events_collect(be, &h->ev, s.iter - before);
         if (s.done || s.error) break;
+        if (s.bail) {                                // the trip was handed back untouched: make room / change mode, do it again
+            const uint64_t nf = s.nf;
+            h->bails[std::min(s.bail, 3)]++;
+            if (s.bail == VBAIL_FLIPS) h->sync_mode = true;
+            else if (s.bail == VBAIL_MARKS) {
+                if (nf * 125u > 0x3fffffffull || !size_marks(h, 2 * nf * 125u, true)) return fail(h, VRG_E_MEM, "vrg_run: marked-voxel arrays");
+            } else {
+                if (!size_pool(h, 2 * ((uint64_t)s.np + nf * 27u), s.np, s.nfree)) return fail(h, VRG_E_MEM, "vrg_run: band arrays");
+            }
+            s.bail = 0; s.nf = 0;
+            put_state(h, s);
+            continue;
+        }
+        if (h->sync_mode && 2 * (uint64_t)s.last_nf <= small) h->sync_mode = false;   // the flips fit one workgroup again
     }
-    be_sync();
+    be_sync(be);
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     int64_t dense_err = 0;                           // raised by the dense stream, possibly after the band side stopped
-    be_download(&dense_err, c.dctl + VD_ERR, sizeof(dense_err));
+    be_download(be, &dense_err, c.dctl + VD_ERR, sizeof(dense_err));
     if (h->dense_off) { dense_err = 0; h->inited = false; }   // the dense pass sequence is broken on purpose: init again
     if (dense_err) s.error = (int32_t)dense_err;
     rc = check_state_error(h, s);
@@ -311,7 +389,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
 
 int API(get_labels)(vrg_handle* h, void* outp, int dtype, const int64_t st[3]) {
     if (!h || !outp || !st || dtype < VRG_U8 || dtype > VRG_F64) return fail(h, VRG_E_ARG, "get_labels: bad argument");
-    if (be_unpack_labels(h->c, h->c.lab[0], outp, dtype, st)) return fail(h, VRG_E_ARG, "get_labels: unsupported strides");
+    if (be_unpack_labels(h->be, h->c, h->c.lab[0], outp, dtype, st)) return fail(h, VRG_E_ARG, "get_labels: unsupported strides");
     return VRG_OK;
 }
 
@@ -324,7 +402,7 @@ int API(get_segmented)(vrg_handle* h, int64_t* coords, int64_t cap, int64_t* n) 
     if (cap < nseg) return fail(h, VRG_E_ARG, "get_segmented: buffer too small");
     std::vector<uint64_t> stamps((size_t)nseg + 1);
     std::vector<uint32_t> idxs((size_t)nseg + 1);
-    uint32_t got = be_collect_segmented(h->c, 0, stamps.data(), idxs.data(), (uint32_t)nseg);
+    uint32_t got = be_collect_segmented(h->be, h->c, stamps.data(), idxs.data(), (uint32_t)nseg);
     if ((int64_t)got != nseg) return fail(h, VRG_E_INTERNAL, "get_segmented: count mismatch");
     std::vector<uint32_t> order(got);
     for (uint32_t i = 0; i < got; i++) order[i] = i;
@@ -334,22 +412,30 @@ int API(get_segmented)(vrg_handle* h, int64_t* coords, int64_t cap, int64_t* n) 
     return VRG_OK;
 }
 
+// innerBndList (which = 0) / outerBndList (1) in the reference's list order: the pool's live slots of that list, by key
 int API(get_band)(vrg_handle* h, int which, int64_t* coords, double* ip, double* op, int64_t cap, int64_t* n) {
     if (!h || !n) return VRG_E_ARG;
     if (!h->inited) return fail(h, VRG_E_STATE, "get_band: not initialised");
     VrgState s = get_state(h);
-    int par = s.iter & 1;
-    uint32_t cnt = which ? s.no : s.ni, off = which ? s.ni : 0;
+    uint32_t cnt = which ? s.no : s.ni;
     *n = cnt;
     if (!coords && !ip && !op) return VRG_OK;
     if (cap < cnt) return fail(h, VRG_E_ARG, "get_band: buffer too small");
+    const uint32_t np = s.np;
+    std::vector<uint8_t> flag(np + 1); std::vector<uint64_t> key(np + 1);
+    be_download(h->be, flag.data(), h->c.p_flag, np); be_download(h->be, key.data(), h->c.p_key, (size_t)np * 8);
+    std::vector<uint32_t> sel; sel.reserve(cnt);
+    const uint8_t want = (uint8_t)(PF_ALIVE | (which ? 0 : PF_INNER));
+    for (uint32_t i = 0; i < np; i++) if ((flag[i] & (PF_ALIVE | PF_INNER)) == want) sel.push_back(i);
+    if (sel.size() != cnt) return fail(h, VRG_E_INTERNAL, "get_band: list length differs from the pool's live slots");
+    std::sort(sel.begin(), sel.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+    std::vector<uint32_t> idx(np + 1); std::vector<double> v(np + 1);
     if (coords) {
-        std::vector<uint32_t> idx(cnt + 1);
-        be_download(idx.data(), h->c.b_idx[par] + off, (size_t)cnt * 4);
-        for (uint32_t i = 0; i < cnt; i++) idx_to_xyz(h->c, idx[i], coords + 3 * (size_t)i);
+        be_download(h->be, idx.data(), h->c.p_idx, (size_t)np * 4);
+        for (uint32_t i = 0; i < cnt; i++) idx_to_xyz(h->c, idx[sel[i]], coords + 3 * (size_t)i);
     }
-    if (ip) be_download(ip, h->c.b_ip[par] + off, (size_t)cnt * 8);
-    if (op) be_download(op, h->c.b_op[par] + off, (size_t)cnt * 8);
+    if (ip) { be_download(h->be, v.data(), h->c.p_ip, (size_t)np * 8); for (uint32_t i = 0; i < cnt; i++) ip[i] = v[sel[i]]; }
+    if (op) { be_download(h->be, v.data(), h->c.p_op, (size_t)np * 8); for (uint32_t i = 0; i < cnt; i++) op[i] = v[sel[i]]; }
     return VRG_OK;
 }
 
@@ -361,7 +447,8 @@ int API(get_trace)(vrg_handle* h, vrg_trace_rec* outp, int64_t cap, int64_t* n) 
     if (!outp) return VRG_OK;
     if (cap < *n) return fail(h, VRG_E_ARG, "get_trace: buffer too small");
     static_assert(sizeof(vrg_trace_rec) == sizeof(VrgTrace), "trace record layout");
-    be_download(outp, h->c.trace, (size_t)(*n) * sizeof(VrgTrace));
+    be_sync(h->be);                                  // the dense stream files the intensity sums
+    be_download(h->be, outp, h->c.trace, (size_t)(*n) * sizeof(VrgTrace));
     return VRG_OK;
 }
 
@@ -373,18 +460,28 @@ int API(get_levels)(vrg_handle* h, double* values, int32_t* hin, int32_t* hout, 
     *n = L;
     if (!values && !hin && !hout && !rin && !rout) return VRG_OK;
     if (cap < L) return fail(h, VRG_E_ARG, "get_levels: buffer too small");
-    if (values) be_download(values, h->c.lev, (size_t)L * 8);
-    if (hin) be_download(hin, h->c.hin, (size_t)L * 4);
-    if (hout) be_download(hout, h->c.hout, (size_t)L * 4);
+    if (values) be_download(h->be, values, h->c.lev, (size_t)L * 8);
+    if (hin) be_download(h->be, hin, h->c.hin, (size_t)L * 4);
+    if (hout) be_download(h->be, hout, h->c.hout, (size_t)L * 4);
     if (rin && rout) {
-        int32_t* di = (int32_t*)be_alloc((size_t)L * 4);
-        int32_t* dout = (int32_t*)be_alloc((size_t)L * 4);
+        int32_t* di = (int32_t*)be_alloc(h->be, (size_t)L * 4);
+        int32_t* dout = (int32_t*)be_alloc(h->be, (size_t)L * 4);
         if (!di || !dout) return fail(h, VRG_E_MEM, "get_levels");
-        be_fill(di, 0, (size_t)L * 4); be_fill(dout, 0, (size_t)L * 4);
-        be_recount_hist(h->c, 0, di, dout);
-        be_download(rin, di, (size_t)L * 4); be_download(rout, dout, (size_t)L * 4);
-        be_free(di); be_free(dout);
+        be_fill(h->be, di, 0, (size_t)L * 4); be_fill(h->be, dout, 0, (size_t)L * 4);
+        be_recount_hist(h->be, h->c, di, dout);
+        be_download(h->be, rin, di, (size_t)L * 4); be_download(h->be, rout, dout, (size_t)L * 4);
+        be_free(h->be, di); be_free(h->be, dout);
     }
+    return VRG_OK;
+}
+
+// how the run went (diagnostics): out[0..3] = trips handed back {-, flips, marks, pool}, out[4] = host-driven trips,
+// out[5] = pool capacity, out[6] = marked-list capacity, out[7] = pool slots in use
+int API(get_stats)(vrg_handle* h, int64_t* outp, int64_t cap) {
+    if (!h || !outp || cap < 8) return VRG_E_ARG;
+    for (int i = 0; i < 4; i++) outp[i] = h->bails[i];
+    outp[4] = h->sync_trips; outp[5] = h->c.bcap; outp[6] = h->c.mcap;
+    outp[7] = h->inited ? get_state(h).np : 0;
     return VRG_OK;
 }
 
@@ -400,7 +497,12 @@ int API(comm_unique_id)(void* id128) { return (id128 && be_comm_unique_id(id128)
 
 int API(comm_init)(vrg_handle* h, int nranks, int rank, const void* id128) {
     if (!h || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, VRG_E_ARG, "comm_init: bad argument");
-    if (be_comm_init(nranks, rank, id128) != 0) return fail(h, VRG_E_INTERNAL, "comm_init: RCCL communicator could not be created");
+    if (be_comm_init(h->be, nranks, rank, id128) != 0) {
+        const char* m = be_last_error(h->be);
+        std::string msg = m ? m : "comm_init: RCCL communicator could not be created";
+        be_clear_error(h->be);
+        return fail(h, VRG_E_INTERNAL, msg);
+    }
     h->c.world = nranks;
     return VRG_OK;
 }

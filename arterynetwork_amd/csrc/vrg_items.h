@@ -1,12 +1,12 @@
-// vrg_items.h - per-item device functions of the VRG sweep (one band entry, one listed flip, one voxel).
+// vrg_items.h - per-item device functions of the VRG sweep (one band slot, one listed flip, one voxel).
 //
 // These restate variationalRegionGrowing.py's SEQUENTIAL update() (:124-261) as order-independent
 // local rules so that every item can run in parallel.  Derivation (validated against the oracle and
 // the reference goldens in tests/):
 //
 //  * flip list = concat(innerBnd, outerBnd)[mask] (:48,:88,:111): all flip-outs (label 1) precede all
-//    flip-ins (label 2).  Only the ORDER of that list matters, and only between 26-neighbours, so the
-//    position e of a voxel in concat(innerBnd, outerBnd) (its band entry index) serves as its "rank".
+//    flip-ins (label 2).  Only the ORDER of that list matters, and only between 26-neighbours; the "rank" of a
+//    flip is its position in the list.
 //  * phase A (flip-outs, :170-196), always applied:  P: 1->2.  A label-0 neighbour becomes 1 (:194).
 //    A label-2 voxel next to a flip-out becomes 3 iff no segmented neighbour is left after all
 //    flip-outs (:186-190) - for a flipped-out voxel itself only if a flip-out neighbour of larger rank
@@ -19,12 +19,19 @@
 //    itself only if an applied flip-in neighbour of larger rank re-examines it ("ghost" 1 otherwise).
 //  * 4->3 inclusion: 1-ring of every listed flip (:166-168) and 2-ring of every applied flip
 //    (:177-179, :206-208).
-//  * list order after the sweep (:257-258): survivors keep their order; appended in order:
-//    inner: phase-A promotions keyed (rank of first flip-out neighbour, k) then applied flip-ins by rank;
-//    outer: flip-outs still labelled 2 by rank, then phase-B promotions keyed (rank of first applied
-//    flip-in neighbour, k); k = position of the promoted voxel in get_neighbours(promoter) (:263-282).
+//  * LIST ORDER (:257-258).  After a sweep: survivors keep their order; appended in order:
+//      inner: phase-A promotions keyed (rank of first flip-out neighbour, k), then applied flip-ins by rank;
+//      outer: flip-outs still labelled 2 by rank, then phase-B promotions keyed (rank of first applied
+//      flip-in neighbour, k); k = position of the promoted voxel in get_neighbours(promoter) (:263-282).
+//    So a 64-bit key per band entry,
+//          key = sweep that appended it << 40 | phase << 39 | rank of the appending flip << 5 | k
+//    (phase 0 = the first group of each list above, 1 = the second; init: sweep 0, rest = init position), orders
+//    each list exactly as the reference does, and an entry keeps its key for as long as it stays in its list.
+//    Nothing is rebuilt per sweep: the flips (tens) are sorted by (list, key) to get their ranks, everything
+//    else keeps its pool slot.
 //  * densities (:232-255): incremental correction for entries that stayed in the band for the whole
-//    sweep, exact recomputation for entries that (re-)entered it (newInnerBndList/newOuterBndList).
+//    sweep (added by the NEXT trip's k_band on its way through the pool), exact recomputation for entries that
+//    (re-)entered it (newInnerBndList/newOuterBndList; slot flag PF_PEND).
 #pragma once
 #include <math.h>
 #include "vrg_types.h"
@@ -36,9 +43,14 @@ VRG_HD int32_t vrg_atomic_add(int32_t* p, int32_t v) { return atomicAdd(p, v); }
 VRG_HD uint32_t vrg_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 VRG_HD void vrg_atomic_add64(int64_t* p, int64_t v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 VRG_HD void vrg_atomic_xor(uint32_t* p, uint32_t v) { atomicXor(p, v); }
+// loads that are served by L2: for bytes / counters that atomics of the SAME kernel may have changed (atomics execute
+// in L2; a plain load could be answered from a line this CU cached before)
 VRG_HD uint8_t vrg_load_coherent(const uint8_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+VRG_HD uint32_t vrg_load_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VRG_HD int32_t vrg_load_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VRG_HD int64_t vrg_load_i64(const int64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #else
 VRG_HD uint32_t vrg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 VRG_HD int32_t vrg_atomic_add(int32_t* p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
@@ -46,6 +58,9 @@ VRG_HD uint32_t vrg_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o
 VRG_HD void vrg_atomic_add64(int64_t* p, int64_t v) { *p += v; }
 VRG_HD void vrg_atomic_xor(uint32_t* p, uint32_t v) { *p ^= v; }
 VRG_HD uint8_t vrg_load_coherent(const uint8_t* p) { return *(const volatile uint8_t*)p; }
+VRG_HD uint32_t vrg_load_u32(const uint32_t* p) { return *p; }
+VRG_HD int32_t vrg_load_i32(const int32_t* p) { return *p; }
+VRG_HD int64_t vrg_load_i64(const int64_t* p) { return *p; }
 #endif
 
 // OR bits into one label byte without disturbing concurrent ORs into its neighbours
@@ -73,13 +88,57 @@ VRG_HD int32_t vrg_off(const VrgCtx& c, int k) {
     int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
     return (dz * c.PY + dy) * c.PX + dx;
 }
-// the 27 label bytes around idx in one go: straight-line loads, so that the device issues them back to back and
-// waits once (a loop with tests between the loads waits for every byte: 26 dependent L2 round trips)
-VRG_HD void vrg_load_nbrs(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t nb[27]) {
+// The 3x3x3 neighbourhood of a voxel as four 27-bit masks (S, L, P, OOB bit of every neighbour).  The labels are
+// fetched as nine 4-byte rows (x-1 .. x+2 of the nine (dy,dz) lines; x is the fastest axis, and the padding makes every
+// row readable); neighbour n = 3*j + (dx+1) with j = 3*(dy+1) + (dz+1) sits at bit n, the centre at bit 13.  All the
+// stencil logic below is bit arithmetic on these masks, and the few neighbours it has to visit (promoters, later
+// flips) are found by iterating set bits - compact code: one workgroup's instruction stream is fetched cold on every
+// launch, and the band kernels are bound by that and by dependent loads, not by arithmetic.
+struct VrgNbr { uint32_t S, L, P, O; };
+VRG_HD uint32_t vrg_load_row(const uint8_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // served by L2 (not by a line this CU cached before atomics of the same kernel changed it); rows are not aligned
+    return __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p));
+#else
+    uint32_t w; __builtin_memcpy(&w, p, 4); return w;
+#endif
+}
+VRG_HD uint64_t vrg_load_row8(const uint8_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(p));
+#else
+    uint64_t w; __builtin_memcpy(&w, p, 8); return w;
+#endif
+}
+// bits 0, 8, 16 of t (one label bit of the three bytes of a row) gathered into bits 0..2
+VRG_HD uint32_t vrg_gather3(uint32_t t) { return (((t & 0x010101u) * 0x00010204u) >> 16) & 7u; }
+VRG_HD VrgNbr vrg_load_masks(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
+    VrgNbr m = {0u, 0u, 0u, 0u};
+    uint32_t w[9];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int k = 0; k < 27; k++) nb[k] = lab[(int64_t)idx + vrg_off(c, k)];
+    for (int j = 0; j < 9; j++) w[j] = vrg_load_row(lab + ((int64_t)idx + ((j % 3 - 1) * c.PY + (j / 3 - 1)) * c.PX - 1));
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 9; j++) {
+        m.S |= vrg_gather3(w[j]) << (3 * j);      m.L |= vrg_gather3(w[j] >> 3) << (3 * j);
+        m.P |= vrg_gather3(w[j] >> 4) << (3 * j); m.O |= vrg_gather3(w[j] >> 5) << (3 * j);
+    }
+    return m;
+}
+// neighbour n of the masks: its voxel offset, and its position k in get_neighbours' order (:266-269: dx slowest)
+VRG_HD int32_t vrg_noff(const VrgCtx& c, uint32_t n) {
+    const int j = (int)(n / 3u);
+    return ((j % 3 - 1) * c.PY + (j / 3 - 1)) * c.PX + ((int)(n % 3u) - 1);
+}
+VRG_HD uint32_t vrg_nk(uint32_t n) { return (n % 3u) * 9u + n / 3u; }
+VRG_HD uint32_t vrg_ctz(uint32_t v) { return (uint32_t)__builtin_ctz(v); }
+
+// the 27 label bytes around idx one by one (skip-rule fix-point only)
+VRG_HD void vrg_load_nbrs(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t nb[27]) {
+    for (int k = 0; k < 27; k++) nb[k] = vrg_load_coherent(lab + ((int64_t)idx + vrg_off(c, k)));
 }
 
 VRG_HD uint8_t vrg_enc(uint8_t ext) {     // reference label -> byte
@@ -93,51 +152,87 @@ VRG_HD uint8_t vrg_dec(uint8_t b) {       // byte -> reference label
 
 VRG_HD double vrg_kern(const VrgCtx& c, double d) { return c.A * exp(-0.5 * c.H * (d * d)); }   // :154
 
+VRG_HD double vrg_voxel_value(const VrgCtx& c, uint32_t idx) { return c.I ? (double)c.I[idx] : c.I64[idx]; }
 VRG_HD uint32_t vrg_level_of(const VrgCtx& c, double v) {   // index of v in the sorted distinct values
     uint32_t lo = 0, hi = c.L - 1;
     while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (c.lev[m] < v) lo = m + 1; else hi = m; }
     return lo;
 }
-
-// the per-level delta counters (dIn, dOut, dConv) exist twice: sweep iter+1 counts into the copy of parity iter & 1,
-// so that the kernel that consumes them can leave clearing to the sweep after (see k_levels_tab_scan)
-VRG_HD uint32_t vrg_delta_off(const VrgCtx& c) { return (c.st->iter & 1) ? c.L : 0u; }
 // level index of a voxel's intensity: stored (16-bit mode) or looked up in the sorted level table
 VRG_HD uint32_t vrg_voxel_level(const VrgCtx& c, uint32_t idx) {
-    return c.lev16 ? (uint32_t)c.lev16[idx] : vrg_level_of(c, (double)c.I[idx]);
+    return c.lev16 ? (uint32_t)c.lev16[idx] : vrg_level_of(c, vrg_voxel_value(c, idx));
 }
 
-// ------------------------------------------------------------------ decide (:79-88) + listing
-// One item per band entry.  A flip is listed at once: L bit (+P for flip-outs, which are always
-// applied), stamp = (sweep, entry index) and an unordered append to the flip list.
-VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, uint32_t e, double ip, double op) {
-    int cur = s.iter & 1;
-    const uint32_t idx = c.b_idx[cur][e];
+// ------------------------------------------------------------------ list order
+VRG_HD uint64_t vrg_key(const VrgState& s, uint32_t phase, uint32_t rank, uint32_t k) {
+    return ((uint64_t)(uint32_t)(s.iter + 1) << 40) | ((uint64_t)phase << 39) | ((uint64_t)rank << 5) | (uint64_t)k;
+}
+// sort key of a listed flip: inner list before outer list (:48), each in list order
+VRG_HD uint64_t vrg_flip_key(const VrgCtx& c, uint32_t slot) {
+    return ((c.p_flag[slot] & PF_INNER) ? 0ull : (1ull << 63)) | c.p_key[slot];
+}
+
+// ------------------------------------------------------------------ k_band: correction of the sweep before + decide (:79-88)
+// density correction of one intensity value (:236-247)
+VRG_HD void vrg_corrections(const VrgCtx& c, uint32_t nnz, const double* nz_val, const uint32_t* nz_cin, const uint32_t* nz_cout,
+                            const uint32_t* nz_cconv, double v, double& ic, double& oc, double& ac) {
+    double a = 0, b = 0, d = 0;
+    for (uint32_t i = 0; i < nnz; i++) {
+        double k = vrg_kern(c, nz_val[i] - v);
+        a += (double)nz_cin[i] * k; b += (double)nz_cout[i] * k; d += (double)nz_cconv[i] * k;
+    }
+    ic = a; oc = b; ac = d;
+}
+VRG_HD void vrg_add_correction(double ic, double oc, double ac, double& ip, double& op) {
+    ip += ic; ip -= oc;             // :243-244
+    op -= ic; op += oc; op += ac;   // :245-247
+}
+// A flip is listed by an unordered append of its slot; the sweep kernel orders the list.
+VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, uint32_t slot, bool inner, double ip, double op) {
     const int64_t n_in = c.inc[VC_NIN], n_out = c.inc[VC_NOUT];
     double inN = ip / (double)n_in;                       // :81
     double outN = op / (double)n_out;                     // :82
     bool ge = inN >= outN;
-    bool inner = e < s.ni;
-    bool flip = inner != ge;                              // :87 xor(segmentedMap, inner >= outer)
-    c.e_flag[e] = flip ? 1 : 0; c.e_res[e] = 0; c.e_mask[e] = 0; c.e_new[e] = 0;
-    if (!flip) return;
+    if (inner == ge) return;                              // :87 xor(segmentedMap, inner >= outer)
     uint32_t q = vrg_atomic_add(&c.st->nf, 1u);
     if (s.time_up || n_in >= s.maxSegmentSize) return;    // :97 / :101 fire before update(): count only
     if (q >= c.fcap) { c.st->error = 2; return; }
-    c.flist[q] = e; c.fidx[q] = idx;
-    vrg_or_byte(c.lab[0], idx, (uint8_t)(VB_L | (inner ? VB_P : 0)));
-    c.stamp[idx] = ((uint64_t)(uint32_t)(s.iter + 1) << 32) | e;
+    c.flist[q] = slot;
 }
-// skip_pending (device): an entry whose densities are still to be computed exactly is decided by the wave that
-// computes them (exact half of k_decide_exact), not here
-VRG_HD void vrg_item_decide(const VrgCtx& c, uint32_t e, bool skip_pending) {
-    const VrgState s = *c.st;                             // a copy (nf is only ever bumped atomically)
-    if (s.iter >= s.iterMax) return;                      // while iterNum <= iterMax (:58)
-    const double ip = c.b_ip[s.iter & 1][e], op = c.b_op[s.iter & 1][e];
-    if (skip_pending && c.b_pend[s.iter & 1][e]) return;
-    vrg_decide_core(c, s, e, ip, op);
+// one pool slot; nz_* = this trip's view of the touched-level list (LDS copy on the device)
+VRG_HD void vrg_item_band(const VrgCtx& c, const VrgState& s, uint32_t slot, const double* nz_val, const uint32_t* nz_cin,
+                          const uint32_t* nz_cout, const uint32_t* nz_cconv) {
+    const uint8_t fl = c.p_flag[slot];
+    if (!(fl & PF_ALIVE)) return;
+    // an entry that (re-)entered the band in the sweep before takes no correction; it is decided by whoever computes
+    // its exact densities (the other half of this launch, which reads only the list bit of the flag)
+    if (fl & PF_PEND) { c.p_flag[slot] = (uint8_t)(fl & ~PF_PEND); return; }
+    double ip = c.p_ip[slot], op = c.p_op[slot];
+    if (s.corr) {
+        const uint32_t lev = c.p_lev[slot];
+        double ic, oc, ac;
+        if (s.use_tab) { ic = c.tabC[3 * (size_t)lev]; oc = c.tabC[3 * (size_t)lev + 1]; ac = c.tabC[3 * (size_t)lev + 2]; }
+        else vrg_corrections(c, s.nnz, nz_val, nz_cin, nz_cout, nz_cconv, c.lev[lev], ic, oc, ac);
+        vrg_add_correction(ic, oc, ac, ip, op);
+        c.p_ip[slot] = ip; c.p_op[slot] = op;
+    }
+    if (s.iter < s.iterMax) vrg_decide_core(c, s, slot, fl & PF_INNER, ip, op);   // while iterNum <= iterMax (:58)
+}
+// exact densities over the whole inner / outer regions (:152-155, :252-255), regrouped by level
+VRG_HD void vrg_exact_serial(const VrgCtx& c, const VrgState& s, uint32_t slot, bool then_decide) {
+    double v = c.lev[c.p_lev[slot]];
+    double si = 0, so = 0;
+    for (uint32_t l = 0; l < c.L; l++) {
+        int32_t a = c.hin[l], b = c.hout[l];
+        if (!(a | b)) continue;
+        double k = vrg_kern(c, c.lev[l] - v);
+        si += (double)a * k; so += (double)b * k;
+    }
+    c.p_ip[slot] = si; c.p_op[slot] = so;
+    if (then_decide && s.iter < s.iterMax) vrg_decide_core(c, s, slot, c.p_flag[slot] & PF_INNER, si, so);
 }
 
+// ------------------------------------------------------------------ the sweep (update(), :156-259)
 // the stop tests in the reference's order, once every entry has decided (the host raises time_up)
 VRG_HD int32_t vrg_stop_test(const VrgCtx& c) {
     const VrgState& s = *c.st;
@@ -147,35 +242,48 @@ VRG_HD int32_t vrg_stop_test(const VrgCtx& c) {
     if (c.inc[VC_NIN] >= s.maxSegmentSize) return VRG_STOP_SIZE;           // :101
     return 0;
 }
+// can this trip's update() run with the arrays as they are?  (checked before anything is modified)
+VRG_HD int32_t vrg_capacity_test(const VrgCtx& c, uint64_t nf) {
+    const VrgState& s = *c.st;
+    if (nf * 125u > (uint64_t)c.mcap) return VBAIL_MARKS;                // 5x5x5 marks per flip, as many class changes at most
+    if ((uint64_t)s.np + nf * 27u > (uint64_t)c.bcap) return VBAIL_POOL; // a flip promotes at most its 26 neighbours
+    return 0;
+}
+// the trip stops (or is handed back): nothing pending for the next k_band
+VRG_HD void vrg_close_without_update(const VrgCtx& c) { c.st->corr = 0; c.st->nfx = 0; }
+// update() begins: k_band has consumed the touched-level list of the sweep before
+VRG_HD void vrg_open_update(const VrgCtx& c) { c.st->nnz = 0; c.st->tab_ok = c.L <= c.st->ni + c.st->no; }
+
+// flip r of the ordered list: L bit (+P for flip-outs, which are always applied), stamp = (sweep, rank)
+VRG_HD void vrg_item_list(const VrgCtx& c, uint32_t r) {
+    const uint32_t slot = c.f_slot[r], idx = c.p_idx[slot];
+    c.f_idx[r] = idx; c.f_res[r] = 0;
+    vrg_or_byte(c.lab[0], idx, (uint8_t)(VB_L | ((c.p_flag[slot] & PF_INNER) ? VB_P : 0)));
+    c.stamp[idx] = ((uint64_t)(uint32_t)(c.st->iter + 1) << 32) | r;
+}
 
 // flip-ins: label after phase A (:183-190) decides whether the flip is applied at once
 VRG_HD void vrg_item_prepass(const VrgCtx& c, uint32_t r) {
-    VrgState& s = *c.st;
-    const uint32_t e = c.flist[r], idx = c.fidx[r];
-    if (e < s.ni) return;
-    const uint8_t* lab = c.lab[0];
-    bool nFO = false, nSegA = false;
-    uint8_t nb[27]; vrg_load_nbrs(c, lab, idx, nb);
-    for (int k = 0; k < 27; k++) {
-        if (k == 13) continue;
-        uint8_t m = nb[k];
-        if (m & VB_S) { if (m & VB_L) nFO = true; else nSegA = true; }
-    }
-    if (nFO && !nSegA) c.pend[vrg_atomic_add(&s.npend, 1u)] = e;   // dropped to 3: skipped unless re-promoted
+    const uint32_t idx = c.f_idx[r];
+    const VrgNbr m = vrg_load_masks(c, c.lab[0], idx);
+    if (m.S & (1u << 13)) return;                          // a flip-out
+    const uint32_t ex = ~m.O & 0x7ffdfffu;                 // existing neighbours (centre excluded)
+    const bool nFO = (m.S & m.L & ex) != 0, nSegA = (m.S & ~m.L & ex) != 0;
+    if (nFO && !nSegA) c.pend[vrg_atomic_add(&c.st->npend, 1u)] = r;   // dropped to 3: skipped unless re-promoted
     else vrg_or_byte(c.lab[0], idx, VB_P);
 }
 
 // one relaxation of the skip rule: applied if an applied flip-in neighbour of smaller rank exists
 // returns 0: still skipped, 1: found applied (by whoever), 2: applied by this call
 VRG_HD int vrg_item_fix(const VrgCtx& c, uint32_t j) {
-    uint32_t e = c.pend[j], idx = c.b_idx[c.st->iter & 1][e];
+    const uint32_t r = c.pend[j], idx = c.f_idx[r];
     uint8_t* lab = c.lab[0];
     if (vrg_load_coherent(lab + idx) & VB_P) return 1;
     for (int k = 0; k < 27; k++) {
         if (k == 13) continue;
         uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
         uint8_t mb = vrg_load_coherent(lab + m);
-        if (!(mb & VB_S) && (mb & VB_L) && (mb & VB_P) && (uint32_t)c.stamp[m] < e) {
+        if (!(mb & VB_S) && (mb & VB_L) && (mb & VB_P) && (uint32_t)c.stamp[m] < r) {
             vrg_or_byte(lab, idx, VB_P);
             return 2;
         }
@@ -187,40 +295,225 @@ VRG_HD int vrg_item_fix(const VrgCtx& c, uint32_t j) {
 // voxels of its 2-ring (needed for applied flips; harmless for a skipped flip-in, whose 2-ring voxels
 // then simply keep their label); the first marker of a voxel appends it to the marked list.
 // Everything else keeps its label this sweep.  Item = (listed flip r, position p of the 5x5x5 cube).
-#define VB_M 128
-VRG_HD void vrg_item_scatter_marks(const VrgCtx& c, uint32_t r, uint32_t p) {
-    if (p >= 125) return;
-    uint8_t* lab = c.lab[0];
-    uint32_t idx = c.fidx[r];
+#define VRG_NONE 0xffffffffu
+// position p of the 5x5x5 cube around flip voxel idx: does that voxel need the stencil? (its byte mb is passed in)
+VRG_HD bool vrg_mark_wanted(uint32_t p, uint8_t mb) {
     int dx = (int)(p % 5) - 2, dy = (int)((p / 5) % 5) - 2, dz = (int)(p / 25) - 2;
     bool ring1 = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
-    int64_t m = (int64_t)idx + (dz * c.PY + dy) * c.PX + dx;   // may be -1,-2 (guard bytes) at voxel (0,0,0)
-    uint8_t mb = lab[m];
-    if (mb & (VB_OOB | VB_M)) return;
-    if (!ring1 && !(mb & VB_X)) return;
+    if (mb & (VB_OOB | VB_M)) return false;
+    return ring1 || (mb & VB_X);
+}
+VRG_HD int64_t vrg_mark_pos(const VrgCtx& c, uint32_t idx, uint32_t p) {
+    int dx = (int)(p % 5) - 2, dy = (int)((p / 5) % 5) - 2, dz = (int)(p / 25) - 2;
+    return (int64_t)idx + (dz * c.PY + dy) * c.PX + dx;    // may be -1,-2 (guard bytes) at voxel (0,0,0)
+}
+// set the mark; true: this caller is the first marker (it appends the voxel to the marked list)
+VRG_HD bool vrg_mark_set(const VrgCtx& c, int64_t m) {
     uint32_t sh = 8 * ((uint32_t)m & 3u);
-    uint32_t old = vrg_atomic_or((uint32_t*)(lab + ((uint32_t)m & ~3u)), (uint32_t)VB_M << sh);
-    if (!((old >> sh) & VB_M)) {
+    uint32_t old = vrg_atomic_or((uint32_t*)(c.lab[0] + ((uint32_t)m & ~3u)), (uint32_t)VB_M << sh);
+    return !((old >> sh) & VB_M);
+}
+VRG_HD void vrg_item_scatter_marks(const VrgCtx& c, uint32_t r, uint32_t p) {
+    if (p >= 125) return;
+    const int64_t m = vrg_mark_pos(c, c.f_idx[r], p);
+    if (!vrg_mark_wanted(p, vrg_load_coherent(c.lab[0] + m))) return;
+    if (vrg_mark_set(c, m)) {
         uint32_t q = vrg_atomic_add(&c.st->nmk, 1u);
         if (q < c.mcap) c.mk_idx[q] = (uint32_t)m; else c.st->error = 4;
     }
 }
-// sparse relabel, phase 1: new byte of every marked voxel from the OLD labels (nothing is written to
-// the label volume yet, so all stencil reads see the pre-sweep state)
-VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t cb);
-#define VE_VALID 0x80          // e_new: the relabel visited the entry's voxel (new bytes never carry bit 7 = VB_M)
+
+// ---- what a relabelled voxel does to the band pool and the density bookkeeping
+// this sweep's innerAdded / outerAdded / addedPoints (:232-235), by level; the first toucher lists the level
+VRG_HD void vrg_note_level(const VrgCtx& c, uint32_t* cnt, uint32_t lev) {
+    vrg_atomic_add(&cnt[lev], 1u);
+    if (vrg_atomic_or(&c.ltouch[lev], 1u) == 0u) {
+        uint32_t q = vrg_atomic_add(&c.st->nnz, 1u);
+        if (q < c.zcap) c.nz_key[q] = lev; else c.st->error = 8;
+    }
+}
+// What the relabel of one voxel means for the band pool: at most one event per voxel.  The stencil only DESCRIBES it;
+// committing it - slot allocation, lists of dead / pending slots, list lengths - is separate, so that a workgroup can
+// commit all its events with one reservation per list (every event bumping the same few words would serialise in L2).
+enum : uint8_t { VE_NONE = 0, VE_NEW = 1, VE_DIE = 2, VE_MOVE = 3 };
+struct VrgEvent {
+    uint64_t key;                // list-order key of a new / re-appended entry
+    uint32_t slot, lev;          // slot concerned (DIE, MOVE); level of a new entry
+    uint8_t kind, from_inner, to_inner, pend;   // pend: (re-)entered the band - exact densities due (:252-255)
+};
+VRG_HD void vrg_ev_new(VrgEvent& e, uint32_t lev, bool inner, uint64_t key) { e.kind = VE_NEW; e.lev = lev; e.to_inner = inner; e.key = key; e.pend = 1; }
+VRG_HD void vrg_ev_die(VrgEvent& e, uint32_t slot, bool inner) { e.kind = VE_DIE; e.slot = slot; e.from_inner = inner; }
+VRG_HD void vrg_ev_move(VrgEvent& e, uint32_t slot, bool from_inner, bool to_inner, uint64_t key, bool pend) {
+    e.kind = VE_MOVE; e.slot = slot; e.from_inner = from_inner; e.to_inner = to_inner; e.key = key; e.pend = pend;
+}
+// list length changes of an event
+VRG_HD int vrg_ev_dni(const VrgEvent& e) { return e.kind == VE_NEW ? (e.to_inner ? 1 : 0) : e.kind == VE_DIE ? (e.from_inner ? -1 : 0) : e.kind == VE_MOVE ? (int)(e.to_inner != 0) - (int)(e.from_inner != 0) : 0; }
+VRG_HD int vrg_ev_dno(const VrgEvent& e) { return e.kind == VE_NEW ? (e.to_inner ? 0 : 1) : e.kind == VE_DIE ? (e.from_inner ? 0 : -1) : e.kind == VE_MOVE ? (int)(e.from_inner != 0) - (int)(e.to_inner != 0) : 0; }
+// the writes of a commit, once the positions are known: q = this event's number among the sweep's allocations,
+// qd / qf = its place in the dead / pending lists
+VRG_HD void vrg_ev_write(const VrgCtx& c, uint32_t idx, const VrgEvent& e, uint32_t q, uint32_t qd, uint32_t qf) {
+    const VrgState& s = *c.st;
+    uint32_t slot = e.slot;
+    if (e.kind == VE_NEW) {                               // a voxel enters the band (newInnerBndList / newOuterBndList, :196, :213)
+        slot = q < s.nfree ? c.freel[s.nfree - 1u - q] : s.np + (q - s.nfree);
+        if (slot >= c.bcap) { c.st->error = 1; return; }
+        c.p_idx[slot] = idx; c.p_lev[slot] = e.lev; c.p_ip[slot] = 0; c.p_op[slot] = 0; c.p_key[slot] = e.key;
+        c.p_flag[slot] = (uint8_t)(PF_ALIVE | PF_PEND | (e.to_inner ? PF_INNER : 0));
+        c.vent[idx] = slot;
+    } else if (e.kind == VE_DIE) {                        // ... leaves it (list.remove, :171-172, :188, :199, :226)
+        c.p_flag[slot] = 0;
+        c.dead[qd] = slot;
+    } else if (e.kind == VE_MOVE) {                       // ... is re-appended to a list (a carried flip; or left and re-entered: pend)
+        c.p_key[slot] = e.key;
+        c.p_flag[slot] = (uint8_t)(PF_ALIVE | (e.to_inner ? PF_INNER : 0) | (e.pend ? PF_PEND : 0));
+    }
+    if (e.kind != VE_DIE && e.pend) c.fresh[qf] = slot;
+}
+// one event committed on its own (host-driven kernels, test model)
+VRG_HD void vrg_commit_event(const VrgCtx& c, uint32_t idx, const VrgEvent& e) {
+    if (e.kind == VE_NONE) return;
+    uint32_t q = 0, qd = 0, qf = 0;
+    if (e.kind == VE_NEW) q = vrg_atomic_add(&c.st->nalloc, 1u);
+    if (e.kind == VE_DIE) qd = vrg_atomic_add(&c.st->ndead, 1u);
+    if (e.kind != VE_DIE && e.pend) qf = vrg_atomic_add(&c.st->nfresh, 1u);
+    const int di = vrg_ev_dni(e), dq = vrg_ev_dno(e);
+    if (di) vrg_atomic_add(&c.st->d_ni, di);
+    if (dq) vrg_atomic_add(&c.st->d_no, dq);
+    vrg_ev_write(c, idx, e, q, qd, qf);
+}
+
+// ------------------------------------------------------------------ the relabel stencil for one voxel
+// who promotes this voxel - `cand` = its applied flip-in neighbours (phase B, 3 -> 2, :210-213) or its flip-out
+// neighbours (phase A, 0 -> 1, :194-196): the one of smallest rank; (rank, k) is the list key of the promoted voxel,
+// k = its position in get_neighbours(promoter) = 26 - the promoter's position seen from here
+VRG_HD void vrg_promoter(const VrgCtx& c, uint32_t cand, uint32_t idx, uint32_t& rank, uint32_t& k_out) {
+    uint32_t best = 0xffffffffu, bk = 0;
+    while (cand) {
+        const uint32_t n = vrg_ctz(cand); cand &= cand - 1u;
+        const uint32_t r = (uint32_t)c.stamp[(uint32_t)((int64_t)idx + vrg_noff(c, n))];
+        if (r < best) { best = r; bk = 26u - vrg_nk(n); }
+    }
+    rank = best; k_out = bk;
+}
+// is one of the listed neighbours in `cand` of larger rank than r?
+VRG_HD bool vrg_later_flip(const VrgCtx& c, uint32_t cand, uint32_t idx, uint32_t r) {
+    while (cand) {
+        const uint32_t n = vrg_ctz(cand); cand &= cand - 1u;
+        if ((uint32_t)c.stamp[(uint32_t)((int64_t)idx + vrg_noff(c, n))] > r) return true;
+    }
+    return false;
+}
+// an excluded voxel: is an applied flip within its 2-ring (:177-179, :206-208)?  25 rows of 5 bytes
+VRG_HD bool vrg_ring2_applied(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
+    for (int j = 0; j < 25; j++) {
+        const uint64_t w = vrg_load_row8(lab + ((int64_t)idx + ((j / 5 - 2) * c.PY + (j % 5 - 2)) * c.PX - 2));
+        if (((w >> 4) & ~(w >> 5)) & 0x0101010101ull) return true;         // P and not OOB, bytes 0..4
+    }
+    return false;
+}
+
+// Returns the voxel's byte after the sweep and files what the change means for the band pool (slot born / dead /
+// re-appended), the class histograms and the sweep's level deltas.  `lab` = this sweep's input labels (L/P bits
+// set); nothing is written to the label volume here, so every stencil read sees the pre-sweep state.
+VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t cb, VrgEvent& ev) {
+    ev.kind = VE_NONE; ev.pend = 0;
+    const VrgNbr m = vrg_load_masks(c, lab, idx);
+    const uint32_t ex = ~m.O & 0x7ffdfffu;                 // neighbours that exist (:278-280), centre excluded
+    const uint32_t segA = m.S & ~m.L & ex, FO = m.S & m.L & ex, AP = ~m.S & m.P & ex;
+    const bool nSegA = segA != 0, nFO = FO != 0, nAP = AP != 0, nNonSegB = (ex & ~(segA | AP)) != 0, nListed = (m.L & ex) != 0;
+    const VrgState& s = *c.st;
+    if (cb & VB_S) {
+        if (cb & VB_L) {                              // flip-out (:170-175), always applied
+            const uint32_t r = (uint32_t)c.stamp[idx], slot = c.f_slot[r], lev = c.p_lev[slot];
+            vrg_atomic_add(&c.hin[lev], -1); vrg_atomic_add(&c.hout[lev], 1);
+            const bool to3 = !nSegA && vrg_later_flip(c, FO, idx, r);   // re-examined by a later flip-out neighbour? (:183-190)
+            if (!to3) {                               // stays 2, carried to the outer list (by rank)
+                c.f_res[r] = FR_WRITTEN | 2;
+                vrg_note_level(c, c.dOut, lev);
+                vrg_ev_move(ev, slot, true, false, vrg_key(s, 0, r, 0), false);
+                return VB_B;
+            }
+            if (nAP) {                                // 3 -> 2 again (:210-213): a new outer entry
+                c.f_res[r] = FR_WRITTEN | 2 | FR_FRESH;
+                vrg_note_level(c, c.dOut, lev);
+                uint32_t pr, pk; vrg_promoter(c, AP, idx, pr, pk);
+                vrg_ev_move(ev, slot, true, false, vrg_key(s, 1, pr, pk), true);
+                return VB_B;
+            }
+            c.f_res[r] = FR_WRITTEN | 3;
+            vrg_ev_die(ev, slot, true);
+            return 0;
+        }
+        bool is1 = (cb & VB_B) || nFO;                // label after phase A (:194)
+        if (!is1) return VB_S;
+        if (nAP && !nNonSegB) {                       // 1 -> 0 (:223-228)
+            if (cb & VB_B) vrg_ev_die(ev, c.vent[idx], true);
+            return VB_S;
+        }
+        if (!(cb & VB_B)) {                           // newly on the inner boundary
+            uint32_t pr, pk; vrg_promoter(c, FO, idx, pr, pk);
+            vrg_ev_new(ev, vrg_voxel_level(c, idx), true, vrg_key(s, 0, pr, pk));
+        }
+        return VB_S | VB_B;
+    }
+    if (cb & VB_B) {
+        if ((cb & VB_L) && (cb & VB_P)) {             // applied flip-in (:198-204)
+            const uint32_t r = (uint32_t)c.stamp[idx], slot = c.f_slot[r], lev = c.p_lev[slot];
+            vrg_atomic_add(&c.hin[lev], 1); vrg_atomic_add(&c.hout[lev], -1);
+            const bool to0 = !nNonSegB && vrg_later_flip(c, AP, idx, r);   // re-examined by a later applied flip-in nbr? (:219-228)
+            bool fresh = nFO && !nSegA;               // had dropped to 3 in phase A: exact density (:212,:251)
+            c.f_res[r] = (uint8_t)(FR_WRITTEN | (to0 ? 0 : 1) | (fresh ? FR_FRESH : 0));
+            if (to0) { vrg_ev_die(ev, slot, false); return VB_S; }
+            vrg_note_level(c, c.dIn, lev);
+            vrg_ev_move(ev, slot, false, true, vrg_key(s, 1, r, 0), fresh);   // appended to the inner list by rank
+            return VB_S | VB_B;
+        }
+        bool to3 = nFO && !nSegA;                     // :183-190
+        uint8_t out, res;
+        if (!to3) { out = VB_B; res = 2; }
+        else if (nAP) {                               // left the band and re-entered: a new outer entry
+            out = VB_B; res = 2 | FR_FRESH;
+            uint32_t pr, pk; vrg_promoter(c, AP, idx, pr, pk);
+            vrg_ev_move(ev, c.vent[idx], false, false, vrg_key(s, 1, pr, pk), true);
+        } else { out = 0; res = 3; vrg_ev_die(ev, c.vent[idx], false); }
+        if (cb & VB_L) {                              // skipped flip-in
+            const uint32_t r = (uint32_t)c.stamp[idx];
+            c.f_res[r] = (uint8_t)(FR_WRITTEN | res);
+            if ((res & FR_FINAL) == 2) vrg_note_level(c, c.dOut, c.p_lev[c.f_slot[r]]);
+        }
+        return out;
+    }
+    // labels 3 and 4
+    bool conv = false;
+    uint32_t lev = 0xffffffffu;
+    if (cb & VB_X) {
+        conv = nListed || vrg_ring2_applied(c, lab, idx);   // 1-ring of any listed flip (:166-168), 2-ring of any applied flip
+        if (conv) {                                   // addedPoints (:235); the voxel joins the outer region
+            lev = vrg_voxel_level(c, idx);
+            vrg_note_level(c, c.dConv, lev);
+            vrg_atomic_add(&c.hout[lev], 1);
+        }
+    }
+    if (nAP) {                                        // 3 -> 2 (:210-213)
+        if (lev == 0xffffffffu) lev = vrg_voxel_level(c, idx);
+        uint32_t pr, pk; vrg_promoter(c, AP, idx, pr, pk);
+        vrg_ev_new(ev, lev, false, vrg_key(s, 1, pr, pk));
+        return VB_B;
+    }
+    return (uint8_t)(((cb & VB_X) && !conv) ? VB_X : 0);
+}
+
+// sparse relabel, phase 1: new byte of every marked voxel from the OLD labels
 VRG_HD void vrg_item_relabel(const VrgCtx& c, uint32_t i) {
-    uint32_t idx = c.mk_idx[i];
-    const uint32_t e = c.vent[idx];                        // meaningful only for a band voxel (B bit)
-    const uint8_t cb = c.lab[0][idx];
-    const uint8_t nw = vrg_sweep_core(c, c.lab[0], idx, cb);
-    c.mk_new[i] = nw;
-    if (cb & VB_B) c.e_new[e] = (uint8_t)(nw | VE_VALID);  // the entry's survivor test need not wait for k_apply
+    const uint32_t idx = c.mk_idx[i];
+    VrgEvent ev;
+    c.mk_new[i] = vrg_sweep_core(c, c.lab[0], idx, vrg_load_coherent(c.lab[0] + idx), ev);
+    vrg_commit_event(c, idx, ev);
 }
 // phase 2: write the new bytes (this also clears the L / P / mark bits)
 // class of a label for the region statistics (:113-116): 1 inner (S), 2 outer (neither S nor excluded), 0 neither
 VRG_HD uint32_t vrg_cls_of(uint8_t b) { return (b & VB_S) ? 1u : ((b & (VB_X | VB_OOB)) ? 0u : 2u); }
-// where voxel idx keeps its two class bits (layout: VrgCtx::cls)
+// where voxel idx keeps its two class bits (layout: VrgCtx::clsb)
 VRG_HD void vrg_cls_pos(uint32_t idx, uint32_t& dw, uint32_t& sh) {
     uint32_t o = idx & 1023u;
     dw = ((idx >> 10) << 6) | ((o & 255u) >> 2);
@@ -236,7 +529,7 @@ VRG_HD void vrg_count_change(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t
     const uint32_t x = (a ^ b) << sh;
     vrg_atomic_xor(&c.clsb[p][dw], x);
     uint32_t q = vrg_atomic_add(&c.nchg[p], 1u);
-    if (q < c.ccap) { c.chg_dw[p][q] = dw; c.chg_x[p][q] = x; } else c.st->error = 7;
+    if (q < c.mcap) { c.chg_dw[p][q] = dw; c.chg_x[p][q] = x; } else c.st->error = 7;
     int din = (int)(b == 1u) - (int)(a == 1u), dout = (int)(b == 2u) - (int)(a == 2u);
     if (din) vrg_atomic_add64(&c.inc[VC_NIN], din);
     if (dout) vrg_atomic_add64(&c.inc[VC_NOUT], dout);
@@ -246,18 +539,20 @@ VRG_HD void vrg_item_catchup(const VrgCtx& c, uint32_t i) {
     const int p = (c.st->iter + 1) & 1;
     vrg_atomic_xor(&c.clsb[p][c.chg_dw[p ^ 1][i]], c.chg_x[p ^ 1][i]);
 }
-VRG_HD uint32_t vrg_catchup_count(const VrgCtx& c) { uint32_t n = c.nchg[((c.st->iter + 1) & 1) ^ 1]; return n < c.ccap ? n : c.ccap; }
-VRG_HD void vrg_item_apply(const VrgCtx& c, uint32_t i) {
-    uint32_t idx = c.mk_idx[i];
-    uint8_t old = c.lab[0][idx], nw = c.mk_new[i];
-    c.lab[0][idx] = (uint8_t)(nw & ~VB_F);                 // F is a note to the entry's survivor test (e_new), not a label bit
+VRG_HD uint32_t vrg_catchup_count(const VrgCtx& c) { uint32_t n = vrg_load_u32(&c.nchg[((c.st->iter + 1) & 1) ^ 1]); return n < c.mcap ? n : c.mcap; }
+VRG_HD void vrg_apply_voxel(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t nw) {
+    c.lab[0][idx] = nw;
     vrg_count_change(c, idx, old, nw);
+}
+VRG_HD void vrg_item_apply(const VrgCtx& c, uint32_t i) {
+    const uint32_t idx = c.mk_idx[i];
+    vrg_apply_voxel(c, idx, vrg_load_coherent(c.lab[0] + idx), c.mk_new[i]);
 }
 // one caller, after every label of sweep iter+1 is written and before anything of the next sweep: file the sizes
 // that sweep's dense pass has to reproduce; the change list just consumed becomes the next sweep's
 VRG_HD void vrg_post_apply(const VrgCtx& c) {
     const int64_t k = (int64_t)c.st->iter + 1;
-    c.inc[VC_EXP + 2 * (k & 3)] = c.inc[VC_NIN]; c.inc[VC_EXP + 2 * (k & 3) + 1] = c.inc[VC_NOUT];
+    c.inc[VC_EXP + 2 * (k & 3)] = vrg_load_i64(&c.inc[VC_NIN]); c.inc[VC_EXP + 2 * (k & 3) + 1] = vrg_load_i64(&c.inc[VC_NOUT]);
     c.nchg[(k & 1) ^ 1] = 0;
 }
 // init: class dword d from the labels (16 voxels), both copies
@@ -289,243 +584,50 @@ VRG_HD void vrg_init_counts(const VrgCtx& c) {
     c.dctl[VD_SEQ] = 0; c.dctl[VD_ERR] = 0; c.nchg[0] = 0; c.nchg[1] = 0;
 }
 
-// ------------------------------------------------------------------ the relabel stencil for one voxel
-// phase-B promotion (3 -> 2, :210-213): list key (first applied flip-in neighbour, k)
-VRG_HD void vrg_promote_b(const VrgCtx& c, const uint8_t* nb, uint32_t idx) {
-    uint32_t best = 0xffffffffu; int bk = 0;
-    for (int k = 0; k < 27; k++) {
-        if (k == 13) continue;
-        uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
-        uint8_t mb = nb[k];
-        if (!(mb & VB_S) && (mb & VB_P)) {
-            uint32_t r = (uint32_t)c.stamp[m];
-            if (r < best) { best = r; bk = 26 - k; }
-        }
-    }
-    vrg_atomic_or(&c.e_mask[best], 1u << bk);
+// ------------------------------------------------------------------ closing the sweep
+// the slots that died go onto the free list, below the entries this sweep's allocations consumed from its top
+VRG_HD uint32_t vrg_free_used(uint32_t nalloc, uint32_t nfree) { return nalloc < nfree ? nalloc : nfree; }
+VRG_HD void vrg_item_free(const VrgCtx& c, uint32_t j) {
+    const uint32_t nfree = c.st->nfree;                   // (not changed during the sweep)
+    c.freel[nfree - vrg_free_used(vrg_load_u32(&c.st->nalloc), nfree) + j] = c.dead[j];
 }
-// phase-A promotion (0 -> 1, :194-196): list key (first flip-out neighbour, k)
-VRG_HD void vrg_promote_a(const VrgCtx& c, const uint8_t* nb, uint32_t idx) {
-    uint32_t best = 0xffffffffu; int bk = 0;
-    for (int k = 0; k < 27; k++) {
-        if (k == 13) continue;
-        uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
-        uint8_t mb = nb[k];
-        if ((mb & VB_S) && (mb & VB_L)) {
-            uint32_t r = (uint32_t)c.stamp[m];
-            if (r < best) { best = r; bk = 26 - k; }
-        }
-    }
-    vrg_atomic_or(&c.e_mask[best], 1u << bk);
+// touched level j of the level-sorted list: value and counts out of the per-level counters.  clear: the counters go
+// back to zero at once; otherwise whoever opens the next update() clears them (vrg_item_level_clear) - the two-launch
+// closing kernel lets other workgroups read the counters while this runs.
+VRG_HD void vrg_item_level_clear(const VrgCtx& c, uint32_t j) {
+    const uint32_t l = (uint32_t)c.nz_key[j];
+    c.dIn[l] = 0; c.dOut[l] = 0; c.dConv[l] = 0; c.ltouch[l] = 0;
 }
-
-// Returns the voxel's byte after the sweep.  Side effects for the rare cases: e_res (listed flips),
-// e_mask (promotions), dConv (4->3 inclusions).  Ranks (low stamp word) are band entry indices.  `lab` = this sweep's input labels (L/P bits set).
-VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t cb) {
-    bool nSegA = false, nFO = false, nAP = false, nNonSegB = false, nListed = false;
-    uint8_t nb[27]; vrg_load_nbrs(c, lab, idx, nb);
-    for (int k = 0; k < 27; k++) {
-        if (k == 13) continue;
-        uint8_t m = nb[k];
-        if (m & VB_OOB) continue;                     // neighbour does not exist (:278-280)
-        bool mS = m & VB_S, mL = m & VB_L, mP = m & VB_P;
-        bool segA = mS && !mL, ap = !mS && mP;
-        nSegA |= segA; nFO |= (mS && mL); nAP |= ap; nNonSegB |= !(segA || ap); nListed |= mL;
-    }
-    if (cb & VB_S) {
-        if (cb & VB_L) {                              // flip-out (:170-175), always applied
-            uint32_t r = (uint32_t)c.stamp[idx];
-            bool to3 = false;
-            if (!nSegA)                               // re-examined by a later flip-out neighbour? (:183-190)
-                for (int k = 0; k < 27 && !to3; k++) {
-                    if (k == 13) continue;
-                    uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
-                    uint8_t mb = nb[k];
-                    if ((mb & VB_S) && (mb & VB_L) && (uint32_t)c.stamp[m] > r) to3 = true;
-                }
-            if (!to3) { c.e_res[r] = FR_WRITTEN | 2; return VB_B; }          // stays 2, carried to the outer list
-            if (nAP) {                                                      // 3 -> 2 again (:210-213): fresh
-                c.e_res[r] = FR_WRITTEN | 2 | FR_FRESH;
-                vrg_promote_b(c, nb, idx);
-                return VB_B;
-            }
-            c.e_res[r] = FR_WRITTEN | 3;
-            return 0;
-        }
-        bool is1 = (cb & VB_B) || nFO;                // label after phase A (:194)
-        if (!is1) return VB_S;
-        if (nAP && !nNonSegB) return VB_S;            // 1 -> 0 (:223-228)
-        if (!(cb & VB_B)) vrg_promote_a(c, nb, idx); // newly on the inner boundary
-        return VB_S | VB_B;
-    }
-    if (cb & VB_B) {
-        if ((cb & VB_L) && (cb & VB_P)) {             // applied flip-in (:198-204)
-            uint32_t r = (uint32_t)c.stamp[idx];
-            bool to0 = false;
-            if (!nNonSegB)                            // re-examined by a later applied flip-in nbr? (:219-228)
-                for (int k = 0; k < 27 && !to0; k++) {
-                    if (k == 13) continue;
-                    uint32_t m = (uint32_t)((int64_t)idx + vrg_off(c, k));
-                    uint8_t mb = nb[k];
-                    if (!(mb & VB_S) && (mb & VB_P) && (uint32_t)c.stamp[m] > r) to0 = true;
-                }
-            bool fresh = nFO && !nSegA;               // had dropped to 3 in phase A: exact density (:212,:251)
-            c.e_res[r] = (uint8_t)(FR_WRITTEN | (to0 ? 0 : 1) | (fresh ? FR_FRESH : 0));
-            return to0 ? (uint8_t)VB_S : (uint8_t)(VB_S | VB_B);
-        }
-        bool to3 = nFO && !nSegA;                     // :183-190
-        uint8_t out, res;
-        if (!to3) { out = VB_B; res = 2; }
-        else if (nAP) { out = VB_B | VB_F; res = 2 | FR_FRESH; vrg_promote_b(c, nb, idx); }
-        else { out = 0; res = 3; }
-        if (cb & VB_L) c.e_res[(uint32_t)c.stamp[idx]] = (uint8_t)(FR_WRITTEN | res);   // skipped flip-in
-        return out;
-    }
-    // labels 3 and 4
-    bool conv = false;
-    if (cb & VB_X) {
-        conv = nListed;                               // 1-ring of any listed flip (:166-168)
-        if (!conv)                                    // 2-ring of any applied flip (:177-179,:206-208)
-            for (int dz = -2; dz <= 2 && !conv; dz++)
-                for (int dy = -2; dy <= 2 && !conv; dy++)
-                    for (int dx = -2; dx <= 2; dx++) {
-                        uint8_t mb = lab[(int64_t)idx + (dz * c.PY + dy) * c.PX + dx];
-                        if ((mb & VB_P) && !(mb & VB_OOB)) { conv = true; break; }
-                    }
-        if (conv) vrg_atomic_add(&c.dConv[vrg_delta_off(c) + vrg_voxel_level(c, idx)], 1u);   // addedPoints (:235)
-    }
-    if (nAP) { vrg_promote_b(c, nb, idx); return VB_B; }   // 3 -> 2 (:210-213)
-    return (uint8_t)(((cb & VB_X) && !conv) ? VB_X : 0);
+VRG_HD void vrg_item_level(const VrgCtx& c, uint32_t j, bool clear) {
+    const uint32_t l = (uint32_t)c.nz_key[j];
+    c.nz_val[j] = c.lev[l];
+    c.nz_cin[j] = vrg_load_u32(&c.dIn[l]); c.nz_cout[j] = vrg_load_u32(&c.dOut[l]); c.nz_cconv[j] = vrg_load_u32(&c.dConv[l]);
+    if (clear) vrg_item_level_clear(c, j);
 }
-
-// ------------------------------------------------------------------ after the relabel
-// Rebuild count array (length 3n, exclusive-scanned into new list positions), n = ni + no, j = e - ni:
-//   A0[e]  inner survivors          A1[e]  voxels promoted to 1 by flip-out e     A2[j]  flip-ins now labelled 1
-//   B0[j]  outer survivors          B1[e]  flip-outs still labelled 2 (carried)   B2[j]  voxels promoted to 2 by flip-in j
-// laid out [A0|A1|A2|B0|B1|B2]: exactly the append order of innerBndList / outerBndList (:257-258).
-VRG_HD uint32_t vrg_slot_A0(const VrgState&, uint32_t e) { return e; }
-VRG_HD uint32_t vrg_slot_A1(const VrgState& s, uint32_t e) { return s.ni + e; }
-VRG_HD uint32_t vrg_slot_A2(const VrgState& s, uint32_t j) { return 2 * s.ni + j; }
-VRG_HD uint32_t vrg_slot_B0(const VrgState& s, uint32_t j) { return 2 * s.ni + s.no + j; }
-VRG_HD uint32_t vrg_slot_B1(const VrgState& s, uint32_t e) { return 2 * s.ni + 2 * s.no + e; }
-VRG_HD uint32_t vrg_slot_B2(const VrgState& s, uint32_t j) { return 3 * s.ni + 2 * s.no + j; }
-
-// per old band entry: survivor test, and for listed flips the density bookkeeping sets (:232-233) and
-// the class histograms
-VRG_HD void vrg_item_entry_post(const VrgCtx& c, uint32_t e) {
-    const VrgState s = *c.st;                                 // a copy: no reloads after the stores below
-    int cur = s.iter & 1;
-    const uint8_t* lab = c.lab[0];
-    // independent loads first (one round trip), then the one that depends on idx
-    uint32_t idx = c.b_idx[cur][e], lev = c.b_lev[cur][e], mask = c.e_mask[e];
-    uint8_t res = c.e_res[e], en = c.e_new[e];
-    bool inner = e < s.ni, flag = c.e_flag[e] != 0;
-    // the voxel's byte after the sweep: from the relabel if it visited the voxel, else the label it kept (k_apply,
-    // which may run beside this kernel, only rewrites visited voxels)
-    uint8_t nb = (en & VE_VALID) ? (uint8_t)(en & ~VE_VALID) : lab[idx];
-    uint8_t fin = res & FR_FINAL;
-    bool fresh = res & FR_FRESH;
-    if (!flag) mask = 0u;
-    if (flag) {
-        if (!(res & FR_WRITTEN)) c.st->error = 3;             // a listed flip the relabel never visited
-        if (fin == 1) vrg_atomic_add(&c.dIn[vrg_delta_off(c) + lev], 1u);        // innerAdded: listed flips labelled 1 at the end
-        else if (fin == 2) vrg_atomic_add(&c.dOut[vrg_delta_off(c) + lev], 1u);  // outerAdded: ... labelled 2
-        if (inner) { vrg_atomic_add(&c.hin[lev], -1); vrg_atomic_add(&c.hout[lev], 1); }             // flip-out
-        else if (fin <= 1) { vrg_atomic_add(&c.hin[lev], 1); vrg_atomic_add(&c.hout[lev], -1); }     // applied flip-in
+// a listed flip the relabel never visited would be an internal error
+VRG_HD void vrg_item_check_flip(const VrgCtx& c, uint32_t r) { if (!(c.f_res[r] & FR_WRITTEN)) c.st->error = 3; }
+// iterNum += 1 (:117), list lengths, free list, trace record; what the next k_band finds pending
+VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
+    VrgState s = *c.st;                               // one round trip for the whole state, one to write it back
+    // ... the counters this kernel's atomics moved come from L2
+    s.nalloc = vrg_load_u32(&c.st->nalloc); s.ndead = vrg_load_u32(&c.st->ndead); s.nfresh = vrg_load_u32(&c.st->nfresh);
+    s.nnz = vrg_load_u32(&c.st->nnz); s.nmk = vrg_load_u32(&c.st->nmk); s.npend = vrg_load_u32(&c.st->npend);
+    s.d_ni = vrg_load_i32(&c.st->d_ni); s.d_no = vrg_load_i32(&c.st->d_no); s.error = vrg_load_i32(&c.st->error);
+    const int64_t n_in = vrg_load_i64(&c.inc[VC_NIN]), n_out = vrg_load_i64(&c.inc[VC_NOUT]);
+    const uint32_t used = vrg_free_used(s.nalloc, s.nfree);
+    s.np += s.nalloc - used; s.nfree = s.nfree - used + s.ndead;
+    s.ni = (uint32_t)((int32_t)s.ni + s.d_ni); s.no = (uint32_t)((int32_t)s.no + s.d_no);
+    s.iter++;
+    if ((uint32_t)s.iter < c.trace_cap) {
+        VrgTrace& t = c.trace[s.iter];                // the intensity sums are filed by the dense pass (vrg_dense_fin)
+        t.nflip = s.nf; t.nseg = n_in; t.n_in = n_in; t.n_out = n_out; t.ni = s.ni; t.no = s.no;
     }
-    bool surv;
-    if (inner) {
-        surv = !flag && (nb & VB_LABEL) == (VB_S | VB_B);
-        c.scan[vrg_slot_A0(s, e)] = surv ? 1u : 0u;
-        c.scan[vrg_slot_A1(s, e)] = (uint32_t)__builtin_popcount(mask);
-        c.scan[vrg_slot_B1(s, e)] = (flag && fin == 2 && !fresh) ? 1u : 0u;
-    } else {
-        uint32_t j = e - s.ni;
-        surv = !flag && (nb & VB_LABEL) == VB_B && !(nb & VB_F);
-        c.scan[vrg_slot_B0(s, j)] = surv ? 1u : 0u;
-        c.scan[vrg_slot_A2(s, j)] = (flag && fin == 1) ? 1u : 0u;
-        c.scan[vrg_slot_B2(s, j)] = (uint32_t)__builtin_popcount(mask);
-    }
-    c.e_surv[e] = surv;
-}
-
-// density correction of one intensity value (:236-247)
-VRG_HD void vrg_corrections(const VrgCtx& c, double v, double& ic, double& oc, double& ac) {
-    const VrgState& s = *c.st;
-    double a = 0, b = 0, d = 0;
-    for (uint32_t i = 0; i < s.nnz; i++) {
-        double k = vrg_kern(c, c.nz_val[i] - v);
-        a += (double)c.nz_cin[i] * k; b += (double)c.nz_cout[i] * k; d += (double)c.nz_cconv[i] * k;
-    }
-    ic = a; oc = b; ac = d;
-}
-VRG_HD void vrg_apply_correction(const VrgCtx& c, uint32_t lev, double& ip, double& op) {
-    double ic, oc, ac;
-    if (c.st->use_tab) { ic = c.tabC[3 * (size_t)lev]; oc = c.tabC[3 * (size_t)lev + 1]; ac = c.tabC[3 * (size_t)lev + 2]; }
-    else vrg_corrections(c, c.lev[lev], ic, oc, ac);
-    ip += ic; ip -= oc;             // :243-244
-    op -= ic; op += oc; op += ac;   // :245-247
-}
-
-VRG_HD void vrg_new_fresh(const VrgCtx& c, int nx, uint32_t pos, uint32_t idx, uint32_t lev) {
-    if (pos >= c.bcap) { c.st->error = 1; return; }
-    c.b_idx[nx][pos] = idx; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = 0; c.b_op[nx][pos] = 0; c.b_pend[nx][pos] = 1;
-    c.vent[idx] = pos;
-    c.fresh[vrg_atomic_add(&c.st->nfresh, 1u)] = pos;
-}
-
-// per old band entry: survivors and carried flips copy themselves to their new position with the
-// incremental correction; a flip that left the band during the sweep re-enters as a fresh entry
-VRG_HD void vrg_item_scatter_entry(const VrgCtx& c, uint32_t e) {
-    const VrgState s = *c.st;                                 // a copy: no reloads after the stores below
-    int cur = s.iter & 1, nx = cur ^ 1;
-    bool inner = e < s.ni;
-    uint32_t j = e - s.ni;
-    // independent loads first (one round trip); the survivor's slot is known without looking anything up
-    const uint8_t surv = c.e_surv[e], flag = c.e_flag[e], res = c.e_res[e];
-    const uint32_t lev = c.b_lev[cur][e], idx = c.b_idx[cur][e];
-    double ip = c.b_ip[cur][e], op = c.b_op[cur][e];
-    uint32_t pos = c.scan[inner ? vrg_slot_A0(s, e) : vrg_slot_B0(s, j)];
-    bool fresh = false;
-    if (!surv) {
-        if (!flag) return;
-        uint8_t fin = res & FR_FINAL;
-        fresh = res & FR_FRESH;
-        if (inner) { if (!(fin == 2 && !fresh)) return; pos = c.scan[vrg_slot_B1(s, e)]; }
-        else { if (fin != 1) return; pos = c.scan[vrg_slot_A2(s, j)]; }
-    }
-    if (fresh) { vrg_new_fresh(c, nx, pos, idx, lev); return; }
-    if (pos >= c.bcap) { c.st->error = 1; return; }
-    vrg_apply_correction(c, lev, ip, op);
-    c.b_idx[nx][pos] = idx; c.b_lev[nx][pos] = lev; c.b_ip[nx][pos] = ip; c.b_op[nx][pos] = op; c.b_pend[nx][pos] = 0;
-    c.vent[idx] = pos;
-}
-
-// the voxels a listed flip promoted (item k = neighbour k of the flip, :263-282 order): fresh entries
-VRG_HD void vrg_item_scatter_promo(const VrgCtx& c, uint32_t r, uint32_t k) {
-    if (k >= 27) return;
-    const VrgState& s = *c.st;
-    int cur = s.iter & 1, nx = cur ^ 1;
-    uint32_t e = c.flist[r], fi = c.fidx[r];
-    uint32_t mask = c.e_mask[e];
-    if (!(mask & (1u << k))) return;
-    uint32_t slot = e < s.ni ? vrg_slot_A1(s, e) : vrg_slot_B2(s, e - s.ni);
-    uint32_t pos = c.scan[slot] + (uint32_t)__builtin_popcount(mask & ((1u << k) - 1u));
-    uint32_t m = (uint32_t)((int64_t)fi + vrg_off(c, (int)k));
-    vrg_new_fresh(c, nx, pos, m, vrg_voxel_level(c, m));
-}
-
-// exact densities over the whole inner / outer regions (:152-155, :252-255), regrouped by level
-VRG_HD void vrg_exact_serial(const VrgCtx& c, int par, uint32_t pos) {
-    double v = c.lev[c.b_lev[par][pos]];
-    double si = 0, so = 0;
-    for (uint32_t l = 0; l < c.L; l++) {
-        int32_t a = c.hin[l], b = c.hout[l];
-        if (!(a | b)) continue;
-        double k = vrg_kern(c, c.lev[l] - v);
-        si += (double)a * k; so += (double)b * k;
-    }
-    c.b_ip[par][pos] = si; c.b_op[par][pos] = so;
+    s.last_nf = s.nf;
+    s.nf = 0; s.npend = 0; s.nmk = 0; s.nalloc = 0; s.ndead = 0; s.d_ni = 0; s.d_no = 0;
+    s.nfx = s.nfresh; s.nfresh = 0;                   // exact densities of the new entries: first thing next trip
+    s.corr = 1; s.use_tab = use_tab ? 1 : 0;          // nnz stays: the next k_band reads the touched-level list
+    if (s.error) s.done = -1;
+    *c.st = s;
 }
 
 // ------------------------------------------------------------------ init mode (:129-155)
@@ -572,9 +674,13 @@ VRG_HD void vrg_item_init_voxel(const VrgCtx& c, uint32_t idx) {
     lab[idx] = VB_B;
 }
 
+// slot e of the initial pool = position e of concat(innerBnd, outerBnd) (p_idx holds the sorted voxels): key = position
 VRG_HD void vrg_item_init_entry(const VrgCtx& c, uint32_t e) {
-    uint32_t idx = c.b_idx[0][e];
-    c.b_lev[0][e] = vrg_voxel_level(c, idx);
+    uint32_t idx = c.p_idx[e];
+    c.p_lev[e] = vrg_voxel_level(c, idx);
+    c.p_key[e] = e;
+    c.p_flag[e] = (uint8_t)(PF_ALIVE | (e < c.st->ni ? PF_INNER : 0));     // (init computes its densities at once: not pending)
+    c.p_ip[e] = 0; c.p_op[e] = 0;
     c.fresh[e] = e;
     c.vent[idx] = e;
 }

@@ -4,15 +4,18 @@
 // that stencil code never tests bounds:
 //     idx(x,y,z) = ((z+2)*PY + (y+2))*PX + x,   PX = roundup(nx+2,16), PY = ny+4, PZ = nz+4
 // Padding label bytes hold VB_OOB forever; x = -1,-2 wrap onto the previous row's padding.
-// A Z-slab (multi-GPU) is the same layout with its two halo planes per side living in the z padding.
 //
 // Label byte (internal encoding of the reference's valueMap, variationalRegionGrowing.py:21):
 //     bit0 S  segmented (labels 0,1)          bit3 L  listed in this sweep's flip list (:88)
 //     bit1 B  in the narrow band (labels 1,2)  bit4 P  flip will be applied (flip-outs always; flip-ins
 //     bit2 X  excluded (label 4)                        per the skip rule, see vrg_items.h)
-//     bit5 OOB padding / outside the volume    bit6 F  transient: outer-boundary voxel that left the band
-//                                                       and re-entered in the same sweep (fresh density)
+//     bit5 OOB padding / outside the volume    bit7 M  marked for this sweep's relabel stencil
 //     label 0 = S, 1 = S|B, 2 = B, 3 = 0, 4 = X
+//
+// The narrow band (innerBndList / outerBndList of the reference, :147-148, :257-258) is an UNORDERED POOL of
+// slots; a voxel keeps its slot for as long as it stays in the band.  The reference's list order - which decides
+// the order in which flips are applied - is carried by a 64-bit key per slot (vrg_items.h, "list order"), so the
+// lists are never rebuilt: per sweep only the few flips are sorted by key.
 #pragma once
 #include <stdint.h>
 #include "../../include/vrg.h"
@@ -25,14 +28,20 @@
 #endif
 
 enum : uint8_t {
-    VB_S = 1, VB_B = 2, VB_X = 4, VB_L = 8, VB_P = 16, VB_OOB = 32, VB_F = 64,
+    VB_S = 1, VB_B = 2, VB_X = 4, VB_L = 8, VB_P = 16, VB_OOB = 32, VB_M = 128,
     VB_LABEL = 7
 };
 
+// band slot flags
+enum : uint8_t { PF_ALIVE = 1, PF_INNER = 2, PF_PEND = 4 };   // PEND: densities still to be computed exactly (:252-255)
+
 // stop reasons VRG_STOP_* (variationalRegionGrowing.py:91-104,118-121) come from include/vrg.h
 
-// e_res codes written by the relabel for every listed flip
+// f_res codes written by the relabel for every listed flip
 enum : uint8_t { FR_FINAL = 3, FR_FRESH = 4, FR_WRITTEN = 8 };
+
+// why the one-workgroup sweep kernel handed a trip back to the host (VrgState::bail); nothing was modified
+enum { VBAIL_FLIPS = 1, VBAIL_MARKS = 2, VBAIL_POOL = 3 };
 
 struct VrgTrace {            // one record per update() call (0 = init)
     int64_t nflip, nseg, n_in, n_out, ni, no;
@@ -46,21 +55,26 @@ struct VrgState {
     int32_t iterMax;
     int32_t error;       // capacity overflow etc.
     int32_t time_up;     // host: wall-clock cap reached (:97) - the next trip only decides and stops
+    int32_t bail;        // VBAIL_*: the trip has to be redone by the host-driven path / with larger arrays
     int64_t maxSegmentSize;
-    uint32_t ni, no;     // band list lengths (inner list = entries [0,ni), outer = [ni,ni+no))
+    uint32_t ni, no;     // lengths of innerBndList / outerBndList
+    uint32_t np;         // pool slots in use (high-water mark; dead slots below it sit on the free list)
+    uint32_t nfree;      // free list length
     uint32_t nf;         // listed flips of the sweep being processed (atomic count)
+    uint32_t last_nf;    // ... of the sweep applied last
     uint32_t npend;      // flip-ins waiting in the skip-rule fix-point
-    uint32_t nfresh;     // band entries needing exact densities
-    uint32_t nfx;        // device: ... of the sweep just closed, computed by the next trip's first kernel (k_decide_exact)
+    uint32_t nfresh;     // slots that (re-)entered the band this sweep: exact densities due
+    uint32_t nfx;        // ... of the sweep just closed, computed by the next trip's first kernel (k_band)
     uint32_t nmk;        // voxels marked for the relabel stencil this sweep
     uint32_t nnz;        // distinct intensity levels touched by this sweep's density corrections
-    uint32_t ncnt;       // length of the rebuild count array
-    uint32_t ni_new, nb_new;
-    uint32_t fix_changed;
+    uint32_t nalloc;     // slots handed out this sweep
+    uint32_t ndead;      // slots that left the band this sweep
+    int32_t d_ni, d_no;  // list length changes of this sweep
     uint32_t ninit_in, ninit_out, nseed;
-    uint32_t nscan;      // length of the array the next device-wide scan runs over
-    uint32_t scan_total; // its total
-    int32_t use_tab;     // this sweep's density corrections are memoised per intensity level (tabC)
+    int32_t corr;        // the corrections of the sweep just applied (:236-247) are still to be added to the surviving
+                         // entries: the next k_band does it on its way through the pool
+    int32_t use_tab;     // ... from the per-level memo tabC instead of entry by entry
+    int32_t tab_ok;      // decided when update() opens: fewer intensity levels than band entries, a memo pays
 };
 
 // results of the dense recount; written by the dense stream only (own allocation, own cache lines).
@@ -83,57 +97,58 @@ struct VrgCtx {
     int32_t z0, z1;            // Z-slab [z0, z1) this device recounts (whole volume on one GPU)
     uint32_t PV;               // PX*PY*PZ
     double H, A;               // kernel A*exp(-0.5*H*d^2) (:7,:10)
-    const float* I;            // intensities, padded layout
+    const float* I;            // intensities, padded layout (fp32-exact volumes)
+    const double* I64;         // ... or float64, when the volume has values fp32 cannot hold (then I is null)
     const uint16_t* lev16;     // optional 16-bit storage: level index per voxel (same layout); the dense pass then
                                // streams 2 B instead of 4 B of intensity per voxel (values come from an LDS table)
     uint8_t* lab[2];           // lab[0]: label bytes, updated in place; lab[1]: scratch of the full-stencil check variant
     // class bits: what the dense pass needs of a label - inner (S) / outer (not S, not excluded) - 2 bits per voxel;
     // lane l of a wave owns dword l of each 1024-voxel unit (its 16 voxels 256*j + 4*l + b), so a unit is one coalesced
-    // 256-B request.  TWO copies: the dense pass of sweep k reads clsb[k & 1] while k_apply of sweep k+1 already
-    // writes clsb[(k+1) & 1]; each copy therefore receives the class changes of two sweeps at a time - its own and,
+    // 256-B request.  TWO copies: the dense pass of sweep k reads clsb[k & 1] while the label write of sweep k+1 already
+    // changes clsb[(k+1) & 1]; each copy therefore receives the class changes of two sweeps at a time - its own and,
     // from the change list of the sweep before (chg_*[(k-1) & 1]), the one it sat out.
     uint32_t* clsb[2];
-    uint32_t ccap;             // capacity of the class-change lists
+    uint32_t mcap;             // capacity of the marked-voxel list and of the class-change lists
     uint32_t* chg_dw[2];       // per sweep parity: dword index ...
     uint32_t* chg_x[2];        // ... and xor mask of every class change that sweep made
     uint32_t* nchg;            // their lengths (2 counters, own allocation)
-    uint32_t mcap;             // marked-voxel list: index and new byte
-    uint32_t* mk_idx;
-    uint8_t* mk_new;
+    uint32_t* mk_idx;          // marked voxels of this sweep ...
+    uint8_t* mk_new;           // ... and their bytes after it
     uint64_t* stamp;           // (sweep<<32 | flip rank) of a voxel's last listing; seeds: lex index
     // intensity levels: sorted distinct values and per-class histograms (:149-150, :249-250)
     uint32_t L;
     const double* lev;
     int32_t* hin;
     int32_t* hout;
-    uint32_t* dIn;             // per-level counts of innerAdded / outerAdded / addedPoints (:232-235)
+    uint32_t* dIn;             // per-level counts of innerAdded / outerAdded / addedPoints (:232-235); zero between sweeps
     uint32_t* dOut;
     uint32_t* dConv;
-    uint32_t* nz_lev;          // compacted list of touched levels ...
-    double* nz_val;            // ... their values and counts
+    uint32_t* ltouch;          // per level: already on this sweep's touched list
+    uint32_t zcap;             // capacity of the touched-level list (a power of two >= L)
+    uint64_t* nz_key;          // touched levels as sort keys (unordered until the sweep's level sort)
+    double* nz_val;            // ... in ascending order: their values and counts
     uint32_t* nz_cin; uint32_t* nz_cout; uint32_t* nz_cconv;
     double* tabC;              // per-level memo of the three corrections (3*L), see VrgState::use_tab
-    // band lists, SoA, ping-pong by sweep parity; capacity bcap entries
+    // band pool, SoA; capacity bcap slots
     uint32_t bcap;
-    uint32_t* b_idx[2];
-    uint32_t* b_lev[2];
-    double* b_ip[2];
-    double* b_op[2];
-    uint8_t* b_pend[2];        // 1: densities still to be computed exactly (entry (re-)entered the band in the sweep that built the list)
-    uint8_t* e_flag;           // per old entry: listed flip
-    uint8_t* e_new;            // per entry: 0x80 | its voxel's byte after this sweep, when the relabel visited that voxel (else 0)
-    uint32_t* vent;            // per voxel: list position of the band entry sitting there (valid while the B bit is set)
-    uint8_t* e_surv;           // per old entry: survives in place
-    uint8_t* e_res;            // per old entry: FR_* result of a listed flip
-    uint32_t* e_mask;          // per old entry: bit k = neighbour k (offset order of get_neighbours :263) promoted by this flip
-    uint32_t* lscan;           // per-level scan workspace (length L)
-    uint32_t* bsum;            // per-workgroup partials of the device-wide scan
-    uint32_t* scan;            // rebuild count array / positions, length 3*(ni+no)
-    uint32_t fcap;
-    uint32_t* flist;           // entry indices of the listed flips, unordered
-    uint32_t* fidx;            // ... and their voxel indices (saves the dependent b_idx look-up in every flip item)
-    uint32_t* pend;            // entry indices of the flip-ins in the skip-rule fix-point
-    uint32_t* fresh;           // new-band positions needing exact densities
+    uint32_t* p_idx;           // voxel
+    uint32_t* p_lev;           // level index of its intensity
+    double* p_ip;              // innerProb / outerProb (:132-133)
+    double* p_op;
+    uint64_t* p_key;           // list-order key (vrg_items.h)
+    uint8_t* p_flag;           // PF_*
+    uint32_t* vent;            // per voxel: slot of the band entry sitting there (valid while the B bit is set)
+    uint32_t* freel;           // free slots (stack)
+    uint32_t* dead;            // slots that died this sweep (moved onto the free list when the sweep closes)
+    // this sweep's flips
+    uint32_t fcap;             // a power of two
+    uint32_t* flist;           // slots of the listed flips as k_band appended them, unordered
+    uint64_t* f_key;           // ... sort keys (scratch of the host-driven sort)
+    uint32_t* f_slot;          // flip list in the reference's order (:88): slot ...
+    uint32_t* f_idx;           // ... and voxel of flip r
+    uint8_t* f_res;            // FR_* result of flip r
+    uint32_t* pend;            // ranks of the flip-ins in the skip-rule fix-point
+    uint32_t* fresh;           // slots needing exact densities
     // dense statistics partials (one slot per sweep workgroup)
     uint32_t nstat;
     int64_t* st_nin; int64_t* st_nout; double* st_sin; double* st_sout;

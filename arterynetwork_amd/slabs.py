@@ -84,19 +84,10 @@ def bench_slabs(shape, args, dev, rank, world, roofline):
     I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels)
     torch.cuda.synchronize()
     V = shape[0] * shape[1] * shape[2]
-    slab_of = int(getattr(args, 'slab_of', 0) or 0)
-    if slab_of > 1 and world == 1:
-        # one GPU standing in for one of `slab_of` ranks: recount the first of that many Z-slabs (projection runs)
-        s = make_slab_session(shape, 0, slab_of, device=dev.index, reduce='none')
-        s.comm_init(1, 0, s.comm_unique_id())
-        s.reduce_mode = 'rccl (1-rank communicator)'
-    else:
-        s = make_slab_session(shape, rank, world, device=dev.index, reduce='rccl-always')
+    s = make_slab_session(shape, rank, world, device=dev.index, reduce='rccl-always')
     if args.sweep_blocks:
         s.set_option('sweep_blocks', args.sweep_blocks)
-    use_graph = int(getattr(args, 'graph', 0))
     s.set_option('events', 1)
-    s.set_option('graph', use_graph)
     s.set_option('batch', 64)
     s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
     s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
@@ -115,11 +106,11 @@ def bench_slabs(shape, args, dev, rank, world, roofline):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max, kern_ms = float(t[0]), float(t[1])
     per_rank = [None] * world
-    chain = s.chain_timing(args.H) if getattr(s, 'reduce_mode', '') else {}
-    dist.all_gather_object(per_rank, {'rank': rank, 'slab': list(s.slab), 'dense_ms': round(dense_ms, 4),
-                                      'band_chain_ms': chain.get('band_chain_ms'), 'seconds': round(dt, 4)})
     valid = (r.sweeps == args.steps) and (r0.sweeps == args.warmup)
     tr = s.trace()
+    chain = s.chain_timing(args.H)               # (last: the session has to be re-initialised after it)
+    dist.all_gather_object(per_rank, {'rank': rank, 'slab': list(s.slab), 'dense_ms': round(dense_ms, 4),
+                                      'band_chain_ms': chain.get('band_chain_ms'), 'seconds': round(dt, 4)})
     z0, z1 = s.slab
     out = {
         'metric': 'Mvoxel-iters/sec, VRG sweep, {} volume'.format(args.shape),
@@ -130,13 +121,11 @@ def bench_slabs(shape, args, dev, rank, world, roofline):
         'config': {'workload': '{} synthetic MRA tube volume ({} intensity levels stored fp32, brain-mask excluded '
                                'voxels), H={}, {} incremental VRG sweeps'.format(args.shape, args.levels, args.H, r.sweeps),
                    'parallelism': 'zslab{} (dense recount sharded into {} Z-slabs, band relabel replicated, one '
-                                  '32-byte RCCL all-reduce per sweep)'.format(slab_of or world, slab_of or world),
-                   'reduction': s.reduce_mode, 'rccl_ranks': s.comm_ranks, 'launch': 'band kernels from hipGraph replay' if use_graph else 'eager',
+                                  '32-byte RCCL all-reduce per sweep)'.format(world, world),
+                   'reduction': s.reduce_mode, 'rccl_ranks': s.comm_ranks,
                    'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
                    'dense_ms': round(kern_ms, 4), 'band_chain_ms': chain.get('band_chain_ms'), 'ranks': per_rank},
         'roofline': roofline(shape, z1 - z0, kern_ms, int(r.sweep_launches), None),
     }
-    if slab_of > 1 and world == 1:
-        out['config']['note'] = 'ONE GPU doing the work of rank 0 of {} (projection run, not a scaling measurement)'.format(slab_of)
     s.close()
     return out

@@ -65,19 +65,27 @@ void vrg_destroy(vrg_handle* h);
 const char* vrg_last_error(const vrg_handle* h);
 
 /* Options (value 0/1 unless noted; before vrg_init unless "any time"):
- *   "band_capacity"  entries reserved for the narrow band (default: all voxels up to 32 Mi, else max(32 Mi, V/8))
+ *   "band_capacity"  slots reserved for the narrow band (default 65536; the arrays grow by themselves when a
+ *                    sweep needs more, so this only saves the re-allocations)
+ *   "capacity_floor" smallest capacity of the pool and of the marked-voxel arrays (default 65536; tests lower it)
  *   "storage16"      keep intensities as 16-bit level indices (needs <= 16384 distinct values): the dense
  *                    pass streams 2 B instead of 4 B per voxel; results are bit-identical
- *   "sweep_variant"  any time; 0 = relabel only the marked voxels (default), 1 = check variant that runs the
+ *   "sweep_variant"  0 = relabel only the marked voxels (default), 1 = check variant that runs the
  *                    label stencil on every voxel (slow; must give the same state)
  *   "events"         any time; time every dense-pass launch with HIP events (vrg_result.sweep_kernel_ms)
  *   "batch"          any time; sweeps enqueued between host checks of the stop flag (default 8)
- *   "graph"          any time; replay the band kernels of each sweep from two captured hipGraphs
+ *   "small_flips"    any time; flips per sweep up to which update() runs as ONE workgroup's kernel (default and
+ *                    maximum 4096); sweeps with more are driven from the host with device-wide kernels
+ *   "dense_off"      any time; measurement aid: the dense recount is not launched (the band chain alone);
+ *                    the handle has to be initialised again afterwards
  *   "sweep_blocks", "prio_mode"
  *                    any time; launch tuning knobs of the dense pass / the two streams (0 = automatic) */
 int vrg_set_option(vrg_handle* h, const char* name, int64_t value);
 
-/* dataArray (:16): any VRG_* dtype; values must be exactly representable in fp32. */
+/* dataArray (:16): any VRG_* dtype.  Kept as fp32 when every value is exactly representable in fp32 (integer
+ * volumes, float32 volumes), as float64 otherwise (the dense pass then streams 8 B per voxel); the arithmetic is
+ * float64 either way.  A device pointer must not be written by other streams any more when the call is made (the
+ * library reads it on its own stream). */
 int vrg_set_volume(vrg_handle* h, const void* data, int dtype, const int64_t strides_xyz[3]);
 /* valueMap on entry (:18-21): labels must be in {0 seed, 3 outside, 4 excluded}. */
 int vrg_set_labels(vrg_handle* h, const void* labels, int dtype, const int64_t strides_xyz[3]);
@@ -103,6 +111,11 @@ int vrg_get_trace(vrg_handle* h, vrg_trace_rec* out, int64_t cap, int64_t* n);
  * from the labels (:149-150 / :249-250) next to the incrementally maintained ones. */
 int vrg_get_levels(vrg_handle* h, double* values, int32_t* hist_in, int32_t* hist_out,
                    int32_t* recount_in, int32_t* recount_out, int64_t cap, int64_t* n);
+
+/* Diagnostics of the handle's runs so far: out[0..3] = trips handed back to the host {unused, too many flips for
+ * one workgroup, marked-voxel arrays grown, band pool grown}, out[4] = host-driven trips, out[5] = band pool
+ * capacity, out[6] = marked-list capacity, out[7] = pool slots in use.  cap >= 8. */
+int vrg_get_stats(vrg_handle* h, int64_t* out, int64_t cap);
 
 /* ---- multi-GPU (one process per GPU) --------------------------------------------------
  * Every rank holds the label volume and applies the O(band) relabel identically (it is deterministic),

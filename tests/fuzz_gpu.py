@@ -29,7 +29,7 @@ for sd in range(300000 + off, 300000 + off + n_small):
     I, vm, H, variant, dmode = random_case(sd)
     try:
         res, k = parity.run_batched(lib, I, vm, H, None, 40, density_mode=dmode,
-                                    options={'sweep_variant': variant, 'batch': 1 + sd % 7, 'graph': (sd // 3) % 2})
+                                    options={'sweep_variant': variant, 'batch': 1 + sd % 7, 'small_flips': (4096, 0, 8)[sd % 3]})
         sweeps += k; amb += res is None
     except Exception as e:
         fails += 1; print('FAIL batched', sd, type(e).__name__, str(e)[:200].replace('\n', ' '))

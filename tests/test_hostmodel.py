@@ -75,6 +75,27 @@ def test_hostmodel_random_volumes(hm):
     assert done >= 280, 'too many cases cut short by an exact tie: {} of 300 completed'.format(done)
 
 
+def test_hostmodel_arrays_grow_on_demand(hm):
+    """Pool and marked-voxel arrays start tiny (capacity_floor 16) and grow when a trip is handed back (VBAIL_MARKS /
+    VBAIL_POOL) or when init counts more band voxels than fit; small_flips 0/3/10^6 runs every sweep host-driven /
+    mixed / as one "workgroup".  Results stay those of the oracle."""
+    from arterynetwork_amd._capi import Session
+    grown = 0
+    for sd, small in ((3, 0), (17, 3), (41, 10 ** 6), (77, 3), (123, 0)):
+        I, vm, H, variant, dmode = random_case(sd, 5, 13)
+        res, k = parity.run_stepwise(hm, I, vm, H, None, 25, density_mode=1, check_hist=True,
+                                     options={'capacity_floor': 16, 'small_flips': small})
+        assert res is not None
+    data, vmap = __import__('arterynetwork_amd.phantoms', fromlist=['x']).scattered_seeds()
+    s = Session(data.shape, lib=hm)
+    s.set_option('capacity_floor', 16); s.set_option('small_flips', 5)
+    s.set_volume(data); s.set_labels(vmap); s.init(2.25)
+    s.run(15, 10 ** 9, None)
+    st = s.stats()
+    assert st['grow_marks'] > 0 and st['pool_capacity'] > 16 and st['bail_flips'] > 0 and st['host_driven_trips'] > 0
+    s.close()
+
+
 def test_hostmodel_rejects_bad_inputs(hm):
     from arterynetwork_amd._capi import Session, VrgError
     s = Session((4, 5, 6), lib=hm)
@@ -87,9 +108,26 @@ def test_hostmodel_rejects_bad_inputs(hm):
     with pytest.raises(VrgError) as e:       # no seed: the reference raises at :48
         s.init(2.25)
     assert e.value.code == -5
-    with pytest.raises(VrgError):            # 0.1 is not an fp32 value
-        s.set_volume(np.full((4, 5, 6), 0.1))
+    s.set_volume(np.full((4, 5, 6), 0.1))    # 0.1 is not an fp32 value: kept as float64 (no VRG_E_INEXACT any more)
     s.close()
+
+
+def test_hostmodel_float64_volume(hm):
+    """Volumes with values fp32 cannot hold (the reference computes in float64 on whatever it is given, and its
+    pipeline writes float64 NIfTI): stored as float64, same results as the oracle."""
+    rng = np.random.default_rng(11)
+    done = 0
+    for sd in range(12):
+        shape = tuple(int(x) for x in rng.integers(3, 12, size=3))
+        I = rng.standard_normal(shape) * (1.0 + sd) + 1e-9 * rng.standard_normal(shape)
+        assert np.any(I.astype(np.float32).astype(np.float64) != I)
+        u = rng.random(shape)
+        vm = np.full(shape, 3, dtype=np.int64); vm[u < 0.15] = 0; vm[u > 0.8] = 4
+        if not (vm == 0).any():
+            vm.reshape(-1)[0] = 0
+        res, k = parity.run_stepwise(hm, I, vm, 2.25, None, 25, density_mode=sd % 2, check_hist=True)
+        done += res is not None
+    assert done >= 10
 
 
 def test_hostmodel_layouts_and_dtypes(hm):

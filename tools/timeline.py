@@ -5,7 +5,7 @@ f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 rows = [r for r in csv.DictReader(open(f)) if 'at::native' not in r['Kernel_Name'] and 'rocprim' not in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'k_decide' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'k_band' in r['Kernel_Name']]
 i0, i1 = idx[which], idx[which + 1]
 t0 = int(rows[i0]['Start_Timestamp'])
 for r in rows[i0:i1 + 1]:
