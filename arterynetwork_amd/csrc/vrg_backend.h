@@ -55,11 +55,14 @@ void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
 //          VRG_SWEEP_NODENSE  the dense recount is not launched (measurement aid)
 //          VRG_SWEEP_SYNC   host-driven trip: the backend synchronises after the decisions, may grow nothing itself,
 //                           but runs update() with device-wide kernels and sorts - any number of flips
-// Without VRG_SWEEP_SYNC the trip is two launches (k_band, k_sweep) and is enqueued without synchronising; k_sweep
-// hands a trip it cannot do in one workgroup back through st->bail.
+// Without VRG_SWEEP_SYNC the trip is four launches (k_band, k_order, k_mark_relabel, k_close) and is enqueued without
+// synchronising; k_order hands a trip it cannot order in one workgroup's LDS back through st->bail.
 enum { VRG_SWEEP_FULL = 1, VRG_SWEEP_NODENSE = 4, VRG_SWEEP_SYNC = 8 };
 void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_reduce_fn cb, void* user);
-// flips one workgroup takes on (k_sweep); more -> VBAIL_FLIPS
+// Z-slabs: all-reduce and close the dense passes whose slab sums are still waiting (they are reduced a few sweeps at a
+// time); collective - every rank calls it at the same point.  The engine calls it before it reads results.
+void be_dense_flush(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user);
+// flips one workgroup takes on (k_order); more -> VBAIL_FLIPS
 uint32_t be_small_flip_limit(VrgBackend* b);
 
 // RCCL communicator for the per-sweep all-reduce of the slab statistics (device backend only)

@@ -52,6 +52,7 @@ struct VrgBackend {
     size_t ev_used = 0;
     void* tmp = nullptr; size_t tmp_bytes = 0;        // scratch of the host-driven sorts
     uint64_t* keys2 = nullptr; size_t keys2_n = 0;
+    int dense_pending = 0;                            // Z-slabs: recounts enqueued since the last staged all-reduce
 };
 
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess && !b->err[0]) { \
@@ -252,30 +253,33 @@ __device__ void wg_sort_pairs(K* key, V* val, uint32_t n, bool has_val) {
 // always true already, so one thread looks at a word instead.)  Spins are bounded: a wait that does not end within
 // SPIN_LIMIT raises an error instead of hanging the queue.
 constexpr unsigned long long SPIN_LIMIT = 300000000ull;    // wall_clock64 ticks (100 MHz): 3 s
-// band side, before the labels of sweep k are written into class copy k & 1: the dense pass k-2 has read that copy
+// band side, before the labels of sweep k are written into class copy k & 1: the recount k-2 has read that copy
 __device__ __forceinline__ void wait_dense_read(const VrgCtx& c) {
     const int64_t need = (int64_t)c.st->iter + 1 - 2;
-    if (need <= 0 || vrg_load_i64(&c.dctl[VD_SEQ]) >= need) return;
+    if (need <= 0 || vrg_load_i64(&c.dctl[VD_RSEQ]) >= need) return;
     const unsigned long long t0 = wall_clock64();
-    while (vrg_load_i64(&c.dctl[VD_SEQ]) < need) {
+    while (vrg_load_i64(&c.dctl[VD_RSEQ]) < need) {
         __builtin_amdgcn_s_sleep(16);
         if (wall_clock64() - t0 > SPIN_LIMIT) { c.st->error = 9; return; }
     }
 }
-// dense side, in front of every recount: a sweep has been applied since the last pass (or the run has stopped)
-__global__ void k_gate(VrgCtx c) {
-    if (threadIdx.x != 0) return;
+// dense side, first thing in every recount (one thread per workgroup looks): a sweep has been applied since the last
+// recount - or the run has stopped and there is nothing to count.  True at once whenever the dense pass is what bounds
+// the step (the band side runs a sweep ahead); otherwise the recount's workgroups wait here for the labels.
+__device__ __forceinline__ bool gate_dense_due(const VrgCtx& c) {
     const unsigned long long t0 = wall_clock64();
     for (;;) {
-        if (vrg_load_i64(&c.inc[VC_REQ]) > vrg_load_i64(&c.dctl[VD_SEQ])) return;
-        if (vrg_load_i32(&c.st->done) || vrg_load_i32(&c.st->bail) || vrg_load_i32(&c.st->error)) {
-            (void)vrg_load_i64(&c.inc[VC_REQ]);     // (the last applied sweep's request is older than the stop flag: the recount itself re-checks)
-            return;
-        }
+        if (vrg_dense_due(c)) return true;
+        if (vrg_load_i32(&c.st->done) || vrg_load_i32(&c.st->bail) || vrg_load_i32(&c.st->error))
+            return vrg_dense_due(c);                   // (the last applied sweep's request is older than the stop flag)
         __builtin_amdgcn_s_sleep(32);
-        if (wall_clock64() - t0 > SPIN_LIMIT) { c.dctl[VD_ERR] = 10; return; }
+        if (wall_clock64() - t0 > SPIN_LIMIT) { c.dctl[VD_ERR] = 10; return false; }
     }
 }
+// the same wait as a kernel of its own, for a recount whose workgroups must not sit on the chip while they wait: the
+// 16-bit variant holds 64 KiB of LDS per workgroup, two per CU - waiting there, it would leave no CU on which k_close
+// (which produces what it waits for) could start
+__global__ void k_gate(VrgCtx c) { if (threadIdx.x == 0) (void)gate_dense_due(c); }
 __global__ void k_wait_dense(VrgCtx c) { if (threadIdx.x == 0) wait_dense_read(c); }
 
 constexpr int KO_THREADS = 256;
@@ -514,7 +518,8 @@ __global__ void k_tab(VrgCtx c, uint32_t nnz) {
     }
 }
 __global__ void k_finalize(VrgCtx c, int use_tab) { vrg_post_apply(c); vrg_request_dense(c); vrg_finalize(c, use_tab != 0); }
-__global__ void k_dense_fin(VrgCtx c) { vrg_dense_fin(c); }
+__global__ void k_dense_pack(VrgCtx c) { vrg_dense_pack(c); }
+__global__ void k_dense_fin(VrgCtx c) { vrg_dense_fin_staged(c); }
 
 // full-stencil check variant: every voxel runs the relabel stencil (no marks); new bytes go to lab[1]
 // and are copied back, so stencil reads only ever see pre-sweep labels.
@@ -606,9 +611,11 @@ __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a, int fi
         d.n_out = (double)(sh_n[1][0] + sh_n[1][1] + sh_n[1][2] + sh_n[1][3]);
         d.sum_in = ((sh_s[0][0] + sh_s[0][1]) + sh_s[0][2]) + sh_s[0][3];
         d.sum_out = ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3];
-        *c.dn_part = d;                              // slab partials: input of the all-reduce
-        if (c.world == 1) *c.dn = d;
-        if (fin == 2) vrg_dense_fin(c);              // nothing to sum over ranks: close the pass here
+        if (fin == 0) { *c.dn_part = d; if (c.world == 1) *c.dn = d; }   // init: the sizes found the incremental counts
+        else {
+            vrg_recount_done(c, d);                  // this device's slab sums of the recount
+            if (fin == 2) vrg_dense_fin_one(c, d);   // nothing to sum over ranks: close the pass here
+        }
     }
 }
 
@@ -663,13 +670,19 @@ __device__ __forceinline__ void load_unit(const VrgCtx& c, const uint32_t* cls, 
 }
 template <int UNITS, bool NT, int MODE>
 __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) {
-    if (check_done && !vrg_dense_due(c)) return;     // no sweep was applied since the last pass (stop flag)
+    __shared__ int s_due;
+    if (check_done) {                                // wait for the sweep's labels; nothing to do once the run has stopped
+        if (threadIdx.x == 0) s_due = ((check_done & 4) ? vrg_dense_due(c) : gate_dense_due(c)) ? 1 : 0;   // (4: k_gate has waited already)
+        __syncthreads();
+        if (!s_due) return;
+        check_done &= 3;
+    }
     __shared__ float s_val[MODE == 1 ? LEV16_MAX : 1];
     if (MODE == 1) {
         for (uint32_t i = threadIdx.x; i < c.L; i += TPB) s_val[i] = (float)c.lev[i];
         __syncthreads();
     }
-    const uint32_t* __restrict__ cls = c.clsb[(c.dctl[VD_SEQ] + 1) & 1];
+    const uint32_t* __restrict__ cls = c.clsb[(vrg_load_i64(&c.dctl[VD_RSEQ]) + 1) & 1];
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
     const uint32_t lo = (2u + (uint32_t)c.z0) * plane;         // this device's Z-slab [z0, z1) as a voxel range
     const uint32_t hi = (2u + (uint32_t)c.z1) * plane;
@@ -1092,6 +1105,33 @@ static void reduce_dense(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* 
     }
 }
 
+// Z-slabs: pack the slab sums of the recounts not yet closed, sum them over the ranks (RCCL on the dense stream, or the
+// host callback once per entry), close those passes
+constexpr int DENSE_GROUP = 8;
+static_assert(DENSE_GROUP <= VRG_STAGE, "staging buffer");
+static void reduce_staged(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
+    b->dense_pending = 0;
+    k_dense_pack<<<1, 1, 0, b->sb>>>(c);
+    if (b->comm) {
+        ncclResult_t r = ncclAllReduce(c.stage_in, c.stage_out, 4 * VRG_STAGE, ncclDouble, ncclSum, b->comm, b->sb);
+        if (r != ncclSuccess && !b->err[0]) {        // sticky: the engine turns it into VRG_E_INTERNAL at its next synchronisation point
+            std::snprintf(b->err, sizeof(b->err), "RCCL all-reduce of the slab statistics failed: %s", ncclGetErrorString(r));
+            std::fprintf(stderr, "%s\n", b->err);
+        }
+    } else if (cb) {
+        double v[4 * VRG_STAGE]; int64_t n = 0;
+        HIP_CHECK(hipMemcpyAsync(v, c.stage_in, sizeof(v), hipMemcpyDeviceToHost, b->sb));
+        HIP_CHECK(hipMemcpyAsync(&n, c.dctl + VD_NST, sizeof(n), hipMemcpyDeviceToHost, b->sb));
+        HIP_CHECK(hipStreamSynchronize(b->sb));
+        for (int64_t j = 0; j < n && j < VRG_STAGE; j++) cb(v + 4 * j, user);
+        HIP_CHECK(hipMemcpyAsync(c.stage_out, v, sizeof(v), hipMemcpyHostToDevice, b->sb));
+        HIP_CHECK(hipStreamSynchronize(b->sb));
+    } else {
+        HIP_CHECK(hipMemcpyAsync(c.stage_out, c.stage_in, VRG_STAGE * sizeof(VrgDense), hipMemcpyDeviceToDevice, b->sb));
+    }
+    k_dense_fin<<<1, 1, 0, b->sb>>>(c);
+}
+
 int be_comm_unique_id(void* id128) {
     static_assert(sizeof(ncclUniqueId) == 128, "id size");
     return ncclGetUniqueId((ncclUniqueId*)id128) == ncclSuccess ? 0 : -1;
@@ -1112,13 +1152,17 @@ int be_comm_init(VrgBackend* b, int nranks, int rank, const void* id128) {
 // The start / stop events ride on the dispatch itself (hipExtLaunchKernel): no separate event packets in the stream,
 // which cost ~4 us each between two back-to-back recounts.
 static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t st, hipEvent_t e_start = nullptr, hipEvent_t e_stop = nullptr) {
-    if (c.lev16) hipExtLaunchKernelGGL((k_recount_bits<3, true, 1>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
+    if (c.lev16) {
+        if (check) { k_gate<<<1, 64, 0, st>>>(c); check |= 4; }
+        hipExtLaunchKernelGGL((k_recount_bits<3, true, 1>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
+    }
     else if (c.I) hipExtLaunchKernelGGL((k_recount_bits<3, true, 0>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
     else hipExtLaunchKernelGGL((k_recount_bits<2, true, 2>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
 }
 
 void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
     use_device(b);
+    b->dense_pending = 0;
     HIP_CHECK(hipStreamSynchronize(b->sb));     // both class copies are rebuilt: no dense pass may be in flight
     k_init_entry<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c);
     if (c.I && c.L <= HIST_LDS_LEVELS) k_hist_lds<<<1024, TPB, 0, b->sa>>>(c);
@@ -1211,14 +1255,19 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
         small_update(b, c, dense);
     }
     if (!dense) return;
-    // dense stream: every voxel once, read-only; the gate holds it until the sweep's labels are in place
+    // dense stream: every voxel once, read-only; the recount itself waits until the sweep's labels are in place
     const bool ranks = c.world > 1 || b->comm || cb;
-    k_gate<<<1, 64, 0, b->sb>>>(c);
     launch_recount(c, dense_blocks(b, c), ranks ? 1 : 2, b->sb, e_start, e_stop);
-    if (ranks) {                                     // one GPU: the last workgroup of the recount closes the pass itself
-        reduce_dense(b, c, cb, user, b->sb);         // sum over the Z-slabs (RCCL on the stream / host callback)
-        k_dense_fin<<<1, 1, 0, b->sb>>>(c);
-    }
+    // one GPU: the last workgroup of the recount closes the pass itself.  Z-slabs: the slab sums of DENSE_GROUP recounts
+    // are summed over the ranks by ONE all-reduce (nothing on the band side waits for it: the decisions use the
+    // incremental sizes; the totals are only cross-checked against them and filed in the trace)
+    if (ranks && ++b->dense_pending >= DENSE_GROUP) reduce_staged(b, c, cb, user);
+}
+
+void be_dense_flush(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
+    use_device(b);
+    const bool ranks = c.world > 1 || b->comm || cb;
+    if (ranks && b->dense_pending) reduce_staged(b, c, cb, user);
 }
 
 void be_events_collect(VrgBackend* b, VrgEvents* ev, long long n_valid) {

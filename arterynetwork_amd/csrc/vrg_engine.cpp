@@ -163,6 +163,8 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.dn = alloc<VrgDense>(h, 16);                   // own allocation: written by the dense kernel only
     c.counters = alloc<uint32_t>(h, 64);
     c.dn_part = alloc<VrgDense>(h, 16);
+    c.dn_ring = alloc<VrgDense>(h, VRG_RING); c.exp_ring = alloc<int64_t>(h, 2 * VRG_RING);
+    c.stage_in = alloc<VrgDense>(h, VRG_STAGE); c.stage_out = alloc<VrgDense>(h, VRG_STAGE);
     c.inc = alloc<int64_t>(h, 32); c.dctl = alloc<int64_t>(h, 32);   // one allocation each: written from different streams
     c.nstat = 4096;
     c.st_nin = alloc<int64_t>(h, c.nstat); c.st_nout = alloc<int64_t>(h, c.nstat);
@@ -170,7 +172,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.trace_cap = 1u << 16;
     c.trace = alloc<VrgTrace>(h, c.trace_cap);
     c.world = 1;
-    if (!c.lab[0] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
+    if (!c.lab[0] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.dn_ring || !c.exp_ring || !c.stage_in || !c.stage_out || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
         !c.nchg || !c.vent || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace) { API(destroy)(h); return VRG_E_MEM; }
     be_fill(be, c.inc, 0, 32 * sizeof(int64_t)); be_fill(be, c.dctl, 0, 32 * sizeof(int64_t));
     be_fill(be, c.clsb[0], 0, PVu / 4); be_fill(be, c.clsb[1], 0, PVu / 4);
@@ -179,6 +181,8 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     be_fill(be, c.st, 0, sizeof(VrgState));
     be_fill(be, c.dn, 0, sizeof(VrgDense));
     be_fill(be, c.dn_part, 0, sizeof(VrgDense));
+    be_fill(be, c.dn_ring, 0, VRG_RING * sizeof(VrgDense)); be_fill(be, c.exp_ring, 0, 2 * VRG_RING * sizeof(int64_t));
+    be_fill(be, c.stage_in, 0, VRG_STAGE * sizeof(VrgDense)); be_fill(be, c.stage_out, 0, VRG_STAGE * sizeof(VrgDense));
     be_fill(be, c.counters, 0, 64 * sizeof(uint32_t));
     *out = h;
     return VRG_OK;
@@ -369,6 +373,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
         }
         if (h->sync_mode && 2 * (uint64_t)s.last_nf <= small) h->sync_mode = false;   // the flips fit one workgroup again
     }
+    if (!h->dense_off) be_dense_flush(be, c, h->reduce_fn, h->reduce_user);   // Z-slabs: close the passes still waiting for their all-reduce
     be_sync(be);
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     int64_t dense_err = 0;                           // raised by the dense stream, possibly after the band side stopped

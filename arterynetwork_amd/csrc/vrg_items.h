@@ -552,7 +552,7 @@ VRG_HD void vrg_item_apply(const VrgCtx& c, uint32_t i) {
 // that sweep's dense pass has to reproduce; the change list just consumed becomes the next sweep's
 VRG_HD void vrg_post_apply(const VrgCtx& c) {
     const int64_t k = (int64_t)c.st->iter + 1;
-    c.inc[VC_EXP + 2 * (k & 3)] = vrg_load_i64(&c.inc[VC_NIN]); c.inc[VC_EXP + 2 * (k & 3) + 1] = vrg_load_i64(&c.inc[VC_NOUT]);
+    c.exp_ring[2 * (k % VRG_RING)] = vrg_load_i64(&c.inc[VC_NIN]); c.exp_ring[2 * (k % VRG_RING) + 1] = vrg_load_i64(&c.inc[VC_NOUT]);
     c.nchg[(k & 1) ^ 1] = 0;
 }
 // init: class dword d from the labels (16 voxels), both copies
@@ -567,21 +567,39 @@ VRG_HD void vrg_item_cls_build(const VrgCtx& c, uint32_t d) {
 }
 // one caller per applied sweep: the labels of sweep iter+1 are in place, a dense pass over them is due
 VRG_HD void vrg_request_dense(const VrgCtx& c) { c.inc[VC_REQ] = (int64_t)c.st->iter + 1; }
-VRG_HD bool vrg_dense_due(const VrgCtx& c) { return c.inc[VC_REQ] > c.dctl[VD_SEQ]; }
-// the dense pass (number seq = passes closed + 1, reading clsb[seq & 1]) has the totals in c.dn: cross-check the sizes
-// it had to reproduce, file the sums, close the pass
-VRG_HD void vrg_dense_fin(const VrgCtx& c) {
-    if (!vrg_dense_due(c)) return;
-    int64_t seq = c.dctl[VD_SEQ] + 1;
-    const VrgDense& d = *c.dn;
-    if ((int64_t)d.n_in != c.inc[VC_EXP + 2 * (seq & 3)] || (int64_t)d.n_out != c.inc[VC_EXP + 2 * (seq & 3) + 1]) c.dctl[VD_ERR] = 5;
+VRG_HD bool vrg_dense_due(const VrgCtx& c) { return vrg_load_i64(&c.inc[VC_REQ]) > vrg_load_i64(&c.dctl[VD_RSEQ]); }
+// recount number rseq = recounts done + 1 (it read class copy rseq & 1) has this device's slab sums: keep them for the pass
+VRG_HD void vrg_recount_done(const VrgCtx& c, const VrgDense& part) {
+    const int64_t rseq = c.dctl[VD_RSEQ] + 1;
+    c.dn_ring[rseq % VRG_RING] = part;
+    c.dctl[VD_RSEQ] = rseq;
+}
+// close pass seq = passes closed + 1 with its totals over all slabs: cross-check the sizes it had to reproduce, file the sums
+VRG_HD void vrg_dense_fin_one(const VrgCtx& c, const VrgDense& d) {
+    const int64_t seq = c.dctl[VD_SEQ] + 1;
+    if ((int64_t)d.n_in != c.exp_ring[2 * (seq % VRG_RING)] || (int64_t)d.n_out != c.exp_ring[2 * (seq % VRG_RING) + 1]) c.dctl[VD_ERR] = 5;
     if ((uint64_t)seq < c.trace_cap) { c.trace[seq].sum_in = d.sum_in; c.trace[seq].sum_out = d.sum_out; }
+    *c.dn = d;
     c.dctl[VD_SEQ] = seq;
+}
+// Z-slabs: the partial sums of the recounts not yet closed, packed (zero-padded to a fixed length) for one all-reduce
+VRG_HD void vrg_dense_pack(const VrgCtx& c) {
+    int64_t n = c.dctl[VD_RSEQ] - c.dctl[VD_SEQ];
+    if (n > VRG_STAGE) n = VRG_STAGE;
+    for (int64_t j = 0; j < VRG_STAGE; j++) {
+        VrgDense z = {0.0, 0.0, 0.0, 0.0};
+        c.stage_in[j] = j < n ? c.dn_ring[(c.dctl[VD_SEQ] + 1 + j) % VRG_RING] : z;
+    }
+    c.dctl[VD_NST] = n;
+}
+VRG_HD void vrg_dense_fin_staged(const VrgCtx& c) {
+    for (int64_t j = 0, n = c.dctl[VD_NST]; j < n; j++) vrg_dense_fin_one(c, c.stage_out[j]);
+    c.dctl[VD_NST] = 0;
 }
 // init: the dense pass founds the incremental sizes
 VRG_HD void vrg_init_counts(const VrgCtx& c) {
     c.inc[VC_NIN] = (int64_t)c.dn->n_in; c.inc[VC_NOUT] = (int64_t)c.dn->n_out; c.inc[VC_REQ] = 0;
-    c.dctl[VD_SEQ] = 0; c.dctl[VD_ERR] = 0; c.nchg[0] = 0; c.nchg[1] = 0;
+    c.dctl[VD_SEQ] = 0; c.dctl[VD_ERR] = 0; c.dctl[VD_RSEQ] = 0; c.dctl[VD_NST] = 0; c.nchg[0] = 0; c.nchg[1] = 0;
 }
 
 // ------------------------------------------------------------------ closing the sweep

@@ -87,9 +87,13 @@ struct VrgDense {            // all four as double so one all-reduce sums them o
     double sum_in, sum_out;  // sums of intensities over the two regions
 };
 
-enum { VC_NIN = 0, VC_NOUT = 1, VC_REQ = 2, VC_EXP = 8 };   // VrgCtx::inc; VC_EXP: ring of 4 x {n_in, n_out}, the sizes
-                                                            // after sweep k at slot k & 3 (what dense pass k must reproduce)
-enum { VD_SEQ = 0, VD_ERR = 1 };                  // VrgCtx::dctl (VD_ERR: the dense pass disagreed with the incremental sizes)
+enum { VC_NIN = 0, VC_NOUT = 1, VC_REQ = 2 };     // VrgCtx::inc (VC_REQ: sweep number of the last label write)
+// VrgCtx::dctl - VD_RSEQ: dense recounts done since init (recount k reads class copy k & 1); VD_SEQ: passes closed, i.e.
+// cross-checked against the incremental sizes and filed in the trace (on one GPU the recount closes its own pass; with
+// Z-slabs the partial sums of several recounts are all-reduced together, so VD_SEQ trails VD_RSEQ); VD_ERR: a pass
+// disagreed with the incremental sizes; VD_NST: entries of the staged all-reduce
+enum { VD_SEQ = 0, VD_ERR = 1, VD_RSEQ = 2, VD_NST = 3 };
+enum { VRG_RING = 64, VRG_STAGE = 16 };           // sweeps a recount result / expected size is kept for; slab sums per all-reduce
 
 struct VrgCtx {
     int32_t nx, ny, nz;
@@ -155,8 +159,12 @@ struct VrgCtx {
     // init scratch
     uint64_t* init_key; uint32_t* init_idx;
     VrgState* st;
-    VrgDense* dn;              // global region statistics (sum over all Z-slabs)
-    VrgDense* dn_part;         // this device's slab partials (input of the all-reduce)
+    VrgDense* dn;              // global region statistics of the last closed pass (sum over all Z-slabs)
+    VrgDense* dn_part;         // init: this device's slab partials
+    VrgDense* dn_ring;         // [VRG_RING] this device's slab partials of recount k at k % VRG_RING
+    int64_t* exp_ring;         // [2 * VRG_RING] region sizes after sweep k at k % VRG_RING: what dense pass k must reproduce
+    VrgDense* stage_in;        // [VRG_STAGE] partials of the recounts not yet closed, packed for ONE all-reduce ...
+    VrgDense* stage_out;       // ... and their totals
     int64_t* inc;              // band side (own cache line): region sizes kept by increments as labels are applied -
                                // what the decisions and stop tests read - and the sweep number of the last apply
     int64_t* dctl;             // dense side (own cache line): dense passes closed since init

@@ -122,7 +122,7 @@ void be_init_sort(VrgBackend*, const VrgCtx& c, uint32_t n_in, uint32_t n_out) {
 // the dense recount over this handle's Z-slab, then the sum over the slabs (callback) if there are several
 static void dense_stats(const VrgCtx& c, const uint8_t* lab, be_reduce_fn cb, void* user) {
     int64_t a = 0, b = 0; double sa = 0, sb = 0;
-    const uint32_t* cls = c.clsb[(c.dctl[VD_SEQ] + 1) & 1];
+    const uint32_t* cls = c.clsb[(c.dctl[VD_RSEQ] + 1) & 1];
     for_real_voxels(c, [&](uint32_t idx, int, int, int z) {
         if (z < c.z0 || z >= c.z1) return;
         uint32_t dw, sh; vrg_cls_pos(idx, dw, sh);
@@ -205,7 +205,9 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents*, be_red
     vrg_post_apply(c);
     if (!(flags & VRG_SWEEP_NODENSE)) {
         dense_stats(c, lab, cb, user);      // the dense recount (:113-116) ...
-        vrg_dense_fin(c);                   // ... cross-checks the incremental sizes and files the sums
+        vrg_recount_done(c, *c.dn_part);
+        VrgDense tot = *c.dn;
+        vrg_dense_fin_one(c, tot);          // ... cross-checks the incremental sizes and files the sums
     }
     // closing: flips all visited, dead slots onto the free list, this sweep's level deltas in level order
     for (uint32_t r = 0; r < nf; r++) vrg_item_check_flip(c, r);
@@ -220,6 +222,7 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents*, be_red
 }
 
 void be_events_collect(VrgBackend*, VrgEvents*, long long) {}
+void be_dense_flush(VrgBackend*, const VrgCtx&, be_reduce_fn, void*) {}
 
 void be_recount_hist(VrgBackend*, const VrgCtx& c, int32_t* rin, int32_t* rout) {
     for_real_voxels(c, [&](uint32_t idx, int, int, int) {
