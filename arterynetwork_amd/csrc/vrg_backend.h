@@ -62,6 +62,9 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
 // Z-slabs: all-reduce and close the dense passes whose slab sums are still waiting (they are reduced a few sweeps at a
 // time); collective - every rank calls it at the same point.  The engine calls it before it reads results.
 void be_dense_flush(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user);
+// true: this volume's trips should be host-driven (VRG_SWEEP_SYNC) from the start - its level table is so large that
+// the exact densities of new band entries are spread over the whole chip, which the host has to size
+bool be_wants_sync(VrgBackend* b, const VrgCtx& c);
 // flips one workgroup takes on (k_order); more -> VBAIL_FLIPS
 uint32_t be_small_flip_limit(VrgBackend* b);
 

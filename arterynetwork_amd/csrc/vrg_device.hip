@@ -196,6 +196,64 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c) {
     }
 }
 
+// ---- exact densities when the level table is huge (continuous-valued volumes: about one level per voxel) -----
+// One wave per pending entry (exact_wave) leaves the chip idle when a few hundred entries each need 10^7 kernel
+// evaluations.  Here the LEVELS are spread over the chip: workgroup = 2048 levels held in registers (8 per thread), looped
+// over every pending entry; partial sums per (entry, workgroup) are added up in a fixed order by k_exact_sum, which
+// also decides the entry.  Host-driven trips only (the host has to know the number of pending entries).
+constexpr uint32_t XB_LEVELS = 2048;
+constexpr uint32_t EXACT_BIG_L = 32768;     // level tables beyond this take the route above
+__global__ void __launch_bounds__(TPB) k_exact_big(VrgCtx c, uint32_t nfx, double* part, uint32_t nchunks) {
+    __shared__ double sh[2][4];
+    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6, chunk = blockIdx.x;
+    double lv[8]; int32_t ha[8], hb[8];
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const uint32_t l = chunk * XB_LEVELS + t + 256u * q;
+        const bool in = l < c.L;
+        lv[q] = in ? c.lev[l] : 0.0; ha[q] = in ? c.hin[l] : 0; hb[q] = in ? c.hout[l] : 0;
+        any |= (ha[q] | hb[q]) != 0;
+    }
+    const bool wg_any = __syncthreads_or(any);
+    for (uint32_t f = 0; f < nfx; f++) {
+        double si = 0, so = 0;
+        if (wg_any) {
+            const double v = c.lev[c.p_lev[c.fresh[f]]];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (!(ha[q] | hb[q])) continue;
+                const double k = vrg_kern(c, lv[q] - v);
+                si += (double)ha[q] * k; so += (double)hb[q] * k;
+            }
+            si = wave_sum(si); so = wave_sum(so);
+            if (lane == 0) { sh[0][wv] = si; sh[1][wv] = so; }
+            __syncthreads();
+            if (t == 0) { si = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3]; so = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3]; }
+            __syncthreads();
+        }
+        if (t == 0) { part[((size_t)f * nchunks + chunk) * 2] = si; part[((size_t)f * nchunks + chunk) * 2 + 1] = so; }
+    }
+}
+__global__ void __launch_bounds__(TPB) k_exact_sum(VrgCtx c, uint32_t nfx, const double* part, uint32_t nchunks) {
+    __shared__ double sh[2][4];
+    const VrgState s = *c.st;
+    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6, f = blockIdx.x;
+    if (f >= nfx) return;
+    double si = 0, so = 0;
+    for (uint32_t ch = t; ch < nchunks; ch += TPB) { si += part[((size_t)f * nchunks + ch) * 2]; so += part[((size_t)f * nchunks + ch) * 2 + 1]; }
+    si = wave_sum(si); so = wave_sum(so);
+    if (lane == 0) { sh[0][wv] = si; sh[1][wv] = so; }
+    __syncthreads();
+    if (t == 0) {
+        si = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3]; so = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3];
+        const uint32_t slot = c.fresh[f];
+        c.p_ip[slot] = si; c.p_op[slot] = so;        // (the pending flag is cleared by the slot's own thread in k_band)
+        if (s.iter < s.iterMax) vrg_decide_core(c, s, slot, c.p_flag[slot] & PF_INNER, si, so);
+    }
+}
+__global__ void k_exact_done(VrgCtx c) { c.st->nfx = 0; }
+
 // ---- sorting inside one workgroup -------------------------------------------------------------------------
 // ascending sort of n (key, value) pairs, keys distinct; n <= capacity of the arrays rounded up to a power of two
 // (LDS arrays, or global ones for the rare long list).  All threads of the workgroup call it.
@@ -267,12 +325,12 @@ __device__ __forceinline__ void wait_dense_read(const VrgCtx& c) {
 // recount - or the run has stopped and there is nothing to count.  True at once whenever the dense pass is what bounds
 // the step (the band side runs a sweep ahead); otherwise the recount's workgroups wait here for the labels.
 __device__ __forceinline__ bool gate_dense_due(const VrgCtx& c) {
+    const int64_t rseq = vrg_load_i64(&c.dctl[VD_RSEQ]);       // (only this stream changes it)
     const unsigned long long t0 = wall_clock64();
     for (;;) {
-        if (vrg_dense_due(c)) return true;
-        if (vrg_load_i32(&c.st->done) || vrg_load_i32(&c.st->bail) || vrg_load_i32(&c.st->error))
-            return vrg_dense_due(c);                   // (the last applied sweep's request is older than the stop flag)
-        __builtin_amdgcn_s_sleep(32);
+        if (vrg_load_i64(&c.gate[VG_REQ]) > rseq) return true;
+        if (vrg_load_i64(&c.gate[VG_STOP])) return vrg_load_i64(&c.gate[VG_REQ]) > rseq;   // (the last applied sweep's request is older than the stop flag)
+        __builtin_amdgcn_s_sleep(48);
         if (wall_clock64() - t0 > SPIN_LIMIT) { c.dctl[VD_ERR] = 10; return false; }
     }
 }
@@ -347,6 +405,7 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
         c.lev = s_lev;
     }
     uint8_t* lab = c.lab[0];
+    const uint32_t idx_lo = vrg_idx(c, 0, 0, 0), idx_hi = vrg_idx(c, c.nx - 1, c.ny - 1, c.nz - 1);
     // (every thread of the workgroup makes the same number of trips: the commit below needs its barriers)
     for (uint64_t base = (uint64_t)blockIdx.x * TPB; base < n; base += (uint64_t)gridDim.x * TPB) {
         if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
@@ -355,7 +414,16 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
         const uint64_t i = base + threadIdx.x;
         const uint32_t r = (uint32_t)(i >> 7), p = (uint32_t)(i & 127u);
         int64_t m = 0; uint8_t mb = VB_OOB;
-        if (i < n && p < 125u) { m = vrg_mark_pos(c, c.f_idx[r], p); mb = lab[m]; }
+        VrgPre pre;
+        if (i < n && p < 125u) {
+            m = vrg_mark_pos(c, c.f_idx[r], p);
+            mb = lab[m];
+            // everything the stencil would read at this voxel, fetched NOW, together with its byte and before it is known
+            // whether this thread will run the stencil: one round trip instead of four dependent ones.  (A position
+            // outside the real volume is padding - never relabelled - so its index is clamped to stay inside the arrays.)
+            const int64_t ms = m < (int64_t)idx_lo ? (int64_t)idx_lo : (m > (int64_t)idx_hi ? (int64_t)idx_hi : m);
+            vrg_preload(c, lab, (uint32_t)ms, pre);
+        }
         const bool first = vrg_mark_wanted(p, mb) && vrg_mark_set(c, m);
         // one reservation in the marked list per wave (every first marker of the chip bumping the same word would
         // serialise in L2)
@@ -370,7 +438,7 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
         VrgEvent ev; ev.kind = VE_NONE; ev.pend = 0;
         uint32_t rn = 0, rd = 0, rf = 0;
         if (first) {
-            const uint8_t nw = vrg_sweep_core(c, lab, (uint32_t)m, mb, ev);   // (L / P bits date from k_order: mb is current)
+            const uint8_t nw = vrg_sweep_core_pre(c, lab, (uint32_t)m, mb, pre, ev);   // (L / P bits date from k_order: mb is current)
             if (q < c.mcap) { c.mk_idx[q] = (uint32_t)m; c.mk_new[q] = nw; } else c.st->error = 4;
             // its event takes a number inside the workgroup ...
             if (ev.kind == VE_NEW) rn = atomicAdd(&s_n[0], 1u);
@@ -965,6 +1033,7 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != b->prio_mode) { b->prio_mode = (int)v; make_streams(b); }
 }
 uint32_t be_small_flip_limit(VrgBackend* b) { return b->small_flips; }
+bool be_wants_sync(VrgBackend*, const VrgCtx& c) { return c.L > EXACT_BIG_L; }
 
 void* be_alloc(VrgBackend* b, size_t bytes) { use_device(b); void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
 void be_free(VrgBackend* b, void* p) { use_device(b); HIP_CHECK(hipFree(p)); }
@@ -1242,6 +1311,18 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
         if (b->ev_used == b->ev_pool.size()) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); b->ev_pool.push_back(n); }
         EvPair& p = b->ev_pool[b->ev_used++];
         e_start = p.a; e_stop = p.b;
+    }
+    if ((flags & VRG_SWEEP_SYNC) && c.L > EXACT_BIG_L) {     // huge level table: the pending entries' densities on the whole chip
+        VrgState s0;
+        HIP_CHECK(hipMemcpyAsync(&s0, c.st, sizeof(s0), hipMemcpyDeviceToHost, b->sa));
+        HIP_CHECK(hipStreamSynchronize(b->sa));
+        if (!s0.done && !s0.bail && s0.nfx) {
+            const uint32_t nchunks = (c.L + XB_LEVELS - 1) / XB_LEVELS;
+            if (!need_tmp(b, (size_t)s0.nfx * nchunks * 16)) { std::snprintf(b->err, sizeof(b->err), "out of device memory (exact densities)"); return; }
+            k_exact_big<<<nchunks, TPB, 0, b->sa>>>(c, s0.nfx, (double*)b->tmp, nchunks);
+            k_exact_sum<<<s0.nfx, TPB, 0, b->sa>>>(c, s0.nfx, (const double*)b->tmp, nchunks);
+            k_exact_done<<<1, 1, 0, b->sa>>>(c);
+        }
     }
     k_band<<<BAND_BLOCKS + EXACT_BLOCKS, TPB, 0, b->sa>>>(c);
     if (flags & VRG_SWEEP_SYNC) {

@@ -83,7 +83,11 @@ VrgDense get_dense(vrg_handle* h) {     // region sizes as the band side keeps t
     return d;
 }
 VrgState get_state(vrg_handle* h) { VrgState s; be_download(h->be, &s, h->c.st, sizeof(s)); return s; }
-void put_state(vrg_handle* h, const VrgState& s) { be_upload(h->be, h->c.st, &s, sizeof(s)); }
+void put_state(vrg_handle* h, const VrgState& s) {
+    be_upload(h->be, h->c.st, &s, sizeof(s));
+    const int64_t stop = (s.done || s.bail) ? 1 : 0;       // the dense side's copy of "stopped / handed back"
+    be_upload(h->be, h->c.gate + VG_STOP, &stop, sizeof(stop));
+}
 
 void idx_to_xyz(const VrgCtx& c, uint32_t idx, int64_t* out) {
     int x, y, z; vrg_coords(c, idx, x, y, z);
@@ -107,7 +111,7 @@ bool size_pool(vrg_handle* h, uint64_t want, uint32_t keep, uint32_t keep_free) 
     if (cap > 0x80000000ull) return false;
     bool ok = grow(h, c.p_idx, keep, cap) && grow(h, c.p_lev, keep, cap) && grow(h, c.p_ip, keep, cap) && grow(h, c.p_op, keep, cap) &&
               grow(h, c.p_key, keep, cap) && grow(h, c.p_flag, keep, cap) && grow(h, c.freel, keep_free, cap) &&
-              grow(h, c.flist, 0, cap) && grow(h, c.f_key, 0, cap) && grow(h, c.f_slot, 0, cap) && grow(h, c.f_idx, 0, cap) &&
+              grow(h, c.flist, 0, cap) && grow(h, c.f_key, 0, cap) && grow(h, c.f_slot, 0, cap) && grow(h, c.f_idx, 0, cap) && grow(h, c.f_lev, 0, cap) &&
               grow(h, c.f_res, 0, cap) && grow(h, c.pend, 0, cap) && grow(h, c.fresh, keep, cap) &&
               grow(h, c.init_key, 0, cap) && grow(h, c.init_idx, 0, cap);
     if (!ok) return false;
@@ -166,15 +170,16 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.dn_ring = alloc<VrgDense>(h, VRG_RING); c.exp_ring = alloc<int64_t>(h, 2 * VRG_RING);
     c.stage_in = alloc<VrgDense>(h, VRG_STAGE); c.stage_out = alloc<VrgDense>(h, VRG_STAGE);
     c.inc = alloc<int64_t>(h, 32); c.dctl = alloc<int64_t>(h, 32);   // one allocation each: written from different streams
+    c.gate = alloc<int64_t>(h, 32);
     c.nstat = 4096;
     c.st_nin = alloc<int64_t>(h, c.nstat); c.st_nout = alloc<int64_t>(h, c.nstat);
     c.st_sin = alloc<double>(h, c.nstat); c.st_sout = alloc<double>(h, c.nstat);
     c.trace_cap = 1u << 16;
     c.trace = alloc<VrgTrace>(h, c.trace_cap);
     c.world = 1;
-    if (!c.lab[0] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.dn_ring || !c.exp_ring || !c.stage_in || !c.stage_out || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
+    if (!c.lab[0] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.gate || !c.dn_ring || !c.exp_ring || !c.stage_in || !c.stage_out || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
         !c.nchg || !c.vent || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace) { API(destroy)(h); return VRG_E_MEM; }
-    be_fill(be, c.inc, 0, 32 * sizeof(int64_t)); be_fill(be, c.dctl, 0, 32 * sizeof(int64_t));
+    be_fill(be, c.inc, 0, 32 * sizeof(int64_t)); be_fill(be, c.dctl, 0, 32 * sizeof(int64_t)); be_fill(be, c.gate, 0, 32 * sizeof(int64_t));
     be_fill(be, c.clsb[0], 0, PVu / 4); be_fill(be, c.clsb[1], 0, PVu / 4);
     be_fill(be, c.nchg, 0, 32 * sizeof(uint32_t));
     be_fill(be, h->lab_base[0], VB_OOB, (size_t)c.PV + 32);
@@ -345,7 +350,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     const int base_flags = ((h->variant & 1) ? VRG_SWEEP_FULL : 0) | (h->dense_off ? VRG_SWEEP_NODENSE : 0);
     const uint32_t small = be_small_flip_limit(be);
     for (;;) {
-        const bool sync = h->sync_mode || (base_flags & VRG_SWEEP_FULL);
+        const bool sync = h->sync_mode || (base_flags & VRG_SWEEP_FULL) || be_wants_sync(be, c);
         int64_t remaining = iterMax - s.iter;
         int nb = sync ? 1 : (int)std::min<int64_t>(h->batch, std::max<int64_t>(remaining, 0) + 1);   // +1: the trip that sets the stop flag
         if (maxSeconds >= 0 && s.iter < iterMax) {   // wall-clock cap (:97): tested after the no-flip test, before update()

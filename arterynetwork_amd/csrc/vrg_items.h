@@ -88,6 +88,19 @@ VRG_HD int32_t vrg_off(const VrgCtx& c, int k) {
     int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
     return (dz * c.PY + dy) * c.PX + dx;
 }
+VRG_HD double vrg_kern(const VrgCtx& c, double d) { return c.A * exp(-0.5 * c.H * (d * d)); }   // :154
+
+VRG_HD double vrg_voxel_value(const VrgCtx& c, uint32_t idx) { return c.I ? (double)c.I[idx] : c.I64[idx]; }
+VRG_HD uint32_t vrg_level_of(const VrgCtx& c, double v) {   // index of v in the sorted distinct values
+    uint32_t lo = 0, hi = c.L - 1;
+    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (c.lev[m] < v) lo = m + 1; else hi = m; }
+    return lo;
+}
+// level index of a voxel's intensity: stored (16-bit mode) or looked up in the sorted level table
+VRG_HD uint32_t vrg_voxel_level(const VrgCtx& c, uint32_t idx) {
+    return c.lev16 ? (uint32_t)c.lev16[idx] : vrg_level_of(c, vrg_voxel_value(c, idx));
+}
+
 // The 3x3x3 neighbourhood of a voxel as four 27-bit masks (S, L, P, OOB bit of every neighbour).  The labels are
 // fetched as nine 4-byte rows (x-1 .. x+2 of the nine (dy,dz) lines; x is the fastest axis, and the padding makes every
 // row readable); neighbour n = 3*j + (dx+1) with j = 3*(dy+1) + (dz+1) sits at bit n, the centre at bit 13.  All the
@@ -112,13 +125,22 @@ VRG_HD uint64_t vrg_load_row8(const uint8_t* p) {
 }
 // bits 0, 8, 16 of t (one label bit of the three bytes of a row) gathered into bits 0..2
 VRG_HD uint32_t vrg_gather3(uint32_t t) { return (((t & 0x010101u) * 0x00010204u) >> 16) & 7u; }
-VRG_HD VrgNbr vrg_load_masks(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
-    VrgNbr m = {0u, 0u, 0u, 0u};
-    uint32_t w[9];
+// everything the stencil of one voxel reads at addresses that follow from the voxel alone - fetched in one batch, so
+// that it travels together (the band kernels are bound by DEPENDENT loads): the nine label rows, the voxel's stamp
+// rank, its band slot, its intensity
+struct VrgPre { uint32_t w[9]; uint32_t rank, vent; double val; uint32_t lev16; };
+VRG_HD void vrg_preload(const VrgCtx& c, const uint8_t* lab, uint32_t idx, VrgPre& p) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int j = 0; j < 9; j++) w[j] = vrg_load_row(lab + ((int64_t)idx + ((j % 3 - 1) * c.PY + (j / 3 - 1)) * c.PX - 1));
+    for (int j = 0; j < 9; j++) p.w[j] = vrg_load_row(lab + ((int64_t)idx + ((j % 3 - 1) * c.PY + (j / 3 - 1)) * c.PX - 1));
+    p.rank = (uint32_t)c.stamp[idx]; p.vent = c.vent[idx];
+    p.lev16 = c.lev16 ? (uint32_t)c.lev16[idx] : 0u;
+    p.val = c.lev16 ? 0.0 : vrg_voxel_value(c, idx);
+}
+VRG_HD uint32_t vrg_pre_level(const VrgCtx& c, const VrgPre& p) { return c.lev16 ? p.lev16 : vrg_level_of(c, p.val); }
+VRG_HD VrgNbr vrg_masks_of(const uint32_t* w) {
+    VrgNbr m = {0u, 0u, 0u, 0u};
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -127,6 +149,14 @@ VRG_HD VrgNbr vrg_load_masks(const VrgCtx& c, const uint8_t* lab, uint32_t idx) 
         m.P |= vrg_gather3(w[j] >> 4) << (3 * j); m.O |= vrg_gather3(w[j] >> 5) << (3 * j);
     }
     return m;
+}
+VRG_HD VrgNbr vrg_load_masks(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
+    uint32_t w[9];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 9; j++) w[j] = vrg_load_row(lab + ((int64_t)idx + ((j % 3 - 1) * c.PY + (j / 3 - 1)) * c.PX - 1));
+    return vrg_masks_of(w);
 }
 // neighbour n of the masks: its voxel offset, and its position k in get_neighbours' order (:266-269: dx slowest)
 VRG_HD int32_t vrg_noff(const VrgCtx& c, uint32_t n) {
@@ -148,19 +178,6 @@ VRG_HD uint8_t vrg_dec(uint8_t b) {       // byte -> reference label
     if (b & VB_S) return (b & VB_B) ? 1 : 0;
     if (b & VB_B) return 2;
     return (b & VB_X) ? 4 : 3;
-}
-
-VRG_HD double vrg_kern(const VrgCtx& c, double d) { return c.A * exp(-0.5 * c.H * (d * d)); }   // :154
-
-VRG_HD double vrg_voxel_value(const VrgCtx& c, uint32_t idx) { return c.I ? (double)c.I[idx] : c.I64[idx]; }
-VRG_HD uint32_t vrg_level_of(const VrgCtx& c, double v) {   // index of v in the sorted distinct values
-    uint32_t lo = 0, hi = c.L - 1;
-    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (c.lev[m] < v) lo = m + 1; else hi = m; }
-    return lo;
-}
-// level index of a voxel's intensity: stored (16-bit mode) or looked up in the sorted level table
-VRG_HD uint32_t vrg_voxel_level(const VrgCtx& c, uint32_t idx) {
-    return c.lev16 ? (uint32_t)c.lev16[idx] : vrg_level_of(c, vrg_voxel_value(c, idx));
 }
 
 // ------------------------------------------------------------------ list order
@@ -250,14 +267,14 @@ VRG_HD int32_t vrg_capacity_test(const VrgCtx& c, uint64_t nf) {
     return 0;
 }
 // the trip stops (or is handed back): nothing pending for the next k_band
-VRG_HD void vrg_close_without_update(const VrgCtx& c) { c.st->corr = 0; c.st->nfx = 0; }
+VRG_HD void vrg_close_without_update(const VrgCtx& c) { c.st->corr = 0; c.st->nfx = 0; c.gate[VG_STOP] = 1; }
 // update() begins: k_band has consumed the touched-level list of the sweep before
 VRG_HD void vrg_open_update(const VrgCtx& c) { c.st->nnz = 0; c.st->tab_ok = c.L <= c.st->ni + c.st->no; }
 
 // flip r of the ordered list: L bit (+P for flip-outs, which are always applied), stamp = (sweep, rank)
 VRG_HD void vrg_item_list(const VrgCtx& c, uint32_t r) {
     const uint32_t slot = c.f_slot[r], idx = c.p_idx[slot];
-    c.f_idx[r] = idx; c.f_res[r] = 0;
+    c.f_idx[r] = idx; c.f_lev[r] = c.p_lev[slot]; c.f_res[r] = 0;
     vrg_or_byte(c.lab[0], idx, (uint8_t)(VB_L | ((c.p_flag[slot] & PF_INNER) ? VB_P : 0)));
     c.stamp[idx] = ((uint64_t)(uint32_t)(c.st->iter + 1) << 32) | r;
 }
@@ -415,16 +432,16 @@ VRG_HD bool vrg_ring2_applied(const VrgCtx& c, const uint8_t* lab, uint32_t idx)
 // Returns the voxel's byte after the sweep and files what the change means for the band pool (slot born / dead /
 // re-appended), the class histograms and the sweep's level deltas.  `lab` = this sweep's input labels (L/P bits
 // set); nothing is written to the label volume here, so every stencil read sees the pre-sweep state.
-VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t cb, VrgEvent& ev) {
+VRG_HD uint8_t vrg_sweep_core_pre(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t cb, const VrgPre& pre, VrgEvent& ev) {
     ev.kind = VE_NONE; ev.pend = 0;
-    const VrgNbr m = vrg_load_masks(c, lab, idx);
+    const VrgNbr m = vrg_masks_of(pre.w);
     const uint32_t ex = ~m.O & 0x7ffdfffu;                 // neighbours that exist (:278-280), centre excluded
     const uint32_t segA = m.S & ~m.L & ex, FO = m.S & m.L & ex, AP = ~m.S & m.P & ex;
     const bool nSegA = segA != 0, nFO = FO != 0, nAP = AP != 0, nNonSegB = (ex & ~(segA | AP)) != 0, nListed = (m.L & ex) != 0;
     const VrgState& s = *c.st;
     if (cb & VB_S) {
         if (cb & VB_L) {                              // flip-out (:170-175), always applied
-            const uint32_t r = (uint32_t)c.stamp[idx], slot = c.f_slot[r], lev = c.p_lev[slot];
+            const uint32_t r = pre.rank, slot = c.f_slot[r], lev = c.f_lev[r];
             vrg_atomic_add(&c.hin[lev], -1); vrg_atomic_add(&c.hout[lev], 1);
             const bool to3 = !nSegA && vrg_later_flip(c, FO, idx, r);   // re-examined by a later flip-out neighbour? (:183-190)
             if (!to3) {                               // stays 2, carried to the outer list (by rank)
@@ -447,18 +464,18 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
         bool is1 = (cb & VB_B) || nFO;                // label after phase A (:194)
         if (!is1) return VB_S;
         if (nAP && !nNonSegB) {                       // 1 -> 0 (:223-228)
-            if (cb & VB_B) vrg_ev_die(ev, c.vent[idx], true);
+            if (cb & VB_B) vrg_ev_die(ev, pre.vent, true);
             return VB_S;
         }
         if (!(cb & VB_B)) {                           // newly on the inner boundary
             uint32_t pr, pk; vrg_promoter(c, FO, idx, pr, pk);
-            vrg_ev_new(ev, vrg_voxel_level(c, idx), true, vrg_key(s, 0, pr, pk));
+            vrg_ev_new(ev, vrg_pre_level(c, pre), true, vrg_key(s, 0, pr, pk));
         }
         return VB_S | VB_B;
     }
     if (cb & VB_B) {
         if ((cb & VB_L) && (cb & VB_P)) {             // applied flip-in (:198-204)
-            const uint32_t r = (uint32_t)c.stamp[idx], slot = c.f_slot[r], lev = c.p_lev[slot];
+            const uint32_t r = pre.rank, slot = c.f_slot[r], lev = c.f_lev[r];
             vrg_atomic_add(&c.hin[lev], 1); vrg_atomic_add(&c.hout[lev], -1);
             const bool to0 = !nNonSegB && vrg_later_flip(c, AP, idx, r);   // re-examined by a later applied flip-in nbr? (:219-228)
             bool fresh = nFO && !nSegA;               // had dropped to 3 in phase A: exact density (:212,:251)
@@ -474,12 +491,12 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
         else if (nAP) {                               // left the band and re-entered: a new outer entry
             out = VB_B; res = 2 | FR_FRESH;
             uint32_t pr, pk; vrg_promoter(c, AP, idx, pr, pk);
-            vrg_ev_move(ev, c.vent[idx], false, false, vrg_key(s, 1, pr, pk), true);
-        } else { out = 0; res = 3; vrg_ev_die(ev, c.vent[idx], false); }
+            vrg_ev_move(ev, pre.vent, false, false, vrg_key(s, 1, pr, pk), true);
+        } else { out = 0; res = 3; vrg_ev_die(ev, pre.vent, false); }
         if (cb & VB_L) {                              // skipped flip-in
-            const uint32_t r = (uint32_t)c.stamp[idx];
+            const uint32_t r = pre.rank;
             c.f_res[r] = (uint8_t)(FR_WRITTEN | res);
-            if ((res & FR_FINAL) == 2) vrg_note_level(c, c.dOut, c.p_lev[c.f_slot[r]]);
+            if ((res & FR_FINAL) == 2) vrg_note_level(c, c.dOut, c.f_lev[r]);
         }
         return out;
     }
@@ -489,18 +506,23 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
     if (cb & VB_X) {
         conv = nListed || vrg_ring2_applied(c, lab, idx);   // 1-ring of any listed flip (:166-168), 2-ring of any applied flip
         if (conv) {                                   // addedPoints (:235); the voxel joins the outer region
-            lev = vrg_voxel_level(c, idx);
+            lev = vrg_pre_level(c, pre);
             vrg_note_level(c, c.dConv, lev);
             vrg_atomic_add(&c.hout[lev], 1);
         }
     }
     if (nAP) {                                        // 3 -> 2 (:210-213)
-        if (lev == 0xffffffffu) lev = vrg_voxel_level(c, idx);
+        if (lev == 0xffffffffu) lev = vrg_pre_level(c, pre);
         uint32_t pr, pk; vrg_promoter(c, AP, idx, pr, pk);
         vrg_ev_new(ev, lev, false, vrg_key(s, 1, pr, pk));
         return VB_B;
     }
     return (uint8_t)(((cb & VB_X) && !conv) ? VB_X : 0);
+}
+
+VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t cb, VrgEvent& ev) {
+    VrgPre pre; vrg_preload(c, lab, idx, pre);
+    return vrg_sweep_core_pre(c, lab, idx, cb, pre, ev);
 }
 
 // sparse relabel, phase 1: new byte of every marked voxel from the OLD labels
@@ -566,8 +588,8 @@ VRG_HD void vrg_item_cls_build(const VrgCtx& c, uint32_t d) {
     c.clsb[0][d] = w; c.clsb[1][d] = w;
 }
 // one caller per applied sweep: the labels of sweep iter+1 are in place, a dense pass over them is due
-VRG_HD void vrg_request_dense(const VrgCtx& c) { c.inc[VC_REQ] = (int64_t)c.st->iter + 1; }
-VRG_HD bool vrg_dense_due(const VrgCtx& c) { return vrg_load_i64(&c.inc[VC_REQ]) > vrg_load_i64(&c.dctl[VD_RSEQ]); }
+VRG_HD void vrg_request_dense(const VrgCtx& c) { c.gate[VG_REQ] = (int64_t)c.st->iter + 1; }
+VRG_HD bool vrg_dense_due(const VrgCtx& c) { return vrg_load_i64(&c.gate[VG_REQ]) > vrg_load_i64(&c.dctl[VD_RSEQ]); }
 // recount number rseq = recounts done + 1 (it read class copy rseq & 1) has this device's slab sums: keep them for the pass
 VRG_HD void vrg_recount_done(const VrgCtx& c, const VrgDense& part) {
     const int64_t rseq = c.dctl[VD_RSEQ] + 1;
@@ -598,7 +620,7 @@ VRG_HD void vrg_dense_fin_staged(const VrgCtx& c) {
 }
 // init: the dense pass founds the incremental sizes
 VRG_HD void vrg_init_counts(const VrgCtx& c) {
-    c.inc[VC_NIN] = (int64_t)c.dn->n_in; c.inc[VC_NOUT] = (int64_t)c.dn->n_out; c.inc[VC_REQ] = 0;
+    c.inc[VC_NIN] = (int64_t)c.dn->n_in; c.inc[VC_NOUT] = (int64_t)c.dn->n_out; c.gate[VG_REQ] = 0; c.gate[VG_STOP] = 0;
     c.dctl[VD_SEQ] = 0; c.dctl[VD_ERR] = 0; c.dctl[VD_RSEQ] = 0; c.dctl[VD_NST] = 0; c.nchg[0] = 0; c.nchg[1] = 0;
 }
 
@@ -644,7 +666,7 @@ VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
     s.nf = 0; s.npend = 0; s.nmk = 0; s.nalloc = 0; s.ndead = 0; s.d_ni = 0; s.d_no = 0;
     s.nfx = s.nfresh; s.nfresh = 0;                   // exact densities of the new entries: first thing next trip
     s.corr = 1; s.use_tab = use_tab ? 1 : 0;          // nnz stays: the next k_band reads the touched-level list
-    if (s.error) s.done = -1;
+    if (s.error) { s.done = -1; c.gate[VG_STOP] = 1; }
     *c.st = s;
 }
 

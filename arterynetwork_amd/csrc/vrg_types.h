@@ -87,7 +87,11 @@ struct VrgDense {            // all four as double so one all-reduce sums them o
     double sum_in, sum_out;  // sums of intensities over the two regions
 };
 
-enum { VC_NIN = 0, VC_NOUT = 1, VC_REQ = 2 };     // VrgCtx::inc (VC_REQ: sweep number of the last label write)
+enum { VC_NIN = 0, VC_NOUT = 1 };                  // VrgCtx::inc
+// VrgCtx::gate - what the dense side polls while it waits for the band side (a cache line nothing else touches: the
+// decisions read VrgCtx::inc all the time): VG_REQ sweep number of the last label write; VG_STOP the run has stopped or the
+// trip was handed back
+enum { VG_REQ = 0, VG_STOP = 1 };
 // VrgCtx::dctl - VD_RSEQ: dense recounts done since init (recount k reads class copy k & 1); VD_SEQ: passes closed, i.e.
 // cross-checked against the incremental sizes and filed in the trace (on one GPU the recount closes its own pass; with
 // Z-slabs the partial sums of several recounts are all-reduced together, so VD_SEQ trails VD_RSEQ); VD_ERR: a pass
@@ -149,7 +153,8 @@ struct VrgCtx {
     uint32_t* flist;           // slots of the listed flips as k_band appended them, unordered
     uint64_t* f_key;           // ... sort keys (scratch of the host-driven sort)
     uint32_t* f_slot;          // flip list in the reference's order (:88): slot ...
-    uint32_t* f_idx;           // ... and voxel of flip r
+    uint32_t* f_idx;           // ... voxel ...
+    uint32_t* f_lev;           // ... and intensity level of flip r
     uint8_t* f_res;            // FR_* result of flip r
     uint32_t* pend;            // ranks of the flip-ins in the skip-rule fix-point
     uint32_t* fresh;           // slots needing exact densities
@@ -168,6 +173,7 @@ struct VrgCtx {
     int64_t* inc;              // band side (own cache line): region sizes kept by increments as labels are applied -
                                // what the decisions and stop tests read - and the sweep number of the last apply
     int64_t* dctl;             // dense side (own cache line): dense passes closed since init
+    int64_t* gate;             // band -> dense hand-off words (own cache line), VG_*
     int32_t world;             // number of slabs / ranks (1: dn is written directly)
     uint32_t* counters;        // arrival tickets of the last-workgroup reductions (zero between launches)
     VrgTrace* trace;

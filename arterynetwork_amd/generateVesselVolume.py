@@ -66,8 +66,16 @@ def labelVolume(volume, minSize=1, maxHop=3, device=0):
     labelResult : list
         [(label, size), ...] for every label present, background included, exactly like
         np.bincount(labeled.ravel()) filtered to non-zero counts (:131-134).  `minSize` is accepted and
-        unused, as in the reference.
+        unused, as in this reference function (the copy in skeletonization.py filters by it; its only caller passes 1).
+
+    Only binary volumes are accepted: skimage.measure.label connects voxels of EQUAL value, so a volume with several
+    non-zero values would be partitioned differently from what this kernel (which looks at zero / non-zero) does -
+    such input raises instead of returning different labels.
     """
+    a = np.asarray(volume)
+    nz = a[a != 0]
+    if nz.size and np.any(nz != nz.flat[0]):
+        raise ValueError('labelVolume: only binary volumes are supported (several distinct non-zero values found)')
     v = _u8c(volume)
     labeled = np.empty(v.shape, np.int32)
     n = C.c_int64()

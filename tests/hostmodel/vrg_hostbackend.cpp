@@ -29,6 +29,7 @@ void be_sync(VrgBackend*) {}
 const char* be_last_error(VrgBackend*) { return nullptr; }
 void be_clear_error(VrgBackend*) {}
 uint32_t be_small_flip_limit(VrgBackend* b) { return b->small_flips; }
+bool be_wants_sync(VrgBackend*, const VrgCtx&) { return false; }
 
 namespace {
 double load_as_double(const void* p, int dtype, int64_t i) {
