@@ -53,6 +53,7 @@ struct VrgBackend {
     void* tmp = nullptr; size_t tmp_bytes = 0;        // scratch of the host-driven sorts
     uint64_t* keys2 = nullptr; size_t keys2_n = 0;
     int dense_pending = 0;                            // Z-slabs: recounts enqueued since the last staged all-reduce
+    int serial = 0;                                   // option "serial_streams": see be_sweep_once
 };
 
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess && !b->err[0]) { \
@@ -321,9 +322,11 @@ __device__ __forceinline__ void wait_dense_read(const VrgCtx& c) {
         if (wall_clock64() - t0 > SPIN_LIMIT) { c.st->error = 9; return; }
     }
 }
-// dense side, first thing in every recount (one thread per workgroup looks): a sweep has been applied since the last
-// recount - or the run has stopped and there is nothing to count.  True at once whenever the dense pass is what bounds
-// the step (the band side runs a sweep ahead); otherwise the recount's workgroups wait here for the labels.
+// dense side, in front of every recount: a sweep has been applied since the last recount - or the run has stopped and
+// there is nothing to count.  True at once whenever the dense pass is what bounds the step (the band side runs a sweep
+// ahead).  A kernel of its own (one thread), not the first thing in the recount: the recount's duration - what the HIP
+// events and rocprofv3 report for the roofline - must be streaming time only, and workgroups that wait while holding
+// LDS (the 16-bit variant: 64 KiB each) could leave no CU for k_close, which produces what they wait for.
 __device__ __forceinline__ bool gate_dense_due(const VrgCtx& c) {
     const int64_t rseq = vrg_load_i64(&c.dctl[VD_RSEQ]);       // (only this stream changes it)
     const unsigned long long t0 = wall_clock64();
@@ -334,9 +337,6 @@ __device__ __forceinline__ bool gate_dense_due(const VrgCtx& c) {
         if (wall_clock64() - t0 > SPIN_LIMIT) { c.dctl[VD_ERR] = 10; return false; }
     }
 }
-// the same wait as a kernel of its own, for a recount whose workgroups must not sit on the chip while they wait: the
-// 16-bit variant holds 64 KiB of LDS per workgroup, two per CU - waiting there, it would leave no CU on which k_close
-// (which produces what it waits for) could start
 __global__ void k_gate(VrgCtx c) { if (threadIdx.x == 0) (void)gate_dense_due(c); }
 __global__ void k_wait_dense(VrgCtx c) { if (threadIdx.x == 0) wait_dense_read(c); }
 
@@ -738,13 +738,7 @@ __device__ __forceinline__ void load_unit(const VrgCtx& c, const uint32_t* cls, 
 }
 template <int UNITS, bool NT, int MODE>
 __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) {
-    __shared__ int s_due;
-    if (check_done) {                                // wait for the sweep's labels; nothing to do once the run has stopped
-        if (threadIdx.x == 0) s_due = ((check_done & 4) ? vrg_dense_due(c) : gate_dense_due(c)) ? 1 : 0;   // (4: k_gate has waited already)
-        __syncthreads();
-        if (!s_due) return;
-        check_done &= 3;
-    }
+    if (check_done && !vrg_dense_due(c)) return;     // k_gate let it through without a sweep to count: the run has stopped
     __shared__ float s_val[MODE == 1 ? LEV16_MAX : 1];
     if (MODE == 1) {
         for (uint32_t i = threadIdx.x; i < c.L; i += TPB) s_val[i] = (float)c.lev[i];
@@ -1029,6 +1023,7 @@ void be_destroy(VrgBackend* b) {
 void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     use_device(b);
     if (std::strcmp(name, "sweep_blocks") == 0 && v >= 0 && v <= 4096) b->sweep_blocks = (int)v;
+    if (std::strcmp(name, "serial_streams") == 0) b->serial = v != 0;
     if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)std::min<long long>(v, NF_SMALL);
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != b->prio_mode) { b->prio_mode = (int)v; make_streams(b); }
 }
@@ -1221,10 +1216,8 @@ int be_comm_init(VrgBackend* b, int nranks, int rank, const void* id128) {
 // The start / stop events ride on the dispatch itself (hipExtLaunchKernel): no separate event packets in the stream,
 // which cost ~4 us each between two back-to-back recounts.
 static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t st, hipEvent_t e_start = nullptr, hipEvent_t e_stop = nullptr) {
-    if (c.lev16) {
-        if (check) { k_gate<<<1, 64, 0, st>>>(c); check |= 4; }
-        hipExtLaunchKernelGGL((k_recount_bits<3, true, 1>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
-    }
+    if (check) k_gate<<<1, 64, 0, st>>>(c);        // waits (on the device) until the sweep's labels are in place
+    if (c.lev16) hipExtLaunchKernelGGL((k_recount_bits<3, true, 1>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
     else if (c.I) hipExtLaunchKernelGGL((k_recount_bits<3, true, 0>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
     else hipExtLaunchKernelGGL((k_recount_bits<2, true, 2>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
 }
@@ -1336,9 +1329,13 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
         small_update(b, c, dense);
     }
     if (!dense) return;
-    // dense stream: every voxel once, read-only; the recount itself waits until the sweep's labels are in place
+    // dense stream: every voxel once, read-only; k_gate in front of the recount waits until the sweep's labels are in place.
+    // (Option "serial_streams", for tools that run one kernel at a time - rocprofv3 --pmc does: a kernel that waits on the
+    // device for another one could then wait for ever, so the host orders the two streams instead.)
+    if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sa));
     const bool ranks = c.world > 1 || b->comm || cb;
     launch_recount(c, dense_blocks(b, c), ranks ? 1 : 2, b->sb, e_start, e_stop);
+    if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sb));
     // one GPU: the last workgroup of the recount closes the pass itself.  Z-slabs: the slab sums of DENSE_GROUP recounts
     // are summed over the ranks by ONE all-reduce (nothing on the band side waits for it: the decisions use the
     // incremental sizes; the totals are only cross-checked against them and filed in the trace)

@@ -196,6 +196,7 @@ def main():
     ap.add_argument('--sweep-blocks', type=int, default=0)
     ap.add_argument('--prio-mode', type=int, default=-1)
     ap.add_argument('--events', type=int, default=1, help='0: no HIP events around the dense launches (no roofline then)')
+    ap.add_argument('--serial', type=int, default=0, help='1: option serial_streams (needed under rocprofv3 --pmc, which runs one kernel at a time)')
     ap.add_argument('--storage16', action='store_true', help='16-bit intensity storage (level indices): config 5 style; 4 B/voxel-iter algorithmic')
     ap.add_argument('--force-dist', action='store_true', help='use the N>1 code path (RCCL comm) even with one rank')
     args = ap.parse_args()
@@ -244,6 +245,8 @@ def main():
         s.set_option('storage16', 1)
     s.set_option('events', args.events)
     s.set_option('batch', 64)
+    if args.serial:
+        s.set_option('serial_streams', 1)
     s.set_volume_ptr(I.data_ptr(), np.float32, [st for st in I.stride()])
     s.set_labels_ptr(vm.data_ptr(), np.uint8, [st for st in vm.stride()])
     t0 = time.perf_counter()

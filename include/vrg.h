@@ -76,6 +76,9 @@ const char* vrg_last_error(const vrg_handle* h);
  *   "batch"          any time; sweeps enqueued between host checks of the stop flag (default 8)
  *   "small_flips"    any time; flips per sweep up to which update() runs as ONE workgroup's kernel (default and
  *                    maximum 4096); sweeps with more are driven from the host with device-wide kernels
+ *   "serial_streams" any time; the host orders the band and dense streams (a synchronisation per sweep) instead of the
+ *                    kernels waiting for each other on the device - for tools that run one kernel at a time
+ *                    (rocprofv3 --pmc), under which a device-side wait could never end
  *   "dense_off"      any time; measurement aid: the dense recount is not launched (the band chain alone);
  *                    the handle has to be initialised again afterwards
  *   "sweep_blocks", "prio_mode"

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/prof_<tag> (tools/profile_gpu.sh) into profiles/<tag>_*.csv + profiles/traffic.json."""
 import csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 tag = sys.argv[1]
 shape = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else '880x880x640').split('x')]
 src = 'gpurun_out/prof_' + tag
@@ -44,13 +46,14 @@ V = shape[0] * shape[1] * shape[2]
 PX = (shape[0] + 2 + 15) // 16 * 16
 streamed = shape[2] * (shape[1] + 4) * PX          # padded interior voxels the kernel actually reads
 out = {
-    'shape': shape, 'n_gpus': 1, 'kernel': 'k_recount_bits',
+    'shape': shape, 'n_gpus': 1, 'storage16': False, 'kernel': 'k_recount_bits', 'src_sha': bench.device_source_sha(),
     'FETCH_SIZE_KB_per_launch_raw': fk, 'WRITE_SIZE_KB_per_launch_raw': wk,
     'note': 'gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md, HBM); '
             'corrected fetch = 2 x raw. WRITE_SIZE is exact.',
     'hbm_bytes_per_launch': int((2 * fk + wk) * 1024),
     'algorithmic_bytes_per_launch': 6 * V, 'bytes_actually_streamed_per_launch': int(4.25 * streamed),
 }
+out['src_sha_note'] = 'sha256[:16] of csrc/vrg_device.hip + vrg_items.h + vrg_types.h at profiling time; bench.py reports this traffic figure only while those sources are unchanged'
 json.dump(out, open('profiles/traffic.json', 'w'), indent=1)
 with open('profiles/%s_pmc.csv' % tag, 'w') as f:
     f.write('# separate passes: rocprofv3 --pmc FETCH_SIZE ... ; rocprofv3 --pmc WRITE_SIZE ... (k_recount rows, per launch)\n')
