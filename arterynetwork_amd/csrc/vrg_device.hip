@@ -136,7 +136,8 @@ __device__ void exact_wave(const VrgCtx& c, const VrgState& s, uint32_t nfresh, 
         si = wave_sum(si); so = wave_sum(so);
         if (lane == 0) {
             c.p_ip[slot] = si; c.p_op[slot] = so;        // (the pending flag is cleared by the slot's own thread in the other half)
-            if (then_decide && s.iter < s.iterMax) vrg_decide_core(c, s, slot, c.p_flag[slot] & PF_INNER, si, so);   // while iterNum <= iterMax (:58)
+            if (then_decide && s.iter < s.iterMax)       // while iterNum <= iterMax (:58)
+                vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot]);
         }
     }
 }
@@ -173,11 +174,11 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c) {
     const uint32_t sub = threadIdx.x & (LPE - 1);
     const uint32_t np_pad = (s.np + (TPB / LPE) - 1) / (TPB / LPE) * (TPB / LPE);      // whole waves stay in the loop together
     for (uint32_t slot = (blockIdx.x * TPB + threadIdx.x) / LPE; slot < np_pad; slot += BAND_BLOCKS * TPB / LPE) {
-        uint8_t fl = 0; double ip = 0, op = 0, v = 0;
+        uint8_t fl = 0; double ip = 0, op = 0, v = 0; uint32_t lev = 0;
         const bool live = slot < s.np;
-        if (live) fl = c.p_flag[slot];
+        if (live) { fl = c.p_flag[slot]; ip = c.p_ip[slot]; op = c.p_op[slot]; lev = c.p_lev[slot]; }   // one batch
         const bool work = live && (fl & PF_ALIVE) && !(fl & PF_PEND);
-        if (work) { ip = c.p_ip[slot]; op = c.p_op[slot]; v = c.lev[c.p_lev[slot]]; }
+        if (work) v = c.lev[lev];
         double a = 0, bb = 0, d = 0;
         if (work)
             for (uint32_t j = sub; j < s.nnz; j += LPE) {
@@ -191,7 +192,8 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c) {
             else if (work) {
                 vrg_add_correction(a, bb, d, ip, op);
                 c.p_ip[slot] = ip; c.p_op[slot] = op;
-                if (s.iter < s.iterMax) vrg_decide_core(c, s, slot, fl & PF_INNER, ip, op);   // while iterNum <= iterMax (:58)
+                if (s.iter < s.iterMax)              // while iterNum <= iterMax (:58)
+                    vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, fl & PF_INNER, ip, op, c.p_key[slot], c.p_idx[slot], lev);
             }
         }
     }
@@ -250,7 +252,8 @@ __global__ void __launch_bounds__(TPB) k_exact_sum(VrgCtx c, uint32_t nfx, const
         si = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3]; so = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3];
         const uint32_t slot = c.fresh[f];
         c.p_ip[slot] = si; c.p_op[slot] = so;        // (the pending flag is cleared by the slot's own thread in k_band)
-        if (s.iter < s.iterMax) vrg_decide_core(c, s, slot, c.p_flag[slot] & PF_INNER, si, so);
+        if (s.iter < s.iterMax)
+            vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot]);
     }
 }
 __global__ void k_exact_done(VrgCtx c) { c.st->nfx = 0; }
@@ -346,8 +349,10 @@ constexpr uint32_t NZ_SORT = 2048;  // touched levels one workgroup sorts in LDS
 
 __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_limit) {
 
+    constexpr uint32_t REC_LDS = 1024;
     __shared__ uint64_t s_key[NF_SMALL];
     __shared__ uint32_t s_slot[NF_SMALL];
+    __shared__ uint32_t s_rslot[REC_LDS], s_ridx[REC_LDS], s_rlev[REC_LDS];
     __shared__ int s_go, s_changed;
     constexpr uint32_t T = KO_THREADS;
     const uint32_t t = threadIdx.x;
@@ -367,11 +372,20 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
     if (!s_go) return;
     const uint32_t nf = c.st->nf;
     for (uint32_t j = t, n = c.st->nnz; j < n; j += T) vrg_item_level_clear(c, j);   // level counters of the sweep before
-    for (uint32_t q = t; q < nf; q += T) { const uint32_t slot = c.flist[q]; s_key[q] = vrg_flip_key(c, slot); s_slot[q] = slot; }
+    // the flips' records as k_band appended them; sorted by key, the payload being the record's number
+    for (uint32_t q = t; q < nf; q += T) { s_key[q] = c.f_key[q]; s_slot[q] = q; }
+    // (a short list - the usual case - keeps the rest of every record in LDS too: no dependent look-up after the sort)
+    const bool rec_lds = nf <= REC_LDS;
+    if (rec_lds) for (uint32_t q = t; q < nf; q += T) { s_rslot[q] = c.flist[q]; s_ridx[q] = c.fr_idx[q]; s_rlev[q] = c.fr_lev[q]; }
     __syncthreads();
     if (t == 0) vrg_open_update(c);
     wg_sort_pairs(s_key, s_slot, nf, true);
-    for (uint32_t r = t; r < nf; r += T) { c.f_slot[r] = s_slot[r]; vrg_item_list(c, r); }   // L (+P) bits, stamps
+    for (uint32_t r = t; r < nf; r += T) {               // L (+P) bits, stamps, the ordered flip arrays
+        const uint32_t q = s_slot[r];
+        const bool inner = !(s_key[r] >> 63);
+        if (rec_lds) vrg_item_list_rec(c, r, s_rslot[q], s_ridx[q], s_rlev[q], inner);
+        else vrg_item_list_rec(c, r, c.flist[q], c.fr_idx[q], c.fr_lev[q], inner);
+    }
     __syncthreads();
     for (uint32_t r = t; r < nf; r += T) vrg_item_prepass(c, r);         // phase-A label of the flip-ins
     __syncthreads();
@@ -537,7 +551,6 @@ __global__ void __launch_bounds__(TPB) k_trip_open(VrgCtx c) {   // stop tests a
     __syncthreads();
     if (threadIdx.x == 0) vrg_open_update(c);
 }
-__global__ void k_flip_keys(VrgCtx c, uint32_t nf) { ITEM_LOOP(nf) c.f_key[i] = vrg_flip_key(c, c.flist[i]); }
 __global__ void k_list(VrgCtx c, uint32_t nf) { ITEM_LOOP(nf) vrg_item_list(c, i); }
 __global__ void k_marks_prepass(VrgCtx c, uint32_t nf) {
     ITEM_LOOP64((uint64_t)nf * 128u) {
@@ -1258,7 +1271,6 @@ static void host_driven_update(VrgBackend* b, const VrgCtx& c, int flags) {
     if (!need_keys2(b, nf)) { std::snprintf(b->err, sizeof(b->err), "out of device memory (flip sort)"); return; }
     HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, c.f_key, b->keys2, c.flist, c.f_slot, nf, 0, 64, b->sa));
     if (!need_tmp(b, tb)) { std::snprintf(b->err, sizeof(b->err), "out of device memory (flip sort)"); return; }
-    k_flip_keys<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nf);
     HIP_CHECK(rocprim::radix_sort_pairs(b->tmp, tb, c.f_key, b->keys2, c.flist, c.f_slot, nf, 0, 64, b->sa));
     k_list<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nf);
     if (flags & VRG_SWEEP_FULL) k_prepass<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nf);

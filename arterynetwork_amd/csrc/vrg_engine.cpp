@@ -111,7 +111,7 @@ bool size_pool(vrg_handle* h, uint64_t want, uint32_t keep, uint32_t keep_free) 
     if (cap > 0x80000000ull) return false;
     bool ok = grow(h, c.p_idx, keep, cap) && grow(h, c.p_lev, keep, cap) && grow(h, c.p_ip, keep, cap) && grow(h, c.p_op, keep, cap) &&
               grow(h, c.p_key, keep, cap) && grow(h, c.p_flag, keep, cap) && grow(h, c.freel, keep_free, cap) &&
-              grow(h, c.flist, 0, cap) && grow(h, c.f_key, 0, cap) && grow(h, c.f_slot, 0, cap) && grow(h, c.f_idx, 0, cap) && grow(h, c.f_lev, 0, cap) &&
+              grow(h, c.flist, 0, cap) && grow(h, c.f_key, 0, cap) && grow(h, c.fr_idx, 0, cap) && grow(h, c.fr_lev, 0, cap) && grow(h, c.f_slot, 0, cap) && grow(h, c.f_idx, 0, cap) && grow(h, c.f_lev, 0, cap) &&
               grow(h, c.f_res, 0, cap) && grow(h, c.pend, 0, cap) && grow(h, c.fresh, keep, cap) &&
               grow(h, c.init_key, 0, cap) && grow(h, c.init_idx, 0, cap);
     if (!ok) return false;

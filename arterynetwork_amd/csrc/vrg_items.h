@@ -51,7 +51,8 @@ VRG_HD uint8_t vrg_load_coherent(const uint8_t* p) {
 VRG_HD uint32_t vrg_load_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 VRG_HD int32_t vrg_load_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 VRG_HD int64_t vrg_load_i64(const int64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#else
+#elif defined(VRG_HOSTMODEL)
+// tests/hostmodel only (sequential test model of the kernels; never part of the product library)
 VRG_HD uint32_t vrg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 VRG_HD int32_t vrg_atomic_add(int32_t* p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
 VRG_HD uint32_t vrg_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
@@ -61,6 +62,18 @@ VRG_HD uint8_t vrg_load_coherent(const uint8_t* p) { return *(const volatile uin
 VRG_HD uint32_t vrg_load_u32(const uint32_t* p) { return *p; }
 VRG_HD int32_t vrg_load_i32(const int32_t* p) { return *p; }
 VRG_HD int64_t vrg_load_i64(const int64_t* p) { return *p; }
+#else
+// host pass of the product build (hipcc compiles __host__ __device__ functions for both sides): the product has no CPU
+// path - the item functions are never called on the host there, and if one ever were it stops right here
+VRG_HD uint32_t vrg_atomic_add(uint32_t*, uint32_t) { __builtin_trap(); }
+VRG_HD int32_t vrg_atomic_add(int32_t*, int32_t) { __builtin_trap(); }
+VRG_HD uint32_t vrg_atomic_or(uint32_t*, uint32_t) { __builtin_trap(); }
+VRG_HD void vrg_atomic_add64(int64_t*, int64_t) { __builtin_trap(); }
+VRG_HD void vrg_atomic_xor(uint32_t*, uint32_t) { __builtin_trap(); }
+VRG_HD uint8_t vrg_load_coherent(const uint8_t*) { __builtin_trap(); }
+VRG_HD uint32_t vrg_load_u32(const uint32_t*) { __builtin_trap(); }
+VRG_HD int32_t vrg_load_i32(const int32_t*) { __builtin_trap(); }
+VRG_HD int64_t vrg_load_i64(const int64_t*) { __builtin_trap(); }
 #endif
 
 // OR bits into one label byte without disturbing concurrent ORs into its neighbours
@@ -185,9 +198,7 @@ VRG_HD uint64_t vrg_key(const VrgState& s, uint32_t phase, uint32_t rank, uint32
     return ((uint64_t)(uint32_t)(s.iter + 1) << 40) | ((uint64_t)phase << 39) | ((uint64_t)rank << 5) | (uint64_t)k;
 }
 // sort key of a listed flip: inner list before outer list (:48), each in list order
-VRG_HD uint64_t vrg_flip_key(const VrgCtx& c, uint32_t slot) {
-    return ((c.p_flag[slot] & PF_INNER) ? 0ull : (1ull << 63)) | c.p_key[slot];
-}
+VRG_HD uint64_t vrg_flip_key(bool inner, uint64_t key) { return (inner ? 0ull : (1ull << 63)) | key; }
 
 // ------------------------------------------------------------------ k_band: correction of the sweep before + decide (:79-88)
 // density correction of one intensity value (:236-247)
@@ -204,9 +215,10 @@ VRG_HD void vrg_add_correction(double ic, double oc, double ac, double& ip, doub
     ip += ic; ip -= oc;             // :243-244
     op -= ic; op += oc; op += ac;   // :245-247
 }
-// A flip is listed by an unordered append of its slot; the sweep kernel orders the list.
-VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, uint32_t slot, bool inner, double ip, double op) {
-    const int64_t n_in = c.inc[VC_NIN], n_out = c.inc[VC_NOUT];
+// A flip is listed by an unordered append of its record (slot, sort key, voxel, level); k_order orders the list.
+// n_in / n_out: the region sizes (VrgCtx::inc), read once per thread by the caller
+VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, int64_t n_in, int64_t n_out, uint32_t slot, bool inner, double ip, double op,
+                            uint64_t key, uint32_t idx, uint32_t lev) {
     double inN = ip / (double)n_in;                       // :81
     double outN = op / (double)n_out;                     // :82
     bool ge = inN >= outN;
@@ -214,26 +226,29 @@ VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, uint32_t slot, b
     uint32_t q = vrg_atomic_add(&c.st->nf, 1u);
     if (s.time_up || n_in >= s.maxSegmentSize) return;    // :97 / :101 fire before update(): count only
     if (q >= c.fcap) { c.st->error = 2; return; }
-    c.flist[q] = slot;
+    c.flist[q] = slot; c.f_key[q] = vrg_flip_key(inner, key); c.fr_idx[q] = idx; c.fr_lev[q] = lev;
 }
 // one pool slot; nz_* = this trip's view of the touched-level list (LDS copy on the device)
 VRG_HD void vrg_item_band(const VrgCtx& c, const VrgState& s, uint32_t slot, const double* nz_val, const uint32_t* nz_cin,
                           const uint32_t* nz_cout, const uint32_t* nz_cconv) {
+    // the slot's fields in one batch (a dead slot's are read for nothing): the kernel is bound by dependent loads
     const uint8_t fl = c.p_flag[slot];
+    double ip = c.p_ip[slot], op = c.p_op[slot];
+    const uint32_t lev = c.p_lev[slot], idx = c.p_idx[slot];
+    const uint64_t key = c.p_key[slot];
+    const int64_t n_in = c.inc[VC_NIN], n_out = c.inc[VC_NOUT];
     if (!(fl & PF_ALIVE)) return;
     // an entry that (re-)entered the band in the sweep before takes no correction; it is decided by whoever computes
     // its exact densities (the other half of this launch, which reads only the list bit of the flag)
     if (fl & PF_PEND) { c.p_flag[slot] = (uint8_t)(fl & ~PF_PEND); return; }
-    double ip = c.p_ip[slot], op = c.p_op[slot];
     if (s.corr) {
-        const uint32_t lev = c.p_lev[slot];
         double ic, oc, ac;
         if (s.use_tab) { ic = c.tabC[3 * (size_t)lev]; oc = c.tabC[3 * (size_t)lev + 1]; ac = c.tabC[3 * (size_t)lev + 2]; }
         else vrg_corrections(c, s.nnz, nz_val, nz_cin, nz_cout, nz_cconv, c.lev[lev], ic, oc, ac);
         vrg_add_correction(ic, oc, ac, ip, op);
         c.p_ip[slot] = ip; c.p_op[slot] = op;
     }
-    if (s.iter < s.iterMax) vrg_decide_core(c, s, slot, fl & PF_INNER, ip, op);   // while iterNum <= iterMax (:58)
+    if (s.iter < s.iterMax) vrg_decide_core(c, s, n_in, n_out, slot, fl & PF_INNER, ip, op, key, idx, lev);   // while iterNum <= iterMax (:58)
 }
 // exact densities over the whole inner / outer regions (:152-155, :252-255), regrouped by level
 VRG_HD void vrg_exact_serial(const VrgCtx& c, const VrgState& s, uint32_t slot, bool then_decide) {
@@ -246,7 +261,8 @@ VRG_HD void vrg_exact_serial(const VrgCtx& c, const VrgState& s, uint32_t slot, 
         si += (double)a * k; so += (double)b * k;
     }
     c.p_ip[slot] = si; c.p_op[slot] = so;
-    if (then_decide && s.iter < s.iterMax) vrg_decide_core(c, s, slot, c.p_flag[slot] & PF_INNER, si, so);
+    if (then_decide && s.iter < s.iterMax)
+        vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot]);
 }
 
 // ------------------------------------------------------------------ the sweep (update(), :156-259)
@@ -272,11 +288,15 @@ VRG_HD void vrg_close_without_update(const VrgCtx& c) { c.st->corr = 0; c.st->nf
 VRG_HD void vrg_open_update(const VrgCtx& c) { c.st->nnz = 0; c.st->tab_ok = c.L <= c.st->ni + c.st->no; }
 
 // flip r of the ordered list: L bit (+P for flip-outs, which are always applied), stamp = (sweep, rank)
-VRG_HD void vrg_item_list(const VrgCtx& c, uint32_t r) {
-    const uint32_t slot = c.f_slot[r], idx = c.p_idx[slot];
-    c.f_idx[r] = idx; c.f_lev[r] = c.p_lev[slot]; c.f_res[r] = 0;
-    vrg_or_byte(c.lab[0], idx, (uint8_t)(VB_L | ((c.p_flag[slot] & PF_INNER) ? VB_P : 0)));
+VRG_HD void vrg_item_list_rec(const VrgCtx& c, uint32_t r, uint32_t slot, uint32_t idx, uint32_t lev, bool inner) {
+    c.f_slot[r] = slot; c.f_idx[r] = idx; c.f_lev[r] = lev; c.f_res[r] = 0;
+    vrg_or_byte(c.lab[0], idx, (uint8_t)(VB_L | (inner ? VB_P : 0)));
     c.stamp[idx] = ((uint64_t)(uint32_t)(c.st->iter + 1) << 32) | r;
+}
+// ... when only the slot order is known (f_slot[r]; host-driven sort)
+VRG_HD void vrg_item_list(const VrgCtx& c, uint32_t r) {
+    const uint32_t slot = c.f_slot[r];
+    vrg_item_list_rec(c, r, slot, c.p_idx[slot], c.p_lev[slot], (c.p_flag[slot] & PF_INNER) != 0);
 }
 
 // flip-ins: label after phase A (:183-190) decides whether the flip is applied at once

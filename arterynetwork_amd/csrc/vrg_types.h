@@ -150,8 +150,10 @@ struct VrgCtx {
     uint32_t* dead;            // slots that died this sweep (moved onto the free list when the sweep closes)
     // this sweep's flips
     uint32_t fcap;             // a power of two
-    uint32_t* flist;           // slots of the listed flips as k_band appended them, unordered
-    uint64_t* f_key;           // ... sort keys (scratch of the host-driven sort)
+    uint32_t* flist;           // the listed flips as k_band appended them, unordered: slot ...
+    uint64_t* f_key;           // ... sort key (list bit | list-order key) ...
+    uint32_t* fr_idx;          // ... voxel ...
+    uint32_t* fr_lev;          // ... and intensity level (so that ordering the flips needs no look-up through the slot)
     uint32_t* f_slot;          // flip list in the reference's order (:88): slot ...
     uint32_t* f_idx;           // ... voxel ...
     uint32_t* f_lev;           // ... and intensity level of flip r

@@ -178,11 +178,14 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents*, be_red
     vrg_open_update(c);
     {   // the flip list in the reference's order (:88)
         std::vector<std::pair<uint64_t, uint32_t>> v(nf);
-        for (uint32_t q = 0; q < nf; q++) v[q] = {vrg_flip_key(c, c.flist[q]), c.flist[q]};
+        for (uint32_t q = 0; q < nf; q++) v[q] = {c.f_key[q], q};
         std::sort(v.begin(), v.end());
-        for (uint32_t r = 0; r < nf; r++) c.f_slot[r] = v[r].second;
+        for (uint32_t r = 0; r < nf; r++) {             // alternately from the flip's record / through its slot
+            const uint32_t q = v[r].second;
+            if (r & 1) vrg_item_list_rec(c, r, c.flist[q], c.fr_idx[q], c.fr_lev[q], !(c.f_key[q] >> 63));
+            else { c.f_slot[r] = c.flist[q]; vrg_item_list(c, r); }
+        }
     }
-    for (uint32_t r = 0; r < nf; r++) vrg_item_list(c, r);
     for (uint32_t r = 0; r < nf; r++) vrg_item_prepass(c, r);
     for (bool changed = true; changed;) {
         changed = false;
