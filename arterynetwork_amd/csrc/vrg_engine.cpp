@@ -213,7 +213,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "dense_off") h->dense_off = value != 0;   // measurement aid: band chain alone; re-initialise afterwards
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
     else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "serial_streams") be_set_tuning(h->be, name, value);
-    else if (n == "storage16") { if (h->inited) return fail(h, VRG_E_STATE, "storage16 must be set before vrg_init"); h->storage16 = value != 0; }
+    else if (n == "storage16") h->storage16 = value != 0;      // takes effect at the next vrg_init
     else return fail(h, VRG_E_ARG, "unknown option " + n);
     return VRG_OK;
 }

@@ -68,7 +68,7 @@ const char* vrg_last_error(const vrg_handle* h);
  *   "band_capacity"  slots reserved for the narrow band (default 65536; the arrays grow by themselves when a
  *                    sweep needs more, so this only saves the re-allocations)
  *   "capacity_floor" smallest capacity of the pool and of the marked-voxel arrays (default 65536; tests lower it)
- *   "storage16"      keep intensities as 16-bit level indices (needs <= 16384 distinct values): the dense
+ *   "storage16"      (takes effect at the next vrg_init) keep intensities as 16-bit level indices (needs <= 16384 distinct values): the dense
  *                    pass streams 2 B instead of 4 B per voxel; results are bit-identical
  *   "sweep_variant"  0 = relabel only the marked voxels (default), 1 = check variant that runs the
  *                    label stencil on every voxel (slow; must give the same state)

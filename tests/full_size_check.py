@@ -2,6 +2,8 @@
 """Full-size property checks of the HIP path; run by tests/test_gpu_parity.py in their own process.
 
 default      880x880x640 (the headline size), the torch-generated bench volume, 60 sweeps
+--oracle3    the same volume, 100 sweeps, against the ORACLE at full size (all cores; ~25 GB of host memory, a few minutes):
+             labels of all 495 616 000 voxels, both band list orders and densities, `segmented` order, whole trace
 --config5    1024^3 with 16-bit intensity storage (BASELINE configs[4] on one GPU), 40 sweeps, and the same volume with
              fp32 storage: labels, `segmented` and the whole trace (incl. the f64 intensity sums) must be identical
 """
@@ -68,8 +70,55 @@ def run_and_check(shape, I, vm, dev, sweeps, storage16):
     return lab, seg, tr, bands
 
 
+def oracle_full_size(dev, sweeps=100):
+    import time
+    import parity
+    from oracle import vrg_oracle as O
+    shape = (880, 880, 640)
+    I, vm = phantoms.bench_volume_torch(shape, dev)
+    torch.cuda.synchronize()
+    s = Session(shape)
+    s.set_option('batch', 32)
+    s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
+    s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
+    s.init(2.25)
+    r = s.run(sweeps, 10 ** 12, None)
+    assert r.sweeps == sweeps
+    t0 = time.time()
+    Ih = np.ascontiguousarray(I.cpu().numpy(), dtype=np.float64)        # logical (x,y,z), C order for the oracle
+    vh = np.ascontiguousarray(vm.cpu().numpy())
+    o = O.Oracle(Ih, vh, 2.25, density_mode=1, omp=True)
+    del Ih
+    o.init()
+    t1 = time.time()
+    for _ in range(sweeps):
+        assert o.step(10 ** 6, 10 ** 12, -1.0) == 0
+    t2 = time.time()
+    lab = np.empty(shape, np.uint8)
+    s.labels(out=lab)
+    assert np.array_equal(lab, o.labels()), 'labels differ'
+    assert np.array_equal(parity.lex_of(s.segmented(), shape), o.segmented_lex()), 'segmented order differs'
+    for which in (0, 1):
+        co, ip, op = s.band(which)
+        oi, oip, oop = o.band(which)
+        assert np.array_equal(parity.lex_of(co, shape), oi), 'band list %d order differs' % which
+        parity.assert_probs_close(ip, oip, 1e-9, 'innerProb list %d' % which)
+        parity.assert_probs_close(op, oop, 1e-9, 'outerProb list %d' % which)
+    tr, otr = s.trace(), o.trace()
+    for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no'):
+        assert np.array_equal(tr[f], otr[f]), f
+    np.testing.assert_allclose(tr['sum_in'], otr['sum_in'], rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(tr['sum_out'], otr['sum_out'], rtol=1e-9, atol=1e-6)
+    print('ORACLE3 OK: 880x880x640 x %d sweeps identical to the oracle (nseg %d -> %d, band %d); oracle init %.0f s, sweeps %.0f s'
+          % (sweeps, tr['nseg'][0], tr['nseg'][-1], tr['ni'][-1] + tr['no'][-1], t1 - t0, t2 - t1))
+    s.close(); o.close()
+
+
 def main():
     dev = torch.device('cuda', 0)
+    if '--oracle3' in sys.argv:
+        oracle_full_size(dev)
+        return
     if '--config5' in sys.argv:
         shape = (1024, 1024, 1024)
         I, vm = phantoms.bench_volume_torch(shape, dev, seed=5)

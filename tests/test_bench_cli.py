@@ -1,0 +1,43 @@
+"""bench.py plumbing that needs no GPU: `--gpus N` started plainly launches the N ranks itself (a child
+torch.distributed.run, before this process touches the GPU); the roofline arithmetic; the traffic stamp."""
+import json
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench
+
+
+def test_gpus_n_spawns_a_launcher(monkeypatch):
+    calls = []
+    monkeypatch.setattr(bench.subprocess, 'call', lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '7', '--warmup', '3'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '8' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-6:] == ['--gpus', '8', '--steps', '7', '--warmup', '3'] and os.path.basename(cmd[-7]) == 'bench.py'
+    assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_roofline_is_a_fraction_of_peak():
+    r = bench.roofline((880, 880, 640), 640, 0.32, 500, None)
+    assert r['bytes_per_launch'] == int(4.25 * 896 * 884 * 640) == 2154414080
+    assert 0.8 < r['frac'] < 0.86 and r['frac'] == round(r['achieved'] / 8000.0, 4)
+    assert r['algorithmic_equiv_gbs'] > r['achieved']            # 6 B/voxel accounting is kept apart, never as frac
+    r16 = bench.roofline((880, 880, 640), 640, 0.24, 500, None, storage16=True)
+    assert r16['bytes_per_voxel'] == 2.25 and r16['frac'] < 1
+
+
+def test_traffic_only_for_the_sources_it_was_measured_on():
+    t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+    got = bench.load_traffic(tuple(t['shape']), 1, False)
+    assert got == (t['hbm_bytes_per_launch'] if t.get('src_sha') == bench.device_source_sha() else None)
+    assert bench.load_traffic((1, 2, 3), 1, False) is None and bench.load_traffic(tuple(t['shape']), 1, True) is None

@@ -499,6 +499,46 @@ def test_two_live_sessions_are_independent(lib, golden_loader):
         s.close(); o.close()
 
 
+def test_handle_reuse(lib):
+    """One handle used again and again: new labels on the same volume, a new volume (other level table), 16-bit storage
+    switched on and off, a run continued with a larger iterMax - each time the result of a fresh handle."""
+    from arterynetwork_amd._capi import Session
+    from arterynetwork_amd import phantoms
+    d1, v1 = phantoms.tube_phantom(shape=(40, 36, 24), radius=3.0, seed=5, seed_planes=3, amp_y=7.0, amp_z=4.0, levels=16, brain_mask=True)
+    d2, v2 = phantoms.noise_volume((40, 36, 24), seed=9, p_seed=0.1, p_excl=0.2, levels=6)
+    v1b = v1.copy(); v1b[20:23, 16:20, 10:14] = 0
+
+    def fresh(data, vmap, n, st16=0):
+        s = Session(data.shape, lib=lib)
+        s.set_option('storage16', st16)
+        s.set_volume(data); s.set_labels(vmap); s.init(2.25)
+        s.run(n, 10 ** 9, None)
+        out = (s.labels(), s.segmented(), s.trace(), s.band(0), s.band(1))
+        s.close()
+        return out
+
+    def same(a, b):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no'):
+            assert np.array_equal(a[2][f], b[2][f]), f
+        for w in (3, 4):
+            assert np.array_equal(a[w][0], b[w][0])
+            np.testing.assert_allclose(a[w][1], b[w][1], rtol=1e-12); np.testing.assert_allclose(a[w][2], b[w][2], rtol=1e-12)
+
+    s = Session(d1.shape, lib=lib)
+    steps = ((d1, v1, 12, 0), (None, v1b, 9, 0), (d2, v2, 6, 0), (d1, v1, 12, 1), (None, v1b, 9, 0))
+    cur = None
+    for data, vmap, n, st16 in steps:
+        if data is not None:
+            s.set_volume(data); cur = data
+        s.set_option('storage16', st16)
+        s.set_labels(vmap); s.init(2.25)
+        s.run(n // 2, 10 ** 9, None)
+        s.run(n, 10 ** 9, None)                          # continued with a larger iterMax
+        same((s.labels(), s.segmented(), s.trace(), s.band(0), s.band(1)), fresh(cur, vmap, n, st16))
+    s.close()
+
+
 def test_float64_volume(lib):
     """Values fp32 cannot hold (the reference computes in float64 on whatever it is given): float64 storage, the dense
     pass streams 8 B per voxel; same results as the oracle."""
@@ -523,6 +563,19 @@ def test_config3_full_size_properties():
     from conftest import ROOT
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'full_size_check.py')], capture_output=True, text=True)
     assert out.returncode == 0 and 'FULL SIZE OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_config3_full_size_vs_oracle():
+    """BASELINE configs[2] at FULL size against the oracle: 880x880x640, the bench volume, 100 sweeps - labels of all
+    495 616 000 voxels, both band list orders and densities, `segmented` order, whole trace.  The oracle (all-cores build)
+    needs ~25 GB of host memory and about a minute; skipped on a host with less than 64 GB available."""
+    import subprocess, sys, os
+    import psutil
+    from conftest import ROOT
+    if psutil.virtual_memory().available < 64 * 2 ** 30:
+        pytest.skip('needs 64 GB of host memory')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'full_size_check.py'), '--oracle3'], capture_output=True, text=True)
+    assert out.returncode == 0 and 'ORACLE3 OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_drop_in_messages_and_trace(golden_loader, capsys):
