@@ -284,6 +284,7 @@ def main():
                    'dense_ms': round(kern_ms, 4)},
         'roofline': roofline(shape, shape[2], kern_ms, int(r.sweep_launches), load_traffic(shape, 1, args.storage16), args.storage16),
     }
+    out['config']['engine'] = s.stats()                     # trips handed back to the host / array growth during the run
     out['config'].update(s.chain_timing(args.H))
     s.close()
     if not args.no_cpu_baseline:
