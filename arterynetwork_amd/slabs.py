@@ -117,7 +117,7 @@ def bench_slabs(shape, args, dev, rank, world, roofline):
         'value': round(V * r.sweeps / dt_max / 1e6, 1), 'unit': 'Mvoxel-iter/s', 'n_gpus': world,
         'steps': int(r.sweeps), 'warmup': args.warmup, 'ms_per_step': round(dt_max / max(1, r.sweeps) * 1e3, 4),
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
-        'dtype': 'u8 labels + f32 intensities (f64 region sums / densities)', 'data': 'synthetic', 'valid': bool(valid),
+        'dtype': 'f64', 'data': 'synthetic', 'valid': bool(valid),
         'config': {'workload': '{} synthetic MRA tube volume ({} intensity levels stored fp32, brain-mask excluded '
                                'voxels), H={}, {} incremental VRG sweeps'.format(args.shape, args.levels, args.H, r.sweeps),
                    'parallelism': 'zslab{} (dense recount sharded into {} Z-slabs, band relabel replicated, one '

@@ -271,7 +271,7 @@ def main():
         'metric': 'Mvoxel-iters/sec, VRG sweep, {} volume'.format(args.shape), 'value': round(value, 1),
         'unit': 'Mvoxel-iter/s', 'n_gpus': 1, 'steps': int(r.sweeps), 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'strong',
-        'vs_baseline': None, 'dtype': 'u8 labels + f32 intensities (f64 region sums / densities)',
+        'vs_baseline': None, 'dtype': 'f64',                # region sums, densities and decisions in float64; labels u8
         'data': 'synthetic', 'valid': bool(valid),
         'config': {'workload': '{} synthetic MRA tube volume ({} stored {}, brain-mask excluded '
                                'voxels), H={}, {} incremental VRG sweeps'.format(
