@@ -653,8 +653,15 @@ typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 
 struct SweepAcc { long long nin, nout; double sin_, sout; };
 
-// per-workgroup slot, then the LAST workgroup to arrive adds all slots in slot order and publishes the
-// totals (agent-scope release before the ticket, acquire after it: cdna guide, Guideline 16)
+// per-workgroup slot, then the LAST workgroup to arrive adds all slots in slot order and publishes the totals.
+// Hand-off without fences (cdna guide, Guideline 16 / "Valid forms", first row of the measured table): one lane stores its
+// workgroup's four values write-through (sc1), drains them (vmcnt(0)), takes a ticket with an agent-scope atomic add;
+// the workgroup whose add came last reads every slot with sc1 loads behind a workgroup barrier.  (An agent-scope release
+// + acquire pair costs ~1.7 us each - a tenth of a slab's recount.)
+__device__ __forceinline__ void st_sc1(long long* p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ long long ld_sc1(const long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_sc1(const double* p) { return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a, int fin) {
     __shared__ long long sh_n[2][4];
     __shared__ double sh_s[2][4];
@@ -664,24 +671,21 @@ __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a, int fi
     if (lane == 0) { sh_n[0][wv] = a.nin; sh_n[1][wv] = a.nout; sh_s[0][wv] = a.sin_; sh_s[1][wv] = a.sout; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        c.st_nin[blockIdx.x] = sh_n[0][0] + sh_n[0][1] + sh_n[0][2] + sh_n[0][3];
-        c.st_nout[blockIdx.x] = sh_n[1][0] + sh_n[1][1] + sh_n[1][2] + sh_n[1][3];
-        c.st_sin[blockIdx.x] = ((sh_s[0][0] + sh_s[0][1]) + sh_s[0][2]) + sh_s[0][3];
-        c.st_sout[blockIdx.x] = ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        st_sc1((long long*)&c.st_nin[blockIdx.x], sh_n[0][0] + sh_n[0][1] + sh_n[0][2] + sh_n[0][3]);
+        st_sc1((long long*)&c.st_nout[blockIdx.x], sh_n[1][0] + sh_n[1][1] + sh_n[1][2] + sh_n[1][3]);
+        st_sc1(&c.st_sin[blockIdx.x], ((sh_s[0][0] + sh_s[0][1]) + sh_s[0][2]) + sh_s[0][3]);
+        st_sc1(&c.st_sout[blockIdx.x], ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t t = __hip_atomic_fetch_add(&c.counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = (t == gridDim.x - 1);
-        if (is_last) {
-            c.counters[0] = 0;                       // every workgroup has arrived: reset for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (is_last) c.counters[0] = 0;              // every workgroup has arrived: reset for the next launch
     }
     __syncthreads();
     if (!is_last) return;
     long long x = 0, y = 0; double sx = 0, sy = 0;
-    for (uint32_t i = threadIdx.x; i < gridDim.x; i += TPB) { x += c.st_nin[i]; y += c.st_nout[i]; sx += c.st_sin[i]; sy += c.st_sout[i]; }
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += TPB) {
+        x += ld_sc1((const long long*)&c.st_nin[i]); y += ld_sc1((const long long*)&c.st_nout[i]); sx += ld_sc1(&c.st_sin[i]); sy += ld_sc1(&c.st_sout[i]);
+    }
     x = wave_sum(x); y = wave_sum(y); sx = wave_sum(sx); sy = wave_sum(sy);
     __syncthreads();
     if (lane == 0) { sh_n[0][wv] = x; sh_n[1][wv] = y; sh_s[0][wv] = sx; sh_s[1][wv] = sy; }
