@@ -240,10 +240,10 @@ class Session:
 
     def stats(self):
         """Diagnostics: how often a trip was handed back to the host and why, array capacities."""
-        a = (C.c_int64 * 8)()
-        self._check(self.lib.get_stats(self._h, a, 8))
+        a = (C.c_int64 * 9)()
+        self._check(self.lib.get_stats(self._h, a, 9))
         return {'bail_flips': a[1], 'grow_marks': a[2], 'grow_pool': a[3], 'host_driven_trips': a[4],
-                'pool_capacity': a[5], 'mark_capacity': a[6], 'pool_slots': a[7]}
+                'pool_capacity': a[5], 'mark_capacity': a[6], 'pool_slots': a[7], 'dense_bytes': a[8]}
 
     def nlevels(self):
         """Number of distinct intensity values of the volume (after init)."""

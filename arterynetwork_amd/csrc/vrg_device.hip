@@ -54,6 +54,7 @@ struct VrgBackend {
     uint64_t* keys2 = nullptr; size_t keys2_n = 0;
     int dense_pending = 0;                            // Z-slabs: recounts enqueued since the last staged all-reduce
     int serial = 0;                                   // option "serial_streams": see be_sweep_once
+    int skip = 1;                                     // option "skip_excluded": the dense pass does not fetch the intensities of excluded voxels
 };
 
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess && !b->err[0]) { \
@@ -717,46 +718,81 @@ constexpr uint32_t LEV16_MAX = 16384;   // 16-bit storage: the level values sit 
 // MODE 0: fp32 intensities, 1: 16-bit level indices + LDS value table, 2: float64 intensities.
 // Dense pass number seq (= passes closed + 1) reads copy seq & 1 of the class bits.
 template <int MODE> struct UnitVals { f4v f[4]; };
+template <> struct UnitVals<1> { u2v q[4]; };           // raw level indices: the LDS look-ups wait until the sums are formed
 template <> struct UnitVals<2> { d2v f[4][2]; };
 template <int MODE>
-__device__ __forceinline__ void stats_bits(SweepAcc& a, uint32_t w, const UnitVals<MODE>& u) {
-    a.nin += __popc(w & 0x55555555u); a.nout += __popc(w & 0xAAAAAAAAu);
+__device__ __forceinline__ void stats_group(SweepAcc& a, uint32_t wj, const UnitVals<MODE>& u, int j, const float* s_val) {
+    float lv[4];
+    if constexpr (MODE == 1) {
+        lv[0] = s_val[u.q[j].x & 0xffffu]; lv[1] = s_val[u.q[j].x >> 16];
+        lv[2] = s_val[u.q[j].y & 0xffffu]; lv[3] = s_val[u.q[j].y >> 16];
+    }
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int bb = 0; bb < 4; bb++) {
-            uint32_t t = w >> (2 * (4 * j + bb));
-            double x;
-            if constexpr (MODE == 2) x = u.f[j][bb >> 1][bb & 1]; else x = (double)u.f[j][bb];
+    for (int bb = 0; bb < 4; bb++) {
+        if constexpr (MODE == 2) {
+            const uint32_t t = wj >> (2 * bb);
+            const double x = u.f[j][bb >> 1][bb & 1];
             a.sin_ += (t & 1u) ? x : 0.0;
             a.sout += (t & 2u) ? x : 0.0;
-        }
-}
-template <int MODE, bool NT>
-__device__ __forceinline__ void load_unit(const VrgCtx& c, const uint32_t* cls, const float* s_val, uint32_t u, uint32_t lane, uint32_t& w, UnitVals<MODE>& o) {
-    const uint32_t* pc = cls + ((size_t)u << 6) + lane;
-    w = NT ? __builtin_nontemporal_load(pc) : *pc;
-    const uint32_t base = (u << 10) + (lane << 2);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if constexpr (MODE == 1) {
-            const u2v* pq = reinterpret_cast<const u2v*>(c.lev16 + base + (j << 8));
-            u2v q = NT ? __builtin_nontemporal_load(pq) : *pq;
-            o.f[j] = f4v{s_val[q.x & 0xffffu], s_val[q.x >> 16], s_val[q.y & 0xffffu], s_val[q.y >> 16]};
-        } else if constexpr (MODE == 2) {
-            const d2v* pd = reinterpret_cast<const d2v*>(c.I64 + base + (j << 8));
-            o.f[j][0] = NT ? __builtin_nontemporal_load(pd) : pd[0];
-            o.f[j][1] = NT ? __builtin_nontemporal_load(pd + 1) : pd[1];
         } else {
-            const f4v* pi = reinterpret_cast<const f4v*>(c.I + base + (j << 8));
-            o.f[j] = NT ? __builtin_nontemporal_load(pi) : *pi;
+            // class bit -> all-ones / all-zeros mask over the float's bits: a masked-out voxel adds +0.0
+            uint32_t xi;
+            if constexpr (MODE == 1) xi = __float_as_uint(lv[bb]); else xi = __float_as_uint(u.f[j][bb]);
+            const uint32_t m_in = (uint32_t)((int32_t)(wj << (31 - 2 * bb)) >> 31);
+            const uint32_t m_out = (uint32_t)((int32_t)(wj << (30 - 2 * bb)) >> 31);
+            a.sin_ += (double)__uint_as_float(xi & m_in);
+            a.sout += (double)__uint_as_float(xi & m_out);
         }
     }
 }
-template <int UNITS, bool NT, int MODE>
+// SKIP: a group of four voxels per lane whose 256 voxels are all excluded costs the wave nothing (the branch is
+// wave-uniform there); partly excluded groups run with the excluded lanes masked off.  Adding +0.0 or not adding at
+// all gives the same sums (the accumulators never hold -0.0: they start at +0.0).
+template <int MODE, bool SKIP>
+__device__ __forceinline__ void stats_bits(SweepAcc& a, uint32_t w, const UnitVals<MODE>& u, const float* s_val) {
+    a.nin += __popc(w & 0x55555555u); a.nout += __popc(w & 0xAAAAAAAAu);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t wj = (w >> (8 * j)) & 0xffu;
+        if (!SKIP || wj != 0u) stats_group<MODE>(a, wj, u, j, s_val);
+    }
+}
+template <bool NT>
+__device__ __forceinline__ uint32_t load_cls(const uint32_t* cls, uint32_t u, uint32_t lane) {
+    const uint32_t* pc = cls + ((size_t)u << 6) + lane;
+    return NT ? __builtin_nontemporal_load(pc) : *pc;
+}
+// the intensities of the lane's 4 x 4 voxels of unit u.  SKIP: a group of four voxels that are all excluded (class 0:
+// label 4 or padding) is not fetched - the reference's dataArray[mask] gathers (:249-250) do not touch excluded voxels
+// either; a 128-byte line is then not transferred when all eight lanes that share it skip it, i.e. wherever 32
+// consecutive voxels are excluded (the brain mask leaves long runs).  The sums are bit-identical: a class-0 voxel
+// contributes +0.0 either way.
+template <int MODE, bool NT, bool SKIP>
+__device__ __forceinline__ void load_vals(const VrgCtx& c, uint32_t u, uint32_t lane, uint32_t w, UnitVals<MODE>& o) {
+    const uint32_t base = (u << 10) + (lane << 2);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool need = !SKIP || ((w >> (8 * j)) & 0xffu) != 0u;
+        if constexpr (MODE == 1) {
+            o.q[j] = u2v{0u, 0u};
+            if (need) { const u2v* pq = reinterpret_cast<const u2v*>(c.lev16 + base + (j << 8)); o.q[j] = NT ? __builtin_nontemporal_load(pq) : *pq; }
+        } else if constexpr (MODE == 2) {
+            o.f[j][0] = d2v{0.0, 0.0}; o.f[j][1] = d2v{0.0, 0.0};
+            if (need) {
+                const d2v* pd = reinterpret_cast<const d2v*>(c.I64 + base + (j << 8));
+                o.f[j][0] = NT ? __builtin_nontemporal_load(pd) : pd[0];
+                o.f[j][1] = NT ? __builtin_nontemporal_load(pd + 1) : pd[1];
+            }
+        } else {
+            o.f[j] = f4v{0.f, 0.f, 0.f, 0.f};
+            if (need) { const f4v* pi = reinterpret_cast<const f4v*>(c.I + base + (j << 8)); o.f[j] = NT ? __builtin_nontemporal_load(pi) : *pi; }
+        }
+    }
+}
+template <int UNITS, bool NT, int MODE, bool SKIP>
 __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) {
     if (check_done && !vrg_dense_due(c)) return;     // k_gate let it through without a sweep to count: the run has stopped
-    __shared__ float s_val[MODE == 1 ? LEV16_MAX : 1];
+    extern __shared__ float s_val[];        // 16-bit storage: the level values (c.L floats, sized at launch)
     if (MODE == 1) {
         for (uint32_t i = threadIdx.x; i < c.L; i += TPB) s_val[i] = (float)c.lev[i];
         __syncthreads();
@@ -771,36 +807,80 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     SweepAcc acc = {0, 0, 0.0, 0.0};
     uint32_t u = f_lo + wave * UNITS;
-    for (; u + UNITS <= f_hi; u += nwaves * UNITS) {
-        uint32_t w[UNITS]; UnitVals<MODE> f[UNITS];
+    // the class words of a trip are fetched one trip ahead: the intensity loads depend on them when excluded groups are skipped
+    uint32_t w[UNITS];
+    if (u + UNITS <= f_hi) {
 #pragma unroll
-        for (int q = 0; q < UNITS; q++) load_unit<MODE, NT>(c, cls, s_val, u + q, lane, w[q], f[q]);
+        for (int q = 0; q < UNITS; q++) w[q] = load_cls<NT>(cls, u + q, lane);
+    }
 #pragma unroll
-        for (int q = 0; q < UNITS; q++) stats_bits<MODE>(acc, w[q], f[q]);
+    for (int q = 0; q < UNITS; q++) asm volatile("" : "+v"(w[q]));       // settle the first trip's class words here: no waits in mid-loop
+    while (u + UNITS <= f_hi) {
+        // next trip's class words first (unconditionally - clamped to the last full trip - so that the wait counts stay
+        // static), then this trip's intensities: loads return in order, so the class words cost no wait of their own
+        const uint32_t un = u + nwaves * UNITS;
+        const uint32_t up = un + UNITS <= f_hi ? un : f_hi - UNITS;
+        uint32_t wn[UNITS];
+#pragma unroll
+        for (int q = 0; q < UNITS; q++) wn[q] = load_cls<NT>(cls, up + q, lane);
+        UnitVals<MODE> f[UNITS];
+#pragma unroll
+        for (int q = 0; q < UNITS; q++) load_vals<MODE, NT, SKIP>(c, u + q, lane, w[q], f[q]);
+#pragma unroll
+        for (int q = 0; q < UNITS; q++) stats_bits<MODE, SKIP>(acc, w[q], f[q], s_val);
+#pragma unroll
+        for (int q = 0; q < UNITS; q++) w[q] = wn[q];
+        u = un;
     }
     for (; u < f_hi; u++) {                                    // whole units left over by the UNITS-stride
-        uint32_t w; UnitVals<MODE> f;
-        load_unit<MODE, false>(c, cls, s_val, u, lane, w, f);
-        stats_bits<MODE>(acc, w, f);
+        UnitVals<MODE> f;
+        const uint32_t w1 = load_cls<false>(cls, u, lane);
+        load_vals<MODE, false, SKIP>(c, u, lane, w1, f);
+        stats_bits<MODE, SKIP>(acc, w1, f, s_val);
     }
     // units the slab edges cut: the first and the last unit touching [lo, hi), masked to the slab
     const uint32_t e0 = lo >> 10, e1 = (hi - 1u) >> 10;
     const uint32_t edge = wave == 0 ? e0 : (wave == nwaves - 1 && e1 != e0 ? e1 : 0xffffffffu);
     if (edge != 0xffffffffu && !(edge >= f_lo && edge < f_hi)) {
-        uint32_t w; UnitVals<MODE> f;
-        load_unit<MODE, false>(c, cls, s_val, edge, lane, w, f);
+        UnitVals<MODE> f;
+        uint32_t w1 = load_cls<false>(cls, edge, lane);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             uint32_t v = (edge << 10) + (j << 8) + (lane << 2);        // groups of 4 voxels never straddle a plane
-            if (v < lo || v >= hi) w &= ~(0xffu << (8 * j));
+            if (v < lo || v >= hi) w1 &= ~(0xffu << (8 * j));
         }
-        stats_bits<MODE>(acc, w, f);
+        load_vals<MODE, false, SKIP>(c, edge, lane, w1, f);
+        stats_bits<MODE, SKIP>(acc, w1, f, s_val);
     }
     sweep_finish(c, acc, check_done);
 }
 __global__ void k_cls_build(VrgCtx c) {
     const uint32_t nd = (uint32_t)((((uint64_t)c.PV + 1023u) >> 10) << 6);
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < nd; d += gridDim.x * blockDim.x) vrg_item_cls_build(c, d);
+}
+
+// Bytes one dense pass requests from memory for the class copy the last pass read: 256 B of class words per unit
+// of the slab + every 128-byte intensity line that holds an included voxel (what k_recount_bits<.., SKIP> fetches).
+__global__ void __launch_bounds__(TPB) k_dense_bytes(VrgCtx c, unsigned long long* out) {
+    const uint32_t* __restrict__ cls = c.clsb[vrg_load_i64(&c.dctl[VD_RSEQ]) & 1];
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
+    const uint32_t lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
+    const uint32_t e0 = lo >> 10, e1 = (hi - 1u) >> 10;
+    const uint32_t lpl = c.lev16 ? 16u : (c.I ? 8u : 4u);          // lanes (of 4 voxels each) per 128-byte line
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    unsigned long long bytes = 0;
+    for (uint32_t u = e0 + wave; u <= e1; u += nwaves) {
+        uint32_t w = cls[((size_t)u << 6) + lane];
+        bytes += 256u;
+        for (int j = 0; j < 4; j++) {
+            const uint32_t v = (u << 10) + (j << 8) + (lane << 2);
+            const bool need = v >= lo && v < hi && ((w >> (8 * j)) & 0xffu) != 0u;
+            const uint64_t m = __ballot(need);
+            for (uint32_t g = 0; g < 64u; g += lpl) bytes += ((m >> g) & ((1ull << lpl) - 1ull)) ? 128u : 0u;
+        }
+    }
+    if (lane == 0 && bytes) atomicAdd(out, bytes);
 }
 
 // ---- dense helpers over the real voxels -------------------------------------------------------------
@@ -977,8 +1057,11 @@ int voxel_blocks(const VrgCtx& c) {
 int dense_blocks(const VrgBackend* b, const VrgCtx& c) {
     if (b->sweep_blocks > 0) return b->sweep_blocks;
     uint64_t units = ((uint64_t)(c.z1 - c.z0) * c.PY * c.PX) >> 10;
-    // the 16-bit variant spends issue slots on LDS table look-ups and wants twice the waves (512: 0.275 ms, 256: 0.335)
-    return (int)std::min<uint64_t>(c.lev16 ? 2 * SWEEP_BLOCKS : SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128));
+    // skipping pass: few registers, many short trips - 3 waves per SIMD, the 16-bit variant (LDS look-ups, half the
+    // bytes per trip) 8; measured in DESIGN.md section 5.  Streaming pass (skip_excluded = 0): 1 resp. 2 workgroups per CU.
+    if (!b->skip) return (int)std::min<uint64_t>(c.lev16 ? 2 * SWEEP_BLOCKS : SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128));
+    return (int)(c.lev16 ? std::min<uint64_t>(8 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 48))
+                         : std::min<uint64_t>(3 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128)));
 }
 
 void use_device(VrgBackend* b) { HIP_CHECK(hipSetDevice(b->device)); }
@@ -1041,6 +1124,7 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     use_device(b);
     if (std::strcmp(name, "sweep_blocks") == 0 && v >= 0 && v <= 4096) b->sweep_blocks = (int)v;
     if (std::strcmp(name, "serial_streams") == 0) b->serial = v != 0;
+    if (std::strcmp(name, "skip_excluded") == 0) b->skip = v != 0;
     if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)std::min<long long>(v, NF_SMALL);
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != b->prio_mode) { b->prio_mode = (int)v; make_streams(b); }
 }
@@ -1232,11 +1316,17 @@ int be_comm_init(VrgBackend* b, int nranks, int rank, const void* id128) {
 
 // The start / stop events ride on the dispatch itself (hipExtLaunchKernel): no separate event packets in the stream,
 // which cost ~4 us each between two back-to-back recounts.
-static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t st, hipEvent_t e_start = nullptr, hipEvent_t e_stop = nullptr) {
+static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t st, bool skip, hipEvent_t e_start = nullptr, hipEvent_t e_stop = nullptr) {
     if (check) k_gate<<<1, 64, 0, st>>>(c);        // waits (on the device) until the sweep's labels are in place
-    if (c.lev16) hipExtLaunchKernelGGL((k_recount_bits<3, true, 1>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
-    else if (c.I) hipExtLaunchKernelGGL((k_recount_bits<3, true, 0>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
-    else hipExtLaunchKernelGGL((k_recount_bits<2, true, 2>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
+    if (skip) {
+        if (c.lev16) hipExtLaunchKernelGGL((k_recount_bits<3, true, 1, true>), dim3(blocks), dim3(TPB), c.L * sizeof(float), st, e_start, e_stop, 0, c, check);
+        else if (c.I) hipExtLaunchKernelGGL((k_recount_bits<3, true, 0, true>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
+        else hipExtLaunchKernelGGL((k_recount_bits<2, true, 2, true>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
+        return;
+    }
+    if (c.lev16) hipExtLaunchKernelGGL((k_recount_bits<3, true, 1, false>), dim3(blocks), dim3(TPB), c.L * sizeof(float), st, e_start, e_stop, 0, c, check);
+    else if (c.I) hipExtLaunchKernelGGL((k_recount_bits<3, true, 0, false>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
+    else hipExtLaunchKernelGGL((k_recount_bits<2, true, 2, false>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
 }
 
 void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
@@ -1248,7 +1338,7 @@ void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
     else k_hist_voxel<<<voxel_blocks(c), TPB, 0, b->sa>>>(c);
     k_exact_init<<<1024, TPB, 0, b->sa>>>(c);
     k_cls_build<<<2048, TPB, 0, b->sa>>>(c);
-    launch_recount(c, dense_blocks(b, c), 0, b->sa);
+    launch_recount(c, dense_blocks(b, c), 0, b->sa, b->skip != 0);
     reduce_dense(b, c, cb, user, b->sa);
     k_fin_init<<<1, 1, 0, b->sa>>>(c);
 }
@@ -1350,7 +1440,7 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
     // device for another one could then wait for ever, so the host orders the two streams instead.)
     if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sa));
     const bool ranks = c.world > 1 || b->comm || cb;
-    launch_recount(c, dense_blocks(b, c), ranks ? 1 : 2, b->sb, e_start, e_stop);
+    launch_recount(c, dense_blocks(b, c), ranks ? 1 : 2, b->sb, b->skip != 0, e_start, e_stop);
     if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sb));
     // one GPU: the last workgroup of the recount closes the pass itself.  Z-slabs: the slab sums of DENSE_GROUP recounts
     // are summed over the ranks by ONE all-reduce (nothing on the band side waits for it: the decisions use the
@@ -1382,6 +1472,24 @@ void be_recount_hist(VrgBackend* b, const VrgCtx& c, int32_t* rin, int32_t* rout
     use_device(b);
     k_recount_hist<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, rin, rout);
     HIP_CHECK(hipStreamSynchronize(b->sa));
+}
+
+uint64_t be_dense_bytes(VrgBackend* b, const VrgCtx& c) {
+    use_device(b);
+    if (!b->skip) {            // every voxel of the slab's units is streamed
+        const uint64_t plane = (uint64_t)c.PY * c.PX, lo = (2u + (uint64_t)c.z0) * plane, hi = (2u + (uint64_t)c.z1) * plane;
+        const uint64_t bpv4 = c.lev16 ? 9 : (c.I ? 17 : 33);      // 4 x (intensity bytes + 0.25)
+        return (hi - lo) * bpv4 / 4;
+    }
+    unsigned long long* d = nullptr; unsigned long long v = 0;
+    HIP_CHECK(hipMalloc(&d, 8));
+    if (!d) return 0;
+    HIP_CHECK(hipMemsetAsync(d, 0, 8, b->sa));
+    k_dense_bytes<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, d);
+    HIP_CHECK(hipMemcpyAsync(&v, d, 8, hipMemcpyDeviceToHost, b->sa));
+    HIP_CHECK(hipStreamSynchronize(b->sa));
+    HIP_CHECK(hipFree(d));
+    return v;
 }
 
 uint32_t be_collect_segmented(VrgBackend* b, const VrgCtx& c, uint64_t* stamps, uint32_t* idxs, uint32_t cap) {

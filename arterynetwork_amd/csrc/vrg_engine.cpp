@@ -212,7 +212,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "events") h->ev.enabled = value != 0;
     else if (n == "dense_off") h->dense_off = value != 0;   // measurement aid: band chain alone; re-initialise afterwards
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
-    else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "serial_streams") be_set_tuning(h->be, name, value);
+    else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "serial_streams" || n == "skip_excluded") be_set_tuning(h->be, name, value);
     else if (n == "storage16") h->storage16 = value != 0;      // takes effect at the next vrg_init
     else return fail(h, VRG_E_ARG, "unknown option " + n);
     return VRG_OK;
@@ -486,12 +486,17 @@ int API(get_levels)(vrg_handle* h, double* values, int32_t* hin, int32_t* hout, 
 }
 
 // how the run went (diagnostics): out[0..3] = trips handed back {-, flips, marks, pool}, out[4] = host-driven trips,
-// out[5] = pool capacity, out[6] = marked-list capacity, out[7] = pool slots in use
+// out[5] = pool capacity, out[6] = marked-list capacity, out[7] = pool slots in use; with cap >= 9 also
+// out[8] = bytes one dense pass requests from memory with the current labels (0 before init)
 int API(get_stats)(vrg_handle* h, int64_t* outp, int64_t cap) {
     if (!h || !outp || cap < 8) return VRG_E_ARG;
     for (int i = 0; i < 4; i++) outp[i] = h->bails[i];
     outp[4] = h->sync_trips; outp[5] = h->c.bcap; outp[6] = h->c.mcap;
     outp[7] = h->inited ? get_state(h).np : 0;
+    if (cap >= 9) {
+        outp[8] = 0;
+        if (h->inited) { be_sync(h->be); outp[8] = (int64_t)be_dense_bytes(h->be, h->c); }
+    }
     return VRG_OK;
 }
 

@@ -77,7 +77,7 @@ def make_slab_session(shape, rank, world, device=0, lib=None, reduce='rccl', gro
 def bench_slabs(shape, args, dev, rank, world, roofline):
     """bench.py body for N > 1 ranks: every rank generates the same synthetic volume in its HBM, recounts
     its own Z-slab; barrier + synchronize around exactly K sweeps; MAX over ranks; whole-job throughput.
-    `roofline` is bench.py's roofline(shape, planes, kernel_ms, launches, traffic, storage16)."""
+    `roofline` is bench.py's roofline(shape, planes, kernel_ms, launches, traffic, storage16, dense_bytes)."""
     import torch
     import torch.distributed as dist
     from . import phantoms
@@ -94,6 +94,7 @@ def bench_slabs(shape, args, dev, rank, world, roofline):
     s.init(args.H)
     big = 10 ** 15
     r0 = s.run(args.warmup, big, None)
+    db0 = s.stats()['dense_bytes']
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
@@ -101,6 +102,7 @@ def bench_slabs(shape, args, dev, rank, world, roofline):
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
+    dense_bytes = (db0 + s.stats()['dense_bytes']) / 2.0
     dense_ms = r.sweep_kernel_ms / max(1, r.sweep_launches)
     t = torch.tensor([dt, dense_ms], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -125,7 +127,7 @@ def bench_slabs(shape, args, dev, rank, world, roofline):
                    'reduction': s.reduce_mode, 'rccl_ranks': s.comm_ranks,
                    'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
                    'dense_ms': round(kern_ms, 4), 'band_chain_ms': chain.get('band_chain_ms'), 'ranks': per_rank},
-        'roofline': roofline(shape, z1 - z0, kern_ms, int(r.sweep_launches), None),
+        'roofline': roofline(shape, z1 - z0, kern_ms, int(r.sweep_launches), None, False, dense_bytes),
     }
     s.close()
     return out

@@ -62,22 +62,29 @@ def padded_slab_voxels(shape, planes):
     return ((nx + 2 + 15) // 16 * 16) * (ny + 4) * planes
 
 
-def roofline(shape, planes, kern_ms, launches, traffic, storage16=False):
+def roofline(shape, planes, kern_ms, launches, traffic, storage16=False, dense_bytes=None):
     """Dominant kernel = k_recount_bits (dense region recount, one launch per sweep), HBM-bound.
-    `achieved` = the bytes the kernel has to move by its own design - 4 B fp32 intensity (2 B level index with
-    16-bit storage) + 2 class bits per voxel of the padded slab it streams - divided by the HIP-event time of the
-    launch; `frac` = achieved / 8 TB/s.  The label bytes are NOT streamed (labels are updated in place at the
-    ~10^3 marked voxels), so this is below SURVEY.md §8(d)'s 6 B/voxel-iteration accounting,
-    which is kept as `algorithmic_equiv_gbs` (what a kernel moving 6 B/voxel would need to match the time)."""
+    `achieved` = the bytes the kernel has to fetch by its own design divided by the HIP-event time of the launch;
+    `frac` = achieved / 8 TB/s.  The design bytes are `dense_bytes` when given: counted on the device from the class
+    bits (vrg_get_stats out[8]; mean of the count before and after the timed sweeps) - 2 class bits per voxel of the
+    padded slab + every 128-byte intensity line that holds an included voxel; runs of excluded voxels (the brain mask)
+    are not fetched.  Without it (option skip_excluded = 0) every voxel is streamed: 4 B fp32 intensity (2 B level
+    index with 16-bit storage) + 2 class bits per padded voxel.  The label bytes are NOT streamed (labels are updated
+    in place at the ~10^3 marked voxels).  Two figures are kept beside it and are never `frac`:
+    `streamed_equiv_gbs` (what a kernel that streams every voxel of the slab would have to reach for the same time)
+    and `algorithmic_equiv_gbs` (SURVEY.md section 8(d)'s 6 B/voxel-iteration accounting)."""
     bpv = 2.25 if storage16 else 4.25
-    design = bpv * padded_slab_voxels(shape, planes)
+    streamed = bpv * padded_slab_voxels(shape, planes)
+    design = float(dense_bytes) if dense_bytes else streamed
     V = shape[0] * shape[1] * planes
     achieved = design / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
-    out = {'bound': 'hbm', 'kernel': 'k_recount_bits<3,true,{}>'.format('true' if storage16 else 'false'),
+    out = {'bound': 'hbm', 'kernel': 'k_recount_bits<3,true,{},{}>'.format(1 if storage16 else 0, 'true' if dense_bytes else 'false'),
            'achieved': round(achieved, 1) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
            'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
            'kernel_ms_avg': round(kern_ms, 4), 'launches': launches,
-           'bytes_per_launch': int(design), 'bytes_per_voxel': bpv,
+           'bytes_per_launch': int(design), 'bytes_per_voxel': round(design / padded_slab_voxels(shape, planes), 4),
+           'bytes_counted_on_device': bool(dense_bytes),
+           'streamed_equiv_gbs': round(streamed / (kern_ms * 1e-3) / 1e9, 1) if kern_ms > 0 else None,
            'algorithmic_equiv_gbs': round((4 if storage16 else BYTES_PER_VOXEL_ITER) * V / (kern_ms * 1e-3) / 1e9, 1) if kern_ms > 0 else None,
            'traffic': traffic}
     if traffic and kern_ms > 0:
@@ -196,6 +203,7 @@ def main():
     ap.add_argument('--sweep-blocks', type=int, default=0)
     ap.add_argument('--prio-mode', type=int, default=-1)
     ap.add_argument('--events', type=int, default=1, help='0: no HIP events around the dense launches (no roofline then)')
+    ap.add_argument('--skip-excluded', type=int, default=1, help='0: the dense pass fetches the intensities of excluded voxels too')
     ap.add_argument('--serial', type=int, default=0, help='1: option serial_streams (needed under rocprofv3 --pmc, which runs one kernel at a time)')
     ap.add_argument('--storage16', action='store_true', help='16-bit intensity storage (level indices): config 5 style; 4 B/voxel-iter algorithmic')
     ap.add_argument('--force-dist', action='store_true', help='use the N>1 code path (RCCL comm) even with one rank')
@@ -247,6 +255,7 @@ def main():
     s.set_option('batch', 64)
     if args.serial:
         s.set_option('serial_streams', 1)
+    s.set_option('skip_excluded', args.skip_excluded)
     s.set_volume_ptr(I.data_ptr(), np.float32, [st for st in I.stride()])
     s.set_labels_ptr(vm.data_ptr(), np.uint8, [st for st in vm.stride()])
     t0 = time.perf_counter()
@@ -255,11 +264,13 @@ def main():
     big = 10 ** 15
     r0 = s.run(args.warmup, big, None)                      # W untimed warm-up sweeps
     assert r0.sweeps == args.warmup, 'warm-up stopped early: {}'.format(r0.stop_reason)
+    db0 = s.stats()['dense_bytes']                          # bytes a dense pass has to fetch with the labels as they are now
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     r = s.run(args.warmup + args.steps, big, None)          # EXACTLY K timed sweeps
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dense_bytes = (db0 + s.stats()['dense_bytes']) / 2.0 if args.skip_excluded else None
     valid = (r.sweeps == args.steps)
     ms_per_step = dt / max(1, r.sweeps) * 1e3
     value = V * r.sweeps / dt / 1e6
@@ -282,7 +293,7 @@ def main():
                    'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
                    'flips_per_sweep_mean': round(float(tr['nflip'][args.warmup + 1:].mean()), 1),
                    'dense_ms': round(kern_ms, 4)},
-        'roofline': roofline(shape, shape[2], kern_ms, int(r.sweep_launches), load_traffic(shape, 1, args.storage16), args.storage16),
+        'roofline': roofline(shape, shape[2], kern_ms, int(r.sweep_launches), load_traffic(shape, 1, args.storage16), args.storage16, dense_bytes),
     }
     out['config']['engine'] = s.stats()                     # trips handed back to the host / array growth during the run
     out['config'].update(s.chain_timing(args.H))

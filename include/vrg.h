@@ -79,6 +79,9 @@ const char* vrg_last_error(const vrg_handle* h);
  *   "serial_streams" any time; the host orders the band and dense streams (a synchronisation per sweep) instead of the
  *                    kernels waiting for each other on the device - for tools that run one kernel at a time
  *                    (rocprofv3 --pmc), under which a device-side wait could never end
+ *   "skip_excluded"  any time; 1 (default): the dense pass does not fetch the intensities of runs of excluded voxels
+ *                    (label 4, as the reference's dataArray[mask] gathers :249-250 never touch them); 0: it streams
+ *                    the whole slab.  Same sums bit for bit.
  *   "dense_off"      any time; measurement aid: the dense recount is not launched (the band chain alone);
  *                    the handle has to be initialised again afterwards
  *   "sweep_blocks", "prio_mode"
@@ -117,7 +120,9 @@ int vrg_get_levels(vrg_handle* h, double* values, int32_t* hist_in, int32_t* his
 
 /* Diagnostics of the handle's runs so far: out[0..3] = trips handed back to the host {unused, too many flips for
  * one workgroup, marked-voxel arrays grown, band pool grown}, out[4] = host-driven trips, out[5] = band pool
- * capacity, out[6] = marked-list capacity, out[7] = pool slots in use.  cap >= 8. */
+ * capacity, out[6] = marked-list capacity, out[7] = pool slots in use.  cap >= 8.  With cap >= 9 also out[8] =
+ * the bytes one dense pass requests from memory with the current labels (class words + the 128-byte intensity lines
+ * that hold an included voxel; every line of the slab with option skip_excluded = 0) - the roofline's numerator. */
 int vrg_get_stats(vrg_handle* h, int64_t* out, int64_t cap);
 
 /* ---- multi-GPU (one process per GPU) --------------------------------------------------

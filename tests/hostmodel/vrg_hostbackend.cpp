@@ -237,6 +237,28 @@ void be_recount_hist(VrgBackend*, const VrgCtx& c, int32_t* rin, int32_t* rout) 
     });
 }
 
+// same definition as the device kernel (k_dense_bytes), as a plain loop over the class words
+uint64_t be_dense_bytes(VrgBackend*, const VrgCtx& c) {
+    const uint32_t* cls = c.clsb[c.dctl[VD_RSEQ] & 1];
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
+    const uint32_t lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
+    const uint32_t lpl = c.lev16 ? 16u : (c.I ? 8u : 4u);
+    uint64_t bytes = 0;
+    for (uint32_t u = lo >> 10; u <= (hi - 1u) >> 10; u++) {
+        bytes += 256u;
+        for (int j = 0; j < 4; j++)
+            for (uint32_t g = 0; g < 64u; g += lpl) {
+                bool any = false;
+                for (uint32_t lane = g; lane < g + lpl; lane++) {
+                    const uint32_t v = (u << 10) + (j << 8) + (lane << 2);
+                    if (v >= lo && v < hi && ((cls[((size_t)u << 6) + lane] >> (8 * j)) & 0xffu)) any = true;
+                }
+                if (any) bytes += 128u;
+            }
+    }
+    return bytes;
+}
+
 uint32_t be_collect_segmented(VrgBackend*, const VrgCtx& c, uint64_t* stamps, uint32_t* idxs, uint32_t cap) {
     uint32_t n = 0;
     for_real_voxels(c, [&](uint32_t idx, int, int, int) {

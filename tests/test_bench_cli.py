@@ -34,6 +34,10 @@ def test_roofline_is_a_fraction_of_peak():
     assert r['algorithmic_equiv_gbs'] > r['achieved']            # 6 B/voxel accounting is kept apart, never as frac
     r16 = bench.roofline((880, 880, 640), 640, 0.24, 500, None, storage16=True)
     assert r16['bytes_per_voxel'] == 2.25 and r16['frac'] < 1
+    # bytes counted on the device (excluded runs not fetched) replace the streamed figure in frac, which stays <= 1
+    rs = bench.roofline((880, 880, 640), 640, 0.19, 500, None, dense_bytes=1.06e9)
+    assert rs['bytes_per_launch'] == 1060000000 and rs['bytes_counted_on_device'] and 0.6 < rs['frac'] < 0.75
+    assert rs['streamed_equiv_gbs'] > 8000 > rs['achieved']
 
 
 def test_traffic_only_for_the_sources_it_was_measured_on():

@@ -51,8 +51,15 @@ out = {
     'note': 'gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md, HBM); '
             'corrected fetch = 2 x raw. WRITE_SIZE is exact.',
     'hbm_bytes_per_launch': int((2 * fk + wk) * 1024),
-    'algorithmic_bytes_per_launch': 6 * V, 'bytes_actually_streamed_per_launch': int(4.25 * streamed),
+    'algorithmic_bytes_per_launch': 6 * V, 'bytes_if_every_voxel_streamed': int(4.25 * streamed),
 }
+# the bytes the kernel requests by its design, counted on the device in the PMC pass itself (bench.py roofline.bytes_per_launch)
+try:
+    line = [l for l in open(src + '/bench_fetch.log') if l.startswith('{')][-1]
+    out['design_bytes_per_launch_counted_on_device'] = json.loads(line)['roofline']['bytes_per_launch']
+    out['hbm_over_design'] = round(out['hbm_bytes_per_launch'] / out['design_bytes_per_launch_counted_on_device'], 4)
+except Exception:
+    pass
 out['src_sha_note'] = 'sha256[:16] of csrc/vrg_device.hip + vrg_items.h + vrg_types.h at profiling time; bench.py reports this traffic figure only while those sources are unchanged'
 json.dump(out, open('profiles/traffic.json', 'w'), indent=1)
 with open('profiles/%s_pmc.csv' % tag, 'w') as f:
