@@ -748,13 +748,34 @@ __device__ __forceinline__ void stats_group(SweepAcc& a, uint32_t wj, const Unit
 // SKIP: a group of four voxels per lane whose 256 voxels are all excluded costs the wave nothing (the branch is
 // wave-uniform there); partly excluded groups run with the excluded lanes masked off.  Adding +0.0 or not adding at
 // all gives the same sums (the accumulators never hold -0.0: they start at +0.0).
+template <int MODE>
+__device__ __forceinline__ double unit_value(const UnitVals<MODE>& u, int j, int bb, const float* lv) {
+    if constexpr (MODE == 2) return u.f[j][bb >> 1][bb & 1];
+    else if constexpr (MODE == 1) return (double)lv[bb];
+    else return (double)u.f[j][bb];
+}
+// Most groups inside the brain mask hold four outer voxels (class byte 0xAA): when every lane that takes part has
+// such a group, the four values go straight into the outer sum - the same additions in the same order as the general
+// path makes (which also adds +0.0 to the inner sum four times: no change).
 template <int MODE, bool SKIP>
 __device__ __forceinline__ void stats_bits(SweepAcc& a, uint32_t w, const UnitVals<MODE>& u, const float* s_val) {
     a.nin += __popc(w & 0x55555555u); a.nout += __popc(w & 0xAAAAAAAAu);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t wj = (w >> (8 * j)) & 0xffu;
-        if (!SKIP || wj != 0u) stats_group<MODE>(a, wj, u, j, s_val);
+        if (!SKIP || wj != 0u) {
+            if (SKIP && __builtin_amdgcn_ballot_w64(wj != 0xAAu) == 0ull) {
+                float lv[4];
+                if constexpr (MODE == 1) {
+                    lv[0] = s_val[u.q[j].x & 0xffffu]; lv[1] = s_val[u.q[j].x >> 16];
+                    lv[2] = s_val[u.q[j].y & 0xffffu]; lv[3] = s_val[u.q[j].y >> 16];
+                }
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) a.sout += unit_value<MODE>(u, j, bb, lv);
+            } else {
+                stats_group<MODE>(a, wj, u, j, s_val);
+            }
+        }
     }
 }
 template <bool NT>
@@ -823,11 +844,16 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
         uint32_t wn[UNITS];
 #pragma unroll
         for (int q = 0; q < UNITS; q++) wn[q] = load_cls<NT>(cls, up + q, lane);
-        UnitVals<MODE> f[UNITS];
+        uint32_t w_any = 0u;
 #pragma unroll
-        for (int q = 0; q < UNITS; q++) load_vals<MODE, NT, SKIP>(c, u + q, lane, w[q], f[q]);
+        for (int q = 0; q < UNITS; q++) w_any |= w[q];
+        if (!SKIP || __builtin_amdgcn_ballot_w64(w_any != 0u) != 0ull) {      // (a trip outside the mask: one compare, one scalar branch)
+            UnitVals<MODE> f[UNITS];
 #pragma unroll
-        for (int q = 0; q < UNITS; q++) stats_bits<MODE, SKIP>(acc, w[q], f[q], s_val);
+            for (int q = 0; q < UNITS; q++) load_vals<MODE, NT, SKIP>(c, u + q, lane, w[q], f[q]);
+#pragma unroll
+            for (int q = 0; q < UNITS; q++) stats_bits<MODE, SKIP>(acc, w[q], f[q], s_val);
+        }
 #pragma unroll
         for (int q = 0; q < UNITS; q++) w[q] = wn[q];
         u = un;
