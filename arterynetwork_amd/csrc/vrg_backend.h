@@ -14,7 +14,7 @@
 struct VrgBackend;             // opaque: defined by the backend
 
 struct VrgEvents {            // optional HIP-event timing of the dense sweep launches
-    int enabled;
+    int enabled;              // 0: off; n > 0: every n-th trip of a batch is timed
     double ms_total;
     long long launches;
 };

@@ -37,7 +37,7 @@
 #include "vrg_backend.h"
 #include "vrg_items.h"
 
-struct EvPair { hipEvent_t a, b; };
+struct EvPair { hipEvent_t a, b; long long trip; };
 
 struct VrgBackend {
     int device = 0;
@@ -50,6 +50,7 @@ struct VrgBackend {
     char err[256] = "";                  // first HIP / RCCL failure; the engine turns it into VRG_E_INTERNAL
     std::vector<EvPair> ev_pool;
     size_t ev_used = 0;
+    long long ev_trip = 0;               // trips enqueued since the last be_events_collect
     void* tmp = nullptr; size_t tmp_bytes = 0;        // scratch of the host-driven sorts
     uint64_t* keys2 = nullptr; size_t keys2_n = 0;
     int dense_pending = 0;                            // Z-slabs: recounts enqueued since the last staged all-reduce
@@ -71,7 +72,9 @@ constexpr int SWEEP_BLOCKS = 256;   // 1 workgroup (4 waves) per CU, each wave w
                                     // it (880x880x640: 256 -> 0.38 ms, 192/384 -> 0.42-0.43, 320 -> 0.49, 512 -> 0.40, 1024 -> 0.44)
 constexpr uint32_t NF_SMALL = 4096; // flips one workgroup sorts in LDS
 constexpr uint32_t NZ_LDS = 1024;   // touched levels k_band keeps in LDS
-constexpr int KS_THREADS = 1024;    // k_close, k_fix: one big workgroup
+constexpr int KS_THREADS = 1024;    // k_fix (host-driven trips): one big workgroup
+constexpr int KC_THREADS = 256;     // k_close: one wave per SIMD, so that its workgroups fit on a CU beside the three recount waves
+                                    // per SIMD (16-wave workgroups had to wait for the recount to end: 0.1 ms per sweep)
 
 // ---- wave / block primitives (wave = 64 lanes) -------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
@@ -345,7 +348,7 @@ __global__ void k_gate(VrgCtx c) { if (threadIdx.x == 0) (void)gate_dense_due(c)
 __global__ void k_wait_dense(VrgCtx c) { if (threadIdx.x == 0) wait_dense_read(c); }
 
 constexpr int KO_THREADS = 256;
-constexpr int TAB_BLOCKS = 64;
+constexpr int TAB_BLOCKS = 256;     // k_close: memo workgroups (1024 waves, one level each at a time)
 constexpr uint32_t NZ_SORT = 2048;  // touched levels one workgroup sorts in LDS
 
 __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_limit) {
@@ -475,9 +478,9 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
     }
 }
 
-__global__ void __launch_bounds__(KS_THREADS) k_close(VrgCtx c, int dense_on) {
+__global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
     if (c.st->done || c.st->bail) return;
-    constexpr uint32_t T = KS_THREADS;
+    constexpr uint32_t T = KC_THREADS;
     const uint32_t t = threadIdx.x;
     __shared__ uint64_t s_key[NZ_SORT];
     __shared__ double s_val[NZ_SORT];
@@ -1425,16 +1428,18 @@ static void host_driven_update(VrgBackend* b, const VrgCtx& c, int flags) {
 static void small_update(VrgBackend* b, const VrgCtx& c, bool dense) {
     k_order<<<1, KO_THREADS, 0, b->sa>>>(c, b->small_flips);
     k_mark_relabel<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c);
-    k_close<<<1 + TAB_BLOCKS, KS_THREADS, 0, b->sa>>>(c, dense ? 1 : 0);   // (waits on the device for the dense pass of two sweeps ago)
+    k_close<<<1 + TAB_BLOCKS, KC_THREADS, 0, b->sa>>>(c, dense ? 1 : 0);   // (waits on the device for the dense pass of two sweeps ago)
 }
 
 void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_reduce_fn cb, void* user) {
     use_device(b);
     hipEvent_t e_start = nullptr, e_stop = nullptr;
     const bool dense = !(flags & VRG_SWEEP_NODENSE);
-    if (dense && ev && ev->enabled) {
-        if (b->ev_used == b->ev_pool.size()) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); b->ev_pool.push_back(n); }
+    const long long trip = b->ev_trip++;
+    if (dense && ev && ev->enabled > 0 && trip % ev->enabled == 0) {     // (every enabled-th trip: an event pair costs the dense stream a few us)
+        if (b->ev_used == b->ev_pool.size()) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); n.trip = 0; b->ev_pool.push_back(n); }
         EvPair& p = b->ev_pool[b->ev_used++];
+        p.trip = trip;
         e_start = p.a; e_stop = p.b;
     }
     if ((flags & VRG_SWEEP_SYNC) && c.L > EXACT_BIG_L) {     // huge level table: the pending entries' densities on the whole chip
@@ -1485,13 +1490,13 @@ void be_events_collect(VrgBackend* b, VrgEvents* ev, long long n_valid) {
     use_device(b);
     if (b->ev_used) HIP_CHECK(hipStreamSynchronize(b->sb));   // the dense stream may trail the band stream by one pass
     for (size_t i = 0; i < b->ev_used; i++) {
-        if ((long long)i < n_valid) {
+        if (b->ev_pool[i].trip < n_valid) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, b->ev_pool[i].a, b->ev_pool[i].b) == hipSuccess) { ev->ms_total += ms; ev->launches++; }
             else (void)hipGetLastError();
         }
     }
-    b->ev_used = 0;
+    b->ev_used = 0; b->ev_trip = 0;
 }
 
 void be_recount_hist(VrgBackend* b, const VrgCtx& c, int32_t* rin, int32_t* rout) {

@@ -209,7 +209,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     if (n == "band_capacity") { if (h->inited || value < 1) return fail(h, VRG_E_STATE, "band_capacity must be set before vrg_init"); h->band_capacity = (uint64_t)value; }
     else if (n == "capacity_floor") { if (h->c.p_idx || value < 1) return fail(h, VRG_E_STATE, "capacity_floor must be set before the first vrg_init"); h->cap_floor = (uint64_t)value; }
     else if (n == "sweep_variant") { if (h->inited) return fail(h, VRG_E_STATE, "sweep_variant must be set before vrg_init"); h->variant = (int)value; }
-    else if (n == "events") h->ev.enabled = value != 0;
+    else if (n == "events") h->ev.enabled = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20);
     else if (n == "dense_off") h->dense_off = value != 0;   // measurement aid: band chain alone; re-initialise afterwards
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
     else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "serial_streams" || n == "skip_excluded") be_set_tuning(h->be, name, value);

@@ -87,7 +87,7 @@ def bench_slabs(shape, args, dev, rank, world, roofline):
     s = make_slab_session(shape, rank, world, device=dev.index, reduce='rccl-always')
     if args.sweep_blocks:
         s.set_option('sweep_blocks', args.sweep_blocks)
-    s.set_option('events', 1)
+    s.set_option('events', 4)            # HIP events around every 4th dense launch
     s.set_option('batch', 64)
     s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
     s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
@@ -126,7 +126,7 @@ def bench_slabs(shape, args, dev, rank, world, roofline):
                                   '32-byte RCCL all-reduce per sweep)'.format(world, world),
                    'reduction': s.reduce_mode, 'rccl_ranks': s.comm_ranks,
                    'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
-                   'dense_ms': round(kern_ms, 4), 'band_chain_ms': chain.get('band_chain_ms'), 'ranks': per_rank},
+                   'dense_ms': round(kern_ms, 4), 'dense_events_every': 4, 'band_chain_ms': chain.get('band_chain_ms'), 'ranks': per_rank},
         'roofline': roofline(shape, z1 - z0, kern_ms, int(r.sweep_launches), None, False, dense_bytes),
     }
     s.close()

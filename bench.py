@@ -202,7 +202,8 @@ def main():
     ap.add_argument('--variant', type=int, default=0)
     ap.add_argument('--sweep-blocks', type=int, default=0)
     ap.add_argument('--prio-mode', type=int, default=-1)
-    ap.add_argument('--events', type=int, default=1, help='0: no HIP events around the dense launches (no roofline then)')
+    ap.add_argument('--events', type=int, default=4, help='HIP events around every n-th dense launch (they cost the dense stream '
+                    'a few us each); 0: none (no roofline then)')
     ap.add_argument('--skip-excluded', type=int, default=1, help='0: the dense pass fetches the intensities of excluded voxels too')
     ap.add_argument('--serial', type=int, default=0, help='1: option serial_streams (needed under rocprofv3 --pmc, which runs one kernel at a time)')
     ap.add_argument('--storage16', action='store_true', help='16-bit intensity storage (level indices): config 5 style; 4 B/voxel-iter algorithmic')
@@ -292,7 +293,7 @@ def main():
                    'init_seconds': round(t_init, 3), 'nseg_start': int(tr['nseg'][args.warmup]),
                    'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
                    'flips_per_sweep_mean': round(float(tr['nflip'][args.warmup + 1:].mean()), 1),
-                   'dense_ms': round(kern_ms, 4)},
+                   'dense_ms': round(kern_ms, 4), 'dense_events_every': args.events},
         'roofline': roofline(shape, shape[2], kern_ms, int(r.sweep_launches), load_traffic(shape, 1, args.storage16), args.storage16, dense_bytes),
     }
     out['config']['engine'] = s.stats()                     # trips handed back to the host / array growth during the run

@@ -72,7 +72,8 @@ const char* vrg_last_error(const vrg_handle* h);
  *                    pass streams 2 B instead of 4 B per voxel; results are bit-identical
  *   "sweep_variant"  0 = relabel only the marked voxels (default), 1 = check variant that runs the
  *                    label stencil on every voxel (slow; must give the same state)
- *   "events"         any time; time every dense-pass launch with HIP events (vrg_result.sweep_kernel_ms)
+ *   "events"         any time; n > 0: time the dense pass of every n-th sweep of a batch with HIP events
+ *                    (vrg_result.sweep_kernel_ms / sweep_launches; an event pair costs the dense stream a few us)
  *   "batch"          any time; sweeps enqueued between host checks of the stop flag (default 8)
  *   "small_flips"    any time; flips per sweep up to which update() runs as ONE workgroup's kernel (default and
  *                    maximum 4096); sweeps with more are driven from the host with device-wide kernels
