@@ -447,6 +447,44 @@ def test_16bit_storage_identical(lib, golden_loader):
     s.close()
 
 
+def test_skip_excluded_is_bit_identical(lib):
+    """The dense pass does not fetch runs of excluded voxels (option skip_excluded, default 1): same labels and the same
+    f64 intensity sums, bit for bit, as the pass that streams every voxel - fp32, 16-bit and float64 storage; brain
+    mask (long runs), scattered excluded voxels (every group mixed), nothing excluded.  The byte count the roofline
+    uses follows the documented definition."""
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session
+    from test_hostmodel import dense_bytes_by_definition
+    rng = np.random.default_rng(21)
+    cases = []
+    d, v = phantoms.bench_volume((256, 192, 96), seed=4)
+    cases += [(d, v, 0, 32, 40), (d, v, 1, 64, 40)]
+    shape = (83, 61, 47)
+    u = rng.random(shape)
+    vm = np.full(shape, 3, dtype=np.int64); vm[u < 0.03] = 0; vm[u > 0.55] = 4
+    cases.append((rng.integers(0, 7, size=shape).astype(np.float64), vm, 0, 32, 12))
+    cases.append((rng.integers(0, 7, size=shape).astype(np.float64), vm, 1, 64, 12))
+    cases.append((np.round(rng.standard_normal(shape), 1) + 1e-9 * rng.standard_normal(shape), vm, 0, 16, 6))   # float64 storage
+    vm2 = np.full(shape, 3, dtype=np.int64); vm2[u < 0.03] = 0
+    cases.append((rng.integers(0, 7, size=shape).astype(np.float64), vm2, 0, 32, 12))
+    for I, vmap, s16, line, sweeps in cases:
+        outs = []
+        for skip in (0, 1):
+            s = Session(I.shape, lib=lib)
+            s.set_option('storage16', s16); s.set_option('skip_excluded', skip)
+            s.set_volume(I); s.set_labels(vmap.astype(np.uint8)); s.init(2.25)
+            r = s.run(sweeps, 10 ** 9, None)
+            outs.append((s.labels(), s.trace(), r.sweeps, s.stats()['dense_bytes']))
+            s.close()
+        assert outs[0][2] == outs[1][2] > 0
+        assert np.array_equal(outs[0][0], outs[1][0])
+        assert outs[0][1].tobytes() == outs[1][1].tobytes()            # trace incl. sum_in / sum_out: bit-identical
+        nx, ny, nz = I.shape
+        streamed = ((nx + 2 + 15) // 16 * 16) * (ny + 4) * nz * (128 // line) + ((nx + 2 + 15) // 16 * 16) * (ny + 4) * nz // 4
+        assert outs[0][3] == streamed                                  # skip_excluded = 0: every voxel of the slab
+        assert outs[1][3] == dense_bytes_by_definition(outs[1][0], line) <= streamed + 512
+
+
 def test_host_driven_and_one_workgroup_sweeps_identical(lib, golden_loader):
     """update() as the three batched kernels (k_order / k_mark_relabel / k_close) and as host-driven device-wide kernels
     (sweeps with more flips than "small_flips"; rocPRIM sorts) must give the same state; so must arrays that start tiny

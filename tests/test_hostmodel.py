@@ -224,3 +224,49 @@ def test_hostmodel_16bit_storage(hm, golden_loader, name):
     res, k = parity.run_stepwise(hm, data, vmap, g.H, g.maxSegmentSize, iterMax, density_mode=1, check_hist=True,
                                  options={'storage16': 1})
     assert res is not None and k == g.ncalls - 1
+
+
+def dense_bytes_by_definition(labels, line_voxels=32):
+    """The bytes one dense pass has to fetch for a label volume [x][y][z], from the documented layout (DESIGN.md
+    section 3/4): padded x-fastest volume, 256 B of class words per 1024-voxel unit that the slab's planes touch +
+    128 B for every aligned run of `line_voxels` voxels (one cache line of intensities) that holds an included
+    (label != 4) voxel."""
+    nx, ny, nz = labels.shape
+    PX, PY = (nx + 2 + 15) // 16 * 16, ny + 4
+    pad = np.zeros(((nz + 4) * PY * PX + 2048,), dtype=bool)
+    vol = pad[:(nz + 4) * PY * PX].reshape(nz + 4, PY, PX)
+    vol[2:nz + 2, 2:ny + 2, :nx] = np.transpose(labels != 4, (2, 1, 0))
+    lo, hi = 2 * PY * PX, (nz + 2) * PY * PX
+    units = ((hi - 1) >> 10) - (lo >> 10) + 1
+    first = (lo // line_voxels) * line_voxels
+    last = -(-hi // line_voxels) * line_voxels
+    lines = pad[first:last].reshape(-1, line_voxels).any(axis=1).sum()
+    return 256 * units + 128 * int(lines)
+
+
+def test_hostmodel_dense_bytes_counter(hm):
+    """vrg_get_stats out[8] (what bench.py's roofline divides by the kernel time) counts class words + intensity lines
+    with an included voxel: checked against the definition on volumes with a brain mask, scattered excluded voxels,
+    none, and for the three storage widths (16-bit: 64 voxels per line, float64: 16)."""
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session
+    cases = []
+    d, v = phantoms.bench_volume((70, 45, 33), seed=4)
+    cases.append((d, v, 0, 32)); cases.append((d, v, 1, 64))
+    rng = np.random.default_rng(11)
+    shape = (37, 22, 19)
+    u = rng.random(shape)
+    vm = np.full(shape, 3, dtype=np.int64); vm[u < 0.05] = 0; vm[u > 0.6] = 4
+    cases.append((rng.integers(0, 5, size=shape).astype(np.float64), vm, 0, 32))
+    cases.append((rng.standard_normal(shape) + 1e-9 * rng.standard_normal(shape), vm, 0, 16))      # float64 storage
+    vm2 = np.full(shape, 3, dtype=np.int64); vm2[u < 0.05] = 0
+    cases.append((rng.integers(0, 5, size=shape).astype(np.float64), vm2, 0, 32))                   # nothing excluded
+    for I, vmap, s16, line in cases:
+        s = Session(I.shape, lib=hm)
+        s.set_option('storage16', s16)
+        s.set_volume(I); s.set_labels(vmap.astype(np.uint8)); s.init(2.25)
+        s.run(5, 10 ** 9, None)
+        got = s.stats()['dense_bytes']
+        lab = s.labels()
+        s.close()
+        assert got == dense_bytes_by_definition(lab, line), (I.shape, s16, line)
