@@ -6,8 +6,9 @@
 // EDT: Meijster's exact integer algorithm (the squared distance is an integer, so any exact method -
 //   scipy uses a Voronoi feature transform - yields the same value; out = sqrt in float64).
 //   Phase 1 along axis 0 (two scans), then the lower-envelope pass along axis 1 and along axis 2,
-//   one thread per line with the wave's lanes on neighbouring lines (coalesced); for axis 2 the volume is
-//   transposed i1 <-> i2 in 64 x 64 LDS tiles before and after.  HBM-bound: ~13 volume passes of 4 B/voxel.
+//   one thread per line with the wave's lanes on neighbouring lines (coalesced), the envelope stack in registers /
+//   LDS / a chunked spill area (k_edt_envelope); for axis 2 the volume is transposed i1 <-> i2 in 64 x 64 LDS tiles
+//   before and after.  HBM-bound.
 // Labelling: union-find with compare-and-swap linking (root = smallest raster index of the component), one
 //   union pass over the 3/9/13 forward neighbours, path flattening, component sizes by atomics, and
 //   raster-order numbering = exclusive scan of the root flags (what skimage / scipy number by).
@@ -62,41 +63,83 @@ __device__ __forceinline__ long long floordiv(long long a, long long b) {   // b
     return (a % b != 0 && a < 0) ? q - 1 : q;
 }
 
-// Meijster phase 2 along one axis: Gout(u) = min_i (u-i)^2 + Gin(i).  The lower envelope is a per-line stack
-// kept in global memory (ST = site | start << 16, GS = Gin at the site; same indexing as the data) with its
-// TOP cached in registers, so the forward scan touches the stack only on pops (no dependent gathers otherwise).
-__global__ void k_edt_envelope(const int32_t* __restrict__ Gin, int32_t* __restrict__ Gout, uint32_t* __restrict__ ST,
-                               int32_t* __restrict__ GS, Dims d, int axis) {
-    const uint32_t nlines = axis == 1 ? (uint32_t)d.n0 * d.n2 : (uint32_t)d.n0 * d.n1;
-    const int32_t m = axis == 1 ? d.n1 : d.n2;
-    const size_t stride = axis == 1 ? (size_t)d.n2 : 1;
+// Meijster phase 2 along axis 1: Gout(u) = min_i (u-i)^2 + Gin(i), one thread per line, the lanes of a wave on
+// neighbouring lines (i2 consecutive: every row access is one 256-byte request).  The lower envelope is a per-line
+// stack of (site | start << 16, G(site)).  Its top sits in registers and its topmost <= EDT_RING entries in LDS (a ring
+// per thread, [slot][thread]: conflict-free).  Deeper entries live in a spill area in global memory, one contiguous
+// region per line (padded to EDT_CHUNK entries), and move between the two in aligned chunks of EDT_CHUNK entries =
+// 64 bytes: a full ring sheds its oldest chunk, a pop below the ring brings one back (leaving room for as many pushes
+// before the next move).  The line's values are fetched EDT_AHEAD rows ahead of the scan.
+// (Round 1: every push wrote and every pop read global memory in the data's layout, 4 bytes at a time at addresses
+// that differ from lane to lane, and every step waited for its own load - 12.4 ms per pass at 880x880x640.)
+constexpr int EDT_RING = 16;
+constexpr int EDT_CHUNK = 8;
+constexpr int EDT_AHEAD = 8;
+__global__ void __launch_bounds__(TPB) k_edt_envelope(const int32_t* __restrict__ Gin, int32_t* __restrict__ Gout, uint2* __restrict__ SP, Dims d) {
+    __shared__ uint32_t r_st[EDT_RING][TPB];
+    __shared__ int32_t r_g[EDT_RING][TPB];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nlines = (uint32_t)d.n0 * d.n2;
+    const int32_t m = d.n1;
+    const size_t mp = ((size_t)m + EDT_CHUNK - 1) / EDT_CHUNK * EDT_CHUNK;
+    const size_t stride = (size_t)d.n2;
     for (uint32_t line = blockIdx.x * blockDim.x + threadIdx.x; line < nlines; line += gridDim.x * blockDim.x) {
-        size_t base = axis == 1 ? (size_t)(line / d.n2) * d.n1 * d.n2 + (line % d.n2) : (size_t)line * d.n2;
+        const size_t base = (size_t)(line / d.n2) * d.n1 * d.n2 + (line % d.n2);
+        uint2* __restrict__ spill = SP + (size_t)line * mp;
 #define AT(u) (base + (size_t)(u) * stride)
-        int32_t q = 0;
+        // entries [low, q] of the stack are in the ring (entry i in slot i % EDT_RING), entries [0, low) in the spill
+        // area; low is a multiple of EDT_CHUNK
+        int32_t q = 0, low = 0;
         long long ts = 0, tt = 0, tg = Gin[AT(0)];               // top of the stack: site, start, G(site)
-        ST[AT(0)] = 0; GS[AT(0)] = (int32_t)tg;
-        for (int32_t u = 1; u < m; u++) {
-            const long long Gu = Gin[AT(u)];
-            while (q >= 0) {
-                long long f1 = (tt - ts) * (tt - ts) + tg;
-                long long f2 = (tt - u) * (tt - u) + Gu;
-                if (f1 <= f2) break;
-                if (--q >= 0) { uint32_t p = ST[AT(q)]; ts = p & 0xffffu; tt = p >> 16; tg = GS[AT(q)]; }
+        r_st[0][tid] = 0; r_g[0][tid] = (int32_t)tg;
+        auto pop = [&]() {                                        // q was decremented and is >= 0: its entry becomes the top
+            if (q < low) {                                        // (q == low - 1: the chunk below the ring comes back)
+                low -= EDT_CHUNK;
+                uint2 e[EDT_CHUNK];
+#pragma unroll
+                for (int i = 0; i < EDT_CHUNK; i++) e[i] = spill[low + i];
+#pragma unroll
+                for (int i = 0; i < EDT_CHUNK; i++) { r_st[(low + i) % EDT_RING][tid] = e[i].x; r_g[(low + i) % EDT_RING][tid] = (int32_t)e[i].y; }
             }
-            if (q < 0) { q = 0; ts = u; tt = 0; tg = Gu; ST[AT(0)] = (uint32_t)u; GS[AT(0)] = (int32_t)Gu; }
-            else {
-                long long w = 1 + floordiv((long long)u * u - ts * ts + Gu - tg, 2 * (u - ts));
-                if (w < m) {                                      // w >= 1 here: the top still wins at its own start
-                    q++; ts = u; tt = w; tg = Gu;
-                    ST[AT(q)] = (uint32_t)u | ((uint32_t)w << 16); GS[AT(q)] = (int32_t)Gu;
+            const uint32_t p = r_st[q % EDT_RING][tid];
+            ts = p & 0xffffu; tt = p >> 16; tg = r_g[q % EDT_RING][tid];
+        };
+        for (int32_t u0 = 1; u0 < m; u0 += EDT_AHEAD) {
+            int32_t gv[EDT_AHEAD];
+#pragma unroll
+            for (int k = 0; k < EDT_AHEAD; k++) gv[k] = u0 + k < m ? Gin[AT(u0 + k)] : 0;
+#pragma unroll
+            for (int k = 0; k < EDT_AHEAD; k++) {
+                const int32_t u = u0 + k;
+                if (u >= m) break;
+                const long long Gu = gv[k];
+                while (q >= 0) {
+                    long long f1 = (tt - ts) * (tt - ts) + tg;
+                    long long f2 = (tt - u) * (tt - u) + Gu;
+                    if (f1 <= f2) break;
+                    if (--q >= 0) pop();
+                }
+                if (q < 0) { q = 0; low = 0; ts = u; tt = 0; tg = Gu; r_st[0][tid] = (uint32_t)u; r_g[0][tid] = (int32_t)Gu; }
+                else {
+                    long long w = 1 + floordiv((long long)u * u - ts * ts + Gu - tg, 2 * (u - ts));
+                    if (w < m) {                                  // w >= 1 here: the top still wins at its own start
+                        q++;
+                        if (q - low >= EDT_RING) {                // the ring is full: its oldest chunk moves to the spill area
+#pragma unroll
+                            for (int i = 0; i < EDT_CHUNK; i++)
+                                spill[low + i] = make_uint2(r_st[(low + i) % EDT_RING][tid], (uint32_t)r_g[(low + i) % EDT_RING][tid]);
+                            low += EDT_CHUNK;
+                        }
+                        ts = u; tt = w; tg = Gu;
+                        r_st[q % EDT_RING][tid] = (uint32_t)u | ((uint32_t)w << 16); r_g[q % EDT_RING][tid] = (int32_t)Gu;
+                    }
                 }
             }
         }
         for (int32_t u = m - 1; u >= 0; u--) {
             long long v = (u - ts) * (u - ts) + tg;
             Gout[AT(u)] = v >= EDT_INF ? EDT_INF : (int32_t)v;
-            if (u == tt && --q >= 0) { uint32_t p = ST[AT(q)]; ts = p & 0xffffu; tt = p >> 16; tg = GS[AT(q)]; }
+            if (u == tt && --q >= 0) pop();
         }
 #undef AT
     }
@@ -129,19 +172,29 @@ __global__ void __launch_bounds__(256) k_transpose12(const int32_t* __restrict__
     }
 }
 
-// squared EDT of a device-resident mask into G (device); tmp: three more int32 volumes.
+// squared EDT of a device-resident mask into G (device).  Scratch: one more int32 volume and the envelope pass's
+// spill area (8 bytes per voxel, lines padded to EDT_CHUNK entries).
 // The lower-envelope pass runs one thread per line with the lanes of a wave on neighbouring lines, which is
 // coalesced only when the lines are NOT along the fastest axis: the axis-2 pass therefore runs on the i1 <-> i2
 // transposed volume (two tiled transposes, ~4 GB of traffic each at 880x880x640, instead of a 20x slower pass).
-int edt_squared(const uint8_t* dmask, Dims d, int32_t* G, int32_t* G2, int32_t* S, int32_t* T) {
+int edt_squared(const uint8_t* dmask, Dims d, int32_t* G) {
+    const size_t V = (size_t)d.n0 * d.n1 * d.n2;
+    auto padded = [](size_t m) { return (m + EDT_CHUNK - 1) / EDT_CHUNK * EDT_CHUNK; };
+    const size_t spill_entries = std::max((size_t)d.n0 * d.n2 * padded((size_t)d.n1), (size_t)d.n0 * d.n1 * padded((size_t)d.n2));
+    int32_t* G2 = nullptr; uint2* SP = nullptr;
+    VM_TRY(hipMalloc(&G2, V * 4));
+    if (hipMalloc(&SP, spill_entries * sizeof(uint2)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(G2); g_err = "out of device memory (EDT scratch)"; return VRG_E_MEM; }
     k_edt_axis0<<<grid_for((uint64_t)d.n1 * d.n2), TPB>>>(dmask, G, d);
-    k_edt_envelope<<<grid_for((uint64_t)d.n0 * d.n2), TPB>>>(G, G2, (uint32_t*)S, T, d, 1);
+    k_edt_envelope<<<grid_for((uint64_t)d.n0 * d.n2), TPB>>>(G, G2, SP, d);
     const int tgrid = (int)std::min<uint64_t>(65535u * 4u, (uint64_t)d.n0 * ((d.n1 + 63) / 64) * ((d.n2 + 63) / 64));
     k_transpose12<<<tgrid, 256>>>(G2, G, d.n0, d.n1, d.n2);                 // G = [n0][n2][n1]
     Dims dt = {d.n0, d.n2, d.n1};
-    k_edt_envelope<<<grid_for((uint64_t)d.n0 * d.n1), TPB>>>(G, G2, (uint32_t*)S, T, dt, 1);
+    k_edt_envelope<<<grid_for((uint64_t)d.n0 * d.n1), TPB>>>(G, G2, SP, dt);
     k_transpose12<<<tgrid, 256>>>(G2, G, d.n0, d.n2, d.n1);                 // back to [n0][n1][n2]
-    VM_TRY(hipGetLastError());
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(G2); (void)hipFree(SP);
+    if (e != hipSuccess) { g_err = std::string("EDT kernels: ") + hipGetErrorString(e); return VRG_E_INTERNAL; }
     return VRG_OK;
 }
 
@@ -296,10 +349,9 @@ int check(int device, int64_t n0, int64_t n1, int64_t n2, Dims& d) {
 template <class T> int vessel_mask_impl(const uint8_t* dbrain, const T* dves, Dims d, double edt_max, double frac1, double frac2,
                                         int64_t min_size, uint8_t* dout, int64_t* kept) {
     size_t V = (size_t)d.n0 * d.n1 * d.n2;
-    int32_t *G = nullptr, *G2 = nullptr, *S = nullptr, *Tt = nullptr;
-    VM_TRY(hipMalloc(&G, V * 4)); VM_TRY(hipMalloc(&G2, V * 4)); VM_TRY(hipMalloc(&S, V * 4)); VM_TRY(hipMalloc(&Tt, V * 4));
-    int rc = edt_squared(dbrain, d, G, G2, S, Tt);                 // distance_transform_edt(brainVolumeMask) :183
-    (void)hipFree(G2); (void)hipFree(S); (void)hipFree(Tt);
+    int32_t* G = nullptr;
+    VM_TRY(hipMalloc(&G, V * 4));
+    int rc = edt_squared(dbrain, d, G);                            // distance_transform_edt(brainVolumeMask) :183
     if (rc) { (void)hipFree(G); return rc; }
     const int nb = 1024;
     T* mm = nullptr;
@@ -344,10 +396,9 @@ int vmask_edt(int device, const uint8_t* mask, int64_t n0, int64_t n1, int64_t n
     const uint8_t* dm; void* own;
     rc = stage(mask, V, &dm, &own);
     if (rc) return rc;
-    int32_t *G = nullptr, *G2 = nullptr, *S = nullptr, *T = nullptr; double* dout = nullptr;
-    VM_TRY(hipMalloc(&G, V * 4)); VM_TRY(hipMalloc(&G2, V * 4)); VM_TRY(hipMalloc(&S, V * 4)); VM_TRY(hipMalloc(&T, V * 4));
-    rc = edt_squared(dm, d, G, G2, S, T);
-    (void)hipFree(G2); (void)hipFree(S); (void)hipFree(T);
+    int32_t* G = nullptr; double* dout = nullptr;
+    VM_TRY(hipMalloc(&G, V * 4));
+    rc = edt_squared(dm, d, G);
     if (!rc) {
         bool od = is_dev(out);
         if (od) dout = out; else VM_TRY(hipMalloc(&dout, V * 8));
