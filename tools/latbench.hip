@@ -72,5 +72,29 @@ int main() {
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         printf("20 dependent empty kernels: %.2f us each\n", ms * 1000 / 20);
     }
+    // the same chain as kernel nodes of a captured hipGraph (does a graph shorten the dependent-dispatch gap?)
+    {
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        for (int i = 0; i < 200; i++) empty<<<1, 64, 0, st>>>(nullptr);
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int r = 0; r < 4; r++) {
+            hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+            CK(hipEventRecord(a, st));
+            CK(hipGraphLaunch(ge, st));
+            CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b));
+            printf("graph of 200 dependent empty kernels: %.2f us each\n", ms * 1000 / 200);
+        }
+        for (int r = 0; r < 3; r++) {
+            hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+            CK(hipEventRecord(a, st));
+            for (int i = 0; i < 200; i++) empty<<<1, 64, 0, st>>>(nullptr);
+            CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b));
+            printf("200 dependent empty kernels, plain launches: %.2f us each\n", ms * 1000 / 200);
+        }
+    }
     return 0;
 }
