@@ -205,6 +205,7 @@ def main():
     ap.add_argument('--events', type=int, default=4, help='HIP events around every n-th dense launch (they cost the dense stream '
                     'a few us each); 0: none (no roofline then)')
     ap.add_argument('--skip-excluded', type=int, default=1, help='0: the dense pass fetches the intensities of excluded voxels too')
+    ap.add_argument('--no-brain-mask', action='store_true', help='experiment: no excluded voxels (the dense pass then has nothing to skip)')
     ap.add_argument('--serial', type=int, default=0, help='1: option serial_streams (needed under rocprofv3 --pmc, which runs one kernel at a time)')
     ap.add_argument('--storage16', action='store_true', help='16-bit intensity storage (level indices): config 5 style; 4 B/voxel-iter algorithmic')
     ap.add_argument('--force-dist', action='store_true', help='use the N>1 code path (RCCL comm) even with one rank')
@@ -241,7 +242,7 @@ def main():
         return
 
     from arterynetwork_amd._capi import Session
-    I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels)
+    I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels, brain_mask=not args.no_brain_mask)
     torch.cuda.synchronize()
     V = shape[0] * shape[1] * shape[2]
     s = Session(shape, device=local_rank)
