@@ -66,7 +66,7 @@ namespace {
 
 constexpr int TPB = 256;            // 4 waves of 64
 constexpr int ITEM_BLOCKS = 256;    // item kernels: 64 Ki threads, grid-stride
-constexpr int EXACT_BLOCKS = 128;   // k_band: workgroups for the exact densities (512 waves)
+constexpr int EXACT_BLOCKS = 512;   // k_band: workgroups for the exact densities (one pending slot per workgroup at a time)
 constexpr int SWEEP_BLOCKS = 256;   // 1 workgroup (4 waves) per CU, each wave with 3 KiB of labels + 12 KiB of intensities in
                                     // flight: measured best for the HBM-bound recount while stream B's band kernels run beside
                                     // it (880x880x640: 256 -> 0.38 ms, 192/384 -> 0.42-0.43, 320 -> 0.49, 512 -> 0.40, 1024 -> 0.44)
@@ -112,12 +112,15 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
 // exact densities (:152-155, :252-255): one wave per pending slot, lanes stride over the levels.  The level table
 // (the same for every entry) is fetched first, four levels per lane at a time, so that it travels together with
 // the entry's own look-ups instead of behind them.  The wave that computed an entry's densities decides it.
+// Every lane sums its levels (lane, lane + 64, ...) in ascending order whatever the batching - the order of the
+// additions, and so the result, does not depend on EXQ.
+constexpr int EXQ = 8;      // levels per lane fetched together: 512 per wave and batch
 __device__ void exact_wave(const VrgCtx& c, const VrgState& s, uint32_t nfresh, uint32_t wid, uint32_t nw, bool then_decide) {
     const int lane = threadIdx.x & 63;
     if (wid >= nfresh) return;
-    int32_t ha[4], hb[4]; double lv[4];
+    int32_t ha[EXQ], hb[EXQ]; double lv[EXQ];      // the first batch stays in registers for every entry of this wave
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < EXQ; q++) {
         uint32_t l = lane + 64u * q;
         bool in = l < c.L;
         ha[q] = in ? c.hin[l] : 0; hb[q] = in ? c.hout[l] : 0; lv[q] = in ? c.lev[l] : 0.0;
@@ -126,16 +129,25 @@ __device__ void exact_wave(const VrgCtx& c, const VrgState& s, uint32_t nfresh, 
         const uint32_t slot = c.fresh[f];
         double v = c.lev[c.p_lev[slot]], si = 0, so = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < EXQ; q++) {
             if (!(ha[q] | hb[q])) continue;
             double k = vrg_kern(c, lv[q] - v);
             si += (double)ha[q] * k; so += (double)hb[q] * k;
         }
-        for (uint32_t l = lane + 256u; l < c.L; l += 64) {
-            int32_t a = c.hin[l], bb = c.hout[l];
-            if (!(a | bb)) continue;
-            double k = vrg_kern(c, c.lev[l] - v);
-            si += (double)a * k; so += (double)bb * k;
+        for (uint32_t l0 = 64u * EXQ; l0 < c.L; l0 += 64u * EXQ) {     // (one round trip per batch, not per level)
+            int32_t a[EXQ], bb[EXQ]; double x[EXQ];
+#pragma unroll
+            for (int q = 0; q < EXQ; q++) {
+                const uint32_t l = l0 + lane + 64u * q;
+                const bool in = l < c.L;
+                a[q] = in ? c.hin[l] : 0; bb[q] = in ? c.hout[l] : 0; x[q] = in ? c.lev[l] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < EXQ; q++) {
+                if (!(a[q] | bb[q])) continue;
+                double k = vrg_kern(c, x[q] - v);
+                si += (double)a[q] * k; so += (double)bb[q] * k;
+            }
         }
         si = wave_sum(si); so = wave_sum(so);
         if (lane == 0) {
@@ -145,20 +157,72 @@ __device__ void exact_wave(const VrgCtx& c, const VrgState& s, uint32_t nfresh, 
         }
     }
 }
+// The same for the few hundred slots a sweep adds: one WORKGROUP per pending slot, its four waves taking every fourth
+// batch of 512 levels (with a wave per slot most of the chip idles while each wave walks the whole table: 38 us of
+// k_band at 6111 levels).  Wave partial sums are added in the order 0..3; a table of <= 512 levels is wave 0's alone,
+// which then makes exactly exact_wave's additions.
+__device__ void exact_wg(const VrgCtx& c, const VrgState& s, uint32_t nfresh, uint32_t wg, uint32_t nwg) {
+    __shared__ double sh_i[TPB / 64], sh_o[TPB / 64];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr uint32_t NWV = TPB / 64, BATCH = 64u * EXQ;
+    if (wg >= nfresh) return;
+    int32_t ha[EXQ], hb[EXQ]; double lv[EXQ];      // this wave's first batch stays in registers for every slot
+#pragma unroll
+    for (int q = 0; q < EXQ; q++) {
+        uint32_t l = BATCH * wv + lane + 64u * q;
+        bool in = l < c.L;
+        ha[q] = in ? c.hin[l] : 0; hb[q] = in ? c.hout[l] : 0; lv[q] = in ? c.lev[l] : 0.0;
+    }
+    for (uint32_t f = wg; f < nfresh; f += nwg) {
+        const uint32_t slot = c.fresh[f];
+        double v = c.lev[c.p_lev[slot]], si = 0, so = 0;
+#pragma unroll
+        for (int q = 0; q < EXQ; q++) {
+            if (!(ha[q] | hb[q])) continue;
+            double k = vrg_kern(c, lv[q] - v);
+            si += (double)ha[q] * k; so += (double)hb[q] * k;
+        }
+        for (uint32_t l0 = BATCH * (wv + NWV); l0 < c.L; l0 += BATCH * NWV) {
+            int32_t a[EXQ], bb[EXQ]; double x[EXQ];
+#pragma unroll
+            for (int q = 0; q < EXQ; q++) {
+                const uint32_t l = l0 + lane + 64u * q;
+                const bool in = l < c.L;
+                a[q] = in ? c.hin[l] : 0; bb[q] = in ? c.hout[l] : 0; x[q] = in ? c.lev[l] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < EXQ; q++) {
+                if (!(a[q] | bb[q])) continue;
+                double k = vrg_kern(c, x[q] - v);
+                si += (double)a[q] * k; so += (double)bb[q] * k;
+            }
+        }
+        si = wave_sum(si); so = wave_sum(so);
+        if (lane == 0) { sh_i[wv] = si; sh_o[wv] = so; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            si = sh_i[0]; so = sh_o[0];
+            for (uint32_t w = 1; w < NWV; w++) { si += sh_i[w]; so += sh_o[w]; }
+            c.p_ip[slot] = si; c.p_op[slot] = so;        // (the pending flag is cleared by the slot's own thread in the other half)
+            if (s.iter < s.iterMax)                      // while iterNum <= iterMax (:58)
+                vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot]);
+        }
+        __syncthreads();
+    }
+}
 // First kernel of a trip.  Workgroups [0, BAND_BLOCKS): the pool slots - correction of the sweep before, then the sign
 // test; a flip is appended to the unordered flip list.  When the correction is evaluated entry by entry from the
 // touched-level list (staged in LDS when it fits), LPE lanes share one slot: each sums every LPE-th level (nnz f64
 // exp per entry is what this kernel costs), a fixed butterfly adds the partial sums.  With the per-level memo (or
 // nothing to correct) it is one thread per slot.  Workgroups [BAND_BLOCKS, +EXACT_BLOCKS): the exact densities of the
-// slots that (re-)entered the band in the sweep before, then their sign tests.
+// slots that (re-)entered the band in the sweep before, then their sign tests (exact_wg).
 constexpr int BAND_BLOCKS = 1024;
 constexpr int LPE = 8;
 __global__ void __launch_bounds__(TPB) k_band(VrgCtx c) {
     const VrgState s = *c.st;                             // a copy (nf is only ever bumped atomically)
     if (s.done || s.bail) return;
     if (blockIdx.x >= BAND_BLOCKS) {
-        const uint32_t wid = ((blockIdx.x - BAND_BLOCKS) * TPB + threadIdx.x) >> 6, nw = (EXACT_BLOCKS * TPB) >> 6;
-        exact_wave(c, s, s.nfx, wid, nw, true);
+        exact_wg(c, s, s.nfx, blockIdx.x - BAND_BLOCKS, EXACT_BLOCKS);
         return;
     }
     const bool direct = s.corr && !s.use_tab;
@@ -209,7 +273,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c) {
 // over every pending entry; partial sums per (entry, workgroup) are added up in a fixed order by k_exact_sum, which
 // also decides the entry.  Host-driven trips only (the host has to know the number of pending entries).
 constexpr uint32_t XB_LEVELS = 2048;
-constexpr uint32_t EXACT_BIG_L = 32768;     // level tables beyond this take the route above
+constexpr uint32_t EXACT_BIG_L = 262144;    // level tables beyond this take the route above
 __global__ void __launch_bounds__(TPB) k_exact_big(VrgCtx c, uint32_t nfx, double* part, uint32_t nchunks) {
     __shared__ double sh[2][4];
     const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6, chunk = blockIdx.x;
