@@ -56,6 +56,8 @@ struct VrgBackend {
     int dense_pending = 0;                            // Z-slabs: recounts enqueued since the last staged all-reduce
     int serial = 0;                                   // option "serial_streams": see be_sweep_once
     int skip = 1;                                     // option "skip_excluded": the dense pass does not fetch the intensities of excluded voxels
+    uint32_t band_hint = 0;                           // pool slots in use when the engine last read the state (0: unknown)
+    int direct_hint = 1;                              // ... and whether corrections are then evaluated entry by entry (8 lanes per slot)
 };
 
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess && !b->err[0]) { \
@@ -216,18 +218,18 @@ __device__ void exact_wg(const VrgCtx& c, const VrgState& s, uint32_t nfresh, ui
 // exp per entry is what this kernel costs), a fixed butterfly adds the partial sums.  With the per-level memo (or
 // nothing to correct) it is one thread per slot.  Workgroups [BAND_BLOCKS, +EXACT_BLOCKS): the exact densities of the
 // slots that (re-)entered the band in the sweep before, then their sign tests (exact_wg).
-constexpr int BAND_BLOCKS = 1024;
+constexpr int BAND_BLOCKS = 1024;     // most workgroups k_band uses for the pool; fewer when the engine knows the pool is small (band_blocks())
 constexpr int LPE = 8;
-__global__ void __launch_bounds__(TPB) k_band(VrgCtx c) {
+__global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks) {
     const VrgState s = *c.st;                             // a copy (nf is only ever bumped atomically)
     if (s.done || s.bail) return;
-    if (blockIdx.x >= BAND_BLOCKS) {
-        exact_wg(c, s, s.nfx, blockIdx.x - BAND_BLOCKS, EXACT_BLOCKS);
+    if (blockIdx.x >= band_blocks) {
+        exact_wg(c, s, s.nfx, blockIdx.x - band_blocks, EXACT_BLOCKS);
         return;
     }
     const bool direct = s.corr && !s.use_tab;
     if (!direct) {
-        for (uint32_t slot = blockIdx.x * TPB + threadIdx.x; slot < s.np; slot += BAND_BLOCKS * TPB)
+        for (uint32_t slot = blockIdx.x * TPB + threadIdx.x; slot < s.np; slot += band_blocks * TPB)
             vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv);
         return;
     }
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c) {
     }
     const uint32_t sub = threadIdx.x & (LPE - 1);
     const uint32_t np_pad = (s.np + (TPB / LPE) - 1) / (TPB / LPE) * (TPB / LPE);      // whole waves stay in the loop together
-    for (uint32_t slot = (blockIdx.x * TPB + threadIdx.x) / LPE; slot < np_pad; slot += BAND_BLOCKS * TPB / LPE) {
+    for (uint32_t slot = (blockIdx.x * TPB + threadIdx.x) / LPE; slot < np_pad; slot += band_blocks * TPB / LPE) {
         uint8_t fl = 0; double ip = 0, op = 0, v = 0; uint32_t lev = 0;
         const bool live = slot < s.np;
         if (live) { fl = c.p_flag[slot]; ip = c.p_ip[slot]; op = c.p_op[slot]; lev = c.p_lev[slot]; }   // one batch
@@ -1147,6 +1149,15 @@ int voxel_blocks(const VrgCtx& c) {
 }
 
 // workgroups of the dense recount: >= 32 one-KiB units per wave, at most 1 workgroup per CU
+// Workgroups k_band gets for the pool.  Its loops are grid-stride, so any number is correct; beside a recount only two
+// of its waves fit on a SIMD, and 1024 workgroups of which 800 find nothing to do then cost it two extra rounds.  The
+// pool can grow by at most a few thousand slots within a batch of trips: 1.5 x the last known size leaves room.
+uint32_t band_blocks(const VrgBackend* b) {
+    if (!b->band_hint) return BAND_BLOCKS;
+    const uint64_t threads = ((uint64_t)b->band_hint * 3 / 2 + 4096) * (b->direct_hint ? LPE : 1);
+    return (uint32_t)std::min<uint64_t>(BAND_BLOCKS, std::max<uint64_t>(32, (threads + TPB - 1) / TPB));
+}
+
 int dense_blocks(const VrgBackend* b, const VrgCtx& c) {
     if (b->sweep_blocks > 0) return b->sweep_blocks;
     uint64_t units = ((uint64_t)(c.z1 - c.z0) * c.PY * c.PX) >> 10;
@@ -1218,6 +1229,8 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "sweep_blocks") == 0 && v >= 0 && v <= 4096) b->sweep_blocks = (int)v;
     if (std::strcmp(name, "serial_streams") == 0) b->serial = v != 0;
     if (std::strcmp(name, "skip_excluded") == 0) b->skip = v != 0;
+    if (std::strcmp(name, "band_hint") == 0) b->band_hint = (uint32_t)std::min<long long>(std::max<long long>(v, 0), 0x7fffffff);
+    if (std::strcmp(name, "direct_hint") == 0) b->direct_hint = v != 0;
     if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)std::min<long long>(v, NF_SMALL);
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != b->prio_mode) { b->prio_mode = (int)v; make_streams(b); }
 }
@@ -1518,7 +1531,8 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
             k_exact_done<<<1, 1, 0, b->sa>>>(c);
         }
     }
-    k_band<<<BAND_BLOCKS + EXACT_BLOCKS, TPB, 0, b->sa>>>(c);
+    const uint32_t nbb = band_blocks(b);
+    k_band<<<nbb + EXACT_BLOCKS, TPB, 0, b->sa>>>(c, nbb);
     if (flags & VRG_SWEEP_SYNC) {
         VrgState s;
         HIP_CHECK(hipMemcpyAsync(&s, c.st, sizeof(s), hipMemcpyDeviceToHost, b->sa));

@@ -82,7 +82,13 @@ VrgDense get_dense(vrg_handle* h) {     // region sizes as the band side keeps t
     d.n_in = (double)n[0]; d.n_out = (double)n[1];
     return d;
 }
-VrgState get_state(vrg_handle* h) { VrgState s; be_download(h->be, &s, h->c.st, sizeof(s)); return s; }
+// (every read of the state also tells the backend how large the pool is: it sizes k_band's grid by it)
+VrgState get_state(vrg_handle* h) {
+    VrgState s; be_download(h->be, &s, h->c.st, sizeof(s));
+    be_set_tuning(h->be, "band_hint", s.np);
+    be_set_tuning(h->be, "direct_hint", (uint64_t)h->c.L > (uint64_t)s.ni + s.no);
+    return s;
+}
 void put_state(vrg_handle* h, const VrgState& s) {
     be_upload(h->be, h->c.st, &s, sizeof(s));
     const int64_t stop = (s.done || s.bail) ? 1 : 0;       // the dense side's copy of "stopped / handed back"
