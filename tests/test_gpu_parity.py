@@ -485,6 +485,31 @@ def test_skip_excluded_is_bit_identical(lib):
         assert outs[1][3] == dense_bytes_by_definition(outs[1][0], line) <= streamed + 512
 
 
+def test_dense_pass_event_sampling(lib):
+    """Option events = n: the dense pass of every n-th sweep of a batch is timed (vrg_result.sweep_kernel_ms over
+    sweep_launches launches); 0 times nothing.  Results do not depend on it."""
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session
+    d, v = phantoms.bench_volume((96, 80, 64), seed=6)
+    traces = []
+    for every, batch in ((0, 8), (1, 8), (4, 8), (3, 5)):
+        s = Session(d.shape, lib=lib)
+        s.set_option('events', every); s.set_option('batch', batch)
+        s.set_volume(d); s.set_labels(v.astype(np.uint8)); s.init(2.25)
+        r = s.run(24, 10 ** 9, None)
+        assert r.sweeps == 24
+        if every == 0:
+            assert r.sweep_launches == 0 and r.sweep_kernel_ms == 0
+        else:
+            # batches of `batch` trips (the last one carries the trip that finds the stop flag): every n-th trip of each
+            want = sum(len(range(0, min(batch, 24 - b0), every)) for b0 in range(0, 24, batch))
+            assert abs(r.sweep_launches - want) <= 1 and r.sweep_kernel_ms > 0
+            assert 0.001 < r.sweep_kernel_ms / r.sweep_launches < 5.0
+        traces.append(s.trace().tobytes())
+        s.close()
+    assert all(t == traces[0] for t in traces)
+
+
 def test_host_driven_and_one_workgroup_sweeps_identical(lib, golden_loader):
     """update() as the three batched kernels (k_order / k_mark_relabel / k_close) and as host-driven device-wide kernels
     (sweeps with more flips than "small_flips"; rocPRIM sorts) must give the same state; so must arrays that start tiny
