@@ -51,6 +51,8 @@ VRG_HD uint8_t vrg_load_coherent(const uint8_t* p) {
 VRG_HD uint32_t vrg_load_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 VRG_HD int32_t vrg_load_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 VRG_HD int64_t vrg_load_i64(const int64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the error word is written through: another workgroup of the SAME kernel may be the one that reads it (k_close)
+VRG_HD void vrg_store_i32(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #elif defined(VRG_HOSTMODEL)
 // tests/hostmodel only (sequential test model of the kernels; never part of the product library)
 VRG_HD uint32_t vrg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
@@ -62,6 +64,7 @@ VRG_HD uint8_t vrg_load_coherent(const uint8_t* p) { return *(const volatile uin
 VRG_HD uint32_t vrg_load_u32(const uint32_t* p) { return *p; }
 VRG_HD int32_t vrg_load_i32(const int32_t* p) { return *p; }
 VRG_HD int64_t vrg_load_i64(const int64_t* p) { return *p; }
+VRG_HD void vrg_store_i32(int32_t* p, int32_t v) { *p = v; }
 #else
 // host pass of the product build (hipcc compiles __host__ __device__ functions for both sides): the product has no CPU
 // path - the item functions are never called on the host there, and if one ever were it stops right here
@@ -74,6 +77,7 @@ VRG_HD uint8_t vrg_load_coherent(const uint8_t*) { __builtin_trap(); }
 VRG_HD uint32_t vrg_load_u32(const uint32_t*) { __builtin_trap(); }
 VRG_HD int32_t vrg_load_i32(const int32_t*) { __builtin_trap(); }
 VRG_HD int64_t vrg_load_i64(const int64_t*) { __builtin_trap(); }
+VRG_HD void vrg_store_i32(int32_t*, int32_t) { __builtin_trap(); }
 #endif
 
 // OR bits into one label byte without disturbing concurrent ORs into its neighbours
@@ -571,7 +575,7 @@ VRG_HD void vrg_count_change(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t
     const uint32_t x = (a ^ b) << sh;
     vrg_atomic_xor(&c.clsb[p][dw], x);
     uint32_t q = vrg_atomic_add(&c.nchg[p], 1u);
-    if (q < c.mcap) { c.chg_dw[p][q] = dw; c.chg_x[p][q] = x; } else c.st->error = 7;
+    if (q < c.mcap) { c.chg_dw[p][q] = dw; c.chg_x[p][q] = x; } else vrg_store_i32(&c.st->error, 7);
     int din = (int)(b == 1u) - (int)(a == 1u), dout = (int)(b == 2u) - (int)(a == 2u);
     if (din) vrg_atomic_add64(&c.inc[VC_NIN], din);
     if (dout) vrg_atomic_add64(&c.inc[VC_NOUT], dout);
@@ -665,7 +669,7 @@ VRG_HD void vrg_item_level(const VrgCtx& c, uint32_t j, bool clear) {
     if (clear) vrg_item_level_clear(c, j);
 }
 // a listed flip the relabel never visited would be an internal error
-VRG_HD void vrg_item_check_flip(const VrgCtx& c, uint32_t r) { if (!(c.f_res[r] & FR_WRITTEN)) c.st->error = 3; }
+VRG_HD void vrg_item_check_flip(const VrgCtx& c, uint32_t r) { if (!(c.f_res[r] & FR_WRITTEN)) vrg_store_i32(&c.st->error, 3); }
 // iterNum += 1 (:117), list lengths, free list, trace record; what the next k_band finds pending
 VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
     VrgState s = *c.st;                               // one round trip for the whole state, one to write it back
