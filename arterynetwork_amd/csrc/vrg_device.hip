@@ -220,21 +220,41 @@ __device__ void exact_wg(const VrgCtx& c, const VrgState& s, uint32_t nfresh, ui
 // slots that (re-)entered the band in the sweep before, then their sign tests (exact_wg).
 constexpr int BAND_BLOCKS = 1024;     // most workgroups k_band uses for the pool; fewer when the engine knows the pool is small (band_blocks())
 constexpr int LPE = 8;
+constexpr uint32_t TAB_LDS = 832;     // levels whose memo entries k_band stages in LDS (the room of the entry-by-entry path's arrays)
 __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks) {
+    // One LDS block, two uses: the touched-level list (entry-by-entry corrections) or the head of the per-level memo.
+    __shared__ double s_raw[NZ_LDS + NZ_LDS * 3 / 2];
+    double* s_val = s_raw;
+    uint32_t* s_cin = reinterpret_cast<uint32_t*>(s_raw + NZ_LDS); uint32_t* s_cout = s_cin + NZ_LDS; uint32_t* s_cconv = s_cout + NZ_LDS;
+    static_assert(3 * TAB_LDS <= NZ_LDS + NZ_LDS * 3 / 2, "memo head must fit the block");
+    // The kernel is a chain of dependent round trips (state -> slot fields -> memo entry -> flip counter), each of which
+    // takes 2-3 x longer beside a recount.  The pool workgroups therefore fetch, together with the state, what the first
+    // slot of every thread will need: its fields (any slot below the capacity is readable) and the head of the memo.
+    const bool pool_wg = blockIdx.x < band_blocks;
+    const uint32_t slot0 = blockIdx.x * TPB + threadIdx.x;
+    uint8_t fl0 = 0; double ip0 = 0, op0 = 0; uint32_t lev0 = 0, idx0 = 0; uint64_t key0 = 0; int64_t nin0 = 0, nout0 = 0;
+    const uint32_t tab_n = c.L < TAB_LDS ? c.L : TAB_LDS;
+    if (pool_wg) {
+        if (slot0 < c.bcap) { fl0 = c.p_flag[slot0]; ip0 = c.p_ip[slot0]; op0 = c.p_op[slot0]; lev0 = c.p_lev[slot0]; idx0 = c.p_idx[slot0]; key0 = c.p_key[slot0]; }
+        nin0 = c.inc[VC_NIN]; nout0 = c.inc[VC_NOUT];
+        for (uint32_t j = threadIdx.x; j < 3 * tab_n; j += TPB) s_raw[j] = c.tabC[j];
+    }
     const VrgState s = *c.st;                             // a copy (nf is only ever bumped atomically)
     if (s.done || s.bail) return;
-    if (blockIdx.x >= band_blocks) {
+    if (!pool_wg) {
         exact_wg(c, s, s.nfx, blockIdx.x - band_blocks, EXACT_BLOCKS);
         return;
     }
     const bool direct = s.corr && !s.use_tab;
     if (!direct) {
-        for (uint32_t slot = blockIdx.x * TPB + threadIdx.x; slot < s.np; slot += band_blocks * TPB)
-            vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv);
+        __syncthreads();                                  // (the memo head is in LDS)
+        if (slot0 < s.np)
+            vrg_item_band_fields(c, s, slot0, fl0, ip0, op0, lev0, idx0, key0, nin0, nout0, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n);
+        for (uint32_t slot = slot0 + band_blocks * TPB; slot < s.np; slot += band_blocks * TPB)
+            vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n);
         return;
     }
-    __shared__ double s_val[NZ_LDS];
-    __shared__ uint32_t s_cin[NZ_LDS], s_cout[NZ_LDS], s_cconv[NZ_LDS];
+    __syncthreads();                                      // (everyone is done staging the memo head: the block changes hands)
     const double* nzv = c.nz_val; const uint32_t* nzi = c.nz_cin; const uint32_t* nzo = c.nz_cout; const uint32_t* nzc = c.nz_cconv;
     if (s.nnz <= NZ_LDS) {
         for (uint32_t j = threadIdx.x; j < s.nnz; j += TPB) { s_val[j] = c.nz_val[j]; s_cin[j] = c.nz_cin[j]; s_cout[j] = c.nz_cout[j]; s_cconv[j] = c.nz_cconv[j]; }
@@ -426,6 +446,9 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
     __shared__ int s_go, s_changed;
     constexpr uint32_t T = KO_THREADS;
     const uint32_t t = threadIdx.x;
+    // (this thread's first flip record travels with the state: k_band has appended it, whatever the state says)
+    uint64_t k0 = 0; uint32_t rs0 = 0, ri0 = 0, rl0 = 0;
+    if (t < c.fcap) { k0 = c.f_key[t]; rs0 = c.flist[t]; ri0 = c.fr_idx[t]; rl0 = c.fr_lev[t]; }
     if (c.st->done || c.st->bail) return;
     if (t == 0) {
         int go = 1;
@@ -443,10 +466,14 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
     const uint32_t nf = c.st->nf;
     for (uint32_t j = t, n = c.st->nnz; j < n; j += T) vrg_item_level_clear(c, j);   // level counters of the sweep before
     // the flips' records as k_band appended them; sorted by key, the payload being the record's number
-    for (uint32_t q = t; q < nf; q += T) { s_key[q] = c.f_key[q]; s_slot[q] = q; }
+    if (t < nf) { s_key[t] = k0; s_slot[t] = t; }
+    for (uint32_t q = t + T; q < nf; q += T) { s_key[q] = c.f_key[q]; s_slot[q] = q; }
     // (a short list - the usual case - keeps the rest of every record in LDS too: no dependent look-up after the sort)
     const bool rec_lds = nf <= REC_LDS;
-    if (rec_lds) for (uint32_t q = t; q < nf; q += T) { s_rslot[q] = c.flist[q]; s_ridx[q] = c.fr_idx[q]; s_rlev[q] = c.fr_lev[q]; }
+    if (rec_lds) {
+        if (t < nf) { s_rslot[t] = rs0; s_ridx[t] = ri0; s_rlev[t] = rl0; }
+        for (uint32_t q = t + T; q < nf; q += T) { s_rslot[q] = c.flist[q]; s_ridx[q] = c.fr_idx[q]; s_rlev[q] = c.fr_lev[q]; }
+    }
     __syncthreads();
     if (t == 0) vrg_open_update(c);
     wg_sort_pairs(s_key, s_slot, nf, true);
@@ -474,8 +501,13 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
 
 constexpr uint32_t LEV_LDS = 2048;  // level values a workgroup of k_mark_relabel keeps in LDS
 __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
-    if (cg.st->done || cg.st->bail) return;
+    // (the flip voxel of this thread's first item travels with the state: k_order has written the list, whatever the state says)
+    const uint32_t r_first = (uint32_t)(((uint64_t)blockIdx.x * TPB + threadIdx.x) >> 7);
+    const uint32_t fidx_first = r_first < cg.fcap ? cg.f_idx[r_first] : 0u;
+    const int32_t st_done = cg.st->done, st_bail = cg.st->bail;
     const uint32_t nf = cg.st->nf, lane = threadIdx.x & 63;
+    asm volatile("" :: "v"(fidx_first), "v"(st_done), "v"(st_bail), "v"(nf));     // one wait for the four
+    if (st_done || st_bail) return;
     const uint64_t n = (uint64_t)nf * 128u;
     if ((uint64_t)blockIdx.x * TPB >= n) return;                          // (no item for this workgroup)
     // a voxel that enters the band needs the level index of its intensity: a binary search, i.e. log2(L) DEPENDENT loads -
@@ -500,7 +532,7 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
         int64_t m = 0; uint8_t mb = VB_OOB;
         VrgPre pre;
         if (i < n && p < 125u) {
-            m = vrg_mark_pos(c, c.f_idx[r], p);
+            m = vrg_mark_pos(c, base == (uint64_t)blockIdx.x * TPB ? fidx_first : c.f_idx[r], p);
             mb = lab[m];
             // everything the stencil would read at this voxel, fetched NOW, together with its byte and before it is known
             // whether this thread will run the stencil: one round trip instead of four dependent ones.  (A position
@@ -552,9 +584,13 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
 // device-scope atomics / write-through stores) files the sizes, asks for the dense pass and closes the sweep.
 constexpr int CLOSE_APPLY = 8;
 __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
-    if (c.st->done || c.st->bail) return;              // (the same for every workgroup: the state is written by the last one to finish)
     constexpr uint32_t T = KC_THREADS;
     const uint32_t t = threadIdx.x;
+    // (what a thread's first item needs travels with the state: the lists are complete, whatever the state says)
+    uint32_t mk0 = 0; uint8_t mn0 = 0; uint64_t zk0 = 0;
+    if (blockIdx.x < CLOSE_APPLY) { const uint32_t g0 = blockIdx.x * T + t; if (g0 < c.mcap) { mk0 = c.mk_idx[g0]; mn0 = c.mk_new[g0]; } }
+    else if (t < c.zcap) zk0 = c.nz_key[t];
+    if (c.st->done || c.st->bail) return;              // (the same for every workgroup: the state is written by the last one to finish)
     __shared__ uint64_t s_key[NZ_SORT];
     __shared__ double s_val[NZ_SORT];
     __shared__ uint32_t s_cin[NZ_SORT], s_cout[NZ_SORT], s_cconv[NZ_SORT];
@@ -566,7 +602,8 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
         __syncthreads();
         const uint32_t g = blockIdx.x * T + t, G = CLOSE_APPLY * T;
         const uint32_t nmk = min(c.st->nmk, c.mcap), nf = c.st->nf;
-        for (uint32_t i = g; i < nmk; i += G) vrg_item_apply(c, i);
+        if (g < nmk) vrg_apply_voxel(c, mk0, vrg_load_coherent(c.lab[0] + mk0), mn0);
+        for (uint32_t i = g + G; i < nmk; i += G) vrg_item_apply(c, i);
         for (uint32_t i = g, nc = vrg_catchup_count(c); i < nc; i += G) vrg_item_catchup(c, i);
         for (uint32_t r = g; r < nf; r += G) vrg_item_check_flip(c, r);
         for (uint32_t j = g, nd = c.st->ndead; j < nd; j += G) vrg_item_free(c, j);
@@ -577,7 +614,8 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
         }
     } else if (nnz <= NZ_SORT && (use_tab || blockIdx.x == CLOSE_APPLY)) {
         // this sweep's touched levels in ascending order (a fixed summation order), with their counts
-        for (uint32_t j = t; j < nnz; j += T) s_key[j] = c.nz_key[j];
+        if (t < nnz) s_key[t] = zk0;
+        for (uint32_t j = t + T; j < nnz; j += T) s_key[j] = c.nz_key[j];
         __syncthreads();
         wg_sort_pairs(s_key, (uint32_t*)nullptr, nnz, false);
         for (uint32_t j = t; j < nnz; j += T) {

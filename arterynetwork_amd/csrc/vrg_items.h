@@ -232,27 +232,36 @@ VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, int64_t n_in, in
     if (q >= c.fcap) { c.st->error = 2; return; }
     c.flist[q] = slot; c.f_key[q] = vrg_flip_key(inner, key); c.fr_idx[q] = idx; c.fr_lev[q] = lev;
 }
-// one pool slot; nz_* = this trip's view of the touched-level list (LDS copy on the device)
-VRG_HD void vrg_item_band(const VrgCtx& c, const VrgState& s, uint32_t slot, const double* nz_val, const uint32_t* nz_cin,
-                          const uint32_t* nz_cout, const uint32_t* nz_cconv) {
-    // the slot's fields in one batch (a dead slot's are read for nothing): the kernel is bound by dependent loads
-    const uint8_t fl = c.p_flag[slot];
-    double ip = c.p_ip[slot], op = c.p_op[slot];
-    const uint32_t lev = c.p_lev[slot], idx = c.p_idx[slot];
-    const uint64_t key = c.p_key[slot];
-    const int64_t n_in = c.inc[VC_NIN], n_out = c.inc[VC_NOUT];
+// one pool slot whose fields the caller has fetched; nz_* = this trip's view of the touched-level list (LDS copy on the
+// device), tab = the per-level memo (the device may pass an LDS copy of its first tab_n levels; the rest comes from c.tabC)
+VRG_HD void vrg_item_band_fields(const VrgCtx& c, const VrgState& s, uint32_t slot, uint8_t fl, double ip, double op, uint32_t lev, uint32_t idx,
+                                 uint64_t key, int64_t n_in, int64_t n_out, const double* nz_val, const uint32_t* nz_cin,
+                                 const uint32_t* nz_cout, const uint32_t* nz_cconv, const double* tab, uint32_t tab_n) {
     if (!(fl & PF_ALIVE)) return;
     // an entry that (re-)entered the band in the sweep before takes no correction; it is decided by whoever computes
     // its exact densities (the other half of this launch, which reads only the list bit of the flag)
     if (fl & PF_PEND) { c.p_flag[slot] = (uint8_t)(fl & ~PF_PEND); return; }
     if (s.corr) {
         double ic, oc, ac;
-        if (s.use_tab) { ic = c.tabC[3 * (size_t)lev]; oc = c.tabC[3 * (size_t)lev + 1]; ac = c.tabC[3 * (size_t)lev + 2]; }
+        if (s.use_tab) {
+            const double* t3 = lev < tab_n ? tab + 3 * (size_t)lev : c.tabC + 3 * (size_t)lev;
+            ic = t3[0]; oc = t3[1]; ac = t3[2];
+        }
         else vrg_corrections(c, s.nnz, nz_val, nz_cin, nz_cout, nz_cconv, c.lev[lev], ic, oc, ac);
         vrg_add_correction(ic, oc, ac, ip, op);
         c.p_ip[slot] = ip; c.p_op[slot] = op;
     }
     if (s.iter < s.iterMax) vrg_decide_core(c, s, n_in, n_out, slot, fl & PF_INNER, ip, op, key, idx, lev);   // while iterNum <= iterMax (:58)
+}
+VRG_HD void vrg_item_band(const VrgCtx& c, const VrgState& s, uint32_t slot, const double* nz_val, const uint32_t* nz_cin,
+                          const uint32_t* nz_cout, const uint32_t* nz_cconv, const double* tab = nullptr, uint32_t tab_n = 0) {
+    // the slot's fields in one batch (a dead slot's are read for nothing): the kernel is bound by dependent loads
+    const uint8_t fl = c.p_flag[slot];
+    const double ip = c.p_ip[slot], op = c.p_op[slot];
+    const uint32_t lev = c.p_lev[slot], idx = c.p_idx[slot];
+    const uint64_t key = c.p_key[slot];
+    const int64_t n_in = c.inc[VC_NIN], n_out = c.inc[VC_NOUT];
+    vrg_item_band_fields(c, s, slot, fl, ip, op, lev, idx, key, n_in, n_out, nz_val, nz_cin, nz_cout, nz_cconv, tab, tab_n);
 }
 // exact densities over the whole inner / outer regions (:152-155, :252-255), regrouped by level
 VRG_HD void vrg_exact_serial(const VrgCtx& c, const VrgState& s, uint32_t slot, bool then_decide) {
