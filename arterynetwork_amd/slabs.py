@@ -89,6 +89,7 @@ def bench_slabs(shape, args, dev, rank, world, roofline):
         s.set_option('sweep_blocks', args.sweep_blocks)
     s.set_option('events', 4)            # HIP events around every 4th dense launch
     s.set_option('batch', 64)
+    s.set_option('nt_loads', getattr(args, 'nt_loads', -1))
     s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
     s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
     s.init(args.H)

@@ -83,6 +83,8 @@ const char* vrg_last_error(const vrg_handle* h);
  *   "skip_excluded"  any time; 1 (default): the dense pass does not fetch the intensities of runs of excluded voxels
  *                    (label 4, as the reference's dataArray[mask] gathers :249-250 never touch them); 0: it streams
  *                    the whole slab.  Same sums bit for bit.
+ *   "nt_loads"       any time; -1 (default): the dense pass uses non-temporal loads when it fetches more than the
+ *                    Infinity Cache can keep (about 300 MB per pass) and ordinary loads below that; 0 / 1 force one
  *   "dense_off"      any time; measurement aid: the dense recount is not launched (the band chain alone);
  *                    the handle has to be initialised again afterwards
  *   "sweep_blocks", "prio_mode"
