@@ -296,7 +296,9 @@ def main():
                    'init_seconds': round(t_init, 3), 'nseg_start': int(tr['nseg'][args.warmup]),
                    'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
                    'flips_per_sweep_mean': round(float(tr['nflip'][args.warmup + 1:].mean()), 1),
-                   'dense_ms': round(kern_ms, 4), 'dense_events_every': args.events},
+                   'dense_ms': round(kern_ms, 4), 'dense_events_every': args.events,
+                   # (vrg.h option nt_loads: a pass of up to ~300 MB is read with ordinary loads and stays in the Infinity Cache)
+                   'dense_pass_loads': ('non-temporal' if (args.nt_loads == 1 or (args.nt_loads < 0 and db0 > (300 << 20))) else 'ordinary')},
         'roofline': roofline(shape, shape[2], kern_ms, int(r.sweep_launches), load_traffic(shape, 1, args.storage16), args.storage16, dense_bytes),
     }
     out['config']['engine'] = s.stats()                     # trips handed back to the host / array growth during the run
