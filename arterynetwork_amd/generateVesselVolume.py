@@ -54,6 +54,24 @@ def distance_transform_edt(mask, device=0):
     return out
 
 
+DISTANCE_CACHE = 'vesselVolumeDistanceTransform.npz'
+
+
+def vesselDistanceTransform(vesselVolume, directory=None, device=0):
+    """The vessel mask's distance transform as the reference's graph stage keeps it (manualCorrectionGUI.py:242-248,
+    SURVEY.md section 8 row f4): read from ``<directory>/vesselVolumeDistanceTransform.npz`` (key ``distanceTransform``)
+    when that file exists, otherwise computed on the GPU and written there.  A voxel's vessel radius is then a plain
+    look-up, ``distanceTransform[tuple(coords.T)]``."""
+    import os
+    path = os.path.join(directory, DISTANCE_CACHE) if directory is not None else None
+    if path is not None and os.path.exists(path):
+        return np.load(path)['distanceTransform']
+    dt = distance_transform_edt(vesselVolume, device=device)
+    if path is not None:
+        np.savez_compressed(path, distanceTransform=dt)
+    return dt
+
+
 def labelVolume(volume, minSize=1, maxHop=3, device=0):
     """
     Partition the volume into connected components and attach labels (generateVesselVolume.py:107-136).

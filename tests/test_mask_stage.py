@@ -95,6 +95,23 @@ def test_skeletoniser_export(tmp_path):
 
 
 @pytest.mark.gpu
+def test_vessel_distance_transform_cache(tmp_path):
+    """Row f4: the distance transform of the vessel mask under the reference's cache file name and key; radius look-up."""
+    from arterynetwork_amd.generateVesselVolume import vesselDistanceTransform, DISTANCE_CACHE
+    brain, ves = _volumes(3, (40, 36, 30))
+    mask = MO.vesselVolumeMask(brain, ves)
+    ref = MO.distance_transform_edt(mask)
+    dt = vesselDistanceTransform(mask, str(tmp_path))
+    assert np.array_equal(dt, ref)
+    z = np.load(os.path.join(str(tmp_path), DISTANCE_CACHE))
+    assert list(z.keys()) == ['distanceTransform'] and np.array_equal(z['distanceTransform'], ref)
+    again = vesselDistanceTransform(np.zeros_like(mask), str(tmp_path))          # (the cache wins, as in the reference)
+    assert np.array_equal(again, ref)
+    coords = np.argwhere(mask)[::50]
+    assert np.array_equal(dt[tuple(coords.T)], ref[tuple(coords.T)]) and (dt[tuple(coords.T)] >= 1).all()
+
+
+@pytest.mark.gpu
 def test_nifti_main_round_trip(tmp_path):
     from arterynetwork_amd import nifti, generateVesselVolume as G
     brain, ves = _volumes(7, (48, 40, 32))
