@@ -28,11 +28,12 @@ class Result(C.Structure):
     _fields_ = [('stop_reason', C.c_int32), ('iter_num', C.c_int32), ('sweeps', C.c_int64),
                 ('nseg', C.c_int64), ('n_in', C.c_int64), ('n_out', C.c_int64),
                 ('ni', C.c_int64), ('no', C.c_int64), ('sum_in', C.c_double), ('sum_out', C.c_double),
-                ('seconds', C.c_double), ('sweep_kernel_ms', C.c_double), ('sweep_launches', C.c_int64)]
+                ('seconds', C.c_double), ('sweep_kernel_ms', C.c_double), ('sweep_launches', C.c_int64),
+                ('ties', C.c_int64), ('near_ties', C.c_int64)]
 
 
 TRACE_DTYPE = np.dtype([('nflip', 'i8'), ('nseg', 'i8'), ('n_in', 'i8'), ('n_out', 'i8'),
-                        ('ni', 'i8'), ('no', 'i8'), ('sum_in', 'f8'), ('sum_out', 'f8')])
+                        ('ni', 'i8'), ('no', 'i8'), ('sum_in', 'f8'), ('sum_out', 'f8'), ('ties', 'i8'), ('near_ties', 'i8')])
 
 
 REDUCE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_void_p)

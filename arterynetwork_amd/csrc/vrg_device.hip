@@ -1098,7 +1098,8 @@ __global__ void k_fin_init(VrgCtx c) {
     const VrgDense& d = *c.dn;
     VrgTrace& t = c.trace[0];
     t.nflip = 0; t.nseg = (int64_t)d.n_in; t.n_in = (int64_t)d.n_in; t.n_out = (int64_t)d.n_out; t.ni = s.ni; t.no = s.no;
-    t.sum_in = d.sum_in; t.sum_out = d.sum_out;
+    t.sum_in = d.sum_in; t.sum_out = d.sum_out; t.ties = 0; t.near_ties = 0;
+    s.ties = 0; s.near_ties = 0; s.ties_filed = 0; s.near_filed = 0;
 }
 __global__ void k_recount_hist(VrgCtx c, int32_t* rin, int32_t* rout) {
     VOXEL_LOOP(c) {

@@ -348,6 +348,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     int rc = check_state_error(h, s);
     if (rc) return rc;
     int32_t iter0 = s.iter;
+    const uint32_t ties0 = s.ties, near0 = s.near_ties;
     s.done = 0; s.time_up = 0; s.bail = 0; s.iterMax = (int32_t)iterMax; s.maxSegmentSize = maxSegmentSize;
     s.nf = 0; s.npend = 0; s.nmk = 0;                    // counters of a trip that stopped before update()
     put_state(h, s);
@@ -372,6 +373,11 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
         if (s.bail) {                                // the trip was handed back untouched: make room / change mode, do it again
             const uint64_t nf = s.nf;
             h->bails[std::min(s.bail, 3)]++;
+            // The rest of the batch was enqueued behind the trip that came back: its k_gate + recount pairs may still sit
+            // in the dense stream.  They have to run out while the device's stop word (gate[VG_STOP]) is still set -
+            // put_state below clears it; a leftover gate would then wait for the NEXT sweep's request and shift which
+            // launch counts which sweep (and, on Z-slabs, let ranks pack different numbers of recounts into one all-reduce).
+            be_sync(be);
             if (s.bail == VBAIL_FLIPS) h->sync_mode = true;
             else if (s.bail == VBAIL_MARKS) {
                 if (nf * 125u > 0x3fffffffull || !size_marks(h, 2 * nf * 125u, true)) return fail(h, VRG_E_MEM, "vrg_run: marked-voxel arrays");
@@ -379,6 +385,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
                 if (!size_pool(h, 2 * ((uint64_t)s.np + nf * 27u), s.np, s.nfree)) return fail(h, VRG_E_MEM, "vrg_run: band arrays");
             }
             s.bail = 0; s.nf = 0;
+            s.ties = s.ties_filed; s.near_ties = s.near_filed;   // the trip's sign tests are made again: count them once
             put_state(h, s);
             continue;
         }
@@ -399,6 +406,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
         out->nseg = (int64_t)d.n_in; out->n_in = (int64_t)d.n_in; out->n_out = (int64_t)d.n_out; out->ni = s.ni; out->no = s.no;
         out->sum_in = d.sum_in; out->sum_out = d.sum_out; out->seconds = secs;
         out->sweep_kernel_ms = h->ev.ms_total - ms0; out->sweep_launches = h->ev.launches - l0;
+        out->ties = (int64_t)(uint32_t)(s.ties - ties0); out->near_ties = (int64_t)(uint32_t)(s.near_ties - near0);
     }
     return VRG_OK;
 }

@@ -226,6 +226,11 @@ VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, int64_t n_in, in
     double inN = ip / (double)n_in;                       // :81
     double outN = op / (double)n_out;                     // :82
     bool ge = inN >= outN;
+    {   // a decision at rounding level is the reference's summation order's to make, not ours: count it (VRG_TIE_REL)
+        const double d = fabs(inN - outN), m = fmax(fabs(inN), fabs(outN));
+        if (n_in == 0 || n_out == 0 || !(d > VRG_TIE_REL * m)) vrg_atomic_add(&c.st->ties, 1u);
+        else if (!(d > VRG_TIE_NEAR_REL * m)) vrg_atomic_add(&c.st->near_ties, 1u);
+    }
     if (inner == ge) return;                              // :87 xor(segmentedMap, inner >= outer)
     uint32_t q = vrg_atomic_add(&c.st->nf, 1u);
     if (s.time_up || n_in >= s.maxSegmentSize) return;    // :97 / :101 fire before update(): count only
@@ -686,6 +691,7 @@ VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
     s.nalloc = vrg_load_u32(&c.st->nalloc); s.ndead = vrg_load_u32(&c.st->ndead); s.nfresh = vrg_load_u32(&c.st->nfresh);
     s.nnz = vrg_load_u32(&c.st->nnz); s.nmk = vrg_load_u32(&c.st->nmk); s.npend = vrg_load_u32(&c.st->npend);
     s.d_ni = vrg_load_i32(&c.st->d_ni); s.d_no = vrg_load_i32(&c.st->d_no); s.error = vrg_load_i32(&c.st->error);
+    s.ties = vrg_load_u32(&c.st->ties); s.near_ties = vrg_load_u32(&c.st->near_ties);
     const int64_t n_in = vrg_load_i64(&c.inc[VC_NIN]), n_out = vrg_load_i64(&c.inc[VC_NOUT]);
     const uint32_t used = vrg_free_used(s.nalloc, s.nfree);
     s.np += s.nalloc - used; s.nfree = s.nfree - used + s.ndead;
@@ -694,7 +700,9 @@ VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
     if ((uint32_t)s.iter < c.trace_cap) {
         VrgTrace& t = c.trace[s.iter];                // the intensity sums are filed by the dense pass (vrg_dense_fin)
         t.nflip = s.nf; t.nseg = n_in; t.n_in = n_in; t.n_out = n_out; t.ni = s.ni; t.no = s.no;
+        t.ties = s.ties - s.ties_filed; t.near_ties = s.near_ties - s.near_filed;
     }
+    s.ties_filed = s.ties; s.near_filed = s.near_ties;
     s.last_nf = s.nf;
     s.nf = 0; s.npend = 0; s.nmk = 0; s.nalloc = 0; s.ndead = 0; s.d_ni = 0; s.d_no = 0;
     s.nfx = s.nfresh; s.nfresh = 0;                   // exact densities of the new entries: first thing next trip

@@ -46,7 +46,15 @@ enum { VBAIL_FLIPS = 1, VBAIL_MARKS = 2, VBAIL_POOL = 3 };
 struct VrgTrace {            // one record per update() call (0 = init)
     int64_t nflip, nseg, n_in, n_out, ni, no;
     double sum_in, sum_out;  // sum of intensities over the inner / outer regions
+    int64_t ties, near_ties; // sign tests (:87) behind this sweep's flip list that were exact ties / near ties (VRG_TIE_*)
 };
+
+// Sign tests whose outcome the reference's own rounding decides (vrg_decide_core): |inner/innerSize - outer/outerSize|
+// <= VRG_TIE_REL * max(|.|, |.|) - an exact mathematical tie (proportional class histograms of an integer volume), which
+// np.sum's pairwise rounding decides in the reference (:87) - or an empty region (x / 0).  Near ties (<= VRG_TIE_NEAR_REL)
+// are decisions the reference's float32 arithmetic (float32 dataArray under numpy 2) could make differently.
+#define VRG_TIE_REL 1e-11
+#define VRG_TIE_NEAR_REL 4e-6
 
 // device-resident scalars; every kernel reads them at entry (no host round trip per sweep)
 struct VrgState {
@@ -75,6 +83,8 @@ struct VrgState {
                          // entries: the next k_band does it on its way through the pool
     int32_t use_tab;     // ... from the per-level memo tabC instead of entry by entry
     int32_t tab_ok;      // decided when update() opens: fewer intensity levels than band entries, a memo pays
+    uint32_t ties, near_ties;          // tie / near-tie sign tests since init (atomic counts; see VRG_TIE_REL)
+    uint32_t ties_filed, near_filed;   // ... as of the last trace record
 };
 
 // results of the dense recount; written by the dense stream only (own allocation, own cache lines).

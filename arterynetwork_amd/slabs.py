@@ -29,9 +29,11 @@ def partition(nz, world):
     return out
 
 
-def make_slab_session(shape, rank, world, device=0, lib=None, reduce='rccl', group=None):
+def make_slab_session(shape, rank, world, device=0, lib=None, reduce='rccl', group=None, observer=None):
     """Session restricted to this rank's Z-slab with the cross-rank statistics reduction wired up.
-    Collective: every rank of `group` must call it."""
+    Collective: every rank of `group` must call it.  `observer(partial, total)` (callback reduction only) sees this
+    rank's slab statistics {n_in, n_out, sum_in, sum_out} and their sum over the ranks, once per vrg_init and once per
+    sweep in sweep order - tests use it to check the partition."""
     import torch
     import torch.distributed as dist
     if shape[2] < world:
@@ -66,10 +68,13 @@ def make_slab_session(shape, rank, world, device=0, lib=None, reduce='rccl', gro
             def allreduce(v):
                 t = torch.tensor(v, dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-                return t.tolist()
+                out = t.tolist()
+                if observer is not None:
+                    observer(list(v), out)
+                return out
             s.set_reduce_callback(allreduce)
             if s.reduce_mode == 'none':
-                s.reduce_mode = 'callback' 
+                s.reduce_mode = 'callback'
     s.slab = (z0, z1)
     return s
 

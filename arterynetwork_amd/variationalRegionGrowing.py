@@ -10,6 +10,8 @@ Extra knobs are keyword-only and default to the reference's hard-coded constants
 """
 from __future__ import annotations
 
+import warnings
+
 import numpy as np
 
 from ._capi import Session, VrgError, STOP_NAMES
@@ -81,6 +83,14 @@ def variationalRegionGrowing(dataArray, valueMap, H=2.25, maxSegmentSize=5000, *
                 raise ValueError(str(e)) from None
             raise
         r = s.run(iterMax, maxSegmentSize, maxTime)
+        if r.ties:
+            warnings.warn('{} sign test(s) (variationalRegionGrowing.py:87) were exact ties (relative margin < 1e-11, or an empty '
+                          'region): the reference decides those by the rounding of np.sum, so the labels may differ from its '
+                          'at the voxels concerned'.format(r.ties), RuntimeWarning, stacklevel=2)
+        if r.near_ties and dataArray.dtype == np.float32:
+            warnings.warn('{} sign test(s) had a relative margin below 4e-6: for float32 dataArray the reference computes in '
+                          'float32 and may decide those differently (this library computes in float64)'.format(r.near_ties),
+                          RuntimeWarning, stacklevel=2)
         segmented = s.segmented()
         s.labels(out=valueMap)               # in place, caller's dtype
         segmentedMap = (np.asarray(valueMap) <= 1).astype(np.int64)

@@ -52,11 +52,17 @@ typedef struct {
     double seconds;           /* wall time of this call's sweeps (device synchronised) */
     double sweep_kernel_ms;   /* HIP-event time summed over this call's dense sweep launches (option "events") */
     int64_t sweep_launches;
+    int64_t ties;             /* sign tests (:87) of this call whose two sides agreed to a relative 1e-11, or that divided by an
+                                 empty region: the reference decides those by the rounding of np.sum's pairwise order, which
+                                 no regrouped summation reproduces - labels are bit-exact unless ties > 0 */
+    int64_t near_ties;        /* ... whose relative margin was below 4e-6: decisions the reference's float32 arithmetic
+                                 (float32 dataArray under numpy 2) could make differently; harmless for float64 / integer input */
 } vrg_result;
 
 typedef struct {              /* one record per update() call; index 0 = init mode (:129-155) */
     int64_t nflip, nseg, n_in, n_out, ni, no;
     double sum_in, sum_out;
+    int64_t ties, near_ties;  /* of the sign tests that produced this sweep's flip list (see vrg_result) */
 } vrg_trace_rec;
 
 /* Create a handle for an nx*ny*nz volume on HIP device `device`. */

@@ -16,8 +16,11 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
-def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+def golden_names(float32=False):
+    """Golden cases; those whose dataArray went into the reference as float32 (suffix _f32: the reference then computes
+    in float32, tests/test_float32_input.py) are listed separately from the float64 / integer ones."""
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+    return [n for n in names if n.endswith('_f32') == bool(float32)]
 
 
 class Golden:
@@ -32,12 +35,15 @@ class Golden:
         self.max_sweeps = int(self.z['max_sweeps'])
         self.ncalls = len(self.z['nflip'])          # init + incremental update calls
 
-    def inputs(self):
+    def inputs(self, as_input_dtype=False):
+        """(dataArray, valueMap); float64 data unless `as_input_dtype` asks for the dtype the reference was given."""
+        dt = np.dtype(str(self.z['input_dtype'])) if (as_input_dtype and 'input_dtype' in self.z.files) else np.float64
         if 'data' in self.z.files:
-            return self.z['data'].astype(np.float64).reshape(self.shape), self.z['labels0'].astype(np.int64).reshape(self.shape)
+            return self.z['data'].astype(dt).reshape(self.shape), self.z['labels0'].astype(np.int64).reshape(self.shape)
         from arterynetwork_amd import phantoms as P
-        assert self.name == 'config1_tube'
+        assert self.name in ('config1_tube', 'config1_tube_f32')
         data, vmap = P.config1()
+        data = data.astype(dt)
         import hashlib
         assert hashlib.sha256(np.ascontiguousarray(data, np.float64).tobytes()).hexdigest() == str(self.z['data_sha256'])
         return data, vmap

@@ -4,6 +4,11 @@
 default      880x880x640 (the headline size), the torch-generated bench volume, 60 sweeps
 --oracle3    the same volume, 100 sweeps, against the ORACLE at full size (all cores; ~25 GB of host memory, a few minutes):
              labels of all 495 616 000 voxels, both band list orders and densities, `segmented` order, whole trace
+--slabs W NXxNYxNZ SWEEPS
+             BASELINE configs[3]'s partition at full size on ONE GPU: W ranks (processes) share GPU 0, each recounts its own
+             Z-slab of the same bench volume (host-callback reduction over gloo); every rank's labels, `segmented` and
+             integer trace must equal the single-process run, and the ranks' slab counts must add up to the incremental
+             region sizes of every sweep
 --config5    1024^3 with 16-bit intensity storage (BASELINE configs[4] on one GPU), 40 sweeps, and the same volume with
              fp32 storage: labels, `segmented` and the whole trace (incl. the f64 intensity sums) must be identical
 """
@@ -114,7 +119,104 @@ def oracle_full_size(dev, sweeps=100):
     s.close(); o.close()
 
 
+def label_digest(s, shape, dev):
+    """sha256 of the uint8 label volume (x-fastest layout), fetched through the C-ABI into a device buffer."""
+    import hashlib
+    lab = torch.empty((shape[2], shape[1], shape[0]), dtype=torch.uint8, device=dev).permute(2, 1, 0)
+    s._check(s.lib.get_labels(s._h, lab.data_ptr(), 0, (ctypes.c_int64 * 3)(*lab.stride())))
+    torch.cuda.synchronize()
+    return hashlib.sha256(lab.permute(2, 1, 0).contiguous().cpu().numpy().tobytes()).hexdigest(), lab
+
+
+def slab_worker(rank, world, port, shape, sweeps, outdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from arterynetwork_amd import slabs
+    dev = torch.device('cuda', 0)                          # every rank on GPU 0
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    I, vm = phantoms.bench_volume_torch(shape, dev)
+    torch.cuda.synchronize()
+    seen = []
+    s = slabs.make_slab_session(shape, rank, world, device=0, reduce='callback', observer=lambda p, t: seen.append(p + t))
+    s.set_option('batch', 16)
+    s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
+    s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
+    s.init(2.25)
+    r = s.run(sweeps, 10 ** 12, None)
+    assert r.sweeps == sweeps, (r.sweeps, r.stop_reason)
+    digest, _ = label_digest(s, shape, dev)
+    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), digest=np.str_(digest), seg=s.segmented(), tr=s.trace(),
+             seen=np.asarray(seen, np.float64), slab=np.asarray(s.slab), dense_bytes=np.int64(s.stats()['dense_bytes']))
+    s.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def slabs_one_gpu(world, shape, sweeps):
+    """Parent: the single-process run, then `world` rank processes on the same GPU; compare."""
+    import subprocess
+    import tempfile
+    import socket
+    dev = torch.device('cuda', 0)
+    I, vm = phantoms.bench_volume_torch(shape, dev)
+    torch.cuda.synchronize()
+    s = Session(shape)
+    s.set_option('batch', 16)
+    s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
+    s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
+    s.init(2.25)
+    r = s.run(sweeps, 10 ** 12, None)
+    assert r.sweeps == sweeps
+    ref_digest, _ = label_digest(s, shape, dev)
+    ref_seg, ref_tr, ref_bytes = s.segmented(), s.trace(), s.stats()['dense_bytes']
+    s.close()
+    del I, vm
+    torch.cuda.empty_cache()
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    outdir = tempfile.mkdtemp(prefix='slabs_')
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--slab-worker', str(rk), str(world), str(port),
+                               'x'.join(map(str, shape)), str(sweeps), outdir]) for rk in range(world)]
+    rcs = [p.wait() for p in procs]
+    assert all(rc == 0 for rc in rcs), rcs
+    planes = []
+    seen_sum = None
+    nbytes = 0
+    for rk in range(world):
+        z = np.load(os.path.join(outdir, 'rank%d.npz' % rk))
+        assert str(z['digest']) == ref_digest, 'rank %d: labels differ from the single-process run' % rk
+        assert np.array_equal(z['seg'], ref_seg), 'rank %d: segmented differs' % rk
+        for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no', 'ties'):
+            assert np.array_equal(z['tr'][f], ref_tr[f]), (rk, f)
+        np.testing.assert_allclose(z['tr']['sum_in'], ref_tr['sum_in'], rtol=1e-12)
+        np.testing.assert_allclose(z['tr']['sum_out'], ref_tr['sum_out'], rtol=1e-12)
+        seen = z['seen']
+        assert seen.shape == (sweeps + 1, 8), seen.shape           # one reduction at init, one per sweep
+        # what every rank got back is the same total, and it is the incremental region size of that sweep
+        assert np.array_equal(seen[:, 4], ref_tr['n_in'].astype(np.float64)) and np.array_equal(seen[:, 5], ref_tr['n_out'].astype(np.float64))
+        seen_sum = seen[:, :4].copy() if seen_sum is None else seen_sum + seen[:, :4]
+        planes.append(int(z['slab'][1] - z['slab'][0]))
+        nbytes += int(z['dense_bytes'])
+    # the ranks' slab counts add up to the region sizes, sweep by sweep (exact: integers below 2^53)
+    assert np.array_equal(seen_sum[:, 0], ref_tr['n_in'].astype(np.float64)) and np.array_equal(seen_sum[:, 1], ref_tr['n_out'].astype(np.float64))
+    np.testing.assert_allclose(seen_sum[:, 2], ref_tr['sum_in'], rtol=1e-12)
+    assert sum(planes) == shape[2] and max(planes) - min(planes) <= 1
+    # the slabs' dense passes fetch what the single pass fetches, plus at most the two class-word units a face cuts
+    assert ref_bytes <= nbytes <= ref_bytes + world * 2 * (256 + 4 * 1024 * 4)
+    print('SLABS OK: %s, %d ranks on one GPU (slabs of %s planes), %d sweeps: labels / segmented / trace identical on every rank, '
+          'slab counts add up every sweep (nseg %d -> %d)' % ('x'.join(map(str, shape)), world, sorted(set(planes)), sweeps, ref_tr['nseg'][0], ref_tr['nseg'][-1]))
+
+
 def main():
+    if '--slab-worker' in sys.argv:
+        a = sys.argv[sys.argv.index('--slab-worker') + 1:]
+        slab_worker(int(a[0]), int(a[1]), int(a[2]), tuple(int(v) for v in a[3].split('x')), int(a[4]), a[5])
+        return
+    if '--slabs' in sys.argv:
+        a = sys.argv[sys.argv.index('--slabs') + 1:]
+        slabs_one_gpu(int(a[0]), tuple(int(v) for v in a[1].split('x')), int(a[2]))
+        return
     dev = torch.device('cuda', 0)
     if '--oracle3' in sys.argv:
         oracle_full_size(dev)

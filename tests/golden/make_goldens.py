@@ -169,6 +169,20 @@ def cases():
                              kw=dict(shape=(48, 40, 24), radius=3.0, seed=5, seed_planes=3, amp_y=8.0,
                                      amp_z=4.0, levels=16, brain_mask=True),
                              run=dict(max_sweeps=40), full=True, store_inputs=True)
+    # float32 dataArray: under numpy 2 the reference then evaluates every Gaussian term and every np.sum in float32
+    # (:149-155, :236-255).  The product computes in float64 whatever the input dtype, so these
+    # fixtures MEASURE the divergence (tests/test_float32_input.py): same recipes as config1_tube / tube_q_small /
+    # adv_noise_q, passed as np.float32.
+    c['config1_tube_f32'] = dict(gen=P.config1, kw={}, run=dict(max_sweeps=50), full=False,
+                                 prob_iters=(0, 1, 2, 3, 5, 10, 15, 20, 25, 30, 40, 50), store_inputs=False, cast=np.float32)
+    c['tube_q_small_f32'] = dict(gen=P.tube_phantom,
+                                 kw=dict(shape=(48, 40, 24), radius=3.0, seed=5, seed_planes=3, amp_y=8.0,
+                                         amp_z=4.0, levels=16, brain_mask=True),
+                                 run=dict(max_sweeps=40), full=True, store_inputs=True, cast=np.float32)
+    c['adv_noise_q_f32'] = dict(gen=P.noise_volume, kw=dict(shape=(16, 18, 20), seed=200, levels=4),
+                                run=dict(max_sweeps=30), full=True, store_inputs=True, cast=np.float32)
+    c['adv_scattered_f32'] = dict(gen=P.scattered_seeds, kw={}, run=dict(max_sweeps=40), full=True, store_inputs=True,
+                                  cast=np.float32)
     # size stop + border seeds: maxSegmentSize reached, seeds on the volume faces
     c['border_size_stop'] = dict(gen=P.noise_volume, kw=dict(shape=(10, 9, 8), seed=300, p_seed=0.5, p_excl=0.1),
                                  run=dict(maxSegmentSize=300), full=True, store_inputs=True)
@@ -185,8 +199,12 @@ def main(argv):
         if spec.get('quant'):
             q = spec['quant']
             data = np.round(data * q) / q
+        if spec.get('cast') is not None:
+            assert np.array_equal(data.astype(spec['cast']).astype(np.float64), np.asarray(data, np.float64))
+            data = data.astype(spec['cast'])      # the reference now takes its float32 path
         run = dict(spec['run'])
         out = run_reference(V, data, vmap, full=spec['full'], prob_iters=spec.get('prob_iters', ()), **run)
+        out['input_dtype'] = np.str_(np.asarray(data).dtype.name)
         out['recipe'] = np.str_(f"{spec['gen'].__name__}({spec['kw']}) quant={spec.get('quant')}")
         out['data_sha256'] = np.str_(sha(np.asarray(data, np.float64)))
         out['labels0_sha256'] = np.str_(sha(np.asarray(vmap, np.uint8)))

@@ -153,7 +153,8 @@ void be_init_finish(VrgBackend*, const VrgCtx& c, be_reduce_fn cb, void* user) {
     const VrgDense& d = *c.dn;
     VrgTrace& t = c.trace[0];
     t.nflip = 0; t.nseg = (int64_t)d.n_in; t.n_in = (int64_t)d.n_in; t.n_out = (int64_t)d.n_out; t.ni = s.ni; t.no = s.no;
-    t.sum_in = d.sum_in; t.sum_out = d.sum_out;
+    t.sum_in = d.sum_in; t.sum_out = d.sum_out; t.ties = 0; t.near_ties = 0;
+    s.ties = 0; s.near_ties = 0; s.ties_filed = 0; s.near_filed = 0;
 }
 
 int be_comm_unique_id(void*) { return -1; }

@@ -664,3 +664,71 @@ def test_drop_in_messages_and_trace(golden_loader, capsys):
     assert mine == theirs and 'Max iteration reached! Finished at iteration 3' in mine
     assert np.array_equal(vm1, vm2)
     assert [t['nflip'] for t in tr] == [int(v) for v in g.z['nflip'][:3]] and tr[2]['nseg'] == int(g.z['nseg'][2])
+
+
+@pytest.mark.parametrize('shape,sweeps', [('880x880x640', 40), ('512x512x170', 40)])
+def test_config4_partition_8_ranks_one_gpu(shape, sweeps):
+    """BASELINE configs[3]'s partition at FULL size on the one GPU of the box: 8 rank processes share GPU 0, each recounts
+    its own Z-slab of the bench volume (880x880x640: 80 planes each, plane = 896 x 884 voxels against 1024-voxel units;
+    512x512x170: uneven slabs of 22 / 21 planes), host-callback reduction over gloo.  Every rank's labels, `segmented`
+    and integer trace equal the single-process run; the ranks' slab counts add up to the incremental region sizes of
+    every sweep.  (tests/full_size_check.py --slabs, own processes.)"""
+    import subprocess, sys, os
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'full_size_check.py'), '--slabs', '8', shape, str(sweeps)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and 'SLABS OK' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_reports_ties(lib):
+    """An integer volume with proportional class histograms (constant intensity): every sign test (:87) is an exact tie,
+    which the reference decides by np.sum's rounding.  The library counts them (vrg_result.ties, trace field `ties`) and
+    the drop-in function warns - 'bit-exact labels' holds unless ties > 0."""
+    from arterynetwork_amd import variationalRegionGrowing
+    from arterynetwork_amd._capi import Session
+    from test_hostmodel import tie_volume
+    I, vm = tie_volume()
+    s = Session(I.shape, lib=lib)
+    s.set_volume(I); s.set_labels(vm); s.init(2.25)
+    r = s.run(3, 10 ** 9, None)
+    tr = s.trace()
+    band0 = int(tr['ni'][0] + tr['no'][0])
+    assert r.ties >= band0 > 0 and int(tr['ties'][1]) == band0
+    s.close()
+    with pytest.warns(RuntimeWarning, match='exact ties'):
+        variationalRegionGrowing(I, vm.copy(), iterMax=3, maxSegmentSize=10 ** 9, quiet=True)
+    import warnings
+    from arterynetwork_amd import phantoms
+    d, v = phantoms.scattered_seeds()
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        variationalRegionGrowing(d, v.copy(), iterMax=5, maxSegmentSize=10 ** 9, quiet=True)     # no tie: no warning
+
+
+def test_handed_back_trip_with_callback_reduce(lib):
+    """A trip handed back because of its flip count (VBAIL_FLIPS) in the middle of a long batch, with a slab reduction
+    callback and no event timing: the launches of the rest of the batch must drain before the stop word is cleared
+    (else a leftover gate would take the next sweep's request).  Result = the oracle's."""
+    from arterynetwork_amd._capi import Session
+    from oracle import vrg_oracle as O
+    I, vm, H, _, _ = random_case(200041, 10, 40)
+    for small in (1, 3):
+        o = O.Oracle(I, vm, H, 1); o.init()
+        k = 0
+        while o.step(25, 10 ** 9, -1.0) == 0:
+            k += 1
+        s = Session(I.shape, lib=lib)
+        calls = []
+        s.set_reduce_callback(lambda v: (calls.append(list(v)), v)[1])
+        for kk, vv in (('small_flips', small), ('events', 0), ('batch', 64)):
+            s.set_option(kk, vv)
+        s.set_volume(I); s.set_labels(vm); s.init(H)
+        r = s.run(25, 10 ** 9, None)
+        assert r.sweeps == k and r.ties == 0
+        assert s.stats()['bail_flips'] >= 1
+        parity.compare_state(s, o, I.shape, 1e-9, 'handed-back trips, small_flips %d' % small)
+        tr, otr = s.trace(), o.trace()
+        for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no'):
+            assert np.array_equal(tr[f], otr[f]), f
+        assert len(calls) == k + 1 and [c[0] for c in calls] == [float(x) for x in tr['n_in']]
+        s.close(); o.close()

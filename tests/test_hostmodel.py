@@ -270,3 +270,33 @@ def test_hostmodel_dense_bytes_counter(hm):
         lab = s.labels()
         s.close()
         assert got == dense_bytes_by_definition(lab, line), (I.shape, s16, line)
+
+
+def tie_volume():
+    """An integer volume whose class histograms are proportional (here: constant intensity): every sign test (:87) is an
+    exact mathematical tie, inner/innerSize == outer/outerSize == A."""
+    I = np.full((12, 11, 10), 3, dtype=np.int64)
+    vm = np.full(I.shape, 3, dtype=np.int64)
+    vm[4:7, 4:7, 3:6] = 0
+    return I, vm
+
+
+def test_hostmodel_reports_ties(hm):
+    """Exact ties are counted where they are decided (vrg_result.ties, trace field `ties`), so a caller knows when
+    'bit-exact labels' does not apply; a volume without ties reports none."""
+    from arterynetwork_amd._capi import Session
+    I, vm = tie_volume()
+    s = Session(I.shape, lib=hm)
+    s.set_volume(I); s.set_labels(vm); s.init(2.25)
+    r = s.run(3, 10 ** 9, None)
+    tr = s.trace()
+    band0 = int(tr['ni'][0] + tr['no'][0])
+    assert r.ties >= band0 > 0 and int(tr['ties'][1]) == band0       # every entry of the initial band was a tie
+    assert int(tr['ties'].sum()) <= r.ties
+    s.close()
+    g_I, g_vm, H, _, _ = random_case(7)
+    s = Session(g_I.shape, lib=hm)
+    s.set_volume(g_I); s.set_labels(g_vm); s.init(H)
+    r = s.run(5, 10 ** 9, None)
+    assert r.ties == 0 and int(s.trace()['ties'].sum()) == 0
+    s.close()
