@@ -933,10 +933,26 @@ __device__ __forceinline__ void load_vals(const VrgCtx& c, uint32_t u, uint32_t 
         }
     }
 }
+// Work split: wave w owns the whole units [wrange[w], wrange[w+1]) of the slab, contiguous ranges of equal cost made at
+// init (k_unit_cost / k_wrange).  It lists the non-empty units of its range (VrgCtx::ubits: one bit per unit, scanned 64
+// words = 2048 units at a time) into an LDS list of its own and then walks that list UNITS at a time: every trip fetches
+// units that hold included voxels - no trip is spent on the class words of the 54 % of the bench volume outside the brain
+// mask (such trips moved 768 B per memory round trip: a wave crossing the outside of the mask added nothing to the
+// bandwidth for a quarter of its life).  SKIP = false lists every unit of the range; each lane then makes the same
+// additions in the same order (a unit that is not listed holds class 0 only and would add +0.0): bit-identical sums.
+constexpr uint32_t RL_CAP = 512;        // units a wave lists at a time
+constexpr uint32_t RL_PAD = 8;          // room for the sentinel units that round a list up to whole trips + the prefetch past its end
 template <int UNITS, bool NT, int MODE, bool SKIP>
 __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) {
     if (check_done && !vrg_dense_due(c)) return;     // k_gate let it through without a sweep to count: the run has stopped
     extern __shared__ float s_val[];        // 16-bit storage: the level values (c.L floats, sized at launch)
+    __shared__ uint32_t s_list[TPB / 64][RL_CAP + RL_PAD];
+    static_assert(2 * UNITS <= (int)RL_PAD, "list padding");
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    // (the range travels with everything else a wave reads first)
+    uint32_t ua = 0, ub = 0;
+    if (wave < c.nwr) { ua = c.wrange[wave]; ub = c.wrange[wave + 1]; }
     if (MODE == 1) {
         for (uint32_t i = threadIdx.x; i < c.L; i += TPB) s_val[i] = (float)c.lev[i];
         __syncthreads();
@@ -947,45 +963,50 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
     const uint32_t hi = (2u + (uint32_t)c.z1) * plane;
     uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10;       // units wholly inside it
     if (f_hi < f_lo) f_hi = f_lo;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    ua = __builtin_amdgcn_readfirstlane(ua); ub = __builtin_amdgcn_readfirstlane(ub);
+    volatile uint32_t* list = s_list[wv];
     SweepAcc acc = {0, 0, 0.0, 0.0};
-    uint32_t u = f_lo + wave * UNITS;
-    // the class words of a trip are fetched one trip ahead: the intensity loads depend on them when excluded groups are skipped
-    uint32_t w[UNITS];
-    if (u + UNITS <= f_hi) {
+    for (uint32_t pos = ua; pos < ub;) {
+        // ---- list the next non-empty units of [pos, ub): lane l takes the 32 units of bitmap word (pos >> 5) + l
+        uint32_t n = 0;
+        for (;;) {
+            const uint32_t wi = (pos >> 5) + lane, u0 = wi << 5;
+            uint32_t bits = 0u;
+            if (u0 < ub) bits = SKIP ? c.ubits[wi] : 0xffffffffu;
+            if (u0 < pos) bits &= 0xffffffffu << (pos - u0);                  // (lane 0 of a range's first round)
+            if (u0 < ub && ub - u0 < 32u) bits &= (1u << (ub - u0)) - 1u;
+            const uint32_t cnt = __popc(bits), incl = wave_incl_scan(cnt);
+            const bool fits = n + incl <= RL_CAP;                              // (true for a prefix of the lanes)
+            const uint32_t nfit = (uint32_t)__popcll(__ballot(fits));
+            if (fits) {
+                uint32_t q = n + incl - cnt;
+                while (bits) { list[q++] = u0 + vrg_ctz(bits); bits &= bits - 1u; }
+            }
+            n += nfit ? (uint32_t)__shfl((int)incl, (int)nfit - 1, 64) : 0u;
+            pos = ((pos >> 5) + nfit) << 5;
+            if (nfit < 64u || pos >= ub) break;                               // the list is full / the range is done
+        }
+        if (lane < RL_PAD) list[n + lane] = 0u;                               // sentinel: unit 0 is padding (class 0), always readable
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // (one wave: its LDS accesses are in order)
+        // ---- walk the list, UNITS at a time; the class words of a trip are fetched one trip ahead (the intensity loads
+        // depend on them), before this trip's intensities: loads return in order, so they cost no wait of their own
+        uint32_t uu[UNITS], w[UNITS];
 #pragma unroll
-        for (int q = 0; q < UNITS; q++) w[q] = load_cls<NT>(cls, u + q, lane);
-    }
+        for (int q = 0; q < UNITS; q++) { uu[q] = __builtin_amdgcn_readfirstlane(list[q]); w[q] = load_cls<NT>(cls, uu[q], lane); }
 #pragma unroll
-    for (int q = 0; q < UNITS; q++) asm volatile("" : "+v"(w[q]));       // settle the first trip's class words here: no waits in mid-loop
-    while (u + UNITS <= f_hi) {
-        // next trip's class words first (unconditionally - clamped to the last full trip - so that the wait counts stay
-        // static), then this trip's intensities: loads return in order, so the class words cost no wait of their own
-        const uint32_t un = u + nwaves * UNITS;
-        const uint32_t up = un + UNITS <= f_hi ? un : f_hi - UNITS;
-        uint32_t wn[UNITS];
+        for (int q = 0; q < UNITS; q++) asm volatile("" : "+v"(w[q]));        // settle the first trip's class words here: no waits in mid-loop
+        for (uint32_t i = 0; i < n; i += UNITS) {
+            uint32_t un[UNITS], wn[UNITS];
 #pragma unroll
-        for (int q = 0; q < UNITS; q++) wn[q] = load_cls<NT>(cls, up + q, lane);
-        uint32_t w_any = 0u;
-#pragma unroll
-        for (int q = 0; q < UNITS; q++) w_any |= w[q];
-        if (!SKIP || __builtin_amdgcn_ballot_w64(w_any != 0u) != 0ull) {      // (a trip outside the mask: one compare, one scalar branch)
+            for (int q = 0; q < UNITS; q++) { un[q] = __builtin_amdgcn_readfirstlane(list[i + UNITS + q]); wn[q] = load_cls<NT>(cls, un[q], lane); }
             UnitVals<MODE> f[UNITS];
 #pragma unroll
-            for (int q = 0; q < UNITS; q++) load_vals<MODE, NT, SKIP>(c, u + q, lane, w[q], f[q]);
+            for (int q = 0; q < UNITS; q++) load_vals<MODE, NT, SKIP>(c, uu[q], lane, w[q], f[q]);
 #pragma unroll
             for (int q = 0; q < UNITS; q++) stats_bits<MODE, SKIP>(acc, w[q], f[q], s_val);
-        }
 #pragma unroll
-        for (int q = 0; q < UNITS; q++) w[q] = wn[q];
-        u = un;
-    }
-    for (; u < f_hi; u++) {                                    // whole units left over by the UNITS-stride
-        UnitVals<MODE> f;
-        const uint32_t w1 = load_cls<false>(cls, u, lane);
-        load_vals<MODE, false, SKIP>(c, u, lane, w1, f);
-        stats_bits<MODE, SKIP>(acc, w1, f, s_val);
+            for (int q = 0; q < UNITS; q++) { w[q] = wn[q]; uu[q] = un[q]; }
+        }
     }
     // units the slab edges cut: the first and the last unit touching [lo, hi), masked to the slab
     const uint32_t e0 = lo >> 10, e1 = (hi - 1u) >> 10;
@@ -1003,23 +1024,72 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
     }
     sweep_finish(c, acc, check_done);
 }
+// ---- the work split of the dense pass (init, and whenever the number of recount waves changes) ----------------------------
+// cost of every whole unit of the slab (vrg_unit_cost; 0 outside it), one wave per unit
+__global__ void __launch_bounds__(TPB) k_unit_cost(VrgCtx c, uint32_t* cost, uint32_t nu) {
+    const uint32_t* __restrict__ cls = c.clsb[0];
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
+    const uint32_t lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
+    uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10;
+    if (f_hi < f_lo) f_hi = f_lo;
+    const uint32_t lpl = c.lev16 ? 16u : (c.I ? 8u : 4u), lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t u = wave; u < nu; u += nwaves) {
+        uint32_t lines = 0u;
+        if (u >= f_lo && u < f_hi && ((c.ubits[u >> 5] >> (u & 31u)) & 1u)) {
+            const uint32_t w = cls[((size_t)u << 6) + lane];
+            lines = 2u;
+            for (int j = 0; j < 4; j++) {
+                const uint64_t m = __ballot(((w >> (8 * j)) & 0xffu) != 0u);
+                for (uint32_t g = 0; g < 64u; g += lpl) lines += ((m >> g) & ((1ull << lpl) - 1ull)) ? 1u : 0u;
+            }
+        }
+        if (lane == 0) cost[u] = lines;
+    }
+}
+// boundary i of nw + 1: the first unit whose cumulative cost reaches i / nw of the total (cum = inclusive scan of cost)
+__global__ void k_wrange(VrgCtx c, const uint32_t* cum, uint32_t nu, uint32_t nw) {
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
+    const uint32_t lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
+    uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10;
+    if (f_hi < f_lo) f_hi = f_lo;
+    const uint64_t total = nu ? cum[nu - 1] : 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= nw; i += gridDim.x * blockDim.x) {
+        uint32_t r;
+        if (i == 0) r = f_lo;
+        else if (i == nw) r = f_hi;
+        else {
+            const uint64_t target = total * i / nw;                    // units [0, r) cost <= target
+            uint32_t a = 0, b = nu;                                    // first u with cum[u] > target
+            while (a < b) { const uint32_t m = (a + b) >> 1; if ((uint64_t)cum[m] > target) b = m; else a = m + 1; }
+            r = a < f_lo ? f_lo : (a > f_hi ? f_hi : a);
+        }
+        c.wrange[i] = r;
+    }
+}
 __global__ void k_cls_build(VrgCtx c) {
     const uint32_t nd = (uint32_t)((((uint64_t)c.PV + 1023u) >> 10) << 6);
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < nd; d += gridDim.x * blockDim.x) vrg_item_cls_build(c, d);
 }
 
-// Bytes one dense pass requests from memory for the class copy the last pass read: 256 B of class words per unit
-// of the slab + every 128-byte intensity line that holds an included voxel (what k_recount_bits<.., SKIP> fetches).
+// Bytes one dense pass requests from memory for the class copy the last pass read: 4 B of unit bitmap per 32 units of the
+// slab + 256 B of class words per listed unit (the units the slab's faces cut: always) + every 128-byte intensity line
+// that holds an included voxel (what k_recount_bits<.., SKIP> fetches).
 __global__ void __launch_bounds__(TPB) k_dense_bytes(VrgCtx c, unsigned long long* out) {
     const uint32_t* __restrict__ cls = c.clsb[vrg_load_i64(&c.dctl[VD_RSEQ]) & 1];
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
     const uint32_t lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
     const uint32_t e0 = lo >> 10, e1 = (hi - 1u) >> 10;
+    uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10;
+    if (f_hi < f_lo) f_hi = f_lo;
     const uint32_t lpl = c.lev16 ? 16u : (c.I ? 8u : 4u);          // lanes (of 4 voxels each) per 128-byte line
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     unsigned long long bytes = 0;
     for (uint32_t u = e0 + wave; u <= e1; u += nwaves) {
+        const bool whole = u >= f_lo && u < f_hi;
+        if (whole && (u & 31u) == 0u) bytes += 4u;                  // (the bitmap word of these 32 units)
+        if (whole && !((c.ubits[u >> 5] >> (u & 31u)) & 1u)) continue;
         uint32_t w = cls[((size_t)u << 6) + lane];
         bytes += 256u;
         for (int j = 0; j < 4; j++) {
@@ -1502,6 +1572,24 @@ static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t s
     else { if (nt) launch_recount_as<true, false>(c, blocks, check, st, e_start, e_stop); else launch_recount_as<false, false>(c, blocks, check, st, e_start, e_stop); }
 }
 
+// The work split of the dense pass (VrgCtx::wrange): whole units of the slab in contiguous ranges of equal cost, one per
+// recount wave.  Needs the class bits and the unit bitmap (k_cls_build); stream A.
+uint32_t be_dense_waves(VrgBackend* b, const VrgCtx& c) { return (uint32_t)dense_blocks(b, c) * (TPB / 64); }
+void be_partition(VrgBackend* b, const VrgCtx& c, uint32_t nw) {
+    use_device(b);
+    const uint32_t nu = (uint32_t)(((uint64_t)c.PV + 1023u) >> 10);
+    uint32_t *cost = nullptr, *cum = nullptr; void* tmp = nullptr; size_t tb = 0;
+    HIP_CHECK(hipMalloc(&cost, (size_t)nu * 4)); HIP_CHECK(hipMalloc(&cum, (size_t)nu * 4));
+    if (!cost || !cum) { if (cost) (void)hipFree(cost); if (cum) (void)hipFree(cum); if (!b->err[0]) std::snprintf(b->err, sizeof(b->err), "out of device memory (dense work split)"); return; }
+    k_unit_cost<<<1024, TPB, 0, b->sa>>>(c, cost, nu);
+    HIP_CHECK(rocprim::inclusive_scan(nullptr, tb, cost, cum, nu, rocprim::plus<uint32_t>(), b->sa));
+    HIP_CHECK(hipMalloc(&tmp, tb ? tb : 4));
+    HIP_CHECK(rocprim::inclusive_scan(tmp, tb, cost, cum, nu, rocprim::plus<uint32_t>(), b->sa));
+    k_wrange<<<(nw + 1 + TPB - 1) / TPB, TPB, 0, b->sa>>>(c, cum, nu, nw);
+    HIP_CHECK(hipStreamSynchronize(b->sa));
+    HIP_CHECK(hipFree(cost)); HIP_CHECK(hipFree(cum)); if (tmp) HIP_CHECK(hipFree(tmp));
+}
+
 void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
     use_device(b);
     b->dense_pending = 0;
@@ -1511,7 +1599,8 @@ void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
     else k_hist_voxel<<<voxel_blocks(c), TPB, 0, b->sa>>>(c);
     k_exact_init<<<1024, TPB, 0, b->sa>>>(c);
     k_cls_build<<<2048, TPB, 0, b->sa>>>(c);
-    launch_recount(c, dense_blocks(b, c), 0, b->sa, b->skip != 0, dense_nt(b, c));
+    be_partition(b, c, c.nwr);
+    launch_recount(c, (int)(c.nwr / (TPB / 64)), 0, b->sa, b->skip != 0, dense_nt(b, c));
     reduce_dense(b, c, cb, user, b->sa);
     k_fin_init<<<1, 1, 0, b->sa>>>(c);
     b->pass_bytes = be_dense_bytes(b, c);       // (decides between ordinary and non-temporal loads for the sweeps' passes)
@@ -1617,7 +1706,7 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
     // device for another one could then wait for ever, so the host orders the two streams instead.)
     if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sa));
     const bool ranks = c.world > 1 || b->comm || cb;
-    launch_recount(c, dense_blocks(b, c), ranks ? 1 : 2, b->sb, b->skip != 0, dense_nt(b, c), e_start, e_stop);
+    launch_recount(c, (int)(c.nwr / (TPB / 64)), ranks ? 1 : 2, b->sb, b->skip != 0, dense_nt(b, c), e_start, e_stop);
     if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sb));
     // one GPU: the last workgroup of the recount closes the pass itself.  Z-slabs: the slab sums of DENSE_GROUP recounts
     // are summed over the ranks by ONE all-reduce (nothing on the band side waits for it: the decisions use the
@@ -1658,6 +1747,7 @@ uint64_t be_dense_bytes(VrgBackend* b, const VrgCtx& c) {
         const uint64_t bpv4 = c.lev16 ? 9 : (c.I ? 17 : 33);      // 4 x (intensity bytes + 0.25)
         return (hi - lo) * bpv4 / 4;
     }
+    HIP_CHECK(hipStreamSynchronize(b->sb));
     unsigned long long* d = nullptr; unsigned long long v = 0;
     HIP_CHECK(hipMalloc(&d, 8));
     if (!d) return 0;

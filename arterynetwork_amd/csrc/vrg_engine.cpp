@@ -164,6 +164,8 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     h->PVu = PVu;
     c.clsb[0] = alloc<uint32_t>(h, PVu / 16); c.clsb[1] = alloc<uint32_t>(h, PVu / 16);
     c.nchg = alloc<uint32_t>(h, 32);
+    c.ubits = alloc<uint32_t>(h, PVu / 1024 / 32 + 64);
+    c.wrange = alloc<uint32_t>(h, VRG_MAX_DENSE_WAVES + 1);
     c.vent = alloc<uint32_t>(h, PVu);
     // 16 guard bytes in front: voxel (0,0,0)'s 2-ring reaches 2 bytes before the padded array
     h->lab_base[0] = alloc<uint8_t>(h, (size_t)c.PV + 32);
@@ -184,7 +186,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.trace = alloc<VrgTrace>(h, c.trace_cap);
     c.world = 1;
     if (!c.lab[0] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.gate || !c.dn_ring || !c.exp_ring || !c.stage_in || !c.stage_out || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
-        !c.nchg || !c.vent || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace) { API(destroy)(h); return VRG_E_MEM; }
+        !c.nchg || !c.ubits || !c.wrange || !c.vent || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace) { API(destroy)(h); return VRG_E_MEM; }
     be_fill(be, c.inc, 0, 32 * sizeof(int64_t)); be_fill(be, c.dctl, 0, 32 * sizeof(int64_t)); be_fill(be, c.gate, 0, 32 * sizeof(int64_t));
     be_fill(be, c.clsb[0], 0, PVu / 4); be_fill(be, c.clsb[1], 0, PVu / 4);
     be_fill(be, c.nchg, 0, 32 * sizeof(uint32_t));
@@ -329,6 +331,8 @@ int API(init)(vrg_handle* h, double H) {
     s.ni = s.ninit_in; s.no = s.ninit_out; s.nfresh = s.ni + s.no; s.error = 0;
     put_state(h, s);
     be_fill(be, c.p_flag, 0, c.bcap);
+    be_fill(be, c.ubits, 0, (h->PVu / 1024 / 32 + 64) * sizeof(uint32_t));     // rebuilt from the labels by be_init_finish
+    c.nwr = std::min<uint32_t>(be_dense_waves(be, c), VRG_MAX_DENSE_WAVES);
     be_init_finish(be, c, h->reduce_fn, h->reduce_user);
     s = get_state(h);
     int rc = check_state_error(h, s);
@@ -352,6 +356,10 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     s.done = 0; s.time_up = 0; s.bail = 0; s.iterMax = (int32_t)iterMax; s.maxSegmentSize = maxSegmentSize;
     s.nf = 0; s.npend = 0; s.nmk = 0;                    // counters of a trip that stopped before update()
     put_state(h, s);
+    {   // an option changed the number of recount waves since the work split was made: split again
+        const uint32_t nw = std::min<uint32_t>(be_dense_waves(be, c), VRG_MAX_DENSE_WAVES);
+        if (nw != c.nwr) { be_sync(be); c.nwr = nw; be_partition(be, c, nw); }
+    }
     double ms0 = h->ev.ms_total; long long l0 = h->ev.launches;
     auto t_begin = std::chrono::steady_clock::now();
     const int base_flags = ((h->variant & 1) ? VRG_SWEEP_FULL : 0) | (h->dense_off ? VRG_SWEEP_NODENSE : 0);

@@ -587,6 +587,7 @@ VRG_HD void vrg_count_change(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t
     const int p = (c.st->iter + 1) & 1;
     uint32_t dw, sh; vrg_cls_pos(idx, dw, sh);
     const uint32_t x = (a ^ b) << sh;
+    if (a == 0u) vrg_atomic_or(&c.ubits[idx >> 15], 1u << ((idx >> 10) & 31u));   // (before the class bits: a listed unit may read as empty, never the reverse)
     vrg_atomic_xor(&c.clsb[p][dw], x);
     uint32_t q = vrg_atomic_add(&c.nchg[p], 1u);
     if (q < c.mcap) { c.chg_dw[p][q] = dw; c.chg_x[p][q] = x; } else vrg_store_i32(&c.st->error, 7);
@@ -624,6 +625,20 @@ VRG_HD void vrg_item_cls_build(const VrgCtx& c, uint32_t d) {
             if (idx < c.PV) w |= vrg_cls_of(c.lab[0][idx]) << (2u * (4u * j + b));
         }
     c.clsb[0][d] = w; c.clsb[1][d] = w;
+    if (w) vrg_atomic_or(&c.ubits[d >> 11], 1u << ((d >> 6) & 31u));     // (the bitmap was zeroed before)
+}
+// cost of unit u to the dense pass, in 128-byte lines: its class words (2) + every intensity line that holds an included
+// voxel (`lpl` lanes of 4 voxels share a line); 0 for a unit that is not listed.  cls = one of the class copies.
+VRG_HD uint32_t vrg_unit_cost(const VrgCtx& c, const uint32_t* cls, uint32_t u, uint32_t lpl) {
+    if (!((c.ubits[u >> 5] >> (u & 31u)) & 1u)) return 0u;
+    uint32_t lines = 2u;
+    for (uint32_t j = 0; j < 4u; j++)
+        for (uint32_t g = 0; g < 64u; g += lpl) {
+            bool any = false;
+            for (uint32_t l = g; l < g + lpl; l++) any = any || ((cls[((size_t)u << 6) + l] >> (8u * j)) & 0xffu);
+            lines += any ? 1u : 0u;
+        }
+    return lines;
 }
 // one caller per applied sweep: the labels of sweep iter+1 are in place, a dense pass over them is due
 VRG_HD void vrg_request_dense(const VrgCtx& c) { c.gate[VG_REQ] = (int64_t)c.st->iter + 1; }

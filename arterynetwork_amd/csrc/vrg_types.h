@@ -107,6 +107,7 @@ enum { VG_REQ = 0, VG_STOP = 1 };
 // Z-slabs the partial sums of several recounts are all-reduced together, so VD_SEQ trails VD_RSEQ); VD_ERR: a pass
 // disagreed with the incremental sizes; VD_NST: entries of the staged all-reduce
 enum { VD_SEQ = 0, VD_ERR = 1, VD_RSEQ = 2, VD_NST = 3 };
+enum { VRG_MAX_DENSE_WAVES = 16384 };              // recount waves a work split is made for at most
 enum { VRG_RING = 64, VRG_STAGE = 16 };           // sweeps a recount result / expected size is kept for; slab sums per all-reduce
 
 struct VrgCtx {
@@ -126,6 +127,15 @@ struct VrgCtx {
     // changes clsb[(k+1) & 1]; each copy therefore receives the class changes of two sweeps at a time - its own and,
     // from the change list of the sweep before (chg_*[(k-1) & 1]), the one it sat out.
     uint32_t* clsb[2];
+    // Which 1024-voxel units hold a voxel of class != 0 at all (one bit per unit, 32 units per word).  Excluded voxels
+    // (label 4) only ever turn into outer ones (:166-168, :177-179) and padding never changes, so bits are only ever SET:
+    // one copy serves both class copies (a unit listed too early is read as all-excluded and adds nothing).  The dense
+    // pass visits only the listed units: the 54 % of the bench volume outside the brain mask cost it one bit per KiB.
+    uint32_t* ubits;
+    // Dense pass, work split: wave w of the recount owns the whole units [wrange[w], wrange[w+1]) of the slab - contiguous
+    // ranges of equal cost (class words + intensity lines to fetch), computed when init has built the class bits.
+    uint32_t* wrange;
+    uint32_t nwr;              // waves the split was made for (the recount is launched with exactly that many)
     uint32_t mcap;             // capacity of the marked-voxel list and of the class-change lists
     uint32_t* chg_dw[2];       // per sweep parity: dword index ...
     uint32_t* chg_x[2];        // ... and xor mask of every class change that sweep made

@@ -228,20 +228,30 @@ def test_hostmodel_16bit_storage(hm, golden_loader, name):
 
 def dense_bytes_by_definition(labels, line_voxels=32):
     """The bytes one dense pass has to fetch for a label volume [x][y][z], from the documented layout (DESIGN.md
-    section 3/4): padded x-fastest volume, 256 B of class words per 1024-voxel unit that the slab's planes touch +
-    128 B for every aligned run of `line_voxels` voxels (one cache line of intensities) that holds an included
-    (label != 4) voxel."""
+    section 3/4): padded x-fastest volume; per 32 whole 1024-voxel units of the slab 4 B of unit bitmap; 256 B of class
+    words per unit that holds an included (label != 4) voxel (the units the slab's faces cut: always) + 128 B for every
+    aligned run of `line_voxels` voxels (one cache line of intensities) that holds an included voxel."""
     nx, ny, nz = labels.shape
     PX, PY = (nx + 2 + 15) // 16 * 16, ny + 4
     pad = np.zeros(((nz + 4) * PY * PX + 2048,), dtype=bool)
     vol = pad[:(nz + 4) * PY * PX].reshape(nz + 4, PY, PX)
     vol[2:nz + 2, 2:ny + 2, :nx] = np.transpose(labels != 4, (2, 1, 0))
     lo, hi = 2 * PY * PX, (nz + 2) * PY * PX
-    units = ((hi - 1) >> 10) - (lo >> 10) + 1
+    f_lo, f_hi = (lo + 1023) >> 10, hi >> 10
+    f_hi = max(f_hi, f_lo)
+    listed = pad[:(len(pad) // 1024) * 1024].reshape(-1, 1024).any(axis=1)
+    nbytes = 0
+    for u in range(lo >> 10, ((hi - 1) >> 10) + 1):
+        whole = f_lo <= u < f_hi
+        if whole and u % 32 == 0:
+            nbytes += 4
+        if whole and not listed[u]:
+            continue
+        nbytes += 256
     first = (lo // line_voxels) * line_voxels
     last = -(-hi // line_voxels) * line_voxels
     lines = pad[first:last].reshape(-1, line_voxels).any(axis=1).sum()
-    return 256 * units + 128 * int(lines)
+    return nbytes + 128 * int(lines)
 
 
 def test_hostmodel_dense_bytes_counter(hm):
