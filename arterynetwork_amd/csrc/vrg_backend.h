@@ -79,6 +79,7 @@ void be_events_collect(VrgBackend* b, VrgEvents* ev, long long n_valid);
 // be_partition fills c.wrange[0 .. nw] (contiguous unit ranges of equal cost, from the class bits and the unit bitmap).
 // The engine keeps c.nwr = nw; the recount is launched with exactly c.nwr waves.
 uint32_t be_dense_waves(VrgBackend* b, const VrgCtx& c);
+uint32_t be_partition_key(VrgBackend* b, const VrgCtx& c);    // changes whenever an option the split depends on does
 void be_partition(VrgBackend* b, const VrgCtx& c, uint32_t nw);
 
 // dense recount of the class histograms (verification aid)

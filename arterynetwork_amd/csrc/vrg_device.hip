@@ -60,6 +60,8 @@ struct VrgBackend {
     uint64_t pass_bytes = 0;                          // bytes a dense pass fetches, counted at the end of init (0: not known yet)
     uint32_t band_hint = 0;                           // pool slots in use when the engine last read the state (0: unknown)
     int direct_hint = 1;                              // ... and whether corrections are then evaluated entry by entry (8 lanes per slot)
+    uint32_t cost_floor = 14;                         // option "dense_cost_floor": least cost of a listed unit in the dense pass's work split, in 128-B lines
+    int dense_units = 3;                              // option "dense_units": units a recount wave fetches per trip (3 or 6; fp32 storage)
 };
 
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess && !b->err[0]) { \
@@ -941,7 +943,7 @@ __device__ __forceinline__ void load_vals(const VrgCtx& c, uint32_t u, uint32_t 
 // bandwidth for a quarter of its life).  SKIP = false lists every unit of the range; each lane then makes the same
 // additions in the same order (a unit that is not listed holds class 0 only and would add +0.0): bit-identical sums.
 constexpr uint32_t RL_CAP = 512;        // units a wave lists at a time
-constexpr uint32_t RL_PAD = 8;          // room for the sentinel units that round a list up to whole trips + the prefetch past its end
+constexpr uint32_t RL_PAD = 12;         // room for the sentinel units that round a list up to whole trips + the prefetch past its end
 template <int UNITS, bool NT, int MODE, bool SKIP>
 __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) {
     if (check_done && !vrg_dense_due(c)) return;     // k_gate let it through without a sweep to count: the run has stopped
@@ -986,7 +988,7 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
             pos = ((pos >> 5) + nfit) << 5;
             if (nfit < 64u || pos >= ub) break;                               // the list is full / the range is done
         }
-        if (lane < RL_PAD) list[n + lane] = 0u;                               // sentinel: unit 0 is padding (class 0), always readable
+        if (lane < RL_PAD) list[n + lane] = ua;                               // past the end: any readable unit (its class words are masked off below)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // (one wave: its LDS accesses are in order)
         // ---- walk the list, UNITS at a time; the class words of a trip are fetched one trip ahead (the intensity loads
         // depend on them), before this trip's intensities: loads return in order, so they cost no wait of their own
@@ -994,11 +996,13 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
 #pragma unroll
         for (int q = 0; q < UNITS; q++) { uu[q] = __builtin_amdgcn_readfirstlane(list[q]); w[q] = load_cls<NT>(cls, uu[q], lane); }
 #pragma unroll
-        for (int q = 0; q < UNITS; q++) asm volatile("" : "+v"(w[q]));        // settle the first trip's class words here: no waits in mid-loop
+        for (int q = 0; q < UNITS; q++) { asm volatile("" : "+v"(w[q])); if ((uint32_t)q >= n) w[q] = 0u; }   // settle the first trip's class words here: no waits in mid-loop
         for (uint32_t i = 0; i < n; i += UNITS) {
             uint32_t un[UNITS], wn[UNITS];
 #pragma unroll
             for (int q = 0; q < UNITS; q++) { un[q] = __builtin_amdgcn_readfirstlane(list[i + UNITS + q]); wn[q] = load_cls<NT>(cls, un[q], lane); }
+#pragma unroll
+            for (int q = 0; q < UNITS; q++) if (i + UNITS + q >= n) wn[q] = 0u;   // (uniform: a trip's slots beyond the list hold nothing)
             UnitVals<MODE> f[UNITS];
 #pragma unroll
             for (int q = 0; q < UNITS; q++) load_vals<MODE, NT, SKIP>(c, uu[q], lane, w[q], f[q]);
@@ -1026,7 +1030,10 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
 }
 // ---- the work split of the dense pass (init, and whenever the number of recount waves changes) ----------------------------
 // cost of every whole unit of the slab (vrg_unit_cost; 0 outside it), one wave per unit
-__global__ void __launch_bounds__(TPB) k_unit_cost(VrgCtx c, uint32_t* cost, uint32_t nu) {
+// floor_lines: what a unit costs at least - a trip is one memory round trip however little it fetches, so a wave whose
+// range is all short chords (near the rim of the brain mask) must not get three times the units of one inside it;
+// all_units (skip_excluded = 0): every whole unit is streamed in full.
+__global__ void __launch_bounds__(TPB) k_unit_cost(VrgCtx c, uint32_t* cost, uint32_t nu, uint32_t floor_lines, int all_units) {
     const uint32_t* __restrict__ cls = c.clsb[0];
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
     const uint32_t lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
@@ -1036,13 +1043,15 @@ __global__ void __launch_bounds__(TPB) k_unit_cost(VrgCtx c, uint32_t* cost, uin
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t u = wave; u < nu; u += nwaves) {
         uint32_t lines = 0u;
-        if (u >= f_lo && u < f_hi && ((c.ubits[u >> 5] >> (u & 31u)) & 1u)) {
+        if (u >= f_lo && u < f_hi && all_units) lines = 2u + 256u / lpl;
+        else if (u >= f_lo && u < f_hi && ((c.ubits[u >> 5] >> (u & 31u)) & 1u)) {
             const uint32_t w = cls[((size_t)u << 6) + lane];
             lines = 2u;
             for (int j = 0; j < 4; j++) {
                 const uint64_t m = __ballot(((w >> (8 * j)) & 0xffu) != 0u);
                 for (uint32_t g = 0; g < 64u; g += lpl) lines += ((m >> g) & ((1ull << lpl) - 1ull)) ? 1u : 0u;
             }
+            lines = lines < floor_lines ? floor_lines : lines;
         }
         if (lane == 0) cost[u] = lines;
     }
@@ -1367,6 +1376,8 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "nt_loads") == 0) b->nt_loads = v < 0 ? -1 : (v != 0);
     if (std::strcmp(name, "band_hint") == 0) b->band_hint = (uint32_t)std::min<long long>(std::max<long long>(v, 0), 0x7fffffff);
     if (std::strcmp(name, "direct_hint") == 0) b->direct_hint = v != 0;
+    if (std::strcmp(name, "dense_units") == 0 && (v == 3 || v == 6)) b->dense_units = (int)v;
+    if (std::strcmp(name, "dense_cost_floor") == 0 && v >= 0 && v <= 64) b->cost_floor = (uint32_t)v;
     if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)std::min<long long>(v, NF_SMALL);
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != b->prio_mode) { b->prio_mode = (int)v; make_streams(b); }
 }
@@ -1559,29 +1570,34 @@ int be_comm_init(VrgBackend* b, int nranks, int rank, const void* id128) {
 // The start / stop events ride on the dispatch itself (hipExtLaunchKernel): no separate event packets in the stream,
 // which cost ~4 us each between two back-to-back recounts.
 template <bool NT, bool SKIP>
-static void launch_recount_as(const VrgCtx& c, int blocks, int check, hipStream_t st, hipEvent_t e_start, hipEvent_t e_stop) {
+static void launch_recount_as(const VrgCtx& c, int blocks, int check, hipStream_t st, hipEvent_t e_start, hipEvent_t e_stop, int units) {
+    if constexpr (SKIP) {
+        if (c.I && !c.lev16 && units == 6) { hipExtLaunchKernelGGL((k_recount_bits<6, NT, 0, true>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check); return; }
+    }
     if (c.lev16) hipExtLaunchKernelGGL((k_recount_bits<3, NT, 1, SKIP>), dim3(blocks), dim3(TPB), c.L * sizeof(float), st, e_start, e_stop, 0, c, check);
     else if (c.I) hipExtLaunchKernelGGL((k_recount_bits<3, NT, 0, SKIP>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
     else hipExtLaunchKernelGGL((k_recount_bits<2, NT, 2, SKIP>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
 }
 // nt: non-temporal loads - for a pass that is larger than the 256-MiB Infinity Cache, where nothing is worth keeping;
 // a smaller slab is read with ordinary loads and then comes out of that cache sweep after sweep.
-static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t st, bool skip, bool nt, hipEvent_t e_start = nullptr, hipEvent_t e_stop = nullptr) {
+static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t st, bool skip, bool nt, hipEvent_t e_start = nullptr, hipEvent_t e_stop = nullptr, int units = 3) {
     if (check) k_gate<<<1, 64, 0, st>>>(c);        // waits (on the device) until the sweep's labels are in place
-    if (skip) { if (nt) launch_recount_as<true, true>(c, blocks, check, st, e_start, e_stop); else launch_recount_as<false, true>(c, blocks, check, st, e_start, e_stop); }
-    else { if (nt) launch_recount_as<true, false>(c, blocks, check, st, e_start, e_stop); else launch_recount_as<false, false>(c, blocks, check, st, e_start, e_stop); }
+    if (skip) { if (nt) launch_recount_as<true, true>(c, blocks, check, st, e_start, e_stop, units); else launch_recount_as<false, true>(c, blocks, check, st, e_start, e_stop, units); }
+    else { if (nt) launch_recount_as<true, false>(c, blocks, check, st, e_start, e_stop, units); else launch_recount_as<false, false>(c, blocks, check, st, e_start, e_stop, units); }
 }
 
 // The work split of the dense pass (VrgCtx::wrange): whole units of the slab in contiguous ranges of equal cost, one per
 // recount wave.  Needs the class bits and the unit bitmap (k_cls_build); stream A.
 uint32_t be_dense_waves(VrgBackend* b, const VrgCtx& c) { return (uint32_t)dense_blocks(b, c) * (TPB / 64); }
+// identifies the option set a work split depends on (waves, cost floor, skip mode): the engine splits again when it changes
+uint32_t be_partition_key(VrgBackend* b, const VrgCtx& c) { return be_dense_waves(b, c) * 256u + b->cost_floor * 2u + (b->skip ? 1u : 0u); }
 void be_partition(VrgBackend* b, const VrgCtx& c, uint32_t nw) {
     use_device(b);
     const uint32_t nu = (uint32_t)(((uint64_t)c.PV + 1023u) >> 10);
     uint32_t *cost = nullptr, *cum = nullptr; void* tmp = nullptr; size_t tb = 0;
     HIP_CHECK(hipMalloc(&cost, (size_t)nu * 4)); HIP_CHECK(hipMalloc(&cum, (size_t)nu * 4));
     if (!cost || !cum) { if (cost) (void)hipFree(cost); if (cum) (void)hipFree(cum); if (!b->err[0]) std::snprintf(b->err, sizeof(b->err), "out of device memory (dense work split)"); return; }
-    k_unit_cost<<<1024, TPB, 0, b->sa>>>(c, cost, nu);
+    k_unit_cost<<<1024, TPB, 0, b->sa>>>(c, cost, nu, b->cost_floor, b->skip ? 0 : 1);
     HIP_CHECK(rocprim::inclusive_scan(nullptr, tb, cost, cum, nu, rocprim::plus<uint32_t>(), b->sa));
     HIP_CHECK(hipMalloc(&tmp, tb ? tb : 4));
     HIP_CHECK(rocprim::inclusive_scan(tmp, tb, cost, cum, nu, rocprim::plus<uint32_t>(), b->sa));
@@ -1706,7 +1722,7 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
     // device for another one could then wait for ever, so the host orders the two streams instead.)
     if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sa));
     const bool ranks = c.world > 1 || b->comm || cb;
-    launch_recount(c, (int)(c.nwr / (TPB / 64)), ranks ? 1 : 2, b->sb, b->skip != 0, dense_nt(b, c), e_start, e_stop);
+    launch_recount(c, (int)(c.nwr / (TPB / 64)), ranks ? 1 : 2, b->sb, b->skip != 0, dense_nt(b, c), e_start, e_stop, b->dense_units);
     if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sb));
     // one GPU: the last workgroup of the recount closes the pass itself.  Z-slabs: the slab sums of DENSE_GROUP recounts
     // are summed over the ranks by ONE all-reduce (nothing on the band side waits for it: the decisions use the

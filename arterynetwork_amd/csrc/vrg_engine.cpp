@@ -42,6 +42,7 @@ struct vrg_handle {
     void* reduce_user = nullptr;
     long long bails[4] = {0, 0, 0, 0};   // how often a trip came back, by VBAIL_* reason
     long long sync_trips = 0;
+    uint32_t part_key = 0;               // option set the dense pass's work split was made for
 };
 
 extern "C" void API(destroy)(vrg_handle* h);
@@ -220,7 +221,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "events") h->ev.enabled = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20);
     else if (n == "dense_off") h->dense_off = value != 0;   // measurement aid: band chain alone; re-initialise afterwards
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
-    else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads") be_set_tuning(h->be, name, value);
+    else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads" || n == "dense_cost_floor" || n == "dense_units") be_set_tuning(h->be, name, value);
     else if (n == "storage16") h->storage16 = value != 0;      // takes effect at the next vrg_init
     else return fail(h, VRG_E_ARG, "unknown option " + n);
     return VRG_OK;
@@ -333,6 +334,7 @@ int API(init)(vrg_handle* h, double H) {
     be_fill(be, c.p_flag, 0, c.bcap);
     be_fill(be, c.ubits, 0, (h->PVu / 1024 / 32 + 64) * sizeof(uint32_t));     // rebuilt from the labels by be_init_finish
     c.nwr = std::min<uint32_t>(be_dense_waves(be, c), VRG_MAX_DENSE_WAVES);
+    h->part_key = be_partition_key(be, c);
     be_init_finish(be, c, h->reduce_fn, h->reduce_user);
     s = get_state(h);
     int rc = check_state_error(h, s);
@@ -358,7 +360,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     put_state(h, s);
     {   // an option changed the number of recount waves since the work split was made: split again
         const uint32_t nw = std::min<uint32_t>(be_dense_waves(be, c), VRG_MAX_DENSE_WAVES);
-        if (nw != c.nwr) { be_sync(be); c.nwr = nw; be_partition(be, c, nw); }
+        if (nw != c.nwr || be_partition_key(be, c) != h->part_key) { be_sync(be); c.nwr = nw; be_partition(be, c, nw); h->part_key = be_partition_key(be, c); }
     }
     double ms0 = h->ev.ms_total; long long l0 = h->ev.launches;
     auto t_begin = std::chrono::steady_clock::now();

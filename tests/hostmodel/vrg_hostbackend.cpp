@@ -232,6 +232,7 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents*, be_red
 
 void be_events_collect(VrgBackend*, VrgEvents*, long long) {}
 uint32_t be_dense_waves(VrgBackend*, const VrgCtx&) { return 4; }
+uint32_t be_partition_key(VrgBackend*, const VrgCtx&) { return 4; }
 void be_partition(VrgBackend*, const VrgCtx& c, uint32_t nw) {     // (the model recounts its slab in one loop; the split is checked for shape only)
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX, lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
     uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10;
