@@ -75,13 +75,6 @@ int be_comm_init(VrgBackend* b, int nranks, int rank, const void* id128);
 // fold the HIP-event pairs recorded since the last call into ev (only the first n_valid were real sweeps)
 void be_events_collect(VrgBackend* b, VrgEvents* ev, long long n_valid);
 
-// Work split of the dense pass: be_dense_waves = recount waves the backend would launch for this slab / option set;
-// be_partition fills c.wrange[0 .. nw] (contiguous unit ranges of equal cost, from the class bits and the unit bitmap).
-// The engine keeps c.nwr = nw; the recount is launched with exactly c.nwr waves.
-uint32_t be_dense_waves(VrgBackend* b, const VrgCtx& c);
-uint32_t be_partition_key(VrgBackend* b, const VrgCtx& c);    // changes whenever an option the split depends on does
-void be_partition(VrgBackend* b, const VrgCtx& c, uint32_t nw);
-
 // dense recount of the class histograms (verification aid)
 void be_recount_hist(VrgBackend* b, const VrgCtx& c, int32_t* rin, int32_t* rout);
 // bytes one dense pass requests from memory with the current labels: class words + the 128-byte intensity lines that

@@ -60,8 +60,6 @@ struct VrgBackend {
     uint64_t pass_bytes = 0;                          // bytes a dense pass fetches, counted at the end of init (0: not known yet)
     uint32_t band_hint = 0;                           // pool slots in use when the engine last read the state (0: unknown)
     int direct_hint = 1;                              // ... and whether corrections are then evaluated entry by entry (8 lanes per slot)
-    uint32_t cost_floor = 14;                         // option "dense_cost_floor": least cost of a listed unit in the dense pass's work split, in 128-B lines
-    int dense_units = 3;                              // option "dense_units": units a recount wave fetches per trip (3 or 6; fp32 storage)
 };
 
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess && !b->err[0]) { \
@@ -434,7 +432,7 @@ __device__ __forceinline__ bool gate_dense_due(const VrgCtx& c) {
         if (wall_clock64() - t0 > SPIN_LIMIT) { c.dctl[VD_ERR] = 10; return false; }
     }
 }
-__global__ void k_gate(VrgCtx c) { if (threadIdx.x == 0) (void)gate_dense_due(c); }
+
 __global__ void k_wait_dense(VrgCtx c) { if (threadIdx.x == 0) wait_dense_read(c); }
 
 constexpr int KO_THREADS = 256;
@@ -935,28 +933,31 @@ __device__ __forceinline__ void load_vals(const VrgCtx& c, uint32_t u, uint32_t 
         }
     }
 }
-// Work split: wave w owns the whole units [wrange[w], wrange[w+1]) of the slab, contiguous ranges of equal cost made at
-// init (k_unit_cost / k_wrange).  It lists the non-empty units of its range (VrgCtx::ubits: one bit per unit, scanned 64
-// words = 2048 units at a time) into an LDS list of its own and then walks that list UNITS at a time: every trip fetches
-// units that hold included voxels - no trip is spent on the class words of the 54 % of the bench volume outside the brain
-// mask (such trips moved 768 B per memory round trip: a wave crossing the outside of the mask added nothing to the
-// bandwidth for a quarter of its life).  SKIP = false lists every unit of the range; each lane then makes the same
-// additions in the same order (a unit that is not listed holds class 0 only and would add +0.0): bit-identical sums.
-constexpr uint32_t RL_CAP = 512;        // units a wave lists at a time
-constexpr uint32_t RL_PAD = 12;         // room for the sentinel units that round a list up to whole trips + the prefetch past its end
+// The pass walks the LIST of units that hold an included voxel (VrgCtx::ulist, ascending; the 28 % of the bench volume's
+// units that lie wholly outside the brain mask are never visited), all waves in formation: trip t of wave w takes
+// entries (t * nwaves + w) * UNITS ..., so neighbouring waves read neighbouring units at about the same time and memory
+// sees one dense sweep through the volume.  (Measured at 880x880x640: each wave streaming a contiguous range of its own
+// - same bytes, every trip useful - took 0.20-0.37 ms by how the ranges were cut; in formation 0.177; the all-units walk
+// of round 2, which fetched the class words of the empty units too, 0.19.)
+// SKIP = false (option skip_excluded = 0): the listed units are walked the same way with unpredicated loads - each lane
+// makes the same additions in the same order, a class-0 voxel adding +0.0: bit-identical sums - and the units that are
+// not listed are streamed afterwards for their bytes only.
 template <int UNITS, bool NT, int MODE, bool SKIP>
 __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) {
     if (check_done && !vrg_dense_due(c)) return;     // k_gate let it through without a sweep to count: the run has stopped
     extern __shared__ float s_val[];        // 16-bit storage: the level values (c.L floats, sized at launch)
-    __shared__ uint32_t s_list[TPB / 64][RL_CAP + RL_PAD];
-    static_assert(2 * UNITS <= (int)RL_PAD, "list padding");
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    // (the range travels with everything else a wave reads first)
-    uint32_t ua = 0, ub = 0;
-    if (wave < c.nwr) { ua = c.wrange[wave]; ub = c.wrange[wave + 1]; }
+    const uint32_t* __restrict__ ulist = c.ulist;
+    const uint32_t n = c.uctl[UC_N];
+    const uint32_t last = n ? n - 1u : 0u;
+    uint32_t i = wave * UNITS;
+    // (the first trip's units travel with everything else a wave reads first)
+    uint32_t uu[UNITS];
+#pragma unroll
+    for (int q = 0; q < UNITS; q++) uu[q] = ulist[min(i + q, last)];
     if (MODE == 1) {
-        for (uint32_t i = threadIdx.x; i < c.L; i += TPB) s_val[i] = (float)c.lev[i];
+        for (uint32_t k = threadIdx.x; k < c.L; k += TPB) s_val[k] = (float)c.lev[k];
         __syncthreads();
     }
     const uint32_t* __restrict__ cls = c.clsb[(vrg_load_i64(&c.dctl[VD_RSEQ]) + 1) & 1];
@@ -965,51 +966,39 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
     const uint32_t hi = (2u + (uint32_t)c.z1) * plane;
     uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10;       // units wholly inside it
     if (f_hi < f_lo) f_hi = f_lo;
-    ua = __builtin_amdgcn_readfirstlane(ua); ub = __builtin_amdgcn_readfirstlane(ub);
-    volatile uint32_t* list = s_list[wv];
     SweepAcc acc = {0, 0, 0.0, 0.0};
-    for (uint32_t pos = ua; pos < ub;) {
-        // ---- list the next non-empty units of [pos, ub): lane l takes the 32 units of bitmap word (pos >> 5) + l
-        uint32_t n = 0;
-        for (;;) {
-            const uint32_t wi = (pos >> 5) + lane, u0 = wi << 5;
-            uint32_t bits = 0u;
-            if (u0 < ub) bits = SKIP ? c.ubits[wi] : 0xffffffffu;
-            if (u0 < pos) bits &= 0xffffffffu << (pos - u0);                  // (lane 0 of a range's first round)
-            if (u0 < ub && ub - u0 < 32u) bits &= (1u << (ub - u0)) - 1u;
-            const uint32_t cnt = __popc(bits), incl = wave_incl_scan(cnt);
-            const bool fits = n + incl <= RL_CAP;                              // (true for a prefix of the lanes)
-            const uint32_t nfit = (uint32_t)__popcll(__ballot(fits));
-            if (fits) {
-                uint32_t q = n + incl - cnt;
-                while (bits) { list[q++] = u0 + vrg_ctz(bits); bits &= bits - 1u; }
-            }
-            n += nfit ? (uint32_t)__shfl((int)incl, (int)nfit - 1, 64) : 0u;
-            pos = ((pos >> 5) + nfit) << 5;
-            if (nfit < 64u || pos >= ub) break;                               // the list is full / the range is done
-        }
-        if (lane < RL_PAD) list[n + lane] = ua;                               // past the end: any readable unit (its class words are masked off below)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // (one wave: its LDS accesses are in order)
-        // ---- walk the list, UNITS at a time; the class words of a trip are fetched one trip ahead (the intensity loads
-        // depend on them), before this trip's intensities: loads return in order, so they cost no wait of their own
-        uint32_t uu[UNITS], w[UNITS];
+    // the class words of a trip are fetched one trip ahead (the intensity loads depend on them), before this trip's
+    // intensities: loads return in order, so they cost no wait of their own
+    uint32_t w[UNITS];
 #pragma unroll
-        for (int q = 0; q < UNITS; q++) { uu[q] = __builtin_amdgcn_readfirstlane(list[q]); w[q] = load_cls<NT>(cls, uu[q], lane); }
+    for (int q = 0; q < UNITS; q++) { uu[q] = __builtin_amdgcn_readfirstlane(uu[q]); w[q] = load_cls<NT>(cls, uu[q], lane); }
 #pragma unroll
-        for (int q = 0; q < UNITS; q++) { asm volatile("" : "+v"(w[q])); if ((uint32_t)q >= n) w[q] = 0u; }   // settle the first trip's class words here: no waits in mid-loop
-        for (uint32_t i = 0; i < n; i += UNITS) {
-            uint32_t un[UNITS], wn[UNITS];
+    for (int q = 0; q < UNITS; q++) { asm volatile("" : "+v"(w[q])); if (i + q >= n) w[q] = 0u; }   // settle the first trip's class words here: no waits in mid-loop
+    while (i < n) {
+        const uint32_t in = i + nwaves * UNITS;
+        uint32_t un[UNITS], wn[UNITS];
 #pragma unroll
-            for (int q = 0; q < UNITS; q++) { un[q] = __builtin_amdgcn_readfirstlane(list[i + UNITS + q]); wn[q] = load_cls<NT>(cls, un[q], lane); }
+        for (int q = 0; q < UNITS; q++) { un[q] = __builtin_amdgcn_readfirstlane(ulist[min(in + q, last)]); wn[q] = load_cls<NT>(cls, un[q], lane); }
 #pragma unroll
-            for (int q = 0; q < UNITS; q++) if (i + UNITS + q >= n) wn[q] = 0u;   // (uniform: a trip's slots beyond the list hold nothing)
-            UnitVals<MODE> f[UNITS];
+        for (int q = 0; q < UNITS; q++) if (in + q >= n) wn[q] = 0u;          // (uniform: slots past the list's end hold nothing)
+        UnitVals<MODE> f[UNITS];
 #pragma unroll
-            for (int q = 0; q < UNITS; q++) load_vals<MODE, NT, SKIP>(c, uu[q], lane, w[q], f[q]);
+        for (int q = 0; q < UNITS; q++) load_vals<MODE, NT, SKIP>(c, uu[q], lane, w[q], f[q]);
 #pragma unroll
-            for (int q = 0; q < UNITS; q++) stats_bits<MODE, SKIP>(acc, w[q], f[q], s_val);
+        for (int q = 0; q < UNITS; q++) stats_bits<MODE, SKIP>(acc, w[q], f[q], s_val);
 #pragma unroll
-            for (int q = 0; q < UNITS; q++) { w[q] = wn[q]; uu[q] = un[q]; }
+        for (int q = 0; q < UNITS; q++) { w[q] = wn[q]; uu[q] = un[q]; }
+        i = in;
+    }
+    if (!SKIP) {                                               // the bytes of the units that are not listed (they add nothing)
+        for (uint32_t u = f_lo + wave; u < f_hi; u += nwaves) {
+            if ((c.ubits[u >> 5] >> (u & 31u)) & 1u) continue;
+            UnitVals<MODE> f;
+            const uint32_t w1 = load_cls<NT>(cls, u, lane);
+            load_vals<MODE, NT, false>(c, u, lane, w1, f);
+            if constexpr (MODE == 1) { asm volatile("" :: "v"(f.q[0]), "v"(f.q[1]), "v"(f.q[2]), "v"(f.q[3]), "v"(w1)); }
+            else if constexpr (MODE == 2) { asm volatile("" :: "v"(f.f[0][0]), "v"(f.f[1][1]), "v"(f.f[2][0]), "v"(f.f[3][1]), "v"(f.f[0][1]), "v"(f.f[1][0]), "v"(f.f[2][1]), "v"(f.f[3][0]), "v"(w1)); }
+            else { asm volatile("" :: "v"(f.f[0]), "v"(f.f[1]), "v"(f.f[2]), "v"(f.f[3]), "v"(w1)); }
         }
     }
     // units the slab edges cut: the first and the last unit touching [lo, hi), masked to the slab
@@ -1028,62 +1017,61 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
     }
     sweep_finish(c, acc, check_done);
 }
-// ---- the work split of the dense pass (init, and whenever the number of recount waves changes) ----------------------------
-// cost of every whole unit of the slab (vrg_unit_cost; 0 outside it), one wave per unit
-// floor_lines: what a unit costs at least - a trip is one memory round trip however little it fetches, so a wave whose
-// range is all short chords (near the rim of the brain mask) must not get three times the units of one inside it;
-// all_units (skip_excluded = 0): every whole unit is streamed in full.
-__global__ void __launch_bounds__(TPB) k_unit_cost(VrgCtx c, uint32_t* cost, uint32_t nu, uint32_t floor_lines, int all_units) {
-    const uint32_t* __restrict__ cls = c.clsb[0];
-    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
-    const uint32_t lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
+// The unit list from the bitmap, by one workgroup of 1024 threads (a few microseconds): thread t counts the set bits of
+// its stretch of bitmap words, a block scan gives its place, it writes its units.  Bitmap words are read past L1 / a
+// stale L2 line (sc1): band kernels of the other stream set bits with device-scope atomics.
+constexpr int GATE_THREADS = 1024;
+__device__ void ulist_refresh(const VrgCtx& c, bool force) {
+    __shared__ uint32_t s_part[GATE_THREADS / 64];
+    __shared__ uint32_t s_gen;
+    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) s_gen = vrg_load_u32(&c.uctl[UC_GEN]);
+    __syncthreads();
+    const uint32_t g = s_gen;
+    if (!force && c.uctl[UC_LGEN] == g) return;                // (only this stream writes UC_LGEN; uniform)
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX, lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
     uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10;
     if (f_hi < f_lo) f_hi = f_lo;
-    const uint32_t lpl = c.lev16 ? 16u : (c.I ? 8u : 4u), lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t u = wave; u < nu; u += nwaves) {
-        uint32_t lines = 0u;
-        if (u >= f_lo && u < f_hi && all_units) lines = 2u + 256u / lpl;
-        else if (u >= f_lo && u < f_hi && ((c.ubits[u >> 5] >> (u & 31u)) & 1u)) {
-            const uint32_t w = cls[((size_t)u << 6) + lane];
-            lines = 2u;
-            for (int j = 0; j < 4; j++) {
-                const uint64_t m = __ballot(((w >> (8 * j)) & 0xffu) != 0u);
-                for (uint32_t g = 0; g < 64u; g += lpl) lines += ((m >> g) & ((1ull << lpl) - 1ull)) ? 1u : 0u;
-            }
-            lines = lines < floor_lines ? floor_lines : lines;
-        }
-        if (lane == 0) cost[u] = lines;
+    const uint32_t w0 = f_lo >> 5, w1 = (f_hi + 31u) >> 5, nwords = w1 - w0;
+    const uint32_t per = (nwords + GATE_THREADS - 1) / GATE_THREADS;
+    const uint32_t a = w0 + t * per, b = min(a + per, w1);
+    auto word = [&](uint32_t wi) -> uint32_t {
+        uint32_t bits = vrg_load_u32(&c.ubits[wi]);
+        const uint32_t u0 = wi << 5;
+        if (u0 < f_lo) bits &= 0xffffffffu << (f_lo - u0);
+        if (f_hi - u0 < 32u) bits &= (1u << (f_hi - u0)) - 1u;
+        return bits;
+    };
+    uint32_t cnt = 0;
+    for (uint32_t wi = a; wi < b; wi++) cnt += __popc(word(wi));
+    const uint32_t incl = wave_incl_scan(cnt);
+    if (lane == 63) s_part[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int k = 0; k < GATE_THREADS / 64; k++) { if (k < (int)wv) base += s_part[k]; total += s_part[k]; }
+    uint32_t q = base + incl - cnt;
+    for (uint32_t wi = a; wi < b; wi++) {
+        uint32_t bits = word(wi);
+        while (bits) { c.ulist[q++] = (wi << 5) + vrg_ctz(bits); bits &= bits - 1u; }
     }
+    if (t == 0) { c.uctl[UC_N] = total; c.uctl[UC_LGEN] = g; }
 }
-// boundary i of nw + 1: the first unit whose cumulative cost reaches i / nw of the total (cum = inclusive scan of cost)
-__global__ void k_wrange(VrgCtx c, const uint32_t* cum, uint32_t nu, uint32_t nw) {
-    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
-    const uint32_t lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
-    uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10;
-    if (f_hi < f_lo) f_hi = f_lo;
-    const uint64_t total = nu ? cum[nu - 1] : 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= nw; i += gridDim.x * blockDim.x) {
-        uint32_t r;
-        if (i == 0) r = f_lo;
-        else if (i == nw) r = f_hi;
-        else {
-            const uint64_t target = total * i / nw;                    // units [0, r) cost <= target
-            uint32_t a = 0, b = nu;                                    // first u with cum[u] > target
-            while (a < b) { const uint32_t m = (a + b) >> 1; if ((uint64_t)cum[m] > target) b = m; else a = m + 1; }
-            r = a < f_lo ? f_lo : (a > f_hi ? f_hi : a);
-        }
-        c.wrange[i] = r;
-    }
+__global__ void __launch_bounds__(GATE_THREADS) k_ulist_init(VrgCtx c) { ulist_refresh(c, true); }
+// in front of every recount (dense stream): wait for the sweep's labels, then bring the unit list up to date if that sweep
+// (or an earlier one) listed a new unit - rare: label 4 turns into 3 only next to the band
+__global__ void __launch_bounds__(GATE_THREADS) k_gate(VrgCtx c) {
+    if (threadIdx.x == 0) (void)gate_dense_due(c);
+    __syncthreads();
+    ulist_refresh(c, false);
 }
 __global__ void k_cls_build(VrgCtx c) {
     const uint32_t nd = (uint32_t)((((uint64_t)c.PV + 1023u) >> 10) << 6);
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < nd; d += gridDim.x * blockDim.x) vrg_item_cls_build(c, d);
 }
 
-// Bytes one dense pass requests from memory for the class copy the last pass read: 4 B of unit bitmap per 32 units of the
-// slab + 256 B of class words per listed unit (the units the slab's faces cut: always) + every 128-byte intensity line
-// that holds an included voxel (what k_recount_bits<.., SKIP> fetches).
+// Bytes one dense pass requests from memory for the class copy the last pass read: per listed unit its list entry (4 B)
+// and its class words (256 B; the units the slab's faces cut: always) + every 128-byte intensity line that holds an
+// included voxel (what k_recount_bits<.., SKIP> fetches).
 __global__ void __launch_bounds__(TPB) k_dense_bytes(VrgCtx c, unsigned long long* out) {
     const uint32_t* __restrict__ cls = c.clsb[vrg_load_i64(&c.dctl[VD_RSEQ]) & 1];
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
@@ -1097,10 +1085,9 @@ __global__ void __launch_bounds__(TPB) k_dense_bytes(VrgCtx c, unsigned long lon
     unsigned long long bytes = 0;
     for (uint32_t u = e0 + wave; u <= e1; u += nwaves) {
         const bool whole = u >= f_lo && u < f_hi;
-        if (whole && (u & 31u) == 0u) bytes += 4u;                  // (the bitmap word of these 32 units)
         if (whole && !((c.ubits[u >> 5] >> (u & 31u)) & 1u)) continue;
         uint32_t w = cls[((size_t)u << 6) + lane];
-        bytes += 256u;
+        bytes += whole ? 260u : 256u;                               // class words (+ the unit's list entry)
         for (int j = 0; j < 4; j++) {
             const uint32_t v = (u << 10) + (j << 8) + (lane << 2);
             const bool need = v >= lo && v < hi && ((w >> (8 * j)) & 0xffu) != 0u;
@@ -1309,7 +1296,7 @@ int dense_blocks(const VrgBackend* b, const VrgCtx& c) {
     // bytes per trip) 8; measured in DESIGN.md section 5.  Streaming pass (skip_excluded = 0): 1 resp. 2 workgroups per CU.
     if (!b->skip) return (int)std::min<uint64_t>(c.lev16 ? 2 * SWEEP_BLOCKS : SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128));
     return (int)(c.lev16 ? std::min<uint64_t>(8 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 48))
-                         : std::min<uint64_t>(3 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128)));
+                         : std::min<uint64_t>(3 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 64)));
 }
 
 void use_device(VrgBackend* b) { HIP_CHECK(hipSetDevice(b->device)); }
@@ -1376,8 +1363,6 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "nt_loads") == 0) b->nt_loads = v < 0 ? -1 : (v != 0);
     if (std::strcmp(name, "band_hint") == 0) b->band_hint = (uint32_t)std::min<long long>(std::max<long long>(v, 0), 0x7fffffff);
     if (std::strcmp(name, "direct_hint") == 0) b->direct_hint = v != 0;
-    if (std::strcmp(name, "dense_units") == 0 && (v == 3 || v == 6)) b->dense_units = (int)v;
-    if (std::strcmp(name, "dense_cost_floor") == 0 && v >= 0 && v <= 64) b->cost_floor = (uint32_t)v;
     if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)std::min<long long>(v, NF_SMALL);
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != b->prio_mode) { b->prio_mode = (int)v; make_streams(b); }
 }
@@ -1570,40 +1555,17 @@ int be_comm_init(VrgBackend* b, int nranks, int rank, const void* id128) {
 // The start / stop events ride on the dispatch itself (hipExtLaunchKernel): no separate event packets in the stream,
 // which cost ~4 us each between two back-to-back recounts.
 template <bool NT, bool SKIP>
-static void launch_recount_as(const VrgCtx& c, int blocks, int check, hipStream_t st, hipEvent_t e_start, hipEvent_t e_stop, int units) {
-    if constexpr (SKIP) {
-        if (c.I && !c.lev16 && units == 6) { hipExtLaunchKernelGGL((k_recount_bits<6, NT, 0, true>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check); return; }
-    }
+static void launch_recount_as(const VrgCtx& c, int blocks, int check, hipStream_t st, hipEvent_t e_start, hipEvent_t e_stop) {
     if (c.lev16) hipExtLaunchKernelGGL((k_recount_bits<3, NT, 1, SKIP>), dim3(blocks), dim3(TPB), c.L * sizeof(float), st, e_start, e_stop, 0, c, check);
     else if (c.I) hipExtLaunchKernelGGL((k_recount_bits<3, NT, 0, SKIP>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
     else hipExtLaunchKernelGGL((k_recount_bits<2, NT, 2, SKIP>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
 }
 // nt: non-temporal loads - for a pass that is larger than the 256-MiB Infinity Cache, where nothing is worth keeping;
 // a smaller slab is read with ordinary loads and then comes out of that cache sweep after sweep.
-static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t st, bool skip, bool nt, hipEvent_t e_start = nullptr, hipEvent_t e_stop = nullptr, int units = 3) {
-    if (check) k_gate<<<1, 64, 0, st>>>(c);        // waits (on the device) until the sweep's labels are in place
-    if (skip) { if (nt) launch_recount_as<true, true>(c, blocks, check, st, e_start, e_stop, units); else launch_recount_as<false, true>(c, blocks, check, st, e_start, e_stop, units); }
-    else { if (nt) launch_recount_as<true, false>(c, blocks, check, st, e_start, e_stop, units); else launch_recount_as<false, false>(c, blocks, check, st, e_start, e_stop, units); }
-}
-
-// The work split of the dense pass (VrgCtx::wrange): whole units of the slab in contiguous ranges of equal cost, one per
-// recount wave.  Needs the class bits and the unit bitmap (k_cls_build); stream A.
-uint32_t be_dense_waves(VrgBackend* b, const VrgCtx& c) { return (uint32_t)dense_blocks(b, c) * (TPB / 64); }
-// identifies the option set a work split depends on (waves, cost floor, skip mode): the engine splits again when it changes
-uint32_t be_partition_key(VrgBackend* b, const VrgCtx& c) { return be_dense_waves(b, c) * 256u + b->cost_floor * 2u + (b->skip ? 1u : 0u); }
-void be_partition(VrgBackend* b, const VrgCtx& c, uint32_t nw) {
-    use_device(b);
-    const uint32_t nu = (uint32_t)(((uint64_t)c.PV + 1023u) >> 10);
-    uint32_t *cost = nullptr, *cum = nullptr; void* tmp = nullptr; size_t tb = 0;
-    HIP_CHECK(hipMalloc(&cost, (size_t)nu * 4)); HIP_CHECK(hipMalloc(&cum, (size_t)nu * 4));
-    if (!cost || !cum) { if (cost) (void)hipFree(cost); if (cum) (void)hipFree(cum); if (!b->err[0]) std::snprintf(b->err, sizeof(b->err), "out of device memory (dense work split)"); return; }
-    k_unit_cost<<<1024, TPB, 0, b->sa>>>(c, cost, nu, b->cost_floor, b->skip ? 0 : 1);
-    HIP_CHECK(rocprim::inclusive_scan(nullptr, tb, cost, cum, nu, rocprim::plus<uint32_t>(), b->sa));
-    HIP_CHECK(hipMalloc(&tmp, tb ? tb : 4));
-    HIP_CHECK(rocprim::inclusive_scan(tmp, tb, cost, cum, nu, rocprim::plus<uint32_t>(), b->sa));
-    k_wrange<<<(nw + 1 + TPB - 1) / TPB, TPB, 0, b->sa>>>(c, cum, nu, nw);
-    HIP_CHECK(hipStreamSynchronize(b->sa));
-    HIP_CHECK(hipFree(cost)); HIP_CHECK(hipFree(cum)); if (tmp) HIP_CHECK(hipFree(tmp));
+static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t st, bool skip, bool nt, hipEvent_t e_start = nullptr, hipEvent_t e_stop = nullptr) {
+    if (check) k_gate<<<1, GATE_THREADS, 0, st>>>(c);        // waits (on the device) until the sweep's labels are in place; keeps the unit list current
+    if (skip) { if (nt) launch_recount_as<true, true>(c, blocks, check, st, e_start, e_stop); else launch_recount_as<false, true>(c, blocks, check, st, e_start, e_stop); }
+    else { if (nt) launch_recount_as<true, false>(c, blocks, check, st, e_start, e_stop); else launch_recount_as<false, false>(c, blocks, check, st, e_start, e_stop); }
 }
 
 void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
@@ -1615,8 +1577,8 @@ void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
     else k_hist_voxel<<<voxel_blocks(c), TPB, 0, b->sa>>>(c);
     k_exact_init<<<1024, TPB, 0, b->sa>>>(c);
     k_cls_build<<<2048, TPB, 0, b->sa>>>(c);
-    be_partition(b, c, c.nwr);
-    launch_recount(c, (int)(c.nwr / (TPB / 64)), 0, b->sa, b->skip != 0, dense_nt(b, c));
+    k_ulist_init<<<1, GATE_THREADS, 0, b->sa>>>(c);
+    launch_recount(c, dense_blocks(b, c), 0, b->sa, b->skip != 0, dense_nt(b, c));
     reduce_dense(b, c, cb, user, b->sa);
     k_fin_init<<<1, 1, 0, b->sa>>>(c);
     b->pass_bytes = be_dense_bytes(b, c);       // (decides between ordinary and non-temporal loads for the sweeps' passes)
@@ -1722,7 +1684,7 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
     // device for another one could then wait for ever, so the host orders the two streams instead.)
     if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sa));
     const bool ranks = c.world > 1 || b->comm || cb;
-    launch_recount(c, (int)(c.nwr / (TPB / 64)), ranks ? 1 : 2, b->sb, b->skip != 0, dense_nt(b, c), e_start, e_stop, b->dense_units);
+    launch_recount(c, dense_blocks(b, c), ranks ? 1 : 2, b->sb, b->skip != 0, dense_nt(b, c), e_start, e_stop);
     if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sb));
     // one GPU: the last workgroup of the recount closes the pass itself.  Z-slabs: the slab sums of DENSE_GROUP recounts
     // are summed over the ranks by ONE all-reduce (nothing on the band side waits for it: the decisions use the

@@ -42,7 +42,6 @@ struct vrg_handle {
     void* reduce_user = nullptr;
     long long bails[4] = {0, 0, 0, 0};   // how often a trip came back, by VBAIL_* reason
     long long sync_trips = 0;
-    uint32_t part_key = 0;               // option set the dense pass's work split was made for
 };
 
 extern "C" void API(destroy)(vrg_handle* h);
@@ -166,7 +165,8 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.clsb[0] = alloc<uint32_t>(h, PVu / 16); c.clsb[1] = alloc<uint32_t>(h, PVu / 16);
     c.nchg = alloc<uint32_t>(h, 32);
     c.ubits = alloc<uint32_t>(h, PVu / 1024 / 32 + 64);
-    c.wrange = alloc<uint32_t>(h, VRG_MAX_DENSE_WAVES + 1);
+    c.ulist = alloc<uint32_t>(h, PVu / 1024 + 64);
+    c.uctl = alloc<uint32_t>(h, 64);
     c.vent = alloc<uint32_t>(h, PVu);
     // 16 guard bytes in front: voxel (0,0,0)'s 2-ring reaches 2 bytes before the padded array
     h->lab_base[0] = alloc<uint8_t>(h, (size_t)c.PV + 32);
@@ -187,7 +187,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.trace = alloc<VrgTrace>(h, c.trace_cap);
     c.world = 1;
     if (!c.lab[0] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.gate || !c.dn_ring || !c.exp_ring || !c.stage_in || !c.stage_out || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
-        !c.nchg || !c.ubits || !c.wrange || !c.vent || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace) { API(destroy)(h); return VRG_E_MEM; }
+        !c.nchg || !c.ubits || !c.ulist || !c.uctl || !c.vent || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace) { API(destroy)(h); return VRG_E_MEM; }
     be_fill(be, c.inc, 0, 32 * sizeof(int64_t)); be_fill(be, c.dctl, 0, 32 * sizeof(int64_t)); be_fill(be, c.gate, 0, 32 * sizeof(int64_t));
     be_fill(be, c.clsb[0], 0, PVu / 4); be_fill(be, c.clsb[1], 0, PVu / 4);
     be_fill(be, c.nchg, 0, 32 * sizeof(uint32_t));
@@ -221,7 +221,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "events") h->ev.enabled = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20);
     else if (n == "dense_off") h->dense_off = value != 0;   // measurement aid: band chain alone; re-initialise afterwards
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
-    else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads" || n == "dense_cost_floor" || n == "dense_units") be_set_tuning(h->be, name, value);
+    else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads") be_set_tuning(h->be, name, value);
     else if (n == "storage16") h->storage16 = value != 0;      // takes effect at the next vrg_init
     else return fail(h, VRG_E_ARG, "unknown option " + n);
     return VRG_OK;
@@ -333,8 +333,7 @@ int API(init)(vrg_handle* h, double H) {
     put_state(h, s);
     be_fill(be, c.p_flag, 0, c.bcap);
     be_fill(be, c.ubits, 0, (h->PVu / 1024 / 32 + 64) * sizeof(uint32_t));     // rebuilt from the labels by be_init_finish
-    c.nwr = std::min<uint32_t>(be_dense_waves(be, c), VRG_MAX_DENSE_WAVES);
-    h->part_key = be_partition_key(be, c);
+    be_fill(be, c.uctl, 0, 64 * sizeof(uint32_t));
     be_init_finish(be, c, h->reduce_fn, h->reduce_user);
     s = get_state(h);
     int rc = check_state_error(h, s);
@@ -358,10 +357,6 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     s.done = 0; s.time_up = 0; s.bail = 0; s.iterMax = (int32_t)iterMax; s.maxSegmentSize = maxSegmentSize;
     s.nf = 0; s.npend = 0; s.nmk = 0;                    // counters of a trip that stopped before update()
     put_state(h, s);
-    {   // an option changed the number of recount waves since the work split was made: split again
-        const uint32_t nw = std::min<uint32_t>(be_dense_waves(be, c), VRG_MAX_DENSE_WAVES);
-        if (nw != c.nwr || be_partition_key(be, c) != h->part_key) { be_sync(be); c.nwr = nw; be_partition(be, c, nw); h->part_key = be_partition_key(be, c); }
-    }
     double ms0 = h->ev.ms_total; long long l0 = h->ev.launches;
     auto t_begin = std::chrono::steady_clock::now();
     const int base_flags = ((h->variant & 1) ? VRG_SWEEP_FULL : 0) | (h->dense_off ? VRG_SWEEP_NODENSE : 0);

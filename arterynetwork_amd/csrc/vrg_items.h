@@ -587,7 +587,10 @@ VRG_HD void vrg_count_change(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t
     const int p = (c.st->iter + 1) & 1;
     uint32_t dw, sh; vrg_cls_pos(idx, dw, sh);
     const uint32_t x = (a ^ b) << sh;
-    if (a == 0u) vrg_atomic_or(&c.ubits[idx >> 15], 1u << ((idx >> 10) & 31u));   // (before the class bits: a listed unit may read as empty, never the reverse)
+    if (a == 0u) {             // (before the class bits: a listed unit may read as empty, never the reverse)
+        const uint32_t bit = 1u << ((idx >> 10) & 31u);
+        if (!(vrg_atomic_or(&c.ubits[idx >> 15], bit) & bit)) vrg_atomic_add(&c.uctl[UC_GEN], 1u);   // first to list the unit: the unit list is out of date
+    }
     vrg_atomic_xor(&c.clsb[p][dw], x);
     uint32_t q = vrg_atomic_add(&c.nchg[p], 1u);
     if (q < c.mcap) { c.chg_dw[p][q] = dw; c.chg_x[p][q] = x; } else vrg_store_i32(&c.st->error, 7);
@@ -627,18 +630,13 @@ VRG_HD void vrg_item_cls_build(const VrgCtx& c, uint32_t d) {
     c.clsb[0][d] = w; c.clsb[1][d] = w;
     if (w) vrg_atomic_or(&c.ubits[d >> 11], 1u << ((d >> 6) & 31u));     // (the bitmap was zeroed before)
 }
-// cost of unit u to the dense pass, in 128-byte lines: its class words (2) + every intensity line that holds an included
-// voxel (`lpl` lanes of 4 voxels share a line); 0 for a unit that is not listed.  cls = one of the class copies.
-VRG_HD uint32_t vrg_unit_cost(const VrgCtx& c, const uint32_t* cls, uint32_t u, uint32_t lpl) {
-    if (!((c.ubits[u >> 5] >> (u & 31u)) & 1u)) return 0u;
-    uint32_t lines = 2u;
-    for (uint32_t j = 0; j < 4u; j++)
-        for (uint32_t g = 0; g < 64u; g += lpl) {
-            bool any = false;
-            for (uint32_t l = g; l < g + lpl; l++) any = any || ((cls[((size_t)u << 6) + l] >> (8u * j)) & 0xffu);
-            lines += any ? 1u : 0u;
-        }
-    return lines;
+// the unit list from the bitmap, sequentially (init of the test model; the device builds it in parallel: ulist_refresh)
+VRG_HD void vrg_ulist_rebuild_serial(const VrgCtx& c) {
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX, lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
+    uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10, n = 0;
+    const uint32_t g = c.uctl[UC_GEN];
+    for (uint32_t u = f_lo; u < f_hi; u++) if ((c.ubits[u >> 5] >> (u & 31u)) & 1u) c.ulist[n++] = u;
+    c.uctl[UC_N] = n; c.uctl[UC_LGEN] = g;
 }
 // one caller per applied sweep: the labels of sweep iter+1 are in place, a dense pass over them is due
 VRG_HD void vrg_request_dense(const VrgCtx& c) { c.gate[VG_REQ] = (int64_t)c.st->iter + 1; }

@@ -107,7 +107,7 @@ enum { VG_REQ = 0, VG_STOP = 1 };
 // Z-slabs the partial sums of several recounts are all-reduced together, so VD_SEQ trails VD_RSEQ); VD_ERR: a pass
 // disagreed with the incremental sizes; VD_NST: entries of the staged all-reduce
 enum { VD_SEQ = 0, VD_ERR = 1, VD_RSEQ = 2, VD_NST = 3 };
-enum { VRG_MAX_DENSE_WAVES = 16384 };              // recount waves a work split is made for at most
+enum { UC_N = 0, UC_LGEN = 1, UC_GEN = 16 };       // VrgCtx::uctl
 enum { VRG_RING = 64, VRG_STAGE = 16 };           // sweeps a recount result / expected size is kept for; slab sums per all-reduce
 
 struct VrgCtx {
@@ -132,10 +132,12 @@ struct VrgCtx {
     // one copy serves both class copies (a unit listed too early is read as all-excluded and adds nothing).  The dense
     // pass visits only the listed units: the 54 % of the bench volume outside the brain mask cost it one bit per KiB.
     uint32_t* ubits;
-    // Dense pass, work split: wave w of the recount owns the whole units [wrange[w], wrange[w+1]) of the slab - contiguous
-    // ranges of equal cost (class words + intensity lines to fetch), computed when init has built the class bits.
-    uint32_t* wrange;
-    uint32_t nwr;              // waves the split was made for (the recount is launched with exactly that many)
+    // The listed units of this device's slab (whole units only) in ascending order: what the dense pass walks, all its
+    // waves in formation (trip t of wave w takes entries (t * nwaves + w) * UNITS ...).  Rebuilt from the bitmap by the
+    // dense stream's gate kernel whenever a sweep listed a new unit (uctl[UC_GEN] != uctl[UC_LGEN]): always sorted, so the
+    // order of the sums does not depend on which thread listed a unit first.
+    uint32_t* ulist;
+    uint32_t* uctl;            // UC_*: list length, generation the list was built at | generation of the bitmap (own cache line)
     uint32_t mcap;             // capacity of the marked-voxel list and of the class-change lists
     uint32_t* chg_dw[2];       // per sweep parity: dword index ...
     uint32_t* chg_x[2];        // ... and xor mask of every class change that sweep made

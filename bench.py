@@ -209,8 +209,6 @@ def main():
     ap.add_argument('--nt-loads', type=int, default=-1, help='dense pass: -1 = non-temporal loads when the pass exceeds the Infinity Cache (default), 0 / 1 = never / always')
     ap.add_argument('--serial', type=int, default=0, help='1: option serial_streams (needed under rocprofv3 --pmc, which runs one kernel at a time)')
     ap.add_argument('--storage16', action='store_true', help='16-bit intensity storage (level indices): config 5 style; 4 B/voxel-iter algorithmic')
-    ap.add_argument('--cost-floor', type=int, default=-1, help='experiment: option dense_cost_floor (least cost of a listed unit in the dense work split, in 128-B lines)')
-    ap.add_argument('--dense-units', type=int, default=0, help='experiment: option dense_units (3 or 6 units per recount trip)')
     ap.add_argument('--force-dist', action='store_true', help='use the N>1 code path (RCCL comm) even with one rank')
     args = ap.parse_args()
     shape = tuple(int(s) for s in args.shape.lower().split('x'))
@@ -262,10 +260,6 @@ def main():
         s.set_option('serial_streams', 1)
     s.set_option('skip_excluded', args.skip_excluded)
     s.set_option('nt_loads', args.nt_loads)
-    if args.cost_floor >= 0:
-        s.set_option('dense_cost_floor', args.cost_floor)
-    if args.dense_units:
-        s.set_option('dense_units', args.dense_units)
     s.set_volume_ptr(I.data_ptr(), np.float32, [st for st in I.stride()])
     s.set_labels_ptr(vm.data_ptr(), np.uint8, [st for st in vm.stride()])
     t0 = time.perf_counter()

@@ -124,12 +124,17 @@ void be_init_sort(VrgBackend*, const VrgCtx& c, uint32_t n_in, uint32_t n_out) {
 static void dense_stats(const VrgCtx& c, const uint8_t* lab, be_reduce_fn cb, void* user) {
     int64_t a = 0, b = 0; double sa = 0, sb = 0;
     const uint32_t* cls = c.clsb[(c.dctl[VD_RSEQ] + 1) & 1];
+    if (c.uctl[UC_LGEN] != c.uctl[UC_GEN]) vrg_ulist_rebuild_serial(c);          // (the device: k_gate, before every recount)
+    std::vector<uint8_t> in_list((((size_t)c.PV + 1023) >> 10) + 1, 0);
+    for (uint32_t i = 0; i < c.uctl[UC_N]; i++) { if (i && c.ulist[i] <= c.ulist[i - 1]) c.st->error = 6; in_list[c.ulist[i]] = 1; }
+    const uint32_t plane_ = (uint32_t)c.PY * (uint32_t)c.PX, lo_ = (2u + (uint32_t)c.z0) * plane_, hi_ = (2u + (uint32_t)c.z1) * plane_;
+    const uint32_t f_lo_ = (uint32_t)(((uint64_t)lo_ + 1023u) >> 10), f_hi_ = hi_ >> 10;
     for_real_voxels(c, [&](uint32_t idx, int, int, int z) {
         if (z < c.z0 || z >= c.z1) return;
         uint32_t dw, sh; vrg_cls_pos(idx, dw, sh);
         uint32_t k = (cls[dw] >> sh) & 3u;                   // the dense pass reads its copy of the class bits ...
         if (k != vrg_cls_of(lab[idx])) c.st->error = 6;      // ... which every label write must have kept in step
-        if (k != 0u && !((c.ubits[idx >> 15] >> ((idx >> 10) & 31u)) & 1u)) c.st->error = 6;   // ... and visits listed units only
+        if (k != 0u && (idx >> 10) >= f_lo_ && (idx >> 10) < f_hi_ && !in_list[idx >> 10]) c.st->error = 6;   // ... and walks the unit list only
         double v = c.lev16 ? (c.I ? (double)(float)c.lev[c.lev16[idx]] : c.lev[c.lev16[idx]]) : vrg_voxel_value(c, idx);
         if (k == 1u) { a++; sa += v; }
         else if (k == 2u) { b++; sb += v; }
@@ -140,7 +145,6 @@ static void dense_stats(const VrgCtx& c, const uint8_t* lab, be_reduce_fn cb, vo
     if (cb) cb(&c.dn->n_in, user);
 }
 
-void be_partition(VrgBackend*, const VrgCtx& c, uint32_t nw);
 void be_init_finish(VrgBackend*, const VrgCtx& c, be_reduce_fn cb, void* user) {
     VrgState& s = *c.st;
     uint32_t n = s.ni + s.no;
@@ -148,8 +152,7 @@ void be_init_finish(VrgBackend*, const VrgCtx& c, be_reduce_fn cb, void* user) {
     for_real_voxels(c, [&](uint32_t idx, int, int, int) { vrg_item_hist_voxel(c, idx); });
     for (uint32_t i = 0; i < n; i++) vrg_exact_serial(c, s, c.fresh[i], false);
     for (uint32_t d = 0; d < (((c.PV + 1023u) >> 10) << 6); d++) vrg_item_cls_build(c, d);
-    be_partition(nullptr, c, c.nwr);
-    for (uint32_t i = 0; i < c.nwr; i++) if (c.wrange[i] > c.wrange[i + 1]) s.error = 6;
+    vrg_ulist_rebuild_serial(c);
     dense_stats(c, c.lab[0], cb, user);
     s.np = n; s.nfree = 0; s.nfresh = 0; s.nfx = 0; s.nf = 0; s.npend = 0; s.nmk = 0; s.nnz = 0; s.nalloc = 0; s.ndead = 0;
     s.d_ni = 0; s.d_no = 0; s.corr = 0; s.use_tab = 0; s.bail = 0;
@@ -231,24 +234,6 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents*, be_red
 }
 
 void be_events_collect(VrgBackend*, VrgEvents*, long long) {}
-uint32_t be_dense_waves(VrgBackend*, const VrgCtx&) { return 4; }
-uint32_t be_partition_key(VrgBackend*, const VrgCtx&) { return 4; }
-void be_partition(VrgBackend*, const VrgCtx& c, uint32_t nw) {     // (the model recounts its slab in one loop; the split is checked for shape only)
-    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX, lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
-    uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10;
-    if (f_hi < f_lo) f_hi = f_lo;
-    uint64_t total = 0;
-    const uint32_t lpl = c.lev16 ? 16u : (c.I ? 8u : 4u);
-    for (uint32_t u = f_lo; u < f_hi; u++) total += vrg_unit_cost(c, c.clsb[0], u, lpl);
-    uint64_t cum = 0; uint32_t u = f_lo;
-    c.wrange[0] = f_lo;
-    for (uint32_t i = 1; i < nw; i++) {
-        const uint64_t target = total * i / nw;
-        while (u < f_hi && cum + vrg_unit_cost(c, c.clsb[0], u, lpl) <= target) cum += vrg_unit_cost(c, c.clsb[0], u++, lpl);
-        c.wrange[i] = u;
-    }
-    c.wrange[nw] = f_hi;
-}
 void be_dense_flush(VrgBackend*, const VrgCtx&, be_reduce_fn, void*) {}
 
 void be_recount_hist(VrgBackend*, const VrgCtx& c, int32_t* rin, int32_t* rout) {
@@ -271,9 +256,8 @@ uint64_t be_dense_bytes(VrgBackend*, const VrgCtx& c) {
     uint64_t bytes = 0;
     for (uint32_t u = lo >> 10; u <= (hi - 1u) >> 10; u++) {
         const bool whole = u >= f_lo && u < f_hi;
-        if (whole && (u & 31u) == 0u) bytes += 4u;
         if (whole && !((c.ubits[u >> 5] >> (u & 31u)) & 1u)) continue;
-        bytes += 256u;
+        bytes += whole ? 260u : 256u;                     // class words (+ the unit's list entry)
         for (int j = 0; j < 4; j++)
             for (uint32_t g = 0; g < 64u; g += lpl) {
                 bool any = false;

@@ -228,8 +228,8 @@ def test_hostmodel_16bit_storage(hm, golden_loader, name):
 
 def dense_bytes_by_definition(labels, line_voxels=32):
     """The bytes one dense pass has to fetch for a label volume [x][y][z], from the documented layout (DESIGN.md
-    section 3/4): padded x-fastest volume; per 32 whole 1024-voxel units of the slab 4 B of unit bitmap; 256 B of class
-    words per unit that holds an included (label != 4) voxel (the units the slab's faces cut: always) + 128 B for every
+    section 3/4): padded x-fastest volume; 256 B of class words (+ 4 B of list entry for a whole unit of the slab) per
+    1024-voxel unit that holds an included (label != 4) voxel (the units the slab's faces cut: always) + 128 B for every
     aligned run of `line_voxels` voxels (one cache line of intensities) that holds an included voxel."""
     nx, ny, nz = labels.shape
     PX, PY = (nx + 2 + 15) // 16 * 16, ny + 4
@@ -243,11 +243,9 @@ def dense_bytes_by_definition(labels, line_voxels=32):
     nbytes = 0
     for u in range(lo >> 10, ((hi - 1) >> 10) + 1):
         whole = f_lo <= u < f_hi
-        if whole and u % 32 == 0:
-            nbytes += 4
         if whole and not listed[u]:
             continue
-        nbytes += 256
+        nbytes += 260 if whole else 256
     first = (lo // line_voxels) * line_voxels
     last = -(-hi // line_voxels) * line_voxels
     lines = pad[first:last].reshape(-1, line_voxels).any(axis=1).sum()

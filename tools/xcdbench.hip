@@ -79,6 +79,59 @@ __global__ void __launch_bounds__(256) k_chain(uint32_t* ctr, uint32_t* payload,
     if (bad) atomicAdd(errs, bad);
 }
 
+// The same chain among the workgroups that find themselves on ONE XCD, without any CU mask: 8 x the workgroups are
+// launched; the first to arrive elects its XCD (CAS on a word), every workgroup adds itself to `started` and - when it
+// sits on the elected XCD - to `members`; the others leave at once.  The first barrier also waits for every launched
+// workgroup to have started, so that `members` is final.  Same-XCD is then a hardware fact each member checked for
+// itself (HW_REG_XCC_ID), not an assumption about the dispatcher: plain stores + L1-bypassing loads meet in that L2.
+// ctl: [0] barrier counter, [16] elected XCD + 1, [32] started, [48] members   (words on cache lines of their own)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_chain_elect(uint32_t* ctl, uint32_t* payload, uint32_t iters, uint32_t* errs, uint32_t* tmo, unsigned long long* ticks, uint32_t* xcc) {
+    __shared__ uint32_t s_me, s_n, s_go;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) {
+        const uint32_t mine = xcc_id() + 1u;
+        uint32_t expected = 0u;
+        __hip_atomic_compare_exchange_strong(ctl + 16, &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t elected = expected ? expected : mine;
+        s_go = elected == mine;
+        s_me = s_go ? __hip_atomic_fetch_add(ctl + 48, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (the member count before the start count)
+        __hip_atomic_fetch_add(ctl + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_go) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(ctl + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) { __builtin_amdgcn_s_sleep(4); if (wall_clock64() - t0 > SPIN_LIMIT) { *tmo = 2; s_go = 0; break; } }
+            s_n = __hip_atomic_load(ctl + 48, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!s_go) return;
+    const uint32_t n = s_n, b = s_me;
+    if (t == 0) { xcc[b] = xcc_id(); if (b == 0) xcc[1023] = n; }
+    uint32_t gen = 0, bad = 0;
+    const unsigned long long t0 = wall_clock64();
+    for (uint32_t it = 1; it <= iters; it++) {
+        if (MODE != 0) {
+            const uint32_t v = it * 4096u + b;
+            uint32_t* p = payload + (size_t)b * 256 + t;
+            if (MODE == 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+        }
+        if (!grid_barrier(ctl, n, ++gen, tmo)) break;
+        if (MODE != 0) {
+            const uint32_t src = (b + 1u) % n;
+            const uint32_t* p = payload + (size_t)src * 256 + t;
+            uint32_t v;
+            if (MODE == 1) v = __builtin_nontemporal_load(p);
+            else if (MODE == 2) v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else v = *(volatile const uint32_t*)p;
+            if (v != it * 4096u + src) bad++;
+        }
+        if (!grid_barrier(ctl, n, ++gen, tmo)) break;
+    }
+    if (t == 0 && b == 0) *ticks = wall_clock64() - t0;
+    if (bad) atomicAdd(errs, bad);
+}
+
 // background load: streams `n` float4 from src with non-temporal loads, `reps` times
 typedef float f4v __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) k_stream(const float4* src_, size_t n, int reps, float* sink) {
@@ -155,8 +208,33 @@ int main(int argc, char** argv) {
                     ticks * 0.01 / iters, mode ? " + store + dependent load" : "", errs, (unsigned long long)iters * nwg * 256, tmo ? "  TIMEOUT" : "");
         return errs;
     };
+    auto run_elect = [&](const char* what, int mode, uint32_t launched, bool loaded) {
+        CK(hipMemset(d_ctr, 0, 256)); CK(hipMemset(d_errs, 0, 4)); CK(hipMemset(d_tmo, 0, 4)); CK(hipMemset(d_payload, 0, 256 * 256 * 4)); CK(hipMemset(d_xcc, 0, 1024 * 4));
+        CK(hipDeviceSynchronize());
+        if (loaded) k_stream<<<1792, 256, 0, s_bg>>>(d_big, big / 16, 300, d_sink);
+        switch (mode) {
+            case 0: k_chain_elect<0><<<launched, 256, 0, s_all>>>(d_ctr, d_payload, iters, d_errs, d_tmo, d_ticks, d_xcc); break;
+            case 1: k_chain_elect<1><<<launched, 256, 0, s_all>>>(d_ctr, d_payload, iters, d_errs, d_tmo, d_ticks, d_xcc); break;
+            case 2: k_chain_elect<2><<<launched, 256, 0, s_all>>>(d_ctr, d_payload, iters, d_errs, d_tmo, d_ticks, d_xcc); break;
+            default: k_chain_elect<3><<<launched, 256, 0, s_all>>>(d_ctr, d_payload, iters, d_errs, d_tmo, d_ticks, d_xcc); break;
+        }
+        CK(hipDeviceSynchronize());
+        uint32_t errs, tmo, n; unsigned long long ticks;
+        CK(hipMemcpy(&errs, d_errs, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&tmo, d_tmo, 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&ticks, d_ticks, 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&n, d_xcc + 1023, 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> x(n ? n : 1); CK(hipMemcpy(x.data(), d_xcc, x.size() * 4, hipMemcpyDeviceToHost));
+        int used = 0, hist[16] = {0}; for (auto v : x) hist[v & 15]++; for (int i = 0; i < 16; i++) used += hist[i] != 0;
+        std::printf("%-58s %3u members of %u launched, on %d XCD(s) %s: %.3f us per iteration (2 barriers%s), errors %u%s\n", what, n, launched, used, loaded ? "beside an HBM stream" : "alone",
+                    ticks * 0.01 / iters, mode ? " + store + dependent load" : "", errs, tmo ? "  TIMEOUT" : "");
+        return errs;
+    };
     int rc = 0;
     for (int loaded = 0; loaded < 2; loaded++) {
+        for (uint32_t launched : {64u, 256u, 512u}) run_elect("ELECTED XCD: barriers only", 0, launched, loaded);
+        for (uint32_t launched : {256u, 512u}) if (run_elect("ELECTED XCD LITMUS plain store -> drain -> barrier -> nt load", 1, launched, loaded)) rc = 1;
+        if (run_elect("ELECTED XCD LITMUS sc1 store -> drain -> barrier -> sc1 load", 2, 256, loaded)) rc = 1;
+        { const uint32_t neg = run_elect("ELECTED XCD NEGATIVE plain store -> barrier -> PLAIN load", 3, 256, loaded);
+          std::printf("   negative variant %s\n", neg ? "failed as expected: the litmus can see a broken protocol" : "showed NO error (litmus blind here?)"); }
         if (s_one) {
             for (uint32_t nwg : {8u, 32u, 64u}) run("barriers only, one XCD", 0, s_one, nwg, loaded, s_rest);
             if (run("LITMUS plain store -> drain -> barrier -> nt load, one XCD", 1, s_one, 32, loaded, s_rest)) rc = 1;
