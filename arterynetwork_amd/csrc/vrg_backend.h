@@ -17,6 +17,10 @@ struct VrgEvents {            // optional HIP-event timing of the dense sweep la
     int enabled;              // 0: off; n > 0: every n-th trip of a batch is timed
     double ms_total;
     long long launches;
+    // ... and of the band chain of a trip (start of k_band to end of k_close, on the band stream, i.e. BESIDE the dense pass)
+    int chain_enabled;
+    double chain_ms_total;
+    long long chain_launches;
 };
 
 VrgBackend* be_create(int device);                             // nullptr: no usable device
@@ -80,5 +84,6 @@ void be_recount_hist(VrgBackend* b, const VrgCtx& c, int32_t* rin, int32_t* rout
 // bytes one dense pass requests from memory with the current labels: class words + the 128-byte intensity lines that
 // hold an included voxel (all lines of the slab with option skip_excluded = 0); measurement aid for the roofline
 uint64_t be_dense_bytes(VrgBackend* b, const VrgCtx& c);
+void be_dense_info(VrgBackend* b, const VrgCtx& c, int64_t out[4]);   // {nt loads, storage mode, workgroups, skip_excluded} of the dense pass
 // (stamp, idx) of every segmented voxel, unordered; returns the count
 uint32_t be_collect_segmented(VrgBackend* b, const VrgCtx& c, uint64_t* stamps, uint32_t* idxs, uint32_t cap);

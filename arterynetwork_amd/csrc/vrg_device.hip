@@ -37,7 +37,7 @@
 #include "vrg_backend.h"
 #include "vrg_items.h"
 
-struct EvPair { hipEvent_t a, b; long long trip; };
+struct EvPair { hipEvent_t a, b; long long trip; int kind; };   // kind 0: a dense launch, 1: a trip's band chain
 
 struct VrgBackend {
     int device = 0;
@@ -703,7 +703,7 @@ __global__ void k_apply(VrgCtx c) {
     const uint32_t nm = min(c.st->nmk, c.mcap);
     ITEM_LOOP(nm + vrg_catchup_count(c)) { if (i < nm) vrg_item_apply(c, i); else vrg_item_catchup(c, i - nm); }
 }
-__global__ void k_close(VrgCtx c, uint32_t nf) {
+__global__ void k_close_items(VrgCtx c, uint32_t nf) {
     ITEM_LOOP(nf) vrg_item_check_flip(c, i);
     ITEM_LOOP(c.st->ndead) vrg_item_free(c, i);
 }
@@ -955,7 +955,7 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
     // (the first trip's units travel with everything else a wave reads first)
     uint32_t uu[UNITS];
 #pragma unroll
-    for (int q = 0; q < UNITS; q++) uu[q] = ulist[min(i + q, last)];
+    for (int q = 0; q < UNITS; q++) uu[q] = i < n ? ulist[min(i + q, last)] : 0u;     // (an empty list has no readable entry)
     if (MODE == 1) {
         for (uint32_t k = threadIdx.x; k < c.L; k += TPB) s_val[k] = (float)c.lev[k];
         __syncthreads();
@@ -971,7 +971,7 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
     // intensities: loads return in order, so they cost no wait of their own
     uint32_t w[UNITS];
 #pragma unroll
-    for (int q = 0; q < UNITS; q++) { uu[q] = __builtin_amdgcn_readfirstlane(uu[q]); w[q] = load_cls<NT>(cls, uu[q], lane); }
+    for (int q = 0; q < UNITS; q++) { uu[q] = __builtin_amdgcn_readfirstlane(uu[q]); w[q] = i < n ? load_cls<NT>(cls, uu[q], lane) : 0u; }
 #pragma unroll
     for (int q = 0; q < UNITS; q++) { asm volatile("" : "+v"(w[q])); if (i + q >= n) w[q] = 0u; }   // settle the first trip's class words here: no waits in mid-loop
     while (i < n) {
@@ -1296,7 +1296,7 @@ int dense_blocks(const VrgBackend* b, const VrgCtx& c) {
     // bytes per trip) 8; measured in DESIGN.md section 5.  Streaming pass (skip_excluded = 0): 1 resp. 2 workgroups per CU.
     if (!b->skip) return (int)std::min<uint64_t>(c.lev16 ? 2 * SWEEP_BLOCKS : SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128));
     return (int)(c.lev16 ? std::min<uint64_t>(8 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 48))
-                         : std::min<uint64_t>(3 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 64)));
+                         : std::min<uint64_t>(3 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128)));
 }
 
 void use_device(VrgBackend* b) { HIP_CHECK(hipSetDevice(b->device)); }
@@ -1617,7 +1617,7 @@ static void host_driven_update(VrgBackend* b, const VrgCtx& c, int flags) {
     if (!(flags & VRG_SWEEP_NODENSE)) k_wait_dense<<<1, 64, 0, b->sa>>>(c);
     if (flags & VRG_SWEEP_FULL) k_copy_back<<<2048, TPB, 0, b->sa>>>(c);
     else k_apply<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c);
-    k_close<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nf);
+    k_close_items<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nf);
     HIP_CHECK(hipMemcpyAsync(&s, c.st, sizeof(s), hipMemcpyDeviceToHost, b->sa));
     HIP_CHECK(hipStreamSynchronize(b->sa));
     const uint32_t nnz = std::min(s.nnz, c.zcap);
@@ -1637,10 +1637,11 @@ static void host_driven_update(VrgBackend* b, const VrgCtx& c, int flags) {
 }
 
 // update() for a sweep with few flips: three launches, nothing from the host in between
-static void small_update(VrgBackend* b, const VrgCtx& c, bool dense) {
+static void small_update(VrgBackend* b, const VrgCtx& c, bool dense, hipEvent_t e_chain_stop = nullptr) {
     k_order<<<1, KO_THREADS, 0, b->sa>>>(c, b->small_flips);
     k_mark_relabel<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c);
-    k_close<<<CLOSE_APPLY + TAB_BLOCKS, KC_THREADS, 0, b->sa>>>(c, dense ? 1 : 0);   // (waits on the device for the dense pass of two sweeps ago)
+    // (waits on the device for the dense pass of two sweeps ago)
+    hipExtLaunchKernelGGL(k_close, dim3(CLOSE_APPLY + TAB_BLOCKS), dim3(KC_THREADS), 0, b->sa, nullptr, e_chain_stop, 0, c, dense ? 1 : 0);
 }
 
 void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_reduce_fn cb, void* user) {
@@ -1648,11 +1649,20 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
     hipEvent_t e_start = nullptr, e_stop = nullptr;
     const bool dense = !(flags & VRG_SWEEP_NODENSE);
     const long long trip = b->ev_trip++;
-    if (dense && ev && ev->enabled > 0 && trip % ev->enabled == 0) {     // (every enabled-th trip: an event pair costs the dense stream a few us)
-        if (b->ev_used == b->ev_pool.size()) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); n.trip = 0; b->ev_pool.push_back(n); }
+    auto take_pair = [&](int kind) -> EvPair& {
+        if (b->ev_used == b->ev_pool.size()) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); n.trip = 0; n.kind = 0; b->ev_pool.push_back(n); }
         EvPair& p = b->ev_pool[b->ev_used++];
-        p.trip = trip;
+        p.trip = trip; p.kind = kind;
+        return p;
+    };
+    if (dense && ev && ev->enabled > 0 && trip % ev->enabled == 0) {     // (every enabled-th trip: an event pair costs the dense stream a few us)
+        EvPair& p = take_pair(0);
         e_start = p.a; e_stop = p.b;
+    }
+    hipEvent_t e_c0 = nullptr, e_c1 = nullptr;                           // the band chain of this trip: k_band's start to k_close's end
+    if (ev && ev->chain_enabled > 0 && !(flags & VRG_SWEEP_SYNC) && trip % ev->chain_enabled == 0) {
+        EvPair& p = take_pair(1);
+        e_c0 = p.a; e_c1 = p.b;
     }
     if ((flags & VRG_SWEEP_SYNC) && c.L > EXACT_BIG_L) {     // huge level table: the pending entries' densities on the whole chip
         VrgState s0;
@@ -1667,7 +1677,7 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
         }
     }
     const uint32_t nbb = band_blocks(b);
-    k_band<<<nbb + EXACT_BLOCKS, TPB, 0, b->sa>>>(c, nbb);
+    hipExtLaunchKernelGGL(k_band, dim3(nbb + EXACT_BLOCKS), dim3(TPB), 0, b->sa, e_c0, nullptr, 0, c, nbb);
     if (flags & VRG_SWEEP_SYNC) {
         VrgState s;
         HIP_CHECK(hipMemcpyAsync(&s, c.st, sizeof(s), hipMemcpyDeviceToHost, b->sa));
@@ -1676,7 +1686,7 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
         if (s.nf > b->small_flips || (flags & VRG_SWEEP_FULL)) host_driven_update(b, c, flags);
         else small_update(b, c, dense);
     } else {
-        small_update(b, c, dense);
+        small_update(b, c, dense, e_c1);
     }
     if (!dense) return;
     // dense stream: every voxel once, read-only; k_gate in front of the recount waits until the sweep's labels are in place.
@@ -1701,11 +1711,13 @@ void be_dense_flush(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
 void be_events_collect(VrgBackend* b, VrgEvents* ev, long long n_valid) {
     if (!ev) return;
     use_device(b);
-    if (b->ev_used) HIP_CHECK(hipStreamSynchronize(b->sb));   // the dense stream may trail the band stream by one pass
+    if (b->ev_used) { HIP_CHECK(hipStreamSynchronize(b->sb)); HIP_CHECK(hipStreamSynchronize(b->sa)); }   // the dense stream may trail the band stream by one pass
     for (size_t i = 0; i < b->ev_used; i++) {
         if (b->ev_pool[i].trip < n_valid) {
             float ms = 0;
-            if (hipEventElapsedTime(&ms, b->ev_pool[i].a, b->ev_pool[i].b) == hipSuccess) { ev->ms_total += ms; ev->launches++; }
+            if (hipEventElapsedTime(&ms, b->ev_pool[i].a, b->ev_pool[i].b) == hipSuccess) {
+                if (b->ev_pool[i].kind == 0) { ev->ms_total += ms; ev->launches++; } else { ev->chain_ms_total += ms; ev->chain_launches++; }
+            }
             else (void)hipGetLastError();
         }
     }
@@ -1718,6 +1730,11 @@ void be_recount_hist(VrgBackend* b, const VrgCtx& c, int32_t* rin, int32_t* rout
     HIP_CHECK(hipStreamSynchronize(b->sa));
 }
 
+// what the dense pass of this handle is launched as: {non-temporal loads, storage mode (0 fp32, 1 u16 level index, 2 f64),
+// workgroups, skip_excluded}
+void be_dense_info(VrgBackend* b, const VrgCtx& c, int64_t out[4]) {
+    out[0] = dense_nt(b, c) ? 1 : 0; out[1] = c.lev16 ? 1 : (c.I ? 0 : 2); out[2] = dense_blocks(b, c); out[3] = b->skip ? 1 : 0;
+}
 uint64_t be_dense_bytes(VrgBackend* b, const VrgCtx& c) {
     use_device(b);
     if (!b->skip) {            // every voxel of the slab's units is streamed

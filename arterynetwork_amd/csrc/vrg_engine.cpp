@@ -33,7 +33,7 @@ struct vrg_handle {
     float* I32 = nullptr; double* I64 = nullptr;
     uint64_t band_capacity = 0;
     uint64_t cap_floor = 1u << 16;       // smallest pool / marked-list capacity (tests lower it to exercise the growth paths)
-    VrgEvents ev{0, 0.0, 0};
+    VrgEvents ev{0, 0.0, 0, 0, 0.0, 0};
     std::chrono::steady_clock::time_point t0;
     int64_t V = 0;
     size_t PVu = 0;
@@ -219,6 +219,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "capacity_floor") { if (h->c.p_idx || value < 1) return fail(h, VRG_E_STATE, "capacity_floor must be set before the first vrg_init"); h->cap_floor = (uint64_t)value; }
     else if (n == "sweep_variant") { if (h->inited) return fail(h, VRG_E_STATE, "sweep_variant must be set before vrg_init"); h->variant = (int)value; }
     else if (n == "events") h->ev.enabled = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20);
+    else if (n == "chain_events") h->ev.chain_enabled = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20);
     else if (n == "dense_off") h->dense_off = value != 0;   // measurement aid: band chain alone; re-initialise afterwards
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
     else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads") be_set_tuning(h->be, name, value);
@@ -339,7 +340,7 @@ int API(init)(vrg_handle* h, double H) {
     int rc = check_state_error(h, s);
     if (rc) return rc;
     h->inited = true; h->sync_mode = false;
-    h->ev.ms_total = 0; h->ev.launches = 0;
+    h->ev.ms_total = 0; h->ev.launches = 0; h->ev.chain_ms_total = 0; h->ev.chain_launches = 0;
     return VRG_OK;
 }
 
@@ -358,6 +359,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     s.nf = 0; s.npend = 0; s.nmk = 0;                    // counters of a trip that stopped before update()
     put_state(h, s);
     double ms0 = h->ev.ms_total; long long l0 = h->ev.launches;
+    double cms0 = h->ev.chain_ms_total; long long cl0 = h->ev.chain_launches;
     auto t_begin = std::chrono::steady_clock::now();
     const int base_flags = ((h->variant & 1) ? VRG_SWEEP_FULL : 0) | (h->dense_off ? VRG_SWEEP_NODENSE : 0);
     const uint32_t small = be_small_flip_limit(be);
@@ -411,6 +413,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
         out->nseg = (int64_t)d.n_in; out->n_in = (int64_t)d.n_in; out->n_out = (int64_t)d.n_out; out->ni = s.ni; out->no = s.no;
         out->sum_in = d.sum_in; out->sum_out = d.sum_out; out->seconds = secs;
         out->sweep_kernel_ms = h->ev.ms_total - ms0; out->sweep_launches = h->ev.launches - l0;
+        out->chain_kernel_ms = h->ev.chain_ms_total - cms0; out->chain_launches = h->ev.chain_launches - cl0;
         out->ties = (int64_t)(uint32_t)(s.ties - ties0); out->near_ties = (int64_t)(uint32_t)(s.near_ties - near0);
     }
     return VRG_OK;
@@ -506,7 +509,9 @@ int API(get_levels)(vrg_handle* h, double* values, int32_t* hin, int32_t* hout, 
 
 // how the run went (diagnostics): out[0..3] = trips handed back {-, flips, marks, pool}, out[4] = host-driven trips,
 // out[5] = pool capacity, out[6] = marked-list capacity, out[7] = pool slots in use; with cap >= 9 also
-// out[8] = bytes one dense pass requests from memory with the current labels (0 before init)
+// out[8] = bytes one dense pass requests from memory with the current labels (0 before init); with cap >= 14 also how the
+// dense pass is launched: out[9] = non-temporal loads, out[10] = storage (0 fp32, 1 u16 level index, 2 f64), out[11] =
+// workgroups, out[12] = skip_excluded, out[13] = listed units
 int API(get_stats)(vrg_handle* h, int64_t* outp, int64_t cap) {
     if (!h || !outp || cap < 8) return VRG_E_ARG;
     for (int i = 0; i < 4; i++) outp[i] = h->bails[i];
@@ -515,6 +520,12 @@ int API(get_stats)(vrg_handle* h, int64_t* outp, int64_t cap) {
     if (cap >= 9) {
         outp[8] = 0;
         if (h->inited) { be_sync(h->be); outp[8] = (int64_t)be_dense_bytes(h->be, h->c); }
+    }
+    if (cap >= 14) {
+        int64_t di[4] = {0, 0, 0, 0};
+        uint32_t uc[2] = {0, 0};
+        if (h->inited) { be_dense_info(h->be, h->c, di); be_download(h->be, uc, h->c.uctl, sizeof(uc)); }
+        outp[9] = di[0]; outp[10] = di[1]; outp[11] = di[2]; outp[12] = di[3]; outp[13] = uc[0];
     }
     return VRG_OK;
 }

@@ -79,25 +79,23 @@ def make_slab_session(shape, rank, world, device=0, lib=None, reduce='rccl', gro
     return s
 
 
-def bench_slabs(shape, args, dev, rank, world, roofline):
-    """bench.py body for N > 1 ranks: every rank generates the same synthetic volume in its HBM, recounts
-    its own Z-slab; barrier + synchronize around exactly K sweeps; MAX over ranks; whole-job throughput.
-    `roofline` is bench.py's roofline(shape, planes, kernel_ms, launches, traffic, storage16, dense_bytes)."""
+def bench_slabs(shape, args, dev, rank, world, roofline, configure, load_traffic):
+    """bench.py body for N > 1 ranks (the twin of its one-GPU body: same options through `configure`): every rank generates
+    the same synthetic volume in its HBM, recounts its own Z-slab; barrier + synchronize around exactly K sweeps; MAX
+    over ranks; whole-job throughput.  `roofline`, `configure`, `load_traffic` are bench.py's."""
     import torch
     import torch.distributed as dist
     from . import phantoms
-    I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels)
+    I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels, brain_mask=not args.no_brain_mask)
     torch.cuda.synchronize()
     V = shape[0] * shape[1] * shape[2]
     s = make_slab_session(shape, rank, world, device=dev.index, reduce='rccl-always')
-    if args.sweep_blocks:
-        s.set_option('sweep_blocks', args.sweep_blocks)
-    s.set_option('events', 4)            # HIP events around every 4th dense launch
-    s.set_option('batch', 64)
-    s.set_option('nt_loads', getattr(args, 'nt_loads', -1))
+    configure(s, args)
     s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
     s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
+    t0 = time.perf_counter()
     s.init(args.H)
+    t_init = time.perf_counter() - t0
     big = 10 ** 15
     r0 = s.run(args.warmup, big, None)
     db0 = s.stats()['dense_bytes']
@@ -108,32 +106,45 @@ def bench_slabs(shape, args, dev, rank, world, roofline):
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
-    dense_bytes = (db0 + s.stats()['dense_bytes']) / 2.0
+    st = s.stats()
+    dense_bytes = (db0 + st['dense_bytes']) / 2.0 if args.skip_excluded else None
     dense_ms = r.sweep_kernel_ms / max(1, r.sweep_launches)
-    t = torch.tensor([dt, dense_ms], dtype=torch.float64, device=dev)
+    chain_beside = r.chain_kernel_ms / r.chain_launches if r.chain_launches else 0.0
+    t = torch.tensor([dt, dense_ms, chain_beside], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max, kern_ms = float(t[0]), float(t[1])
+    dt_max, kern_ms, chain_max = float(t[0]), float(t[1]), float(t[2])
     per_rank = [None] * world
     valid = (r.sweeps == args.steps) and (r0.sweeps == args.warmup)
     tr = s.trace()
+    nlev = s.nlevels()
     chain = s.chain_timing(args.H)               # (last: the session has to be re-initialised after it)
-    dist.all_gather_object(per_rank, {'rank': rank, 'slab': list(s.slab), 'dense_ms': round(dense_ms, 4),
-                                      'band_chain_ms': chain.get('band_chain_ms'), 'seconds': round(dt, 4)})
     z0, z1 = s.slab
+    dist.all_gather_object(per_rank, {'rank': rank, 'slab': [z0, z1], 'dense_ms': round(dense_ms, 4),
+                                      'band_chain_beside_dense_ms': round(chain_beside, 4), 'band_chain_ms': chain.get('band_chain_ms'),
+                                      'seconds': round(dt, 4), 'dense_bytes': int(dense_bytes) if dense_bytes else None,
+                                      'rccl_ranks': s.comm_ranks, 'reduction': s.reduce_mode})
     out = {
         'metric': 'Mvoxel-iters/sec, VRG sweep, {} volume'.format(args.shape),
         'value': round(V * r.sweeps / dt_max / 1e6, 1), 'unit': 'Mvoxel-iter/s', 'n_gpus': world,
         'steps': int(r.sweeps), 'warmup': args.warmup, 'ms_per_step': round(dt_max / max(1, r.sweeps) * 1e3, 4),
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
         'dtype': 'f64', 'data': 'synthetic', 'valid': bool(valid),
-        'config': {'workload': '{} synthetic MRA tube volume ({} intensity levels stored fp32, brain-mask excluded '
-                               'voxels), H={}, {} incremental VRG sweeps'.format(args.shape, args.levels, args.H, r.sweeps),
-                   'parallelism': 'zslab{} (dense recount sharded into {} Z-slabs, band relabel replicated, one '
-                                  '32-byte RCCL all-reduce per sweep)'.format(world, world),
-                   'reduction': s.reduce_mode, 'rccl_ranks': s.comm_ranks,
+        'config': {'workload': '{} synthetic MRA tube volume ({} distinct intensities stored {}, {}), H={}, {} incremental VRG sweeps'.format(
+                       args.shape, nlev, 'as u16 level indices' if args.storage16 else 'fp32',
+                       'no excluded voxels' if args.no_brain_mask else 'brain-mask excluded voxels', args.H, r.sweeps),
+                   'parallelism': 'zslab{} (dense recount sharded into {} Z-slabs; labels and the O(band) relabel replicated on every rank - no halo '
+                                  'plane travels; one RCCL all-reduce of the slab statistics per 8 sweeps)'.format(world, world),
+                   'reduction': s.reduce_mode, 'rccl_ranks': min(p['rccl_ranks'] for p in per_rank),
+                   'intensity_storage': 'u16 level index (2 B/voxel)' if args.storage16 else 'fp32 (4 B/voxel)',
+                   'init_seconds': round(t_init, 3),
                    'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
-                   'dense_ms': round(kern_ms, 4), 'dense_events_every': 4, 'band_chain_ms': chain.get('band_chain_ms'), 'ranks': per_rank},
-        'roofline': roofline(shape, z1 - z0, kern_ms, int(r.sweep_launches), None, False, dense_bytes),
+                   'dense_ms': round(kern_ms, 4), 'dense_events_every': args.events,
+                   'band_chain_beside_dense_ms': round(chain_max, 4) if chain_max else None,
+                   'band_chain_ms': chain.get('band_chain_ms'), 'band_chain_note': chain.get('band_chain_note'),
+                   'dense_pass_loads': 'non-temporal' if st['dense_nt_loads'] else 'ordinary', 'dense_workgroups': st['dense_workgroups'],
+                   'ranks': per_rank},
+        'roofline': roofline(shape, z1 - z0, kern_ms, int(r.sweep_launches), load_traffic(shape, world, args.storage16, z1 - z0),
+                             args.storage16, dense_bytes, st['dense_kernel']),
     }
     s.close()
     return out

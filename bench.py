@@ -43,17 +43,37 @@ def device_source_sha():
     return h.hexdigest()[:16]
 
 
-def load_traffic(shape, n_gpus, storage16):
-    """HBM bytes per dense launch from the committed rocprofv3 PMC passes (profiles/traffic.json) - only when that
-    file was measured on these very kernel sources (src_sha) and workload; None otherwise (never a stale figure)."""
+def load_traffic(shape, n_gpus, storage16, planes=None):
+    """HBM bytes per dense launch from the committed rocprofv3 PMC passes (profiles/traffic.json) - only when an entry was
+    measured on these very kernel sources (src_sha) and workload (shape, ranks, storage, slab planes); None otherwise
+    (never a stale figure)."""
     try:
         t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
-        if (t.get('shape') == list(shape) and t.get('n_gpus', 1) == n_gpus and bool(t.get('storage16', False)) == bool(storage16)
-                and t.get('src_sha') == device_source_sha()):
-            return t.get('hbm_bytes_per_launch')
+        for e in t.get('entries', [t]):
+            if (e.get('shape') == list(shape) and e.get('n_gpus', 1) == n_gpus and bool(e.get('storage16', False)) == bool(storage16)
+                    and e.get('planes', shape[2]) == (planes if planes is not None else shape[2]) and e.get('src_sha') == device_source_sha()):
+                return e.get('hbm_bytes_per_launch')
     except Exception:
         pass
     return None
+
+
+def configure(s, args):
+    """The option set of a bench session, the same for one GPU and for a rank of N."""
+    s.set_option('sweep_variant', args.variant)
+    if args.sweep_blocks:
+        s.set_option('sweep_blocks', args.sweep_blocks)
+    if args.prio_mode >= 0:
+        s.set_option('prio_mode', args.prio_mode)
+    if args.storage16:
+        s.set_option('storage16', 1)
+    s.set_option('events', args.events)
+    s.set_option('chain_events', args.events)
+    s.set_option('batch', 64)
+    if args.serial:
+        s.set_option('serial_streams', 1)
+    s.set_option('skip_excluded', args.skip_excluded)
+    s.set_option('nt_loads', args.nt_loads)
 
 
 def padded_slab_voxels(shape, planes):
@@ -62,7 +82,7 @@ def padded_slab_voxels(shape, planes):
     return ((nx + 2 + 15) // 16 * 16) * (ny + 4) * planes
 
 
-def roofline(shape, planes, kern_ms, launches, traffic, storage16=False, dense_bytes=None):
+def roofline(shape, planes, kern_ms, launches, traffic, storage16=False, dense_bytes=None, kernel=None):
     """Dominant kernel = k_recount_bits (dense region recount, one launch per sweep), HBM-bound.
     `achieved` = the bytes the kernel has to fetch by its own design divided by the HIP-event time of the launch;
     `frac` = achieved / 8 TB/s.  The design bytes are `dense_bytes` when given: counted on the device from the class
@@ -78,7 +98,7 @@ def roofline(shape, planes, kern_ms, launches, traffic, storage16=False, dense_b
     design = float(dense_bytes) if dense_bytes else streamed
     V = shape[0] * shape[1] * planes
     achieved = design / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
-    out = {'bound': 'hbm', 'kernel': 'k_recount_bits<3,true,{},{}>'.format(1 if storage16 else 0, 'true' if dense_bytes else 'false'),
+    out = {'bound': 'hbm', 'kernel': kernel or 'k_recount_bits<3,true,{},{}>'.format(1 if storage16 else 0, 'true' if dense_bytes else 'false'),
            'achieved': round(achieved, 1) if achieved else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
            'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
            'kernel_ms_avg': round(kern_ms, 4), 'launches': launches,
@@ -86,6 +106,11 @@ def roofline(shape, planes, kern_ms, launches, traffic, storage16=False, dense_b
            'bytes_counted_on_device': bool(dense_bytes),
            'streamed_equiv_gbs': round(streamed / (kern_ms * 1e-3) / 1e9, 1) if kern_ms > 0 else None,
            'algorithmic_equiv_gbs': round((4 if storage16 else BYTES_PER_VOXEL_ITER) * V / (kern_ms * 1e-3) / 1e9, 1) if kern_ms > 0 else None,
+           # SURVEY.md section 8(d)'s accounting as the driver would compute it: 6 B x voxels / kernel time / peak.  NOT a
+           # fraction of anything (it exceeds 1): the kernel does not move those bytes - no label write-back, 2 class bits
+           # instead of a label byte, excluded runs not fetched
+           'section8d_frac': round((4 if storage16 else BYTES_PER_VOXEL_ITER) * V / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern_ms > 0 else None,
+           'section8d_note': 'algorithmic 6 B/voxel-iteration of SURVEY 8(d) / kernel time / 8 TB/s; not a fraction (the kernel fetches bytes_per_launch, not 6 B per voxel)',
            'traffic': traffic}
     if traffic and kern_ms > 0:
         out['traffic_gbs'] = round(traffic / (kern_ms * 1e-3) / 1e9, 1)
@@ -103,77 +128,98 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(I_t, vm_t, H, levels_note, budget_s=(8.0, 12.0), max_vox=70e6):
-    """The oracle (oracle/vrg_oracle.c, a C port of the reference; level-histogram mode) timed on this host, with one
-    thread and with all cores (OpenMP build of the same file), on the workload's own volume when it is small enough
-    (config 2) and otherwise on a crop around the seeds.  The sweeps it made are then repeated by the HIP path on the
-    same sample and compared (labels, segmented order, integer trace): `parity`.  Outside the timed region."""
+def cpu_baseline(I_t, vm_t, H, levels_note, min_free_gb=48.0, crop_vox=70e6):
+    """The oracle (oracle/vrg_oracle.c, a C port of the reference; level-histogram mode, OpenMP build of the same file)
+    timed on this host on the WHOLE workload volume (880x880x640: about 20 GB of host memory; when the host has less than
+    `min_free_gb` available, on a crop around the seeds - the line then says so).  One thread first, then candidate thread
+    counts probed for >= 10 sweeps and >= 1 s each (the dense loops are memory-bound and a container may own fewer cores
+    than it sees), then the best one again for >= 20 sweeps: `value` is THAT run's own rate, so it can never sit far below
+    `threads_tried`.  The sweeps the oracle made are then repeated by the HIP path on the same volume and compared
+    (labels, segmented order, integer trace): `parity`.  Outside the timed region."""
+    import psutil
     from oracle import vrg_oracle as O
     from arterynetwork_amd._capi import Session
     nx, ny, nz = I_t.shape
-    if nx * ny * nz <= max_vox:
+    free_gb = psutil.virtual_memory().available / 2 ** 30
+    whole = nx * ny * nz <= crop_vox or free_gb >= min_free_gb
+    if whole:
         cx, cyy, czz, y0, z0 = nx, ny, nz, 0, 0
         what = 'the whole {}x{}x{} volume'.format(nx, ny, nz)
     else:
         cx, cyy, czz = min(nx, 448), min(ny, 448), min(nz, 320)
         y0 = max(0, min(ny - cyy, ny // 2 - cyy // 2))
         z0 = max(0, min(nz - czz, int(nz / 2.0 + 0.18 * nz) - czz // 2))
-        what = 'the {}x{}x{} crop around the seeds of the same volume'.format(cx, cyy, czz)
-    Ic = I_t[:cx, y0:y0 + cyy, z0:z0 + czz].contiguous().cpu().numpy()
+        what = 'the {}x{}x{} crop around the seeds of the same volume (only {:.0f} GB of host memory available)'.format(cx, cyy, czz, free_gb)
+    t_prep = time.perf_counter()
+    Ic32 = I_t[:cx, y0:y0 + cyy, z0:z0 + czz].contiguous().cpu().numpy()
     vm = vm_t[:cx, y0:y0 + cyy, z0:z0 + czz].contiguous().cpu().numpy()
     if not (vm == 0).any():
         return None
-    o = O.Oracle(Ic.astype(np.float64), vm, H, density_mode=1, omp=True)
+    o = O.Oracle(Ic32.astype(np.float64), vm, H, density_mode=1, omp=True)
     try:
         navail = len(os.sched_getaffinity(0))
     except Exception:
         navail = os.cpu_count() or 1
+    o.set_threads(min(navail, 64))
     o.init()
+    t_prep = time.perf_counter() - t_prep
     sweeps = 0
 
-    def timed(threads, budget, cap):
+    def timed(threads, min_sweeps, min_s, cap_s):
+        """>= min_sweeps sweeps and >= min_s seconds (one discarded sweep first), at most cap_s seconds."""
         nonlocal sweeps
         got = o.set_threads(threads)
+        if o.step(10 ** 6, 10 ** 12, -1.0) != 0:
+            return got, 0, 0.0
+        sweeps += 1
         t0 = time.perf_counter()
         n = 0
-        while time.perf_counter() - t0 < budget and n < cap:
+        while True:
+            el = time.perf_counter() - t0
+            if (n >= min_sweeps and el >= min_s) or el >= cap_s:
+                break
             if o.step(10 ** 6, 10 ** 12, -1.0) != 0:
                 break
             n += 1
         sweeps += n
         return got, n, time.perf_counter() - t0
-    t1 = timed(1, budget_s[0], 40)
-    # "all cores": the dense loops are memory-bound and a container may own fewer cores than it sees, so the thread
-    # count is calibrated (3 sweeps each) and the best one gets the rest of the budget
-    cands = sorted({t for t in (4, 8, 16, 32, 64, 128, navail) if t <= navail})
-    probe = [(timed(t, 2.0, 3), t) for t in cands]
-    probe = [(n / dt if n else 0.0, t) for (got, n, dt), t in probe]
-    best = max(probe)[1] if probe else 1
-    tn = timed(best, budget_s[1], 400)
-    timings = [t1, tn]
+    t1 = timed(1, 3, 1.0, 6.0)
+    cands = sorted({t for t in (8, 16, 32, 64, 128, navail) if t <= navail})
+    probe = {t: timed(t, 10, 1.0, 5.0) for t in cands}
+    rate = {t: (n / dt if n and dt > 0 else 0.0) for t, (got, n, dt) in probe.items()}
+    best = max(rate, key=rate.get) if rate else 1
+    tn = timed(best, 20, 2.0, 10.0)
     if sweeps == 0 or tn[1] == 0:
         o.close()
         return None
-    # the same sweeps by the HIP path on the same sample
-    s = Session(Ic.shape)
-    s.set_volume(Ic)
+    # the same sweeps by the HIP path on the same volume
+    s = Session(Ic32.shape)
+    s.set_volume(Ic32)
     s.set_labels(vm)
     s.init(H)
     r = s.run(sweeps, 10 ** 15, None)
     tr, otr = s.trace(), o.trace()
-    parity = bool(r.sweeps == sweeps and np.array_equal(s.labels(), o.labels())
-                  and np.array_equal((lambda c: (c[:, 0] * Ic.shape[1] + c[:, 1]) * Ic.shape[2] + c[:, 2])(s.segmented()), o.segmented_lex())
+    lab = np.empty(Ic32.shape, np.uint8)
+    s.labels(out=lab)
+    parity = bool(r.sweeps == sweeps and r.ties == 0 and np.array_equal(lab, o.labels())
+                  and np.array_equal((lambda c: (c[:, 0] * Ic32.shape[1] + c[:, 1]) * Ic32.shape[2] + c[:, 2])(s.segmented()), o.segmented_lex())
                   and all(np.array_equal(tr[f], otr[f]) for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no')))
     s.close()
     o.close()
-    (t1, n1, d1), (tn, nn, dn) = timings
-    return {'value': round(Ic.size * nn / dn / 1e6, 1), 'unit': 'Mvoxel-iter/s', 'cores': tn, 'kind': 'port',
-            'single_core': {'value': round(Ic.size * n1 / d1 / 1e6, 1) if n1 else None, 'cores': 1, 'sweeps': n1, 'seconds': round(d1, 1)},
-            'cpu': cpu_model(), 'cpus_visible': navail, 'threads_tried': {str(t): round(Ic.size * r / 1e6, 1) for r, t in probe},
+    (g1, n1, d1), (gn, nn, dn) = t1, tn
+    V = Ic32.size
+    value = V * nn / dn / 1e6
+    best_probe = V * rate[best] / 1e6
+    return {'value': round(value, 1), 'unit': 'Mvoxel-iter/s', 'cores': gn, 'kind': 'port',
+            'single_core': {'value': round(V * n1 / d1 / 1e6, 1) if n1 else None, 'cores': 1, 'sweeps': n1, 'seconds': round(d1, 1)},
+            'cpu': cpu_model(), 'cpus_visible': navail,
+            'threads_tried': {str(t): {'value': round(V * rate[t] / 1e6, 1), 'sweeps': probe[t][1], 'seconds': round(probe[t][2], 2)} for t in cands},
+            'probe_to_final': round(value / best_probe, 3) if best_probe else None,
+            'whole_volume': bool(whole), 'prepare_seconds': round(t_prep, 1),
             'parity': parity, 'parity_sweeps': sweeps,
-            'sample': '{} sweeps with 1 thread ({:.1f} s) then {} sweeps with {} threads ({:.1f} s) of the oracle (C port of the '
-                      'reference, level-histogram mode, OpenMP build) on {} ({}); the HIP path repeated the {} sweeps on the same '
-                      'sample and was compared with it'.format(n1, d1, nn, tn, dn, what, levels_note, sweeps),
+            'sample': '{} sweeps with 1 thread ({:.1f} s), >= 10-sweep probes of {} threads, then {} sweeps with {} threads ({:.1f} s) of '
+                      'the oracle (C port of the reference, level-histogram mode, OpenMP build) on {} ({}); the HIP path repeated the {} '
+                      'sweeps on the same volume and was compared with it'.format(n1, d1, '/'.join(str(t) for t in cands), nn, gn, dn, what, levels_note, sweeps),
             'reference_itself': REFERENCE_ITSELF}
 
 
@@ -235,11 +281,13 @@ def main():
         if 'MASTER_ADDR' not in os.environ:
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=dev)
-        out = slabs.bench_slabs(shape, args, dev, rank, world, roofline)
+        out = slabs.bench_slabs(shape, args, dev, rank, world, roofline, configure, load_traffic)
         if rank == 0:
             print(json.dumps(out), flush=True)
         dist.barrier()
         dist.destroy_process_group()
+        if out['config']['rccl_ranks'] != world:            # the data path must be RCCL over all ranks, or the line is not the N-GPU line
+            raise SystemExit(3)
         return
 
     from arterynetwork_amd._capi import Session
@@ -247,19 +295,7 @@ def main():
     torch.cuda.synchronize()
     V = shape[0] * shape[1] * shape[2]
     s = Session(shape, device=local_rank)
-    s.set_option('sweep_variant', args.variant)
-    if args.sweep_blocks:
-        s.set_option('sweep_blocks', args.sweep_blocks)
-    if args.prio_mode >= 0:
-        s.set_option('prio_mode', args.prio_mode)
-    if args.storage16:
-        s.set_option('storage16', 1)
-    s.set_option('events', args.events)
-    s.set_option('batch', 64)
-    if args.serial:
-        s.set_option('serial_streams', 1)
-    s.set_option('skip_excluded', args.skip_excluded)
-    s.set_option('nt_loads', args.nt_loads)
+    configure(s, args)
     s.set_volume_ptr(I.data_ptr(), np.float32, [st for st in I.stride()])
     s.set_labels_ptr(vm.data_ptr(), np.uint8, [st for st in vm.stride()])
     t0 = time.perf_counter()
@@ -279,8 +315,10 @@ def main():
     ms_per_step = dt / max(1, r.sweeps) * 1e3
     value = V * r.sweeps / dt / 1e6
     kern_ms = r.sweep_kernel_ms / max(1, r.sweep_launches)
+    chain_beside_ms = r.chain_kernel_ms / r.chain_launches if r.chain_launches else None
     tr = s.trace()
     nlev = s.nlevels()
+    st = s.stats()
     lev_note = '{} distinct intensities'.format(nlev)
     out = {
         'metric': 'Mvoxel-iters/sec, VRG sweep, {} volume'.format(args.shape), 'value': round(value, 1),
@@ -296,13 +334,24 @@ def main():
                    'init_seconds': round(t_init, 3), 'nseg_start': int(tr['nseg'][args.warmup]),
                    'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
                    'flips_per_sweep_mean': round(float(tr['nflip'][args.warmup + 1:].mean()), 1),
+                   'init_note': 'vrg_init of a fresh handle in a fresh process: allocation, code-object load, level table, band, histograms, class bits, unit list, first recount',
                    'dense_ms': round(kern_ms, 4), 'dense_events_every': args.events,
+                   # the band chain of a sweep (k_band's start to k_close's end) as it ran BESIDE the dense pass in the timed
+                   # sweeps; where the dense pass bounds the step it includes k_close's wait for the pass of two sweeps ago
+                   'band_chain_beside_dense_ms': round(chain_beside_ms, 4) if chain_beside_ms else None,
                    # (vrg.h option nt_loads: a pass of up to ~300 MB is read with ordinary loads and stays in the Infinity Cache)
-                   'dense_pass_loads': ('non-temporal' if (args.nt_loads == 1 or (args.nt_loads < 0 and db0 > (300 << 20))) else 'ordinary')},
-        'roofline': roofline(shape, shape[2], kern_ms, int(r.sweep_launches), load_traffic(shape, 1, args.storage16), args.storage16, dense_bytes),
+                   'dense_pass_loads': 'non-temporal' if st['dense_nt_loads'] else 'ordinary', 'dense_workgroups': st['dense_workgroups'],
+                   'dense_listed_units': st['dense_listed_units']},
+        'roofline': roofline(shape, shape[2], kern_ms, int(r.sweep_launches), load_traffic(shape, 1, args.storage16), args.storage16, dense_bytes, st['dense_kernel']),
     }
-    out['config']['engine'] = s.stats()                     # trips handed back to the host / array growth during the run
+    out['config']['engine'] = st                            # trips handed back to the host / array growth during the run
     out['config'].update(s.chain_timing(args.H))
+    # init once more on the warm handle (labels set again): what a second volume of the same shape costs
+    s.set_option('dense_off', 0)
+    s.set_labels_ptr(vm.data_ptr(), np.uint8, [st_ for st_ in vm.stride()])
+    t0 = time.perf_counter()
+    s.init(args.H)
+    out['config']['reinit_seconds'] = round(time.perf_counter() - t0, 4)
     s.close()
     if not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(I, vm, args.H, lev_note)

@@ -52,6 +52,9 @@ typedef struct {
     double seconds;           /* wall time of this call's sweeps (device synchronised) */
     double sweep_kernel_ms;   /* HIP-event time summed over this call's dense sweep launches (option "events") */
     int64_t sweep_launches;
+    double chain_kernel_ms;   /* HIP-event time from the start of k_band to the end of k_close, summed over the trips option
+                                 "chain_events" selected: the band chain of a sweep as it runs BESIDE the dense pass */
+    int64_t chain_launches;
     int64_t ties;             /* sign tests (:87) of this call whose two sides agreed to a relative 1e-11, or that divided by an
                                  empty region: the reference decides those by the rounding of np.sum's pairwise order, which
                                  no regrouped summation reproduces - labels are bit-exact unless ties > 0 */
@@ -80,6 +83,8 @@ const char* vrg_last_error(const vrg_handle* h);
  *                    label stencil on every voxel (slow; must give the same state)
  *   "events"         any time; n > 0: time the dense pass of every n-th sweep of a batch with HIP events
  *                    (vrg_result.sweep_kernel_ms / sweep_launches; an event pair costs the dense stream a few us)
+ *   "chain_events"   any time; n > 0: time the band chain (k_band's start to k_close's end, band stream) of every n-th
+ *                    trip of a batch with HIP events (vrg_result.chain_kernel_ms / chain_launches)
  *   "batch"          any time; sweeps enqueued between host checks of the stop flag (default 8)
  *   "small_flips"    any time; flips per sweep up to which update() runs as ONE workgroup's kernel (default and
  *                    maximum 4096); sweeps with more are driven from the host with device-wide kernels
@@ -131,7 +136,9 @@ int vrg_get_levels(vrg_handle* h, double* values, int32_t* hist_in, int32_t* his
  * one workgroup, marked-voxel arrays grown, band pool grown}, out[4] = host-driven trips, out[5] = band pool
  * capacity, out[6] = marked-list capacity, out[7] = pool slots in use.  cap >= 8.  With cap >= 9 also out[8] =
  * the bytes one dense pass requests from memory with the current labels (class words + the 128-byte intensity lines
- * that hold an included voxel; every line of the slab with option skip_excluded = 0) - the roofline's numerator. */
+ * that hold an included voxel; every line of the slab with option skip_excluded = 0) - the roofline's numerator.
+ * With cap >= 14 also how the dense pass is launched: out[9] = 1 for non-temporal loads, out[10] = intensity storage
+ * (0 fp32, 1 u16 level index, 2 float64), out[11] = workgroups, out[12] = skip_excluded, out[13] = units on its list. */
 int vrg_get_stats(vrg_handle* h, int64_t* out, int64_t cap);
 
 /* ---- multi-GPU (one process per GPU) --------------------------------------------------
