@@ -868,6 +868,27 @@ __device__ __forceinline__ void stats_group(SweepAcc& a, uint32_t wj, const Unit
         }
     }
 }
+// the same for a group in which no lane holds an inner voxel: only the outer sum moves (same additions, same order)
+template <int MODE>
+__device__ __forceinline__ void stats_group_outer(SweepAcc& a, uint32_t wj, const UnitVals<MODE>& u, int j, const float* s_val) {
+    float lv[4];
+    if constexpr (MODE == 1) {
+        lv[0] = s_val[u.q[j].x & 0xffffu]; lv[1] = s_val[u.q[j].x >> 16];
+        lv[2] = s_val[u.q[j].y & 0xffffu]; lv[3] = s_val[u.q[j].y >> 16];
+    }
+#pragma unroll
+    for (int bb = 0; bb < 4; bb++) {
+        if constexpr (MODE == 2) {
+            const double x = u.f[j][bb >> 1][bb & 1];
+            a.sout += ((wj >> (2 * bb)) & 2u) ? x : 0.0;
+        } else {
+            uint32_t xi;
+            if constexpr (MODE == 1) xi = __float_as_uint(lv[bb]); else xi = __float_as_uint(u.f[j][bb]);
+            const uint32_t m_out = (uint32_t)((int32_t)(wj << (30 - 2 * bb)) >> 31);
+            a.sout += (double)__uint_as_float(xi & m_out);
+        }
+    }
+}
 // SKIP: a group of four voxels per lane whose 256 voxels are all excluded costs the wave nothing (the branch is
 // wave-uniform there); partly excluded groups run with the excluded lanes masked off.  Adding +0.0 or not adding at
 // all gives the same sums (the accumulators never hold -0.0: they start at +0.0).
@@ -895,6 +916,10 @@ __device__ __forceinline__ void stats_bits(SweepAcc& a, uint32_t w, const UnitVa
                 }
 #pragma unroll
                 for (int bb = 0; bb < 4; bb++) a.sout += unit_value<MODE>(u, j, bb, lv);
+            } else if (SKIP && __builtin_amdgcn_ballot_w64((wj & 0x55u) != 0u) == 0ull) {
+                // no lane holds an inner voxel here (the rim of the brain mask: outer and excluded voxels mixed): the outer
+                // sum alone, masked - the general path would add +0.0 to the inner sum sixteen times for nothing
+                stats_group_outer<MODE>(a, wj, u, j, s_val);
             } else {
                 stats_group<MODE>(a, wj, u, j, s_val);
             }
@@ -1292,11 +1317,15 @@ bool dense_nt(const VrgBackend* b, const VrgCtx&) {
 int dense_blocks(const VrgBackend* b, const VrgCtx& c) {
     if (b->sweep_blocks > 0) return b->sweep_blocks;
     uint64_t units = ((uint64_t)(c.z1 - c.z0) * c.PY * c.PX) >> 10;
-    // skipping pass: few registers, many short trips - 3 waves per SIMD, the 16-bit variant (LDS look-ups, half the
-    // bytes per trip) 8; measured in DESIGN.md section 5.  Streaming pass (skip_excluded = 0): 1 resp. 2 workgroups per CU.
+    // skipping pass: few registers, many short trips - 3 waves per SIMD on a big volume, the 16-bit variant (LDS look-ups,
+    // half the bytes per trip) 8; measured in DESIGN.md section 5.  A SMALL pass (512x512x170, an 80-plane slab) is not
+    // what bounds the step - the band chain is, and every recount wave on a CU is a queue of loads the band kernels'
+    // dependent loads wait behind: 200-280 workgroups there (512x512x170: step 0.0447 ms with 192-256, 0.0456 with 353,
+    // 0.0481 with 512; 880x880x80: 0.0466 with 256, 0.0493 with 483, 0.0505 with 512).
+    // Streaming pass (skip_excluded = 0): 1 resp. 2 workgroups per CU.
     if (!b->skip) return (int)std::min<uint64_t>(c.lev16 ? 2 * SWEEP_BLOCKS : SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128));
     return (int)(c.lev16 ? std::min<uint64_t>(8 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 48))
-                         : std::min<uint64_t>(3 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128)));
+                         : std::min<uint64_t>(3 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 224)));
 }
 
 void use_device(VrgBackend* b) { HIP_CHECK(hipSetDevice(b->device)); }

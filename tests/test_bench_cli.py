@@ -42,6 +42,16 @@ def test_roofline_is_a_fraction_of_peak():
 
 def test_traffic_only_for_the_sources_it_was_measured_on():
     t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
-    got = bench.load_traffic(tuple(t['shape']), 1, False)
-    assert got == (t['hbm_bytes_per_launch'] if t.get('src_sha') == bench.device_source_sha() else None)
-    assert bench.load_traffic((1, 2, 3), 1, False) is None and bench.load_traffic(tuple(t['shape']), 1, True) is None
+    entries = t.get('entries', [t])
+    assert entries
+    for e in entries:                                  # one entry per profiled workload (shape, ranks, storage, slab planes)
+        got = bench.load_traffic(tuple(e['shape']), e.get('n_gpus', 1), bool(e.get('storage16')), e.get('planes'))
+        assert got == (e['hbm_bytes_per_launch'] if e.get('src_sha') == bench.device_source_sha() else None)
+        assert bench.load_traffic(tuple(e['shape']), e.get('n_gpus', 1), not e.get('storage16'), e.get('planes')) is None or len(entries) > 1
+    assert bench.load_traffic((1, 2, 3), 1, False) is None
+
+
+def test_section8d_figure_is_kept_apart_from_frac():
+    r = bench.roofline((880, 880, 640), 640, 0.178, 125, None, dense_bytes=1.0616e9, kernel='k_recount_bits<3,true,0,true>')
+    assert r['kernel'] == 'k_recount_bits<3,true,0,true>' and 0.7 < r['frac'] < 0.8
+    assert r['section8d_frac'] > 1.5 and 'not a fraction' in r['section8d_note']      # 6 B x voxels / time / peak: the driver's own figure

@@ -308,3 +308,40 @@ def test_hostmodel_reports_ties(hm):
     r = s.run(5, 10 ** 9, None)
     assert r.ties == 0 and int(s.trace()['ties'].sum()) == 0
     s.close()
+
+
+ASAN_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))
+import numpy as np
+import parity
+from conftest import Golden
+from test_hostmodel import random_case
+from arterynetwork_amd._capi import VrgLib
+lib = VrgLib(os.path.join({root!r}, 'tests', 'hostmodel', 'libvrg_hostmodel_asan.so'), 'vrgm_')
+for name in ('adv_noise_q', 'tube_q_small', 'border_size_stop'):
+    g = Golden(name)
+    data, vmap = g.inputs()
+    res, k = parity.run_stepwise(lib, data, vmap, g.H, g.maxSegmentSize, g.max_sweeps if g.max_sweeps >= 0 else 200, density_mode=1, check_hist=True,
+                                 options={{'capacity_floor': 16}})
+    assert res is not None
+for sd in range(40):
+    I, vm, H, variant, dmode = random_case(sd)
+    parity.run_stepwise(lib, I, vm, H, None, 12, density_mode=dmode, options={{'sweep_variant': variant, 'capacity_floor': 16, 'storage16': sd % 2 if len(np.unique(I)) < 1000 else 0}})
+print('ASAN RUN OK')
+'''
+
+
+def test_hostmodel_under_address_and_ub_sanitizers():
+    """The engine (vrg_engine.cpp: handle management, arrays that grow on demand, hand-back protocol) and the item
+    functions under -fsanitize=address,undefined, through the sequential test model that shares them with the product:
+    goldens and random volumes with 16-entry initial arrays.  Any report fails the test."""
+    import sys
+    subprocess.check_call(['make', '-C', HM_DIR, '-s', 'libvrg_hostmodel_asan.so'])
+    libasan = subprocess.check_output(['gcc', '-print-file-name=libasan.so'], text=True).strip()
+    libubsan = subprocess.check_output(['gcc', '-print-file-name=libubsan.so'], text=True).strip()
+    env = dict(os.environ, LD_PRELOAD=libasan + ' ' + libubsan, ASAN_OPTIONS='detect_leaks=0:abort_on_error=0:exitcode=23',
+               UBSAN_OPTIONS='halt_on_error=1:print_stacktrace=1')
+    out = subprocess.run([sys.executable, '-c', ASAN_SCRIPT.format(root=ROOT)], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and 'ASAN RUN OK' in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+    assert 'AddressSanitizer' not in out.stderr and 'runtime error' not in out.stderr, out.stderr[-3000:]

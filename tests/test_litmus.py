@@ -1,0 +1,39 @@
+"""The cross-workgroup hand-off protocols of the kernels, pinned by a litmus program that can fail (tools/xcdbench.hip).
+
+The product hands data between workgroups of ONE launch in two places - the last-workgroup reduction of the dense recount
+(sweep_finish) and k_close's closing ticket - without release/acquire fences: payload stored write-through (sc1), drained
+with s_waitcnt vmcnt(0), then an agent-scope ticket; the workgroup whose ticket came last reads with sc1 loads.  The litmus
+runs exactly that pattern 10^6 times on 256 workgroups spread over all XCDs, alone and beside a kernel that saturates HBM,
+checking every total - and its NEGATIVE twin (one plain store in the hand-off set), which must be caught.  The same for the
+barrier + hand-off forms the persistent-kernel study used (plain stores are stale across XCDs: must be caught too).
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_handoff_litmus_and_its_negative_variants():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as G
+    exe = G.build_litmus()
+    out = subprocess.run([exe, '4000', '1000000'], capture_output=True, text=True, timeout=900)
+    text = out.stdout + out.stderr
+    d = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(d):
+        open(os.path.join(d, 'litmus.log'), 'w').write(text)
+    assert out.returncode == 0 and 'LITMUS OK' in text, text[-3000:]
+    lines = text.splitlines()
+    tick = [l for l in lines if l.startswith('TICKET sc1-stored')]
+    assert len(tick) == 2 and all('1000000 rounds checked, 0 wrong totals' in l for l in tick), tick
+    neg = [l for l in lines if l.startswith('TICKET PLAIN-stored')]
+    assert len(neg) == 2 and all(' 0 wrong totals' not in l for l in neg), neg                # the broken protocol IS seen
+    cross = [l for l in lines if 'ALL XCDs (cross-XCD: expect errors)' in l]
+    assert cross and all('errors 0 of' not in l for l in cross)
+    ok = [l for l in lines if l.startswith('LITMUS sc1 store')]
+    assert ok and all('errors 0 of' in l for l in ok)

@@ -69,7 +69,7 @@ def test_partition():
     assert max(b - a for a, b in p) - min(b - a for a, b in p) <= 1
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])
 def test_slabs_equal_single_process(tmp_path, world):
     from arterynetwork_amd._capi import Session, VrgLib
     import subprocess

@@ -1,8 +1,9 @@
 #!/bin/bash
 # per-kernel durations of a bench command: tools/gpu_prof.sh <tag> [bench args...]
-tag=$1; shift
-out=gpurun_out/$tag
-rm -rf $out; mkdir -p $out
+set -u
+tag=${1:?usage: gpu_prof.sh <tag> [bench args...]}; shift
+out="gpurun_out/$tag"
+rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > $out/build.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline "$@" > $out/bench.log 2>&1

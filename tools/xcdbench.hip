@@ -6,7 +6,9 @@
 //      with s_waitcnt vmcnt(0) before the arrival; read with L1-bypassing loads (nt / sc1) - checked every iteration;
 //      and the NEGATIVE variant (payload re-read with plain loads: stale lines in the reader's L1), which is EXPECTED to
 //      show errors - so that the protocol is pinned by a test that can fail.
-// Build: hipcc --offload-arch=gfx950 -O3 tools/xcdbench.hip -o tools/xcdbench.bin    Run: tools/xcdbench.bin [iters]
+//   4. LITMUS: the ticket pattern of the product's last-workgroup reductions (k_ticket), with its negative variant
+// Build: hipcc --offload-arch=gfx950 -O3 tools/xcdbench.hip -o tools/xcdbench.bin    Run: tools/xcdbench.bin [iters [ticket rounds]]
+// (tests/test_litmus.py runs it on the GPU box)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <cstdio>
@@ -19,6 +21,13 @@
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u; }   // HW_REG_XCC_ID[3:0]
 
 __global__ void k_where(uint32_t* out) { if (threadIdx.x == 0) out[blockIdx.x] = xcc_id(); }
+
+// a load with no cache-policy bits at all (a `volatile` access compiles to sc0 sc1: that is not the hazard under test)
+__device__ __forceinline__ uint32_t plain_load(const uint32_t* p) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 
 constexpr unsigned long long SPIN_LIMIT = 200000000ull;   // 2 s of the 100 MHz wall clock
 
@@ -70,7 +79,7 @@ __global__ void __launch_bounds__(256) k_chain(uint32_t* ctr, uint32_t* payload,
             uint32_t v;
             if (MODE == 1 || MODE == 4) v = __builtin_nontemporal_load(p);
             else if (MODE == 2) v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else v = *(volatile const uint32_t*)p;
+            else v = plain_load(p);
             if (v != it * 4096u + src) bad++;
         }
         if (!grid_barrier(ctr, n, ++gen, tmo)) break;       // (the payload is rewritten next iteration)
@@ -123,13 +132,54 @@ __global__ void __launch_bounds__(256) k_chain_elect(uint32_t* ctl, uint32_t* pa
             uint32_t v;
             if (MODE == 1) v = __builtin_nontemporal_load(p);
             else if (MODE == 2) v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else v = *(volatile const uint32_t*)p;
+            else v = plain_load(p);
             if (v != it * 4096u + src) bad++;
         }
         if (!grid_barrier(ctl, n, ++gen, tmo)) break;
     }
     if (t == 0 && b == 0) *ticks = wall_clock64() - t0;
     if (bad) atomicAdd(errs, bad);
+}
+
+// TICKET pattern of the product (sweep_finish of k_recount_bits, k_close): every workgroup stores its four partial values
+// write-through (sc1), drains them, takes a ticket (relaxed agent-scope add); the workgroup whose add came LAST reads every
+// slot with sc1 loads behind a workgroup barrier and checks the total.  PLAIN = 1: the negative variant - the slots are
+// stored with plain stores, which stay in the storing XCD's L2: the last workgroup (on another XCD) must see stale slots.
+// Rounds are separated by the grid barrier (the product: by a kernel boundary).
+template <int PLAIN>
+__global__ void __launch_bounds__(256) k_ticket(uint32_t* ctr, uint32_t* ticket, unsigned long long* slots, uint32_t iters, uint32_t* errs, uint32_t* tmo, uint32_t* lasts) {
+    __shared__ int s_last;
+    const uint32_t n = gridDim.x, b = blockIdx.x, t = threadIdx.x;
+    uint32_t gen = 0;
+    for (uint32_t it = 1; it <= iters; it++) {
+        if (t < 4) {
+            const unsigned long long v = (unsigned long long)it * 1000003ull + b * 4u + t;
+            if (PLAIN) slots[(size_t)b * 4 + t] = v; else __hip_atomic_store(&slots[(size_t)b * 4 + t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            const uint32_t k = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (k == it * n - 1u);
+        }
+        __syncthreads();
+        if (s_last) {
+            unsigned long long sum = 0;
+            for (uint32_t i = t; i < n * 4u; i += 256u) sum += __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            __shared__ unsigned long long s_sum[4];
+            if ((t & 63) == 0) s_sum[t >> 6] = sum;
+            __syncthreads();
+            if (t == 0) {
+                const unsigned long long got = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+                unsigned long long want = 0;
+                for (uint32_t i = 0; i < n * 4u; i++) want += (unsigned long long)it * 1000003ull + i;
+                if (got != want) atomicAdd(errs, 1u);
+                atomicAdd(lasts, 1u);
+            }
+        }
+        if (!grid_barrier(ctr, n, ++gen, tmo)) break;
+    }
 }
 
 // background load: streams `n` float4 from src with non-temporal loads, `reps` times
@@ -249,6 +299,28 @@ int main(int argc, char** argv) {
         if (run("LITMUS sc1 store -> drain -> barrier -> sc1 load, all XCDs", 2, s_all, 256, loaded, s_bg)) rc = 1;
         const uint32_t e1 = run("plain store -> drain -> barrier -> nt load, ALL XCDs (cross-XCD: expect errors)", 1, s_all, 32, loaded, s_bg);
         std::printf("   plain stores across XCDs: %s\n", e1 ? "stale, as the guide says (plain stores are not write-through)" : "no error seen");
+    }
+    // ---- ticket pattern of the product's last-workgroup reductions
+    {
+        unsigned long long* d_slots; uint32_t* d_ticket; uint32_t* d_lasts;
+        CK(hipMalloc(&d_slots, 1024 * 4 * 8)); CK(hipMalloc(&d_ticket, 256)); CK(hipMalloc(&d_lasts, 4));
+        for (int plain = 0; plain < 2; plain++)
+            for (int loaded = 0; loaded < 2; loaded++) {
+                const uint32_t nwg = 256, its = argc > 2 ? (uint32_t)std::atoi(argv[2]) : iters * 5;
+                CK(hipMemset(d_ctr, 0, 256)); CK(hipMemset(d_ticket, 0, 256)); CK(hipMemset(d_errs, 0, 4)); CK(hipMemset(d_tmo, 0, 4)); CK(hipMemset(d_lasts, 0, 4)); CK(hipMemset(d_slots, 0, 1024 * 4 * 8));
+                CK(hipDeviceSynchronize());
+                if (loaded) k_stream<<<1792, 256, 0, s_bg>>>(d_big, big / 16, 300, d_sink);
+                if (plain) k_ticket<1><<<nwg, 256, 0, s_all>>>(d_ctr, d_ticket, d_slots, its, d_errs, d_tmo, d_lasts);
+                else k_ticket<0><<<nwg, 256, 0, s_all>>>(d_ctr, d_ticket, d_slots, its, d_errs, d_tmo, d_lasts);
+                CK(hipDeviceSynchronize());
+                uint32_t errs, tmo, lasts;
+                CK(hipMemcpy(&errs, d_errs, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&tmo, d_tmo, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&lasts, d_lasts, 4, hipMemcpyDeviceToHost));
+                std::printf("TICKET %s slots -> drain -> ticket -> last workgroup reads sc1, 256 workgroups on all XCDs %s: %u rounds checked, %u wrong totals%s\n",
+                            plain ? "PLAIN-stored (negative)" : "sc1-stored", loaded ? "beside an HBM stream" : "alone", lasts, errs, tmo ? "  TIMEOUT" : "");
+                if (!plain && (errs || lasts != its)) rc = 1;
+                if (plain) std::printf("   negative variant %s\n", errs ? "failed as expected: a plain store in the hand-off set is caught" : "showed NO error");
+                if (plain && !errs) rc = 1;
+            }
     }
     std::printf(rc ? "LITMUS FAILED\n" : "LITMUS OK\n");
     return rc;
