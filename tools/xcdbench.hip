@@ -125,7 +125,9 @@ __global__ void __launch_bounds__(256) k_chain_elect(uint32_t* ctl, uint32_t* pa
             uint32_t* p = payload + (size_t)b * 256 + t;
             if (MODE == 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
         }
+        if (MODE == 6) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // (every wave: the textbook form, L2 write-back)
         if (!grid_barrier(ctl, n, ++gen, tmo)) break;
+        if (MODE >= 5) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // L1 invalidate, every wave
         if (MODE != 0) {
             const uint32_t src = (b + 1u) % n;
             const uint32_t* p = payload + (size_t)src * 256 + t;
@@ -266,7 +268,9 @@ int main(int argc, char** argv) {
             case 0: k_chain_elect<0><<<launched, 256, 0, s_all>>>(d_ctr, d_payload, iters, d_errs, d_tmo, d_ticks, d_xcc); break;
             case 1: k_chain_elect<1><<<launched, 256, 0, s_all>>>(d_ctr, d_payload, iters, d_errs, d_tmo, d_ticks, d_xcc); break;
             case 2: k_chain_elect<2><<<launched, 256, 0, s_all>>>(d_ctr, d_payload, iters, d_errs, d_tmo, d_ticks, d_xcc); break;
-            default: k_chain_elect<3><<<launched, 256, 0, s_all>>>(d_ctr, d_payload, iters, d_errs, d_tmo, d_ticks, d_xcc); break;
+            case 3: k_chain_elect<3><<<launched, 256, 0, s_all>>>(d_ctr, d_payload, iters, d_errs, d_tmo, d_ticks, d_xcc); break;
+            case 5: k_chain_elect<5><<<launched, 256, 0, s_all>>>(d_ctr, d_payload, iters, d_errs, d_tmo, d_ticks, d_xcc); break;
+            default: k_chain_elect<6><<<launched, 256, 0, s_all>>>(d_ctr, d_payload, iters, d_errs, d_tmo, d_ticks, d_xcc); break;
         }
         CK(hipDeviceSynchronize());
         uint32_t errs, tmo, n; unsigned long long ticks;
@@ -283,6 +287,8 @@ int main(int argc, char** argv) {
         for (uint32_t launched : {64u, 256u, 512u}) run_elect("ELECTED XCD: barriers only", 0, launched, loaded);
         for (uint32_t launched : {256u, 512u}) if (run_elect("ELECTED XCD LITMUS plain store -> drain -> barrier -> nt load", 1, launched, loaded)) rc = 1;
         if (run_elect("ELECTED XCD LITMUS sc1 store -> drain -> barrier -> sc1 load", 2, 256, loaded)) rc = 1;
+        if (run_elect("ELECTED XCD plain store -> drain -> barrier -> ACQUIRE fence (L1 inv) -> plain load", 5, 256, loaded)) rc = 1;
+        if (run_elect("ELECTED XCD plain store -> RELEASE fence -> barrier -> ACQUIRE fence -> plain load", 6, 256, loaded)) rc = 1;
         { const uint32_t neg = run_elect("ELECTED XCD NEGATIVE plain store -> barrier -> PLAIN load", 3, 256, loaded);
           std::printf("   negative variant %s\n", neg ? "failed as expected: the litmus can see a broken protocol" : "showed NO error (litmus blind here?)"); }
         if (s_one) {
