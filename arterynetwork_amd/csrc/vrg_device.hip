@@ -57,6 +57,7 @@ struct VrgBackend {
     int serial = 0;                                   // option "serial_streams": see be_sweep_once
     int skip = 1;                                     // option "skip_excluded": the dense pass does not fetch the intensities of excluded voxels
     int nt_loads = -1;                                // option "nt_loads": -1 = by the size of the pass, 0 / 1 = ordinary / non-temporal loads
+    int dense_pipe = 1;                               // option "dense_pipe": fp32 storage + skip_excluded run the two-trips-deep recount (k_recount_pipe)
     uint64_t pass_bytes = 0;                          // bytes a dense pass fetches, counted at the end of init (0: not known yet)
     uint32_t band_hint = 0;                           // pool slots in use when the engine last read the state (0: unknown)
     int direct_hint = 1;                              // ... and whether corrections are then evaluated entry by entry (8 lanes per slot)
@@ -976,7 +977,7 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
     const uint32_t* __restrict__ ulist = c.ulist;
     const uint32_t n = c.uctl[UC_N];
     const uint32_t last = n ? n - 1u : 0u;
-    uint32_t i = wave * UNITS;
+    uint32_t i = __builtin_amdgcn_readfirstlane(wave * UNITS);     // (wave-uniform: the list is read through the scalar cache)
     // (the first trip's units travel with everything else a wave reads first)
     uint32_t uu[UNITS];
 #pragma unroll
@@ -1039,6 +1040,78 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
         }
         load_vals<MODE, false, SKIP>(c, edge, lane, w1, f);
         stats_bits<MODE, SKIP>(acc, w1, f, s_val);
+    }
+    sweep_finish(c, acc, check_done);
+}
+// fp32 storage + skip_excluded (the default; option dense_pipe = 0 switches it off): the same walk, software-pipelined two
+// trips deep.  Every intensity load is issued unconditionally - a lane whose group is excluded reads one fixed dummy line
+// (the first 16 bytes of the padded volume) instead of being predicated off - so the number of loads in flight is static,
+// the compiler's wait counts are exact, and the NEXT trip's intensities are requested before this trip's sums are formed
+// (with predicated loads the compiler waits for everything before it forms a sum).  Same additions in the same order:
+// bit-identical to k_recount_bits.  Measured (one process, alternating): 880x880x640 0.173 vs 0.178-0.183 ms; 512x512x170
+// 0.031 vs 0.036 ms; without a brain mask 0.340 vs 0.335 (nothing to hide there).
+template <int UNITS, bool NT>
+__device__ __forceinline__ void load_vals_uncond(const VrgCtx& c, uint32_t u, uint32_t lane, uint32_t w, UnitVals<0>& o) {
+    const uint32_t base = (u << 10) + (lane << 2);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool need = ((w >> (8 * j)) & 0xffu) != 0u;
+        const f4v* pi = reinterpret_cast<const f4v*>(need ? c.I + base + (j << 8) : c.I);
+        o.f[j] = NT ? __builtin_nontemporal_load(pi) : *pi;
+    }
+}
+template <int UNITS, bool NT>
+__global__ void __launch_bounds__(TPB) k_recount_pipe(VrgCtx c, int check_done) {
+    if (check_done && !vrg_dense_due(c)) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t* __restrict__ ulist = c.ulist;
+    const uint32_t n = c.uctl[UC_N];
+    const uint32_t last = n ? n - 1u : 0u, stride = nwaves * UNITS;
+    uint32_t i = __builtin_amdgcn_readfirstlane(wave * UNITS);     // (wave-uniform: the list is read through the scalar cache)
+    const uint32_t* __restrict__ cls = c.clsb[(vrg_load_i64(&c.dctl[VD_RSEQ]) + 1) & 1];
+    const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
+    const uint32_t lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
+    uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10;
+    if (f_hi < f_lo) f_hi = f_lo;
+    SweepAcc acc = {0, 0, 0.0, 0.0};
+    if (i < n) {
+        uint32_t u0[UNITS], u1[UNITS], w0[UNITS], w1[UNITS];
+        UnitVals<0> fa[UNITS];
+#pragma unroll
+        for (int q = 0; q < UNITS; q++) { u0[q] = __builtin_amdgcn_readfirstlane(ulist[min(i + q, last)]); w0[q] = load_cls<NT>(cls, u0[q], lane); }
+#pragma unroll
+        for (int q = 0; q < UNITS; q++) { u1[q] = __builtin_amdgcn_readfirstlane(ulist[min(i + stride + q, last)]); w1[q] = load_cls<NT>(cls, u1[q], lane); }
+#pragma unroll
+        for (int q = 0; q < UNITS; q++) { if (i + q >= n) w0[q] = 0u; if (i + stride + q >= n) w1[q] = 0u; }
+#pragma unroll
+        for (int q = 0; q < UNITS; q++) load_vals_uncond<UNITS, NT>(c, u0[q], lane, w0[q], fa[q]);
+        while (i < n) {
+            uint32_t u2[UNITS], w2[UNITS];
+            UnitVals<0> fb[UNITS];
+#pragma unroll
+            for (int q = 0; q < UNITS; q++) { u2[q] = __builtin_amdgcn_readfirstlane(ulist[min(i + 2u * stride + q, last)]); w2[q] = load_cls<NT>(cls, u2[q], lane); }
+#pragma unroll
+            for (int q = 0; q < UNITS; q++) load_vals_uncond<UNITS, NT>(c, u1[q], lane, w1[q], fb[q]);      // the next trip's intensities first ...
+#pragma unroll
+            for (int q = 0; q < UNITS; q++) stats_bits<0, true>(acc, w0[q], fa[q], nullptr);                 // ... then this trip's sums
+#pragma unroll
+            for (int q = 0; q < UNITS; q++) { if (i + 2u * stride + q >= n) w2[q] = 0u; w0[q] = w1[q]; u0[q] = u1[q]; fa[q] = fb[q]; w1[q] = w2[q]; u1[q] = u2[q]; }
+            i += stride;
+        }
+    }
+    const uint32_t e0 = lo >> 10, e1 = (hi - 1u) >> 10;
+    const uint32_t edge = wave == 0 ? e0 : (wave == nwaves - 1 && e1 != e0 ? e1 : 0xffffffffu);
+    if (edge != 0xffffffffu && !(edge >= f_lo && edge < f_hi)) {
+        UnitVals<0> f;
+        uint32_t w1e = load_cls<false>(cls, edge, lane);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t v = (edge << 10) + (j << 8) + (lane << 2);
+            if (v < lo || v >= hi) w1e &= ~(0xffu << (8 * j));
+        }
+        load_vals<0, false, true>(c, edge, lane, w1e, f);
+        stats_bits<0, true>(acc, w1e, f, nullptr);
     }
     sweep_finish(c, acc, check_done);
 }
@@ -1392,6 +1465,7 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "nt_loads") == 0) b->nt_loads = v < 0 ? -1 : (v != 0);
     if (std::strcmp(name, "band_hint") == 0) b->band_hint = (uint32_t)std::min<long long>(std::max<long long>(v, 0), 0x7fffffff);
     if (std::strcmp(name, "direct_hint") == 0) b->direct_hint = v != 0;
+    if (std::strcmp(name, "dense_pipe") == 0) b->dense_pipe = (int)v;
     if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)std::min<long long>(v, NF_SMALL);
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != b->prio_mode) { b->prio_mode = (int)v; make_streams(b); }
 }
@@ -1723,6 +1797,12 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
     // device for another one could then wait for ever, so the host orders the two streams instead.)
     if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sa));
     const bool ranks = c.world > 1 || b->comm || cb;
+    if (b->dense_pipe && c.I && !c.lev16 && b->skip) {
+        k_gate<<<1, GATE_THREADS, 0, b->sb>>>(c);
+        const int check = ranks ? 1 : 2;
+        if (dense_nt(b, c)) hipExtLaunchKernelGGL((k_recount_pipe<3, true>), dim3(dense_blocks(b, c)), dim3(TPB), 0, b->sb, e_start, e_stop, 0, c, check);
+        else hipExtLaunchKernelGGL((k_recount_pipe<3, false>), dim3(dense_blocks(b, c)), dim3(TPB), 0, b->sb, e_start, e_stop, 0, c, check);
+    } else
     launch_recount(c, dense_blocks(b, c), ranks ? 1 : 2, b->sb, b->skip != 0, dense_nt(b, c), e_start, e_stop);
     if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sb));
     // one GPU: the last workgroup of the recount closes the pass itself.  Z-slabs: the slab sums of DENSE_GROUP recounts

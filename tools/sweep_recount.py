@@ -30,7 +30,7 @@ for od in orders:
   for fl in floors:
     for un in units:
         for bl in blocks:
-            s.set_option('sweep_blocks', bl)
+            s.set_option('sweep_blocks', bl); s.set_option('dense_pipe', od)
             r = s.run(done + 10, 10 ** 15, None); done += r.sweeps           # (re-split + warm-up)
             t0 = time.perf_counter()
             r = s.run(done + sweeps, 10 ** 15, None); done += r.sweeps
