@@ -75,6 +75,7 @@ class VrgLib:
         self.get_trace = fn('get_trace', [p, p, C.c_int64, i64p])
         self.get_levels = fn('get_levels', [p, p, p, p, p, p, C.c_int64, i64p])
         self.get_stats = fn('get_stats', [p, i64p, C.c_int64])
+        self.debug_stamps = fn('debug_stamps', [p, p])
         self.set_slab = fn('set_slab', [p, C.c_int64, C.c_int64])
         self.comm_unique_id = fn('comm_unique_id', [p])
         self.comm_init = fn('comm_init', [p, C.c_int, C.c_int, p])

@@ -109,6 +109,16 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
 }
 
 
+// in-kernel time stamps of the band chain (diagnostic build -DVRG_STAMPS only; in the product build no stamp executes)
+#if defined(VRG_STAMPS)
+#define VRG_STAMP(c, k) do { c.dbg[k] = wall_clock64(); } while (0)
+#define VRG_STAMP_NOW() wall_clock64()
+#define VRG_STAMP_PUT(c, k, v) do { c.dbg[k] = (v); } while (0)
+#else
+#define VRG_STAMP(c, k) do { } while (0)
+#define VRG_STAMP_NOW() 0ull
+#define VRG_STAMP_PUT(c, k, v) do { (void)(v); } while (0)
+#endif
 #define ITEM_LOOP(n) for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += gridDim.x * blockDim.x)
 // same with a 64-bit item index: (listed flips) x (positions) can exceed 2^32 on adversarial volumes
 #define ITEM_LOOP64(n) for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += (uint64_t)gridDim.x * blockDim.x)
@@ -234,6 +244,8 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks) {
     // takes 2-3 x longer beside a recount.  The pool workgroups therefore fetch, together with the state, what the first
     // slot of every thread will need: its fields (any slot below the capacity is readable) and the head of the memo.
     const bool pool_wg = blockIdx.x < band_blocks;
+    const bool st0 = blockIdx.x == 0 && threadIdx.x == 0, stx = blockIdx.x == band_blocks && threadIdx.x == 0;
+    const unsigned long long t_entry = (st0 || stx) ? VRG_STAMP_NOW() : 0ull;     // (written below, and only by a trip that applies a sweep)
     const uint32_t slot0 = blockIdx.x * TPB + threadIdx.x;
     uint8_t fl0 = 0; double ip0 = 0, op0 = 0; uint32_t lev0 = 0, idx0 = 0; uint64_t key0 = 0; int64_t nin0 = 0, nout0 = 0;
     const uint32_t tab_n = c.L < TAB_LDS ? c.L : TAB_LDS;
@@ -244,8 +256,11 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks) {
     }
     const VrgState s = *c.st;                             // a copy (nf is only ever bumped atomically)
     if (s.done || s.bail) return;
+    const bool live = s.iter < s.iterMax;
+    if (st0 && live) { VRG_STAMP_PUT(c, 0, t_entry); VRG_STAMP(c, 1); }
     if (!pool_wg) {
         exact_wg(c, s, s.nfx, blockIdx.x - band_blocks, EXACT_BLOCKS);
+        if (stx && live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP_PUT(c, 3, t_entry); VRG_STAMP(c, 4); }
         return;
     }
     const bool direct = s.corr && !s.use_tab;
@@ -255,6 +270,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks) {
             vrg_item_band_fields(c, s, slot0, fl0, ip0, op0, lev0, idx0, key0, nin0, nout0, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n);
         for (uint32_t slot = slot0 + band_blocks * TPB; slot < s.np; slot += band_blocks * TPB)
             vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n);
+        if (st0 && live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 2); }
         return;
     }
     __syncthreads();                                      // (everyone is done staging the memo head: the block changes hands)
@@ -451,6 +467,7 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
     const uint32_t t = threadIdx.x;
     // (this thread's first flip record travels with the state: k_band has appended it, whatever the state says)
     uint64_t k0 = 0; uint32_t rs0 = 0, ri0 = 0, rl0 = 0;
+    const unsigned long long t_entry = t == 0 ? VRG_STAMP_NOW() : 0ull;
     if (t < c.fcap) { k0 = c.f_key[t]; rs0 = c.flist[t]; ri0 = c.fr_idx[t]; rl0 = c.fr_lev[t]; }
     if (c.st->done || c.st->bail) return;
     if (t == 0) {
@@ -466,6 +483,7 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
     }
     __syncthreads();
     if (!s_go) return;
+    if (t == 0) { VRG_STAMP_PUT(c, 8, t_entry); VRG_STAMP(c, 9); }
     const uint32_t nf = c.st->nf;
     for (uint32_t j = t, n = c.st->nnz; j < n; j += T) vrg_item_level_clear(c, j);   // level counters of the sweep before
     // the flips' records as k_band appended them; sorted by key, the payload being the record's number
@@ -480,6 +498,7 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
     __syncthreads();
     if (t == 0) vrg_open_update(c);
     wg_sort_pairs(s_key, s_slot, nf, true);
+    if (t == 0) VRG_STAMP(c, 10);
     for (uint32_t r = t; r < nf; r += T) {               // L (+P) bits, stamps, the ordered flip arrays
         const uint32_t q = s_slot[r];
         const bool inner = !(s_key[r] >> 63);
@@ -487,8 +506,10 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
         else vrg_item_list_rec(c, r, c.flist[q], c.fr_idx[q], c.fr_lev[q], inner);
     }
     __syncthreads();
+    if (t == 0) VRG_STAMP(c, 11);
     for (uint32_t r = t; r < nf; r += T) vrg_item_prepass(c, r);         // phase-A label of the flip-ins
     __syncthreads();
+    if (t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 12); }
     const uint32_t np_ = vrg_load_u32(&c.st->npend);
     if (np_) {                                                           // skip-rule fix-point (rare)
         for (;;) {
@@ -505,12 +526,15 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
 constexpr uint32_t LEV_LDS = 2048;  // level values a workgroup of k_mark_relabel keeps in LDS
 __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
     // (the flip voxel of this thread's first item travels with the state: k_order has written the list, whatever the state says)
+    const bool st0 = blockIdx.x == 0 && threadIdx.x == 0;
+    const unsigned long long t_entry = st0 ? VRG_STAMP_NOW() : 0ull;
     const uint32_t r_first = (uint32_t)(((uint64_t)blockIdx.x * TPB + threadIdx.x) >> 7);
     const uint32_t fidx_first = r_first < cg.fcap ? cg.f_idx[r_first] : 0u;
     const int32_t st_done = cg.st->done, st_bail = cg.st->bail;
     const uint32_t nf = cg.st->nf, lane = threadIdx.x & 63;
     asm volatile("" :: "v"(fidx_first), "v"(st_done), "v"(st_bail), "v"(nf));     // one wait for the four
     if (st_done || st_bail) return;
+    if (st0) { VRG_STAMP_PUT(cg, 16, t_entry); VRG_STAMP(cg, 17); }
     const uint64_t n = (uint64_t)nf * 128u;
     if ((uint64_t)blockIdx.x * TPB >= n) return;                          // (no item for this workgroup)
     // a voxel that enters the band needs the level index of its intensity: a binary search, i.e. log2(L) DEPENDENT loads -
@@ -543,6 +567,7 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
             const int64_t ms = m < (int64_t)idx_lo ? (int64_t)idx_lo : (m > (int64_t)idx_hi ? (int64_t)idx_hi : m);
             vrg_preload(c, lab, (uint32_t)ms, pre);
         }
+        if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 18); }
         const bool first = vrg_mark_wanted(p, mb) && vrg_mark_set(c, m);
         // one reservation in the marked list per wave (every first marker of the chip bumping the same word would
         // serialise in L2)
@@ -556,6 +581,7 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
         }
         VrgEvent ev; ev.kind = VE_NONE; ev.pend = 0;
         uint32_t rn = 0, rd = 0, rf = 0;
+        if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 19); }
         if (first) {
             const uint8_t nw = vrg_sweep_core_pre(c, lab, (uint32_t)m, mb, pre, ev);   // (L / P bits date from k_order: mb is current)
             if (q < c.mcap) { c.mk_idx[q] = (uint32_t)m; c.mk_new[q] = nw; } else c.st->error = 4;
@@ -568,6 +594,7 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
             if (dq) atomicAdd(&s_d[1], dq);
         }
         __syncthreads();
+        if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 20); }
         // ... the workgroup reserves its stretch of every list with ONE atomic each ...
         if (threadIdx.x < 3 && s_n[threadIdx.x])
             s_base[threadIdx.x] = vrg_atomic_add(threadIdx.x == 0 ? &c.st->nalloc : threadIdx.x == 1 ? &c.st->ndead : &c.st->nfresh, s_n[threadIdx.x]);
@@ -576,6 +603,7 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
         // ... and every event is written at its place
         if (ev.kind != VE_NONE) vrg_ev_write(c, (uint32_t)m, ev, s_base[0] + rn, s_base[1] + rd, s_base[2] + rf);
         __syncthreads();
+        if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 21); }
     }
 }
 
@@ -591,6 +619,8 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
     const uint32_t t = threadIdx.x;
     // (what a thread's first item needs travels with the state: the lists are complete, whatever the state says)
     uint32_t mk0 = 0; uint8_t mn0 = 0; uint64_t zk0 = 0;
+    const bool st0 = blockIdx.x == 0 && t == 0, stm = blockIdx.x == CLOSE_APPLY && t == 0;
+    const unsigned long long t_entry = (st0 || stm) ? VRG_STAMP_NOW() : 0ull;
     if (blockIdx.x < CLOSE_APPLY) { const uint32_t g0 = blockIdx.x * T + t; if (g0 < c.mcap) { mk0 = c.mk_idx[g0]; mn0 = c.mk_new[g0]; } }
     else if (t < c.zcap) zk0 = c.nz_key[t];
     if (c.st->done || c.st->bail) return;              // (the same for every workgroup: the state is written by the last one to finish)
@@ -600,9 +630,12 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
     __shared__ int s_last;
     const uint32_t nnz = min(c.st->nnz, c.zcap);
     const bool use_tab = nnz <= NZ_SORT && c.st->tab_ok;                 // fewer levels than entries: memoise per level
+    if (st0) { VRG_STAMP_PUT(c, 24, t_entry); VRG_STAMP(c, 25); }
+    if (stm) VRG_STAMP_PUT(c, 32, t_entry);
     if (blockIdx.x < CLOSE_APPLY) {
         if (t == 0 && dense_on) wait_dense_read(c);
         __syncthreads();
+        if (st0) VRG_STAMP(c, 26);
         const uint32_t g = blockIdx.x * T + t, G = CLOSE_APPLY * T;
         const uint32_t nmk = min(c.st->nmk, c.mcap), nf = c.st->nf;
         if (g < nmk) vrg_apply_voxel(c, mk0, vrg_load_coherent(c.lab[0] + mk0), mn0);
@@ -610,6 +643,7 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
         for (uint32_t i = g, nc = vrg_catchup_count(c); i < nc; i += G) vrg_item_catchup(c, i);
         for (uint32_t r = g; r < nf; r += G) vrg_item_check_flip(c, r);
         for (uint32_t j = g, nd = c.st->ndead; j < nd; j += G) vrg_item_free(c, j);
+        if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 27); }
         if (blockIdx.x == 0 && nnz > NZ_SORT) {                          // (rare: a long level list is sorted in place in global memory)
             wg_sort_pairs(c.nz_key, (uint32_t*)nullptr, nnz, false);
             __syncthreads();
@@ -621,6 +655,7 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
         for (uint32_t j = t + T; j < nnz; j += T) s_key[j] = c.nz_key[j];
         __syncthreads();
         wg_sort_pairs(s_key, (uint32_t*)nullptr, nnz, false);
+        if (stm) VRG_STAMP(c, 33);
         for (uint32_t j = t; j < nnz; j += T) {
             const uint32_t l = (uint32_t)s_key[j];
             s_val[j] = c.lev[l]; s_cin[j] = c.dIn[l]; s_cout[j] = c.dOut[l]; s_cconv[j] = c.dConv[l];
@@ -646,12 +681,15 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
     // everything this workgroup sent to memory has arrived before it takes its ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (stm) VRG_STAMP(c, 34);
     if (t == 0) {
         const uint32_t k = __hip_atomic_fetch_add(&c.counters[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (k == gridDim.x - 1);
         if (s_last) {
+            VRG_STAMP(c, 28);
             c.counters[1] = 0;                                           // every workgroup has arrived: reset for the next launch
             vrg_post_apply(c); vrg_request_dense(c); vrg_finalize(c, use_tab);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 29);
         }
     }
 }

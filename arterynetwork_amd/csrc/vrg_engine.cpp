@@ -175,6 +175,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.st = alloc<VrgState>(h, 1);
     c.dn = alloc<VrgDense>(h, 16);                   // own allocation: written by the dense kernel only
     c.counters = alloc<uint32_t>(h, 64);
+    c.dbg = alloc<uint64_t>(h, 64);
     c.dn_part = alloc<VrgDense>(h, 16);
     c.dn_ring = alloc<VrgDense>(h, VRG_RING); c.exp_ring = alloc<int64_t>(h, 2 * VRG_RING);
     c.stage_in = alloc<VrgDense>(h, VRG_STAGE); c.stage_out = alloc<VrgDense>(h, VRG_STAGE);
@@ -198,6 +199,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     be_fill(be, c.dn_ring, 0, VRG_RING * sizeof(VrgDense)); be_fill(be, c.exp_ring, 0, 2 * VRG_RING * sizeof(int64_t));
     be_fill(be, c.stage_in, 0, VRG_STAGE * sizeof(VrgDense)); be_fill(be, c.stage_out, 0, VRG_STAGE * sizeof(VrgDense));
     be_fill(be, c.counters, 0, 64 * sizeof(uint32_t));
+    if (c.dbg) be_fill(be, c.dbg, 0, 64 * sizeof(uint64_t));
     *out = h;
     return VRG_OK;
 }
@@ -527,6 +529,14 @@ int API(get_stats)(vrg_handle* h, int64_t* outp, int64_t cap) {
         if (h->inited) { be_dense_info(h->be, h->c, di); be_download(h->be, uc, h->c.uctl, sizeof(uc)); }
         outp[9] = di[0]; outp[10] = di[1]; outp[11] = di[2]; outp[12] = di[3]; outp[13] = uc[0];
     }
+    return VRG_OK;
+}
+
+// diagnostic build (-DVRG_STAMPS): the 64 in-kernel time stamps of the last sweep (100-MHz ticks); zeros otherwise
+int API(debug_stamps)(vrg_handle* h, uint64_t* out64) {
+    if (!h || !out64 || !h->c.dbg) return VRG_E_ARG;
+    be_sync(h->be);
+    be_download(h->be, out64, h->c.dbg, 64 * sizeof(uint64_t));
     return VRG_OK;
 }
 

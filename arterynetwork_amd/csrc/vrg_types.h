@@ -200,6 +200,7 @@ struct VrgCtx {
     int64_t* gate;             // band -> dense hand-off words (own cache line), VG_*
     int32_t world;             // number of slabs / ranks (1: dn is written directly)
     uint32_t* counters;        // arrival tickets of the last-workgroup reductions (zero between launches)
+    uint64_t* dbg;             // diagnostic build only (-DVRG_STAMPS): in-kernel time stamps of the band chain, see tools/chain_stamps.py
     VrgTrace* trace;
     uint32_t trace_cap;
 };

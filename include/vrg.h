@@ -141,6 +141,10 @@ int vrg_get_levels(vrg_handle* h, double* values, int32_t* hist_in, int32_t* his
  * (0 fp32, 1 u16 level index, 2 float64), out[11] = workgroups, out[12] = skip_excluded, out[13] = units on its list. */
 int vrg_get_stats(vrg_handle* h, int64_t* out, int64_t cap);
 
+/* Diagnostic builds only (compiled with -DVRG_STAMPS, tools/chain_stamps.py): 64 in-kernel time stamps (100-MHz ticks) of
+ * the band chain's last sweep; all zero in the product build. */
+int vrg_debug_stamps(vrg_handle* h, uint64_t* out64);
+
 /* ---- multi-GPU (one process per GPU) --------------------------------------------------
  * Every rank holds the label volume and applies the O(band) relabel identically (it is deterministic),
  * so no label halo has to travel; the O(V) per-sweep work - the dense region recount - is cut into
