@@ -469,14 +469,18 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
     uint64_t k0 = 0; uint32_t rs0 = 0, ri0 = 0, rl0 = 0;
     const unsigned long long t_entry = t == 0 ? VRG_STAMP_NOW() : 0ull;
     if (t < c.fcap) { k0 = c.f_key[t]; rs0 = c.flist[t]; ri0 = c.fr_idx[t]; rl0 = c.fr_lev[t]; }
-    if (c.st->done || c.st->bail) return;
+    // (... and so do the whole state, the region size the size stop looks at and this thread's first touched level: one
+    // round trip for everything the kernel needs before it can order the flips)
+    const VrgState s0 = *c.st;
+    const int64_t nin0 = c.inc[VC_NIN];
+    const uint64_t zk0 = t < c.zcap ? c.nz_key[t] : 0ull;
+    if (s0.done || s0.bail) return;
     if (t == 0) {
         int go = 1;
-        const int32_t stop = vrg_stop_test(c);                           // :91-104, in the reference's order
-        if (stop || c.st->error) { c.st->done = stop ? stop : -1; vrg_close_without_update(c); go = 0; }
+        const int32_t stop = vrg_stop_test_v(s0, nin0);                  // :91-104, in the reference's order
+        if (stop || s0.error) { c.st->done = stop ? stop : -1; vrg_close_without_update(c); go = 0; }
         else {
-            const uint32_t nf = c.st->nf;
-            const int32_t bail = nf > small_limit ? (int32_t)VBAIL_FLIPS : vrg_capacity_test(c, nf);
+            const int32_t bail = s0.nf > small_limit ? (int32_t)VBAIL_FLIPS : vrg_capacity_test(c, s0.nf);
             if (bail) { c.st->bail = bail; vrg_close_without_update(c); go = 0; }
         }
         s_go = go;
@@ -484,8 +488,9 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
     __syncthreads();
     if (!s_go) return;
     if (t == 0) { VRG_STAMP_PUT(c, 8, t_entry); VRG_STAMP(c, 9); }
-    const uint32_t nf = c.st->nf;
-    for (uint32_t j = t, n = c.st->nnz; j < n; j += T) vrg_item_level_clear(c, j);   // level counters of the sweep before
+    const uint32_t nf = s0.nf;
+    if (t < s0.nnz) { const uint32_t l = (uint32_t)zk0; c.dIn[l] = 0; c.dOut[l] = 0; c.dConv[l] = 0; c.ltouch[l] = 0; }   // level counters of the sweep before
+    for (uint32_t j = t + T; j < s0.nnz; j += T) vrg_item_level_clear(c, j);
     // the flips' records as k_band appended them; sorted by key, the payload being the record's number
     if (t < nf) { s_key[t] = k0; s_slot[t] = t; }
     for (uint32_t q = t + T; q < nf; q += T) { s_key[q] = c.f_key[q]; s_slot[q] = q; }
@@ -543,29 +548,47 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
     __shared__ uint32_t s_n[3], s_base[3];                                // this workgroup's new / dead / pending events
     __shared__ int32_t s_d[2];                                            // ... and list length changes
     VrgCtx c = cg;
+    uint8_t* lab = c.lab[0];
+    const uint32_t idx_lo = vrg_idx(c, 0, 0, 0), idx_hi = vrg_idx(c, c.nx - 1, c.ny - 1, c.nz - 1);
+    // The first item of every thread: its voxel's byte AND everything the stencil would read there, requested now -
+    // before the level table is staged (its loads then queue behind these and one wait covers both) and before it is known
+    // whether this thread will run the stencil: one round trip instead of four dependent ones.  (A position outside the
+    // real volume is padding - never relabelled - so its index is clamped to stay inside the arrays.)
+    const uint64_t base0 = (uint64_t)blockIdx.x * TPB;
+    int64_t m0 = 0; uint8_t mb0 = VB_OOB;
+    VrgPre pre0;
+    {
+        const uint64_t i0 = base0 + threadIdx.x;
+        const uint32_t p0 = (uint32_t)(i0 & 127u);
+        if (i0 < n && p0 < 125u) {
+            m0 = vrg_mark_pos(c, fidx_first, p0);
+            mb0 = lab[m0];
+            const int64_t ms = m0 < (int64_t)idx_lo ? (int64_t)idx_lo : (m0 > (int64_t)idx_hi ? (int64_t)idx_hi : m0);
+            vrg_preload(c, lab, (uint32_t)ms, pre0);
+        }
+    }
     if (cg.L <= LEV_LDS && !cg.lev16) {
         for (uint32_t l = threadIdx.x; l < cg.L; l += TPB) s_lev[l] = cg.lev[l];
         c.lev = s_lev;
     }
-    uint8_t* lab = c.lab[0];
-    const uint32_t idx_lo = vrg_idx(c, 0, 0, 0), idx_hi = vrg_idx(c, c.nx - 1, c.ny - 1, c.nz - 1);
+    c.lev_fast = (cg.L <= LEV_LDS || cg.lev16) ? 1 : 0;
     // (every thread of the workgroup makes the same number of trips: the commit below needs its barriers)
-    for (uint64_t base = (uint64_t)blockIdx.x * TPB; base < n; base += (uint64_t)gridDim.x * TPB) {
+    for (uint64_t base = base0; base < n; base += (uint64_t)gridDim.x * TPB) {
         if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
         if (threadIdx.x < 2) s_d[threadIdx.x] = 0;
         __syncthreads();
         const uint64_t i = base + threadIdx.x;
         const uint32_t r = (uint32_t)(i >> 7), p = (uint32_t)(i & 127u);
-        int64_t m = 0; uint8_t mb = VB_OOB;
-        VrgPre pre;
-        if (i < n && p < 125u) {
-            m = vrg_mark_pos(c, base == (uint64_t)blockIdx.x * TPB ? fidx_first : c.f_idx[r], p);
-            mb = lab[m];
-            // everything the stencil would read at this voxel, fetched NOW, together with its byte and before it is known
-            // whether this thread will run the stencil: one round trip instead of four dependent ones.  (A position
-            // outside the real volume is padding - never relabelled - so its index is clamped to stay inside the arrays.)
-            const int64_t ms = m < (int64_t)idx_lo ? (int64_t)idx_lo : (m > (int64_t)idx_hi ? (int64_t)idx_hi : m);
-            vrg_preload(c, lab, (uint32_t)ms, pre);
+        int64_t m = m0; uint8_t mb = mb0;
+        VrgPre pre = pre0;
+        if (base != base0) {
+            m = 0; mb = VB_OOB;
+            if (i < n && p < 125u) {
+                m = vrg_mark_pos(c, c.f_idx[r], p);
+                mb = lab[m];
+                const int64_t ms = m < (int64_t)idx_lo ? (int64_t)idx_lo : (m > (int64_t)idx_hi ? (int64_t)idx_hi : m);
+                vrg_preload(c, lab, (uint32_t)ms, pre);
+            }
         }
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 18); }
         const bool first = vrg_mark_wanted(p, mb) && vrg_mark_set(c, m);
@@ -584,7 +607,7 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 19); }
         if (first) {
             const uint8_t nw = vrg_sweep_core_pre(c, lab, (uint32_t)m, mb, pre, ev);   // (L / P bits date from k_order: mb is current)
-            if (q < c.mcap) { c.mk_idx[q] = (uint32_t)m; c.mk_new[q] = nw; } else c.st->error = 4;
+            if (q < c.mcap) { c.mk_idx[q] = (uint32_t)m; c.mk_new[q] = nw; c.mk_old[q] = mb; } else c.st->error = 4;
             // its event takes a number inside the workgroup ...
             if (ev.kind == VE_NEW) rn = atomicAdd(&s_n[0], 1u);
             if (ev.kind == VE_DIE) rd = atomicAdd(&s_n[1], 1u);
@@ -617,50 +640,101 @@ constexpr int CLOSE_APPLY = 8;
 __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
     constexpr uint32_t T = KC_THREADS;
     const uint32_t t = threadIdx.x;
-    // (what a thread's first item needs travels with the state: the lists are complete, whatever the state says)
-    uint32_t mk0 = 0; uint8_t mn0 = 0; uint64_t zk0 = 0;
     const bool st0 = blockIdx.x == 0 && t == 0, stm = blockIdx.x == CLOSE_APPLY && t == 0;
     const unsigned long long t_entry = (st0 || stm) ? VRG_STAMP_NOW() : 0ull;
-    if (blockIdx.x < CLOSE_APPLY) { const uint32_t g0 = blockIdx.x * T + t; if (g0 < c.mcap) { mk0 = c.mk_idx[g0]; mn0 = c.mk_new[g0]; } }
-    else if (t < c.zcap) zk0 = c.nz_key[t];
-    if (c.st->done || c.st->bail) return;              // (the same for every workgroup: the state is written by the last one to finish)
+    // What a thread's FIRST item of every list needs travels with the state (the lists are complete, whatever the state
+    // says; any index below a list's capacity is readable): the apply workgroups' marked voxel with its current byte, the
+    // class change of the sweep before, a flip's result, a dead slot - one round trip, where a loop after a loop made five.
+    const uint32_t g = blockIdx.x * T + t, G = CLOSE_APPLY * T;
+    uint32_t mk0 = 0, cdwA = VRG_NOCHG, cxA = 0, cdwB = VRG_NOCHG, cxB = 0, dead0 = 0, ncA = 0, ncB = 0; uint8_t mn0 = 0, old0 = 0, fres0 = FR_WRITTEN; uint64_t zk0 = 0;
+    int64_t rseq0 = 0;
+    if (blockIdx.x < CLOSE_APPLY) {
+        if (g < c.mcap) {                              // (both parities of the change list: which one the sweep before filed follows from the state)
+            mk0 = c.mk_idx[g]; mn0 = c.mk_new[g]; old0 = c.mk_old[g]; dead0 = c.dead[g];
+            cdwA = c.chg_dw[0][g]; cxA = c.chg_x[0][g]; cdwB = c.chg_dw[1][g]; cxB = c.chg_x[1][g];
+        }
+        if (g < c.fcap) fres0 = c.f_res[g];
+        ncA = c.nchg[0]; ncB = c.nchg[1];
+        if (t == 0 && dense_on) rseq0 = vrg_load_i64(&c.dctl[VD_RSEQ]);
+    } else if (!c.lvl_scan && t < c.zcap) zk0 = c.nz_key[t];
+    const VrgState s0 = *c.st;
+    if (s0.done || s0.bail) return;                    // (the same for every workgroup: the state is written by the last one to finish)
+    const int pc = ((s0.iter + 1) & 1) ^ 1;                              // parity of the change list the sweep before filed
+    const uint32_t cdw0 = pc ? cdwB : cdwA, cx0 = pc ? cxB : cxA;
     __shared__ uint64_t s_key[NZ_SORT];
     __shared__ double s_val[NZ_SORT];
     __shared__ uint32_t s_cin[NZ_SORT], s_cout[NZ_SORT], s_cconv[NZ_SORT];
+    __shared__ uint32_t s_scan[T / 64];
     __shared__ int s_last;
-    const uint32_t nnz = min(c.st->nnz, c.zcap);
-    const bool use_tab = nnz <= NZ_SORT && c.st->tab_ok;                 // fewer levels than entries: memoise per level
+    uint32_t nnz = c.lvl_scan ? 0u : min(s0.nnz, c.zcap);
+    const bool use_tab = (c.lvl_scan || nnz <= NZ_SORT) && s0.tab_ok;   // fewer levels than entries: memoise per level
+    const uint32_t nmk = min(s0.nmk, c.mcap);
     if (st0) { VRG_STAMP_PUT(c, 24, t_entry); VRG_STAMP(c, 25); }
     if (stm) VRG_STAMP_PUT(c, 32, t_entry);
     if (blockIdx.x < CLOSE_APPLY) {
-        if (t == 0 && dense_on) wait_dense_read(c);
+        const uint32_t nf = s0.nf, nd = s0.ndead, nalloc = s0.nalloc, nc = min(pc ? ncB : ncA, c.mcap);
+        if (t == 0 && dense_on && (int64_t)s0.iter - 1 > rseq0) wait_dense_read(c);        // (the pass of two sweeps ago has read the class copy this sweep rewrites)
         __syncthreads();
         if (st0) VRG_STAMP(c, 26);
-        const uint32_t g = blockIdx.x * T + t, G = CLOSE_APPLY * T;
-        const uint32_t nmk = min(c.st->nmk, c.mcap), nf = c.st->nf;
-        if (g < nmk) vrg_apply_voxel(c, mk0, vrg_load_coherent(c.lab[0] + mk0), mn0);
-        for (uint32_t i = g + G; i < nmk; i += G) vrg_item_apply(c, i);
-        for (uint32_t i = g, nc = vrg_catchup_count(c); i < nc; i += G) vrg_item_catchup(c, i);
-        for (uint32_t r = g; r < nf; r += G) vrg_item_check_flip(c, r);
-        for (uint32_t j = g, nd = c.st->ndead; j < nd; j += G) vrg_item_free(c, j);
+        // the sweep's label bytes (+ class bits, region sizes; the change filed at the voxel's place of the marked list)
+        if (g < nmk) vrg_apply_at(c, g, mk0, old0, mn0);
+        for (uint32_t i = g + G; i < nmk; i += G) vrg_apply_at(c, i, c.mk_idx[i], c.mk_old[i], c.mk_new[i]);
+        // the class changes of the sweep before go into this sweep's copy of the class bits
+        if (g < nc) vrg_catchup_entry(c, cdw0, cx0);
+        for (uint32_t i = g + G; i < nc; i += G) vrg_item_catchup(c, i);
+        if (g < nf && !(fres0 & FR_WRITTEN)) vrg_store_i32(&c.st->error, 3);       // a listed flip the relabel never visited
+        for (uint32_t r = g + G; r < nf; r += G) vrg_item_check_flip(c, r);
+        if (g < nd) vrg_free_entry(c, g, dead0, s0.nfree, nalloc);
+        for (uint32_t j = g + G; j < nd; j += G) vrg_item_free(c, j);
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 27); }
-        if (blockIdx.x == 0 && nnz > NZ_SORT) {                          // (rare: a long level list is sorted in place in global memory)
+        if (blockIdx.x == 0 && !c.lvl_scan && nnz > NZ_SORT) {           // (rare: a long level list is sorted in place in global memory)
             wg_sort_pairs(c.nz_key, (uint32_t*)nullptr, nnz, false);
             __syncthreads();
             for (uint32_t j = t; j < nnz; j += T) vrg_item_level(c, j, false);
         }
-    } else if (nnz <= NZ_SORT && (use_tab || blockIdx.x == CLOSE_APPLY)) {
+    } else if ((c.lvl_scan || nnz <= NZ_SORT) && (use_tab || blockIdx.x == CLOSE_APPLY)) {
         // this sweep's touched levels in ascending order (a fixed summation order), with their counts
-        if (t < nnz) s_key[t] = zk0;
-        for (uint32_t j = t + T; j < nnz; j += T) s_key[j] = c.nz_key[j];
-        __syncthreads();
-        wg_sort_pairs(s_key, (uint32_t*)nullptr, nnz, false);
-        if (stm) VRG_STAMP(c, 33);
-        for (uint32_t j = t; j < nnz; j += T) {
-            const uint32_t l = (uint32_t)s_key[j];
-            s_val[j] = c.lev[l]; s_cin[j] = c.dIn[l]; s_cout[j] = c.dOut[l]; s_cconv[j] = c.dConv[l];
+        if (c.lvl_scan) {
+            // small level table: every level's three counters are looked at - thread t its stretch of levels - and the
+            // touched ones are listed by a block scan: in ascending order by construction, and k_mark_relabel needed no
+            // list-building atomics (two dependent returning atomics per touching thread)
+            const uint32_t per = (c.L + T - 1) / T, l0 = t * per, l1 = min(l0 + per, c.L);
+            uint32_t ci[NZ_SORT / T], co[NZ_SORT / T], cc[NZ_SORT / T], cnt = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < NZ_SORT / T; k++) {
+                const uint32_t l = l0 + k;
+                ci[k] = co[k] = cc[k] = 0;
+                if (k < per && l < l1) { ci[k] = c.dIn[l]; co[k] = c.dOut[l]; cc[k] = c.dConv[l]; }
+                cnt += (ci[k] | co[k] | cc[k]) ? 1u : 0u;
+            }
+            const uint32_t incl = wave_incl_scan(cnt);
+            if ((t & 63) == 63) s_scan[t >> 6] = incl;
+            __syncthreads();
+            uint32_t base = 0, total = 0;
+            for (uint32_t w = 0; w < T / 64; w++) { if (w < (t >> 6)) base += s_scan[w]; total += s_scan[w]; }
+            uint32_t q = base + incl - cnt;
+#pragma unroll
+            for (uint32_t k = 0; k < NZ_SORT / T; k++)
+                if (ci[k] | co[k] | cc[k]) { const uint32_t l = l0 + k; s_key[q] = l; s_val[q] = c.lev[l]; s_cin[q] = ci[k]; s_cout[q] = co[k]; s_cconv[q] = cc[k]; q++; }
+            nnz = total;
+            __syncthreads();
+            if (stm) VRG_STAMP(c, 33);
+            if (blockIdx.x == CLOSE_APPLY) {                             // the list itself: the next k_order clears these counters, an entry-by-entry k_band sums over it
+                for (uint32_t j = t; j < nnz; j += T) c.nz_key[j] = s_key[j];
+                if (t == 0) __hip_atomic_store(&c.st->nnz, nnz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by whoever closes the sweep)
+            }
+        } else {
+            if (t < nnz) s_key[t] = zk0;
+            for (uint32_t j = t + T; j < nnz; j += T) s_key[j] = c.nz_key[j];
+            __syncthreads();
+            wg_sort_pairs(s_key, (uint32_t*)nullptr, nnz, false);
+            if (stm) VRG_STAMP(c, 33);
+            for (uint32_t j = t; j < nnz; j += T) {
+                const uint32_t l = (uint32_t)s_key[j];
+                s_val[j] = c.lev[l]; s_cin[j] = c.dIn[l]; s_cout[j] = c.dOut[l]; s_cconv[j] = c.dConv[l];
+            }
+            __syncthreads();
         }
-        __syncthreads();
         if (blockIdx.x == CLOSE_APPLY)                                   // the ordered level list, for an entry-by-entry k_band
             // (nz_key itself stays as it is: the other workgroups may still be reading it, and only the set matters later)
             for (uint32_t j = t; j < nnz; j += T) { c.nz_val[j] = s_val[j]; c.nz_cin[j] = s_cin[j]; c.nz_cout[j] = s_cout[j]; c.nz_cconv[j] = s_cconv[j]; }
@@ -688,7 +762,7 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
         if (s_last) {
             VRG_STAMP(c, 28);
             c.counters[1] = 0;                                           // every workgroup has arrived: reset for the next launch
-            vrg_post_apply(c); vrg_request_dense(c); vrg_finalize(c, use_tab);
+            vrg_post_apply(c, (int64_t)nmk); vrg_request_dense(c); vrg_finalize(c, use_tab);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 29);
         }
     }
@@ -1778,7 +1852,9 @@ static void host_driven_update(VrgBackend* b, const VrgCtx& c, int flags) {
 }
 
 // update() for a sweep with few flips: three launches, nothing from the host in between
-static void small_update(VrgBackend* b, const VrgCtx& c, bool dense, hipEvent_t e_chain_stop = nullptr) {
+static void small_update(VrgBackend* b, const VrgCtx& c0, bool dense, hipEvent_t e_chain_stop = nullptr) {
+    VrgCtx c = c0;
+    c.lvl_scan = c.L <= NZ_SORT ? 1 : 0;             // small level table: the touched levels are found by scanning the counters (k_close)
     k_order<<<1, KO_THREADS, 0, b->sa>>>(c, b->small_flips);
     k_mark_relabel<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c);
     // (waits on the device for the dense pass of two sweeps ago)

@@ -131,7 +131,7 @@ bool size_marks(vrg_handle* h, uint64_t want, bool keep) {
     uint64_t cap = pow2_at_least(std::max<uint64_t>(want, h->cap_floor));
     if (cap > 0x80000000ull) return false;
     const size_t k = keep ? c.mcap : 0;
-    bool ok = grow(h, c.mk_idx, 0, cap) && grow(h, c.mk_new, 0, cap + 16) && grow(h, c.dead, 0, cap);
+    bool ok = grow(h, c.mk_idx, 0, cap) && grow(h, c.mk_new, 0, cap + 16) && grow(h, c.mk_old, 0, cap + 16) && grow(h, c.dead, 0, cap);
     for (int p = 0; p < 2 && ok; p++) ok = grow(h, c.chg_dw[p], k, cap) && grow(h, c.chg_x[p], k, cap);
     if (!ok) return false;
     c.mcap = (uint32_t)cap;

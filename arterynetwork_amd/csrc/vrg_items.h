@@ -285,14 +285,14 @@ VRG_HD void vrg_exact_serial(const VrgCtx& c, const VrgState& s, uint32_t slot, 
 
 // ------------------------------------------------------------------ the sweep (update(), :156-259)
 // the stop tests in the reference's order, once every entry has decided (the host raises time_up)
-VRG_HD int32_t vrg_stop_test(const VrgCtx& c) {
-    const VrgState& s = *c.st;
+VRG_HD int32_t vrg_stop_test_v(const VrgState& s, int64_t n_in) {
     if (s.iter >= s.iterMax) return VRG_STOP_ITERMAX;                    // :58
     if (s.nf == 0) return VRG_STOP_CONVERGED;                            // :91
     if (s.time_up) return VRG_STOP_TIME;                                 // :97
-    if (c.inc[VC_NIN] >= s.maxSegmentSize) return VRG_STOP_SIZE;           // :101
+    if (n_in >= s.maxSegmentSize) return VRG_STOP_SIZE;                  // :101
     return 0;
 }
+VRG_HD int32_t vrg_stop_test(const VrgCtx& c) { return vrg_stop_test_v(*c.st, c.inc[VC_NIN]); }
 // can this trip's update() run with the arrays as they are?  (checked before anything is modified)
 VRG_HD int32_t vrg_capacity_test(const VrgCtx& c, uint64_t nf) {
     const VrgState& s = *c.st;
@@ -382,6 +382,7 @@ VRG_HD void vrg_item_scatter_marks(const VrgCtx& c, uint32_t r, uint32_t p) {
 // this sweep's innerAdded / outerAdded / addedPoints (:232-235), by level; the first toucher lists the level
 VRG_HD void vrg_note_level(const VrgCtx& c, uint32_t* cnt, uint32_t lev) {
     vrg_atomic_add(&cnt[lev], 1u);
+    if (c.lvl_scan) return;                           // (whoever closes the sweep scans the counters: no returning atomics here)
     if (vrg_atomic_or(&c.ltouch[lev], 1u) == 0u) {
         uint32_t q = vrg_atomic_add(&c.st->nnz, 1u);
         if (q < c.zcap) c.nz_key[q] = lev; else c.st->error = 8;
@@ -479,7 +480,7 @@ VRG_HD uint8_t vrg_sweep_core_pre(const VrgCtx& c, const uint8_t* lab, uint32_t 
     const VrgState& s = *c.st;
     if (cb & VB_S) {
         if (cb & VB_L) {                              // flip-out (:170-175), always applied
-            const uint32_t r = pre.rank, slot = c.f_slot[r], lev = c.f_lev[r];
+            const uint32_t r = pre.rank, slot = pre.vent, lev = c.lev_fast ? vrg_pre_level(c, pre) : c.f_lev[r];   // (a flip is a band entry: its slot is the voxel's)
             vrg_atomic_add(&c.hin[lev], -1); vrg_atomic_add(&c.hout[lev], 1);
             const bool to3 = !nSegA && vrg_later_flip(c, FO, idx, r);   // re-examined by a later flip-out neighbour? (:183-190)
             if (!to3) {                               // stays 2, carried to the outer list (by rank)
@@ -513,7 +514,7 @@ VRG_HD uint8_t vrg_sweep_core_pre(const VrgCtx& c, const uint8_t* lab, uint32_t 
     }
     if (cb & VB_B) {
         if ((cb & VB_L) && (cb & VB_P)) {             // applied flip-in (:198-204)
-            const uint32_t r = pre.rank, slot = c.f_slot[r], lev = c.f_lev[r];
+            const uint32_t r = pre.rank, slot = pre.vent, lev = c.lev_fast ? vrg_pre_level(c, pre) : c.f_lev[r];   // (a flip is a band entry: its slot is the voxel's)
             vrg_atomic_add(&c.hin[lev], 1); vrg_atomic_add(&c.hout[lev], -1);
             const bool to0 = !nNonSegB && vrg_later_flip(c, AP, idx, r);   // re-examined by a later applied flip-in nbr? (:219-228)
             bool fresh = nFO && !nSegA;               // had dropped to 3 in phase A: exact density (:212,:251)
@@ -534,7 +535,7 @@ VRG_HD uint8_t vrg_sweep_core_pre(const VrgCtx& c, const uint8_t* lab, uint32_t 
         if (cb & VB_L) {                              // skipped flip-in
             const uint32_t r = pre.rank;
             c.f_res[r] = (uint8_t)(FR_WRITTEN | res);
-            if ((res & FR_FINAL) == 2) vrg_note_level(c, c.dOut, c.f_lev[r]);
+            if ((res & FR_FINAL) == 2) vrg_note_level(c, c.dOut, c.lev_fast ? vrg_pre_level(c, pre) : c.f_lev[r]);
         }
         return out;
     }
@@ -598,10 +599,33 @@ VRG_HD void vrg_count_change(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t
     if (din) vrg_atomic_add64(&c.inc[VC_NIN], din);
     if (dout) vrg_atomic_add64(&c.inc[VC_NOUT], dout);
 }
+// the same with the change filed at a given place of the sweep's change list (the voxel's place in the marked list) instead
+// of appended through a counter - no returning atomic; a voxel whose class did not change files VRG_NOCHG.  Whoever closes
+// the sweep sets the list's length (vrg_post_apply).
+#define VRG_NOCHG 0xffffffffu
+VRG_HD void vrg_count_change_at(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t nw, uint32_t pos) {
+    uint32_t a = vrg_cls_of(old), b = vrg_cls_of(nw);
+    const int p = (c.st->iter + 1) & 1;
+    if (a == b) { c.chg_dw[p][pos] = VRG_NOCHG; return; }
+    uint32_t dw, sh; vrg_cls_pos(idx, dw, sh);
+    const uint32_t x = (a ^ b) << sh;
+    if (a == 0u) {
+        const uint32_t bit = 1u << ((idx >> 10) & 31u);
+        if (!(vrg_atomic_or(&c.ubits[idx >> 15], bit) & bit)) vrg_atomic_add(&c.uctl[UC_GEN], 1u);
+    }
+    vrg_atomic_xor(&c.clsb[p][dw], x);
+    c.chg_dw[p][pos] = dw; c.chg_x[p][pos] = x;
+    int din = (int)(b == 1u) - (int)(a == 1u), dout = (int)(b == 2u) - (int)(a == 2u);
+    if (din) vrg_atomic_add64(&c.inc[VC_NIN], din);
+    if (dout) vrg_atomic_add64(&c.inc[VC_NOUT], dout);
+}
 // change i of the sweep before: this sweep's copy of the class bits sat that sweep out
+VRG_HD void vrg_catchup_entry(const VrgCtx& c, uint32_t dw, uint32_t x) {
+    if (dw != VRG_NOCHG) vrg_atomic_xor(&c.clsb[(c.st->iter + 1) & 1][dw], x);
+}
 VRG_HD void vrg_item_catchup(const VrgCtx& c, uint32_t i) {
     const int p = (c.st->iter + 1) & 1;
-    vrg_atomic_xor(&c.clsb[p][c.chg_dw[p ^ 1][i]], c.chg_x[p ^ 1][i]);
+    vrg_catchup_entry(c, c.chg_dw[p ^ 1][i], c.chg_x[p ^ 1][i]);
 }
 VRG_HD uint32_t vrg_catchup_count(const VrgCtx& c) { uint32_t n = vrg_load_u32(&c.nchg[((c.st->iter + 1) & 1) ^ 1]); return n < c.mcap ? n : c.mcap; }
 VRG_HD void vrg_apply_voxel(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t nw) {
@@ -612,12 +636,19 @@ VRG_HD void vrg_item_apply(const VrgCtx& c, uint32_t i) {
     const uint32_t idx = c.mk_idx[i];
     vrg_apply_voxel(c, idx, vrg_load_coherent(c.lab[0] + idx), c.mk_new[i]);
 }
+// ... with the class change filed at place i of the change list (see vrg_count_change_at)
+VRG_HD void vrg_apply_at(const VrgCtx& c, uint32_t i, uint32_t idx, uint8_t old, uint8_t nw) {
+    c.lab[0][idx] = nw;
+    vrg_count_change_at(c, idx, old, nw, i);
+}
 // one caller, after every label of sweep iter+1 is written and before anything of the next sweep: file the sizes
 // that sweep's dense pass has to reproduce; the change list just consumed becomes the next sweep's
-VRG_HD void vrg_post_apply(const VrgCtx& c) {
+// nchg_at >= 0: the sweep filed its changes by place (vrg_count_change_at): that many places
+VRG_HD void vrg_post_apply(const VrgCtx& c, int64_t nchg_at = -1) {
     const int64_t k = (int64_t)c.st->iter + 1;
     c.exp_ring[2 * (k % VRG_RING)] = vrg_load_i64(&c.inc[VC_NIN]); c.exp_ring[2 * (k % VRG_RING) + 1] = vrg_load_i64(&c.inc[VC_NOUT]);
     c.nchg[(k & 1) ^ 1] = 0;
+    if (nchg_at >= 0) c.nchg[k & 1] = (uint32_t)nchg_at;
 }
 // init: class dword d from the labels (16 voxels), both copies
 VRG_HD void vrg_item_cls_build(const VrgCtx& c, uint32_t d) {
@@ -681,6 +712,9 @@ VRG_HD uint32_t vrg_free_used(uint32_t nalloc, uint32_t nfree) { return nalloc <
 VRG_HD void vrg_item_free(const VrgCtx& c, uint32_t j) {
     const uint32_t nfree = c.st->nfree;                   // (not changed during the sweep)
     c.freel[nfree - vrg_free_used(vrg_load_u32(&c.st->nalloc), nfree) + j] = c.dead[j];
+}
+VRG_HD void vrg_free_entry(const VrgCtx& c, uint32_t j, uint32_t dead_slot, uint32_t nfree, uint32_t nalloc) {
+    c.freel[nfree - vrg_free_used(nalloc, nfree) + j] = dead_slot;
 }
 // touched level j of the level-sorted list: value and counts out of the per-level counters.  clear: the counters go
 // back to zero at once; otherwise whoever opens the next update() clears them (vrg_item_level_clear) - the two-launch

@@ -144,6 +144,7 @@ struct VrgCtx {
     uint32_t* nchg;            // their lengths (2 counters, own allocation)
     uint32_t* mk_idx;          // marked voxels of this sweep ...
     uint8_t* mk_new;           // ... and their bytes after it
+    uint8_t* mk_old;           // ... and before it (the class of the old byte is what the apply step compares)
     uint64_t* stamp;           // (sweep<<32 | flip rank) of a voxel's last listing; seeds: lex index
     // intensity levels: sorted distinct values and per-class histograms (:149-150, :249-250)
     uint32_t L;
@@ -199,6 +200,11 @@ struct VrgCtx {
     int64_t* dctl;             // dense side (own cache line): dense passes closed since init
     int64_t* gate;             // band -> dense hand-off words (own cache line), VG_*
     int32_t world;             // number of slabs / ranks (1: dn is written directly)
+    // per-launch modes of the batched kernels (a kernel gets its own copy of this struct):
+    int32_t lvl_scan;          // 1: the levels a sweep touched are found by scanning the per-level counters when it closes
+                               //    (small level tables); vrg_note_level then only counts - no list-building atomics
+    int32_t lev_fast;          // 1: a voxel's level index is cheap here (16-bit storage, or the level table in LDS): a flip's
+                               //    level is looked up from its intensity instead of fetched through its rank
     uint32_t* counters;        // arrival tickets of the last-workgroup reductions (zero between launches)
     uint64_t* dbg;             // diagnostic build only (-DVRG_STAMPS): in-kernel time stamps of the band chain, see tools/chain_stamps.py
     VrgTrace* trace;

@@ -167,9 +167,14 @@ void be_init_finish(VrgBackend*, const VrgCtx& c, be_reduce_fn cb, void* user) {
 int be_comm_unique_id(void*) { return -1; }
 int be_comm_init(VrgBackend*, int, int, const void*) { return -1; }
 
-void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents*, be_reduce_fn cb, void* user) {
-    VrgState& s = *c.st;
+void be_sweep_once(VrgBackend* b, const VrgCtx& c0, int flags, VrgEvents*, be_reduce_fn cb, void* user) {
+    VrgState& s = *c0.st;
     if (s.done || s.bail) return;
+    // the per-launch modes of the batched kernels, alternated so that both forms of every item function run here: the
+    // touched levels listed by atomics / found by scanning the counters; a flip's level fetched through its rank / looked up
+    VrgCtx c = c0;
+    c.lvl_scan = (s.iter & 1) && c.L <= 2048;
+    c.lev_fast = (s.iter >> 1) & 1;
     // ---- k_band: corrections of the sweep before, decisions, exact densities of the entries that sweep added
     {
         const VrgState snap = s;
@@ -205,7 +210,8 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents*, be_red
         for (uint32_t r = 0; r < nf; r++) for (uint32_t p = 0; p < 125; p++) vrg_item_scatter_marks(c, r, p);
         if (s.nmk > c.mcap) { s.error = 4; s.done = -1; return; }
         for (uint32_t i = 0; i < s.nmk; i++) vrg_item_relabel(c, i);
-        for (uint32_t i = 0; i < s.nmk; i++) vrg_item_apply(c, i);
+        // (as k_close does: the class change filed at the voxel's place of the marked list, no counter)
+        for (uint32_t i = 0; i < s.nmk; i++) { const uint32_t idx = c.mk_idx[i]; vrg_apply_at(c, i, idx, lab[idx], c.mk_new[i]); }
         for (uint32_t i = 0, nc = vrg_catchup_count(c); i < nc; i++) vrg_item_catchup(c, i);
     } else {
         // full-stencil check variant: every voxel, through the scratch volume
@@ -214,7 +220,7 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents*, be_red
         for (uint32_t i = 0, nc = vrg_catchup_count(c); i < nc; i++) vrg_item_catchup(c, i);
     }
     vrg_request_dense(c);
-    vrg_post_apply(c);
+    vrg_post_apply(c, (flags & VRG_SWEEP_FULL) ? -1 : (int64_t)s.nmk);
     if (!(flags & VRG_SWEEP_NODENSE)) {
         dense_stats(c, lab, cb, user);      // the dense recount (:113-116) ...
         vrg_recount_done(c, *c.dn_part);
@@ -224,6 +230,10 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents*, be_red
     // closing: flips all visited, dead slots onto the free list, this sweep's level deltas in level order
     for (uint32_t r = 0; r < nf; r++) vrg_item_check_flip(c, r);
     for (uint32_t j = 0; j < s.ndead; j++) vrg_item_free(c, j);
+    if (c.lvl_scan) {                          // (k_close, small level table: the touched levels by a scan of the counters)
+        s.nnz = 0;
+        for (uint32_t l = 0; l < c.L; l++) if (c.dIn[l] | c.dOut[l] | c.dConv[l]) c.nz_key[s.nnz++] = l;
+    }
     std::sort(c.nz_key, c.nz_key + s.nnz);
     for (uint32_t j = 0; j < s.nnz; j++) vrg_item_level(c, j, (s.iter & 1) != 0);     // alternate: cleared at once / by the next update()
     const bool use_tab = s.tab_ok != 0;          // either way the same sums; the model alternates with the band size
