@@ -53,6 +53,10 @@ VRG_HD int32_t vrg_load_i32(const int32_t* p) { return __hip_atomic_load(p, __AT
 VRG_HD int64_t vrg_load_i64(const int64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // the error word is written through: another workgroup of the SAME kernel may be the one that reads it (k_close)
 VRG_HD void vrg_store_i32(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// words another STREAM's kernel polls or reads while this kernel is still running (the dense side's gate and expected
+// sizes): written through to memory, and drained before the word that announces them
+VRG_HD void vrg_store_i64(int64_t* p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VRG_HD void vrg_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #elif defined(VRG_HOSTMODEL)
 // tests/hostmodel only (sequential test model of the kernels; never part of the product library)
 VRG_HD uint32_t vrg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
@@ -65,6 +69,8 @@ VRG_HD uint32_t vrg_load_u32(const uint32_t* p) { return *p; }
 VRG_HD int32_t vrg_load_i32(const int32_t* p) { return *p; }
 VRG_HD int64_t vrg_load_i64(const int64_t* p) { return *p; }
 VRG_HD void vrg_store_i32(int32_t* p, int32_t v) { *p = v; }
+VRG_HD void vrg_store_i64(int64_t* p, int64_t v) { *p = v; }
+VRG_HD void vrg_drain() {}
 #else
 // host pass of the product build (hipcc compiles __host__ __device__ functions for both sides): the product has no CPU
 // path - the item functions are never called on the host there, and if one ever were it stops right here
@@ -78,12 +84,27 @@ VRG_HD uint32_t vrg_load_u32(const uint32_t*) { __builtin_trap(); }
 VRG_HD int32_t vrg_load_i32(const int32_t*) { __builtin_trap(); }
 VRG_HD int64_t vrg_load_i64(const int64_t*) { __builtin_trap(); }
 VRG_HD void vrg_store_i32(int32_t*, int32_t) { __builtin_trap(); }
+VRG_HD void vrg_store_i64(int64_t*, int64_t) { __builtin_trap(); }
+VRG_HD void vrg_drain() { __builtin_trap(); }
 #endif
 
 // OR bits into one label byte without disturbing concurrent ORs into its neighbours
 VRG_HD void vrg_or_byte(uint8_t* lab, uint32_t idx, uint8_t bits) {
     uint32_t* w = (uint32_t*)(lab + (idx & ~3u));
     vrg_atomic_or(w, (uint32_t)bits << (8 * (idx & 3u)));
+}
+
+// the whole state, every word past L1 (another workgroup of the same launch may have written it)
+VRG_HD VrgState vrg_load_state(const VrgState* g) {
+    VrgState s;
+    uint32_t w[sizeof(VrgState) / 4];
+    static_assert(sizeof(VrgState) % 4 == 0, "state is a whole number of words");
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (unsigned i = 0; i < sizeof(VrgState) / 4; i++) w[i] = vrg_ld(reinterpret_cast<const uint32_t*>(g) + i);
+    __builtin_memcpy(&s, w, sizeof(s));
+    return s;
 }
 
 // ------------------------------------------------------------------ geometry
@@ -228,13 +249,13 @@ VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, int64_t n_in, in
     bool ge = inN >= outN;
     {   // a decision at rounding level is the reference's summation order's to make, not ours: count it (VRG_TIE_REL)
         const double d = fabs(inN - outN), m = fmax(fabs(inN), fabs(outN));
-        if (n_in == 0 || n_out == 0 || !(d > VRG_TIE_REL * m)) vrg_atomic_add(&c.st->ties, 1u);
-        else if (!(d > VRG_TIE_NEAR_REL * m)) vrg_atomic_add(&c.st->near_ties, 1u);
+        if (n_in == 0 || n_out == 0 || !(d > VRG_TIE_REL * m)) vrg_atomic_add(&c.stg->ties, 1u);
+        else if (!(d > VRG_TIE_NEAR_REL * m)) vrg_atomic_add(&c.stg->near_ties, 1u);
     }
     if (inner == ge) return;                              // :87 xor(segmentedMap, inner >= outer)
-    uint32_t q = vrg_atomic_add(&c.st->nf, 1u);
+    uint32_t q = vrg_atomic_add(&c.stg->nf, 1u);
     if (s.time_up || n_in >= s.maxSegmentSize) return;    // :97 / :101 fire before update(): count only
-    if (q >= c.fcap) { c.st->error = 2; return; }
+    if (q >= c.fcap) { c.stg->error = 2; return; }
     c.flist[q] = slot; c.f_key[q] = vrg_flip_key(inner, key); c.fr_idx[q] = idx; c.fr_lev[q] = lev;
 }
 // one pool slot whose fields the caller has fetched; nz_* = this trip's view of the touched-level list (LDS copy on the
@@ -249,8 +270,8 @@ VRG_HD void vrg_item_band_fields(const VrgCtx& c, const VrgState& s, uint32_t sl
     if (s.corr) {
         double ic, oc, ac;
         if (s.use_tab) {
-            const double* t3 = lev < tab_n ? tab + 3 * (size_t)lev : c.tabC + 3 * (size_t)lev;
-            ic = t3[0]; oc = t3[1]; ac = t3[2];
+            if (lev < tab_n) { const double* t3 = tab + 3 * (size_t)lev; ic = t3[0]; oc = t3[1]; ac = t3[2]; }
+            else { ic = c.tabC[3 * (size_t)lev]; oc = c.tabC[3 * (size_t)lev + 1]; ac = c.tabC[3 * (size_t)lev + 2]; }
         }
         else vrg_corrections(c, s.nnz, nz_val, nz_cin, nz_cout, nz_cconv, c.lev[lev], ic, oc, ac);
         vrg_add_correction(ic, oc, ac, ip, op);
@@ -301,9 +322,9 @@ VRG_HD int32_t vrg_capacity_test(const VrgCtx& c, uint64_t nf) {
     return 0;
 }
 // the trip stops (or is handed back): nothing pending for the next k_band
-VRG_HD void vrg_close_without_update(const VrgCtx& c) { c.st->corr = 0; c.st->nfx = 0; c.gate[VG_STOP] = 1; }
+VRG_HD void vrg_close_without_update(const VrgCtx& c) { c.stg->corr = 0; c.stg->nfx = 0; vrg_store_i64(&c.gate[VG_STOP], 1); }
 // update() begins: k_band has consumed the touched-level list of the sweep before
-VRG_HD void vrg_open_update(const VrgCtx& c) { c.st->nnz = 0; c.st->tab_ok = c.L <= c.st->ni + c.st->no; }
+VRG_HD void vrg_open_update(const VrgCtx& c) { c.stg->nnz = 0; c.stg->tab_ok = c.L <= c.st->ni + c.st->no; }
 
 // flip r of the ordered list: L bit (+P for flip-outs, which are always applied), stamp = (sweep, rank)
 VRG_HD void vrg_item_list_rec(const VrgCtx& c, uint32_t r, uint32_t slot, uint32_t idx, uint32_t lev, bool inner) {
@@ -324,7 +345,7 @@ VRG_HD void vrg_item_prepass(const VrgCtx& c, uint32_t r) {
     if (m.S & (1u << 13)) return;                          // a flip-out
     const uint32_t ex = ~m.O & 0x7ffdfffu;                 // existing neighbours (centre excluded)
     const bool nFO = (m.S & m.L & ex) != 0, nSegA = (m.S & ~m.L & ex) != 0;
-    if (nFO && !nSegA) c.pend[vrg_atomic_add(&c.st->npend, 1u)] = r;   // dropped to 3: skipped unless re-promoted
+    if (nFO && !nSegA) c.pend[vrg_atomic_add(&c.stg->npend, 1u)] = r;   // dropped to 3: skipped unless re-promoted
     else vrg_or_byte(c.lab[0], idx, VB_P);
 }
 
@@ -373,8 +394,8 @@ VRG_HD void vrg_item_scatter_marks(const VrgCtx& c, uint32_t r, uint32_t p) {
     const int64_t m = vrg_mark_pos(c, c.f_idx[r], p);
     if (!vrg_mark_wanted(p, vrg_load_coherent(c.lab[0] + m))) return;
     if (vrg_mark_set(c, m)) {
-        uint32_t q = vrg_atomic_add(&c.st->nmk, 1u);
-        if (q < c.mcap) c.mk_idx[q] = (uint32_t)m; else c.st->error = 4;
+        uint32_t q = vrg_atomic_add(&c.stg->nmk, 1u);
+        if (q < c.mcap) c.mk_idx[q] = (uint32_t)m; else c.stg->error = 4;
     }
 }
 
@@ -384,8 +405,8 @@ VRG_HD void vrg_note_level(const VrgCtx& c, uint32_t* cnt, uint32_t lev) {
     vrg_atomic_add(&cnt[lev], 1u);
     if (c.lvl_scan) return;                           // (whoever closes the sweep scans the counters: no returning atomics here)
     if (vrg_atomic_or(&c.ltouch[lev], 1u) == 0u) {
-        uint32_t q = vrg_atomic_add(&c.st->nnz, 1u);
-        if (q < c.zcap) c.nz_key[q] = lev; else c.st->error = 8;
+        uint32_t q = vrg_atomic_add(&c.stg->nnz, 1u);
+        if (q < c.zcap) c.nz_key[q] = lev; else c.stg->error = 8;
     }
 }
 // What the relabel of one voxel means for the band pool: at most one event per voxel.  The stencil only DESCRIBES it;
@@ -412,7 +433,7 @@ VRG_HD void vrg_ev_write(const VrgCtx& c, uint32_t idx, const VrgEvent& e, uint3
     uint32_t slot = e.slot;
     if (e.kind == VE_NEW) {                               // a voxel enters the band (newInnerBndList / newOuterBndList, :196, :213)
         slot = q < s.nfree ? c.freel[s.nfree - 1u - q] : s.np + (q - s.nfree);
-        if (slot >= c.bcap) { c.st->error = 1; return; }
+        if (slot >= c.bcap) { c.stg->error = 1; return; }
         c.p_idx[slot] = idx; c.p_lev[slot] = e.lev; c.p_ip[slot] = 0; c.p_op[slot] = 0; c.p_key[slot] = e.key;
         c.p_flag[slot] = (uint8_t)(PF_ALIVE | PF_PEND | (e.to_inner ? PF_INNER : 0));
         c.vent[idx] = slot;
@@ -429,12 +450,12 @@ VRG_HD void vrg_ev_write(const VrgCtx& c, uint32_t idx, const VrgEvent& e, uint3
 VRG_HD void vrg_commit_event(const VrgCtx& c, uint32_t idx, const VrgEvent& e) {
     if (e.kind == VE_NONE) return;
     uint32_t q = 0, qd = 0, qf = 0;
-    if (e.kind == VE_NEW) q = vrg_atomic_add(&c.st->nalloc, 1u);
-    if (e.kind == VE_DIE) qd = vrg_atomic_add(&c.st->ndead, 1u);
-    if (e.kind != VE_DIE && e.pend) qf = vrg_atomic_add(&c.st->nfresh, 1u);
+    if (e.kind == VE_NEW) q = vrg_atomic_add(&c.stg->nalloc, 1u);
+    if (e.kind == VE_DIE) qd = vrg_atomic_add(&c.stg->ndead, 1u);
+    if (e.kind != VE_DIE && e.pend) qf = vrg_atomic_add(&c.stg->nfresh, 1u);
     const int di = vrg_ev_dni(e), dq = vrg_ev_dno(e);
-    if (di) vrg_atomic_add(&c.st->d_ni, di);
-    if (dq) vrg_atomic_add(&c.st->d_no, dq);
+    if (di) vrg_atomic_add(&c.stg->d_ni, di);
+    if (dq) vrg_atomic_add(&c.stg->d_no, dq);
     vrg_ev_write(c, idx, e, q, qd, qf);
 }
 
@@ -594,7 +615,7 @@ VRG_HD void vrg_count_change(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t
     }
     vrg_atomic_xor(&c.clsb[p][dw], x);
     uint32_t q = vrg_atomic_add(&c.nchg[p], 1u);
-    if (q < c.mcap) { c.chg_dw[p][q] = dw; c.chg_x[p][q] = x; } else vrg_store_i32(&c.st->error, 7);
+    if (q < c.mcap) { c.chg_dw[p][q] = dw; c.chg_x[p][q] = x; } else vrg_store_i32(&c.stg->error, 7);
     int din = (int)(b == 1u) - (int)(a == 1u), dout = (int)(b == 2u) - (int)(a == 2u);
     if (din) vrg_atomic_add64(&c.inc[VC_NIN], din);
     if (dout) vrg_atomic_add64(&c.inc[VC_NOUT], dout);
@@ -646,7 +667,7 @@ VRG_HD void vrg_apply_at(const VrgCtx& c, uint32_t i, uint32_t idx, uint8_t old,
 // nchg_at >= 0: the sweep filed its changes by place (vrg_count_change_at): that many places
 VRG_HD void vrg_post_apply(const VrgCtx& c, int64_t nchg_at = -1) {
     const int64_t k = (int64_t)c.st->iter + 1;
-    c.exp_ring[2 * (k % VRG_RING)] = vrg_load_i64(&c.inc[VC_NIN]); c.exp_ring[2 * (k % VRG_RING) + 1] = vrg_load_i64(&c.inc[VC_NOUT]);
+    vrg_store_i64(&c.exp_ring[2 * (k % VRG_RING)], vrg_load_i64(&c.inc[VC_NIN])); vrg_store_i64(&c.exp_ring[2 * (k % VRG_RING) + 1], vrg_load_i64(&c.inc[VC_NOUT]));
     c.nchg[(k & 1) ^ 1] = 0;
     if (nchg_at >= 0) c.nchg[k & 1] = (uint32_t)nchg_at;
 }
@@ -670,7 +691,8 @@ VRG_HD void vrg_ulist_rebuild_serial(const VrgCtx& c) {
     c.uctl[UC_N] = n; c.uctl[UC_LGEN] = g;
 }
 // one caller per applied sweep: the labels of sweep iter+1 are in place, a dense pass over them is due
-VRG_HD void vrg_request_dense(const VrgCtx& c) { c.gate[VG_REQ] = (int64_t)c.st->iter + 1; }
+// (the expected sizes and every class bit of the sweep have reached memory before the request does)
+VRG_HD void vrg_request_dense(const VrgCtx& c) { vrg_drain(); vrg_store_i64(&c.gate[VG_REQ], (int64_t)c.st->iter + 1); }
 VRG_HD bool vrg_dense_due(const VrgCtx& c) { return vrg_load_i64(&c.gate[VG_REQ]) > vrg_load_i64(&c.dctl[VD_RSEQ]); }
 // recount number rseq = recounts done + 1 (it read class copy rseq & 1) has this device's slab sums: keep them for the pass
 VRG_HD void vrg_recount_done(const VrgCtx& c, const VrgDense& part) {
@@ -711,7 +733,7 @@ VRG_HD void vrg_init_counts(const VrgCtx& c) {
 VRG_HD uint32_t vrg_free_used(uint32_t nalloc, uint32_t nfree) { return nalloc < nfree ? nalloc : nfree; }
 VRG_HD void vrg_item_free(const VrgCtx& c, uint32_t j) {
     const uint32_t nfree = c.st->nfree;                   // (not changed during the sweep)
-    c.freel[nfree - vrg_free_used(vrg_load_u32(&c.st->nalloc), nfree) + j] = c.dead[j];
+    c.freel[nfree - vrg_free_used(vrg_load_u32(&c.stg->nalloc), nfree) + j] = c.dead[j];
 }
 VRG_HD void vrg_free_entry(const VrgCtx& c, uint32_t j, uint32_t dead_slot, uint32_t nfree, uint32_t nalloc) {
     c.freel[nfree - vrg_free_used(nalloc, nfree) + j] = dead_slot;
@@ -730,15 +752,15 @@ VRG_HD void vrg_item_level(const VrgCtx& c, uint32_t j, bool clear) {
     if (clear) vrg_item_level_clear(c, j);
 }
 // a listed flip the relabel never visited would be an internal error
-VRG_HD void vrg_item_check_flip(const VrgCtx& c, uint32_t r) { if (!(c.f_res[r] & FR_WRITTEN)) vrg_store_i32(&c.st->error, 3); }
+VRG_HD void vrg_item_check_flip(const VrgCtx& c, uint32_t r) { if (!(c.f_res[r] & FR_WRITTEN)) vrg_store_i32(&c.stg->error, 3); }
 // iterNum += 1 (:117), list lengths, free list, trace record; what the next k_band finds pending
 VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
-    VrgState s = *c.st;                               // one round trip for the whole state, one to write it back
+    VrgState s = vrg_load_state(c.stg);               // one round trip for the whole state (past L1), one to write it back
     // ... the counters this kernel's atomics moved come from L2
-    s.nalloc = vrg_load_u32(&c.st->nalloc); s.ndead = vrg_load_u32(&c.st->ndead); s.nfresh = vrg_load_u32(&c.st->nfresh);
-    s.nnz = vrg_load_u32(&c.st->nnz); s.nmk = vrg_load_u32(&c.st->nmk); s.npend = vrg_load_u32(&c.st->npend);
-    s.d_ni = vrg_load_i32(&c.st->d_ni); s.d_no = vrg_load_i32(&c.st->d_no); s.error = vrg_load_i32(&c.st->error);
-    s.ties = vrg_load_u32(&c.st->ties); s.near_ties = vrg_load_u32(&c.st->near_ties);
+    s.nalloc = vrg_load_u32(&c.stg->nalloc); s.ndead = vrg_load_u32(&c.stg->ndead); s.nfresh = vrg_load_u32(&c.stg->nfresh);
+    s.nnz = vrg_load_u32(&c.stg->nnz); s.nmk = vrg_load_u32(&c.stg->nmk); s.npend = vrg_load_u32(&c.stg->npend);
+    s.d_ni = vrg_load_i32(&c.stg->d_ni); s.d_no = vrg_load_i32(&c.stg->d_no); s.error = vrg_load_i32(&c.stg->error);
+    s.ties = vrg_load_u32(&c.stg->ties); s.near_ties = vrg_load_u32(&c.stg->near_ties);
     const int64_t n_in = vrg_load_i64(&c.inc[VC_NIN]), n_out = vrg_load_i64(&c.inc[VC_NOUT]);
     const uint32_t used = vrg_free_used(s.nalloc, s.nfree);
     s.np += s.nalloc - used; s.nfree = s.nfree - used + s.ndead;
@@ -754,8 +776,8 @@ VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
     s.nf = 0; s.npend = 0; s.nmk = 0; s.nalloc = 0; s.ndead = 0; s.d_ni = 0; s.d_no = 0;
     s.nfx = s.nfresh; s.nfresh = 0;                   // exact densities of the new entries: first thing next trip
     s.corr = 1; s.use_tab = use_tab ? 1 : 0;          // nnz stays: the next k_band reads the touched-level list
-    if (s.error) { s.done = -1; c.gate[VG_STOP] = 1; }
-    *c.st = s;
+    if (s.error) { s.done = -1; vrg_store_i64(&c.gate[VG_STOP], 1); }
+    *c.stg = s;
 }
 
 // ------------------------------------------------------------------ init mode (:129-155)
