@@ -482,11 +482,15 @@ VRG_HD bool vrg_later_flip(const VrgCtx& c, uint32_t cand, uint32_t idx, uint32_
 }
 // an excluded voxel: is an applied flip within its 2-ring (:177-179, :206-208)?  25 rows of 5 bytes
 VRG_HD bool vrg_ring2_applied(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
+    uint64_t any = 0;                                      // (no early exit: the 25 rows are then requested together, not one after the other)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
     for (int j = 0; j < 25; j++) {
         const uint64_t w = vrg_load_row8(lab + ((int64_t)idx + ((j / 5 - 2) * c.PY + (j % 5 - 2)) * c.PX - 2));
-        if (((w >> 4) & ~(w >> 5)) & 0x0101010101ull) return true;         // P and not OOB, bytes 0..4
+        any |= ((w >> 4) & ~(w >> 5)) & 0x0101010101ull;                   // P and not OOB, bytes 0..4
     }
-    return false;
+    return any != 0;
 }
 
 // Returns the voxel's byte after the sweep and files what the change means for the band pool (slot born / dead /

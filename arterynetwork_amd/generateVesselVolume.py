@@ -38,6 +38,24 @@ def _check(rc):
         raise VrgError(rc, _lib().vmask_last_error().decode())
 
 
+def _on_device(a):
+    """A torch tensor that lives on the GPU: the volume is handed to the C-ABI by its device pointer (include/vmask.h accepts
+    host and device pointers alike) and the result comes back as a tensor on the same device - stage 1 -> VRG -> export can
+    then run without a PCIe round trip per call (0.3 s each at 880x880x640 with host arrays)."""
+    return hasattr(a, 'data_ptr') and bool(getattr(a, 'is_cuda', False))
+
+
+def _dev_index(t):
+    return t.device.index if t.device.index is not None else 0
+
+
+def _u8t(t):
+    import torch
+    if t.dim() != 3:
+        raise ValueError('expected a 3-D volume')
+    return (t != 0).to(torch.uint8).contiguous()
+
+
 def _u8c(a):
     a = np.asarray(a)
     if a.ndim != 3:
@@ -48,6 +66,13 @@ def _u8c(a):
 def distance_transform_edt(mask, device=0):
     """scipy.ndimage.distance_transform_edt(mask) with unit sampling (generateVesselVolume.py:183,
     manualCorrectionGUI.py:248): float64 distance of every non-zero voxel to the nearest zero voxel."""
+    if _on_device(mask):                               # device-resident: tensor in, tensor out
+        import torch
+        m = _u8t(mask)
+        out = torch.empty(m.shape, dtype=torch.float64, device=m.device)
+        torch.cuda.synchronize(m.device)
+        _check(_lib().vmask_edt(_dev_index(m), m.data_ptr(), *m.shape, out.data_ptr()))
+        return out
     m = _u8c(mask)
     out = np.empty(m.shape, np.float64)
     _check(_lib().vmask_edt(device, m.ctypes.data, *m.shape, out.ctypes.data))
@@ -90,6 +115,25 @@ def labelVolume(volume, minSize=1, maxHop=3, device=0):
     non-zero values would be partitioned differently from what this kernel (which looks at zero / non-zero) does -
     such input raises instead of returning different labels.
     """
+    if _on_device(volume):                             # device-resident: labels stay on the GPU (int32), the sizes come to the host
+        import torch
+        nzv = volume[volume != 0]
+        if nzv.numel() and bool((nzv != nzv.flatten()[0]).any()):
+            raise ValueError('labelVolume: only binary volumes are supported (several distinct non-zero values found)')
+        v = _u8t(volume)
+        labeled = torch.empty(v.shape, dtype=torch.int32, device=v.device)
+        n = C.c_int64()
+        cap = max(1, v.numel() // 2 + 1)
+        sizes = np.empty(cap, np.int64)
+        torch.cuda.synchronize(v.device)
+        _check(_lib().vmask_label(_dev_index(v), v.data_ptr(), *v.shape, int(maxHop), labeled.data_ptr(), sizes.ctypes.data, cap, C.byref(n)))
+        ncomp = n.value
+        labelResult = []
+        nbg = int(v.numel() - sizes[:ncomp].sum())
+        if nbg:
+            labelResult.append((0, nbg))
+        labelResult.extend((k + 1, int(sizes[k])) for k in range(ncomp))
+        return labeled, labelResult
     a = np.asarray(volume)
     nz = a[a != 0]
     if nz.size and np.any(nz != nz.flat[0]):
@@ -121,6 +165,21 @@ def vesselVolumeMask(brainVolumeMask, vesselnessVolume, edtMax=10, frac1=0.8, fr
     """The body of the reference's main() between loading and saving (generateVesselVolume.py:177-199):
     suppress weak vesselness near the brain-mask boundary (EDT <= 10 and <= min + 0.8*range), threshold at
     min + 0.7*range, binarise, drop 26-connected components of <= 150 voxels.  Returns the uint8 mask."""
+    if _on_device(vesselnessVolume):                   # device-resident: the uint8 mask comes back as a tensor on the same GPU
+        import torch
+        ves = vesselnessVolume.contiguous()
+        if ves.dtype not in (torch.float32, torch.float64):
+            ves = ves.to(torch.float64)
+        b = _u8t(brainVolumeMask if _on_device(brainVolumeMask) else torch.as_tensor(np.asarray(brainVolumeMask), device=ves.device))
+        if tuple(b.shape) != tuple(ves.shape):
+            raise ValueError('brainVolumeMask and vesselnessVolume must have the same shape')
+        out = torch.empty(ves.shape, dtype=torch.uint8, device=ves.device)
+        kept = C.c_int64()
+        torch.cuda.synchronize(ves.device)
+        _check(_lib().vmask_vessel_mask(_dev_index(ves), b.data_ptr(), ves.data_ptr(), 5 if ves.dtype == torch.float32 else 6,
+                                        *ves.shape, float(edtMax), float(frac1), float(frac2), int(minSize), out.data_ptr(), C.byref(kept)))
+        print('Number of voxels in segmentation: {}'.format(kept.value))      # :211
+        return out
     ves = np.ascontiguousarray(vesselnessVolume)
     if ves.dtype not in (np.float32, np.float64):
         ves = ves.astype(np.float64)

@@ -123,3 +123,40 @@ def test_nifti_main_round_trip(tmp_path):
     out, aff2 = nifti.loadVolume(str(tmp_path), 'vesselVolumeMask.nii.gz')
     assert out.dtype == np.uint8 and np.array_equal(out, m) and np.allclose(aff2, aff)
     assert np.array_equal(m, MO.vesselVolumeMask(brain, ves))
+
+
+DEVICE_RESIDENT_SCRIPT = r"""
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch                      # before the HIP library: one ROCm runtime per process (INTEGRATION.md)
+from arterynetwork_amd import generateVesselVolume as G
+rng = np.random.default_rng(12)
+shape = (40, 36, 31)
+ves = rng.random(shape).astype(np.float32)
+brain = np.zeros(shape, np.uint8); brain[3:-3, 4:-2, 2:-4] = 1
+dev = torch.device('cuda', 0)
+m_host = G.vesselVolumeMask(brain, ves, minSize=5)
+m_dev = G.vesselVolumeMask(torch.as_tensor(brain, device=dev), torch.as_tensor(ves, device=dev), minSize=5)
+assert m_dev.is_cuda and m_dev.dtype == torch.uint8 and np.array_equal(m_dev.cpu().numpy(), m_host)
+assert m_host.sum() > 0
+lab_h, res_h = G.labelVolume(m_host)
+lab_d, res_d = G.labelVolume(m_dev)
+assert lab_d.is_cuda and np.array_equal(lab_d.cpu().numpy().astype(np.int64), lab_h) and res_d == res_h
+d_h = G.distance_transform_edt(m_host)
+d_d = G.distance_transform_edt(m_dev)
+assert d_d.is_cuda and np.array_equal(d_d.cpu().numpy(), d_h)
+print('DEVICE RESIDENT OK')
+"""
+
+
+@pytest.mark.gpu
+def test_device_resident_volumes_in_and_out():
+    """Tensors that live on the GPU go to the C-ABI by their device pointers and the results stay on the GPU: the same
+    mask, labels and distances as with host arrays (no PCIe round trip per call).  Own process: torch is imported
+    before the HIP library there."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, '-c', DEVICE_RESIDENT_SCRIPT.format(root=ROOT)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'DEVICE RESIDENT OK' in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
