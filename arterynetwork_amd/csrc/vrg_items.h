@@ -463,22 +463,37 @@ VRG_HD void vrg_commit_event(const VrgCtx& c, uint32_t idx, const VrgEvent& e) {
 // who promotes this voxel - `cand` = its applied flip-in neighbours (phase B, 3 -> 2, :210-213) or its flip-out
 // neighbours (phase A, 0 -> 1, :194-196): the one of smallest rank; (rank, k) is the list key of the promoted voxel,
 // k = its position in get_neighbours(promoter) = 26 - the promoter's position seen from here
+// (The candidates' ranks are fetched four at a time: a loop that loads one stamp per turn - or leaves at the first hit - is a
+// chain of dependent round trips, one per flip neighbour; the usual one to three neighbours now cost one.)
+constexpr int VRG_RANK_BATCH = 4;
+VRG_HD void vrg_rank_batch(const VrgCtx& c, uint32_t& cand, uint32_t idx, uint32_t n[VRG_RANK_BATCH], uint32_t r[VRG_RANK_BATCH]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < VRG_RANK_BATCH; k++) { n[k] = cand ? vrg_ctz(cand) : 32u; if (cand) cand &= cand - 1u; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < VRG_RANK_BATCH; k++) r[k] = n[k] < 27u ? (uint32_t)c.stamp[(uint32_t)((int64_t)idx + vrg_noff(c, n[k]))] : 0u;
+}
 VRG_HD void vrg_promoter(const VrgCtx& c, uint32_t cand, uint32_t idx, uint32_t& rank, uint32_t& k_out) {
     uint32_t best = 0xffffffffu, bk = 0;
     while (cand) {
-        const uint32_t n = vrg_ctz(cand); cand &= cand - 1u;
-        const uint32_t r = (uint32_t)c.stamp[(uint32_t)((int64_t)idx + vrg_noff(c, n))];
-        if (r < best) { best = r; bk = 26u - vrg_nk(n); }
+        uint32_t n[VRG_RANK_BATCH], r[VRG_RANK_BATCH];
+        vrg_rank_batch(c, cand, idx, n, r);
+        for (int k = 0; k < VRG_RANK_BATCH; k++) if (n[k] < 27u && r[k] < best) { best = r[k]; bk = 26u - vrg_nk(n[k]); }   // (ascending n: the first of equal ranks wins, as before)
     }
     rank = best; k_out = bk;
 }
 // is one of the listed neighbours in `cand` of larger rank than r?
 VRG_HD bool vrg_later_flip(const VrgCtx& c, uint32_t cand, uint32_t idx, uint32_t r) {
-    while (cand) {
-        const uint32_t n = vrg_ctz(cand); cand &= cand - 1u;
-        if ((uint32_t)c.stamp[(uint32_t)((int64_t)idx + vrg_noff(c, n))] > r) return true;
+    bool later = false;
+    while (cand && !later) {
+        uint32_t n[VRG_RANK_BATCH], rk[VRG_RANK_BATCH];
+        vrg_rank_batch(c, cand, idx, n, rk);
+        for (int k = 0; k < VRG_RANK_BATCH; k++) later = later || (n[k] < 27u && rk[k] > r);
     }
-    return false;
+    return later;
 }
 // an excluded voxel: is an applied flip within its 2-ring (:177-179, :206-208)?  25 rows of 5 bytes
 VRG_HD bool vrg_ring2_applied(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
