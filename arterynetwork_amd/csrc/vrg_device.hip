@@ -117,10 +117,12 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
 #define VRG_STAMP(c, k) do { c.dbg[k] = wall_clock64(); } while (0)
 #define VRG_STAMP_NOW() wall_clock64()
 #define VRG_STAMP_PUT(c, k, v) do { c.dbg[k] = (v); } while (0)
+#define VRG_STAMP_MAX(c, k) do { atomicMax(&c.dbg[k], (unsigned long long)wall_clock64()); } while (0)   // the last workgroup's exit
 #else
 #define VRG_STAMP(c, k) do { } while (0)
 #define VRG_STAMP_NOW() 0ull
 #define VRG_STAMP_PUT(c, k, v) do { (void)(v); } while (0)
+#define VRG_STAMP_MAX(c, k) do { } while (0)
 #endif
 #define ITEM_LOOP(n) for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += gridDim.x * blockDim.x)
 // same with a 64-bit item index: (listed flips) x (positions) can exceed 2^32 on adversarial volumes
@@ -260,7 +262,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks) {
     const VrgState s = *c.st;                             // a copy (nf is only ever bumped atomically)
     if (s.done || s.bail) return;
     const bool live = s.iter < s.iterMax;
-    if (st0 && live) { VRG_STAMP_PUT(c, 0, t_entry); VRG_STAMP(c, 1); }
+    if (st0 && live) { VRG_STAMP_PUT(c, 6, c.dbg[0]); VRG_STAMP_PUT(c, 0, t_entry); VRG_STAMP(c, 1); }    // (6: the sweep before this one)
     if (!pool_wg) {
         exact_wg(c, s, s.nfx, blockIdx.x - band_blocks, EXACT_BLOCKS);
         if (stx && live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP_PUT(c, 3, t_entry); VRG_STAMP(c, 4); }
@@ -532,11 +534,14 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
 }
 
 constexpr uint32_t LEV_LDS = 2048;  // level values a workgroup of k_mark_relabel keeps in LDS
-__global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
+constexpr int KM_THREADS = 128;     // k_mark_relabel: one flip's 125 places per workgroup - its scattered row loads then share a CU's
+                                    // address unit with one other wave instead of three (A/B in one session: 256 threads +1.0 us alone, 64 +0.5 us)
+constexpr int KM_BLOCKS = ITEM_BLOCKS * TPB / KM_THREADS;
+__global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
     // (the flip voxel of this thread's first item travels with the state: k_order has written the list, whatever the state says)
     const bool st0 = blockIdx.x == 0 && threadIdx.x == 0;
     const unsigned long long t_entry = st0 ? VRG_STAMP_NOW() : 0ull;
-    const uint32_t r_first = (uint32_t)(((uint64_t)blockIdx.x * TPB + threadIdx.x) >> 7);
+    const uint32_t r_first = (uint32_t)(((uint64_t)blockIdx.x * KM_THREADS + threadIdx.x) >> 7);
     const uint32_t fidx_first = r_first < cg.fcap ? cg.f_idx[r_first] : 0u;
     const int32_t st_done = cg.st->done, st_bail = cg.st->bail;
     const uint32_t nf = cg.st->nf, lane = threadIdx.x & 63;
@@ -544,7 +549,7 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
     if (st_done || st_bail) return;
     if (st0) { VRG_STAMP_PUT(cg, 16, t_entry); VRG_STAMP(cg, 17); }
     const uint64_t n = (uint64_t)nf * 128u;
-    if ((uint64_t)blockIdx.x * TPB >= n) return;                          // (no item for this workgroup)
+    if ((uint64_t)blockIdx.x * KM_THREADS >= n) return;                          // (no item for this workgroup)
     // a voxel that enters the band needs the level index of its intensity: a binary search, i.e. log2(L) DEPENDENT loads -
     // from LDS when the table fits
     __shared__ double s_lev[LEV_LDS];
@@ -557,7 +562,7 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
     // before the level table is staged (its loads then queue behind these and one wait covers both) and before it is known
     // whether this thread will run the stencil: one round trip instead of four dependent ones.  (A position outside the
     // real volume is padding - never relabelled - so its index is clamped to stay inside the arrays.)
-    const uint64_t base0 = (uint64_t)blockIdx.x * TPB;
+    const uint64_t base0 = (uint64_t)blockIdx.x * KM_THREADS;
     int64_t m0 = 0; uint8_t mb0 = VB_OOB;
     VrgPre pre0;
     {
@@ -571,12 +576,12 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
         }
     }
     if (cg.L <= LEV_LDS && !cg.lev16) {
-        for (uint32_t l = threadIdx.x; l < cg.L; l += TPB) s_lev[l] = cg.lev[l];
+        for (uint32_t l = threadIdx.x; l < cg.L; l += KM_THREADS) s_lev[l] = cg.lev[l];
         c.lev = s_lev;
     }
     c.lev_fast = (cg.L <= LEV_LDS || cg.lev16) ? 1 : 0;
     // (every thread of the workgroup makes the same number of trips: the commit below needs its barriers)
-    for (uint64_t base = base0; base < n; base += (uint64_t)gridDim.x * TPB) {
+    for (uint64_t base = base0; base < n; base += (uint64_t)gridDim.x * KM_THREADS) {
         if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
         if (threadIdx.x < 2) s_d[threadIdx.x] = 0;
         __syncthreads();
@@ -631,6 +636,7 @@ __global__ void __launch_bounds__(TPB) k_mark_relabel(VrgCtx cg) {
         __syncthreads();
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 21); }
     }
+    if (threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP_MAX(c, 22); }
 }
 
 // Workgroups [0, CLOSE_APPLY): the sweep's label bytes in place (+ class bits, region sizes, the class changes of the
@@ -2212,7 +2218,7 @@ static void small_update(VrgBackend* b, const VrgCtx& c0, bool dense, hipEvent_t
     VrgCtx c = c0;
     c.lvl_scan = c.L <= NZ_SORT ? 1 : 0;             // small level table: the touched levels are found by scanning the counters (k_close)
     k_order<<<1, KO_THREADS, 0, b->sa>>>(c, b->small_flips);
-    k_mark_relabel<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c);
+    k_mark_relabel<<<KM_BLOCKS, KM_THREADS, 0, b->sa>>>(c);
     // (waits on the device for the dense pass of two sweeps ago)
     hipExtLaunchKernelGGL(k_close, dim3(CLOSE_APPLY + TAB_BLOCKS), dim3(KC_THREADS), 0, b->sa, nullptr, e_chain_stop, 0, c, dense ? 1 : 0);
 }

@@ -476,25 +476,6 @@ VRG_HD void vrg_rank_batch(const VrgCtx& c, uint32_t& cand, uint32_t idx, uint32
 #endif
     for (int k = 0; k < VRG_RANK_BATCH; k++) r[k] = n[k] < 27u ? (uint32_t)c.stamp[(uint32_t)((int64_t)idx + vrg_noff(c, n[k]))] : 0u;
 }
-VRG_HD void vrg_promoter(const VrgCtx& c, uint32_t cand, uint32_t idx, uint32_t& rank, uint32_t& k_out) {
-    uint32_t best = 0xffffffffu, bk = 0;
-    while (cand) {
-        uint32_t n[VRG_RANK_BATCH], r[VRG_RANK_BATCH];
-        vrg_rank_batch(c, cand, idx, n, r);
-        for (int k = 0; k < VRG_RANK_BATCH; k++) if (n[k] < 27u && r[k] < best) { best = r[k]; bk = 26u - vrg_nk(n[k]); }   // (ascending n: the first of equal ranks wins, as before)
-    }
-    rank = best; k_out = bk;
-}
-// is one of the listed neighbours in `cand` of larger rank than r?
-VRG_HD bool vrg_later_flip(const VrgCtx& c, uint32_t cand, uint32_t idx, uint32_t r) {
-    bool later = false;
-    while (cand && !later) {
-        uint32_t n[VRG_RANK_BATCH], rk[VRG_RANK_BATCH];
-        vrg_rank_batch(c, cand, idx, n, rk);
-        for (int k = 0; k < VRG_RANK_BATCH; k++) later = later || (n[k] < 27u && rk[k] > r);
-    }
-    return later;
-}
 // an excluded voxel: is an applied flip within its 2-ring (:177-179, :206-208)?  25 rows of 5 bytes
 VRG_HD bool vrg_ring2_applied(const VrgCtx& c, const uint8_t* lab, uint32_t idx) {
     uint64_t any = 0;                                      // (no early exit: the 25 rows are then requested together, not one after the other)
@@ -508,6 +489,25 @@ VRG_HD bool vrg_ring2_applied(const VrgCtx& c, const uint8_t* lab, uint32_t idx)
     return any != 0;
 }
 
+// The ranks of a voxel's flip-out neighbours (FO) and applied flip-in neighbours (AP), all fetched in one go BEFORE the case
+// analysis below: smallest rank of each set with the k of its owner (the promoter of a new band voxel and its list key),
+// largest rank (is the voxel re-examined by a later flip?).  The cases of the stencil diverge inside a wave; loads inside
+// them run one case after the other - a chain of round trips per wave - while these travel together for all lanes.
+struct VrgRanks { uint32_t minFO, kFO, maxFO, minAP, kAP, maxAP; };
+VRG_HD void vrg_nbr_ranks(const VrgCtx& c, uint32_t FO, uint32_t AP, uint32_t idx, VrgRanks& q) {
+    q.minFO = q.minAP = 0xffffffffu; q.kFO = q.kAP = 0; q.maxFO = q.maxAP = 0;
+    uint32_t cand = FO | AP;
+    while (cand) {
+        uint32_t n[VRG_RANK_BATCH], r[VRG_RANK_BATCH];
+        vrg_rank_batch(c, cand, idx, n, r);
+        for (int k = 0; k < VRG_RANK_BATCH; k++) {
+            if (n[k] >= 27u) continue;
+            if ((FO >> n[k]) & 1u) { if (r[k] < q.minFO) { q.minFO = r[k]; q.kFO = 26u - vrg_nk(n[k]); } if (r[k] > q.maxFO) q.maxFO = r[k]; }
+            else { if (r[k] < q.minAP) { q.minAP = r[k]; q.kAP = 26u - vrg_nk(n[k]); } if (r[k] > q.maxAP) q.maxAP = r[k]; }
+        }
+    }
+}
+
 // Returns the voxel's byte after the sweep and files what the change means for the band pool (slot born / dead /
 // re-appended), the class histograms and the sweep's level deltas.  `lab` = this sweep's input labels (L/P bits
 // set); nothing is written to the label volume here, so every stencil read sees the pre-sweep state.
@@ -518,11 +518,13 @@ VRG_HD uint8_t vrg_sweep_core_pre(const VrgCtx& c, const uint8_t* lab, uint32_t 
     const uint32_t segA = m.S & ~m.L & ex, FO = m.S & m.L & ex, AP = ~m.S & m.P & ex;
     const bool nSegA = segA != 0, nFO = FO != 0, nAP = AP != 0, nNonSegB = (ex & ~(segA | AP)) != 0, nListed = (m.L & ex) != 0;
     const VrgState& s = *c.st;
+    VrgRanks q; vrg_nbr_ranks(c, FO, AP, idx, q);         // (before the cases: see VrgRanks)
+    const uint32_t lev_here = c.lev_fast ? vrg_pre_level(c, pre) : 0xffffffffu;   // the voxel's level where that costs no global load
     if (cb & VB_S) {
         if (cb & VB_L) {                              // flip-out (:170-175), always applied
-            const uint32_t r = pre.rank, slot = pre.vent, lev = c.lev_fast ? vrg_pre_level(c, pre) : c.f_lev[r];   // (a flip is a band entry: its slot is the voxel's)
+            const uint32_t r = pre.rank, slot = pre.vent, lev = c.lev_fast ? lev_here : c.f_lev[r];   // (a flip is a band entry: its slot is the voxel's)
             vrg_atomic_add(&c.hin[lev], -1); vrg_atomic_add(&c.hout[lev], 1);
-            const bool to3 = !nSegA && vrg_later_flip(c, FO, idx, r);   // re-examined by a later flip-out neighbour? (:183-190)
+            const bool to3 = !nSegA && q.maxFO > r;   // re-examined by a later flip-out neighbour? (:183-190)
             if (!to3) {                               // stays 2, carried to the outer list (by rank)
                 c.f_res[r] = FR_WRITTEN | 2;
                 vrg_note_level(c, c.dOut, lev);
@@ -532,8 +534,7 @@ VRG_HD uint8_t vrg_sweep_core_pre(const VrgCtx& c, const uint8_t* lab, uint32_t 
             if (nAP) {                                // 3 -> 2 again (:210-213): a new outer entry
                 c.f_res[r] = FR_WRITTEN | 2 | FR_FRESH;
                 vrg_note_level(c, c.dOut, lev);
-                uint32_t pr, pk; vrg_promoter(c, AP, idx, pr, pk);
-                vrg_ev_move(ev, slot, true, false, vrg_key(s, 1, pr, pk), true);
+                vrg_ev_move(ev, slot, true, false, vrg_key(s, 1, q.minAP, q.kAP), true);
                 return VB_B;
             }
             c.f_res[r] = FR_WRITTEN | 3;
@@ -547,16 +548,15 @@ VRG_HD uint8_t vrg_sweep_core_pre(const VrgCtx& c, const uint8_t* lab, uint32_t 
             return VB_S;
         }
         if (!(cb & VB_B)) {                           // newly on the inner boundary
-            uint32_t pr, pk; vrg_promoter(c, FO, idx, pr, pk);
-            vrg_ev_new(ev, vrg_pre_level(c, pre), true, vrg_key(s, 0, pr, pk));
+            vrg_ev_new(ev, c.lev_fast ? lev_here : vrg_pre_level(c, pre), true, vrg_key(s, 0, q.minFO, q.kFO));
         }
         return VB_S | VB_B;
     }
     if (cb & VB_B) {
         if ((cb & VB_L) && (cb & VB_P)) {             // applied flip-in (:198-204)
-            const uint32_t r = pre.rank, slot = pre.vent, lev = c.lev_fast ? vrg_pre_level(c, pre) : c.f_lev[r];   // (a flip is a band entry: its slot is the voxel's)
+            const uint32_t r = pre.rank, slot = pre.vent, lev = c.lev_fast ? lev_here : c.f_lev[r];   // (a flip is a band entry: its slot is the voxel's)
             vrg_atomic_add(&c.hin[lev], 1); vrg_atomic_add(&c.hout[lev], -1);
-            const bool to0 = !nNonSegB && vrg_later_flip(c, AP, idx, r);   // re-examined by a later applied flip-in nbr? (:219-228)
+            const bool to0 = !nNonSegB && q.maxAP > r;   // re-examined by a later applied flip-in nbr? (:219-228)
             bool fresh = nFO && !nSegA;               // had dropped to 3 in phase A: exact density (:212,:251)
             c.f_res[r] = (uint8_t)(FR_WRITTEN | (to0 ? 0 : 1) | (fresh ? FR_FRESH : 0));
             if (to0) { vrg_ev_die(ev, slot, false); return VB_S; }
@@ -569,13 +569,12 @@ VRG_HD uint8_t vrg_sweep_core_pre(const VrgCtx& c, const uint8_t* lab, uint32_t 
         if (!to3) { out = VB_B; res = 2; }
         else if (nAP) {                               // left the band and re-entered: a new outer entry
             out = VB_B; res = 2 | FR_FRESH;
-            uint32_t pr, pk; vrg_promoter(c, AP, idx, pr, pk);
-            vrg_ev_move(ev, pre.vent, false, false, vrg_key(s, 1, pr, pk), true);
+            vrg_ev_move(ev, pre.vent, false, false, vrg_key(s, 1, q.minAP, q.kAP), true);
         } else { out = 0; res = 3; vrg_ev_die(ev, pre.vent, false); }
         if (cb & VB_L) {                              // skipped flip-in
             const uint32_t r = pre.rank;
             c.f_res[r] = (uint8_t)(FR_WRITTEN | res);
-            if ((res & FR_FINAL) == 2) vrg_note_level(c, c.dOut, c.lev_fast ? vrg_pre_level(c, pre) : c.f_lev[r]);
+            if ((res & FR_FINAL) == 2) vrg_note_level(c, c.dOut, c.lev_fast ? lev_here : c.f_lev[r]);
         }
         return out;
     }
@@ -583,17 +582,16 @@ VRG_HD uint8_t vrg_sweep_core_pre(const VrgCtx& c, const uint8_t* lab, uint32_t 
     bool conv = false;
     uint32_t lev = 0xffffffffu;
     if (cb & VB_X) {
-        conv = nListed || vrg_ring2_applied(c, lab, idx);   // 1-ring of any listed flip (:166-168), 2-ring of any applied flip
+                conv = nListed || vrg_ring2_applied(c, lab, idx);   // 1-ring of any listed flip (:166-168), 2-ring of any applied flip
         if (conv) {                                   // addedPoints (:235); the voxel joins the outer region
-            lev = vrg_pre_level(c, pre);
+            lev = c.lev_fast ? lev_here : vrg_pre_level(c, pre);
             vrg_note_level(c, c.dConv, lev);
             vrg_atomic_add(&c.hout[lev], 1);
         }
     }
     if (nAP) {                                        // 3 -> 2 (:210-213)
-        if (lev == 0xffffffffu) lev = vrg_pre_level(c, pre);
-        uint32_t pr, pk; vrg_promoter(c, AP, idx, pr, pk);
-        vrg_ev_new(ev, lev, false, vrg_key(s, 1, pr, pk));
+        if (lev == 0xffffffffu) lev = c.lev_fast ? lev_here : vrg_pre_level(c, pre);
+        vrg_ev_new(ev, lev, false, vrg_key(s, 1, q.minAP, q.kAP));
         return VB_B;
     }
     return (uint8_t)(((cb & VB_X) && !conv) ? VB_X : 0);

@@ -29,7 +29,7 @@ done = s.run(40, 10 ** 15, None).sweeps
 NAMES = {0: 'k_band entry (wg 0)', 1: 'k_band state loaded', 2: 'k_band pool wg 0 done', 3: 'k_band first exact wg entry', 4: 'k_band first exact wg done',
          8: 'k_order entry', 9: 'k_order stop tests done', 10: 'k_order flips sorted', 11: 'k_order L/P bits + stamps written', 12: 'k_order prepass done',
          16: 'k_mark_relabel entry (wg 0)', 17: 'k_mark state loaded', 18: 'k_mark label byte + preload back', 19: 'k_mark mark atomics back',
-         20: 'k_mark stencil done', 21: 'k_mark events committed',
+         20: 'k_mark stencil done', 21: 'k_mark events committed', 22: 'k_mark last workgroup done',
          24: 'k_close entry (wg 0)', 25: 'k_close state loaded', 26: 'k_close dense wait over', 27: 'k_close apply done (wg 0)',
          32: 'k_close first memo wg entry', 33: 'k_close memo wg levels sorted', 34: 'k_close memo wg done',
          28: 'k_close last ticket taken', 29: 'k_close finalize done'}
@@ -38,6 +38,7 @@ if os.environ.get('VRG_CHAIN_KERNEL') == '1':
              51: 'order: done', 43: 'barrier 1 passed (member 0)', 44: 'snapshot 2 taken', 45: 'stencil done (member 0)', 46: 'barrier 2 passed (dense wait)',
              52: 'close: apply done (member 0)', 47: 'close: memo done (member 0)', 48: 'barrier 3 passed (sweep closed)'}
 acc = {k: [] for k in NAMES}
+period = []
 buf = (C.c_uint64 * 64)()
 for _ in range(samples):
     if dense_off:                                          # (the handle has to be initialised again after a dense_off run)
@@ -50,6 +51,8 @@ for _ in range(samples):
     t0 = buf[40] if os.environ.get('VRG_CHAIN_KERNEL') == '1' else buf[0]
     if not t0:
         raise SystemExit('no stamps: not the -DVRG_STAMPS build (set VRG_HIP_LIB)')
+    if buf[6] and not os.environ.get('VRG_CHAIN_KERNEL') == '1':
+        period.append((t0 - buf[6]) * 0.01)
     for k in NAMES:
         if buf[k] >= t0:
             acc[k].append((buf[k] - t0) * 0.01)
@@ -58,4 +61,6 @@ for k in sorted(NAMES, key=lambda k: (np.mean(acc[k]) if acc[k] else 1e9)):
     v = acc[k]
     if v:
         print('  %7.2f  (%6.2f .. %6.2f)  %s' % (np.mean(v), np.min(v), np.max(v), NAMES[k]))
+if period:
+    print('  %7.2f  (%6.2f .. %6.2f)  k_band entry of the sweep before to this one (the step)' % (np.mean(period), np.min(period), np.max(period)))
 s.close()
