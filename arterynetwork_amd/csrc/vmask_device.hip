@@ -58,9 +58,23 @@ __global__ void k_edt_axis0(const uint8_t* __restrict__ mask, int32_t* __restric
     }
 }
 
-__device__ __forceinline__ long long floordiv(long long a, long long b) {   // b > 0
-    long long q = a / b;
-    return (a % b != 0 && a < 0) ? q - 1 : q;
+// floor(a / b) for b > 0, |a| < 2^52 (here |a| < 2^34, b < 2^17): the double quotient of a non-multiple lies at least 1/b
+// away from an integer - more than its rounding error while |a| < 2^52 -, so the floor of the rounded quotient is exact.
+// (A 64-bit integer division is a ~150-instruction routine on this chip, one per step of every line.)
+__device__ __forceinline__ long long floordiv(long long a, long long b) {
+    return (long long)floor((double)a / (double)b);
+}
+// the same for volumes whose squared diagonal is below EDT_INF, in 32-bit arithmetic (every square and sum stays under 2^30 there;
+// the kernel is bound by its instruction count, and 64-bit integer arithmetic is 2-4 instructions per operation): a float
+// quotient, exact to +-1 while it is below 2^15, set right by one multiplication; a quotient of 2^15 or more only has to
+// come out >= m (the entry is then not pushed)
+__device__ __forceinline__ int32_t floordiv(int32_t a, int32_t b) {
+    const float qf = (float)a * __frcp_rn((float)b);
+    if (fabsf(qf) >= 32768.f) return qf > 0 ? (1 << 20) : -(1 << 20);
+    int32_t q = (int32_t)qf;
+    const int32_t r = a - q * b;
+    if (r < 0) q--; else if (r >= b) q++;
+    return q;
 }
 
 // Meijster phase 2 along axis 1: Gout(u) = min_i (u-i)^2 + Gin(i), one thread per line, the lanes of a wave on
@@ -70,11 +84,20 @@ __device__ __forceinline__ long long floordiv(long long a, long long b) {   // b
 // region per line (padded to EDT_CHUNK entries), and move between the two in aligned chunks of EDT_CHUNK entries =
 // 64 bytes: a full ring sheds its oldest chunk, a pop below the ring brings one back (leaving room for as many pushes
 // before the next move).  The line's values are fetched EDT_AHEAD rows ahead of the scan.
+// Most entries never get that far (round 3): an entry (site s, start t, value v = (t-s)^2 + G(s) at its start) can only be
+// popped by a later site u' with v > (t-u')^2 + G(u') - impossible once (u-t)^2 >= v for the scan position u, as G >= 0
+// and u' >= u.  Such an entry is FINAL, and so is everything below it (a stack pops from the top).  So before site u is
+// taken, the bottom of the stack is written out for good - entry i's rows [t_i, t_(i+1)) as soon as entry i+1 is final -
+// and leaves the ring at that end.  A background voxel (G = 0, t = s) is final at once: in a vessel mask, where nearly
+// every voxel is background, the stack never outgrows the ring, rows leave one step behind the scan (all lanes of a wave
+// the same row: whole 256-byte requests), and the spill area - 3.4 GB written and read back per pass at 880x880x640 in
+// round 2, 2.7 x the pass's floor - is touched only inside large solid regions, whose entries stay poppable for long.
 // (Round 1: every push wrote and every pop read global memory in the data's layout, 4 bytes at a time at addresses
 // that differ from lane to lane, and every step waited for its own load - 12.4 ms per pass at 880x880x640.)
 constexpr int EDT_RING = 16;
 constexpr int EDT_CHUNK = 8;
 constexpr int EDT_AHEAD = 8;
+template <typename I>      // int32_t for volumes whose squared diagonal is below EDT_INF (edt_squared), else long long
 __global__ void __launch_bounds__(TPB) k_edt_envelope(const int32_t* __restrict__ Gin, int32_t* __restrict__ Gout, uint2* __restrict__ SP, Dims d) {
     __shared__ uint32_t r_st[EDT_RING][TPB];
     __shared__ int32_t r_g[EDT_RING][TPB];
@@ -87,12 +110,12 @@ __global__ void __launch_bounds__(TPB) k_edt_envelope(const int32_t* __restrict_
         const size_t base = (size_t)(line / d.n2) * d.n1 * d.n2 + (line % d.n2);
         uint2* __restrict__ spill = SP + (size_t)line * mp;
 #define AT(u) (base + (size_t)(u) * stride)
-        // entries [low, q] of the stack are in the ring (entry i in slot i % EDT_RING), entries [0, low) in the spill
-        // area; low is a multiple of EDT_CHUNK
-        int32_t q = 0, low = 0;
-        long long ts = 0, tt = 0, tg = Gin[AT(0)];               // top of the stack: site, start, G(site)
+        // entries [low, q] of the stack are in the ring (entry i in slot i % EDT_RING), entries [eb, low) in the spill
+        // area (low - eb a multiple of EDT_CHUNK), entries [0, eb) are final and written: rows [0, ue) of the output
+        int32_t q = 0, low = 0, eb = 0, ue = 0;
+        I ts = 0, tt = 0, tg = Gin[AT(0)];               // top of the stack: site, start, G(site)
         r_st[0][tid] = 0; r_g[0][tid] = (int32_t)tg;
-        auto pop = [&]() {                                        // q was decremented and is >= 0: its entry becomes the top
+        auto pop = [&]() {                                        // q was decremented and is >= eb: its entry becomes the top
             if (q < low) {                                        // (q == low - 1: the chunk below the ring comes back)
                 low -= EDT_CHUNK;
                 uint2 e[EDT_CHUNK];
@@ -112,16 +135,29 @@ __global__ void __launch_bounds__(TPB) k_edt_envelope(const int32_t* __restrict_
             for (int k = 0; k < EDT_AHEAD; k++) {
                 const int32_t u = u0 + k;
                 if (u >= m) break;
-                const long long Gu = gv[k];
-                while (q >= 0) {
-                    long long f1 = (tt - ts) * (tt - ts) + tg;
-                    long long f2 = (tt - u) * (tt - u) + Gu;
-                    if (f1 <= f2) break;
-                    if (--q >= 0) pop();
+                while (low == eb && low < q) {                    // the final bottom of the stack leaves (nothing of it is in the spill area)
+                    const uint32_t p1 = r_st[(low + 1) % EDT_RING][tid];
+                    const I s1 = p1 & 0xffffu, t1 = p1 >> 16, v1 = (t1 - s1) * (t1 - s1) + r_g[(low + 1) % EDT_RING][tid];
+                    const I dd = u - t1;
+                    if (dd < 0 || v1 > dd * dd) break;            // entry low + 1 can still be popped: entry low may become the top again
+                    const uint32_t p0 = r_st[low % EDT_RING][tid];
+                    const I s0 = p0 & 0xffffu, g0 = r_g[low % EDT_RING][tid];
+                    for (I r = p0 >> 16; r < t1; r++) {
+                        const I v = (r - s0) * (r - s0) + g0;
+                        Gout[AT(r)] = v >= EDT_INF ? EDT_INF : (int32_t)v;
+                    }
+                    ue = (int32_t)t1; low++; eb++;
                 }
-                if (q < 0) { q = 0; low = 0; ts = u; tt = 0; tg = Gu; r_st[0][tid] = (uint32_t)u; r_g[0][tid] = (int32_t)Gu; }
+                const I Gu = gv[k];
+                while (q >= eb) {
+                    const I f1 = (tt - ts) * (tt - ts) + tg;
+                    const I f2 = (tt - u) * (tt - u) + Gu;
+                    if (f1 <= f2) break;
+                    if (--q >= eb) pop();
+                }
+                if (q < eb) { q = 0; low = 0; ts = u; tt = 0; tg = Gu; r_st[0][tid] = (uint32_t)u; r_g[0][tid] = (int32_t)Gu; }   // (eb == 0: a final entry is never popped)
                 else {
-                    long long w = 1 + floordiv((long long)u * u - ts * ts + Gu - tg, 2 * (u - ts));
+                    const I w = 1 + floordiv((I)u * u - ts * ts + Gu - tg, (I)2 * (u - ts));
                     if (w < m) {                                  // w >= 1 here: the top still wins at its own start
                         q++;
                         if (q - low >= EDT_RING) {                // the ring is full: its oldest chunk moves to the spill area
@@ -136,10 +172,10 @@ __global__ void __launch_bounds__(TPB) k_edt_envelope(const int32_t* __restrict_
                 }
             }
         }
-        for (int32_t u = m - 1; u >= 0; u--) {
-            long long v = (u - ts) * (u - ts) + tg;
+        for (int32_t u = m - 1; u >= ue; u--) {
+            const I v = (u - ts) * (u - ts) + tg;
             Gout[AT(u)] = v >= EDT_INF ? EDT_INF : (int32_t)v;
-            if (u == tt && --q >= 0) pop();
+            if (u == tt && --q >= eb) pop();
         }
 #undef AT
     }
@@ -184,12 +220,16 @@ int edt_squared(const uint8_t* dmask, Dims d, int32_t* G) {
     int32_t* G2 = nullptr; uint2* SP = nullptr;
     VM_TRY(hipMalloc(&G2, V * 4));
     if (hipMalloc(&SP, spill_entries * sizeof(uint2)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(G2); g_err = "out of device memory (EDT scratch)"; return VRG_E_MEM; }
+    // (every finite squared distance, and so every square and sum of the envelope pass, below EDT_INF = 2^29)
+    const bool small = (int64_t)d.n0 * d.n0 + (int64_t)d.n1 * d.n1 + (int64_t)d.n2 * d.n2 < (int64_t)EDT_INF;
     k_edt_axis0<<<grid_for((uint64_t)d.n1 * d.n2), TPB>>>(dmask, G, d);
-    k_edt_envelope<<<grid_for((uint64_t)d.n0 * d.n2), TPB>>>(G, G2, SP, d);
+    if (small) k_edt_envelope<int32_t><<<grid_for((uint64_t)d.n0 * d.n2), TPB>>>(G, G2, SP, d);
+    else k_edt_envelope<long long><<<grid_for((uint64_t)d.n0 * d.n2), TPB>>>(G, G2, SP, d);
     const int tgrid = (int)std::min<uint64_t>(65535u * 4u, (uint64_t)d.n0 * ((d.n1 + 63) / 64) * ((d.n2 + 63) / 64));
     k_transpose12<<<tgrid, 256>>>(G2, G, d.n0, d.n1, d.n2);                 // G = [n0][n2][n1]
     Dims dt = {d.n0, d.n2, d.n1};
-    k_edt_envelope<<<grid_for((uint64_t)d.n0 * d.n1), TPB>>>(G, G2, SP, dt);
+    if (small) k_edt_envelope<int32_t><<<grid_for((uint64_t)d.n0 * d.n1), TPB>>>(G, G2, SP, dt);
+    else k_edt_envelope<long long><<<grid_for((uint64_t)d.n0 * d.n1), TPB>>>(G, G2, SP, dt);
     k_transpose12<<<tgrid, 256>>>(G2, G, d.n0, d.n2, d.n1);                 // back to [n0][n1][n2]
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
