@@ -86,12 +86,16 @@ __device__ __forceinline__ int32_t floordiv(int32_t a, int32_t b) {
 // before the next move).  The line's values are fetched EDT_AHEAD rows ahead of the scan.
 // Most entries never get that far (round 3): an entry (site s, start t, value v = (t-s)^2 + G(s) at its start) can only be
 // popped by a later site u' with v > (t-u')^2 + G(u') - impossible once (u-t)^2 >= v for the scan position u, as G >= 0
-// and u' >= u.  Such an entry is FINAL, and so is everything below it (a stack pops from the top).  So before site u is
-// taken, the bottom of the stack is written out for good - entry i's rows [t_i, t_(i+1)) as soon as entry i+1 is final -
-// and leaves the ring at that end.  A background voxel (G = 0, t = s) is final at once: in a vessel mask, where nearly
-// every voxel is background, the stack never outgrows the ring, rows leave one step behind the scan (all lanes of a wave
-// the same row: whole 256-byte requests), and the spill area - 3.4 GB written and read back per pass at 880x880x640 in
-// round 2, 2.7 x the pass's floor - is touched only inside large solid regions, whose entries stay poppable for long.
+// and u' >= u.  Such an entry is FINAL, and so is everything below it (a stack pops from the top).  So before each batch
+// of EDT_AHEAD sites the bottom of the stack is written out for good - entry i's rows [t_i, t_(i+1)) as soon as entry
+// i+1 is final - and leaves the ring at that end.  A background voxel (G = 0, t = s) is final at once: in a vessel mask,
+// where nearly every voxel is background, the stack never outgrows the ring, rows leave a batch behind the scan (all lanes
+// of a wave the same rows: whole 256-byte requests), and the spill area - 3.4 GB written and read back per pass at
+// 880x880x640 in round 2, 2.7 x the pass's floor - is touched only inside large solid regions, whose entries stay poppable
+// for long.  What was spilled there is written out from the spill area once it is final (the oldest chunk first, all lanes
+// of the wave together), so that the ring's bottom can leave again behind it.
+// Measured (profiles/r03_mask_pmc.csv, brain-sized ellipsoid): 10.7 -> 6.8 GB and 4.53 -> 3.07 ms per pass; the pass is
+// then bound by its ~150 VALU instructions per site (SQ counters: VALU busy 0.6), not by HBM.
 // (Round 1: every push wrote and every pop read global memory in the data's layout, 4 bytes at a time at addresses
 // that differ from lane to lane, and every step waited for its own load - 12.4 ms per pass at 880x880x640.)
 constexpr int EDT_RING = 16;
@@ -114,6 +118,7 @@ __global__ void __launch_bounds__(TPB) k_edt_envelope(const int32_t* __restrict_
         // area (low - eb a multiple of EDT_CHUNK), entries [0, eb) are final and written: rows [0, ue) of the output
         int32_t q = 0, low = 0, eb = 0, ue = 0;
         I ts = 0, tt = 0, tg = Gin[AT(0)];               // top of the stack: site, start, G(site)
+        I dn_t = 0, dn_v = 0;                            // while low > eb: start of entry eb + EDT_CHUNK (the one above the oldest spilled chunk) and its value there
         r_st[0][tid] = 0; r_g[0][tid] = (int32_t)tg;
         auto pop = [&]() {                                        // q was decremented and is >= eb: its entry becomes the top
             if (q < low) {                                        // (q == low - 1: the chunk below the ring comes back)
@@ -128,26 +133,57 @@ __global__ void __launch_bounds__(TPB) k_edt_envelope(const int32_t* __restrict_
             ts = p & 0xffffu; tt = p >> 16; tg = r_g[q % EDT_RING][tid];
         };
         for (int32_t u0 = 1; u0 < m; u0 += EDT_AHEAD) {
-            int32_t gv[EDT_AHEAD];
+            int32_t gv[EDT_AHEAD];                                // (requested before the bottom of the stack is written out: in flight meanwhile)
 #pragma unroll
             for (int k = 0; k < EDT_AHEAD; k++) gv[k] = u0 + k < m ? Gin[AT(u0 + k)] : 0;
+            // (once per batch of EDT_AHEAD sites: everything below is about sites >= u0)
+            for (;;) {                                            // final entries that had to be spilled: the oldest chunk [eb, eb + EDT_CHUNK)
+                const I dd = u0 - dn_t;                           // ... is final when the entry above it (start dn_t, value dn_v there) is
+                const bool has = low > eb, fin = has && dd >= 0 && dn_v <= dd * dd;
+                // (the lanes of a wave - neighbouring lines - write their chunks out TOGETHER: a lane on its own would leave
+                // 4 bytes in each of its rows' cache lines long before or after its neighbours do, every one a write of its own)
+                const unsigned long long wh = __ballot(has), wf = __ballot(fin);
+                if (!wh || wf != wh) break;
+                if (!has) continue;
+                uint2 e[EDT_CHUNK];
+#pragma unroll
+                for (int i = 0; i < EDT_CHUNK; i++) e[i] = spill[eb + i];
+#pragma unroll
+                for (int i = 0; i < EDT_CHUNK; i++) {
+                    const I s0 = e[i].x & 0xffffu, g0 = (int32_t)e[i].y, t1 = i + 1 < EDT_CHUNK ? (I)(e[(i + 1) % EDT_CHUNK].x >> 16) : dn_t;
+                    for (I r = e[i].x >> 16; r < t1; r++) {
+                        const I v = (r - s0) * (r - s0) + g0;
+                        Gout[AT(r)] = v >= EDT_INF ? EDT_INF : (int32_t)v;
+                    }
+                }
+                ue = (int32_t)dn_t; eb += EDT_CHUNK;
+                if (low > eb) {                                   // the entry above the next chunk: spilled itself, or the bottom of the ring
+                    uint2 n;
+                    if (eb + EDT_CHUNK < low) n = spill[eb + EDT_CHUNK];
+                    else n = make_uint2(r_st[low % EDT_RING][tid], (uint32_t)r_g[low % EDT_RING][tid]);
+                    const I sn = n.x & 0xffffu;
+                    dn_t = n.x >> 16; dn_v = (dn_t - sn) * (dn_t - sn) + (int32_t)n.y;
+                }
+            }
+            for (;;) {                                        // the final bottom of the stack leaves (nothing of it is in the spill area)
+                const bool cand = low == eb && low < q;
+                const uint32_t p1 = cand ? r_st[(low + 1) % EDT_RING][tid] : 0u;
+                const I s1 = p1 & 0xffffu, t1 = p1 >> 16, v1 = cand ? (t1 - s1) * (t1 - s1) + r_g[(low + 1) % EDT_RING][tid] : 0;
+                const I dd = u0 - t1;
+                const bool fin = cand && dd >= 0 && v1 <= dd * dd;   // (else entry low + 1 can still be popped: entry low may become the top again)
+                if (!fin) break;
+                const uint32_t p0 = r_st[low % EDT_RING][tid];
+                const I s0 = p0 & 0xffffu, g0 = r_g[low % EDT_RING][tid];
+                for (I r = p0 >> 16; r < t1; r++) {
+                    const I v = (r - s0) * (r - s0) + g0;
+                    Gout[AT(r)] = v >= EDT_INF ? EDT_INF : (int32_t)v;
+                }
+                ue = (int32_t)t1; low++; eb++;
+            }
 #pragma unroll
             for (int k = 0; k < EDT_AHEAD; k++) {
                 const int32_t u = u0 + k;
                 if (u >= m) break;
-                while (low == eb && low < q) {                    // the final bottom of the stack leaves (nothing of it is in the spill area)
-                    const uint32_t p1 = r_st[(low + 1) % EDT_RING][tid];
-                    const I s1 = p1 & 0xffffu, t1 = p1 >> 16, v1 = (t1 - s1) * (t1 - s1) + r_g[(low + 1) % EDT_RING][tid];
-                    const I dd = u - t1;
-                    if (dd < 0 || v1 > dd * dd) break;            // entry low + 1 can still be popped: entry low may become the top again
-                    const uint32_t p0 = r_st[low % EDT_RING][tid];
-                    const I s0 = p0 & 0xffffu, g0 = r_g[low % EDT_RING][tid];
-                    for (I r = p0 >> 16; r < t1; r++) {
-                        const I v = (r - s0) * (r - s0) + g0;
-                        Gout[AT(r)] = v >= EDT_INF ? EDT_INF : (int32_t)v;
-                    }
-                    ue = (int32_t)t1; low++; eb++;
-                }
                 const I Gu = gv[k];
                 while (q >= eb) {
                     const I f1 = (tt - ts) * (tt - ts) + tg;
@@ -165,6 +201,11 @@ __global__ void __launch_bounds__(TPB) k_edt_envelope(const int32_t* __restrict_
                             for (int i = 0; i < EDT_CHUNK; i++)
                                 spill[low + i] = make_uint2(r_st[(low + i) % EDT_RING][tid], (uint32_t)r_g[(low + i) % EDT_RING][tid]);
                             low += EDT_CHUNK;
+                            if (low - eb == EDT_CHUNK) {          // the first spilled chunk: the entry above it is the ring's bottom now
+                                const uint32_t pn = r_st[low % EDT_RING][tid];
+                                const I sn = pn & 0xffffu;
+                                dn_t = pn >> 16; dn_v = (dn_t - sn) * (dn_t - sn) + r_g[low % EDT_RING][tid];
+                            }
                         }
                         ts = u; tt = w; tg = Gu;
                         r_st[q % EDT_RING][tid] = (uint32_t)u | ((uint32_t)w << 16); r_g[q % EDT_RING][tid] = (int32_t)Gu;

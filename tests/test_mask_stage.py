@@ -35,7 +35,8 @@ def test_oracle_pipeline_properties():
 
 # ------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize('shape', [(40, 36, 30), (17, 64, 9), (1, 50, 33), (96, 80, 72), (3, 700, 5), (2, 6, 900), (130, 150, 140)])
+@pytest.mark.parametrize('shape', [(40, 36, 30), (17, 64, 9), (1, 50, 33), (96, 80, 72), (3, 700, 5), (2, 6, 900), (130, 150, 140),
+                                   (2, 5, 23200)])      # (squared diagonal >= 2^29: the envelope pass in 64-bit arithmetic)
 def test_edt_bit_exact(shape):
     from arterynetwork_amd.generateVesselVolume import distance_transform_edt
     brain, _ = _volumes(1, shape)

@@ -10,7 +10,8 @@ def short(name):
     m = re.search(r'(k_[a-z0-9_]+(?:<\w+>)?)', name)
     return m.group(1) if m else name[:40]
 
-f = glob.glob(src + '/trace/*/*kernel_stats.csv')[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)      # (gpurun merges into gpurun_out/: an older run's files may still be there)
+f = newest(src + '/trace/*/*kernel_stats.csv')
 with open('profiles/%s_mask_kernel_stats.csv' % out, 'w') as o:
     o.write('# rocprofv3 --kernel-trace --stats -- python3 tools/bench_mask.py 880x880x640  (EDT x4, label x4, stage-1 pipeline x4 calls)\n')
     o.write('Name,Calls,TotalDurationNs,AverageNs\n')
@@ -18,7 +19,7 @@ with open('profiles/%s_mask_kernel_stats.csv' % out, 'w') as o:
         o.write('"%s",%s,%s,%s\n' % (short(r['Name']), r['Calls'], r['TotalDurationNs'], r['AverageNs']))
 rows = {}
 for d, c in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
-    g = glob.glob(src + '/%s/*/*counter_collection.csv' % d)[0]
+    g = newest(src + '/%s/*/*counter_collection.csv' % d)
     for r in csv.DictReader(open(g)):
         if r['Counter_Name'] == c and ('k_' in r['Kernel_Name'] or 'rocprim' in r['Kernel_Name']):
             rows.setdefault(short(r['Kernel_Name']), {}).setdefault(c, []).append(float(r['Counter_Value']))
