@@ -2361,9 +2361,11 @@ void be_recount_hist(VrgBackend* b, const VrgCtx& c, int32_t* rin, int32_t* rout
 }
 
 // what the dense pass of this handle is launched as: {non-temporal loads, storage mode (0 fp32, 1 u16 level index, 2 f64),
-// workgroups, skip_excluded}
-void be_dense_info(VrgBackend* b, const VrgCtx& c, int64_t out[4]) {
+// workgroups, skip_excluded, k_recount_pipe instead of k_recount_bits}
+static bool dense_is_pipe(VrgBackend* b, const VrgCtx& c) { return b->dense_pipe && c.I && !c.lev16 && b->skip; }
+void be_dense_info(VrgBackend* b, const VrgCtx& c, int64_t out[5]) {
     out[0] = dense_nt(b, c) ? 1 : 0; out[1] = c.lev16 ? 1 : (c.I ? 0 : 2); out[2] = dense_blocks(b, c); out[3] = b->skip ? 1 : 0;
+    out[4] = dense_is_pipe(b, c) ? 1 : 0;
 }
 uint64_t be_dense_bytes(VrgBackend* b, const VrgCtx& c) {
     use_device(b);

@@ -528,10 +528,11 @@ int API(get_stats)(vrg_handle* h, int64_t* outp, int64_t cap) {
         if (h->inited) { be_sync(h->be); outp[8] = (int64_t)be_dense_bytes(h->be, h->c); }
     }
     if (cap >= 14) {
-        int64_t di[4] = {0, 0, 0, 0};
+        int64_t di[5] = {0, 0, 0, 0, 0};
         uint32_t uc[2] = {0, 0};
         if (h->inited) { be_dense_info(h->be, h->c, di); be_download(h->be, uc, h->c.uctl, sizeof(uc)); }
         outp[9] = di[0]; outp[10] = di[1]; outp[11] = di[2]; outp[12] = di[3]; outp[13] = uc[0];
+        if (cap >= 15) outp[14] = di[4];
     }
     return VRG_OK;
 }

@@ -246,7 +246,7 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c0, int flags, VrgEvents*, be_re
 void be_events_collect(VrgBackend*, VrgEvents*, long long) {}
 bool be_has_chain() { return false; }
 void be_sweep_batch(VrgBackend* b, const VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user) { for (int i = 0; i < n; i++) be_sweep_once(b, c, flags, ev, cb, user); }
-void be_dense_info(VrgBackend*, const VrgCtx& c, int64_t out[4]) { out[0] = 0; out[1] = c.lev16 ? 1 : (c.I ? 0 : 2); out[2] = 1; out[3] = 1; }
+void be_dense_info(VrgBackend*, const VrgCtx& c, int64_t out[5]) { out[0] = 0; out[1] = c.lev16 ? 1 : (c.I ? 0 : 2); out[2] = 1; out[3] = 1; out[4] = 0; }
 void be_dense_flush(VrgBackend*, const VrgCtx&, be_reduce_fn, void*) {}
 
 void be_recount_hist(VrgBackend*, const VrgCtx& c, int32_t* rin, int32_t* rout) {
