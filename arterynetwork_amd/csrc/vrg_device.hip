@@ -534,72 +534,113 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
 }
 
 constexpr uint32_t LEV_LDS = 2048;  // level values a workgroup of k_mark_relabel keeps in LDS
-constexpr int KM_THREADS = 128;     // k_mark_relabel: one flip's 125 places per workgroup - its scattered row loads then share a CU's
-                                    // address unit with one other wave instead of three (A/B in one session: 256 threads +1.0 us alone, 64 +0.5 us)
-constexpr int KM_BLOCKS = ITEM_BLOCKS * TPB / KM_THREADS;
+// k_mark_relabel: ONE flip per workgroup and trip - thread p < 125 is place p of the flip's 5x5x5 cube.  Everything the
+// stencils of those 125 voxels read of the LABELS lies within 4 voxels of the flip: the workgroup fetches that 9x9x9
+// neighbourhood once - 81 rows of 16 bytes, one load each for 81 threads - into LDS, and the nine 3-byte rows of a voxel's
+// 3x3x3 masks, its own byte and the 25 rows of an excluded voxel's 2-ring come from there.  (Round 2 / early round 3:
+// every thread fetched its own 9 + 25 rows from memory, 34 scattered requests per lane through one address unit per CU -
+// the "label byte + preload" phase alone took 3.1 us - and the 2-ring and the neighbour ranks were two more dependent round
+// trips inside the case analysis.)  What stays per voxel - its stamp rank, slot and intensity - is requested together with
+// the tile; the ranks of its listed neighbours travel together with the marking atomic.
+constexpr int KM_THREADS = 128;
+constexpr int KM_BLOCKS = 512;
+typedef uint32_t km_u4 __attribute__((ext_vector_type(4)));
+constexpr int KM_ROWS = 81;         // (dy, dz) in [-4, 4]^2; row bytes 0..8 = dx -4..+4 (16 bytes are fetched)
+__device__ __forceinline__ uint32_t km_row(int dy, int dz) { return (uint32_t)((dz + 4) * 9 + (dy + 4)); }
 __global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
-    // (the flip voxel of this thread's first item travels with the state: k_order has written the list, whatever the state says)
-    const bool st0 = blockIdx.x == 0 && threadIdx.x == 0;
+    // (the first flip's voxel travels with the state: k_order has written the list, whatever the state says)
+    const uint32_t t = threadIdx.x, lane = t & 63;
+    const bool st0 = blockIdx.x == 0 && t == 0;
     const unsigned long long t_entry = st0 ? VRG_STAMP_NOW() : 0ull;
-    const uint32_t r_first = (uint32_t)(((uint64_t)blockIdx.x * KM_THREADS + threadIdx.x) >> 7);
-    const uint32_t fidx_first = r_first < cg.fcap ? cg.f_idx[r_first] : 0u;
+    const uint32_t fidx_first = blockIdx.x < cg.fcap ? cg.f_idx[blockIdx.x] : 0u;
     const int32_t st_done = cg.st->done, st_bail = cg.st->bail;
-    const uint32_t nf = cg.st->nf, lane = threadIdx.x & 63;
+    const uint32_t nf = cg.st->nf;
     asm volatile("" :: "v"(fidx_first), "v"(st_done), "v"(st_bail), "v"(nf));     // one wait for the four
     if (st_done || st_bail) return;
     if (st0) { VRG_STAMP_PUT(cg, 16, t_entry); VRG_STAMP(cg, 17); }
-    const uint64_t n = (uint64_t)nf * 128u;
-    if ((uint64_t)blockIdx.x * KM_THREADS >= n) return;                          // (no item for this workgroup)
+    if (blockIdx.x >= nf) return;                                         // (no flip for this workgroup)
     // a voxel that enters the band needs the level index of its intensity: a binary search, i.e. log2(L) DEPENDENT loads -
     // from LDS when the table fits
     __shared__ double s_lev[LEV_LDS];
+    __shared__ uint32_t s_tile[KM_ROWS * 4];
     __shared__ uint32_t s_n[3], s_base[3];                                // this workgroup's new / dead / pending events
     __shared__ int32_t s_d[2];                                            // ... and list length changes
     VrgCtx c = cg;
     uint8_t* lab = c.lab[0];
     const uint32_t idx_lo = vrg_idx(c, 0, 0, 0), idx_hi = vrg_idx(c, c.nx - 1, c.ny - 1, c.nz - 1);
-    // The first item of every thread: its voxel's byte AND everything the stencil would read there, requested now -
-    // before the level table is staged (its loads then queue behind these and one wait covers both) and before it is known
-    // whether this thread will run the stencil: one round trip instead of four dependent ones.  (A position outside the
-    // real volume is padding - never relabelled - so its index is clamped to stay inside the arrays.)
-    const uint64_t base0 = (uint64_t)blockIdx.x * KM_THREADS;
-    int64_t m0 = 0; uint8_t mb0 = VB_OOB;
-    VrgPre pre0;
-    {
-        const uint64_t i0 = base0 + threadIdx.x;
-        const uint32_t p0 = (uint32_t)(i0 & 127u);
-        if (i0 < n && p0 < 125u) {
-            m0 = vrg_mark_pos(c, fidx_first, p0);
-            mb0 = lab[m0];
-            const int64_t ms = m0 < (int64_t)idx_lo ? (int64_t)idx_lo : (m0 > (int64_t)idx_hi ? (int64_t)idx_hi : m0);
-            vrg_preload(c, lab, (uint32_t)ms, pre0);
-        }
-    }
-    if (cg.L <= LEV_LDS && !cg.lev16) {
-        for (uint32_t l = threadIdx.x; l < cg.L; l += KM_THREADS) s_lev[l] = cg.lev[l];
-        c.lev = s_lev;
-    }
+    const uint32_t p = t;
+    const int dx = (int)(p % 5) - 2, dy = (int)((p / 5) % 5) - 2, dz = (int)(p / 25) - 2;     // vrg_mark_pos
+    const int ry = (int)(t % 9) - 4, rz = (int)(t / 9) - 4;                                   // the tile row thread t < 81 fetches
     c.lev_fast = (cg.L <= LEV_LDS || cg.lev16) ? 1 : 0;
     // (every thread of the workgroup makes the same number of trips: the commit below needs its barriers)
-    for (uint64_t base = base0; base < n; base += (uint64_t)gridDim.x * KM_THREADS) {
-        if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
-        if (threadIdx.x < 2) s_d[threadIdx.x] = 0;
-        __syncthreads();
-        const uint64_t i = base + threadIdx.x;
-        const uint32_t r = (uint32_t)(i >> 7), p = (uint32_t)(i & 127u);
-        int64_t m = m0; uint8_t mb = mb0;
-        VrgPre pre = pre0;
-        if (base != base0) {
-            m = 0; mb = VB_OOB;
-            if (i < n && p < 125u) {
-                m = vrg_mark_pos(c, c.f_idx[r], p);
-                mb = lab[m];
-                const int64_t ms = m < (int64_t)idx_lo ? (int64_t)idx_lo : (m > (int64_t)idx_hi ? (int64_t)idx_hi : m);
-                vrg_preload(c, lab, (uint32_t)ms, pre);
-            }
+    for (uint32_t r = blockIdx.x; r < nf; r += gridDim.x) {
+        const uint32_t fidx = r == blockIdx.x ? fidx_first : c.f_idx[r];
+        // the tile row (a row that is not wholly inside the allocation - 16 guard bytes at either end - belongs to no real
+        // voxel's neighbourhood: it reads as out-of-bounds bytes)
+        km_u4 row = {0x01010101u * VB_OOB, 0x01010101u * VB_OOB, 0x01010101u * VB_OOB, 0x01010101u * VB_OOB};
+        if (t < KM_ROWS) {
+            const int64_t a = (int64_t)fidx + ((int64_t)rz * c.PY + ry) * c.PX - 4;
+            if (a >= -16 && a + 16 <= (int64_t)c.PV + 16) row = __builtin_nontemporal_load(reinterpret_cast<const km_u4*>(lab + a));
         }
+        // this thread's voxel and what is kept per voxel elsewhere (a position outside the real volume is padding - never
+        // relabelled - so its index is clamped to stay inside the arrays)
+        const int64_t m = (int64_t)fidx + ((int64_t)dz * c.PY + dy) * c.PX + dx;
+        VrgPre pre;
+        pre.rank = 0; pre.vent = 0; pre.lev16 = 0; pre.val = 0.0;
+        if (p < 125u) {
+            const uint32_t ms = (uint32_t)(m < (int64_t)idx_lo ? (int64_t)idx_lo : (m > (int64_t)idx_hi ? (int64_t)idx_hi : m));
+            pre.rank = (uint32_t)c.stamp[ms]; pre.vent = c.vent[ms];
+            pre.lev16 = c.lev16 ? (uint32_t)c.lev16[ms] : 0u;
+            pre.val = c.lev16 ? 0.0 : vrg_voxel_value(c, ms);
+        }
+        if (r == blockIdx.x && cg.L <= LEV_LDS && !cg.lev16) {           // (its loads queue behind those: one wait covers both)
+            for (uint32_t l = t; l < cg.L; l += KM_THREADS) s_lev[l] = cg.lev[l];
+            c.lev = s_lev;
+        }
+        if (t < KM_ROWS) { s_tile[4 * t] = row.x; s_tile[4 * t + 1] = row.y; s_tile[4 * t + 2] = row.z; s_tile[4 * t + 3] = row.w; }
+        if (t < 3) s_n[t] = 0;
+        if (t < 2) s_d[t] = 0;
+        __syncthreads();
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 18); }
-        const bool first = vrg_mark_wanted(p, mb) && vrg_mark_set(c, m);
+        uint8_t mb = VB_OOB;
+        if (p < 125u) { const uint32_t o = (uint32_t)(dx + 4); mb = (uint8_t)(s_tile[4 * km_row(dy, dz) + (o >> 2)] >> (8u * (o & 3u))); }
+        const bool wanted = vrg_mark_wanted(p, mb);
+        // the mark (its answer says whether this thread is the voxel's first marker) and the ranks of the listed neighbours
+        // leave together; the tile work below runs while they travel
+        uint32_t old = 0xffffffffu;
+        const uint32_t sh = 8u * ((uint32_t)m & 3u);
+        if (wanted) old = vrg_atomic_or((uint32_t*)(lab + ((uint32_t)m & ~3u)), (uint32_t)VB_M << sh);
+        VrgNbr nb = {0u, 0u, 0u, 0u};
+        uint32_t FO = 0, AP = 0, cand = 0, n0[VRG_RANK_BATCH], r0[VRG_RANK_BATCH];
+        if (wanted) {
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                const uint64_t w8 = *reinterpret_cast<const uint64_t*>(&s_tile[4 * km_row(dy + j / 3 - 1, dz + j % 3 - 1)]);
+                pre.w[j] = (uint32_t)(w8 >> (8 * (dx + 3)));              // bytes x-1 .. x+2 of the row (vrg_preload)
+            }
+            nb = vrg_masks_of(pre.w);
+            uint32_t ex, segA; vrg_nbr_sets(nb, ex, segA, FO, AP);
+            cand = FO | AP;
+        }
+#pragma unroll
+        for (int k = 0; k < VRG_RANK_BATCH; k++) { n0[k] = 32u; r0[k] = 0u; }
+        if (cand) vrg_rank_batch(c, cand, (uint32_t)m, n0, r0);
+        bool ring2 = false;
+        if (wanted && vrg_wants_ring2(mb, nb)) {                          // an applied flip (P and not OOB) within the 2-ring? (vrg_ring2_applied)
+            uint64_t any = 0;
+            const uint32_t o2 = (uint32_t)(dx + 2);
+#pragma unroll
+            for (int j = 0; j < 25; j++) {
+                const uint32_t* rw = &s_tile[4 * km_row(dy + j % 5 - 2, dz + j / 5 - 2)];
+                const uint64_t lo8 = *reinterpret_cast<const uint64_t*>(rw);
+                const uint64_t w8 = o2 ? (lo8 >> (8u * o2)) | ((uint64_t)rw[2] << (64u - 8u * o2)) : lo8;    // bytes x-2 .. x+2
+                any |= ((w8 >> 4) & ~(w8 >> 5)) & 0x0101010101ull;
+            }
+            ring2 = any != 0;
+        }
+        const uint32_t lev_here = (wanted && c.lev_fast) ? vrg_pre_level(c, pre) : 0xffffffffu;
+        const bool first = wanted && !((old >> sh) & VB_M);
+        if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 19); }
         // one reservation in the marked list per wave (every first marker of the chip bumping the same word would
         // serialise in L2)
         const unsigned long long fm = __ballot(first);
@@ -610,11 +651,14 @@ __global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
             if ((int)lane == leader) b0 = vrg_atomic_add(&c.stg->nmk, (uint32_t)__popcll(fm));
             q = __shfl(b0, leader, 64) + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
         }
+        if (st0) { asm volatile("" :: "v"(q)); VRG_STAMP(c, 23); }
         VrgEvent ev; ev.kind = VE_NONE; ev.pend = 0;
         uint32_t rn = 0, rd = 0, rf = 0;
-        if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 19); }
         if (first) {
-            const uint8_t nw = vrg_sweep_core_pre(c, lab, (uint32_t)m, mb, pre, ev);   // (L / P bits date from k_order: mb is current)
+            VrgRanks qr; vrg_ranks_none(qr);
+            vrg_ranks_take(FO, n0, r0, qr);
+            while (cand) { vrg_rank_batch(c, cand, (uint32_t)m, n0, r0); vrg_ranks_take(FO, n0, r0, qr); }     // (more than four listed neighbours: rare)
+            const uint8_t nw = vrg_sweep_cases(c, (uint32_t)m, mb, pre, nb, qr, ring2, lev_here, ev);   // (L / P bits date from k_order: mb is current)
             if (q < c.mcap) { c.mk_idx[q] = (uint32_t)m; c.mk_new[q] = nw; c.mk_old[q] = mb; } else c.stg->error = 4;
             // its event takes a number inside the workgroup ...
             if (ev.kind == VE_NEW) rn = atomicAdd(&s_n[0], 1u);
@@ -627,16 +671,16 @@ __global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
         __syncthreads();
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 20); }
         // ... the workgroup reserves its stretch of every list with ONE atomic each ...
-        if (threadIdx.x < 3 && s_n[threadIdx.x])
-            s_base[threadIdx.x] = vrg_atomic_add(threadIdx.x == 0 ? &c.st->nalloc : threadIdx.x == 1 ? &c.st->ndead : &c.st->nfresh, s_n[threadIdx.x]);
-        if (threadIdx.x >= 4 && threadIdx.x < 6 && s_d[threadIdx.x - 4]) vrg_atomic_add(threadIdx.x == 4 ? &c.st->d_ni : &c.st->d_no, s_d[threadIdx.x - 4]);
+        if (t < 3 && s_n[t])
+            s_base[t] = vrg_atomic_add(t == 0 ? &c.st->nalloc : t == 1 ? &c.st->ndead : &c.st->nfresh, s_n[t]);
+        if (t >= 4 && t < 6 && s_d[t - 4]) vrg_atomic_add(t == 4 ? &c.st->d_ni : &c.st->d_no, s_d[t - 4]);
         __syncthreads();
         // ... and every event is written at its place
         if (ev.kind != VE_NONE) vrg_ev_write(c, (uint32_t)m, ev, s_base[0] + rn, s_base[1] + rd, s_base[2] + rf);
         __syncthreads();
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 21); }
     }
-    if (threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP_MAX(c, 22); }
+    if (t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP_MAX(c, 22); }
 }
 
 // Workgroups [0, CLOSE_APPLY): the sweep's label bytes in place (+ class bits, region sizes, the class changes of the

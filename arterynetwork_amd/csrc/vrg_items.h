@@ -494,32 +494,43 @@ VRG_HD bool vrg_ring2_applied(const VrgCtx& c, const uint8_t* lab, uint32_t idx)
 // largest rank (is the voxel re-examined by a later flip?).  The cases of the stencil diverge inside a wave; loads inside
 // them run one case after the other - a chain of round trips per wave - while these travel together for all lanes.
 struct VrgRanks { uint32_t minFO, kFO, maxFO, minAP, kAP, maxAP; };
+VRG_HD void vrg_ranks_none(VrgRanks& q) { q.minFO = q.minAP = 0xffffffffu; q.kFO = q.kAP = 0; q.maxFO = q.maxAP = 0; }
+VRG_HD void vrg_ranks_take(uint32_t FO, const uint32_t n[VRG_RANK_BATCH], const uint32_t r[VRG_RANK_BATCH], VrgRanks& q) {
+    for (int k = 0; k < VRG_RANK_BATCH; k++) {
+        if (n[k] >= 27u) continue;
+        if ((FO >> n[k]) & 1u) { if (r[k] < q.minFO) { q.minFO = r[k]; q.kFO = 26u - vrg_nk(n[k]); } if (r[k] > q.maxFO) q.maxFO = r[k]; }
+        else { if (r[k] < q.minAP) { q.minAP = r[k]; q.kAP = 26u - vrg_nk(n[k]); } if (r[k] > q.maxAP) q.maxAP = r[k]; }
+    }
+}
 VRG_HD void vrg_nbr_ranks(const VrgCtx& c, uint32_t FO, uint32_t AP, uint32_t idx, VrgRanks& q) {
-    q.minFO = q.minAP = 0xffffffffu; q.kFO = q.kAP = 0; q.maxFO = q.maxAP = 0;
+    vrg_ranks_none(q);
     uint32_t cand = FO | AP;
     while (cand) {
         uint32_t n[VRG_RANK_BATCH], r[VRG_RANK_BATCH];
         vrg_rank_batch(c, cand, idx, n, r);
-        for (int k = 0; k < VRG_RANK_BATCH; k++) {
-            if (n[k] >= 27u) continue;
-            if ((FO >> n[k]) & 1u) { if (r[k] < q.minFO) { q.minFO = r[k]; q.kFO = 26u - vrg_nk(n[k]); } if (r[k] > q.maxFO) q.maxFO = r[k]; }
-            else { if (r[k] < q.minAP) { q.minAP = r[k]; q.kAP = 26u - vrg_nk(n[k]); } if (r[k] > q.maxAP) q.maxAP = r[k]; }
-        }
+        vrg_ranks_take(FO, n, r, q);
     }
 }
 
 // Returns the voxel's byte after the sweep and files what the change means for the band pool (slot born / dead /
 // re-appended), the class histograms and the sweep's level deltas.  `lab` = this sweep's input labels (L/P bits
 // set); nothing is written to the label volume here, so every stencil read sees the pre-sweep state.
-VRG_HD uint8_t vrg_sweep_core_pre(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t cb, const VrgPre& pre, VrgEvent& ev) {
+// (the case analysis proper: everything it reads from memory is handed in - the neighbourhood masks, the neighbour ranks,
+// whether an applied flip lies within the 2-ring (consulted for an excluded voxel without a listed neighbour only), the
+// voxel's level (lev_fast) - so that a kernel can fetch all of it together, or from a tile it keeps in LDS)
+VRG_HD void vrg_nbr_sets(const VrgNbr& m, uint32_t& ex, uint32_t& segA, uint32_t& FO, uint32_t& AP) {
+    ex = ~m.O & 0x7ffdfffu;                               // neighbours that exist (:278-280), centre excluded
+    segA = m.S & ~m.L & ex; FO = m.S & m.L & ex; AP = ~m.S & m.P & ex;
+}
+VRG_HD bool vrg_wants_ring2(uint8_t cb, const VrgNbr& m) {
+    return !(cb & (VB_S | VB_B)) && (cb & VB_X) && (m.L & ~m.O & 0x7ffdfffu) == 0u;
+}
+VRG_HD uint8_t vrg_sweep_cases(const VrgCtx& c, uint32_t idx, uint8_t cb, const VrgPre& pre, const VrgNbr& m, const VrgRanks& q, bool ring2,
+                               uint32_t lev_here, VrgEvent& ev) {
     ev.kind = VE_NONE; ev.pend = 0;
-    const VrgNbr m = vrg_masks_of(pre.w);
-    const uint32_t ex = ~m.O & 0x7ffdfffu;                 // neighbours that exist (:278-280), centre excluded
-    const uint32_t segA = m.S & ~m.L & ex, FO = m.S & m.L & ex, AP = ~m.S & m.P & ex;
+    uint32_t ex, segA, FO, AP; vrg_nbr_sets(m, ex, segA, FO, AP);
     const bool nSegA = segA != 0, nFO = FO != 0, nAP = AP != 0, nNonSegB = (ex & ~(segA | AP)) != 0, nListed = (m.L & ex) != 0;
     const VrgState& s = *c.st;
-    VrgRanks q; vrg_nbr_ranks(c, FO, AP, idx, q);         // (before the cases: see VrgRanks)
-    const uint32_t lev_here = c.lev_fast ? vrg_pre_level(c, pre) : 0xffffffffu;   // the voxel's level where that costs no global load
     if (cb & VB_S) {
         if (cb & VB_L) {                              // flip-out (:170-175), always applied
             const uint32_t r = pre.rank, slot = pre.vent, lev = c.lev_fast ? lev_here : c.f_lev[r];   // (a flip is a band entry: its slot is the voxel's)
@@ -582,7 +593,7 @@ VRG_HD uint8_t vrg_sweep_core_pre(const VrgCtx& c, const uint8_t* lab, uint32_t 
     bool conv = false;
     uint32_t lev = 0xffffffffu;
     if (cb & VB_X) {
-                conv = nListed || vrg_ring2_applied(c, lab, idx);   // 1-ring of any listed flip (:166-168), 2-ring of any applied flip
+                conv = nListed || ring2;                      // 1-ring of any listed flip (:166-168), 2-ring of any applied flip
         if (conv) {                                   // addedPoints (:235); the voxel joins the outer region
             lev = c.lev_fast ? lev_here : vrg_pre_level(c, pre);
             vrg_note_level(c, c.dConv, lev);
@@ -595,6 +606,15 @@ VRG_HD uint8_t vrg_sweep_core_pre(const VrgCtx& c, const uint8_t* lab, uint32_t 
         return VB_B;
     }
     return (uint8_t)(((cb & VB_X) && !conv) ? VB_X : 0);
+}
+
+VRG_HD uint8_t vrg_sweep_core_pre(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t cb, const VrgPre& pre, VrgEvent& ev) {
+    const VrgNbr m = vrg_masks_of(pre.w);
+    uint32_t ex, segA, FO, AP; vrg_nbr_sets(m, ex, segA, FO, AP);
+    VrgRanks q; vrg_nbr_ranks(c, FO, AP, idx, q);         // (before the cases: see VrgRanks)
+    const uint32_t lev_here = c.lev_fast ? vrg_pre_level(c, pre) : 0xffffffffu;   // the voxel's level where that costs no global load
+    const bool ring2 = vrg_wants_ring2(cb, m) && vrg_ring2_applied(c, lab, idx);
+    return vrg_sweep_cases(c, idx, cb, pre, m, q, ring2, lev_here, ev);
 }
 
 VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx, uint8_t cb, VrgEvent& ev) {

@@ -74,6 +74,7 @@ def configure(s, args):
         s.set_option('serial_streams', 1)
     s.set_option('skip_excluded', args.skip_excluded)
     s.set_option('nt_loads', args.nt_loads)
+    s.set_option('dense_pipe', getattr(args, 'dense_pipe', 1))
 
 
 def padded_slab_voxels(shape, planes):
@@ -253,6 +254,7 @@ def main():
     ap.add_argument('--skip-excluded', type=int, default=1, help='0: the dense pass fetches the intensities of excluded voxels too')
     ap.add_argument('--no-brain-mask', action='store_true', help='experiment: no excluded voxels (the dense pass then has nothing to skip)')
     ap.add_argument('--nt-loads', type=int, default=-1, help='dense pass: -1 = non-temporal loads when the pass exceeds the Infinity Cache (default), 0 / 1 = never / always')
+    ap.add_argument('--dense-pipe', type=int, default=1, help='0: the dense pass as k_recount_bits instead of the two-trips-deep k_recount_pipe (A/B)')
     ap.add_argument('--serial', type=int, default=0, help='1: option serial_streams (needed under rocprofv3 --pmc, which runs one kernel at a time)')
     ap.add_argument('--storage16', action='store_true', help='16-bit intensity storage (level indices): config 5 style; 4 B/voxel-iter algorithmic')
     ap.add_argument('--force-dist', action='store_true', help='use the N>1 code path (RCCL comm) even with one rank')

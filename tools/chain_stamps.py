@@ -29,7 +29,7 @@ done = s.run(40, 10 ** 15, None).sweeps
 NAMES = {0: 'k_band entry (wg 0)', 1: 'k_band state loaded', 2: 'k_band pool wg 0 done', 3: 'k_band first exact wg entry', 4: 'k_band first exact wg done',
          8: 'k_order entry', 9: 'k_order stop tests done', 10: 'k_order flips sorted', 11: 'k_order L/P bits + stamps written', 12: 'k_order prepass done',
          16: 'k_mark_relabel entry (wg 0)', 17: 'k_mark state loaded', 18: 'k_mark label byte + preload back', 19: 'k_mark mark atomics back',
-         20: 'k_mark stencil done', 21: 'k_mark events committed', 22: 'k_mark last workgroup done',
+         23: 'k_mark place in the marked list known', 20: 'k_mark stencil done', 21: 'k_mark events committed', 22: 'k_mark last workgroup done',
          24: 'k_close entry (wg 0)', 25: 'k_close state loaded', 26: 'k_close dense wait over', 27: 'k_close apply done (wg 0)',
          32: 'k_close first memo wg entry', 33: 'k_close memo wg levels sorted', 34: 'k_close memo wg done',
          28: 'k_close last ticket taken', 29: 'k_close finalize done'}
