@@ -62,5 +62,6 @@ for k in sorted(NAMES, key=lambda k: (np.mean(acc[k]) if acc[k] else 1e9)):
     if v:
         print('  %7.2f  (%6.2f .. %6.2f)  %s' % (np.mean(v), np.min(v), np.max(v), NAMES[k]))
 if period:
-    print('  %7.2f  (%6.2f .. %6.2f)  k_band entry of the sweep before to this one (the step)' % (np.mean(period), np.min(period), np.max(period)))
+    # (median: beside a dense pass the sweep before is now and then the last one of the run() call before - a host round trip away)
+    print('  %7.2f  (%6.2f .. %6.2f)  k_band entry of the sweep before to this one = the step (MEDIAN, min..max)' % (np.median(period), np.min(period), np.max(period)))
 s.close()

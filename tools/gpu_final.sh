@@ -22,5 +22,12 @@ run 1024_s16 --shape 1024x1024x1024 --storage16 --no-cpu-baseline --steps 200
 run 880_nomask --no-brain-mask --no-cpu-baseline --steps 300
 for lv in 4095 65535 0; do run 512_levels$lv --no-cpu-baseline --shape 512x512x170 --steps 100 --levels $lv; done
 for nz in 320 160 80; do run dist1_880x880x$nz --force-dist --shape 880x880x$nz --no-cpu-baseline --steps 300; done
+# rare-race hunt: 8 seeds x 500 stepwise parity runs of one random case each (labels, lists, histograms after every sweep)
+for sd in 3 11 19 27 42 77 101 202; do timeout 600 python tools/repeat_case.py $sd 500 2>&1 | grep -v amdgpu.ids | tail -1; done > "$out/repeat_case.log" 2>&1; cat "$out/repeat_case.log"
+( export VRG_HIP_LIB=$PWD/arterynetwork_amd/csrc/libvrg_hip_stamps.so
+  python tools/chain_stamps.py 512x512x170 1 60 2>&1 | grep -v amdgpu.ids > "$out/chain_stamps.log"
+  python tools/chain_stamps.py 512x512x170 0 60 2>&1 | grep -v amdgpu.ids >> "$out/chain_stamps.log"
+  python tools/chain_stamps.py 880x880x80 0 60 2>&1 | grep -v amdgpu.ids >> "$out/chain_stamps.log" )
+tail -3 "$out/chain_stamps.log"
 bash tools/profile_r3.sh r03 2>&1 | tail -12
 bash tools/profile_r3.sh r03_slab80 --force-dist --shape 880x880x80 2>&1 | tail -6
