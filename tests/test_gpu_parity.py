@@ -485,6 +485,26 @@ def test_skip_excluded_is_bit_identical(lib):
         assert outs[1][3] == dense_bytes_by_definition(outs[1][0], line) <= streamed + 512
 
 
+def test_dense_pipe_is_bit_identical(lib):
+    """The two-trips-deep dense kernel (option dense_pipe, default 1; fp32 storage with skip_excluded) makes the same
+    additions in the same order as k_recount_bits: same trace, bit for bit - and vrg_get_stats names the kernel that ran."""
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session
+    d, v = phantoms.bench_volume((256, 192, 96), seed=4)
+    outs = []
+    for pipe in (0, 1):
+        s = Session(d.shape, lib=lib)
+        s.set_option('dense_pipe', pipe)
+        s.set_volume(d.astype(np.float32)); s.set_labels(v.astype(np.uint8)); s.init(2.25)
+        r = s.run(40, 10 ** 9, None)
+        st = s.stats()
+        outs.append((s.labels(), s.trace(), r.sweeps, st['dense_bytes'], st['dense_kernel']))
+        s.close()
+    assert outs[0][2] == outs[1][2] > 0 and np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1].tobytes() == outs[1][1].tobytes() and outs[0][3] == outs[1][3]
+    assert outs[0][4].startswith('k_recount_bits<3,') and outs[1][4].startswith('k_recount_pipe<3,')
+
+
 def test_dense_pass_event_sampling(lib):
     """Option events = n: the dense pass of every n-th sweep of a batch is timed (vrg_result.sweep_kernel_ms over
     sweep_launches launches); 0 times nothing.  Results do not depend on it."""
