@@ -815,7 +815,7 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
         if (s_last) {
             VRG_STAMP(c, 28);
             c.counters[1] = 0;                                           // every workgroup has arrived: reset for the next launch
-            vrg_post_apply(c, (int64_t)nmk); vrg_request_dense(c); vrg_finalize(c, use_tab);
+            vrg_close_sweep(c, (int64_t)nmk, use_tab);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 29);
         }
     }
@@ -1238,7 +1238,7 @@ __global__ void k_tab(VrgCtx c, uint32_t nnz) {
         if (lane == 0) { c.tabC[3 * (size_t)l] = a; c.tabC[3 * (size_t)l + 1] = bb; c.tabC[3 * (size_t)l + 2] = d; }
     }
 }
-__global__ void k_finalize(VrgCtx c, int use_tab) { vrg_post_apply(c); vrg_request_dense(c); vrg_finalize(c, use_tab != 0); }
+__global__ void k_finalize(VrgCtx c, int use_tab) { vrg_close_sweep(c, -1, use_tab != 0); }
 __global__ void k_dense_pack(VrgCtx c) { vrg_dense_pack(c); }
 __global__ void k_dense_fin(VrgCtx c) { vrg_dense_fin_staged(c); }
 

@@ -791,14 +791,19 @@ VRG_HD void vrg_item_level(const VrgCtx& c, uint32_t j, bool clear) {
 // a listed flip the relabel never visited would be an internal error
 VRG_HD void vrg_item_check_flip(const VrgCtx& c, uint32_t r) { if (!(c.f_res[r] & FR_WRITTEN)) vrg_store_i32(&c.stg->error, 3); }
 // iterNum += 1 (:117), list lengths, free list, trace record; what the next k_band finds pending
-VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
+// (in three parts, so that whoever closes a sweep on the device can request everything it reads in ONE batch and send
+// everything it writes together: vrg_close_sweep)
+VRG_HD VrgState vrg_finalize_load(const VrgCtx& c, int64_t& n_in, int64_t& n_out) {
     VrgState s = vrg_load_state(c.stg);               // one round trip for the whole state (past L1), one to write it back
     // ... the counters this kernel's atomics moved come from L2
     s.nalloc = vrg_load_u32(&c.stg->nalloc); s.ndead = vrg_load_u32(&c.stg->ndead); s.nfresh = vrg_load_u32(&c.stg->nfresh);
     s.nnz = vrg_load_u32(&c.stg->nnz); s.nmk = vrg_load_u32(&c.stg->nmk); s.npend = vrg_load_u32(&c.stg->npend);
     s.d_ni = vrg_load_i32(&c.stg->d_ni); s.d_no = vrg_load_i32(&c.stg->d_no); s.error = vrg_load_i32(&c.stg->error);
     s.ties = vrg_load_u32(&c.stg->ties); s.near_ties = vrg_load_u32(&c.stg->near_ties);
-    const int64_t n_in = vrg_load_i64(&c.inc[VC_NIN]), n_out = vrg_load_i64(&c.inc[VC_NOUT]);
+    n_in = vrg_load_i64(&c.inc[VC_NIN]); n_out = vrg_load_i64(&c.inc[VC_NOUT]);
+    return s;
+}
+VRG_HD void vrg_finalize_update(const VrgCtx& c, VrgState& s, int64_t n_in, int64_t n_out, bool use_tab) {
     const uint32_t used = vrg_free_used(s.nalloc, s.nfree);
     s.np += s.nalloc - used; s.nfree = s.nfree - used + s.ndead;
     s.ni = (uint32_t)((int32_t)s.ni + s.d_ni); s.no = (uint32_t)((int32_t)s.no + s.d_no);
@@ -814,7 +819,26 @@ VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
     s.nfx = s.nfresh; s.nfresh = 0;                   // exact densities of the new entries: first thing next trip
     s.corr = 1; s.use_tab = use_tab ? 1 : 0;          // nnz stays: the next k_band reads the touched-level list
     if (s.error) { s.done = -1; vrg_store_i64(&c.gate[VG_STOP], 1); }
+}
+VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
+    int64_t n_in, n_out;
+    VrgState s = vrg_finalize_load(c, n_in, n_out);
+    vrg_finalize_update(c, s, n_in, n_out, use_tab);
     *c.stg = s;
+}
+// vrg_post_apply + vrg_request_dense + vrg_finalize by the ONE thread that closes a sweep in a kernel, as two round trips
+// instead of three: what they read in one batch; the expected sizes, the change lists' lengths and the new state out
+// together; the request word last, once all of that (and every class bit of the sweep) has reached memory
+VRG_HD void vrg_close_sweep(const VrgCtx& c, int64_t nchg_at, bool use_tab) {
+    int64_t n_in, n_out;
+    VrgState s = vrg_finalize_load(c, n_in, n_out);
+    const int64_t k = (int64_t)s.iter + 1;
+    vrg_store_i64(&c.exp_ring[2 * (k % VRG_RING)], n_in); vrg_store_i64(&c.exp_ring[2 * (k % VRG_RING) + 1], n_out);
+    c.nchg[(k & 1) ^ 1] = 0;
+    if (nchg_at >= 0) c.nchg[k & 1] = (uint32_t)nchg_at;
+    vrg_finalize_update(c, s, n_in, n_out, use_tab);
+    *c.stg = s;
+    vrg_drain(); vrg_store_i64(&c.gate[VG_REQ], k);
 }
 
 // ------------------------------------------------------------------ init mode (:129-155)
