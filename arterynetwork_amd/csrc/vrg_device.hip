@@ -1912,8 +1912,12 @@ int dense_blocks(const VrgBackend* b, const VrgCtx& c) {
     // 0.0481 with 512; 880x880x80: 0.0466 with 256, 0.0493 with 483, 0.0505 with 512).
     // Streaming pass (skip_excluded = 0): 1 resp. 2 workgroups per CU.
     if (!b->skip) return (int)std::min<uint64_t>(c.lev16 ? 2 * SWEEP_BLOCKS : SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128));
-    return (int)(c.lev16 ? std::min<uint64_t>(8 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 48))
-                         : std::min<uint64_t>(3 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 224)));
+    if (c.lev16) return (int)std::min<uint64_t>(8 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 48));
+    // fp32: whole or half multiples of the CU count only - 552 or 640 workgroups leave some CUs with a wave more than others for
+    // the whole pass (880x880x160: 552 -> 0.058 ms, 384 -> 0.050; 880x880x320: 640 -> 0.103, 512 -> 0.094, 768 -> 0.091 but a
+    // slower step, 0.1035 vs 0.1003, the band chain queueing behind three waves per SIMD); one session, tools/gpu_slabsweep.sh
+    const uint64_t pick = units <= 100000 ? 256 : units <= 200000 ? 384 : units <= 350000 ? 512 : 768;
+    return (int)std::min<uint64_t>(pick, std::max<uint64_t>(64, units / 160));
 }
 
 void use_device(VrgBackend* b) { HIP_CHECK(hipSetDevice(b->device)); }
