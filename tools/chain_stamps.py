@@ -51,7 +51,7 @@ for _ in range(samples):
     t0 = buf[40] if os.environ.get('VRG_CHAIN_KERNEL') == '1' else buf[0]
     if not t0:
         raise SystemExit('no stamps: not the -DVRG_STAMPS build (set VRG_HIP_LIB)')
-    if buf[6] and not os.environ.get('VRG_CHAIN_KERNEL') == '1':
+    if buf[6] and dense_off and not os.environ.get('VRG_CHAIN_KERNEL') == '1':      # (beside a dense pass the stamp of the sweep before is read stale more often than not)
         period.append((t0 - buf[6]) * 0.01)
     for k in NAMES:
         if buf[k] >= t0:
