@@ -1,4 +1,5 @@
 #!/bin/bash
+# One development round trip for a change to the band chain: build + smoke, the quick GPU parity tests, the two small bench shapes twice, in-kernel stamps.
 set -u
 tag=${1:?tag}; out="gpurun_out/$tag"; mkdir -p "$out"; export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -1
