@@ -709,15 +709,19 @@ VRG_HD void vrg_post_apply(const VrgCtx& c, int64_t nchg_at = -1) {
     if (nchg_at >= 0) c.nchg[k & 1] = (uint32_t)nchg_at;
 }
 // init: class dword d from the labels (16 voxels), both copies
-VRG_HD void vrg_item_cls_build(const VrgCtx& c, uint32_t d) {
+VRG_HD uint32_t vrg_cls_word_build(const VrgCtx& c, uint32_t d) {
     uint32_t base = ((d >> 6) << 10) | ((d & 63u) << 2), w = 0;
-    for (uint32_t j = 0; j < 4; j++)
-        for (uint32_t b = 0; b < 4; b++) {
-            uint32_t idx = base + 256u * j + b;
-            if (idx < c.PV) w |= vrg_cls_of(c.lab[0][idx]) << (2u * (4u * j + b));
-        }
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t i4 = base + 256u * j;              // four voxels = one aligned word of labels (PV is a multiple of 16)
+        if (i4 >= c.PV) continue;
+        uint32_t l4; __builtin_memcpy(&l4, c.lab[0] + i4, 4);
+        for (uint32_t b = 0; b < 4; b++) w |= vrg_cls_of((uint8_t)(l4 >> (8u * b))) << (2u * (4u * j + b));
+    }
     c.clsb[0][d] = w; c.clsb[1][d] = w;
-    if (w) vrg_atomic_or(&c.ubits[d >> 11], 1u << ((d >> 6) & 31u));     // (the bitmap was zeroed before)
+    return w;
+}
+VRG_HD void vrg_item_cls_build(const VrgCtx& c, uint32_t d) {
+    if (vrg_cls_word_build(c, d)) vrg_atomic_or(&c.ubits[d >> 11], 1u << ((d >> 6) & 31u));     // (the bitmap was zeroed before)
 }
 // the unit list from the bitmap, sequentially (init of the test model; the device builds it in parallel: ulist_refresh)
 VRG_HD void vrg_ulist_rebuild_serial(const VrgCtx& c) {
@@ -867,6 +871,14 @@ VRG_HD void vrg_item_init_voxel(const VrgCtx& c, uint32_t idx) {
         }
         return;
     }
+    // (nearly every voxel has no seed among its 26 neighbours: nine 4-byte rows say so - 26 byte loads per voxel made this
+    // kernel 14.5 ms of a 40-ms vrg_init at 880x880x640.  S bits do not change during init.)
+    uint32_t any = 0;
+    for (int j = 0; j < 9; j++) {
+        uint32_t w; __builtin_memcpy(&w, lab + ((int64_t)idx + ((j % 3 - 1) * c.PY + (j / 3 - 1)) * c.PX - 1), 4);
+        any |= w;
+    }
+    if (!(any & (0x010101u * VB_S))) return;              // bytes x-1 .. x+1 of the nine (dy, dz) rows
     uint64_t best = ~0ull; int bk = 0;
     for (int k = 0; k < 27; k++) {
         if (k == 13) continue;
