@@ -1354,23 +1354,36 @@ constexpr uint32_t LEV16_MAX = 16384;   // 16-bit storage: the level values sit 
 // wave); padding planes are class 0.
 // UNITS = units a wave loads per trip (bytes in flight); NT = non-temporal loads: the volume is read once per
 // sweep and is far larger than the 256-MiB Infinity Cache, so nothing is worth keeping.
-// MODE 0: fp32 intensities, 1: 16-bit level indices + LDS value table, 2: float64 intensities.
+// MODE 0: fp32 intensities, 1: 16-bit level indices + LDS value table (floats), 2: float64 intensities, 3: as 1 with the table
+// held as doubles (up to TAB64_LEVELS levels): the pass is then bound by its arithmetic, not by memory - SQ counters, 16-bit
+// storage at 880x880x640: VALU busy 0.6-0.8 of all issue slots, a quarter of it the float -> double conversion of every value
+// (half rate on this chip) - and the doubles come out of the table ready to be added.
 // Dense pass number seq (= passes closed + 1) reads copy seq & 1 of the class bits.
 template <int MODE> struct UnitVals { f4v f[4]; };
 template <> struct UnitVals<1> { u2v q[4]; };           // raw level indices: the LDS look-ups wait until the sums are formed
-template <> struct UnitVals<2> { d2v f[4][2]; };
-template <int MODE>
-__device__ __forceinline__ void stats_group(SweepAcc& a, uint32_t wj, const UnitVals<MODE>& u, int j, const float* s_val) {
-    float lv[4];
+template <> struct UnitVals<3> { u2v q[4]; };
+constexpr uint32_t TAB64_LEVELS = 4096;                 // 32 KiB of LDS per workgroup
+template <int MODE> __device__ __forceinline__ void lookup4(const UnitVals<MODE>& u, int j, const float* s_val, float lv[4], double dv[4]) {
     if constexpr (MODE == 1) {
         lv[0] = s_val[u.q[j].x & 0xffffu]; lv[1] = s_val[u.q[j].x >> 16];
         lv[2] = s_val[u.q[j].y & 0xffffu]; lv[3] = s_val[u.q[j].y >> 16];
+    } else if constexpr (MODE == 3) {
+        const double* s_dv = reinterpret_cast<const double*>(s_val);
+        dv[0] = s_dv[u.q[j].x & 0xffffu]; dv[1] = s_dv[u.q[j].x >> 16];
+        dv[2] = s_dv[u.q[j].y & 0xffffu]; dv[3] = s_dv[u.q[j].y >> 16];
     }
+}
+template <> struct UnitVals<2> { d2v f[4][2]; };
+template <int MODE>
+__device__ __forceinline__ void stats_group(SweepAcc& a, uint32_t wj, const UnitVals<MODE>& u, int j, const float* s_val) {
+    float lv[4]; double dv[4];
+    lookup4<MODE>(u, j, s_val, lv, dv);
 #pragma unroll
     for (int bb = 0; bb < 4; bb++) {
-        if constexpr (MODE == 2) {
+        if constexpr (MODE == 2 || MODE == 3) {
             const uint32_t t = wj >> (2 * bb);
-            const double x = u.f[j][bb >> 1][bb & 1];
+            double x;
+            if constexpr (MODE == 2) x = u.f[j][bb >> 1][bb & 1]; else x = dv[bb];
             a.sin_ += (t & 1u) ? x : 0.0;
             a.sout += (t & 2u) ? x : 0.0;
         } else {
@@ -1387,15 +1400,13 @@ __device__ __forceinline__ void stats_group(SweepAcc& a, uint32_t wj, const Unit
 // the same for a group in which no lane holds an inner voxel: only the outer sum moves (same additions, same order)
 template <int MODE>
 __device__ __forceinline__ void stats_group_outer(SweepAcc& a, uint32_t wj, const UnitVals<MODE>& u, int j, const float* s_val) {
-    float lv[4];
-    if constexpr (MODE == 1) {
-        lv[0] = s_val[u.q[j].x & 0xffffu]; lv[1] = s_val[u.q[j].x >> 16];
-        lv[2] = s_val[u.q[j].y & 0xffffu]; lv[3] = s_val[u.q[j].y >> 16];
-    }
+    float lv[4]; double dv[4];
+    lookup4<MODE>(u, j, s_val, lv, dv);
 #pragma unroll
     for (int bb = 0; bb < 4; bb++) {
-        if constexpr (MODE == 2) {
-            const double x = u.f[j][bb >> 1][bb & 1];
+        if constexpr (MODE == 2 || MODE == 3) {
+            double x;
+            if constexpr (MODE == 2) x = u.f[j][bb >> 1][bb & 1]; else x = dv[bb];
             a.sout += ((wj >> (2 * bb)) & 2u) ? x : 0.0;
         } else {
             uint32_t xi;
@@ -1409,8 +1420,9 @@ __device__ __forceinline__ void stats_group_outer(SweepAcc& a, uint32_t wj, cons
 // wave-uniform there); partly excluded groups run with the excluded lanes masked off.  Adding +0.0 or not adding at
 // all gives the same sums (the accumulators never hold -0.0: they start at +0.0).
 template <int MODE>
-__device__ __forceinline__ double unit_value(const UnitVals<MODE>& u, int j, int bb, const float* lv) {
+__device__ __forceinline__ double unit_value(const UnitVals<MODE>& u, int j, int bb, const float* lv, const double* dv) {
     if constexpr (MODE == 2) return u.f[j][bb >> 1][bb & 1];
+    else if constexpr (MODE == 3) return dv[bb];
     else if constexpr (MODE == 1) return (double)lv[bb];
     else return (double)u.f[j][bb];
 }
@@ -1425,13 +1437,10 @@ __device__ __forceinline__ void stats_bits(SweepAcc& a, uint32_t w, const UnitVa
         const uint32_t wj = (w >> (8 * j)) & 0xffu;
         if (!SKIP || wj != 0u) {
             if (SKIP && __builtin_amdgcn_ballot_w64(wj != 0xAAu) == 0ull) {
-                float lv[4];
-                if constexpr (MODE == 1) {
-                    lv[0] = s_val[u.q[j].x & 0xffffu]; lv[1] = s_val[u.q[j].x >> 16];
-                    lv[2] = s_val[u.q[j].y & 0xffffu]; lv[3] = s_val[u.q[j].y >> 16];
-                }
+                float lv[4]; double dv[4];
+                lookup4<MODE>(u, j, s_val, lv, dv);
 #pragma unroll
-                for (int bb = 0; bb < 4; bb++) a.sout += unit_value<MODE>(u, j, bb, lv);
+                for (int bb = 0; bb < 4; bb++) a.sout += unit_value<MODE>(u, j, bb, lv, dv);
             } else if (SKIP && __builtin_amdgcn_ballot_w64((wj & 0x55u) != 0u) == 0ull) {
                 // no lane holds an inner voxel here (the rim of the brain mask: outer and excluded voxels mixed): the outer
                 // sum alone, masked - the general path would add +0.0 to the inner sum sixteen times for nothing
@@ -1458,7 +1467,7 @@ __device__ __forceinline__ void load_vals(const VrgCtx& c, uint32_t u, uint32_t 
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const bool need = !SKIP || ((w >> (8 * j)) & 0xffu) != 0u;
-        if constexpr (MODE == 1) {
+        if constexpr (MODE == 1 || MODE == 3) {
             o.q[j] = u2v{0u, 0u};
             if (need) { const u2v* pq = reinterpret_cast<const u2v*>(c.lev16 + base + (j << 8)); o.q[j] = NT ? __builtin_nontemporal_load(pq) : *pq; }
         } else if constexpr (MODE == 2) {
@@ -1486,7 +1495,7 @@ __device__ __forceinline__ void load_vals(const VrgCtx& c, uint32_t u, uint32_t 
 template <int UNITS, bool NT, int MODE, bool SKIP>
 __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) {
     if (check_done && !vrg_dense_due(c)) return;     // k_gate let it through without a sweep to count: the run has stopped
-    extern __shared__ float s_val[];        // 16-bit storage: the level values (c.L floats, sized at launch)
+    extern __shared__ __attribute__((aligned(16))) float s_val[];   // 16-bit storage: the level values (c.L floats - MODE 3: doubles -, sized at launch)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t* __restrict__ ulist = c.ulist;
@@ -1499,6 +1508,11 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
     for (int q = 0; q < UNITS; q++) uu[q] = i < n ? ulist[min(i + q, last)] : 0u;     // (an empty list has no readable entry)
     if (MODE == 1) {
         for (uint32_t k = threadIdx.x; k < c.L; k += TPB) s_val[k] = (float)c.lev[k];
+        __syncthreads();
+    }
+    if (MODE == 3) {                                 // (the stored value is the float: the same doubles as MODE 1 adds)
+        double* s_dv = reinterpret_cast<double*>(s_val);
+        for (uint32_t k = threadIdx.x; k < c.L; k += TPB) s_dv[k] = (double)(float)c.lev[k];
         __syncthreads();
     }
     const uint32_t* __restrict__ cls = c.clsb[(vrg_load_i64(&c.dctl[VD_RSEQ]) + 1) & 1];
@@ -1537,7 +1551,7 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
             UnitVals<MODE> f;
             const uint32_t w1 = load_cls<NT>(cls, u, lane);
             load_vals<MODE, NT, false>(c, u, lane, w1, f);
-            if constexpr (MODE == 1) { asm volatile("" :: "v"(f.q[0]), "v"(f.q[1]), "v"(f.q[2]), "v"(f.q[3]), "v"(w1)); }
+            if constexpr (MODE == 1 || MODE == 3) { asm volatile("" :: "v"(f.q[0]), "v"(f.q[1]), "v"(f.q[2]), "v"(f.q[3]), "v"(w1)); }
             else if constexpr (MODE == 2) { asm volatile("" :: "v"(f.f[0][0]), "v"(f.f[1][1]), "v"(f.f[2][0]), "v"(f.f[3][1]), "v"(f.f[0][1]), "v"(f.f[1][0]), "v"(f.f[2][1]), "v"(f.f[3][0]), "v"(w1)); }
             else { asm volatile("" :: "v"(f.f[0]), "v"(f.f[1]), "v"(f.f[2]), "v"(f.f[3]), "v"(w1)); }
         }
@@ -1917,7 +1931,9 @@ int dense_blocks(const VrgBackend* b, const VrgCtx& c) {
     // 0.0481 with 512; 880x880x80: 0.0466 with 256, 0.0493 with 483, 0.0505 with 512).
     // Streaming pass (skip_excluded = 0): 1 resp. 2 workgroups per CU.
     if (!b->skip) return (int)std::min<uint64_t>(c.lev16 ? 2 * SWEEP_BLOCKS : SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128));
-    if (c.lev16) return (int)std::min<uint64_t>(8 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 48));
+    // 16-bit storage: six workgroups per CU (one session, 880x880x640 / 1024^3: 1024 -> 0.137 / -, 1280 -> 0.132 / 0.258, 1536 ->
+    // 0.122 / 0.240, 1792 -> 0.122 / -, 2048 -> 0.148 / 0.281 ms)
+    if (c.lev16) return (int)std::min<uint64_t>(6 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 48));
     // fp32: whole or half multiples of the CU count only - 552 or 640 workgroups leave some CUs with a wave more than others for
     // the whole pass (880x880x160: 552 -> 0.058 ms, 384 -> 0.050; 880x880x320: 640 -> 0.103, 512 -> 0.094, 768 -> 0.091 but a
     // slower step, 0.1035 vs 0.1003, the band chain queueing behind three waves per SIMD); one session, tools/gpu_slabsweep.sh
@@ -2186,7 +2202,8 @@ int be_comm_init(VrgBackend* b, int nranks, int rank, const void* id128) {
 // which cost ~4 us each between two back-to-back recounts.
 template <bool NT, bool SKIP>
 static void launch_recount_as(const VrgCtx& c, int blocks, int check, hipStream_t st, hipEvent_t e_start, hipEvent_t e_stop) {
-    if (c.lev16) hipExtLaunchKernelGGL((k_recount_bits<3, NT, 1, SKIP>), dim3(blocks), dim3(TPB), c.L * sizeof(float), st, e_start, e_stop, 0, c, check);
+    if (c.lev16 && c.L <= TAB64_LEVELS) hipExtLaunchKernelGGL((k_recount_bits<3, NT, 3, SKIP>), dim3(blocks), dim3(TPB), c.L * sizeof(double), st, e_start, e_stop, 0, c, check);
+    else if (c.lev16) hipExtLaunchKernelGGL((k_recount_bits<3, NT, 1, SKIP>), dim3(blocks), dim3(TPB), c.L * sizeof(float), st, e_start, e_stop, 0, c, check);
     else if (c.I) hipExtLaunchKernelGGL((k_recount_bits<3, NT, 0, SKIP>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
     else hipExtLaunchKernelGGL((k_recount_bits<2, NT, 2, SKIP>), dim3(blocks), dim3(TPB), 0, st, e_start, e_stop, 0, c, check);
 }
@@ -2417,7 +2434,7 @@ void be_recount_hist(VrgBackend* b, const VrgCtx& c, int32_t* rin, int32_t* rout
 // workgroups, skip_excluded, k_recount_pipe instead of k_recount_bits}
 static bool dense_is_pipe(VrgBackend* b, const VrgCtx& c) { return b->dense_pipe && c.I && !c.lev16 && b->skip; }
 void be_dense_info(VrgBackend* b, const VrgCtx& c, int64_t out[5]) {
-    out[0] = dense_nt(b, c) ? 1 : 0; out[1] = c.lev16 ? 1 : (c.I ? 0 : 2); out[2] = dense_blocks(b, c); out[3] = b->skip ? 1 : 0;
+    out[0] = dense_nt(b, c) ? 1 : 0; out[1] = c.lev16 ? (c.L <= TAB64_LEVELS ? 3 : 1) : (c.I ? 0 : 2); out[2] = dense_blocks(b, c); out[3] = b->skip ? 1 : 0;
     out[4] = dense_is_pipe(b, c) ? 1 : 0;
 }
 uint64_t be_dense_bytes(VrgBackend* b, const VrgCtx& c) {

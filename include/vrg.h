@@ -138,7 +138,7 @@ int vrg_get_levels(vrg_handle* h, double* values, int32_t* hist_in, int32_t* his
  * the bytes one dense pass requests from memory with the current labels (class words + the 128-byte intensity lines
  * that hold an included voxel; every line of the slab with option skip_excluded = 0) - the roofline's numerator.
  * With cap >= 14 also how the dense pass is launched: out[9] = 1 for non-temporal loads, out[10] = intensity storage
- * (0 fp32, 1 u16 level index, 2 float64), out[11] = workgroups, out[12] = skip_excluded, out[13] = units on its list.  With cap >= 15 also out[14] = 1 when the
+ * (0 fp32, 1 u16 level index, 2 float64, 3 u16 level index with the value table of the dense pass held as doubles: up to 4096 levels), out[11] = workgroups, out[12] = skip_excluded, out[13] = units on its list.  With cap >= 15 also out[14] = 1 when the
  * pass is the two-trips-deep kernel k_recount_pipe (option dense_pipe; fp32 storage with skip_excluded), 0 for k_recount_bits. */
 int vrg_get_stats(vrg_handle* h, int64_t* out, int64_t cap);
 
