@@ -2301,7 +2301,10 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
     const bool dense = !(flags & VRG_SWEEP_NODENSE);
     const long long trip = b->ev_trip++;
     auto take_pair = [&](int kind) -> EvPair& {
-        if (b->ev_used == b->ev_pool.size()) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); n.trip = 0; n.kind = 0; n.ntrips = 1; b->ev_pool.push_back(n); }
+        // (32 pairs at a time: an event costs ~10-20 us to create, and a short run - the driver's 20 steps - should not pay
+        // for its events inside its timed sweeps; the first sweep of a handle that times anything creates the lot)
+        if (b->ev_used == b->ev_pool.size())
+            for (int k = 0; k < 32; k++) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); n.trip = 0; n.kind = 0; n.ntrips = 1; b->ev_pool.push_back(n); }
         EvPair& p = b->ev_pool[b->ev_used++];
         p.trip = trip; p.kind = kind; p.ntrips = 1;
         return p;
