@@ -1933,7 +1933,9 @@ int dense_blocks(const VrgBackend* b, const VrgCtx& c) {
     if (!b->skip) return (int)std::min<uint64_t>(c.lev16 ? 2 * SWEEP_BLOCKS : SWEEP_BLOCKS, std::max<uint64_t>(64, units / 128));
     // 16-bit storage: six workgroups per CU (one session, 880x880x640 / 1024^3: 1024 -> 0.137 / -, 1280 -> 0.132 / 0.258, 1536 ->
     // 0.122 / 0.240, 1792 -> 0.122 / -, 2048 -> 0.148 / 0.281 ms)
-    if (c.lev16) return (int)std::min<uint64_t>(6 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 48));
+    // (small passes, where the band chain bounds the step: 512x512x170 942 -> 0.0428 ms/step, 384-512 -> 0.0381; 80-plane slab
+    // 1289 -> 0.0516, 512 -> 0.0394; 160 planes 1536 -> 0.0633, 1024 -> 0.0499)
+    if (c.lev16) return (int)std::min<uint64_t>(units <= 100000 ? 2 * SWEEP_BLOCKS : units <= 200000 ? 4 * SWEEP_BLOCKS : 6 * SWEEP_BLOCKS, std::max<uint64_t>(64, units / 48));
     // fp32: whole or half multiples of the CU count only - 552 or 640 workgroups leave some CUs with a wave more than others for
     // the whole pass (880x880x160: 552 -> 0.058 ms, 384 -> 0.050; 880x880x320: 640 -> 0.103, 512 -> 0.094, 768 -> 0.091 but a
     // slower step, 0.1035 vs 0.1003, the band chain queueing behind three waves per SIMD); one session, tools/gpu_slabsweep.sh
