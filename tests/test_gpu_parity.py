@@ -423,20 +423,24 @@ def test_16bit_storage_identical(lib, golden_loader):
         res, k = parity.run_stepwise(lib, data, vmap, g.H, g.maxSegmentSize, iterMax, density_mode=1, check_hist=True,
                                      options={'storage16': 1})
         assert res is not None and k == g.ncalls - 1
-    data, vmap = phantoms.bench_volume((256, 192, 96), seed=4)
-    outs = []
-    for st in (0, 1):
-        s = Session(data.shape, lib=lib)
-        s.set_option('storage16', st)
-        s.set_volume(data); s.set_labels(vmap.astype(np.uint8)); s.init(2.25)
-        s.run(40, 10 ** 9, None)
-        outs.append((s.labels(), s.segmented(), s.trace(), s.band(0), s.band(1)))
-        s.close()
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
-    assert outs[0][2].tobytes() == outs[1][2].tobytes()          # trace incl. the f64 intensity sums: bit-identical
-    for w in (3, 4):
-        for x, y in zip(outs[0][w], outs[1][w]):
-            assert np.array_equal(x, y)
+    # up to 4096 levels the dense pass keeps the level values in LDS as doubles (kernel mode 3), beyond as floats (mode 1):
+    # a 255-step and a 12-bit quantisation (the latter: > 4096 distinct values)
+    for levels, mode in ((255, 3), (4095, 1)):
+        data, vmap = phantoms.bench_volume((256, 192, 96), seed=4, levels=levels)
+        outs = []
+        for st in (0, 1):
+            s = Session(data.shape, lib=lib)
+            s.set_option('storage16', st)
+            s.set_volume(data); s.set_labels(vmap.astype(np.uint8)); s.init(2.25)
+            s.run(40, 10 ** 9, None)
+            outs.append((s.labels(), s.segmented(), s.trace(), s.band(0), s.band(1), s.stats()['dense_kernel'], s.nlevels()))
+            s.close()
+        assert (outs[1][6] > 4096) == (mode == 1) and ',%d,' % mode in outs[1][5], (outs[1][5], outs[1][6])
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        assert outs[0][2].tobytes() == outs[1][2].tobytes()          # trace incl. the f64 intensity sums: bit-identical
+        for w in (3, 4):
+            for x, y in zip(outs[0][w], outs[1][w]):
+                assert np.array_equal(x, y)
     # continuous-valued data has too many distinct values for 16-bit storage: loud error, no silent fallback
     d2, v2 = phantoms.config1()
     s = Session(d2.shape, lib=lib)
