@@ -45,6 +45,9 @@ int be_unpack_labels(VrgBackend* b, const VrgCtx& c, const uint8_t* lab, void* d
 // sorted distinct intensity values; allocates *lev (backend memory), returns the count in *L
 int be_build_levels(VrgBackend* b, const VrgCtx& c, double** lev, uint32_t* L);
 
+// map[v - lev[0]] = level index for a level table of integers (true), or false when a level is not an integer; `map` holds
+// lev[L-1] - lev[0] + 1 entries
+bool be_build_lev_map(VrgBackend* b, const VrgCtx& c, uint16_t* map, uint32_t span);
 // 16-bit storage: level index of every voxel (after be_build_levels), padded layout
 void be_build_lev16(VrgBackend* b, const VrgCtx& c, uint16_t* dst);
 

@@ -571,7 +571,8 @@ __global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
     const uint32_t p = t;
     const int dx = (int)(p % 5) - 2, dy = (int)((p / 5) % 5) - 2, dz = (int)(p / 25) - 2;     // vrg_mark_pos
     const int ry = (int)(t % 9) - 4, rz = (int)(t / 9) - 4;                                   // the tile row thread t < 81 fetches
-    c.lev_fast = (cg.L <= LEV_LDS || cg.lev16) ? 1 : 0;
+    c.lev_fast = (cg.L <= LEV_LDS || cg.lev16 || cg.lev_map) ? 1 : 0;   // (the direct map: one load, requested with the mark and the ranks)
+    if (cg.L <= LEV_LDS) c.lev_map = nullptr;                              // (a table in LDS needs no load at all)
     // (every thread of the workgroup makes the same number of trips: the commit below needs its barriers)
     for (uint32_t r = blockIdx.x; r < nf; r += gridDim.x) {
         const uint32_t fidx = r == blockIdx.x ? fidx_first : c.f_idx[r];
@@ -2110,6 +2111,25 @@ template <class T> static int build_levels_t(VrgBackend* b, const VrgCtx& c, dou
 int be_build_levels(VrgBackend* b, const VrgCtx& c, double** lev, uint32_t* L) {
     use_device(b);
     return c.I ? build_levels_t<float>(b, c, lev, L) : build_levels_t<double>(b, c, lev, L);
+}
+
+__global__ void k_lev_map(VrgCtx c, uint16_t* map, int* bad) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < c.L; k += gridDim.x * blockDim.x) {
+        const double v = c.lev[k];
+        if (v != floor(v)) *bad = 1; else map[(uint32_t)(v - c.lev[0])] = (uint16_t)k;
+    }
+}
+bool be_build_lev_map(VrgBackend* b, const VrgCtx& c, uint16_t* map, uint32_t span) {
+    use_device(b);
+    int* bad = nullptr; int hbad = 1;
+    if (hipMalloc(&bad, sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), b->sa));
+    HIP_CHECK(hipMemsetAsync(map, 0xff, (size_t)span * 2, b->sa));
+    k_lev_map<<<(c.L + TPB - 1) / TPB, TPB, 0, b->sa>>>(c, map, bad);
+    HIP_CHECK(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, b->sa));
+    HIP_CHECK(hipStreamSynchronize(b->sa));
+    HIP_CHECK(hipFree(bad));
+    return hbad == 0;
 }
 
 void be_build_lev16(VrgBackend* b, const VrgCtx& c, uint16_t* dst) {

@@ -252,6 +252,7 @@ int API(set_volume)(vrg_handle* h, const void* data, int dtype, const int64_t st
     h->have_vol = true; h->inited = false;
     if (c.lev) {                                     // distinct-value table and its arrays are rebuilt by the next vrg_init
         release(h, (void*)c.lev); c.lev = nullptr;
+        if (c.lev_map) { release(h, (void*)c.lev_map); c.lev_map = nullptr; }
         release(h, c.hin); release(h, c.hout); release(h, c.dIn); release(h, c.dOut); release(h, c.dConv); release(h, c.ltouch);
         release(h, c.nz_key); release(h, c.nz_val); release(h, c.nz_cin); release(h, c.nz_cout); release(h, c.nz_cconv); release(h, c.tabC);
         c.hin = c.hout = nullptr; c.dIn = c.dOut = c.dConv = c.ltouch = nullptr; c.nz_key = nullptr; c.nz_val = nullptr;
@@ -301,6 +302,20 @@ int API(init)(vrg_handle* h, double H) {
             return fail(h, VRG_E_MEM, "vrg_init: level arrays");
         }
         c.lev = lev;
+        // integer-valued levels within a span of 65 536: the direct value -> level map (VrgCtx::lev_map)
+        c.lev_map = nullptr; c.lev_min = 0;
+        if (L >= 2 && L <= 65535) {
+            double ends[2] = {0, 0};
+            be_download(be, &ends[0], c.lev, sizeof(double)); be_download(be, &ends[1], c.lev + (L - 1), sizeof(double));
+            const double span = ends[1] - ends[0] + 1.0;
+            if (ends[0] == std::floor(ends[0]) && span >= 2.0 && span <= 65536.0) {
+                uint16_t* map = alloc<uint16_t>(h, (size_t)span);
+                if (map) {
+                    if (be_build_lev_map(be, c, map, (uint32_t)span)) { c.lev_map = map; c.lev_min = ends[0]; }
+                    else release(h, map);
+                }
+            }
+        }
     }
     const uint32_t L = c.L;
     c.lev16 = nullptr;

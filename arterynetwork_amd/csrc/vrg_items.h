@@ -130,6 +130,7 @@ VRG_HD double vrg_kern(const VrgCtx& c, double d) { return c.A * exp(-0.5 * c.H 
 
 VRG_HD double vrg_voxel_value(const VrgCtx& c, uint32_t idx) { return c.I ? (double)c.I[idx] : c.I64[idx]; }
 VRG_HD uint32_t vrg_level_of(const VrgCtx& c, double v) {   // index of v in the sorted distinct values
+    if (c.lev_map) return (uint32_t)c.lev_map[(uint32_t)(v - c.lev_min)];       // (v is a voxel's value: an integer, a level)
     uint32_t lo = 0, hi = c.L - 1;
     while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (c.lev[m] < v) lo = m + 1; else hi = m; }
     return lo;

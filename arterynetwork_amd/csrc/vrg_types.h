@@ -181,6 +181,10 @@ struct VrgCtx {
     // intensity levels: sorted distinct values and per-class histograms (:149-150, :249-250)
     uint32_t L;
     const double* lev;
+    // integer-valued volumes whose values span at most 65 536 (what scanners deliver: 12-bit, 16-bit): value -> level index
+    // directly, lev_map[v - lev_min] - ONE load where the binary search through `lev` makes log2(L) dependent ones; null else
+    const uint16_t* lev_map;
+    double lev_min;
     VrgArr<int32_t> hin;
     VrgArr<int32_t> hout;
     VrgArr<uint32_t> dIn;             // per-level counts of innerAdded / outerAdded / addedPoints (:232-235); zero between sweeps

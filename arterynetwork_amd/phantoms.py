@@ -127,7 +127,7 @@ def bench_volume(shape, seed, levels=255, radius=4.0, noise=0.1, seed_planes=3):
                         dtype=np.float32, noise_dtype=np.float32)
 
 
-def bench_volume_torch(shape, device, seed=3, levels=255, radius=4.0, noise=0.1, seed_planes=3, brain_mask=True):
+def bench_volume_torch(shape, device, seed=3, levels=255, radius=4.0, noise=0.1, seed_planes=3, brain_mask=True, integer_values=False):
     """The configs 2-4 recipe generated directly in HBM with torch (plumbing only), x-fastest
     layout.  Returns (I, vm) as torch tensors of logical shape (nx,ny,nz) with element strides (1,nx,nx*ny).
     ``levels=None`` keeps the continuous float32 noise (one distinct value per voxel, nearly)."""
@@ -145,7 +145,9 @@ def bench_volume_torch(shape, device, seed=3, levels=255, radius=4.0, noise=0.1,
     I = torch.randn((nz, ny, nx), generator=g, device=device, dtype=torch.float32)
     I.mul_(noise).add_(tube.to(torch.float32))
     if levels:
-        I = torch.round(I * levels) / levels
+        I = torch.round(I * levels)                 # integer_values: what a scanner delivers (the caller scales H by 1 / levels^2: same run)
+        if not integer_values:
+            I = I / levels
     ell = (((xs - (nx - 1) / 2.0) / (0.48 * nx)) ** 2 + ((ys - (ny - 1) / 2.0) / (0.48 * ny)) ** 2
            + ((zs - (nz - 1) / 2.0) / (0.48 * nz)) ** 2) <= 1.0
     vm = torch.full((nz, ny, nx), 3, dtype=torch.uint8, device=device)

@@ -245,6 +245,8 @@ def main():
     ap.add_argument('--shape', default='880x880x640')
     ap.add_argument('--levels', type=int, default=255, help='intensity levels of the synthetic volume; 0 = continuous float32 noise')
     ap.add_argument('--H', type=float, default=2.25)
+    ap.add_argument('--integer-values', action='store_true', help='the same volume with integer intensities 0..levels (as a scanner delivers them) and H / levels^2: the same run, '
+                    'with the level of a voxel looked up directly instead of searched for')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--variant', type=int, default=0)
     ap.add_argument('--sweep-blocks', type=int, default=0)
@@ -293,7 +295,9 @@ def main():
         return
 
     from arterynetwork_amd._capi import Session
-    I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels, brain_mask=not args.no_brain_mask)
+    I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels, brain_mask=not args.no_brain_mask, integer_values=args.integer_values)
+    if args.integer_values:
+        args.H = args.H / float(args.levels) ** 2
     torch.cuda.synchronize()
     V = shape[0] * shape[1] * shape[2]
     s = Session(shape, device=local_rank)

@@ -101,6 +101,15 @@ int be_build_levels(VrgBackend*, const VrgCtx& c, double** lev, uint32_t* L) {
     return 0;
 }
 
+bool be_build_lev_map(VrgBackend*, const VrgCtx& c, uint16_t* map, uint32_t span) {
+    std::memset(map, 0xff, (size_t)span * 2);
+    for (uint32_t k = 0; k < c.L; k++) {
+        if (c.lev[k] != std::floor(c.lev[k])) return false;
+        map[(uint32_t)(c.lev[k] - c.lev[0])] = (uint16_t)k;
+    }
+    return true;
+}
+
 void be_build_lev16(VrgBackend*, const VrgCtx& c, uint16_t* dst) {
     std::memset(dst, 0, (size_t)c.PV * 2);
     for_real_voxels(c, [&](uint32_t idx, int, int, int) { dst[idx] = (uint16_t)vrg_level_of(c, vrg_voxel_value(c, idx)); });

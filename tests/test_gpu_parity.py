@@ -489,6 +489,33 @@ def test_skip_excluded_is_bit_identical(lib):
         assert outs[1][3] == dense_bytes_by_definition(outs[1][0], line) <= streamed + 512
 
 
+def test_integer_valued_volume_level_map(lib):
+    """Integer intensities within a span of 65 536 (what scanners deliver): a voxel's level comes from the direct map
+    VrgCtx::lev_map instead of a search through the level table - here with more levels (> 2048) than k_mark_relabel keeps
+    in LDS, so the relabel kernel itself goes through the map.  Against the oracle step by step; and the same volume divided
+    by its quantisation (fractional values: no map) with H scaled accordingly takes the same decisions."""
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session
+    levels = 4095
+    frac, vmap = phantoms.bench_volume((112, 96, 80), seed=11, levels=levels)
+    ints = np.round(frac.astype(np.float64) * levels).astype(np.float32)
+    assert np.array_equal(ints, np.floor(ints)) and len(np.unique(ints)) > 2048
+    H = 2.25 / float(levels) ** 2
+    res, k = parity.run_stepwise(lib, ints, vmap, H, None, 25, density_mode=1, check_hist=True)
+    assert res is not None and k == 25
+    outs = []
+    for data, h in ((ints, H), (ints.astype(np.float64) / levels, 2.25)):
+        s = Session(data.shape, lib=lib)
+        s.set_volume(data); s.set_labels(vmap.astype(np.uint8)); s.init(h)
+        r = s.run(25, 10 ** 9, None)
+        tr = s.trace()
+        outs.append((s.labels(), s.segmented(), r.sweeps, tr['nflip'].copy(), tr['nseg'].copy(), r.ties))
+        s.close()
+    assert outs[0][2] == outs[1][2] == 25 and outs[0][5] == outs[1][5] == 0
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][3], outs[1][3]) and np.array_equal(outs[0][4], outs[1][4])
+
+
 def test_dense_pipe_is_bit_identical(lib):
     """The two-trips-deep dense kernel (option dense_pipe, default 1; fp32 storage with skip_excluded) makes the same
     additions in the same order as k_recount_bits: same trace, bit for bit - and vrg_get_stats names the kernel that ran."""

@@ -18,7 +18,7 @@ shape = tuple(int(v) for v in sys.argv[1].split('x'))
 dense_off = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 samples = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 dev = torch.device('cuda', 0)
-I, vm = phantoms.bench_volume_torch(shape, dev)
+I, vm = phantoms.bench_volume_torch(shape, dev, levels=int(os.environ.get('VRG_STAMP_LEVELS', '255')))   # (env: another quantisation)
 torch.cuda.synchronize()
 s = Session(shape)
 s.set_option('batch', 64)
