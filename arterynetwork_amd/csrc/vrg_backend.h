@@ -66,10 +66,8 @@ void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
 // synchronising; k_order hands a trip it cannot order in one workgroup's LDS back through st->bail.
 enum { VRG_SWEEP_FULL = 1, VRG_SWEEP_NODENSE = 4, VRG_SWEEP_SYNC = 8 };
 void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_reduce_fn cb, void* user);
-// n trips in a row (what the engine enqueues between two looks at the state): the device backend may run their band
-// chains as one persistent launch (option "chain_kernel"); otherwise n x be_sweep_once
+// n trips in a row (what the engine enqueues between two looks at the state)
 void be_sweep_batch(VrgBackend* b, const VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user);
-bool be_has_chain();       // this build contains the persistent band kernel (experimental builds only)
 // Z-slabs: all-reduce and close the dense passes whose slab sums are still waiting (they are reduced a few sweeps at a
 // time); collective - every rank calls it at the same point.  The engine calls it before it reads results.
 void be_dense_flush(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user);

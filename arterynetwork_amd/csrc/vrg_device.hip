@@ -57,9 +57,6 @@ struct VrgBackend {
     int serial = 0;                                   // option "serial_streams": see be_sweep_once
     int skip = 1;                                     // option "skip_excluded": the dense pass does not fetch the intensities of excluded voxels
     int nt_loads = -1;                                // option "nt_loads": -1 = by the size of the pass, 0 / 1 = ordinary / non-temporal loads
-    int chain_kernel = 0;                             // option "chain_kernel": the band chain of a batch of trips as one persistent launch (k_chain)
-    int chain_members = 32;                           // ... workgroups wanted on the elected XCD (8 x as many are launched)
-    uint32_t chain_seq = 0;                           // launches of k_chain so far (selects the launch's control block)
     int dense_pipe = 1;                               // option "dense_pipe": fp32 storage + skip_excluded run the two-trips-deep recount (k_recount_pipe)
     uint64_t pass_bytes = 0;                          // bytes a dense pass fetches, counted at the end of init (0: not known yet)
     uint32_t band_hint = 0;                           // pool slots in use when the engine last read the state (0: unknown)
@@ -742,7 +739,7 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
         for (uint32_t j = g + G; j < nd; j += G) vrg_item_free(c, j);
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 27); }
         if (blockIdx.x == 0 && !c.lvl_scan && nnz > NZ_SORT) {           // (rare: a long level list is sorted in place in global memory)
-            wg_sort_pairs(c.nz_key.p, (uint32_t*)nullptr, nnz, false);
+            wg_sort_pairs(c.nz_key, (uint32_t*)nullptr, nnz, false);
             __syncthreads();
             for (uint32_t j = t; j < nnz; j += T) vrg_item_level(c, j, false);
         }
@@ -821,356 +818,6 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
         }
     }
 }
-
-#if defined(VRG_CHAIN)   // EXPERIMENTAL build only (tools/build_variants.sh): measured slower than the four launches, DESIGN.md section 6
-// ---- the band chain of a whole batch of trips as ONE launch: k_chain (option "chain_kernel") -------------------------
-// Why: the four launches of a trip cost it ~13 of its 32-38 us in seams - a dependent launch boundary (1.3-2.3 us) and then
-// the kernel's first, cold round trips for its arguments, the state and its code (0.3-2.2 us) - and most of the rest is
-// code that runs once per launch and is fetched cold every time (in-kernel stamps, profiles/r03_chain_stamps.log).  One
-// kernel that stays resident for the batch pays the seams as grid barriers and keeps its code in the instruction cache.
-// What makes that correct on this chip (tools/xcdbench.hip, profiles/r03_xcdbench.log):
-//  * The launch PINS ITSELF to one XCD: 8 x CHAIN_MEMBERS workgroups are launched; the first to arrive elects its XCD
-//    (CAS on a word of the launch's control block), a workgroup that reads another HW_REG_XCC_ID leaves at once; the first
-//    barrier also waits until every launched workgroup has started, so the member count is final.  (CU masks place nothing
-//    on this platform.)  Same-XCD is then a hardware fact each member checked for itself: plain stores, drained, are in
-//    that XCD's L2, and every load of band-side data goes past L1 (VrgArr / vrg_load_state) - the litmus in xcdbench runs
-//    exactly this (0 stale words in 1.6e8), and its negative variants (a plain re-load through L1; plain stores across
-//    XCDs) are caught.
-//  * Barriers: one arrival counter + one release word per launch, relaxed agent-scope atomics, no fences (an L1 invalidate
-//    per barrier costs 3.7 us, a barrier 0.7-0.8 us alone, 1.5-2.7 us beside a recount).  The workgroup that arrives LAST
-//    runs the step that needs to see everybody's work - ordering the flips, waiting for the dense pass, closing the sweep -
-//    and then releases the others: three barriers per trip.
-//  * What another stream's kernels read (class bits, unit bitmap: atomics; expected sizes, request / stop words: written
-//    through and drained, vrg_post_apply / vrg_request_dense) does not depend on this kernel ending.
-// A trip that stops or is handed back (VrgState::done / bail) ends the launch; the engine carries on as it does for the
-// four-launch chain, which stays the path of large level tables, host-driven trips and the check variant.
-constexpr int CHAIN_MEMBERS = 32;           // workgroups wanted on the elected XCD (8 x as many are launched)
-constexpr uint32_t CHAIN_MAX_L = NZ_SORT;   // level tables up to this size (memo, touched levels and level values live in LDS)
-enum { CH_ELECT = 0, CH_MEMBERS = 16, CH_STARTED = 32, CH_BAR = 48, CH_REL = 64, CH_FAIL = 80 };   // words of a control block, a cache line apart
-__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u; }   // HW_REG_XCC_ID[3:0]
-__device__ __forceinline__ uint32_t ld_ctl(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// arrive; the last arriver runs `serial` (the whole workgroup calls it) and releases the others.  false: timed out / failed
-template <class F>
-__device__ __forceinline__ bool chain_barrier(uint32_t* ctl, uint32_t n, uint32_t& gen, const VrgCtx& c, F&& serial) {
-    __shared__ int s_role, s_ok;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // everything this wave sent to memory is in L2 ...
-    __syncthreads();                                       // ... and every other wave's of the workgroup
-    ++gen;
-    if (threadIdx.x == 0) {
-        const uint32_t old = __hip_atomic_fetch_add(ctl + CH_BAR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_role = (old + 1u == gen * n) ? 1 : 0;
-        s_ok = 1;
-    }
-    __syncthreads();
-    if (s_role) {
-        serial();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(ctl + CH_REL, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (threadIdx.x == 0) {
-        const unsigned long long t0 = wall_clock64();
-        while (ld_ctl(ctl + CH_REL) < gen) {
-            __builtin_amdgcn_s_sleep(1);
-            if (ld_ctl(ctl + CH_FAIL) || wall_clock64() - t0 > SPIN_LIMIT) {
-                __hip_atomic_store(ctl + CH_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                vrg_store_i32(&c.stg->error, 11);
-                s_ok = 0;
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    return s_ok != 0;
-}
-
-// LDS of a member, by phase (bytes): band: the memo (3 x L doubles) or the touched-level lists | order: keys, record numbers,
-// records | close: the touched levels with their counts; beside them, for the whole launch, the level values
-struct ChainLds {
-    union {
-        struct { double tab[3 * CHAIN_MAX_L]; } band;                                                      // 48 KB
-        struct { double val[CHAIN_MAX_L]; uint32_t cin[CHAIN_MAX_L], cout[CHAIN_MAX_L], cconv[CHAIN_MAX_L]; } nz;   // 40 KB
-        struct { uint64_t key[NF_SMALL]; uint32_t slot[NF_SMALL]; uint32_t rslot[1024], ridx[1024], rlev[1024]; } ord;   // 60 KB
-        struct { uint64_t key[CHAIN_MAX_L]; double val[CHAIN_MAX_L]; uint32_t cin[CHAIN_MAX_L], cout[CHAIN_MAX_L], cconv[CHAIN_MAX_L]; } cl;   // 56 KB
-    } u;
-    double lev[CHAIN_MAX_L];                                                                               // 16 KB
-    VrgState st;
-};
-
-__global__ void __launch_bounds__(TPB) k_chain(VrgCtx cg, uint32_t ntrips, uint32_t small_limit, int dense_on, uint32_t seq) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
-    ChainLds& S = *reinterpret_cast<ChainLds*>(chain_smem);
-    __shared__ uint32_t s_me, s_n, s_go;
-    __shared__ uint32_t s_cnt[3], s_base[3], s_scan[TPB / 64];
-    __shared__ int32_t s_d[2];
-    __shared__ int s_changed, s_serial_go;
-    const uint32_t t = threadIdx.x, lane = t & 63;
-    uint32_t* ctl = cg.chain + (size_t)(seq % VRG_CHAIN_RING) * VRG_CHAIN_BLOCK;
-    // ---- who takes part: the workgroups on the elected XCD
-    if (t == 0) {
-        const uint32_t mine = xcc_id() + 1u;
-        uint32_t expected = 0u;
-        __hip_atomic_compare_exchange_strong(ctl + CH_ELECT, &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t elected = expected ? expected : mine;
-        uint32_t go = elected == mine, me = 0, n = 0;
-        if (go) me = __hip_atomic_fetch_add(ctl + CH_MEMBERS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (a member is counted before it counts as started)
-        __hip_atomic_fetch_add(ctl + CH_STARTED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (go) {
-            const unsigned long long t0 = wall_clock64();
-            while (ld_ctl(ctl + CH_STARTED) < gridDim.x) {
-                __builtin_amdgcn_s_sleep(2);
-                if (wall_clock64() - t0 > SPIN_LIMIT) { vrg_store_i32(&cg.stg->error, 11); go = 0; break; }
-            }
-            n = ld_ctl(ctl + CH_MEMBERS);
-        }
-        s_go = go; s_me = me; s_n = n;
-    }
-    __syncthreads();
-    if (!s_go) return;
-    const uint32_t bid = s_me, nb = s_n;
-    if (bid == 0 && t < VRG_CHAIN_BLOCK) {                 // the control block of a launch half a ring from now (its last user ended long ago)
-        uint32_t* z = cg.chain + (size_t)((seq + VRG_CHAIN_RING / 2) % VRG_CHAIN_RING) * VRG_CHAIN_BLOCK;
-        __hip_atomic_store(z + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // ---- this member's view: the level values in LDS for the whole launch; the state as a snapshot of its own
-    VrgCtx c = cg;
-    for (uint32_t l = t; l < cg.L; l += TPB) S.lev[l] = cg.lev[l];
-    if (!cg.lev16) c.lev = S.lev;
-    c.lev_fast = 1; c.lvl_scan = 1;
-    c.st = &S.st;
-    auto snapshot = [&]() {                                // (all threads; the state was written before the last barrier / launch)
-        __syncthreads();
-        if (t == 0) S.st = vrg_load_state(cg.stg);
-        __syncthreads();
-    };
-    uint8_t* const lab = cg.lab[0];
-    const uint32_t idx_lo = vrg_idx(c, 0, 0, 0), idx_hi = vrg_idx(c, c.nx - 1, c.ny - 1, c.nz - 1);
-    uint32_t gen = 0;
-    for (uint32_t trip = 0; trip < ntrips; trip++) {
-        snapshot();
-        if (S.st.done || S.st.bail) break;                 // (the same for every member)
-        const bool stp = bid == 0 && t == 0 && S.st.iter < S.st.iterMax;
-        if (stp) VRG_STAMP(cg, 40);
-        // ================= decide (k_band): corrections of the sweep before, sign tests, exact densities of its new entries
-        {
-            const VrgState& s = S.st;
-            const bool direct = s.corr && !s.use_tab;
-            if (!direct) {
-                for (uint32_t j = t; j < 3 * c.L; j += TPB) S.u.band.tab[j] = c.tabC[j];
-                __syncthreads();
-                for (uint32_t slot = bid * TPB + t; slot < s.np; slot += nb * TPB)
-                    vrg_item_band(c, s, slot, nullptr, nullptr, nullptr, nullptr, S.u.band.tab, c.L);
-            } else {
-                const uint32_t nnz = min(s.nnz, CHAIN_MAX_L);
-                for (uint32_t j = t; j < nnz; j += TPB) { S.u.nz.val[j] = c.nz_val[j]; S.u.nz.cin[j] = c.nz_cin[j]; S.u.nz.cout[j] = c.nz_cout[j]; S.u.nz.cconv[j] = c.nz_cconv[j]; }
-                __syncthreads();
-                const uint32_t sub = t & (LPE - 1);
-                const uint32_t np_pad = (s.np + (TPB / LPE) - 1) / (TPB / LPE) * (TPB / LPE);      // whole waves stay in the loop together
-                for (uint32_t slot = (bid * TPB + t) / LPE; slot < np_pad; slot += nb * TPB / LPE) {
-                    uint8_t fl = 0; double ip = 0, op = 0, v = 0; uint32_t lev = 0;
-                    const bool live = slot < s.np;
-                    if (live) { fl = c.p_flag[slot]; ip = c.p_ip[slot]; op = c.p_op[slot]; lev = c.p_lev[slot]; }
-                    const bool work = live && (fl & PF_ALIVE) && !(fl & PF_PEND);
-                    if (work) v = c.lev[lev];
-                    double a = 0, bb = 0, d = 0;
-                    if (work)
-                        for (uint32_t j = sub; j < nnz; j += LPE) {
-                            const double k = vrg_kern(c, S.u.nz.val[j] - v);
-                            a += (double)S.u.nz.cin[j] * k; bb += (double)S.u.nz.cout[j] * k; d += (double)S.u.nz.cconv[j] * k;
-                        }
-#pragma unroll
-                    for (int o = LPE / 2; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); bb += __shfl_xor(bb, o, 64); d += __shfl_xor(d, o, 64); }
-                    if (sub == 0 && live) {
-                        if ((fl & PF_ALIVE) && (fl & PF_PEND)) c.p_flag[slot] = (uint8_t)(fl & ~PF_PEND);
-                        else if (work) {
-                            vrg_add_correction(a, bb, d, ip, op);
-                            c.p_ip[slot] = ip; c.p_op[slot] = op;
-                            if (s.iter < s.iterMax)
-                                vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, fl & PF_INNER, ip, op, c.p_key[slot], c.p_idx[slot], lev);
-                        }
-                    }
-                }
-            }
-            if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 41); }
-            // the exact densities of the sweep's new entries: a wave per entry where the table is one batch (<= 512 levels: the
-            // same additions in the same order as a workgroup's wave 0 would make), else a workgroup per entry
-            if (c.L <= 64u * EXQ) exact_wave(c, s, s.nfx, (bid * TPB + t) >> 6, (nb * TPB) >> 6, true);
-            else exact_wg(c, s, s.nfx, bid, nb);
-            if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 42); }
-        }
-        // ================= order the flips (k_order) - the last member to arrive, alone
-        if (!chain_barrier(ctl, nb, gen, c, [&]() {
-                if (t == 0) VRG_STAMP(cg, 50);
-                if (t == 0) S.st = vrg_load_state(cg.stg);           // (the flip count every member bumped)
-                __syncthreads();
-                const VrgState& s = S.st;
-                if (t == 0) {
-                    int go = 1;
-                    const int32_t stop = vrg_stop_test_v(s, c.inc[VC_NIN]);
-                    if (stop || s.error) { c.stg->done = stop ? stop : -1; vrg_close_without_update(c); go = 0; }
-                    else {
-                        const int32_t bail = s.nf > small_limit ? (int32_t)VBAIL_FLIPS : vrg_capacity_test(c, s.nf);
-                        if (bail) { c.stg->bail = bail; vrg_close_without_update(c); go = 0; }
-                    }
-                    s_serial_go = go;
-                }
-                __syncthreads();
-                if (!s_serial_go) return;
-                const uint32_t nf = s.nf;
-                for (uint32_t j = t; j < s.nnz; j += TPB) vrg_item_level_clear(c, j);      // level counters of the sweep before
-                for (uint32_t q = t; q < nf; q += TPB) { S.u.ord.key[q] = c.f_key[q]; S.u.ord.slot[q] = q; }
-                const bool rec_lds = nf <= 1024u;
-                if (rec_lds) for (uint32_t q = t; q < nf; q += TPB) { S.u.ord.rslot[q] = c.flist[q]; S.u.ord.ridx[q] = c.fr_idx[q]; S.u.ord.rlev[q] = c.fr_lev[q]; }
-                __syncthreads();
-                if (t == 0) vrg_open_update(c);
-                wg_sort_pairs(S.u.ord.key, S.u.ord.slot, nf, true);
-                for (uint32_t r = t; r < nf; r += TPB) {
-                    const uint32_t q = S.u.ord.slot[r];
-                    const bool inner = !(S.u.ord.key[r] >> 63);
-                    if (rec_lds) vrg_item_list_rec(c, r, S.u.ord.rslot[q], S.u.ord.ridx[q], S.u.ord.rlev[q], inner);
-                    else vrg_item_list_rec(c, r, c.flist[q], c.fr_idx[q], c.fr_lev[q], inner);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the L / P bits are in place before a neighbour's stencil rows are read)
-                __syncthreads();
-                for (uint32_t r = t; r < nf; r += TPB) vrg_item_prepass(c, r);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                const uint32_t np_ = vrg_load_u32(&c.stg->npend);
-                if (np_) {
-                    for (;;) {
-                        __syncthreads();
-                        if (t == 0) s_changed = 0;
-                        __syncthreads();
-                        for (uint32_t j = t; j < np_; j += TPB) if (vrg_item_fix(c, j) == 2) s_changed = 1;
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __syncthreads();
-                        if (!s_changed) break;
-                    }
-                }
-                if (t == 0) VRG_STAMP(cg, 51);
-            })) break;
-        if (stp) VRG_STAMP(cg, 43);
-        snapshot();
-        if (S.st.done || S.st.bail) break;
-        if (stp) VRG_STAMP(cg, 44);
-        // ================= relabel stencil at the marked voxels (k_mark_relabel)
-        {
-            const uint64_t n = (uint64_t)S.st.nf * 128u;
-            const VrgArr<uint8_t> labv = cg.lab[0];
-            for (uint64_t base = (uint64_t)bid * TPB; base < n; base += (uint64_t)nb * TPB) {      // (a member without items makes no trip: no barrier inside needs it)
-                if (t < 3) s_cnt[t] = 0;
-                if (t < 2) s_d[t] = 0;
-                __syncthreads();
-                const uint64_t i = base + t;
-                const uint32_t r = (uint32_t)(i >> 7), p = (uint32_t)(i & 127u);
-                int64_t m = 0; uint8_t mb = VB_OOB;
-                VrgPre pre;
-                if (i < n && p < 125u) {
-                    m = vrg_mark_pos(c, c.f_idx[r], p);
-                    mb = labv[m];
-                    const int64_t ms = m < (int64_t)idx_lo ? (int64_t)idx_lo : (m > (int64_t)idx_hi ? (int64_t)idx_hi : m);
-                    vrg_preload(c, lab, (uint32_t)ms, pre);
-                }
-                const bool first = vrg_mark_wanted(p, mb) && vrg_mark_set(c, m);
-                const unsigned long long fm = __ballot(first);
-                uint32_t q = 0;
-                if (fm) {
-                    const int leader = __ffsll((long long)fm) - 1;
-                    uint32_t b0 = 0;
-                    if ((int)lane == leader) b0 = vrg_atomic_add(&c.stg->nmk, (uint32_t)__popcll(fm));
-                    q = __shfl(b0, leader, 64) + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
-                }
-                VrgEvent ev; ev.kind = VE_NONE; ev.pend = 0;
-                uint32_t rn = 0, rd = 0, rf = 0;
-                if (first) {
-                    const uint8_t nw = vrg_sweep_core_pre(c, lab, (uint32_t)m, mb, pre, ev);
-                    if (q < c.mcap) { c.mk_idx[q] = (uint32_t)m; c.mk_new[q] = nw; c.mk_old[q] = mb; } else c.stg->error = 4;
-                    if (ev.kind == VE_NEW) rn = atomicAdd(&s_cnt[0], 1u);
-                    if (ev.kind == VE_DIE) rd = atomicAdd(&s_cnt[1], 1u);
-                    if (ev.kind != VE_NONE && ev.kind != VE_DIE && ev.pend) rf = atomicAdd(&s_cnt[2], 1u);
-                    const int di = vrg_ev_dni(ev), dq = vrg_ev_dno(ev);
-                    if (di) atomicAdd(&s_d[0], di);
-                    if (dq) atomicAdd(&s_d[1], dq);
-                }
-                __syncthreads();
-                if (t < 3 && s_cnt[t]) s_base[t] = vrg_atomic_add(t == 0 ? &c.stg->nalloc : t == 1 ? &c.stg->ndead : &c.stg->nfresh, s_cnt[t]);
-                if (t >= 4 && t < 6 && s_d[t - 4]) vrg_atomic_add(t == 4 ? &c.stg->d_ni : &c.stg->d_no, s_d[t - 4]);
-                __syncthreads();
-                if (ev.kind != VE_NONE) vrg_ev_write(c, (uint32_t)m, ev, s_base[0] + rn, s_base[1] + rd, s_base[2] + rf);
-                __syncthreads();
-            }
-        }
-        if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 45); }
-        // ================= wait for the dense pass of two sweeps ago (it reads the class copy this sweep rewrites)
-        if (!chain_barrier(ctl, nb, gen, c, [&]() { if (t == 0 && dense_on) wait_dense_read(c); })) break;
-        if (stp) VRG_STAMP(cg, 46);
-        snapshot();                                        // (the counters the stencil moved: marked voxels, allocations, dead slots)
-        // ================= close the sweep (k_close): labels in place, free list, touched levels, memo
-        uint32_t nmk_apply = 0;
-        bool use_tab = false;
-        {
-            const VrgState& s = S.st;
-            const uint32_t g = bid * TPB + t, G = nb * TPB;
-            const uint32_t nmk = min(s.nmk, c.mcap), nf = s.nf, nd = s.ndead, nalloc = s.nalloc, nc = vrg_catchup_count(c);
-            nmk_apply = nmk;
-            for (uint32_t i = g; i < nmk; i += G) vrg_apply_at(c, i, c.mk_idx[i], c.mk_old[i], c.mk_new[i]);
-            for (uint32_t i = g; i < nc; i += G) vrg_item_catchup(c, i);
-            for (uint32_t r = g; r < nf; r += G) vrg_item_check_flip(c, r);
-            for (uint32_t j = g; j < nd; j += G) vrg_free_entry(c, j, c.dead[j], s.nfree, nalloc);
-            if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 52); }
-            // the touched levels, ascending, by a scan of the per-level counters (every member for itself; member 0 files the list)
-            use_tab = s.tab_ok != 0;
-            if (use_tab || bid == 0) {
-                const uint32_t per = (c.L + TPB - 1) / TPB, l0 = t * per, l1 = min(l0 + per, c.L);
-                uint32_t ci[CHAIN_MAX_L / TPB], co[CHAIN_MAX_L / TPB], cc[CHAIN_MAX_L / TPB], cnt = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < CHAIN_MAX_L / TPB; k++) {
-                    const uint32_t l = l0 + k;
-                    ci[k] = co[k] = cc[k] = 0;
-                    if (k < per && l < l1) { ci[k] = c.dIn[l]; co[k] = c.dOut[l]; cc[k] = c.dConv[l]; }
-                    cnt += (ci[k] | co[k] | cc[k]) ? 1u : 0u;
-                }
-                const uint32_t incl = wave_incl_scan(cnt);
-                __syncthreads();
-                if (lane == 63) s_scan[t >> 6] = incl;
-                __syncthreads();
-                uint32_t base = 0, nnz = 0;
-                for (uint32_t w = 0; w < TPB / 64; w++) { if (w < (t >> 6)) base += s_scan[w]; nnz += s_scan[w]; }
-                uint32_t q = base + incl - cnt;
-#pragma unroll
-                for (uint32_t k = 0; k < CHAIN_MAX_L / TPB; k++)
-                    if (ci[k] | co[k] | cc[k]) { const uint32_t l = l0 + k; S.u.cl.key[q] = l; S.u.cl.val[q] = S.lev[l]; S.u.cl.cin[q] = ci[k]; S.u.cl.cout[q] = co[k]; S.u.cl.cconv[q] = cc[k]; q++; }
-                __syncthreads();
-                if (bid == 0) {
-                    for (uint32_t j = t; j < nnz; j += TPB) { c.nz_key[j] = S.u.cl.key[j]; c.nz_val[j] = S.u.cl.val[j]; c.nz_cin[j] = S.u.cl.cin[j]; c.nz_cout[j] = S.u.cl.cout[j]; c.nz_cconv[j] = S.u.cl.cconv[j]; }
-                    if (t == 0) __hip_atomic_store(&c.stg->nnz, nnz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (use_tab) {                             // the memo: one wave per level
-                    const uint32_t wid = (bid * TPB + t) >> 6, nw = (nb * TPB) >> 6;
-                    for (uint32_t l = wid; l < c.L; l += nw) {
-                        const double v = S.lev[l];
-                        double a = 0, bb = 0, d = 0;
-                        for (uint32_t j = lane; j < nnz; j += 64) {
-                            const double k = vrg_kern(c, S.u.cl.val[j] - v);
-                            a += (double)S.u.cl.cin[j] * k; bb += (double)S.u.cl.cout[j] * k; d += (double)S.u.cl.cconv[j] * k;
-                        }
-                        a = wave_sum(a); bb = wave_sum(bb); d = wave_sum(d);
-                        if (lane == 0) { c.tabC[3 * (size_t)l] = a; c.tabC[3 * (size_t)l + 1] = bb; c.tabC[3 * (size_t)l + 2] = d; }
-                    }
-                }
-            }
-        }
-        if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 47); }
-        // ================= the last member to arrive closes the sweep: expected sizes, request for the dense pass, iterNum += 1
-        if (!chain_barrier(ctl, nb, gen, c, [&]() {
-                if (t == 0) { vrg_post_apply(c, (int64_t)nmk_apply); vrg_request_dense(c); vrg_finalize(c, use_tab); }
-            })) break;
-        if (stp) VRG_STAMP(cg, 48);
-    }
-}
-
-#endif   // VRG_CHAIN
 
 // ---- the same update() as device-wide kernels (host-driven trips: any number of flips) ------------------------
 __global__ void __launch_bounds__(TPB) k_trip_open(VrgCtx c) {   // stop tests and capacity test; opens update() (one workgroup)
@@ -1983,8 +1630,6 @@ VrgBackend* be_create(int device) {
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     VrgBackend* b = new VrgBackend();
     b->device = device;
-    if (const char* e = std::getenv("VRG_CHAIN_KERNEL")) b->chain_kernel = std::atoi(e) != 0;     // (A/B runs of whole test suites)
-    if (const char* e = std::getenv("VRG_CHAIN_MEMBERS")) b->chain_members = std::max(1, std::min(32, std::atoi(e)));   // (<= 1 resident member per CU of an XCD: every launched workgroup must be able to start)
     make_streams(b);
     if (b->err[0]) { be_destroy(b); return nullptr; }
     return b;
@@ -2011,7 +1656,6 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "band_hint") == 0) b->band_hint = (uint32_t)std::min<long long>(std::max<long long>(v, 0), 0x7fffffff);
     if (std::strcmp(name, "direct_hint") == 0) b->direct_hint = v != 0;
     if (std::strcmp(name, "dense_pipe") == 0) b->dense_pipe = (int)v;
-    if (std::strcmp(name, "chain_kernel") == 0) b->chain_kernel = v != 0;
     if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)std::min<long long>(v, NF_SMALL);
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != b->prio_mode) { b->prio_mode = (int)v; make_streams(b); }
 }
@@ -2149,9 +1793,9 @@ void be_init_sort(VrgBackend* b, const VrgCtx& c, uint32_t n_in, uint32_t n_out)
     if (nmax == 0) return;
     uint64_t* kout = nullptr; void* tmp = nullptr; size_t tb = 0;
     HIP_CHECK(hipMalloc(&kout, (size_t)nmax * 8));
-    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, c.init_key, kout, c.init_idx, c.p_idx.p, nmax, 0, 64, b->sa));
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, c.init_key, kout, c.init_idx, c.p_idx, nmax, 0, 64, b->sa));
     HIP_CHECK(hipMalloc(&tmp, tb));
-    if (n_in) HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, c.init_key, kout, c.init_idx, c.p_idx.p, n_in, 0, 64, b->sa));
+    if (n_in) HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, c.init_key, kout, c.init_idx, c.p_idx, n_in, 0, 64, b->sa));
     if (n_out) HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, c.init_key + (c.bcap - n_out), kout, c.init_idx + (c.bcap - n_out),
                                                    c.p_idx + n_in, n_out, 0, 64, b->sa));
     HIP_CHECK(hipStreamSynchronize(b->sa));
@@ -2273,9 +1917,9 @@ static void host_driven_update(VrgBackend* b, const VrgCtx& c, int flags) {
     // the flip list in the reference's order: device-wide sort by (list, key)
     size_t tb = 0;
     if (!need_keys2(b, nf)) { std::snprintf(b->err, sizeof(b->err), "out of device memory (flip sort)"); return; }
-    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, c.f_key.p, b->keys2, c.flist.p, c.f_slot.p, nf, 0, 64, b->sa));
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, c.f_key, b->keys2, c.flist, c.f_slot, nf, 0, 64, b->sa));
     if (!need_tmp(b, tb)) { std::snprintf(b->err, sizeof(b->err), "out of device memory (flip sort)"); return; }
-    HIP_CHECK(rocprim::radix_sort_pairs(b->tmp, tb, c.f_key.p, b->keys2, c.flist.p, c.f_slot.p, nf, 0, 64, b->sa));
+    HIP_CHECK(rocprim::radix_sort_pairs(b->tmp, tb, c.f_key, b->keys2, c.flist, c.f_slot, nf, 0, 64, b->sa));
     k_list<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nf);
     if (flags & VRG_SWEEP_FULL) k_prepass<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nf);
     else k_marks_prepass<<<4 * ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nf);
@@ -2292,9 +1936,9 @@ static void host_driven_update(VrgBackend* b, const VrgCtx& c, int flags) {
     const uint32_t nnz = std::min(s.nnz, c.zcap);
     if (nnz > 1) {                                   // touched levels in ascending order
         if (!need_keys2(b, nnz)) { std::snprintf(b->err, sizeof(b->err), "out of device memory (level sort)"); return; }
-        HIP_CHECK(rocprim::radix_sort_keys(nullptr, tb, c.nz_key.p, b->keys2, nnz, 0, 32, b->sa));
+        HIP_CHECK(rocprim::radix_sort_keys(nullptr, tb, c.nz_key, b->keys2, nnz, 0, 32, b->sa));
         if (!need_tmp(b, tb)) { std::snprintf(b->err, sizeof(b->err), "out of device memory (level sort)"); return; }
-        HIP_CHECK(rocprim::radix_sort_keys(b->tmp, tb, c.nz_key.p, b->keys2, nnz, 0, 32, b->sa));
+        HIP_CHECK(rocprim::radix_sort_keys(b->tmp, tb, c.nz_key, b->keys2, nnz, 0, 32, b->sa));
         HIP_CHECK(hipMemcpyAsync(c.nz_key, b->keys2, (size_t)nnz * 8, hipMemcpyDeviceToDevice, b->sa));
     }
     k_levels<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c, nnz);
@@ -2388,44 +2032,10 @@ static void enqueue_dense(VrgBackend* b, const VrgCtx& c, hipEvent_t e_start, hi
     if (ranks && ++b->dense_pending >= DENSE_GROUP) reduce_staged(b, c, cb, user);
 }
 
-// n trips: as ONE persistent launch of the band chain (k_chain) + the n dense passes, where that kernel applies - small
-// level table, batched trips, sparse relabel -, else trip by trip
-#if !defined(VRG_CHAIN)
-bool be_has_chain() { return false; }
+// n trips in a row: what the engine enqueues between two looks at the state
 void be_sweep_batch(VrgBackend* b, const VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user) {
     for (int i = 0; i < n; i++) be_sweep_once(b, c, flags, ev, cb, user);
 }
-#else
-bool be_has_chain() { return true; }
-bool be_chain_usable(VrgBackend* b, const VrgCtx& c, int flags) {
-    return b->chain_kernel && !(flags & (VRG_SWEEP_SYNC | VRG_SWEEP_FULL)) && c.L <= CHAIN_MAX_L && c.chain != nullptr;
-}
-void be_sweep_batch(VrgBackend* b, const VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user) {
-    if (!be_chain_usable(b, c, flags)) { for (int i = 0; i < n; i++) be_sweep_once(b, c, flags, ev, cb, user); return; }
-    use_device(b);
-    const bool dense = !(flags & VRG_SWEEP_NODENSE);
-    auto take_pair = [&](long long trip, int kind, int ntrips) -> EvPair& {
-        if (b->ev_used == b->ev_pool.size()) { EvPair p; HIP_CHECK(hipEventCreate(&p.a)); HIP_CHECK(hipEventCreate(&p.b)); p.trip = 0; p.kind = 0; p.ntrips = 1; b->ev_pool.push_back(p); }
-        EvPair& p = b->ev_pool[b->ev_used++];
-        p.trip = trip; p.kind = kind; p.ntrips = ntrips;
-        return p;
-    };
-    const int per = b->serial ? 1 : n;                 // (tools that run one kernel at a time: one trip per launch, the host orders the streams)
-    for (int done = 0; done < n; done += per) {
-        const int k = std::min(per, n - done);
-        hipEvent_t e_c0 = nullptr, e_c1 = nullptr;
-        if (ev && ev->chain_enabled > 0) { EvPair& p = take_pair(b->ev_trip + k - 1, 1, k); e_c0 = p.a; e_c1 = p.b; }
-        hipExtLaunchKernelGGL(k_chain, dim3(8 * b->chain_members), dim3(TPB), sizeof(ChainLds), b->sa, e_c0, e_c1, 0, c, (uint32_t)k, b->small_flips, dense ? 1 : 0, b->chain_seq++);
-        for (int i = 0; i < k; i++) {
-            const long long trip = b->ev_trip++;
-            if (!dense) continue;
-            hipEvent_t e_start = nullptr, e_stop = nullptr;
-            if (ev && ev->enabled > 0 && trip % ev->enabled == 0) { EvPair& p = take_pair(trip, 0, 1); e_start = p.a; e_stop = p.b; }
-            enqueue_dense(b, c, e_start, e_stop, cb, user);
-        }
-    }
-}
-#endif   // VRG_CHAIN
 
 void be_dense_flush(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
     use_device(b);

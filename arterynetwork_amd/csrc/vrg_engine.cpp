@@ -74,7 +74,6 @@ template <class T> bool grow(vrg_handle* h, T*& p, size_t keep, size_t n) {
     p = q;
     return true;
 }
-template <class T> bool grow(vrg_handle* h, VrgArr<T>& a, size_t keep, size_t n) { return grow(h, a.p, keep, n); }
 uint64_t pow2_at_least(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
 
 VrgDense get_dense(vrg_handle* h) {     // region sizes as the band side keeps them + the sums of the last dense pass
@@ -177,7 +176,6 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.dn = alloc<VrgDense>(h, 16);                   // own allocation: written by the dense kernel only
     c.counters = alloc<uint32_t>(h, 64);
     c.dbg = alloc<uint64_t>(h, 64);
-    c.chain = alloc<uint32_t>(h, VRG_CHAIN_WORDS);
     c.dn_part = alloc<VrgDense>(h, 16);
     c.dn_ring = alloc<VrgDense>(h, VRG_RING); c.exp_ring = alloc<int64_t>(h, 2 * VRG_RING);
     c.stage_in = alloc<VrgDense>(h, VRG_STAGE); c.stage_out = alloc<VrgDense>(h, VRG_STAGE);
@@ -202,7 +200,6 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     be_fill(be, c.stage_in, 0, VRG_STAGE * sizeof(VrgDense)); be_fill(be, c.stage_out, 0, VRG_STAGE * sizeof(VrgDense));
     be_fill(be, c.counters, 0, 64 * sizeof(uint32_t));
     if (c.dbg) be_fill(be, c.dbg, 0, 64 * sizeof(uint64_t));
-    if (c.chain) be_fill(be, c.chain, 0, VRG_CHAIN_WORDS * sizeof(uint32_t));
     *out = h;
     return VRG_OK;
 }
@@ -228,7 +225,6 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "dense_off") h->dense_off = value != 0;   // measurement aid: band chain alone; re-initialise afterwards
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
     else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads" || n == "dense_pipe") be_set_tuning(h->be, name, value);
-    else if (n == "chain_kernel") { if (value && !be_has_chain()) return fail(h, VRG_E_ARG, "chain_kernel: this build has no persistent band kernel (experimental builds only, tools/build_variants.sh)"); be_set_tuning(h->be, name, value); }
     else if (n == "storage16") h->storage16 = value != 0;      // takes effect at the next vrg_init
     else return fail(h, VRG_E_ARG, "unknown option " + n);
     return VRG_OK;

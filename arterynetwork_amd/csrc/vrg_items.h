@@ -94,7 +94,7 @@ VRG_HD void vrg_or_byte(uint8_t* lab, uint32_t idx, uint8_t bits) {
     vrg_atomic_or(w, (uint32_t)bits << (8 * (idx & 3u)));
 }
 
-// the whole state, every word past L1 (another workgroup of the same launch may have written it)
+// the whole state in one batch of loads
 VRG_HD VrgState vrg_load_state(const VrgState* g) {
     VrgState s;
     uint32_t w[sizeof(VrgState) / 4];
@@ -102,7 +102,7 @@ VRG_HD VrgState vrg_load_state(const VrgState* g) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (unsigned i = 0; i < sizeof(VrgState) / 4; i++) w[i] = vrg_ld(reinterpret_cast<const uint32_t*>(g) + i);
+    for (unsigned i = 0; i < sizeof(VrgState) / 4; i++) w[i] = reinterpret_cast<const uint32_t*>(g)[i];
     __builtin_memcpy(&s, w, sizeof(s));
     return s;
 }

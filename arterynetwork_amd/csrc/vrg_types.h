@@ -27,37 +27,6 @@
 #define VRG_HD inline
 #endif
 
-// ---- band-side arrays: one place that says how they are loaded ---------------------------------------------------------
-// The band-side arrays are written by one workgroup and read by another across the phases of a sweep.  In the product the
-// phases are separate launches, and a kernel boundary makes plain loads see everything: VrgArr<T> is then an ordinary
-// pointer (measured: with every load sent past L1 the four-launch chain is 2 us per sweep SLOWER - label rows and pool
-// fields are re-read by neighbouring threads of a launch).  In the experimental build with the persistent band kernel
-// (-DVRG_CHAIN: k_chain, the phases of a whole batch of sweeps inside ONE launch) a CU's vector L1 is never refreshed by
-// other CUs' stores, so there every LOAD of such an array has to go past L1 (non-temporal load, served by L2) while stores
-// stay plain (L1 is write-through: in L2 once drained).  `a[i]` loads, `a[i] = v` stores, `&a[i]` is the element's address
-// (for atomics), `a + i` a plain pointer.
-template <class T> VRG_HD T vrg_ld(const T* p) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(VRG_CHAIN)
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-template <class T> struct VrgRef {
-    T* p;
-    VRG_HD operator T() const { return vrg_ld(p); }
-    VRG_HD const VrgRef& operator=(T v) const { *p = v; return *this; }
-    VRG_HD const VrgRef& operator=(const VrgRef& o) const { *p = vrg_ld(o.p); return *this; }
-    VRG_HD T* operator&() const { return p; }
-};
-template <class T> struct VrgArr {
-    T* p;
-    template <class I> VRG_HD VrgRef<T> operator[](I i) const { return VrgRef<T>{p + i}; }
-    template <class I> VRG_HD T* operator+(I i) const { return p + i; }
-    VRG_HD operator T*() const { return p; }
-    VRG_HD VrgArr& operator=(T* q) { p = q; return *this; }
-};
-
 enum : uint8_t {
     VB_S = 1, VB_B = 2, VB_X = 4, VB_L = 8, VB_P = 16, VB_OOB = 32, VB_M = 128,
     VB_LABEL = 7
@@ -139,7 +108,6 @@ enum { VG_REQ = 0, VG_STOP = 1 };
 // disagreed with the incremental sizes; VD_NST: entries of the staged all-reduce
 enum { VD_SEQ = 0, VD_ERR = 1, VD_RSEQ = 2, VD_NST = 3 };
 enum { UC_N = 0, UC_LGEN = 1, UC_GEN = 16 };       // VrgCtx::uctl
-enum { VRG_CHAIN_RING = 16, VRG_CHAIN_BLOCK = 96, VRG_CHAIN_WORDS = 16 * 96 };   // VrgCtx::chain: one control block per launch, reused round robin
 enum { VRG_RING = 64, VRG_STAGE = 16 };           // sweeps a recount result / expected size is kept for; slab sums per all-reduce
 
 struct VrgCtx {
@@ -152,7 +120,7 @@ struct VrgCtx {
     const double* I64;         // ... or float64, when the volume has values fp32 cannot hold (then I is null)
     const uint16_t* lev16;     // optional 16-bit storage: level index per voxel (same layout); the dense pass then
                                // streams 2 B instead of 4 B of intensity per voxel (values come from an LDS table)
-    VrgArr<uint8_t> lab[2];           // lab[0]: label bytes, updated in place; lab[1]: scratch of the full-stencil check variant
+    uint8_t* lab[2];           // lab[0]: label bytes, updated in place; lab[1]: scratch of the full-stencil check variant
     // class bits: what the dense pass needs of a label - inner (S) / outer (not S, not excluded) - 2 bits per voxel;
     // lane l of a wave owns dword l of each 1024-voxel unit (its 16 voxels 256*j + 4*l + b), so a unit is one coalesced
     // 256-B request.  TWO copies: the dense pass of sweep k reads clsb[k & 1] while the label write of sweep k+1 already
@@ -171,13 +139,13 @@ struct VrgCtx {
     uint32_t* ulist;
     uint32_t* uctl;            // UC_*: list length, generation the list was built at | generation of the bitmap (own cache line)
     uint32_t mcap;             // capacity of the marked-voxel list and of the class-change lists
-    VrgArr<uint32_t> chg_dw[2];       // per sweep parity: dword index ...
-    VrgArr<uint32_t> chg_x[2];        // ... and xor mask of every class change that sweep made
-    VrgArr<uint32_t> nchg;            // their lengths (2 counters, own allocation)
-    VrgArr<uint32_t> mk_idx;          // marked voxels of this sweep ...
-    VrgArr<uint8_t> mk_new;           // ... and their bytes after it
-    VrgArr<uint8_t> mk_old;           // ... and before it (the class of the old byte is what the apply step compares)
-    VrgArr<uint64_t> stamp;           // (sweep<<32 | flip rank) of a voxel's last listing; seeds: lex index
+    uint32_t* chg_dw[2];       // per sweep parity: dword index ...
+    uint32_t* chg_x[2];        // ... and xor mask of every class change that sweep made
+    uint32_t* nchg;            // their lengths (2 counters, own allocation)
+    uint32_t* mk_idx;          // marked voxels of this sweep ...
+    uint8_t* mk_new;           // ... and their bytes after it
+    uint8_t* mk_old;           // ... and before it (the class of the old byte is what the apply step compares)
+    uint64_t* stamp;           // (sweep<<32 | flip rank) of a voxel's last listing; seeds: lex index
     // intensity levels: sorted distinct values and per-class histograms (:149-150, :249-250)
     uint32_t L;
     const double* lev;
@@ -185,40 +153,40 @@ struct VrgCtx {
     // directly, lev_map[v - lev_min] - ONE load where the binary search through `lev` makes log2(L) dependent ones; null else
     const uint16_t* lev_map;
     double lev_min;
-    VrgArr<int32_t> hin;
-    VrgArr<int32_t> hout;
-    VrgArr<uint32_t> dIn;             // per-level counts of innerAdded / outerAdded / addedPoints (:232-235); zero between sweeps
-    VrgArr<uint32_t> dOut;
-    VrgArr<uint32_t> dConv;
-    VrgArr<uint32_t> ltouch;          // per level: already on this sweep's touched list
+    int32_t* hin;
+    int32_t* hout;
+    uint32_t* dIn;             // per-level counts of innerAdded / outerAdded / addedPoints (:232-235); zero between sweeps
+    uint32_t* dOut;
+    uint32_t* dConv;
+    uint32_t* ltouch;          // per level: already on this sweep's touched list
     uint32_t zcap;             // capacity of the touched-level list (a power of two >= L)
-    VrgArr<uint64_t> nz_key;          // touched levels as sort keys (unordered until the sweep's level sort)
-    VrgArr<double> nz_val;            // ... in ascending order: their values and counts
-    VrgArr<uint32_t> nz_cin; VrgArr<uint32_t> nz_cout; VrgArr<uint32_t> nz_cconv;
-    VrgArr<double> tabC;              // per-level memo of the three corrections (3*L), see VrgState::use_tab
+    uint64_t* nz_key;          // touched levels as sort keys (unordered until the sweep's level sort)
+    double* nz_val;            // ... in ascending order: their values and counts
+    uint32_t* nz_cin; uint32_t* nz_cout; uint32_t* nz_cconv;
+    double* tabC;              // per-level memo of the three corrections (3*L), see VrgState::use_tab
     // band pool, SoA; capacity bcap slots
     uint32_t bcap;
-    VrgArr<uint32_t> p_idx;           // voxel
-    VrgArr<uint32_t> p_lev;           // level index of its intensity
-    VrgArr<double> p_ip;              // innerProb / outerProb (:132-133)
-    VrgArr<double> p_op;
-    VrgArr<uint64_t> p_key;           // list-order key (vrg_items.h)
-    VrgArr<uint8_t> p_flag;           // PF_*
-    VrgArr<uint32_t> vent;            // per voxel: slot of the band entry sitting there (valid while the B bit is set)
-    VrgArr<uint32_t> freel;           // free slots (stack)
-    VrgArr<uint32_t> dead;            // slots that died this sweep (moved onto the free list when the sweep closes)
+    uint32_t* p_idx;           // voxel
+    uint32_t* p_lev;           // level index of its intensity
+    double* p_ip;              // innerProb / outerProb (:132-133)
+    double* p_op;
+    uint64_t* p_key;           // list-order key (vrg_items.h)
+    uint8_t* p_flag;           // PF_*
+    uint32_t* vent;            // per voxel: slot of the band entry sitting there (valid while the B bit is set)
+    uint32_t* freel;           // free slots (stack)
+    uint32_t* dead;            // slots that died this sweep (moved onto the free list when the sweep closes)
     // this sweep's flips
     uint32_t fcap;             // a power of two
-    VrgArr<uint32_t> flist;           // the listed flips as k_band appended them, unordered: slot ...
-    VrgArr<uint64_t> f_key;           // ... sort key (list bit | list-order key) ...
-    VrgArr<uint32_t> fr_idx;          // ... voxel ...
-    VrgArr<uint32_t> fr_lev;          // ... and intensity level (so that ordering the flips needs no look-up through the slot)
-    VrgArr<uint32_t> f_slot;          // flip list in the reference's order (:88): slot ...
-    VrgArr<uint32_t> f_idx;           // ... voxel ...
-    VrgArr<uint32_t> f_lev;           // ... and intensity level of flip r
-    VrgArr<uint8_t> f_res;            // FR_* result of flip r
-    VrgArr<uint32_t> pend;            // ranks of the flip-ins in the skip-rule fix-point
-    VrgArr<uint32_t> fresh;           // slots needing exact densities
+    uint32_t* flist;           // the listed flips as k_band appended them, unordered: slot ...
+    uint64_t* f_key;           // ... sort key (list bit | list-order key) ...
+    uint32_t* fr_idx;          // ... voxel ...
+    uint32_t* fr_lev;          // ... and intensity level (so that ordering the flips needs no look-up through the slot)
+    uint32_t* f_slot;          // flip list in the reference's order (:88): slot ...
+    uint32_t* f_idx;           // ... voxel ...
+    uint32_t* f_lev;           // ... and intensity level of flip r
+    uint8_t* f_res;            // FR_* result of flip r
+    uint32_t* pend;            // ranks of the flip-ins in the skip-rule fix-point
+    uint32_t* fresh;           // slots needing exact densities
     // dense statistics partials (one slot per sweep workgroup)
     uint32_t nstat;
     int64_t* st_nin; int64_t* st_nout; double* st_sin; double* st_sout;
@@ -232,7 +200,7 @@ struct VrgCtx {
     int64_t* exp_ring;         // [2 * VRG_RING] region sizes after sweep k at k % VRG_RING: what dense pass k must reproduce
     VrgDense* stage_in;        // [VRG_STAGE] partials of the recounts not yet closed, packed for ONE all-reduce ...
     VrgDense* stage_out;       // ... and their totals
-    VrgArr<int64_t> inc;              // band side (own cache line): region sizes kept by increments as labels are applied -
+    int64_t* inc;              // band side (own cache line): region sizes kept by increments as labels are applied -
                                // what the decisions and stop tests read - and the sweep number of the last apply
     int64_t* dctl;             // dense side (own cache line): dense passes closed since init
     int64_t* gate;             // band -> dense hand-off words (own cache line), VG_*
@@ -243,7 +211,6 @@ struct VrgCtx {
     int32_t lev_fast;          // 1: a voxel's level index is cheap here (16-bit storage, or the level table in LDS): a flip's
                                //    level is looked up from its intensity instead of fetched through its rank
     uint32_t* counters;        // arrival tickets of the last-workgroup reductions (zero between launches)
-    uint32_t* chain;           // control blocks of the persistent band kernel (k_chain): election, members, barrier words
     uint64_t* dbg;             // diagnostic build only (-DVRG_STAMPS): in-kernel time stamps of the band chain, see tools/chain_stamps.py
     VrgTrace* trace;
     uint32_t trace_cap;

@@ -243,17 +243,16 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c0, int flags, VrgEvents*, be_re
         s.nnz = 0;
         for (uint32_t l = 0; l < c.L; l++) if (c.dIn[l] | c.dOut[l] | c.dConv[l]) c.nz_key[s.nnz++] = l;
     }
-    std::sort(c.nz_key.p, c.nz_key.p + s.nnz);
+    std::sort(c.nz_key, c.nz_key + s.nnz);
     for (uint32_t j = 0; j < s.nnz; j++) vrg_item_level(c, j, (s.iter & 1) != 0);     // alternate: cleared at once / by the next update()
     const bool use_tab = s.tab_ok != 0;          // either way the same sums; the model alternates with the band size
     if (use_tab)
         for (uint32_t l = 0; l < c.L; l++)
-            vrg_corrections(c, s.nnz, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, c.lev[l], c.tabC.p[3 * (size_t)l], c.tabC.p[3 * (size_t)l + 1], c.tabC.p[3 * (size_t)l + 2]);
+            vrg_corrections(c, s.nnz, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, c.lev[l], c.tabC[3 * (size_t)l], c.tabC[3 * (size_t)l + 1], c.tabC[3 * (size_t)l + 2]);
     vrg_finalize(c, use_tab);
 }
 
 void be_events_collect(VrgBackend*, VrgEvents*, long long) {}
-bool be_has_chain() { return false; }
 void be_sweep_batch(VrgBackend* b, const VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user) { for (int i = 0; i < n; i++) be_sweep_once(b, c, flags, ev, cb, user); }
 void be_dense_info(VrgBackend*, const VrgCtx& c, int64_t out[5]) { out[0] = 0; out[1] = c.lev16 ? 1 : (c.I ? 0 : 2); out[2] = 1; out[3] = 1; out[4] = 0; }
 void be_dense_flush(VrgBackend*, const VrgCtx&, be_reduce_fn, void*) {}

@@ -3,8 +3,7 @@
 (csrc/libvrg_hip_stamps.so = the product sources compiled with -DVRG_STAMPS; in the product build no stamp executes).
 
 usage: VRG_HIP_LIB=arterynetwork_amd/csrc/libvrg_hip_stamps.so python tools/chain_stamps.py SHAPE [dense_off] [samples]
-       VRG_HIP_LIB=.../libvrg_hip_chain.so VRG_CHAIN_KERNEL=1 ...   the persistent band kernel of the experimental build
-(both libraries: tools/build_variants.sh)
+(the library: tools/build_stamps.sh)
 Prints, averaged over `samples` sweeps (each read after a run of 3 more sweeps), the stamps of the LAST sweep relative to
 k_band's entry (us).  dense_off = 1: the band chain alone (no recount beside it)."""
 import ctypes as C, os, sys
@@ -33,10 +32,6 @@ NAMES = {0: 'k_band entry (wg 0)', 1: 'k_band state loaded', 2: 'k_band pool wg 
          24: 'k_close entry (wg 0)', 25: 'k_close state loaded', 26: 'k_close dense wait over', 27: 'k_close apply done (wg 0)',
          32: 'k_close first memo wg entry', 33: 'k_close memo wg levels sorted', 34: 'k_close memo wg done',
          28: 'k_close last ticket taken', 29: 'k_close finalize done'}
-if os.environ.get('VRG_CHAIN_KERNEL') == '1':
-    NAMES = {40: 'trip start (member 0, state snapshot taken)', 41: 'decide: pool slots done', 42: 'decide: exact densities done', 50: 'order: last arriver starts',
-             51: 'order: done', 43: 'barrier 1 passed (member 0)', 44: 'snapshot 2 taken', 45: 'stencil done (member 0)', 46: 'barrier 2 passed (dense wait)',
-             52: 'close: apply done (member 0)', 47: 'close: memo done (member 0)', 48: 'barrier 3 passed (sweep closed)'}
 acc = {k: [] for k in NAMES}
 period = []
 buf = (C.c_uint64 * 64)()
@@ -48,10 +43,10 @@ for _ in range(samples):
         done = 0
     done += s.run(done + 48, 10 ** 15, None).sweeps        # whole batches: the last sweep's stamps are of a chain in steady state
     s._check(s.lib.debug_stamps(s._h, buf))
-    t0 = buf[40] if os.environ.get('VRG_CHAIN_KERNEL') == '1' else buf[0]
+    t0 = buf[0]
     if not t0:
         raise SystemExit('no stamps: not the -DVRG_STAMPS build (set VRG_HIP_LIB)')
-    if buf[6] and dense_off and not os.environ.get('VRG_CHAIN_KERNEL') == '1':      # (beside a dense pass the stamp of the sweep before is read stale more often than not)
+    if buf[6] and dense_off:      # (beside a dense pass the stamp of the sweep before is read stale more often than not)
         period.append((t0 - buf[6]) * 0.01)
     for k in NAMES:
         if buf[k] >= t0:
