@@ -32,6 +32,75 @@ def sphere():
     return volume, valueMap
 
 
+def _salted(volume, valueMap, p, seed):
+    """Salt noise on a binary / few-level integer volume: a fraction p of the voxels (never a seed) is set to the top level."""
+    rng = np.random.default_rng(seed)
+    salt = (rng.random(volume.shape) < p) & (valueMap != 0)
+    out = volume.copy()
+    out[salt] = volume.max()
+    return out, valueMap
+
+
+def straight_line_salt(p=0.05, seed=41):
+    """The reference's straight-line KAT (:284-289) cropped to 30x30x60, with 5 % salt noise (integer volume)."""
+    volume = np.zeros((30, 30, 60), dtype=int)
+    volume[12:14, 12:14, 10:30] = 1
+    valueMap = np.full(volume.shape, 3)
+    valueMap[12:14, 12:14, 12:15] = 0
+    return _salted(volume, valueMap, p, seed)
+
+
+def sphere_salt(p=0.05, seed=42):
+    """The reference's sphere KAT (:300-305) at 30^3 / radius 7, with 5 % salt noise (integer volume)."""
+    x, y, z = np.mgrid[:30, :30, :30]
+    volume = ((x - 15) ** 2 + (y - 15) ** 2 + (z - 15) ** 2 <= 49).astype(int)
+    valueMap = np.full(volume.shape, 3)
+    valueMap[15:17, 15:17, 15:17] = 0
+    return _salted(volume, valueMap, p, seed)
+
+
+def two_touching_tubes():
+    """Binary volume: two straight tubes (radius 2.5) along x and along y that touch where they cross; seeds in the first."""
+    n = 36
+    x, y, z = np.mgrid[:n, :n, :n]
+    t1 = ((y - 14) ** 2 + (z - 16) ** 2 <= 6.25) & (x >= 3) & (x < 33)
+    t2 = ((x - 20) ** 2 + (z - 20) ** 2 <= 6.25) & (y >= 3) & (y < 33)
+    volume = (t1 | t2).astype(int)
+    valueMap = np.full(volume.shape, 3)
+    valueMap[t1 & (x < 6)] = 0
+    return volume, valueMap
+
+
+def torus():
+    """Binary torus (R = 11, r = 3) in a 36x36x16 volume; seeds = a short arc of it."""
+    nx, ny, nz = 36, 36, 16
+    x, y, z = np.mgrid[:nx, :ny, :nz]
+    rho = np.sqrt((x - 17.5) ** 2 + (y - 17.5) ** 2)
+    tor = (rho - 11.0) ** 2 + (z - 7.5) ** 2 <= 9.0
+    volume = tor.astype(int)
+    valueMap = np.full(volume.shape, 3)
+    valueMap[tor & (x > 26) & (np.abs(y - 17.5) < 2)] = 0
+    return volume, valueMap
+
+
+def three_level(seed=43):
+    """Three integer levels: background 0, a tissue ellipsoid 1, a vessel tube 2 inside it, with 3 % of the voxels moved
+    one level up or down; excluded (4) outside a larger ellipsoid; seeds = the first planes of the tube."""
+    nx, ny, nz = 40, 32, 24
+    x, y, z = np.mgrid[:nx, :ny, :nz]
+    tissue = ((x - 19.5) / 17.0) ** 2 + ((y - 15.5) / 13.0) ** 2 + ((z - 11.5) / 9.0) ** 2 <= 1.0
+    cy = 15.5 + 5.0 * np.sin(2 * np.pi * x / nx)
+    tube = ((y - cy) ** 2 + (z - 11.5) ** 2 <= 6.25) & (x >= 4) & (x < 36)
+    volume = tissue.astype(int) + tube.astype(int)
+    rng = np.random.default_rng(seed)
+    u = rng.random(volume.shape)
+    volume = np.clip(volume + (u < 0.015).astype(int) - (u > 0.985).astype(int), 0, 2)
+    valueMap = np.full(volume.shape, 3)
+    valueMap[((x - 19.5) / 19.0) ** 2 + ((y - 15.5) / 15.0) ** 2 + ((z - 11.5) / 11.0) ** 2 > 1.0] = 4
+    valueMap[tube & (x < 7)] = 0
+    return volume, valueMap
+
+
 def tube_phantom(shape=(128, 128, 64), radius=3.5, noise=0.1, seed=2024,
                  seed_planes=4, amp_y=20.0, amp_z=8.0, levels=None,
                  brain_mask=False, dtype=np.float64, noise_dtype=np.float64):

@@ -47,11 +47,8 @@ def refine(baseFolder, dataName='brainVolume.nii.gz', seedName='vesselVolumeMask
     brainMask = None
     if brainMaskName and os.path.exists(os.path.join(baseFolder, brainMaskName)):
         brainMask, _ = loadVolume(baseFolder, brainMaskName)
-    if dataArray.dtype.kind == 'f' and dataArray.dtype != np.float32:
-        f32 = dataArray.astype(np.float32)
-        if not np.array_equal(f32, dataArray):
-            raise ValueError('intensities are not exactly representable in float32; quantise or rescale the volume first')
-        dataArray = f32
+    # (any dtype goes through as it is: the library keeps a volume whose values float32 cannot hold - e.g. a NIfTI with a
+    # scl_slope, which loadVolume returns as float64 - as float64 on the device, include/vrg.h vrg_set_volume)
     valueMap = build_value_map(dataArray, seedMask, brainMask, exclude_below)
     if maxSegmentSize is None:
         maxSegmentSize = int(dataArray.size) + 1

@@ -86,7 +86,8 @@ def bench_slabs(shape, args, dev, rank, world, roofline, configure, load_traffic
     import torch
     import torch.distributed as dist
     from . import phantoms
-    I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels, brain_mask=not args.no_brain_mask)
+    I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels, brain_mask=not args.no_brain_mask,
+                                        integer_values=getattr(args, 'integer_values', False))   # (H already scaled by bench.main)
     torch.cuda.synchronize()
     V = shape[0] * shape[1] * shape[2]
     s = make_slab_session(shape, rank, world, device=dev.index, reduce='rccl-always')

@@ -40,8 +40,9 @@ def variationalRegionGrowing(dataArray, valueMap, H=2.25, maxSegmentSize=5000, *
     Parameters
     ----------
     dataArray : ndarray
-        The data volume to which the algorithm is applied (3-D; values must be exactly
-        representable in float32 - integer-valued or float32-valued data are).
+        The data volume to which the algorithm is applied (3-D, any numeric dtype).  Kept on the device as
+        float32 when every value is exactly representable in float32 (integer-valued and float32 data are),
+        as float64 otherwise; the arithmetic is float64 either way.
     valueMap : ndarray
         Initial settings, same shape: 0: inside (seed), 3: outside, 4: excluded.
         Mutated in place and returned, like the reference does.
@@ -88,8 +89,9 @@ def variationalRegionGrowing(dataArray, valueMap, H=2.25, maxSegmentSize=5000, *
                           'region): the reference decides those by the rounding of np.sum, so the labels may differ from its '
                           'at the voxels concerned'.format(r.ties), RuntimeWarning, stacklevel=2)
         if r.near_ties and dataArray.dtype == np.float32:
-            warnings.warn('{} sign test(s) had a relative margin below 4e-6: for float32 dataArray the reference computes in '
-                          'float32 and may decide those differently (this library computes in float64)'.format(r.near_ties),
+            warnings.warn('{} sign test(s) had a relative margin below 2e-5: for float32 dataArray the reference computes in '
+                          'float32 and may decide those differently (this library computes in float64); an indicator, not a '
+                          'certificate'.format(r.near_ties),
                           RuntimeWarning, stacklevel=2)
         segmented = s.segmented()
         s.labels(out=valueMap)               # in place, caller's dtype

@@ -119,6 +119,17 @@ def roofline(shape, planes, kern_ms, launches, traffic, storage16=False, dense_b
     return out
 
 
+def host_memory_available_gb():
+    """MemAvailable of /proc/meminfo (no third-party module)."""
+    try:
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable:'):
+                return int(line.split()[1]) / 2 ** 20
+    except Exception:
+        pass
+    return 0.0
+
+
 def cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
@@ -137,11 +148,10 @@ def cpu_baseline(I_t, vm_t, H, levels_note, min_free_gb=48.0, crop_vox=70e6):
     than it sees), then the best one again for >= 20 sweeps: `value` is THAT run's own rate, so it can never sit far below
     `threads_tried`.  The sweeps the oracle made are then repeated by the HIP path on the same volume and compared
     (labels, segmented order, integer trace): `parity`.  Outside the timed region."""
-    import psutil
     from oracle import vrg_oracle as O
     from arterynetwork_amd._capi import Session
     nx, ny, nz = I_t.shape
-    free_gb = psutil.virtual_memory().available / 2 ** 30
+    free_gb = host_memory_available_gb()
     whole = nx * ny * nz <= crop_vox or free_gb >= min_free_gb
     if whole:
         cx, cyy, czz, y0, z0 = nx, ny, nz, 0, 0
@@ -279,6 +289,10 @@ def main():
     dev = torch.device('cuda', local_rank)
     from arterynetwork_amd import phantoms
 
+    if args.integer_values:                                 # (both paths: the same run as the fractional volume with H / levels^2)
+        if not args.levels:
+            raise SystemExit('--integer-values needs --levels > 0')
+        args.H = args.H / float(args.levels) ** 2
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         from arterynetwork_amd import slabs
@@ -296,8 +310,6 @@ def main():
 
     from arterynetwork_amd._capi import Session
     I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels, brain_mask=not args.no_brain_mask, integer_values=args.integer_values)
-    if args.integer_values:
-        args.H = args.H / float(args.levels) ** 2
     torch.cuda.synchronize()
     V = shape[0] * shape[1] * shape[2]
     s = Session(shape, device=local_rank)

@@ -58,8 +58,10 @@ typedef struct {
     int64_t ties;             /* sign tests (:87) of this call whose two sides agreed to a relative 1e-11, or that divided by an
                                  empty region: the reference decides those by the rounding of np.sum's pairwise order, which
                                  no regrouped summation reproduces - labels are bit-exact unless ties > 0 */
-    int64_t near_ties;        /* ... whose relative margin was below 4e-6: decisions the reference's float32 arithmetic
-                                 (float32 dataArray under numpy 2) could make differently; harmless for float64 / integer input */
+    int64_t near_ties;        /* ... whose relative margin was below 2e-5 (twice the float tolerance of 1e-5): a heuristic
+                                 indicator of decisions the reference's float32 arithmetic (float32 dataArray under numpy 2) or a
+                                 differently ordered / binned summation could make differently.  near_ties == 0 does not
+                                 certify label agreement; it says no decision was closer than that */
 } vrg_result;
 
 typedef struct {              /* one record per update() call; index 0 = init mode (:129-155) */

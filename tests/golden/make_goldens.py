@@ -183,6 +183,14 @@ def cases():
                                 run=dict(max_sweeps=30), full=True, store_inputs=True, cast=np.float32)
     c['adv_scattered_f32'] = dict(gen=P.scattered_seeds, kw={}, run=dict(max_sweeps=40), full=True, store_inputs=True,
                                   cast=np.float32)
+    # the reference's own input class (:284-314 are binary integer volumes): binary / few-level integer fixtures, default H.
+    # Exact ties of the sign test (:87) are at home here (proportional class histograms): tests/test_gpu_parity.py::
+    # test_integer_class_goldens compares up to the first reported tie and records how often they occur.
+    c['int_line_salt'] = dict(gen=P.straight_line_salt, kw={}, run=dict(max_sweeps=40), full=True, store_inputs=True)
+    c['int_sphere_salt'] = dict(gen=P.sphere_salt, kw={}, run=dict(max_sweeps=40), full=True, store_inputs=True)
+    c['int_two_tubes'] = dict(gen=P.two_touching_tubes, kw={}, run=dict(max_sweeps=60), full=True, store_inputs=True)
+    c['int_torus'] = dict(gen=P.torus, kw={}, run=dict(max_sweeps=60), full=True, store_inputs=True)
+    c['int_three_level'] = dict(gen=P.three_level, kw={}, run=dict(max_sweeps=40), full=True, store_inputs=True)
     # size stop + border seeds: maxSegmentSize reached, seeds on the volume faces
     c['border_size_stop'] = dict(gen=P.noise_volume, kw=dict(shape=(10, 9, 8), seed=300, p_seed=0.5, p_excl=0.1),
                                  run=dict(maxSegmentSize=300), full=True, store_inputs=True)

@@ -11,7 +11,7 @@ tests/golden/make_goldens.py running the real reference on np.float32 arrays; th
     carry absolute error);
   * labels after every update() call, both band list orders, `segmented` order, the integer trace: identical - a
     float32 rounding difference can only change a decision whose relative margin is below ~1e-6, and the product
-    counts those (vrg_result.near_ties: sign tests with a relative margin below 4e-6) so that a caller knows when the
+    counts those (vrg_result.near_ties: sign tests with a relative margin below 2e-5) so that a caller knows when the
     reference's float32 arithmetic might have decided differently.  On these fixtures the count is reported and the
     labels are asserted identical.
 

@@ -136,6 +136,59 @@ def test_random_volumes_in_one_call(lib):
     assert done >= 110, 'too many cases cut short by an exact tie: {} of 120 completed'.format(done)
 
 
+def test_integer_class_goldens_and_tie_rate(lib, golden_loader):
+    """The reference's own input class (:284-314: binary integer volumes).  (1) The seven integer fixtures the REAL reference
+    produced (the two KATs, KAT shapes with 5 % salt noise, two touching tubes, a torus, a three-level phantom): whole run
+    in one call, ties == 0, every label / list order / count equal to the reference's record.  (2) How often exact ties
+    occur on this class: random binary / few-level integer volumes, stepwise against the oracle; a case is cut at its first
+    tie (parity.run_stepwise) - the rate goes to gpurun_out/ties_integer.json (committed as profiles/r04_ties_integer.json)."""
+    import json
+    import os
+    from arterynetwork_amd._capi import Session
+    from conftest import ROOT
+    rep = {'fixtures': {}, 'random': {}}
+    for name in ('kat_straight_line', 'kat_sphere', 'int_line_salt', 'int_sphere_salt', 'int_two_tubes', 'int_torus', 'int_three_level'):
+        g = golden_loader(name)
+        data, vmap = g.inputs()
+        z = g.z
+        s = Session(g.shape, lib=lib)
+        s.set_volume(data.astype(np.int16)); s.set_labels(vmap); s.init(g.H)
+        r = s.run(g.max_sweeps if g.max_sweeps >= 0 else 200, g.maxSegmentSize, None)
+        assert r.ties == 0, (name, r.ties)
+        assert np.array_equal(s.labels(), z['final_labels']), name
+        assert np.array_equal(parity.lex_of(s.segmented(), g.shape), z['final_segmented']), name
+        tr = s.trace()
+        for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no'):
+            assert np.array_equal(tr[f], z[f]), (name, f)
+        k = len(z['snap_iters']) - 1
+        _, gi, go = g.snapshot(k)
+        assert np.array_equal(parity.lex_of(s.band(0)[0], g.shape), gi) and np.array_equal(parity.lex_of(s.band(1)[0], g.shape), go), name
+        rep['fixtures'][name] = {'sweeps': int(r.sweeps), 'ties': int(r.ties), 'near_ties': int(r.near_ties), 'levels': int(len(np.unique(data)))}
+        s.close()
+    for levels in (2, 3, 5):
+        cut = sweeps = 0
+        n = 60
+        for sd in range(n):
+            rng = np.random.default_rng(7000 + 100 * levels + sd)
+            shape = tuple(int(v) for v in rng.integers(6, 20, size=3))
+            blob = rng.random(shape) < 0.35
+            I = np.where(blob, levels - 1, 0) + (rng.random(shape) < 0.1) * rng.integers(0, levels, size=shape)
+            I = np.clip(I, 0, levels - 1).astype(np.float64)
+            vm = np.full(shape, 3, dtype=np.int64)
+            vm[(rng.random(shape) < 0.08) & blob] = 0
+            vm[rng.random(shape) > 0.85] = 4
+            if not (vm == 0).any():
+                vm.reshape(-1)[int(np.argmax(I.reshape(-1)))] = 0
+            res, k = parity.run_stepwise(lib, I, vm, 2.25, None, 30, density_mode=1, check_hist=True)
+            sweeps += k
+            cut += res is None
+        rep['random']['{}_levels'.format(levels)] = {'volumes': n, 'cut_short_by_a_tie': int(cut), 'sweeps_compared': int(sweeps)}
+    d = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(d):
+        json.dump(rep, open(os.path.join(d, 'ties_integer.json'), 'w'), indent=1)
+    print(json.dumps(rep))
+
+
 def test_skip_rule_closure_is_race_free(lib):
     """Regression: the skip-rule fix-point is computed by every workgroup of k_relabel for itself.  With a wrong
     termination test one workgroup could stop before another one's write became visible; this case then failed in
@@ -367,6 +420,41 @@ def test_refine_nifti_in_nifti_out(tmp_path):
     assert np.array_equal(vm_o, vmap)
     seg_o, segMap_o, _ = O.variationalRegionGrowing(data.astype(np.float64), vm_o, maxSegmentSize=data.size + 1,
                                                     iterMax=30, maxTime=-1.0, density_mode=1, quiet=True)
+    assert np.array_equal(out, segMap_o) and np.array_equal(seg, seg_o) and np.array_equal(vm, vm_o)
+    assert out.sum() > (vmap == 0).sum()
+
+
+def test_refine_scaled_nifti_goes_through_as_float64(tmp_path):
+    """A NIfTI with scl_slope / scl_inter (hand-written here: int16 storage, value = 0.1 * stored + 0.03) loads as float64
+    with values float32 cannot hold; refine() hands it on as it is - the C-ABI keeps such a volume as float64
+    (vrg_set_volume) - and the result equals the oracle's on the same float64 array."""
+    import struct
+    from arterynetwork_amd import nifti, phantoms
+    from arterynetwork_amd.refine import refine, build_value_map
+    from oracle import vrg_oracle as O
+    data, vmap = phantoms.tube_phantom(shape=(40, 36, 24), radius=3.0, seed=9, seed_planes=3, amp_y=6.0, amp_z=3.0,
+                                       levels=24, brain_mask=True, dtype=np.float32)
+    stored = np.round(data * 24).astype(np.int16)                     # integer levels 0..24 (and noise below / above)
+    hdr = bytearray(352)
+    struct.pack_into('<i', hdr, 0, 348)
+    struct.pack_into('<8h', hdr, 40, 3, *stored.shape, 1, 1, 1, 1)
+    struct.pack_into('<2h', hdr, 70, 4, 16)                           # DT_INT16
+    struct.pack_into('<8f', hdr, 76, 1.0, 0.5, 0.5, 0.5, 0, 0, 0, 0)
+    struct.pack_into('<3f', hdr, 108, 352.0, 0.1, 0.03)               # vox_offset, scl_slope, scl_inter
+    struct.pack_into('<2h', hdr, 252, 0, 1)                           # sform
+    struct.pack_into('<12f', hdr, 280, 0.5, 0, 0, -9.0, 0, 0.5, 0, -8.0, 0, 0, 0.5, 2.0)
+    hdr[344:348] = b'n+1\x00'
+    (tmp_path / 'brainVolume.nii').write_bytes(bytes(hdr) + stored.astype('<i2').tobytes(order='F'))
+    aff = np.array([[0.5, 0, 0, -9.0], [0, 0.5, 0, -8.0], [0, 0, 0.5, 2.0], [0, 0, 0, 1.0]])
+    nifti.saveVolume(vmap == 0, aff, str(tmp_path / 'vesselVolumeMask.nii.gz'))
+    nifti.saveVolume(vmap != 4, aff, str(tmp_path / 'brainVolumeMask.nii.gz'))
+    vol, _ = nifti.loadVolume(str(tmp_path), 'brainVolume.nii')
+    assert vol.dtype == np.float64 and not np.array_equal(vol.astype(np.float32).astype(np.float64), vol)
+    seg, segMap, vm = refine(str(tmp_path), dataName='brainVolume.nii', H=20.0, iterMax=25, quiet=True)
+    out, _ = nifti.loadVolume(str(tmp_path), 'vesselVolumeMaskRefined.nii.gz')
+    vm_o = build_value_map(vol, vmap == 0, vmap != 4).astype(np.int64)
+    seg_o, segMap_o, _ = O.variationalRegionGrowing(np.ascontiguousarray(vol), vm_o, H=20.0, maxSegmentSize=vol.size + 1, iterMax=25,
+                                                    maxTime=-1.0, density_mode=1, quiet=True)
     assert np.array_equal(out, segMap_o) and np.array_equal(seg, seg_o) and np.array_equal(vm, vm_o)
     assert out.sum() > (vmap == 0).sum()
 
