@@ -48,6 +48,8 @@ int be_build_levels(VrgBackend* b, const VrgCtx& c, double** lev, uint32_t* L);
 // map[v - lev[0]] = level index for a level table of integers (true), or false when a level is not an integer; `map` holds
 // lev[L-1] - lev[0] + 1 entries
 bool be_build_lev_map(VrgBackend* b, const VrgCtx& c, uint16_t* map, uint32_t span);
+// ktab[a * L + b] = vrg_kern(lev[b] - lev[a]) for every pair of levels (L <= VRG_KTAB_LEVELS; c.H, c.A set)
+void be_build_ktab(VrgBackend* b, const VrgCtx& c, double* ktab);
 // 16-bit storage: level index of every voxel (after be_build_levels), padded layout
 void be_build_lev16(VrgBackend* b, const VrgCtx& c, uint16_t* dst);
 
@@ -64,7 +66,9 @@ void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
 //                           but runs update() with device-wide kernels and sorts - any number of flips
 // Without VRG_SWEEP_SYNC the trip is four launches (k_band, k_order, k_mark_relabel, k_close) and is enqueued without
 // synchronising; k_order hands a trip it cannot order in one workgroup's LDS back through st->bail.
-enum { VRG_SWEEP_FULL = 1, VRG_SWEEP_NODENSE = 4, VRG_SWEEP_SYNC = 8 };
+//          VRG_SWEEP_FUSED  update() as ONE launch (k_sweep, vrg_items.h "fused sweep"): sweeps with at most be_fuse_limit()
+//                           flips; a sweep with more is handed back (VBAIL_FUSE) and the engine repeats the trip unfused
+enum { VRG_SWEEP_FULL = 1, VRG_SWEEP_NODENSE = 4, VRG_SWEEP_SYNC = 8, VRG_SWEEP_FUSED = 16 };
 void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_reduce_fn cb, void* user);
 // n trips in a row (what the engine enqueues between two looks at the state)
 void be_sweep_batch(VrgBackend* b, const VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user);
@@ -76,6 +80,11 @@ void be_dense_flush(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
 bool be_wants_sync(VrgBackend* b, const VrgCtx& c);
 // flips one workgroup takes on (k_order); more -> VBAIL_FLIPS
 uint32_t be_small_flip_limit(VrgBackend* b);
+// fused trips: flips per sweep they take (more -> VBAIL_FUSE), whether this volume can run them at all, and what has to
+// happen when the engine switches to them after trips of another kind (the stream is idle then)
+uint32_t be_fuse_limit(VrgBackend* b);
+bool be_fuse_ok(VrgBackend* b, const VrgCtx& c);
+void be_fuse_enter(VrgBackend* b, const VrgCtx& c);
 
 // RCCL communicator for the per-sweep all-reduce of the slab statistics (device backend only)
 int be_comm_unique_id(void* id128);

@@ -59,6 +59,9 @@ struct VrgBackend {
     int nt_loads = -1;                                // option "nt_loads": -1 = by the size of the pass, 0 / 1 = ordinary / non-temporal loads
     int dense_pipe = 1;                               // option "dense_pipe": fp32 storage + skip_excluded run the two-trips-deep recount (k_recount_pipe)
     uint64_t pass_bytes = 0;                          // bytes a dense pass fetches, counted at the end of init (0: not known yet)
+    bool fused_memo = false;                          // ... and it kept the per-level memo (k_memo)
+    bool fused_prev = false;                          // the trip enqueued last was a fused one: the dense pass of the sweep it applied is not enqueued yet
+                                                      // (its request comes from THIS trip's k_band; if that trip stopped or handed itself back, the stop word makes the gate leave)
     uint32_t band_hint = 0;                           // pool slots in use when the engine last read the state (0: unknown)
     int direct_hint = 1;                              // ... and whether corrections are then evaluated entry by entry (8 lanes per slot)
 };
@@ -227,39 +230,119 @@ __device__ void exact_wg(const VrgCtx& c, const VrgState& s, uint32_t nfresh, ui
         __syncthreads();
     }
 }
+// band side, before the labels of sweep k are written into class copy k & 1: recount number `need` (= k - 2) has read that copy.
+// Spins are bounded: a wait that does not end within SPIN_LIMIT raises an error instead of hanging the queue.
+constexpr unsigned long long SPIN_LIMIT = 300000000ull;    // wall_clock64 ticks (100 MHz): 3 s
+__device__ __forceinline__ void wait_dense_read_for(const VrgCtx& c, int64_t need) {
+    if (need <= 0 || vrg_load_i64(&c.dctl[VD_RSEQ]) >= need) return;
+    const unsigned long long t0 = wall_clock64();
+    while (vrg_load_i64(&c.dctl[VD_RSEQ]) < need) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > SPIN_LIMIT) { vrg_store_i32(&c.stg->error, 9); return; }
+    }
+}
+// the deferred work of this workgroup has reached memory; the LAST of the `n` workgroups to say so closes it (vrg_deferred_done)
+__device__ __forceinline__ void band_deferred_done(const VrgCtx& c, int k, uint32_t n) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t q = __hip_atomic_fetch_add(&c.counters[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (q == n - 1u) { c.counters[32] = 0; vrg_deferred_done(c, k); }
+    }
+}
 // First kernel of a trip.  Workgroups [0, BAND_BLOCKS): the pool slots - correction of the sweep before, then the sign
 // test; a flip is appended to the unordered flip list.  When the correction is evaluated entry by entry from the
 // touched-level list (staged in LDS when it fits), LPE lanes share one slot: each sums every LPE-th level (nnz f64
 // exp per entry is what this kernel costs), a fixed butterfly adds the partial sums.  With the per-level memo (or
 // nothing to correct) it is one thread per slot.  Workgroups [BAND_BLOCKS, +EXACT_BLOCKS): the exact densities of the
 // slots that (re-)entered the band in the sweep before, then their sign tests (exact_wg).
-constexpr int BAND_BLOCKS = 1024;     // most workgroups k_band uses for the pool; fewer when the engine knows the pool is small (band_blocks())
-constexpr int LPE = 8;
+constexpr int BAND_BLOCKS = 2048;     // most workgroups k_band uses for the pool; fewer when the engine knows the pool is small (band_blocks())
+// Lanes that share a slot when its correction is summed entry by entry (LPE): 16, 8 or 4 by the size of the pool, so that the
+// pool's workgroups stay within one round of the chip (two workgroups per CU) - band_lanes().  Their partial sums are added
+// by a DPP butterfly inside the group (xor 1, xor 2, mirror of 8, mirror of 16: no LDS traffic, where a shuffle is two
+// bpermutes per step); every lane ends up with the total, lane 0's order of additions is the one used (deterministic).
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int LPE> __device__ __forceinline__ double group_sum(double v) {
+    v += dpp_mov_f64<0xB1>(v);                            // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);                            // quad_perm [2,3,0,1]
+    if constexpr (LPE >= 8) v += dpp_mov_f64<0x141>(v);   // row_half_mirror
+    if constexpr (LPE >= 16) v += dpp_mov_f64<0x140>(v);  // row_mirror
+    return v;
+}
 constexpr uint32_t TAB_LDS = 832;     // levels whose memo entries k_band stages in LDS (the room of the entry-by-entry path's arrays)
-__global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks) {
+constexpr uint32_t FUSE_MEMO_ABOVE = 32768;   // band entries above which a fused trip keeps the per-level memo (k_memo behind k_sweep)
+constexpr uint32_t DEFER_WGS = 32;    // pool workgroups of k_band that carry out what a fused sweep deferred (label bytes, class bits, free list)
+template <int LPE>
+__global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, int dense_on, int direct_hint) {
     // One LDS block, two uses: the touched-level list (entry-by-entry corrections) or the head of the per-level memo.
     __shared__ double s_raw[NZ_LDS + NZ_LDS * 3 / 2];
     double* s_val = s_raw;
+    uint32_t* s_nzl = reinterpret_cast<uint32_t*>(s_raw);   // (with the kernel table: the touched levels' indices instead of their values)
     uint32_t* s_cin = reinterpret_cast<uint32_t*>(s_raw + NZ_LDS); uint32_t* s_cout = s_cin + NZ_LDS; uint32_t* s_cconv = s_cout + NZ_LDS;
     static_assert(3 * TAB_LDS <= NZ_LDS + NZ_LDS * 3 / 2, "memo head must fit the block");
-    // The kernel is a chain of dependent round trips (state -> slot fields -> memo entry -> flip counter), each of which
-    // takes 2-3 x longer beside a recount.  The pool workgroups therefore fetch, together with the state, what the first
-    // slot of every thread will need: its fields (any slot below the capacity is readable) and the head of the memo.
-    const bool pool_wg = blockIdx.x < band_blocks;
+    // The kernel is a chain of dependent round trips (state -> slot fields -> memo entry / touched levels -> flip counter),
+    // each of which takes 2-3 x longer beside a recount.  Every workgroup therefore fetches, TOGETHER WITH THE STATE, what
+    // its threads' first items will need (any index below an array's capacity is readable, whatever the state then says):
+    // the first slot's fields; the head of the memo, or - where the engine expects corrections entry by entry
+    // (direct_hint: after a fused sweep, which keeps no memo) - the touched-level list and the level table; the places of
+    // the marked list a fused sweep left to be applied.  A wrong hint costs round trips, never correctness.
+    const bool pool_wg = blockIdx.x < band_blocks, defer_wg = blockIdx.x >= band_blocks + EXACT_BLOCKS;
     const bool st0 = blockIdx.x == 0 && threadIdx.x == 0, stx = blockIdx.x == band_blocks && threadIdx.x == 0;
     const unsigned long long t_entry = (st0 || stx) ? VRG_STAMP_NOW() : 0ull;     // (written below, and only by a trip that applies a sweep)
-    const uint32_t slot0 = blockIdx.x * TPB + threadIdx.x;
+    const uint32_t tid = threadIdx.x, gtid = blockIdx.x * TPB + tid;
+    const uint32_t dtid = (blockIdx.x - (band_blocks + EXACT_BLOCKS)) * TPB + tid;      // (deferred workgroups: their thread number)
+    const bool use_ktab = c.ktab != nullptr;           // (uniform) the kernel between two levels is a table look-up
+    const uint32_t slot0 = direct_hint ? gtid / LPE : gtid;
     uint8_t fl0 = 0; double ip0 = 0, op0 = 0; uint32_t lev0 = 0, idx0 = 0; uint64_t key0 = 0; int64_t nin0 = 0, nout0 = 0;
     const uint32_t tab_n = c.L < TAB_LDS ? c.L : TAB_LDS;
+    constexpr uint32_t NZQ = 1;                           // touched levels per thread fetched with the state (256 per workgroup; a longer list: the rest once its length is known)
+    double zv[NZQ]; uint32_t zi[NZQ], zo[NZQ], zc[NZQ], zl[NZQ];
+    constexpr uint32_t defer_wgs = DEFER_WGS, G = DEFER_WGS * TPB;
+    uint32_t mxa = VRG_NONE, mxb = VRG_NONE, cda0 = VRG_NOCHG, cxa0 = 0, cda1 = VRG_NOCHG, cxa1 = 0; uint8_t moa = 0, mna = 0, mob = 0, mnb = 0; int64_t rseq0 = 0;
     if (pool_wg) {
-        if (slot0 < c.bcap) { fl0 = c.p_flag[slot0]; ip0 = c.p_ip[slot0]; op0 = c.p_op[slot0]; lev0 = c.p_lev[slot0]; idx0 = c.p_idx[slot0]; key0 = c.p_key[slot0]; }
+        // (every load of this batch is unconditional with its index clamped into the array: a load under a divergent branch makes
+        // the compiler wait for all loads in flight before the next one)
+        { const uint32_t q = slot0 < c.bcap ? slot0 : c.bcap - 1u; fl0 = c.p_flag[q]; ip0 = c.p_ip[q]; op0 = c.p_op[q]; lev0 = c.p_lev[q]; idx0 = c.p_idx[q]; key0 = c.p_key[q]; }
         nin0 = c.inc[VC_NIN]; nout0 = c.inc[VC_NOUT];
-        for (uint32_t j = threadIdx.x; j < 3 * tab_n; j += TPB) s_raw[j] = c.tabC[j];
+        if (!direct_hint) { for (uint32_t j = tid; j < 3 * tab_n; j += TPB) s_raw[j] = c.tabC[j]; }
+        else {
+#pragma unroll
+            for (uint32_t k = 0; k < NZQ; k++) { const uint32_t j0 = tid + k * TPB, j = j0 < c.zcap ? j0 : c.zcap - 1u; zv[k] = c.nz_val[j]; zl[k] = (uint32_t)c.nz_key[j]; zi[k] = c.nz_cin[j]; zo[k] = c.nz_cout[j]; zc[k] = c.nz_cconv[j]; }
+        }
+    }
+    if (defer_wg) {                                       // (a fused sweep's marked list: this thread's first two places, its first class change of the sweep before - both parities)
+        const uint32_t qa = dtid < c.mcap ? dtid : c.mcap - 1u, qb = dtid + G < c.mcap ? dtid + G : c.mcap - 1u;
+        mxa = c.mk_idx[qa]; moa = c.mk_old[qa]; mna = c.mk_new[qa]; cda0 = c.chg_dw[0][qa]; cxa0 = c.chg_x[0][qa]; cda1 = c.chg_dw[1][qa]; cxa1 = c.chg_x[1][qa];
+        mxb = c.mk_idx[qb]; mob = c.mk_old[qb]; mnb = c.mk_new[qb];
+        if (dense_on) rseq0 = vrg_load_i64(&c.dctl[VD_RSEQ]);
     }
     const VrgState s = *c.st;                             // a copy (nf is only ever bumped atomically)
     if (s.done || s.bail) return;
     const bool live = s.iter < s.iterMax;
     if (st0 && live) { VRG_STAMP_PUT(c, 6, c.dbg[0]); VRG_STAMP_PUT(c, 0, t_entry); VRG_STAMP(c, 1); }    // (6: the sweep before this one)
+    // What the fused sweep before this trip (k_sweep) left to do - nothing in this kernel reads a label: its label bytes in
+    // place (+ the class bits the dense pass reads, the class changes of the sweep before that), its dead slots onto the
+    // free list - by workgroups of their own (the last DEFER_WGS of the grid), beside the ones that decide the slots.
+    // Whichever of them finishes last (ticket) asks for the sweep's dense pass.
+    if (defer_wg) {
+        if (!s.apply_pending) return;
+        const int k = s.iter;
+        if (tid == 0 && dense_on && (int64_t)k - 2 > rseq0) wait_dense_read_for(c, (int64_t)k - 2);   // (the pass of two sweeps ago has read the class copy this sweep rewrites)
+        __syncthreads();
+        if (dtid < s.ap_n) vrg_deferred_apply_vals(c, dtid, k, mxa, moa, mna);
+        if (dtid + G < s.ap_n) vrg_deferred_apply_vals(c, dtid + G, k, mxb, mob, mnb);
+        for (uint32_t i = dtid + 2u * G; i < s.ap_n; i += G) vrg_deferred_apply(c, i, k);
+        const uint32_t nc = vrg_deferred_catchup_count(c, k), pp = ((uint32_t)k & 1u) ^ 1u;
+        if (dtid < nc) { const uint32_t dw = pp ? cda1 : cda0, x = pp ? cxa1 : cxa0; if (dw != VRG_NOCHG) vrg_atomic_xor(&c.clsb[pp ^ 1u][dw], x); }
+        for (uint32_t i = dtid + G; i < nc; i += G) vrg_deferred_catchup(c, i, k);
+        for (uint32_t j = dtid; j < s.fr_n; j += G) vrg_deferred_free(c, s, j);
+        band_deferred_done(c, k, defer_wgs);
+        return;
+    }
     if (!pool_wg) {
         exact_wg(c, s, s.nfx, blockIdx.x - band_blocks, EXACT_BLOCKS);
         if (stx && live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP_PUT(c, 3, t_entry); VRG_STAMP(c, 4); }
@@ -267,47 +350,86 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks) {
     }
     const bool direct = s.corr && !s.use_tab;
     if (!direct) {
+        if (direct_hint) for (uint32_t j = tid; j < 3 * tab_n; j += TPB) s_raw[j] = c.tabC[j];      // (the hint was wrong: the memo head now)
         __syncthreads();                                  // (the memo head is in LDS)
-        if (slot0 < s.np)
-            vrg_item_band_fields(c, s, slot0, fl0, ip0, op0, lev0, idx0, key0, nin0, nout0, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n);
-        for (uint32_t slot = slot0 + band_blocks * TPB; slot < s.np; slot += band_blocks * TPB)
-            vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n);
+        if (!direct_hint) {
+            if (slot0 < s.np)
+                vrg_item_band_fields(c, s, slot0, fl0, ip0, op0, lev0, idx0, key0, nin0, nout0, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n);
+            for (uint32_t slot = slot0 + band_blocks * TPB; slot < s.np; slot += band_blocks * TPB)
+                vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n);
+        } else
+            for (uint32_t slot = gtid; slot < s.np; slot += band_blocks * TPB)
+                vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n);
         if (st0 && live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 2); }
         return;
     }
     __syncthreads();                                      // (everyone is done staging the memo head: the block changes hands)
     const double* nzv = c.nz_val; const uint32_t* nzi = c.nz_cin; const uint32_t* nzo = c.nz_cout; const uint32_t* nzc = c.nz_cconv;
-    if (s.nnz <= NZ_LDS) {
-        for (uint32_t j = threadIdx.x; j < s.nnz; j += TPB) { s_val[j] = c.nz_val[j]; s_cin[j] = c.nz_cin[j]; s_cout[j] = c.nz_cout[j]; s_cconv[j] = c.nz_cconv[j]; }
-        __syncthreads();
-        nzv = s_val; nzi = s_cin; nzo = s_cout; nzc = s_cconv;
-    }
-    const uint32_t sub = threadIdx.x & (LPE - 1);
-    const uint32_t np_pad = (s.np + (TPB / LPE) - 1) / (TPB / LPE) * (TPB / LPE);      // whole waves stay in the loop together
-    for (uint32_t slot = (blockIdx.x * TPB + threadIdx.x) / LPE; slot < np_pad; slot += band_blocks * TPB / LPE) {
-        uint8_t fl = 0; double ip = 0, op = 0, v = 0; uint32_t lev = 0;
-        const bool live = slot < s.np;
-        if (live) { fl = c.p_flag[slot]; ip = c.p_ip[slot]; op = c.p_op[slot]; lev = c.p_lev[slot]; }   // one batch
-        const bool work = live && (fl & PF_ALIVE) && !(fl & PF_PEND);
-        if (work) v = c.lev[lev];
-        double a = 0, bb = 0, d = 0;
-        if (work)
-            for (uint32_t j = sub; j < s.nnz; j += LPE) {
-                const double k = vrg_kern(c, nzv[j] - v);
-                a += (double)nzi[j] * k; bb += (double)nzo[j] * k; d += (double)nzc[j] * k;
-            }
+    const bool nz_lds = s.nnz <= NZ_LDS;
+    if (nz_lds) {
+        if (direct_hint) {
 #pragma unroll
-        for (int o = LPE / 2; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); bb += __shfl_xor(bb, o, 64); d += __shfl_xor(d, o, 64); }
-        if (sub == 0 && live) {
+            for (uint32_t k = 0; k < NZQ; k++) { const uint32_t j = tid + k * TPB; if (j < s.nnz) { if (use_ktab) s_nzl[j] = zl[k]; else s_val[j] = zv[k]; s_cin[j] = zi[k]; s_cout[j] = zo[k]; s_cconv[j] = zc[k]; } }
+            for (uint32_t j = tid + NZQ * TPB; j < s.nnz; j += TPB) { if (use_ktab) s_nzl[j] = (uint32_t)c.nz_key[j]; else s_val[j] = c.nz_val[j]; s_cin[j] = c.nz_cin[j]; s_cout[j] = c.nz_cout[j]; s_cconv[j] = c.nz_cconv[j]; }
+        } else
+            for (uint32_t j = tid; j < s.nnz; j += TPB) { if (use_ktab) s_nzl[j] = (uint32_t)c.nz_key[j]; else s_val[j] = c.nz_val[j]; s_cin[j] = c.nz_cin[j]; s_cout[j] = c.nz_cout[j]; s_cconv[j] = c.nz_cconv[j]; }
+    }
+    __syncthreads();
+    if (st0 && live) VRG_STAMP(c, 7);
+    const uint32_t sub = tid & (LPE - 1);
+    const uint32_t np_pad = (s.np + (TPB / LPE) - 1) / (TPB / LPE) * (TPB / LPE);      // whole waves stay in the loop together
+    const uint32_t first = gtid / LPE;
+    for (uint32_t slot = first; slot < np_pad; slot += band_blocks * TPB / LPE) {
+        uint8_t fl = 0; double ip = 0, op = 0, v = 0; uint32_t lev = 0, idx = 0; uint64_t key = 0;
+        const bool in_pool = slot < s.np, pre = direct_hint && slot == first;
+        if (in_pool) {
+            if (pre) { fl = fl0; ip = ip0; op = op0; lev = lev0; idx = idx0; key = key0; }
+            else { fl = c.p_flag[slot]; ip = c.p_ip[slot]; op = c.p_op[slot]; lev = c.p_lev[slot]; idx = c.p_idx[slot]; key = c.p_key[slot]; }   // one batch
+        }
+        const bool work = in_pool && (fl & PF_ALIVE) && !(fl & PF_PEND);
+        const bool by_table = use_ktab && nz_lds;
+        if (work && !by_table) v = c.lev[lev];
+        double a = 0, bb = 0, d = 0;
+        if (work) {
+            if (by_table) {
+                // kern(x_j - v) = ktab[lev][level of x_j]: eight look-ups in flight per turn - one turn for up to 128 touched
+                // levels - each unconditional (index clamped: a load under a branch would wait for the ones before it)
+                const double* row = c.ktab + (size_t)lev * c.L;
+                const uint32_t last = s.nnz - 1u;
+                constexpr int KQ = 128 / LPE < 16 ? 128 / LPE : 16;     // (one turn for up to 128 touched levels; 64 with 4 lanes per slot)
+                for (uint32_t j0 = sub; j0 < s.nnz; j0 += KQ * LPE) {
+                    uint32_t jj[KQ]; double kk[KQ];
+#pragma unroll
+                    for (int q = 0; q < KQ; q++) { const uint32_t j = j0 + q * LPE; jj[q] = j < s.nnz ? j : last; }
+#pragma unroll
+                    for (int q = 0; q < KQ; q++) kk[q] = row[s_nzl[jj[q]]];
+#pragma unroll
+                    for (int q = 0; q < KQ; q++)
+                        if (j0 + q * LPE < s.nnz) { a += (double)s_cin[jj[q]] * kk[q]; bb += (double)s_cout[jj[q]] * kk[q]; d += (double)s_cconv[jj[q]] * kk[q]; }
+                }
+            } else if (nz_lds)
+                for (uint32_t j = sub; j < s.nnz; j += LPE) {
+                    const double k = vrg_kern(c, s_val[j] - v);
+                    a += (double)s_cin[j] * k; bb += (double)s_cout[j] * k; d += (double)s_cconv[j] * k;
+                }
+            else
+                for (uint32_t j = sub; j < s.nnz; j += LPE) {
+                    const double k = vrg_kern(c, nzv[j] - v);
+                    a += (double)nzi[j] * k; bb += (double)nzo[j] * k; d += (double)nzc[j] * k;
+                }
+        }
+        a = group_sum<LPE>(a); bb = group_sum<LPE>(bb); d = group_sum<LPE>(d);
+        if (sub == 0 && in_pool) {
             if ((fl & PF_ALIVE) && (fl & PF_PEND)) c.p_flag[slot] = (uint8_t)(fl & ~PF_PEND);   // decided by the exact half
             else if (work) {
                 vrg_add_correction(a, bb, d, ip, op);
                 c.p_ip[slot] = ip; c.p_op[slot] = op;
                 if (s.iter < s.iterMax)              // while iterNum <= iterMax (:58)
-                    vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, fl & PF_INNER, ip, op, c.p_key[slot], c.p_idx[slot], lev);
+                    vrg_decide_core(c, s, nin0, nout0, slot, fl & PF_INNER, ip, op, key, idx, lev);
             }
         }
     }
+    if (st0 && live) { VRG_STAMP(c, 40); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 2); }
 }
 
 // ---- exact densities when the level table is huge (continuous-valued volumes: about one level per voxel) -----
@@ -425,17 +547,8 @@ __device__ void wg_sort_pairs(K* key, V* val, uint32_t n, bool has_val) {
 // (a host event wait / record is a barrier packet of several microseconds in the stream; both conditions are almost
 // always true already, so one thread looks at a word instead.)  Spins are bounded: a wait that does not end within
 // SPIN_LIMIT raises an error instead of hanging the queue.
-constexpr unsigned long long SPIN_LIMIT = 300000000ull;    // wall_clock64 ticks (100 MHz): 3 s
 // band side, before the labels of sweep k are written into class copy k & 1: the recount k-2 has read that copy
-__device__ __forceinline__ void wait_dense_read(const VrgCtx& c) {
-    const int64_t need = (int64_t)c.st->iter + 1 - 2;
-    if (need <= 0 || vrg_load_i64(&c.dctl[VD_RSEQ]) >= need) return;
-    const unsigned long long t0 = wall_clock64();
-    while (vrg_load_i64(&c.dctl[VD_RSEQ]) < need) {
-        __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > SPIN_LIMIT) { vrg_store_i32(&c.stg->error, 9); return; }
-    }
-}
+__device__ __forceinline__ void wait_dense_read(const VrgCtx& c) { wait_dense_read_for(c, (int64_t)c.st->iter + 1 - 2); }
 // dense side, in front of every recount: a sweep has been applied since the last recount - or the run has stopped and
 // there is nothing to count.  True at once whenever the dense pass is what bounds the step (the band side runs a sweep
 // ahead).  A kernel of its own (one thread), not the first thing in the recount: the recount's duration - what the HIP
@@ -447,7 +560,7 @@ __device__ __forceinline__ bool gate_dense_due(const VrgCtx& c) {
     for (;;) {
         if (vrg_load_i64(&c.gate[VG_REQ]) > rseq) return true;
         if (vrg_load_i64(&c.gate[VG_STOP])) return vrg_load_i64(&c.gate[VG_REQ]) > rseq;   // (the last applied sweep's request is older than the stop flag)
-        __builtin_amdgcn_s_sleep(48);
+        __builtin_amdgcn_s_sleep(4);                          // (~0.1 us per look: one thread polls, two words of one cache line)
         if (wall_clock64() - t0 > SPIN_LIMIT) { c.dctl[VD_ERR] = 10; return false; }
     }
 }
@@ -816,6 +929,150 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
             vrg_close_sweep(c, (int64_t)nmk, use_tab);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 29);
         }
+    }
+}
+
+// ---- update() of a sweep with few flips as ONE launch (vrg_items.h, "fused sweep") ------------------------------------
+// One flip per workgroup of 128 threads; no seam inside the sweep - every workgroup ranks all flips and resolves the skip
+// rule itself, a voxel is relabelled by the flip of smallest rank that wants it, and nothing is applied before the kernel
+// ends (the next trip's k_band does that in the shadow of its decisions).  Round trips to memory per workgroup: state +
+// flip records -> label tile, per-voxel fields, flip neighbourhoods -> one reservation per event list -> ticket; the
+// workgroup whose ticket comes last lists the sweep's touched levels and closes it.
+constexpr uint32_t FUSE_MEMO_NNZ = 1024;  // touched levels k_memo keeps in LDS; a sweep that touches more keeps no memo (corrections entry by entry)
+// memo_follows: the launch behind this one is k_memo (large bands: the corrections of the sweep memoised per level)
+__global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_follows) {
+    __shared__ VrgFuseLds sh;
+    __shared__ uint32_t s_scan[VRG_FUSE_THREADS / 64];
+    __shared__ int s_last;
+    constexpr uint32_t T = VRG_FUSE_THREADS;
+    const uint32_t t = threadIdx.x, r = blockIdx.x;
+    const bool st0 = r == 0 && t == 0;
+    const unsigned long long t_entry = st0 ? VRG_STAMP_NOW() : 0ull;
+    VrgFuseThread th;
+    vrg_fuse_load1(cg, th, t);                             // (this thread's flip record travels with the state)
+    const VrgState s0 = *cg.st;
+    const int64_t nin0 = cg.inc[VC_NIN];
+    vrg_fuse_init(sh, t);
+    if (s0.done || s0.bail) return;
+    const int32_t gate = vrg_fuse_gate(cg, s0, nin0);      // stop tests (:91-104) / can the sweep run fused: the same answer everywhere
+    if (gate) {
+        if (st0) {
+            if (gate > 0) cg.stg->done = gate == 1000 ? -1 : gate; else cg.stg->bail = -gate;
+            vrg_close_without_update(cg);
+        }
+        return;
+    }
+    const uint32_t nf = s0.nf;
+    if (r >= nf) return;                                   // (no flip for this workgroup)
+    if (st0) { VRG_STAMP_PUT(cg, 8, t_entry); VRG_STAMP(cg, 9); }
+    VrgState sl = s0;                                      // (what the item functions read of the state: registers, not memory)
+    VrgCtx c = cg;
+    c.st = &sl; c.lev_fast = 1; c.lvl_scan = 1;
+    vrg_fuse_keys(sh, th, t, nf);
+    __syncthreads();
+    vrg_fuse_rank(c, sh, th, t, nf);
+    __syncthreads();
+    if (st0) VRG_STAMP(cg, 10);
+    vrg_fuse_load2(c, sh, th, t, r, nf);
+    constexpr uint32_t PER_MAX = VRG_FUSE_LEVELS / VRG_FUSE_THREADS;
+    double lv[PER_MAX];                                    // the level table (a voxel that enters the band needs the level of its intensity): requested with the rest
+#pragma unroll
+    for (uint32_t k = 0; k < PER_MAX; k++) { const uint32_t l = t + k * T; lv[k] = cg.lev[l < cg.L ? l : cg.L - 1u]; }   // (unconditional, index clamped)
+    vrg_fuse_listed_nbrs(sh, t, nf);                       // (LDS work while the loads travel)
+#pragma unroll
+    for (uint32_t k = 0; k < PER_MAX; k++) { const uint32_t l = t + k * T; if (!cg.lev16 && l < cg.L) sh.lev[l] = lv[k]; }
+    __syncthreads();
+    if (st0) VRG_STAMP(cg, 11);
+    vrg_fuse_prepass(sh, th, t, nf);
+    __syncthreads();
+    if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 18); }
+    if (sh.any_pend)                                       // skip-rule fix-point (rare)
+        for (;;) {
+            vrg_fuse_fix(c, sh, t, nf);
+            __syncthreads();
+            const uint32_t ch = sh.changed;
+            __syncthreads();
+            if (!ch) break;
+            if (t == 0) sh.changed = 0;
+            __syncthreads();
+        }
+    vrg_fuse_annotate(c, sh, t, r, nf);
+    __syncthreads();
+    if (st0) VRG_STAMP(cg, 19);
+    vrg_fuse_stencil(c, sh, th, t, r);
+    __syncthreads();
+    if (st0) { VRG_STAMP(cg, 22); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 20); }
+    vrg_fuse_reserve(c, sh, t);
+    __syncthreads();
+    vrg_fuse_commit(c, sh, th, t, r);
+    // everything this workgroup sent to memory has arrived before it takes its ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st0) VRG_STAMP(cg, 21);
+    if (t == 0) {
+        const uint32_t k = __hip_atomic_fetch_add(&cg.counters[16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (k == nf - 1u);
+        if (s_last) cg.counters[16] = 0;                   // every workgroup with a flip has arrived: reset for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (t == 0) VRG_STAMP(cg, 28);
+    // the touched levels in ascending order (thread t its stretch of levels, a block scan for the places), counters zeroed
+    const uint32_t per = (cg.L + T - 1u) / T, l0 = t * per;
+    int64_t fin_nin, fin_nout;
+    const VrgState fin = vrg_fuse_close_load(c, fin_nin, fin_nout);    // (every thread asks - the same words, one request -: no branch around the loads, they travel with the counters)
+    uint32_t ci[PER_MAX], co[PER_MAX], cc[PER_MAX], cnt = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER_MAX; k++) {
+        const uint32_t l = l0 + k;
+        ci[k] = co[k] = cc[k] = 0;
+        if (k < per && l < cg.L) cnt += vrg_fuse_level_touched(c, l, ci[k], co[k], cc[k]) ? 1u : 0u;
+    }
+    const uint32_t incl = wave_incl_scan(cnt);
+    if ((t & 63u) == 63u) s_scan[t >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (uint32_t w = 0; w < T / 64; w++) { if (w < (t >> 6)) base += s_scan[w]; total += s_scan[w]; }
+    uint32_t q = base + incl - cnt;
+#pragma unroll
+    for (uint32_t k = 0; k < PER_MAX; k++)
+        if (ci[k] | co[k] | cc[k]) {
+            const uint32_t l = l0 + k;
+            if (cg.lev16) vrg_fuse_level_file(c, q++, l, cg.lev[l], ci[k], co[k], cc[k]);     // (two calls: one pointer into LDS, one into memory - never a generic one)
+            else vrg_fuse_level_file(c, q++, l, sh.lev[l], ci[k], co[k], cc[k]);
+        }
+    if (t == 0) { vrg_fuse_close(c, fin, fin_nin, fin_nout, total, memo_follows && total <= FUSE_MEMO_NNZ); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 29); }
+}
+// (entering fused trips after trips of another kind: the per-level counters of the last sweep are still listed, not yet zero)
+__global__ void __launch_bounds__(TPB) k_levels_clear(VrgCtx c) {
+    if (c.st->done || c.st->bail) return;
+    for (uint32_t j = threadIdx.x, n = min(c.st->nnz, c.zcap); j < n; j += TPB) vrg_item_level_clear(c, j);
+}
+
+// Behind a fused sweep on a LARGE band (more entries than k_band decides in one round of workgroups when every entry sums its
+// correction itself): the per-level memo of the corrections (:236-247) from the touched-level list the sweep's closing
+// workgroup filed - one wave per level, the kernel between two levels from the table; the same terms in the same order as
+// k_close's memo.  (Tried first inside k_sweep, by workgroups that wait on the device for the list: 128 polling workgroups
+// slowed the dense pass beside them by 15 % and the sweep's tail by 5 us - a launch of its own costs 2.5.)
+constexpr int MEMO_BLOCKS = 128;
+__global__ void __launch_bounds__(TPB) k_memo(VrgCtx c) {
+    __shared__ uint32_t s_nzl[FUSE_MEMO_NNZ], s_ci[FUSE_MEMO_NNZ], s_co[FUSE_MEMO_NNZ], s_cc[FUSE_MEMO_NNZ];
+    const uint32_t t = threadIdx.x;
+    // (the head of the list travels with the state)
+    const uint32_t q = t < c.zcap ? t : c.zcap - 1u;
+    const uint32_t l0 = (uint32_t)c.nz_key[q], i0 = c.nz_cin[q], o0 = c.nz_cout[q], c0 = c.nz_cconv[q];
+    const VrgState s = *c.st;
+    if (s.done || s.bail || !s.use_tab || !s.corr) return;
+    const uint32_t nnz = s.nnz;
+    if (t < nnz) { s_nzl[t] = l0; s_ci[t] = i0; s_co[t] = o0; s_cc[t] = c0; }
+    for (uint32_t j = t + TPB; j < nnz; j += TPB) { s_nzl[j] = (uint32_t)c.nz_key[j]; s_ci[j] = c.nz_cin[j]; s_co[j] = c.nz_cout[j]; s_cc[j] = c.nz_cconv[j]; }
+    __syncthreads();
+    const uint32_t lane = t & 63u, wid = (blockIdx.x * TPB + t) >> 6, nw = (MEMO_BLOCKS * TPB) >> 6;
+    for (uint32_t l = wid; l < c.L; l += nw) {
+        double a, bb, d;
+        vrg_fuse_memo_terms(c, l, lane, nnz, s_nzl, s_ci, s_co, s_cc, a, bb, d);
+        a = wave_sum(a); bb = wave_sum(bb); d = wave_sum(d);
+        if (lane == 0) { c.tabC[3 * (size_t)l] = a; c.tabC[3 * (size_t)l + 1] = bb; c.tabC[3 * (size_t)l + 2] = d; }
     }
 }
 
@@ -1553,9 +1810,17 @@ int voxel_blocks(const VrgCtx& c) {
 // Workgroups k_band gets for the pool.  Its loops are grid-stride, so any number is correct; beside a recount only two
 // of its waves fit on a SIMD, and 1024 workgroups of which 800 find nothing to do then cost it two extra rounds.  The
 // pool can grow by at most a few thousand slots within a batch of trips: 1.5 x the last known size leaves room.
+// (corrections entry by entry: where the engine says so - more levels than entries - and behind a fused trip that kept no memo)
+bool band_direct(const VrgBackend* b) { return b->direct_hint || (b->fused_prev && !b->fused_memo); }
+uint64_t band_slots(const VrgBackend* b) { return (uint64_t)b->band_hint * 9 / 8 + 2048; }      // (a batch of 64 sweeps adds a few thousand slots at most)
+int band_lanes(const VrgBackend* b) {       // lanes per slot of the entry-by-entry corrections: the pool within 512 workgroups where it can be
+    if (!b->band_hint) return 4;
+    const uint64_t slots = band_slots(b);
+    return slots * 16 <= 512u * TPB ? 16 : slots * 8 <= 512u * TPB ? 8 : 4;
+}
 uint32_t band_blocks(const VrgBackend* b) {
     if (!b->band_hint) return BAND_BLOCKS;
-    const uint64_t threads = ((uint64_t)b->band_hint * 3 / 2 + 4096) * (b->direct_hint ? LPE : 1);
+    const uint64_t threads = band_slots(b) * (band_direct(b) ? band_lanes(b) : 1);
     return (uint32_t)std::min<uint64_t>(BAND_BLOCKS, std::max<uint64_t>(32, (threads + TPB - 1) / TPB));
 }
 
@@ -1660,6 +1925,10 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != b->prio_mode) { b->prio_mode = (int)v; make_streams(b); }
 }
 uint32_t be_small_flip_limit(VrgBackend* b) { return b->small_flips; }
+uint32_t be_fuse_limit(VrgBackend*) { return VRG_FUSE_MAX; }
+// fused trips need the level table in the workgroup's LDS (or 16-bit level indices)
+bool be_fuse_ok(VrgBackend*, const VrgCtx& c) { return c.L <= (uint32_t)VRG_FUSE_LEVELS; }
+void be_fuse_enter(VrgBackend* b, const VrgCtx& c) { use_device(b); k_levels_clear<<<1, TPB, 0, b->sa>>>(c); }
 bool be_wants_sync(VrgBackend*, const VrgCtx& c) { return c.L > EXACT_BIG_L; }
 
 void* be_alloc(VrgBackend* b, size_t bytes) { use_device(b); void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
@@ -1673,7 +1942,8 @@ const char* be_last_error(VrgBackend* b) {
     return b->err[0] ? b->err : nullptr;
 }
 void be_clear_error(VrgBackend* b) { b->err[0] = 0; }
-void be_sync(VrgBackend* b) { use_device(b); HIP_CHECK(hipStreamSynchronize(b->sa)); HIP_CHECK(hipStreamSynchronize(b->sb)); }
+// (the engine synchronises when a run ends or a trip was handed back: no fused sweep is waiting for its dense pass then)
+void be_sync(VrgBackend* b) { use_device(b); HIP_CHECK(hipStreamSynchronize(b->sa)); HIP_CHECK(hipStreamSynchronize(b->sb)); b->fused_prev = false; }
 
 // A device-resident input is read on the library's own stream: the caller's producer must have finished (vrg.h).
 static const void* stage_in(VrgBackend* b, const VrgCtx& c, const void* src, int dtype, void** tmp) {
@@ -1775,6 +2045,15 @@ bool be_build_lev_map(VrgBackend* b, const VrgCtx& c, uint16_t* map, uint32_t sp
     HIP_CHECK(hipFree(bad));
     return hbad == 0;
 }
+
+__global__ void k_ktab(VrgCtx c, double* ktab) {
+    const uint64_t n = (uint64_t)c.L * c.L;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t a = (uint32_t)(i / c.L), b = (uint32_t)(i - (uint64_t)a * c.L);
+        ktab[i] = vrg_kern(c, c.lev[b] - c.lev[a]);
+    }
+}
+void be_build_ktab(VrgBackend* b, const VrgCtx& c, double* ktab) { use_device(b); k_ktab<<<1024, TPB, 0, b->sa>>>(c, ktab); }
 
 void be_build_lev16(VrgBackend* b, const VrgCtx& c, uint16_t* dst) {
     use_device(b);
@@ -1975,9 +2254,10 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
         p.trip = trip; p.kind = kind; p.ntrips = 1;
         return p;
     };
+    size_t dense_pair = (size_t)-1;
     if (dense && ev && ev->enabled > 0 && trip % ev->enabled == 0) {     // (every enabled-th trip: an event pair costs the dense stream a few us)
         EvPair& p = take_pair(0);
-        e_start = p.a; e_stop = p.b;
+        e_start = p.a; e_stop = p.b; dense_pair = b->ev_used - 1;
     }
     hipEvent_t e_c0 = nullptr, e_c1 = nullptr;                           // the band chain of this trip: k_band's start to k_close's end
     if (ev && ev->chain_enabled > 0 && !(flags & VRG_SWEEP_SYNC) && trip % ev->chain_enabled == 0) {
@@ -1997,7 +2277,31 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
         }
     }
     const uint32_t nbb = band_blocks(b);
-    hipExtLaunchKernelGGL(k_band, dim3(nbb + EXACT_BLOCKS), dim3(TPB), 0, b->sa, e_c0, nullptr, 0, c, nbb);
+    // (grid: the pool's workgroups, the exact-density ones, and - behind a fused trip - the ones that carry out what it deferred)
+    {
+        const dim3 grid(nbb + EXACT_BLOCKS + (b->fused_prev ? DEFER_WGS : 0));
+        const int lanes = band_lanes(b), dh = band_direct(b) ? 1 : 0, don = dense ? 1 : 0;
+        if (lanes == 16) hipExtLaunchKernelGGL(k_band<16>, grid, dim3(TPB), 0, b->sa, e_c0, nullptr, 0, c, nbb, don, dh);
+        else if (lanes == 8) hipExtLaunchKernelGGL(k_band<8>, grid, dim3(TPB), 0, b->sa, e_c0, nullptr, 0, c, nbb, don, dh);
+        else hipExtLaunchKernelGGL(k_band<4>, grid, dim3(TPB), 0, b->sa, e_c0, nullptr, 0, c, nbb, don, dh);
+    }
+    // A fused trip leaves the labels of the sweep it applies to the NEXT trip's k_band, which also asks for that sweep's dense
+    // pass: the pass is therefore enqueued here, right behind the k_band that raises its request - never earlier: a gate that
+    // waits for a request nobody has enqueued yet would block every host synchronisation of the dense stream.
+    if (b->fused_prev && dense) {
+        if (dense_pair != (size_t)-1) b->ev_pool[dense_pair].trip = trip - 1;     // (the pass of the sweep BEFORE this trip: it counts if that sweep was applied)
+        enqueue_dense(b, c, e_start, e_stop, cb, user);
+        e_start = e_stop = nullptr;
+    }
+    b->fused_prev = false;
+    if ((flags & VRG_SWEEP_FUSED) && !(flags & (VRG_SWEEP_SYNC | VRG_SWEEP_FULL))) {
+        // update() as ONE launch; on a large band a second one memoises the sweep's corrections per level
+        const bool memo = !b->direct_hint && b->band_hint > FUSE_MEMO_ABOVE && c.ktab;
+        hipExtLaunchKernelGGL(k_sweep, dim3(VRG_FUSE_MAX), dim3(VRG_FUSE_THREADS), 0, b->sa, nullptr, memo ? nullptr : e_c1, 0, c, memo ? 1 : 0);
+        if (memo) hipExtLaunchKernelGGL(k_memo, dim3(MEMO_BLOCKS), dim3(TPB), 0, b->sa, nullptr, e_c1, 0, c);
+        b->fused_prev = true; b->fused_memo = memo;
+        return;
+    }
     if (flags & VRG_SWEEP_SYNC) {
         VrgState s;
         HIP_CHECK(hipMemcpyAsync(&s, c.st, sizeof(s), hipMemcpyDeviceToHost, b->sa));

@@ -28,6 +28,8 @@ struct vrg_handle {
     int device = 0;
     bool have_vol = false, have_lab = false, inited = false;
     bool sync_mode = false;              // trips are driven one at a time from the host (many flips per sweep)
+    int fused = 1;                       // option "fused": sweeps with few flips run update() as ONE launch (k_sweep)
+    bool fuse_mode = false;              // ... and the trips being enqueued now are of that kind
     int variant = 0, batch = 8, storage16 = 0, dense_off = 0;
     uint16_t* lev16_buf = nullptr;
     float* I32 = nullptr; double* I64 = nullptr;
@@ -40,7 +42,8 @@ struct vrg_handle {
     uint8_t* lab_base[2] = {nullptr, nullptr};
     vrg_reduce_fn reduce_fn = nullptr;
     void* reduce_user = nullptr;
-    long long bails[4] = {0, 0, 0, 0};   // how often a trip came back, by VBAIL_* reason
+    long long bails[5] = {0, 0, 0, 0, 0};   // how often a trip came back, by VBAIL_* reason
+    long long fused_trips = 0;
     long long sync_trips = 0;
 };
 
@@ -224,7 +227,8 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "chain_events") h->ev.chain_enabled = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20);
     else if (n == "dense_off") h->dense_off = value != 0;   // measurement aid: band chain alone; re-initialise afterwards
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
-    else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads" || n == "dense_pipe") be_set_tuning(h->be, name, value);
+    else if (n == "fused") h->fused = value != 0;
+    else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "fuse_max" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads" || n == "dense_pipe") be_set_tuning(h->be, name, value);
     else if (n == "storage16") h->storage16 = value != 0;      // takes effect at the next vrg_init
     else return fail(h, VRG_E_ARG, "unknown option " + n);
     return VRG_OK;
@@ -249,6 +253,7 @@ int API(set_volume)(vrg_handle* h, const void* data, int dtype, const int64_t st
     if (c.lev) {                                     // distinct-value table and its arrays are rebuilt by the next vrg_init
         release(h, (void*)c.lev); c.lev = nullptr;
         if (c.lev_map) { release(h, (void*)c.lev_map); c.lev_map = nullptr; }
+        if (c.ktab) { release(h, (void*)c.ktab); c.ktab = nullptr; }
         release(h, c.hin); release(h, c.hout); release(h, c.dIn); release(h, c.dOut); release(h, c.dConv); release(h, c.ltouch);
         release(h, c.nz_key); release(h, c.nz_val); release(h, c.nz_cin); release(h, c.nz_cout); release(h, c.nz_cconv); release(h, c.tabC);
         c.hin = c.hout = nullptr; c.dIn = c.dOut = c.dConv = c.ltouch = nullptr; c.nz_key = nullptr; c.nz_val = nullptr;
@@ -314,6 +319,11 @@ int API(init)(vrg_handle* h, double H) {
         }
     }
     const uint32_t L = c.L;
+    if (L <= (uint32_t)VRG_KTAB_LEVELS) {                // the kernel between every pair of levels (depends on H: rebuilt by every init)
+        if (!c.ktab) c.ktab = alloc<double>(h, (size_t)L * L);
+        if (!c.ktab) return fail(h, VRG_E_MEM, "vrg_init: kernel table");
+        be_build_ktab(be, c, const_cast<double*>(c.ktab));
+    }
     c.lev16 = nullptr;
     if (h->storage16) {                             // 16-bit intensity storage: level indices + LDS value table
         if (L > 16384) return fail(h, VRG_E_ARG, "storage16: more than 16384 distinct intensity values");
@@ -356,7 +366,7 @@ int API(init)(vrg_handle* h, double H) {
     s = get_state(h);
     int rc = check_state_error(h, s);
     if (rc) return rc;
-    h->inited = true; h->sync_mode = false;
+    h->inited = true; h->sync_mode = false; h->fuse_mode = false;
     h->ev.ms_total = 0; h->ev.launches = 0; h->ev.chain_ms_total = 0; h->ev.chain_launches = 0;
     return VRG_OK;
 }
@@ -379,9 +389,14 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     double cms0 = h->ev.chain_ms_total; long long cl0 = h->ev.chain_launches;
     auto t_begin = std::chrono::steady_clock::now();
     const int base_flags = ((h->variant & 1) ? VRG_SWEEP_FULL : 0) | (h->dense_off ? VRG_SWEEP_NODENSE : 0);
-    const uint32_t small = be_small_flip_limit(be);
+    const uint32_t small = be_small_flip_limit(be), fuse_max = be_fuse_limit(be);
+    const bool can_fuse = h->fused && !(base_flags & VRG_SWEEP_FULL) && be_fuse_ok(be, c);
+    // (a run starts fused when the sweep before - if any - had few flips; the switch is made with the streams idle)
+    if (can_fuse && !h->fuse_mode && !h->sync_mode && 2 * (uint64_t)s.last_nf <= fuse_max) { be_fuse_enter(be, c); h->fuse_mode = true; get_state(h); }
+    if (!can_fuse) h->fuse_mode = false;
     for (;;) {
         const bool sync = h->sync_mode || (base_flags & VRG_SWEEP_FULL) || be_wants_sync(be, c);
+        const bool fuse = h->fuse_mode && !sync;
         int64_t remaining = iterMax - s.iter;
         int nb = sync ? 1 : (int)std::min<int64_t>(h->batch, std::max<int64_t>(remaining, 0) + 1);   // +1: the trip that sets the stop flag
         if (maxSeconds >= 0 && s.iter < iterMax) {   // wall-clock cap (:97): tested after the no-flip test, before update()
@@ -389,20 +404,22 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
             if (el >= maxSeconds) { s.time_up = 1; put_state(h, s); nb = 1; }
         }
         int32_t before = s.iter;
-        be_sweep_batch(be, c, base_flags | (sync ? VRG_SWEEP_SYNC : 0), nb, &h->ev, h->reduce_fn, h->reduce_user);
+        be_sweep_batch(be, c, base_flags | (sync ? VRG_SWEEP_SYNC : 0) | (fuse ? VRG_SWEEP_FUSED : 0), nb, &h->ev, h->reduce_fn, h->reduce_user);
         if (sync) h->sync_trips++;
+        if (fuse) h->fused_trips += nb;
         s = get_state(h);
         be_events_collect(be, &h->ev, s.iter - before);
         if (s.done || s.error) break;
         if (s.bail) {                                // the trip was handed back untouched: make room / change mode, do it again
             const uint64_t nf = s.nf;
-            h->bails[std::min(s.bail, 3)]++;
+            h->bails[std::min(s.bail, 4)]++;
             // The rest of the batch was enqueued behind the trip that came back: its k_gate + recount pairs may still sit
             // in the dense stream.  They have to run out while the device's stop word (gate[VG_STOP]) is still set -
             // put_state below clears it; a leftover gate would then wait for the NEXT sweep's request and shift which
             // launch counts which sweep (and, on Z-slabs, let ranks pack different numbers of recounts into one all-reduce).
             be_sync(be);
             if (s.bail == VBAIL_FLIPS) h->sync_mode = true;
+            else if (s.bail == VBAIL_FUSE) h->fuse_mode = false;
             else if (s.bail == VBAIL_MARKS) {
                 if (nf * 125u > 0x3fffffffull || !size_marks(h, 2 * nf * 125u, true)) return fail(h, VRG_E_MEM, "vrg_run: marked-voxel arrays");
             } else {
@@ -414,6 +431,11 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
             continue;
         }
         if (h->sync_mode && 2 * (uint64_t)s.last_nf <= small) h->sync_mode = false;   // the flips fit one workgroup again
+        if (can_fuse && !h->fuse_mode && !h->sync_mode && 2 * (uint64_t)s.last_nf <= fuse_max) {   // ... or one fused launch
+            be_sync(be);
+            be_fuse_enter(be, c); h->fuse_mode = true;
+            get_state(h);                                // (k_band's grid is sized for corrections evaluated entry by entry)
+        }
     }
     if (!h->dense_off) be_dense_flush(be, c, h->reduce_fn, h->reduce_user);   // Z-slabs: close the passes still waiting for their all-reduce
     be_sync(be);
@@ -538,6 +560,7 @@ int API(get_stats)(vrg_handle* h, int64_t* outp, int64_t cap) {
         outp[8] = 0;
         if (h->inited) { be_sync(h->be); outp[8] = (int64_t)be_dense_bytes(h->be, h->c); }
     }
+    if (cap >= 17) { outp[15] = h->fused_trips; outp[16] = h->bails[4]; }
     if (cap >= 14) {
         int64_t di[5] = {0, 0, 0, 0, 0};
         uint32_t uc[2] = {0, 0};

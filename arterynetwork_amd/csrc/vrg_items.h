@@ -57,6 +57,14 @@ VRG_HD void vrg_store_i32(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __AT
 // sizes): written through to memory, and drained before the word that announces them
 VRG_HD void vrg_store_i64(int64_t* p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 VRG_HD void vrg_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+VRG_HD void vrg_store_u32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VRG_HD void vrg_store_u64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VRG_HD uint64_t vrg_load_u64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// atomics on a workgroup's LDS arrays (fused sweep)
+VRG_HD uint32_t vrg_lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+VRG_HD int32_t vrg_lds_add(int32_t* p, int32_t v) { return atomicAdd(p, v); }
+VRG_HD uint32_t vrg_lds_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
+VRG_HD uint32_t vrg_lds_cas(uint32_t* p, uint32_t expect, uint32_t want) { return atomicCAS(p, expect, want); }
 #elif defined(VRG_HOSTMODEL)
 // tests/hostmodel only (sequential test model of the kernels; never part of the product library)
 VRG_HD uint32_t vrg_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
@@ -71,6 +79,13 @@ VRG_HD int64_t vrg_load_i64(const int64_t* p) { return *p; }
 VRG_HD void vrg_store_i32(int32_t* p, int32_t v) { *p = v; }
 VRG_HD void vrg_store_i64(int64_t* p, int64_t v) { *p = v; }
 VRG_HD void vrg_drain() {}
+VRG_HD void vrg_store_u32(uint32_t* p, uint32_t v) { *p = v; }
+VRG_HD void vrg_store_u64(uint64_t* p, uint64_t v) { *p = v; }
+VRG_HD uint64_t vrg_load_u64(const uint64_t* p) { return *p; }
+VRG_HD uint32_t vrg_lds_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+VRG_HD int32_t vrg_lds_add(int32_t* p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
+VRG_HD uint32_t vrg_lds_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+VRG_HD uint32_t vrg_lds_cas(uint32_t* p, uint32_t expect, uint32_t want) { uint32_t o = *p; if (o == expect) *p = want; return o; }
 #else
 // host pass of the product build (hipcc compiles __host__ __device__ functions for both sides): the product has no CPU
 // path - the item functions are never called on the host there, and if one ever were it stops right here
@@ -86,6 +101,13 @@ VRG_HD int64_t vrg_load_i64(const int64_t*) { __builtin_trap(); }
 VRG_HD void vrg_store_i32(int32_t*, int32_t) { __builtin_trap(); }
 VRG_HD void vrg_store_i64(int64_t*, int64_t) { __builtin_trap(); }
 VRG_HD void vrg_drain() { __builtin_trap(); }
+VRG_HD void vrg_store_u32(uint32_t*, uint32_t) { __builtin_trap(); }
+VRG_HD void vrg_store_u64(uint64_t*, uint64_t) { __builtin_trap(); }
+VRG_HD uint64_t vrg_load_u64(const uint64_t*) { __builtin_trap(); }
+VRG_HD uint32_t vrg_lds_add(uint32_t*, uint32_t) { __builtin_trap(); }
+VRG_HD int32_t vrg_lds_add(int32_t*, int32_t) { __builtin_trap(); }
+VRG_HD uint32_t vrg_lds_or(uint32_t*, uint32_t) { __builtin_trap(); }
+VRG_HD uint32_t vrg_lds_cas(uint32_t*, uint32_t, uint32_t) { __builtin_trap(); }
 #endif
 
 // OR bits into one label byte without disturbing concurrent ORs into its neighbours
@@ -823,6 +845,7 @@ VRG_HD void vrg_finalize_update(const VrgCtx& c, VrgState& s, int64_t n_in, int6
     s.nf = 0; s.npend = 0; s.nmk = 0; s.nalloc = 0; s.ndead = 0; s.d_ni = 0; s.d_no = 0;
     s.nfx = s.nfresh; s.nfresh = 0;                   // exact densities of the new entries: first thing next trip
     s.corr = 1; s.use_tab = use_tab ? 1 : 0;          // nnz stays: the next k_band reads the touched-level list
+    s.apply_pending = 0; s.ap_n = 0; s.fr_n = 0; s.d_nin = 0; s.d_nout = 0; s.nvisit = 0;   // (the fused sweep's closing thread sets its own afterwards)
     if (s.error) { s.done = -1; vrg_store_i64(&c.gate[VG_STOP], 1); }
 }
 VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
@@ -844,6 +867,384 @@ VRG_HD void vrg_close_sweep(const VrgCtx& c, int64_t nchg_at, bool use_tab) {
     vrg_finalize_update(c, s, n_in, n_out, use_tab);
     *c.stg = s;
     vrg_drain(); vrg_store_i64(&c.gate[VG_REQ], k);
+}
+
+// ------------------------------------------------------------------ fused sweep (k_sweep): update() of a sweep with few flips as ONE launch
+// The four-launch chain (k_band, k_order, k_mark_relabel, k_close) is bound by its three grid-wide seams and by dependent
+// round trips on shared words.  For a sweep with at most VRG_FUSE_MAX flips - the regime of every
+// bench volume and slab - update() needs no seam at all:
+//  * ORDER WITHOUT A SEAM.  Every workgroup (one per flip) fetches ALL flip records k_band appended, ranks them itself
+//    (counting sort in LDS = the reference's flip order, :88) and resolves the skip rule (:198, the P bit) for every flip-in
+//    from the nine label rows around it and a hash set of the flip voxels: the same answer in every workgroup, so nobody has
+//    to publish L / P bits or ranks through memory - they are written into the workgroup's own 9x9x9 label tile and a rank
+//    tile in LDS, where the stencils of its 125 voxels read them.
+//  * ONE OWNER PER VOXEL WITHOUT AN ATOMIC.  A voxel is relabelled by the flip of SMALLEST RANK that wants it (1-ring; 2-ring
+//    for an excluded voxel) - every workgroup sees all flips within reach of its cube, so ownership needs no election.
+//  * NOTHING IS APPLIED INSIDE THE SWEEP.  The owner files (voxel, old byte, new byte) at a fixed place (rank * 125 + cube
+//    position) of the marked list; the label bytes, the class bits of the dense pass and the free list are brought up to date
+//    by the NEXT trip's k_band, which reads no labels (vrg_deferred_*): the stencils of this sweep all read the pre-sweep labels
+//    because nobody writes labels while they run.  What the next decisions DO need - region sizes, class histograms, band pool,
+//    the sweep's level deltas - is complete when the kernel ends: the workgroup that finishes last (ticket) lists the touched
+//    levels for the next k_band's corrections and closes the sweep (vrg_fuse_close).
+// Same data structures as the four-launch chain, so a trip can go either way (k_sweep hands a sweep with more flips back:
+// VBAIL_FUSE) and both are checked against the oracle by the same tests.
+struct VrgFuseLds {
+    uint64_t key[VRG_FUSE_MAX];                                        // sort keys as appended (place = append order)
+    uint32_t f_idx[VRG_FUSE_MAX], f_slot[VRG_FUSE_MAX], f_lev[VRG_FUSE_MAX];   // by rank: voxel, slot, level
+    uint32_t f_L[VRG_FUSE_MAX], f_FI[VRG_FUSE_MAX];                     // ... which of its 26 neighbours are listed flips / listed flip-ins (27-bit masks)
+    uint8_t f_inner[VRG_FUSE_MAX], f_P[VRG_FUSE_MAX], f_pend[VRG_FUSE_MAX];
+    uint16_t f_x[VRG_FUSE_MAX], f_y[VRG_FUSE_MAX], f_z[VRG_FUSE_MAX];  // ... its coordinates
+    uint32_t tile[81 * 4];                                             // 9x9x9 label bytes around the workgroup's flip (rows of 16 bytes)
+    uint16_t rank[729];                                                // ... rank of the flip sitting there (0xffff: none)
+    uint32_t any_pend, changed;
+    uint32_t n[3], base[3], nvis; int32_t d[4];                        // this workgroup's new / dead / pending events, visited flips, list and size changes
+    double lev[VRG_FUSE_LEVELS];                                       // the level table
+};
+struct VrgFuseThread {                                                 // what a thread keeps in registers between the phases
+    uint64_t key; uint32_t slot, idx, lev;                             // the flip record k_band appended at place t
+    uint32_t row[4];                                                   // tile row t
+    uint32_t frow[9];                                                  // the nine label rows around flip t (by rank)
+    VrgPre pre;                                                        // per-voxel fields of cube place t
+    float valf; double val64; uint16_t l16;                            // ... its intensity as loaded (whichever storage the volume has: converted when used)
+    VrgEvent ev; uint32_t rn, rd, rf;
+};
+VRG_HD uint32_t vrg_fuse_level_of(const VrgFuseLds& sh, uint32_t L, double v) {   // vrg_level_of on the LDS copy of the table
+    uint32_t lo = 0, hi = L - 1u;
+    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (sh.lev[m] < v) lo = m + 1u; else hi = m; }
+    return lo;
+}
+VRG_HD uint32_t vrg_fuse_tile_row(int dy, int dz) { return (uint32_t)((dz + 4) * 9 + (dy + 4)); }
+VRG_HD uint32_t vrg_fuse_tile_pos(int dx, int dy, int dz) { return (uint32_t)(((dz + 4) * 9 + (dy + 4)) * 9 + (dx + 4)); }
+VRG_HD uint8_t vrg_fuse_tile_byte(const VrgFuseLds& sh, int dx, int dy, int dz) {
+    const uint32_t o = (uint32_t)(dx + 4);
+    return (uint8_t)(sh.tile[4 * vrg_fuse_tile_row(dy, dz) + (o >> 2)] >> (8u * (o & 3u)));
+}
+VRG_HD void vrg_load_row16(const uint8_t* p, uint32_t out[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p));
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+#else
+    __builtin_memcpy(out, p, 16);
+#endif
+}
+// can this trip run fused?  0: yes; > 0: stop reason; < 0: -(bail reason).  The same answer in every workgroup (same inputs).
+VRG_HD int32_t vrg_fuse_gate(const VrgCtx& c, const VrgState& s0, int64_t n_in, uint32_t fuse_max = VRG_FUSE_MAX) {
+    const int32_t stop = vrg_stop_test_v(s0, n_in);
+    if (stop) return stop;
+    if (s0.error) return 1000;
+    if (s0.nf > fuse_max) return -(int32_t)VBAIL_FUSE;
+    const int32_t bail = vrg_capacity_test(c, s0.nf);
+    return bail ? -bail : 0;
+}
+// phase 0: LDS arrays that must start empty (runs while the first loads travel)
+VRG_HD void vrg_fuse_init(VrgFuseLds& sh, uint32_t t) {
+    for (uint32_t i = t; i < 729u; i += VRG_FUSE_THREADS) sh.rank[i] = 0xffffu;
+    if (t < (uint32_t)VRG_FUSE_MAX) { sh.f_L[t] = 0; sh.f_FI[t] = 0; }
+    if (t < 3) sh.n[t] = 0;
+    if (t < 4) sh.d[t] = 0;
+    if (t == 0) { sh.any_pend = 0; sh.changed = 0; sh.nvis = 0; }
+}
+// first batch of loads: the flip record at place t (any place below the capacity is readable, whatever the state says)
+// (every load of the two batches is UNCONDITIONAL, its index clamped into the array instead: a load under a branch makes the
+// compiler wait for everything in flight before the next one - a batch would become a chain of round trips)
+VRG_HD void vrg_fuse_load1(const VrgCtx& c, VrgFuseThread& th, uint32_t t) {
+    const uint32_t q = t < c.fcap ? t : c.fcap - 1u;
+    th.key = c.f_key[q]; th.slot = c.flist[q]; th.idx = c.fr_idx[q]; th.lev = c.fr_lev[q];
+}
+VRG_HD void vrg_fuse_keys(VrgFuseLds& sh, const VrgFuseThread& th, uint32_t t, uint32_t nf) { if (t < nf) sh.key[t] = th.key; }
+// rank of record t = number of smaller keys (keys are distinct): the reference's flip order (:48, :88); the records by rank,
+// the voxel -> rank hash set
+VRG_HD void vrg_fuse_rank(const VrgCtx& c, VrgFuseLds& sh, const VrgFuseThread& th, uint32_t t, uint32_t nf) {
+    if (t >= nf) return;
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < nf; j++) r += sh.key[j] < th.key;
+    int x, y, z; vrg_coords(c, th.idx, x, y, z);
+    sh.f_idx[r] = th.idx; sh.f_slot[r] = th.slot; sh.f_lev[r] = th.lev; sh.f_inner[r] = (uint8_t)!(th.key >> 63);
+    sh.f_x[r] = (uint16_t)x; sh.f_y[r] = (uint16_t)(y + 2); sh.f_z[r] = (uint16_t)(z + 2);    // (+2: never negative, differences unchanged)
+}
+// second batch of loads (addresses follow from the ranked records): tile row t of the workgroup's flip, the per-voxel
+// fields of cube place t, the nine label rows around flip t
+VRG_HD void vrg_fuse_load2(const VrgCtx& c, const VrgFuseLds& sh, VrgFuseThread& th, uint32_t t, uint32_t r, uint32_t nf) {
+    const uint8_t* lab = c.lab[0];
+    const uint32_t fidx = sh.f_idx[r];
+    {   // tile row (t < 81; the other threads re-read row 80).  A row that is not wholly inside the allocation - 16 guard bytes at
+        // either end - belongs to no real voxel's neighbourhood: it reads as out-of-bounds bytes (the load goes to the array's start)
+        const uint32_t tr = t < 81u ? t : 80u;
+        const int ry = (int)(tr % 9u) - 4, rz = (int)(tr / 9u) - 4;
+        const int64_t a = (int64_t)fidx + ((int64_t)rz * c.PY + ry) * c.PX - 4;
+        const bool ok = a >= -16 && a + 16 <= (int64_t)c.PV + 16;
+        vrg_load_row16(lab + (ok ? a : 0), th.row);
+        if (!ok) th.row[0] = th.row[1] = th.row[2] = th.row[3] = 0x01010101u * VB_OOB;
+    }
+    {   // per-voxel fields of cube place t (t < 125; a place outside the real volume is padding - never relabelled: its index is
+        // clamped to stay inside the arrays)
+        const uint32_t tp = t < 125u ? t : 124u;
+        const int dx = (int)(tp % 5u) - 2, dy = (int)((tp / 5u) % 5u) - 2, dz = (int)(tp / 25u) - 2;
+        const int64_t m = (int64_t)fidx + ((int64_t)dz * c.PY + dy) * c.PX + dx;
+        const int64_t lo = (int64_t)vrg_idx(c, 0, 0, 0), hi = (int64_t)vrg_idx(c, c.nx - 1, c.ny - 1, c.nz - 1);
+        const uint32_t ms = (uint32_t)(m < lo ? lo : (m > hi ? hi : m));
+        th.pre.rank = 0; th.pre.lev16 = 0; th.pre.val = 0.0;
+        th.pre.vent = c.vent[ms];
+        // the intensity in all three storage forms, each through a pointer that is valid whatever the volume's storage is (a form
+        // the volume does not have reads bytes of another array, never used): no branch, no conversion here - either would
+        // make the compiler wait for every load in flight
+        const float* pf = c.I ? c.I : reinterpret_cast<const float*>(c.I64);
+        const double* pd = c.I64 ? c.I64 : reinterpret_cast<const double*>(c.I);
+        const uint16_t* p16 = c.lev16 ? c.lev16 : reinterpret_cast<const uint16_t*>(c.I ? (const void*)c.I : (const void*)c.I64);
+        th.valf = pf[ms]; th.val64 = pd[c.I64 ? ms : (ms >> 1)]; th.l16 = p16[ms];
+    }
+    {   // the nine label rows around flip t (t < nf; only a flip-in's are looked at - flip-outs are always applied)
+        const uint32_t idx = sh.f_idx[t < nf ? t : nf - 1u];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int j = 0; j < 9; j++) th.frow[j] = vrg_load_row(lab + ((int64_t)idx + ((j % 3 - 1) * c.PY + (j / 3 - 1)) * c.PX - 1));
+    }
+}
+// which neighbours of a flip-in are listed flips (f_L), and which of those flip-ins (f_FI): every pair of flips is looked at,
+// `parts` threads sharing a flip-in's partners.  (Pairs, not a voxel -> flip hash set probed 26 times per flip: a probe is a
+// chain of dependent LDS reads of ~100 cycles each, while the partners' coordinates are read one after the other, independent
+// of each other.)  Neighbour n of the masks = 3 * j + (dx + 1) with j = 3 * (dy + 1) + (dz + 1).
+VRG_HD void vrg_fuse_listed_nbrs(VrgFuseLds& sh, uint32_t t, uint32_t nf) {
+    const uint32_t parts = nf >= (uint32_t)VRG_FUSE_THREADS ? 1u : (uint32_t)VRG_FUSE_THREADS / nf;
+    const uint32_t f = t / parts, part = t - f * parts;
+    if (f >= nf || sh.f_inner[f]) return;                  // (flip-outs are always applied: only a flip-in's neighbourhood is looked at)
+    const int x = sh.f_x[f], y = sh.f_y[f], z = sh.f_z[f];
+    uint32_t L = 0, FI = 0;
+    for (uint32_t g = part; g < nf; g += parts) {
+        const int dx = (int)sh.f_x[g] - x + 1, dy = (int)sh.f_y[g] - y + 1, dz = (int)sh.f_z[g] - z + 1;
+        if ((uint32_t)dx > 2u || (uint32_t)dy > 2u || (uint32_t)dz > 2u || g == f) continue;
+        const uint32_t bit = 1u << (3u * (3u * (uint32_t)dy + (uint32_t)dz) + (uint32_t)dx);
+        L |= bit;
+        if (!sh.f_inner[g]) FI |= bit;
+    }
+    if (L) vrg_lds_or(&sh.f_L[f], L);
+    if (FI) vrg_lds_or(&sh.f_FI[f], FI);
+}
+// the tile into LDS; the skip rule for flip t (:183-190, :198): a flip-in that dropped to 3 in phase A (a flip-out neighbour and
+// no segmented neighbour left) is pending, every other flip is applied
+VRG_HD void vrg_fuse_prepass(VrgFuseLds& sh, const VrgFuseThread& th, uint32_t t, uint32_t nf) {
+    if (t < 81u) { sh.tile[4 * t] = th.row[0]; sh.tile[4 * t + 1] = th.row[1]; sh.tile[4 * t + 2] = th.row[2]; sh.tile[4 * t + 3] = th.row[3]; }
+    if (t >= nf) return;
+    if (sh.f_inner[t]) { sh.f_P[t] = 1; sh.f_pend[t] = 0; return; }
+    uint32_t S = 0, O = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 9; j++) { S |= vrg_gather3(th.frow[j]) << (3 * j); O |= vrg_gather3(th.frow[j] >> 5) << (3 * j); }
+    const uint32_t ex = ~O & 0x7ffdfffu, L = sh.f_L[t];
+    const bool nFO = (S & L & ex) != 0, nSegA = (S & ~L & ex) != 0;     // (a listed segmented neighbour is a flip-out)
+    const bool pend = nFO && !nSegA;
+    sh.f_P[t] = (uint8_t)!pend; sh.f_pend[t] = (uint8_t)pend;
+    if (pend) vrg_lds_or(&sh.any_pend, 1u);
+}
+// one relaxation of the skip rule's fix-point (vrg_item_fix): applied if an applied flip-in neighbour of smaller rank exists
+VRG_HD void vrg_fuse_fix(const VrgCtx& c, VrgFuseLds& sh, uint32_t t, uint32_t nf) {
+    if (t >= nf || !sh.f_pend[t] || sh.f_P[t]) return;
+    const int x = sh.f_x[t], y = sh.f_y[t], z = sh.f_z[t];
+    for (uint32_t g = 0; g < t; g++) {
+        const int dx = (int)sh.f_x[g] - x + 1, dy = (int)sh.f_y[g] - y + 1, dz = (int)sh.f_z[g] - z + 1;
+        if ((uint32_t)dx > 2u || (uint32_t)dy > 2u || (uint32_t)dz > 2u) continue;
+        if (!sh.f_inner[g] && sh.f_P[g]) { sh.f_P[t] = 1; vrg_lds_or(&sh.changed, 1u); return; }
+    }
+}
+// flip t, if it lies inside the workgroup's tile: its L (+ P) bits into the tile, its rank into the rank tile
+VRG_HD void vrg_fuse_annotate(const VrgCtx& c, VrgFuseLds& sh, uint32_t t, uint32_t r, uint32_t nf) {
+    if (t >= nf) return;
+    const int dx = (int)sh.f_x[t] - (int)sh.f_x[r], dy = (int)sh.f_y[t] - (int)sh.f_y[r], dz = (int)sh.f_z[t] - (int)sh.f_z[r];
+    if (dx < -4 || dx > 4 || dy < -4 || dy > 4 || dz < -4 || dz > 4) return;
+    const uint32_t o = (uint32_t)(dx + 4), bits = (uint32_t)(VB_L | (sh.f_P[t] ? VB_P : 0));
+    vrg_lds_or(&sh.tile[4 * vrg_fuse_tile_row(dy, dz) + (o >> 2)], bits << (8u * (o & 3u)));
+    sh.rank[vrg_fuse_tile_pos(dx, dy, dz)] = (uint16_t)t;
+}
+#if defined(VRG_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define VRG_ISTAMP(c, cond, k) do { if (cond) (c).dbg[k] = wall_clock64(); } while (0)
+#else
+#define VRG_ISTAMP(c, cond, k) do { } while (0)
+#endif
+// cube place t: is this workgroup's flip (rank r) the owner of the voxel - the flip of smallest rank that wants it
+// (vrg_mark_wanted: 1-ring of a listed flip; 2-ring too for an excluded voxel)?  Then the relabel stencil from the tile.
+VRG_HD void vrg_fuse_stencil(const VrgCtx& c, VrgFuseLds& sh, VrgFuseThread& th, uint32_t t, uint32_t r) {
+    th.ev.kind = VE_NONE; th.ev.pend = 0; th.rn = th.rd = th.rf = 0;
+    if (t >= 125u) return;
+    const uint32_t place = r * (uint32_t)VRG_FUSE_PLACES + t;
+    const int dx = (int)(t % 5u) - 2, dy = (int)((t / 5u) % 5u) - 2, dz = (int)(t / 25u) - 2;
+    const uint8_t mb = vrg_fuse_tile_byte(sh, dx, dy, dz);
+    // (smallest rank in the voxel's 3x3x3 - 5x5x5 for an excluded voxel - box of the rank tile; 0xffff = no flip there)
+    uint32_t owner = 0xffffu;
+    uint32_t rk[27];                                       // the ranks of the flips in the voxel's 3x3x3 box, in the masks' neighbour order n = 9 * (dy+1) + 3 * (dz+1) + (dx+1)
+    if (!(mb & VB_OOB)) {
+        const uint16_t* r0 = &sh.rank[vrg_fuse_tile_pos(dx - 1, dy - 1, dz - 1)];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int n = 0; n < 27; n++) rk[n] = r0[((n / 3) % 3) * 81 + (n / 9) * 9 + (n % 3)];      // 27 independent reads
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int n = 0; n < 27; n++) owner = rk[n] < owner ? rk[n] : owner;
+        if (mb & VB_X)                                     // an excluded voxel is also wanted by the flips of its 2-ring
+            for (int ez = -2; ez <= 2; ez++)
+                for (int ey = -2; ey <= 2; ey++) {
+                    const uint16_t* row = &sh.rank[vrg_fuse_tile_pos(dx - 2, dy + ey, dz + ez)];
+                    for (int ex = 0; ex < 5; ex++) owner = row[ex] < owner ? row[ex] : owner;
+                }
+    }
+    VRG_ISTAMP(c, r == 0 && t == 62, 12); VRG_ISTAMP(c, r == 0 && t == 87, 35);
+    if (owner != r) { c.mk_idx[place] = VRG_NONE; return; }
+    const uint32_t m = (uint32_t)((int64_t)sh.f_idx[r] + ((int64_t)dz * c.PY + dy) * c.PX + dx);
+    // the voxel's 3x3x3 masks from the tile rows (bytes x-1 .. x+2 of the nine rows: vrg_preload's layout)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 9; j++) {
+        const uint32_t* rw = &sh.tile[4 * vrg_fuse_tile_row(dy + j / 3 - 1, dz + j % 3 - 1)];
+        const uint64_t w8 = (uint64_t)rw[0] | ((uint64_t)rw[1] << 32);
+        th.pre.w[j] = (uint32_t)(w8 >> (8 * (dx + 3)));
+    }
+    const VrgNbr nb = vrg_masks_of(th.pre.w);
+    uint32_t ex, segA, FO, AP; vrg_nbr_sets(nb, ex, segA, FO, AP);
+    VrgRanks q; vrg_ranks_none(q);                                     // the ranks of the listed neighbours: already in registers (no loop over set bits: no dependent reads)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int n = 0; n < 27; n++) {
+        const uint32_t kk = 26u - vrg_nk((uint32_t)n);
+        if ((FO >> n) & 1u) { if (rk[n] < q.minFO) { q.minFO = rk[n]; q.kFO = kk; } if (rk[n] > q.maxFO) q.maxFO = rk[n]; }
+        if ((AP >> n) & 1u) { if (rk[n] < q.minAP) { q.minAP = rk[n]; q.kAP = kk; } if (rk[n] > q.maxAP) q.maxAP = rk[n]; }
+    }
+    VRG_ISTAMP(c, r == 0 && t == 62, 13); VRG_ISTAMP(c, r == 0 && t == 87, 36);
+    bool ring2 = false;
+    if (vrg_wants_ring2(mb, nb)) {                                     // an applied flip (P and not OOB) within the 2-ring? (vrg_ring2_applied)
+        uint64_t any = 0;
+        const uint32_t o2 = (uint32_t)(dx + 2);
+        for (int j = 0; j < 25; j++) {
+            const uint32_t* rw = &sh.tile[4 * vrg_fuse_tile_row(dy + j % 5 - 2, dz + j / 5 - 2)];
+            const uint64_t lo8 = (uint64_t)rw[0] | ((uint64_t)rw[1] << 32);
+            const uint64_t w8 = o2 ? (lo8 >> (8u * o2)) | ((uint64_t)rw[2] << (64u - 8u * o2)) : lo8;    // bytes x-2 .. x+2
+            any |= ((w8 >> 4) & ~(w8 >> 5)) & 0x0101010101ull;
+        }
+        ring2 = any != 0;
+    }
+    th.pre.rank = sh.rank[vrg_fuse_tile_pos(dx, dy, dz)];              // (its own rank, if the voxel is a listed flip)
+    th.pre.lev16 = th.l16; th.pre.val = c.I ? (double)th.valf : th.val64;
+    // the voxel's level, where the cases will ask for it (c.lev_fast = 1): a flip's from its record; a voxel that may enter the
+    // band or the outer region searches the level table in LDS (through sh, not through the context's generic pointer: a
+    // flat load waits for every atomic the wave has in flight); nobody else pays for a search
+    uint32_t lev_here = 0xffffffffu;
+    if (mb & VB_L) lev_here = sh.f_lev[th.pre.rank];
+    else if (!(mb & VB_B) && ((mb & VB_S) ? FO != 0u : (AP != 0u || (mb & VB_X)))) lev_here = c.lev16 ? th.pre.lev16 : vrg_fuse_level_of(sh, c.L, th.pre.val);
+    VRG_ISTAMP(c, r == 0 && t == 62, 14); VRG_ISTAMP(c, r == 0 && t == 87, 37);
+    const uint8_t nw = vrg_sweep_cases(c, m, mb, th.pre, nb, q, ring2, lev_here, th.ev);
+    VRG_ISTAMP(c, r == 0 && t == 62, 15); VRG_ISTAMP(c, r == 0 && t == 87, 38);
+    c.mk_idx[place] = m; c.mk_new[place] = nw; c.mk_old[place] = mb;
+    if (mb & VB_L) vrg_lds_add(&sh.nvis, 1u);
+    const uint32_t a = vrg_cls_of(mb), b = vrg_cls_of(nw);             // region sizes (:113-116): kept by increments
+    const int din = (int)(b == 1u) - (int)(a == 1u), dout = (int)(b == 2u) - (int)(a == 2u);
+    if (din) vrg_lds_add(&sh.d[2], din);
+    if (dout) vrg_lds_add(&sh.d[3], dout);
+    // the event takes a number inside the workgroup (vrg_ev_write's q, qd, qf)
+    if (th.ev.kind == VE_NEW) th.rn = vrg_lds_add(&sh.n[0], 1u);
+    if (th.ev.kind == VE_DIE) th.rd = vrg_lds_add(&sh.n[1], 1u);
+    if (th.ev.kind != VE_NONE && th.ev.kind != VE_DIE && th.ev.pend) th.rf = vrg_lds_add(&sh.n[2], 1u);
+    const int di = vrg_ev_dni(th.ev), dq = vrg_ev_dno(th.ev);
+    if (di) vrg_lds_add(&sh.d[0], di);
+    if (dq) vrg_lds_add(&sh.d[1], dq);
+    VRG_ISTAMP(c, r == 0 && t == 62, 16);
+    VRG_ISTAMP(c, r == 0 && t == 87, 17);
+}
+// the workgroup reserves its stretch of every list with ONE atomic each (threads 0..8)
+VRG_HD void vrg_fuse_reserve(const VrgCtx& c, VrgFuseLds& sh, uint32_t t) {
+    if (t < 3u) { if (sh.n[t]) sh.base[t] = vrg_atomic_add(t == 0 ? &c.stg->nalloc : t == 1 ? &c.stg->ndead : &c.stg->nfresh, sh.n[t]); }
+    else if (t < 7u) { if (sh.d[t - 3u]) vrg_atomic_add(t == 3 ? &c.stg->d_ni : t == 4 ? &c.stg->d_no : t == 5 ? &c.stg->d_nin : &c.stg->d_nout, sh.d[t - 3u]); }
+    else if (t == 7u) { if (sh.nvis) vrg_atomic_add(&c.stg->nvisit, sh.nvis); }
+}
+// ... and every event is written at its place; the workgroup's flip gets its stamp = (sweep, rank) (:200: segmented's list order)
+VRG_HD void vrg_fuse_commit(const VrgCtx& c, const VrgFuseLds& sh, const VrgFuseThread& th, uint32_t t, uint32_t r) {
+    if (th.ev.kind != VE_NONE) {
+        const int dx = (int)(t % 5u) - 2, dy = (int)((t / 5u) % 5u) - 2, dz = (int)(t / 25u) - 2;
+        const uint32_t m = (uint32_t)((int64_t)sh.f_idx[r] + ((int64_t)dz * c.PY + dy) * c.PX + dx);
+        vrg_ev_write(c, m, th.ev, sh.base[0] + th.rn, sh.base[1] + th.rd, sh.base[2] + th.rf);
+    }
+    if (t == 0) c.stamp[sh.f_idx[r]] = ((uint64_t)(uint32_t)(c.st->iter + 1) << 32) | r;
+}
+// the touched levels of the sweep in ascending order with their counts (for the next k_band's corrections, :236-247), the
+// per-level counters back to zero: level l by whoever closes the sweep (counters read past L1: other workgroups' atomics)
+VRG_HD bool vrg_fuse_level_touched(const VrgCtx& c, uint32_t l, uint32_t& ci, uint32_t& co, uint32_t& cc) {
+    ci = vrg_load_u32(&c.dIn[l]); co = vrg_load_u32(&c.dOut[l]); cc = vrg_load_u32(&c.dConv[l]);
+    return (ci | co | cc) != 0u;
+}
+VRG_HD void vrg_fuse_level_file(const VrgCtx& c, uint32_t q, uint32_t l, double v, uint32_t ci, uint32_t co, uint32_t cc) {
+    c.nz_key[q] = l; c.nz_val[q] = v; c.nz_cin[q] = ci; c.nz_cout[q] = co; c.nz_cconv[q] = cc;
+    c.dIn[l] = 0; c.dOut[l] = 0; c.dConv[l] = 0;
+}
+// the per-level memo of the three corrections (:236-247) for level l from the touched-level list (in LDS: levels' indices and
+// counts), lanes striding over the list, the kernel between two levels from the table - the same terms in the same order as
+// the four-launch chain's closing kernel adds them: the memo is bit-identical whichever kind of trip wrote it
+VRG_HD void vrg_fuse_memo_terms(const VrgCtx& c, uint32_t l, uint32_t lane, uint32_t nnz, const uint32_t* nzl, const uint32_t* cin, const uint32_t* cout,
+                                const uint32_t* cconv, double& a, double& b, double& d) {
+    const double* row = c.ktab + (size_t)l * c.L;
+    a = 0; b = 0; d = 0;
+    for (uint32_t j = lane; j < nnz; j += 64u) {
+        const double k = row[nzl[j]];
+        a += (double)cin[j] * k; b += (double)cout[j] * k; d += (double)cconv[j] * k;
+    }
+}
+// iterNum += 1 (:117) by the ONE thread that closes a fused sweep: region sizes from the increments the stencils added up,
+// the sizes the sweep's dense pass has to reproduce, trace record, and what the next trip's k_band finds to do
+// (in two parts, so that the closing workgroup can request what the first part reads together with the level counters)
+VRG_HD VrgState vrg_fuse_close_load(const VrgCtx& c, int64_t& n_in, int64_t& n_out) {
+    VrgState s = vrg_finalize_load(c, n_in, n_out);
+    s.d_nin = vrg_load_i32(&c.stg->d_nin); s.d_nout = vrg_load_i32(&c.stg->d_nout); s.nvisit = vrg_load_u32(&c.stg->nvisit);
+    return s;
+}
+VRG_HD void vrg_fuse_close(const VrgCtx& c, VrgState s, int64_t n_in, int64_t n_out, uint32_t nnz, bool use_tab) {
+    n_in += s.d_nin; n_out += s.d_nout;
+    if (s.nvisit != s.nf && !s.error) s.error = 3;        // a listed flip the stencils never visited
+    const int64_t k = (int64_t)s.iter + 1;
+    vrg_store_i64(&c.exp_ring[2 * (k % VRG_RING)], n_in); vrg_store_i64(&c.exp_ring[2 * (k % VRG_RING) + 1], n_out);
+    c.inc[VC_NIN] = n_in; c.inc[VC_NOUT] = n_out;
+    const uint32_t places = s.nf * (uint32_t)VRG_FUSE_PLACES;
+    c.nchg[k & 1] = places;                               // (filed by the deferred apply: a change sits at its voxel's place)
+    const uint32_t used = vrg_free_used(s.nalloc, s.nfree), fr_base = s.nfree - used, fr_n = s.ndead;
+    s.nnz = nnz;
+    vrg_finalize_update(c, s, n_in, n_out, use_tab);
+    s.apply_pending = 1; s.ap_n = places; s.fr_base = fr_base; s.fr_n = fr_n;
+    *c.stg = s;
+}
+
+// ---- what the fused sweep left for the next trip's k_band (sweep k = the state's iter: already counted)
+// (place i of the marked list, its three fields fetched by the caller - several places in one batch)
+VRG_HD void vrg_deferred_apply_vals(const VrgCtx& c, uint32_t i, int k, uint32_t idx, uint8_t old, uint8_t nw) {
+    const int p = k & 1;
+    if (idx == VRG_NONE) { c.chg_dw[p][i] = VRG_NOCHG; return; }
+    c.lab[0][idx] = nw;                                    // (clean: no L / P / mark bits - the fused sweep never wrote any)
+    const uint32_t a = vrg_cls_of(old), b = vrg_cls_of(nw);
+    if (a == b) { c.chg_dw[p][i] = VRG_NOCHG; return; }
+    uint32_t dw, sh; vrg_cls_pos(idx, dw, sh);
+    const uint32_t x = (a ^ b) << sh;
+    if (a == 0u) {
+        const uint32_t bit = 1u << ((idx >> 10) & 31u);
+        if (!(vrg_atomic_or(&c.ubits[idx >> 15], bit) & bit)) vrg_atomic_add(&c.uctl[UC_GEN], 1u);
+    }
+    vrg_atomic_xor(&c.clsb[p][dw], x);
+    c.chg_dw[p][i] = dw; c.chg_x[p][i] = x;
+}
+VRG_HD void vrg_deferred_apply(const VrgCtx& c, uint32_t i, int k) { vrg_deferred_apply_vals(c, i, k, c.mk_idx[i], c.mk_old[i], c.mk_new[i]); }
+VRG_HD void vrg_deferred_catchup(const VrgCtx& c, uint32_t i, int k) {   // change i of sweep k-1: class copy k & 1 sat that sweep out
+    const int p = k & 1;
+    const uint32_t dw = c.chg_dw[p ^ 1][i], x = c.chg_x[p ^ 1][i];
+    if (dw != VRG_NOCHG) vrg_atomic_xor(&c.clsb[p][dw], x);
+}
+VRG_HD uint32_t vrg_deferred_catchup_count(const VrgCtx& c, int k) { const uint32_t n = c.nchg[(k & 1) ^ 1]; return n < c.mcap ? n : c.mcap; }
+VRG_HD void vrg_deferred_free(const VrgCtx& c, const VrgState& s, uint32_t j) { c.freel[s.fr_base + j] = c.dead[j]; }
+// one caller, once all of the above has reached memory: the list of sweep k-1 is consumed, the labels of sweep k are in place -
+// its dense pass is due
+VRG_HD void vrg_deferred_done(const VrgCtx& c, int k) {
+    c.nchg[(k & 1) ^ 1] = 0;
+    c.stg->apply_pending = 0; c.stg->fr_n = 0;
+    vrg_drain(); vrg_store_i64(&c.gate[VG_REQ], (int64_t)k);
 }
 
 // ------------------------------------------------------------------ init mode (:129-155)

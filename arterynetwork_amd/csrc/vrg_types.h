@@ -41,7 +41,13 @@ enum : uint8_t { PF_ALIVE = 1, PF_INNER = 2, PF_PEND = 4 };   // PEND: densities
 enum : uint8_t { FR_FINAL = 3, FR_FRESH = 4, FR_WRITTEN = 8 };
 
 // why the one-workgroup sweep kernel handed a trip back to the host (VrgState::bail); nothing was modified
-enum { VBAIL_FLIPS = 1, VBAIL_MARKS = 2, VBAIL_POOL = 3 };
+enum { VBAIL_FLIPS = 1, VBAIL_MARKS = 2, VBAIL_POOL = 3, VBAIL_FUSE = 4 };   // FUSE: more flips than the fused sweep kernel takes (k_sweep)
+
+// The fused sweep (k_sweep, vrg_items.h "fused sweep"): update() of a sweep with at most VRG_FUSE_MAX flips as ONE launch, one
+// flip per workgroup of VRG_FUSE_THREADS threads (thread p < 125 = place p of the flip's 5x5x5 cube, thread t < 81 = row t of
+// its 9x9x9 label tile, thread t < nf = flip t of the sweep's list).
+enum { VRG_KTAB_LEVELS = 2048 };
+enum { VRG_FUSE_MAX = 128, VRG_FUSE_THREADS = 128, VRG_FUSE_LEVELS = 2048, VRG_FUSE_PLACES = 125 };
 
 struct VrgTrace {            // one record per update() call (0 = init)
     int64_t nflip, nseg, n_in, n_out, ni, no;
@@ -88,6 +94,12 @@ struct VrgState {
     int32_t tab_ok;      // decided when update() opens: fewer intensity levels than band entries, a memo pays
     uint32_t ties, near_ties;          // tie / near-tie sign tests since init (atomic counts; see VRG_TIE_REL)
     uint32_t ties_filed, near_filed;   // ... as of the last trace record
+    // the fused sweep defers what nothing on the band side waits for to the NEXT trip's k_band (which reads no labels):
+    int32_t apply_pending;             // the label bytes of sweep `iter` are still to be written (+ class bits, the request for its dense pass)
+    uint32_t ap_n;                     // ... places of the marked list to look at (k_sweep files voxel (flip r, place p) at r * 125 + p; VRG_NONE = nothing there)
+    uint32_t fr_base, fr_n;            // ... and the dead slots still to be put onto the free list: freel[fr_base + j] = dead[j], j < fr_n
+    int32_t d_nin, d_nout;             // region size changes of the sweep in progress (k_sweep adds them up; the closing thread moves them into VrgCtx::inc)
+    uint32_t nvisit;                   // listed flips the fused stencil visited (must equal nf)
 };
 
 // results of the dense recount; written by the dense stream only (own allocation, own cache lines).
@@ -167,6 +179,9 @@ struct VrgCtx {
     double* nz_val;            // ... in ascending order: their values and counts
     uint32_t* nz_cin; uint32_t* nz_cout; uint32_t* nz_cconv;
     double* tabC;              // per-level memo of the three corrections (3*L), see VrgState::use_tab
+    // small level tables (L <= VRG_KTAB_LEVELS): the kernel between every pair of levels, ktab[a * L + b] = A*exp(-0.5*H*(lev[b]-lev[a])^2),
+    // built by vrg_init with the very expression the sweeps evaluate - a correction then costs a load where it cost an exp
+    const double* ktab;
     // band pool, SoA; capacity bcap slots
     uint32_t bcap;
     uint32_t* p_idx;           // voxel

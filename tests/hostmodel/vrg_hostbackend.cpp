@@ -14,11 +14,15 @@
 #include "../../arterynetwork_amd/csrc/vrg_backend.h"
 #include "../../arterynetwork_amd/csrc/vrg_items.h"
 
-struct VrgBackend { uint32_t small_flips = 8; };   // a low limit, so that the hand-back protocol (VBAIL_FLIPS) is exercised all the time
+// low limits, so that the hand-back protocols (VBAIL_FUSE: fused -> four-launch trips, VBAIL_FLIPS: -> host-driven) are exercised all the time
+struct VrgBackend { uint32_t small_flips = 8; uint32_t fuse_max = 5; };
 
 VrgBackend* be_create(int) { return new VrgBackend(); }
 void be_destroy(VrgBackend* b) { delete b; }
-void be_set_tuning(VrgBackend* b, const char* name, long long v) { if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)v; }
+void be_set_tuning(VrgBackend* b, const char* name, long long v) {
+    if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)v;
+    if (std::strcmp(name, "fuse_max") == 0 && v >= 0 && v <= VRG_FUSE_MAX) b->fuse_max = (uint32_t)v;
+}
 void* be_alloc(VrgBackend*, size_t bytes) { return std::malloc(bytes); }
 void be_free(VrgBackend*, void* p) { std::free(p); }
 void be_fill(VrgBackend*, void* p, int byte, size_t bytes) { std::memset(p, byte, bytes); }
@@ -29,6 +33,9 @@ void be_sync(VrgBackend*) {}
 const char* be_last_error(VrgBackend*) { return nullptr; }
 void be_clear_error(VrgBackend*) {}
 uint32_t be_small_flip_limit(VrgBackend* b) { return b->small_flips; }
+uint32_t be_fuse_limit(VrgBackend* b) { return b->fuse_max; }
+bool be_fuse_ok(VrgBackend*, const VrgCtx& c) { return c.L <= (uint32_t)VRG_FUSE_LEVELS; }
+void be_fuse_enter(VrgBackend*, const VrgCtx& c) { if (!c.st->done && !c.st->bail) for (uint32_t j = 0; j < c.st->nnz && j < c.zcap; j++) vrg_item_level_clear(c, j); }
 bool be_wants_sync(VrgBackend*, const VrgCtx&) { return false; }
 
 namespace {
@@ -110,6 +117,10 @@ bool be_build_lev_map(VrgBackend*, const VrgCtx& c, uint16_t* map, uint32_t span
     return true;
 }
 
+void be_build_ktab(VrgBackend*, const VrgCtx& c, double* ktab) {
+    for (uint32_t a = 0; a < c.L; a++) for (uint32_t b = 0; b < c.L; b++) ktab[(size_t)a * c.L + b] = vrg_kern(c, c.lev[b] - c.lev[a]);
+}
+
 void be_build_lev16(VrgBackend*, const VrgCtx& c, uint16_t* dst) {
     std::memset(dst, 0, (size_t)c.PV * 2);
     for_real_voxels(c, [&](uint32_t idx, int, int, int) { dst[idx] = (uint16_t)vrg_level_of(c, vrg_voxel_value(c, idx)); });
@@ -176,9 +187,82 @@ void be_init_finish(VrgBackend*, const VrgCtx& c, be_reduce_fn cb, void* user) {
 int be_comm_unique_id(void*) { return -1; }
 int be_comm_init(VrgBackend*, int, int, const void*) { return -1; }
 
+// k_sweep (the fused sweep), workgroup by workgroup and - inside a workgroup - phase by phase over its 128 threads: the very
+// phase functions the kernel runs between its barriers
+static void fused_update(VrgBackend* b, const VrgCtx& c0) {
+    VrgState& g = *c0.st;
+    const VrgState snap = g;                           // the state as it was when the sweep opened (the kernel's LDS copy)
+    const int32_t gate = vrg_fuse_gate(c0, snap, c0.inc[VC_NIN], b->fuse_max);
+    if (gate) {
+        if (gate > 0) g.done = gate == 1000 ? -1 : gate; else g.bail = -gate;
+        vrg_close_without_update(c0);
+        return;
+    }
+    const uint32_t nf = snap.nf, T = VRG_FUSE_THREADS;
+    VrgState st = snap;
+    std::vector<VrgFuseThread> th(T);
+    VrgFuseLds* shp = new VrgFuseLds();
+    VrgFuseLds& sh = *shp;
+    for (uint32_t r = 0; r < nf; r++) {
+        VrgCtx c = c0;
+        c.st = &st; c.lev_fast = 1; c.lvl_scan = 1;
+        for (uint32_t t = 0; t < T; t++) vrg_fuse_load1(c, th[t], t);
+        for (uint32_t t = 0; t < T; t++) vrg_fuse_init(sh, t);
+        for (uint32_t t = 0; t < T; t++) vrg_fuse_keys(sh, th[t], t, nf);
+        for (uint32_t t = 0; t < T; t++) vrg_fuse_rank(c, sh, th[t], t, nf);
+        for (uint32_t t = 0; t < T; t++) vrg_fuse_load2(c, sh, th[t], t, r, nf);
+        if (!c.lev16) for (uint32_t l = 0; l < c.L; l++) sh.lev[l] = c0.lev[l];
+        for (uint32_t t = 0; t < T; t++) vrg_fuse_listed_nbrs(sh, t, nf);
+        for (uint32_t t = 0; t < T; t++) vrg_fuse_prepass(sh, th[t], t, nf);
+        if (sh.any_pend)
+            for (;;) {
+                for (uint32_t t = 0; t < T; t++) vrg_fuse_fix(c, sh, t, nf);
+                if (!sh.changed) break;
+                sh.changed = 0;
+            }
+        for (uint32_t t = 0; t < T; t++) vrg_fuse_annotate(c, sh, t, r, nf);
+        for (uint32_t t = 0; t < T; t++) vrg_fuse_stencil(c, sh, th[t], t, r);
+        for (uint32_t t = 0; t < T; t++) vrg_fuse_reserve(c, sh, t);
+        for (uint32_t t = 0; t < T; t++) vrg_fuse_commit(c, sh, th[t], t, r);
+    }
+    delete shp;
+    // the workgroup that finishes last: touched levels in ascending order, counters zeroed, the sweep closed
+    uint32_t q = 0;
+    for (uint32_t l = 0; l < c0.L; l++) { uint32_t ci, co, cc; if (vrg_fuse_level_touched(c0, l, ci, co, cc)) vrg_fuse_level_file(c0, q++, l, c0.lev[l], ci, co, cc); }
+    int64_t n_in, n_out;
+    const VrgState fin = vrg_fuse_close_load(c0, n_in, n_out);
+    const bool use_tab = c0.L <= snap.ni + snap.no && c0.ktab != nullptr;
+    if (use_tab) {                                     // (the memo workgroups: one wave per level, lanes striding over the list, a fixed butterfly)
+        std::vector<uint32_t> nzl(q);
+        for (uint32_t j = 0; j < q; j++) nzl[j] = (uint32_t)c0.nz_key[j];
+        for (uint32_t l = 0; l < c0.L; l++) {
+            double a[64], b2[64], d[64];
+            for (uint32_t lane = 0; lane < 64; lane++) vrg_fuse_memo_terms(c0, l, lane, q, nzl.data(), c0.nz_cin, c0.nz_cout, c0.nz_cconv, a[lane], b2[lane], d[lane]);
+            for (int o = 32; o > 0; o >>= 1) for (int i = 0; i < 64; i++) if (!(i & o)) { a[i] += a[i ^ o]; b2[i] += b2[i ^ o]; d[i] += d[i ^ o]; a[i ^ o] = a[i]; b2[i ^ o] = b2[i]; d[i ^ o] = d[i]; }
+            c0.tabC[3 * (size_t)l] = a[0]; c0.tabC[3 * (size_t)l + 1] = b2[0]; c0.tabC[3 * (size_t)l + 2] = d[0];
+        }
+    }
+    vrg_fuse_close(c0, fin, n_in, n_out, q, use_tab);
+}
+
+
 void be_sweep_once(VrgBackend* b, const VrgCtx& c0, int flags, VrgEvents*, be_reduce_fn cb, void* user) {
     VrgState& s = *c0.st;
     if (s.done || s.bail) return;
+    if (s.apply_pending) {                             // (k_band: what the fused sweep before this trip left to do)
+        const int k = s.iter;
+        const VrgState snap0 = s;
+        for (uint32_t i = 0; i < snap0.ap_n; i++) vrg_deferred_apply(c0, i, k);
+        for (uint32_t i = 0, nc = vrg_deferred_catchup_count(c0, k); i < nc; i++) vrg_deferred_catchup(c0, i, k);
+        for (uint32_t j = 0; j < snap0.fr_n; j++) vrg_deferred_free(c0, snap0, j);
+        vrg_deferred_done(c0, k);
+        if (!(flags & VRG_SWEEP_NODENSE)) {            // its dense pass (the device: gate + recount on the other stream, asked for by vrg_deferred_done)
+            dense_stats(c0, c0.lab[0], cb, user);
+            vrg_recount_done(c0, *c0.dn_part);
+            VrgDense tot = *c0.dn;
+            vrg_dense_fin_one(c0, tot);
+        }
+    }
     // the per-launch modes of the batched kernels, alternated so that both forms of every item function run here: the
     // touched levels listed by atomics / found by scanning the counters; a flip's level fetched through its rank / looked up
     VrgCtx c = c0;
@@ -190,7 +274,8 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c0, int flags, VrgEvents*, be_re
         for (uint32_t slot = 0; slot < snap.np; slot++) vrg_item_band(c, snap, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv);
         for (uint32_t i = 0; i < snap.nfx; i++) vrg_exact_serial(c, snap, c.fresh[i], true);
     }
-    // ---- k_sweep
+    if ((flags & VRG_SWEEP_FUSED) && !(flags & (VRG_SWEEP_SYNC | VRG_SWEEP_FULL))) { fused_update(b, c0); return; }
+    // ---- update() as the four-launch chain / host-driven
     if (int32_t stop = vrg_stop_test(c)) { s.done = stop; vrg_close_without_update(c); return; }
     if (s.error) { s.done = -1; return; }
     const uint32_t nf = s.nf;

@@ -75,6 +75,41 @@ def test_hostmodel_random_volumes(hm):
     assert done >= 280, 'too many cases cut short by an exact tie: {} of 300 completed'.format(done)
 
 
+def test_hostmodel_fused_sweeps(hm, golden_loader):
+    """The fused sweep (k_sweep's phase functions, run workgroup by workgroup and thread by thread by the host model) with the
+    limit the device uses (128 flips per sweep; the model's default of 5 keeps the hand-back to the four-launch chain busy
+    instead): every golden stepwise and in one call, random volumes, and a count of the trips that really ran fused."""
+    from arterynetwork_amd._capi import Session
+    fused = 0
+    for name in SMALL:
+        g = golden_loader(name)
+        data, vmap = g.inputs()
+        iterMax = g.max_sweeps if g.max_sweeps >= 0 else 200
+        res, k = parity.run_stepwise(hm, data, vmap, g.H, g.maxSegmentSize, iterMax, density_mode=1, check_hist=True, options={'fuse_max': 128})
+        assert res is not None and k == g.ncalls - 1, name
+        res, k = parity.run_batched(hm, data, vmap, g.H, g.maxSegmentSize, iterMax, density_mode=1, options={'fuse_max': 128, 'small_flips': 64, 'batch': 5})
+        assert res is not None, name
+        s = Session(g.shape, lib=hm)
+        s.set_option('fuse_max', 128)
+        s.set_volume(data); s.set_labels(vmap); s.init(g.H)
+        s.run(iterMax, g.maxSegmentSize, None)
+        fused += s.stats()['fused_trips']
+        off = Session(g.shape, lib=hm)
+        off.set_option('fused', 0)
+        off.set_volume(data); off.set_labels(vmap); off.init(g.H)
+        off.run(iterMax, g.maxSegmentSize, None)
+        assert off.stats()['fused_trips'] == 0
+        assert np.array_equal(s.labels(), off.labels()) and np.array_equal(s.segmented(), off.segmented()), name
+        s.close(); off.close()
+    assert fused > 200, fused
+    sweeps = 0
+    for sd in range(700, 800):
+        I, vm, H, variant, dmode = random_case(sd)
+        res, k = parity.run_stepwise(hm, I, vm, H, None, 40, density_mode=dmode, check_hist=True, options={'sweep_variant': variant, 'fuse_max': 128})
+        sweeps += k
+    assert sweeps > 300
+
+
 def test_hostmodel_arrays_grow_on_demand(hm):
     """Pool and marked-voxel arrays start tiny (capacity_floor 16) and grow when a trip is handed back (VBAIL_MARKS /
     VBAIL_POOL) or when init counts more band voxels than fit; small_flips 0/3/10^6 runs every sweep host-driven /
