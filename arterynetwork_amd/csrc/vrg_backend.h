@@ -75,6 +75,9 @@ void be_sweep_batch(VrgBackend* b, const VrgCtx& c, int flags, int n, VrgEvents*
 // Z-slabs: all-reduce and close the dense passes whose slab sums are still waiting (they are reduced a few sweeps at a
 // time); collective - every rank calls it at the same point.  The engine calls it before it reads results.
 void be_dense_flush(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user);
+// option verify_every != 1 (be_set_tuning): at the end of a run - streams idle, passes closed - count the labels of the last
+// sweep after all and compare with the sizes kept by increments (a mismatch: dctl[VD_ERR] = 5); collective over the ranks
+void be_verify_last(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user);
 // true: this volume's trips should be host-driven (VRG_SWEEP_SYNC) from the start - its level table is so large that
 // the exact densities of new band entries are spread over the whole chip, which the host has to size
 bool be_wants_sync(VrgBackend* b, const VrgCtx& c);

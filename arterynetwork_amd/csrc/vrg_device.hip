@@ -57,6 +57,7 @@ struct VrgBackend {
     int serial = 0;                                   // option "serial_streams": see be_sweep_once
     int skip = 1;                                     // option "skip_excluded": the dense pass does not fetch the intensities of excluded voxels
     int nt_loads = -1;                                // option "nt_loads": -1 = by the size of the pass, 0 / 1 = ordinary / non-temporal loads
+    int verify_every = 1;                             // option "verify_every": the dense pass on every n-th sweep only (0: never)
     int dense_pipe = 1;                               // option "dense_pipe": fp32 storage + skip_excluded run the two-trips-deep recount (k_recount_pipe)
     uint64_t pass_bytes = 0;                          // bytes a dense pass fetches, counted at the end of init (0: not known yet)
     bool fused_memo = false;                          // ... and it kept the per-level memo (k_memo)
@@ -1399,7 +1400,7 @@ __device__ __forceinline__ void load_vals(const VrgCtx& c, uint32_t u, uint32_t 
 // not listed are streamed afterwards for their bytes only.
 template <int UNITS, bool NT, int MODE, bool SKIP>
 __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) {
-    if (check_done && !vrg_dense_due(c)) return;     // k_gate let it through without a sweep to count: the run has stopped
+    if (check_done && check_done != 3 && !c.dctl[VD_GO]) return;     // the gate says: no sweep to count (the run has stopped) or this sweep's pass is left out
     extern __shared__ __attribute__((aligned(16))) float s_val[];   // 16-bit storage: the level values (c.L floats - MODE 3: doubles -, sized at launch)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -1420,7 +1421,7 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
         for (uint32_t k = threadIdx.x; k < c.L; k += TPB) s_dv[k] = (double)(float)c.lev[k];
         __syncthreads();
     }
-    const uint32_t* __restrict__ cls = c.clsb[(vrg_load_i64(&c.dctl[VD_RSEQ]) + 1) & 1];
+    const uint32_t* __restrict__ cls = c.clsb[(vrg_load_i64(&c.dctl[VD_RSEQ]) + (check_done == 3 ? 0 : 1)) & 1];   // (3: the run's last sweep, counted after all)
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
     const uint32_t lo = (2u + (uint32_t)c.z0) * plane;         // this device's Z-slab [z0, z1) as a voxel range
     const uint32_t hi = (2u + (uint32_t)c.z1) * plane;
@@ -1475,7 +1476,7 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
         load_vals<MODE, false, SKIP>(c, edge, lane, w1, f);
         stats_bits<MODE, SKIP>(acc, w1, f, s_val);
     }
-    sweep_finish(c, acc, check_done);
+    sweep_finish(c, acc, check_done == 3 ? 0 : check_done);
 }
 // fp32 storage + skip_excluded (the default; option dense_pipe = 0 switches it off): the same walk, software-pipelined two
 // trips deep.  Every intensity load is issued unconditionally - a lane whose group is excluded reads one fixed dummy line
@@ -1496,14 +1497,14 @@ __device__ __forceinline__ void load_vals_uncond(const VrgCtx& c, uint32_t u, ui
 }
 template <int UNITS, bool NT>
 __global__ void __launch_bounds__(TPB) k_recount_pipe(VrgCtx c, int check_done) {
-    if (check_done && !vrg_dense_due(c)) return;
+    if (check_done && check_done != 3 && !c.dctl[VD_GO]) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t* __restrict__ ulist = c.ulist;
     const uint32_t n = c.uctl[UC_N];
     const uint32_t last = n ? n - 1u : 0u, stride = nwaves * UNITS;
     uint32_t i = __builtin_amdgcn_readfirstlane(wave * UNITS);     // (wave-uniform: the list is read through the scalar cache)
-    const uint32_t* __restrict__ cls = c.clsb[(vrg_load_i64(&c.dctl[VD_RSEQ]) + 1) & 1];
+    const uint32_t* __restrict__ cls = c.clsb[(vrg_load_i64(&c.dctl[VD_RSEQ]) + (check_done == 3 ? 0 : 1)) & 1];   // (3: the run's last sweep, counted after all)
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
     const uint32_t lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
     uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10;
@@ -1547,7 +1548,7 @@ __global__ void __launch_bounds__(TPB) k_recount_pipe(VrgCtx c, int check_done) 
         load_vals<0, false, true>(c, edge, lane, w1e, f);
         stats_bits<0, true>(acc, w1e, f, nullptr);
     }
-    sweep_finish(c, acc, check_done);
+    sweep_finish(c, acc, check_done == 3 ? 0 : check_done);
 }
 // The unit list from the bitmap, by one workgroup of 1024 threads (a few microseconds): thread t counts the set bits of
 // its stretch of bitmap words, a block scan gives its place, it writes its units.  Bitmap words are read past L1 / a
@@ -1591,11 +1592,24 @@ __device__ void ulist_refresh(const VrgCtx& c, bool force) {
 __global__ void __launch_bounds__(GATE_THREADS) k_ulist_init(VrgCtx c) { ulist_refresh(c, true); }
 // in front of every recount (dense stream): wait for the sweep's labels, then bring the unit list up to date if that sweep
 // (or an earlier one) listed a new unit - rare: label 4 turns into 3 only next to the band
-__global__ void __launch_bounds__(GATE_THREADS) k_gate(VrgCtx c) {
-    if (threadIdx.x == 0) (void)gate_dense_due(c);
+// ... or, with option verify_every, close the sweep's pass without a count (fin = 2: one GPU, the pass is closed here; 1: the
+// marker travels through the staged all-reduce like a slab's sums).  VD_GO tells the recount behind the gate what to do.
+__global__ void __launch_bounds__(GATE_THREADS) k_gate(VrgCtx c, int every, int fin) {
+    __shared__ int s_go;
+    if (threadIdx.x == 0) {
+        int go = gate_dense_due(c) ? 1 : 0;
+        if (go && every != 1 && vrg_dense_skipped(c.dctl[VD_RSEQ] + 1, every)) {
+            vrg_recount_done(c, vrg_dense_skip_marker());
+            if (fin == 2) vrg_dense_fin_one(c, vrg_dense_skip_marker());
+            go = 0;
+        }
+        c.dctl[VD_GO] = go;
+        s_go = go;
+    }
     __syncthreads();
-    ulist_refresh(c, false);
+    if (s_go) ulist_refresh(c, false);
 }
+__global__ void k_verify_last(VrgCtx c) { vrg_dense_verify_last(c, c.world == 1 ? *c.dn_part : *c.dn); }
 __global__ void k_cls_build(VrgCtx c) {
     const uint32_t nd = (uint32_t)((((uint64_t)c.PV + 1023u) >> 10) << 6);
     // (a wave = the 64 class words of ONE 1024-voxel unit: one atomic per listed unit instead of one per non-empty word - 14 M
@@ -1852,7 +1866,10 @@ int dense_blocks(const VrgBackend* b, const VrgCtx& c) {
     // fp32: whole or half multiples of the CU count only - 552 or 640 workgroups leave some CUs with a wave more than others for
     // the whole pass (880x880x160: 552 -> 0.058 ms, 384 -> 0.050; 880x880x320: 640 -> 0.103, 512 -> 0.094, 768 -> 0.091 but a
     // slower step, 0.1035 vs 0.1003, the band chain queueing behind three waves per SIMD); one session, tools/gpu_slabsweep.sh
-    const uint64_t pick = units <= 100000 ? 256 : units <= 200000 ? 384 : units <= 350000 ? 512 : 768;
+    // (round 4, with the fused band chain beside the pass - fewer dependent round trips for the pass's loads to delay: 80-plane
+    // slab 256 -> 0.0419 ms/step, 384 -> 0.0382, 512 -> 0.0392; 160 planes 384 -> 0.0577, 512 -> 0.0552, 768 -> 0.0582; 512x512x170
+    // 256 -> 0.0343, 384 -> 0.0347, 512 -> 0.0509: the band kernels then wait for a place on the chip)
+    const uint64_t pick = units <= 50000 ? 256 : units <= 100000 ? 384 : units <= 350000 ? 512 : 768;
     return (int)std::min<uint64_t>(pick, std::max<uint64_t>(64, units / 160));
 }
 
@@ -1921,6 +1938,7 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "band_hint") == 0) b->band_hint = (uint32_t)std::min<long long>(std::max<long long>(v, 0), 0x7fffffff);
     if (std::strcmp(name, "direct_hint") == 0) b->direct_hint = v != 0;
     if (std::strcmp(name, "dense_pipe") == 0) b->dense_pipe = (int)v;
+    if (std::strcmp(name, "verify_every") == 0 && v >= 0) b->verify_every = (int)std::min<long long>(v, 1 << 20);
     if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)std::min<long long>(v, NF_SMALL);
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != b->prio_mode) { b->prio_mode = (int)v; make_streams(b); }
 }
@@ -2154,8 +2172,8 @@ static void launch_recount_as(const VrgCtx& c, int blocks, int check, hipStream_
 }
 // nt: non-temporal loads - for a pass that is larger than the 256-MiB Infinity Cache, where nothing is worth keeping;
 // a smaller slab is read with ordinary loads and then comes out of that cache sweep after sweep.
-static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t st, bool skip, bool nt, hipEvent_t e_start = nullptr, hipEvent_t e_stop = nullptr) {
-    if (check) k_gate<<<1, GATE_THREADS, 0, st>>>(c);        // waits (on the device) until the sweep's labels are in place; keeps the unit list current
+static void launch_recount(const VrgCtx& c, int blocks, int check, hipStream_t st, bool skip, bool nt, hipEvent_t e_start = nullptr, hipEvent_t e_stop = nullptr, int every = 1) {
+    if (check == 1 || check == 2) k_gate<<<1, GATE_THREADS, 0, st>>>(c, every, check);        // waits (on the device) until the sweep's labels are in place; keeps the unit list current
     if (skip) { if (nt) launch_recount_as<true, true>(c, blocks, check, st, e_start, e_stop); else launch_recount_as<false, true>(c, blocks, check, st, e_start, e_stop); }
     else { if (nt) launch_recount_as<true, false>(c, blocks, check, st, e_start, e_stop); else launch_recount_as<false, false>(c, blocks, check, st, e_start, e_stop); }
 }
@@ -2323,12 +2341,12 @@ static void enqueue_dense(VrgBackend* b, const VrgCtx& c, hipEvent_t e_start, hi
     if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sa));
     const bool ranks = c.world > 1 || b->comm || cb;
     if (b->dense_pipe && c.I && !c.lev16 && b->skip) {
-        k_gate<<<1, GATE_THREADS, 0, b->sb>>>(c);
         const int check = ranks ? 1 : 2;
+        k_gate<<<1, GATE_THREADS, 0, b->sb>>>(c, b->verify_every, check);
         if (dense_nt(b, c)) hipExtLaunchKernelGGL((k_recount_pipe<3, true>), dim3(dense_blocks(b, c)), dim3(TPB), 0, b->sb, e_start, e_stop, 0, c, check);
         else hipExtLaunchKernelGGL((k_recount_pipe<3, false>), dim3(dense_blocks(b, c)), dim3(TPB), 0, b->sb, e_start, e_stop, 0, c, check);
     } else
-    launch_recount(c, dense_blocks(b, c), ranks ? 1 : 2, b->sb, b->skip != 0, dense_nt(b, c), e_start, e_stop);
+    launch_recount(c, dense_blocks(b, c), ranks ? 1 : 2, b->sb, b->skip != 0, dense_nt(b, c), e_start, e_stop, b->verify_every);
     if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sb));
     // one GPU: the last workgroup of the recount closes the pass itself.  Z-slabs: the slab sums of DENSE_GROUP recounts
     // are summed over the ranks by ONE all-reduce (nothing on the band side waits for it: the decisions use the
@@ -2339,6 +2357,17 @@ static void enqueue_dense(VrgBackend* b, const VrgCtx& c, hipEvent_t e_start, hi
 // n trips in a row: what the engine enqueues between two looks at the state
 void be_sweep_batch(VrgBackend* b, const VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user) {
     for (int i = 0; i < n; i++) be_sweep_once(b, c, flags, ev, cb, user);
+}
+
+// option verify_every != 1, at the end of a run (both streams idle, every pass closed): the labels of the last sweep counted
+// after all and compared with the sizes kept by increments (collective on several ranks)
+void be_verify_last(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
+    use_device(b);
+    if (b->verify_every == 1) return;
+    launch_recount(c, dense_blocks(b, c), 3, b->sa, b->skip != 0, dense_nt(b, c));      // (check 3: no gate - launch_recount puts one in front of checks 1 and 2 only)
+    reduce_dense(b, c, cb, user, b->sa);
+    k_verify_last<<<1, 1, 0, b->sa>>>(c);
+    HIP_CHECK(hipStreamSynchronize(b->sa));
 }
 
 void be_dense_flush(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {

@@ -28,6 +28,7 @@ struct vrg_handle {
     int device = 0;
     bool have_vol = false, have_lab = false, inited = false;
     bool sync_mode = false;              // trips are driven one at a time from the host (many flips per sweep)
+    int verify_every = 1;                // option "verify_every"
     int fused = 1;                       // option "fused": sweeps with few flips run update() as ONE launch (k_sweep)
     bool fuse_mode = false;              // ... and the trips being enqueued now are of that kind
     int variant = 0, batch = 8, storage16 = 0, dense_off = 0;
@@ -228,6 +229,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "dense_off") h->dense_off = value != 0;   // measurement aid: band chain alone; re-initialise afterwards
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
     else if (n == "fused") h->fused = value != 0;
+    else if (n == "verify_every") { if (value < 0) return fail(h, VRG_E_ARG, "verify_every: 0 (never), 1 (every sweep: the default) or n > 1 (every n-th sweep)"); h->verify_every = (int)std::min<int64_t>(value, 1 << 20); be_set_tuning(h->be, name, value); }
     else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "fuse_max" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads" || n == "dense_pipe") be_set_tuning(h->be, name, value);
     else if (n == "storage16") h->storage16 = value != 0;      // takes effect at the next vrg_init
     else return fail(h, VRG_E_ARG, "unknown option " + n);
@@ -439,6 +441,9 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     }
     if (!h->dense_off) be_dense_flush(be, c, h->reduce_fn, h->reduce_user);   // Z-slabs: close the passes still waiting for their all-reduce
     be_sync(be);
+    // passes were left out (option verify_every): the run's last sweep is counted after all, so that the sizes kept by
+    // increments never leave a run unchecked
+    if (!h->dense_off && h->verify_every != 1 && s.iter > iter0 && !s.error) be_verify_last(be, c, h->reduce_fn, h->reduce_user);
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     int64_t dense_err = 0;                           // raised by the dense stream, possibly after the band side stopped
     be_download(be, &dense_err, c.dctl + VD_ERR, sizeof(dense_err));

@@ -758,6 +758,13 @@ VRG_HD void vrg_ulist_rebuild_serial(const VrgCtx& c) {
 // (the expected sizes and every class bit of the sweep have reached memory before the request does)
 VRG_HD void vrg_request_dense(const VrgCtx& c) { vrg_drain(); vrg_store_i64(&c.gate[VG_REQ], (int64_t)c.st->iter + 1); }
 VRG_HD bool vrg_dense_due(const VrgCtx& c) { return vrg_load_i64(&c.gate[VG_REQ]) > vrg_load_i64(&c.dctl[VD_RSEQ]); }
+// Option verify_every = n: the dense pass (:113-116 - here a CHECK of the sizes kept by increments, and the source of the trace's
+// intensity sums) runs on every n-th sweep only (0: never; the run's last sweep is then checked when it ends).  Is sweep number k's
+// pass left out?
+VRG_HD bool vrg_dense_skipped(int64_t k, int64_t every) { return every == 0 || (every > 1 && k % every != 0); }
+// ... then the pass is closed without a count: a marker (negative sizes) takes the place of the slab sums, so that the sequence
+// of passes - which class copy the next one reads, what k_close / k_band wait for - stays what it is
+VRG_HD VrgDense vrg_dense_skip_marker() { VrgDense d; d.n_in = -1.0; d.n_out = -1.0; d.sum_in = 0.0; d.sum_out = 0.0; return d; }
 // recount number rseq = recounts done + 1 (it read class copy rseq & 1) has this device's slab sums: keep them for the pass
 VRG_HD void vrg_recount_done(const VrgCtx& c, const VrgDense& part) {
     const int64_t rseq = c.dctl[VD_RSEQ] + 1;
@@ -767,10 +774,23 @@ VRG_HD void vrg_recount_done(const VrgCtx& c, const VrgDense& part) {
 // close pass seq = passes closed + 1 with its totals over all slabs: cross-check the sizes it had to reproduce, file the sums
 VRG_HD void vrg_dense_fin_one(const VrgCtx& c, const VrgDense& d) {
     const int64_t seq = c.dctl[VD_SEQ] + 1;
+    if (d.n_in < 0.0) {                                   // a pass that was left out (verify_every): no sums for this sweep's trace record
+        if ((uint64_t)seq < c.trace_cap) { c.trace[seq].sum_in = __builtin_nan(""); c.trace[seq].sum_out = __builtin_nan(""); }
+        c.dctl[VD_SEQ] = seq;
+        return;
+    }
     if ((int64_t)d.n_in != c.exp_ring[2 * (seq % VRG_RING)] || (int64_t)d.n_out != c.exp_ring[2 * (seq % VRG_RING) + 1]) c.dctl[VD_ERR] = 5;
     if ((uint64_t)seq < c.trace_cap) { c.trace[seq].sum_in = d.sum_in; c.trace[seq].sum_out = d.sum_out; }
     *c.dn = d;
     c.dctl[VD_SEQ] = seq;
+}
+// the run has ended with passes left out: the labels of the last sweep counted after all (its class copy: the one pass number
+// RSEQ read or would have read) - `d` = the totals over all slabs - against the sizes kept by increments; the sums go to the trace
+VRG_HD void vrg_dense_verify_last(const VrgCtx& c, const VrgDense& d) {
+    const int64_t seq = c.dctl[VD_RSEQ];
+    if ((int64_t)d.n_in != vrg_load_i64(&c.inc[VC_NIN]) || (int64_t)d.n_out != vrg_load_i64(&c.inc[VC_NOUT])) c.dctl[VD_ERR] = 5;
+    if (seq > 0 && (uint64_t)seq < c.trace_cap) { c.trace[seq].sum_in = d.sum_in; c.trace[seq].sum_out = d.sum_out; }
+    *c.dn = d;
 }
 // Z-slabs: the partial sums of the recounts not yet closed, packed (zero-padded to a fixed length) for one all-reduce
 VRG_HD void vrg_dense_pack(const VrgCtx& c) {
@@ -789,7 +809,7 @@ VRG_HD void vrg_dense_fin_staged(const VrgCtx& c) {
 // init: the dense pass founds the incremental sizes
 VRG_HD void vrg_init_counts(const VrgCtx& c) {
     c.inc[VC_NIN] = (int64_t)c.dn->n_in; c.inc[VC_NOUT] = (int64_t)c.dn->n_out; c.gate[VG_REQ] = 0; c.gate[VG_STOP] = 0;
-    c.dctl[VD_SEQ] = 0; c.dctl[VD_ERR] = 0; c.dctl[VD_RSEQ] = 0; c.dctl[VD_NST] = 0; c.nchg[0] = 0; c.nchg[1] = 0;
+    c.dctl[VD_SEQ] = 0; c.dctl[VD_ERR] = 0; c.dctl[VD_RSEQ] = 0; c.dctl[VD_NST] = 0; c.dctl[VD_GO] = 0; c.nchg[0] = 0; c.nchg[1] = 0;
 }
 
 // ------------------------------------------------------------------ closing the sweep

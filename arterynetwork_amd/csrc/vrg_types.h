@@ -121,7 +121,9 @@ enum { VG_REQ = 0, VG_STOP = 1 };
 // cross-checked against the incremental sizes and filed in the trace (on one GPU the recount closes its own pass; with
 // Z-slabs the partial sums of several recounts are all-reduced together, so VD_SEQ trails VD_RSEQ); VD_ERR: a pass
 // disagreed with the incremental sizes; VD_NST: entries of the staged all-reduce
-enum { VD_SEQ = 0, VD_ERR = 1, VD_RSEQ = 2, VD_NST = 3 };
+// VD_GO: written by the gate in front of a recount - 1: count the sweep now; 0: nothing to count (the run has stopped) or the
+// sweep's pass is left out (option verify_every)
+enum { VD_SEQ = 0, VD_ERR = 1, VD_RSEQ = 2, VD_NST = 3, VD_GO = 4 };
 enum { UC_N = 0, UC_LGEN = 1, UC_GEN = 16 };       // VrgCtx::uctl
 enum { VRG_RING = 64, VRG_STAGE = 16 };           // sweeps a recount result / expected size is kept for; slab sums per all-reduce
 

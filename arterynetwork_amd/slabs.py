@@ -79,6 +79,29 @@ def make_slab_session(shape, rank, world, device=0, lib=None, reduce='rccl', gro
     return s
 
 
+def one_gpu_step_ms(shape, world, planes, args):
+    """ms/step of the committed one-GPU bench line of the volume this slab is a share of (profiles/r0x_bench_<nx>.json, newest
+    round first): with one forced rank (--force-dist on a slab shape) the volume is planes * 8 deep by convention of the slab
+    lines (880x880x80 stands for an eighth of 880x880x640); None when no such line is committed."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    nz = shape[2] if world > 1 else {80: 640, 160: 640, 320: 640}.get(shape[2], shape[2])
+    want = '{}x{}x{}'.format(shape[0], shape[1], nz)
+    if getattr(args, 'storage16', False) or getattr(args, 'no_brain_mask', False) or getattr(args, 'levels', 255) != 255:
+        return None
+    for f in sorted(glob.glob(os.path.join(root, 'profiles', 'r*_bench_*.json')), reverse=True):
+        try:
+            d = json.loads(open(f).read().strip().splitlines()[-1])
+            if d.get('n_gpus') == 1 and d.get('valid') and want in d.get('metric', '') and 'single GPU' in d['config'].get('parallelism', '') \
+                    and 'fp32' in d['config'].get('intensity_storage', ''):
+                return d['ms_per_step']
+        except Exception:
+            continue
+    return None
+
+
 def bench_slabs(shape, args, dev, rank, world, roofline, configure, load_traffic):
     """bench.py body for N > 1 ranks (the twin of its one-GPU body: same options through `configure`): every rank generates
     the same synthetic volume in its HBM, recounts its own Z-slab; barrier + synchronize around exactly K sweeps; MAX
@@ -124,6 +147,15 @@ def bench_slabs(shape, args, dev, rank, world, roofline, configure, load_traffic
                                       'band_chain_beside_dense_ms': round(chain_beside, 4), 'band_chain_ms': chain.get('band_chain_ms'),
                                       'seconds': round(dt, 4), 'dense_bytes': int(dense_bytes) if dense_bytes else None,
                                       'rccl_ranks': s.comm_ranks, 'reduction': s.reduce_mode})
+    # what bounds the step of one rank, and the whole-job ratio it allows: every rank repeats the whole band chain (replicated
+    # labels), so the ratio to one GPU cannot exceed (one-GPU step) / (band chain) however many ranks share the dense pass
+    chain_floor = chain_max if chain_max else (chain.get('band_chain_ms') or 0.0)
+    t1 = one_gpu_step_ms(shape, world, z1 - z0, args)
+    scaling_floor = {'chain_ms': round(chain_floor, 4) if chain_floor else None, 'slab_recount_ms': round(kern_ms, 4),
+                     'one_gpu_step_ms': t1, 'amdahl_max': round(t1 / chain_floor, 2) if (t1 and chain_floor) else None,
+                     'note': 'chain_ms = band chain of a sweep beside the dense pass (every rank repeats it); slab_recount_ms = this rank\'s dense pass; '
+                             'one_gpu_step_ms = the committed one-GPU line of the whole volume (profiles/), null when there is none; '
+                             'amdahl_max = one_gpu_step_ms / chain_ms = the ratio to one GPU no number of ranks can exceed'}
     out = {
         'metric': 'Mvoxel-iters/sec, VRG sweep, {} volume'.format(args.shape),
         'value': round(V * r.sweeps / dt_max / 1e6, 1), 'unit': 'Mvoxel-iter/s', 'n_gpus': world,
@@ -143,6 +175,7 @@ def bench_slabs(shape, args, dev, rank, world, roofline, configure, load_traffic
                    'band_chain_beside_dense_ms': round(chain_max, 4) if chain_max else None,
                    'band_chain_ms': chain.get('band_chain_ms'), 'band_chain_note': chain.get('band_chain_note'),
                    'dense_pass_loads': 'non-temporal' if st['dense_nt_loads'] else 'ordinary', 'dense_workgroups': st['dense_workgroups'],
+                   'scaling_floor': scaling_floor,
                    'ranks': per_rank},
         'roofline': roofline(shape, z1 - z0, kern_ms, int(r.sweep_launches), load_traffic(shape, world, args.storage16, z1 - z0),
                              args.storage16, dense_bytes, st['dense_kernel']),

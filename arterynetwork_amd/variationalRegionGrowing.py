@@ -33,7 +33,7 @@ def _finish_messages(reason, iterNum, nseg, nonzero, segmented):
 
 
 def variationalRegionGrowing(dataArray, valueMap, H=2.25, maxSegmentSize=5000, *, iterMax=200,
-                             maxTime=120.0, device=0, trace=None, quiet=False, options=None):
+                             maxTime=120.0, device=0, trace=None, quiet=False, options=None, verify_every=1):
     """
     Variational region growing (https://ieeexplore.ieee.org/document/7096420) on an MI355X.
 
@@ -54,6 +54,12 @@ def variationalRegionGrowing(dataArray, valueMap, H=2.25, maxSegmentSize=5000, *
         The reference's hard-coded 200 iterations (:56) and 120 s (:97); ``maxTime=None`` disables.
     device : int
         HIP device ordinal.
+    verify_every : int, keyword-only
+        The reference recounts innerSize / outerSize densely after every iteration (:113-116).  Here the decisions read sizes
+        kept by increments as labels change, and the dense pass over every voxel only CHECKS them (and supplies the trace's
+        intensity sums): 1 (default) runs it after every sweep like the reference; n > 1 after every n-th sweep; 0 never -
+        the last sweep of the call is then checked when the call ends, so a run never returns unchecked.  Results are
+        identical for every value; at 880x880x640 a sweep costs 0.19 ms with the pass and about 0.03 ms without.
     trace : list, optional
         If given, receives one dict per update() call (0 = init): nflip, nseg, n_in, n_out, ni, no,
         sum_in, sum_out.
@@ -75,6 +81,10 @@ def variationalRegionGrowing(dataArray, valueMap, H=2.25, maxSegmentSize=5000, *
     with Session(dataArray.shape, device=device) as s:
         for k, v in (options or {}).items():
             s.set_option(k, v)
+        if verify_every != 1:
+            if int(verify_every) != verify_every or verify_every < 0:
+                raise ValueError('verify_every must be 0 (never), 1 (every sweep) or n > 1 (every n-th sweep)')
+            s.set_option('verify_every', int(verify_every))
         try:
             s.set_volume(dataArray)
             s.set_labels(valueMap)

@@ -234,17 +234,52 @@ def cpu_baseline(I_t, vm_t, H, levels_note, min_free_gb=48.0, crop_vox=70e6):
             'reference_itself': REFERENCE_ITSELF}
 
 
+def visible_gpus():
+    """Devices this process could use (torch.cuda.device_count() does not initialise the GPU on this image)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def preflight(n, rank=None, local_rank=None):
+    """--gpus N needs N visible devices: say so and leave with exit code 2 BEFORE anything is spawned or initialised
+    (a rank that finds no device of its own would otherwise fail somewhere inside the rendezvous)."""
+    have = visible_gpus()
+    if have < n or (local_rank is not None and local_rank >= have):
+        who = '' if rank is None else '[rank {}] '.format(rank)
+        sys.stderr.write('{}bench.py: --gpus {} needs {} visible GPUs, this node shows {} (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); '
+                         'nothing was run\n'.format(who, n, n, have))
+        raise SystemExit(2)
+
+
 def spawn_ranks(args_list, n):
     """--gpus N without a launcher: start the N ranks as a child torch.distributed.run (this process has not touched the
-    GPU), pass the child's output through, exit with its code."""
+    GPU), pass the child's output through, exit with its code.  Every rank's stderr is also kept in a log directory; when
+    the launch fails the tail of each is printed with its rank, so a failure of one rank cannot hide behind the
+    launcher's summary."""
+    import glob
     import socket
+    import tempfile
+    preflight(n)
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
+    logdir = tempfile.mkdtemp(prefix='bench_ranks_')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + args_list
+           '--master-port', str(port), '--log-dir', logdir, '--tee', '3', os.path.abspath(__file__)] + args_list
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-    return subprocess.call(cmd, env=env)
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        sys.stderr.write('bench.py: the {}-rank launch failed with exit code {}; stderr of every rank (last 25 lines each):\n'.format(n, rc))
+        for f in sorted(glob.glob(os.path.join(logdir, '**', 'stderr.log'), recursive=True)):
+            try:
+                tail = open(f, errors='replace').read().strip().splitlines()[-25:]
+            except OSError:
+                continue
+            sys.stderr.write('---- {}\n{}\n'.format(os.path.relpath(f, logdir), '\n'.join(tail)))
+    return rc
 
 
 def main():
@@ -283,6 +318,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
         raise SystemExit('--gpus {} but the launcher started {} ranks'.format(args.gpus, world))
+    if world > 1:
+        preflight(world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU path)')
     torch.cuda.set_device(local_rank)
@@ -299,7 +336,13 @@ def main():
         if 'MASTER_ADDR' not in os.environ:
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=dev)
-        out = slabs.bench_slabs(shape, args, dev, rank, world, roofline, configure, load_traffic)
+        try:
+            out = slabs.bench_slabs(shape, args, dev, rank, world, roofline, configure, load_traffic)
+        except Exception:
+            import traceback
+            sys.stderr.write('[rank {} of {}] bench_slabs failed:\n{}'.format(rank, world, traceback.format_exc()))
+            sys.stderr.flush()
+            raise
         if rank == 0:
             print(json.dumps(out), flush=True)
         dist.barrier()

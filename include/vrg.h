@@ -98,6 +98,14 @@ const char* vrg_last_error(const vrg_handle* h);
  *                    the whole slab.  Same sums bit for bit.
  *   "nt_loads"       any time; -1 (default): the dense pass uses non-temporal loads when it fetches more than the
  *                    Infinity Cache can keep (about 300 MB per pass) and ordinary loads below that; 0 / 1 force one
+ *   "verify_every"   any time; n = 1 (default): the dense pass over every voxel - the reference's recount of innerSize /
+ *                    outerSize (:113-116), here a CHECK of the sizes the decisions read (kept by increments) and the source
+ *                    of the trace's intensity sums - runs after every sweep; n > 1: after every n-th sweep; 0: never.
+ *                    Labels, lists and densities do not depend on it; the trace's sum_in / sum_out are NaN for sweeps whose
+ *                    pass was left out; the LAST sweep of a vrg_run call is counted when the call ends whatever n is
+ *                    (a mismatch surfaces as VRG_E_INTERNAL), so no run returns unchecked.  The handle stays valid.
+ *   "fused"          any time; 1 (default): a sweep with at most 128 flips runs update() (:156-259) as ONE launch (k_sweep);
+ *                    0: always the four-launch chain (k_order, k_mark_relabel, k_close).  Same results.
  *   "dense_off"      any time; measurement aid: the dense recount is not launched (the band chain alone);
  *                    the handle has to be initialised again afterwards
  *   "sweep_blocks", "prio_mode"

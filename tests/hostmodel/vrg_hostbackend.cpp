@@ -15,13 +15,14 @@
 #include "../../arterynetwork_amd/csrc/vrg_items.h"
 
 // low limits, so that the hand-back protocols (VBAIL_FUSE: fused -> four-launch trips, VBAIL_FLIPS: -> host-driven) are exercised all the time
-struct VrgBackend { uint32_t small_flips = 8; uint32_t fuse_max = 5; };
+struct VrgBackend { uint32_t small_flips = 8; uint32_t fuse_max = 5; int verify_every = 1; };
 
 VrgBackend* be_create(int) { return new VrgBackend(); }
 void be_destroy(VrgBackend* b) { delete b; }
 void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)v;
     if (std::strcmp(name, "fuse_max") == 0 && v >= 0 && v <= VRG_FUSE_MAX) b->fuse_max = (uint32_t)v;
+    if (std::strcmp(name, "verify_every") == 0 && v >= 0) b->verify_every = (int)v;
 }
 void* be_alloc(VrgBackend*, size_t bytes) { return std::malloc(bytes); }
 void be_free(VrgBackend*, void* p) { std::free(p); }
@@ -141,9 +142,9 @@ void be_init_sort(VrgBackend*, const VrgCtx& c, uint32_t n_in, uint32_t n_out) {
 }
 
 // the dense recount over this handle's Z-slab, then the sum over the slabs (callback) if there are several
-static void dense_stats(const VrgCtx& c, const uint8_t* lab, be_reduce_fn cb, void* user) {
+static void dense_stats(const VrgCtx& c, const uint8_t* lab, be_reduce_fn cb, void* user, int last = 0) {
     int64_t a = 0, b = 0; double sa = 0, sb = 0;
-    const uint32_t* cls = c.clsb[(c.dctl[VD_RSEQ] + 1) & 1];
+    const uint32_t* cls = c.clsb[(c.dctl[VD_RSEQ] + (last ? 0 : 1)) & 1];
     if (c.uctl[UC_LGEN] != c.uctl[UC_GEN]) vrg_ulist_rebuild_serial(c);          // (the device: k_gate, before every recount)
     std::vector<uint8_t> in_list((((size_t)c.PV + 1023) >> 10) + 1, 0);
     for (uint32_t i = 0; i < c.uctl[UC_N]; i++) { if (i && c.ulist[i] <= c.ulist[i - 1]) c.st->error = 6; in_list[c.ulist[i]] = 1; }
@@ -186,6 +187,24 @@ void be_init_finish(VrgBackend*, const VrgCtx& c, be_reduce_fn cb, void* user) {
 
 int be_comm_unique_id(void*) { return -1; }
 int be_comm_init(VrgBackend*, int, int, const void*) { return -1; }
+
+// the dense pass of the sweep just applied - or, with option verify_every, its marker (k_gate)
+static void dense_pass(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
+    if (b->verify_every != 1 && vrg_dense_skipped(c.dctl[VD_RSEQ] + 1, b->verify_every)) {
+        vrg_recount_done(c, vrg_dense_skip_marker());
+        vrg_dense_fin_one(c, vrg_dense_skip_marker());
+        return;
+    }
+    dense_stats(c, c.lab[0], cb, user);
+    vrg_recount_done(c, *c.dn_part);
+    VrgDense tot = *c.dn;
+    vrg_dense_fin_one(c, tot);
+}
+void be_verify_last(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
+    if (b->verify_every == 1) return;
+    dense_stats(c, c.lab[0], cb, user, 1);
+    vrg_dense_verify_last(c, *c.dn);
+}
 
 // k_sweep (the fused sweep), workgroup by workgroup and - inside a workgroup - phase by phase over its 128 threads: the very
 // phase functions the kernel runs between its barriers
@@ -256,12 +275,7 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c0, int flags, VrgEvents*, be_re
         for (uint32_t i = 0, nc = vrg_deferred_catchup_count(c0, k); i < nc; i++) vrg_deferred_catchup(c0, i, k);
         for (uint32_t j = 0; j < snap0.fr_n; j++) vrg_deferred_free(c0, snap0, j);
         vrg_deferred_done(c0, k);
-        if (!(flags & VRG_SWEEP_NODENSE)) {            // its dense pass (the device: gate + recount on the other stream, asked for by vrg_deferred_done)
-            dense_stats(c0, c0.lab[0], cb, user);
-            vrg_recount_done(c0, *c0.dn_part);
-            VrgDense tot = *c0.dn;
-            vrg_dense_fin_one(c0, tot);
-        }
+        if (!(flags & VRG_SWEEP_NODENSE)) dense_pass(b, c0, cb, user);   // its dense pass (the device: gate + recount on the other stream, asked for by vrg_deferred_done)
     }
     // the per-launch modes of the batched kernels, alternated so that both forms of every item function run here: the
     // touched levels listed by atomics / found by scanning the counters; a flip's level fetched through its rank / looked up
@@ -315,12 +329,7 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c0, int flags, VrgEvents*, be_re
     }
     vrg_request_dense(c);
     vrg_post_apply(c, (flags & VRG_SWEEP_FULL) ? -1 : (int64_t)s.nmk);
-    if (!(flags & VRG_SWEEP_NODENSE)) {
-        dense_stats(c, lab, cb, user);      // the dense recount (:113-116) ...
-        vrg_recount_done(c, *c.dn_part);
-        VrgDense tot = *c.dn;
-        vrg_dense_fin_one(c, tot);          // ... cross-checks the incremental sizes and files the sums
-    }
+    if (!(flags & VRG_SWEEP_NODENSE)) dense_pass(b, c, cb, user);   // the dense recount (:113-116): cross-checks the incremental sizes and files the sums
     // closing: flips all visited, dead slots onto the free list, this sweep's level deltas in level order
     for (uint32_t r = 0; r < nf; r++) vrg_item_check_flip(c, r);
     for (uint32_t j = 0; j < s.ndead; j++) vrg_item_free(c, j);

@@ -15,6 +15,7 @@ import bench
 def test_gpus_n_spawns_a_launcher(monkeypatch):
     calls = []
     monkeypatch.setattr(bench.subprocess, 'call', lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.setattr(bench, 'visible_gpus', lambda: 8)
     monkeypatch.delenv('WORLD_SIZE', raising=False)
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '7', '--warmup', '3'])
     with pytest.raises(SystemExit) as e:
@@ -25,6 +26,33 @@ def test_gpus_n_spawns_a_launcher(monkeypatch):
     assert cmd[cmd.index('--nproc-per-node') + 1] == '8' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
     assert cmd[-6:] == ['--gpus', '8', '--steps', '7', '--warmup', '3'] and os.path.basename(cmd[-7]) == 'bench.py'
     assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    assert '--log-dir' in cmd and cmd[cmd.index('--tee') + 1] == '3'          # every rank's stderr is shown and kept
+
+
+def test_gpus_n_preflight_and_rank_stderr(monkeypatch, capsys):
+    """--gpus N on a node with fewer devices: exit code 2 and a message BEFORE anything is spawned; a launch that fails
+    prints the tail of every rank's stderr log."""
+    calls = []
+    monkeypatch.setattr(bench.subprocess, 'call', lambda cmd, env=None: calls.append(cmd) or 0)
+    monkeypatch.setattr(bench, 'visible_gpus', lambda: 1)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4'])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 2 and not calls
+    assert 'needs 4 visible GPUs, this node shows 1' in capsys.readouterr().err
+
+    def failing(cmd, env=None):
+        d = os.path.join(cmd[cmd.index('--log-dir') + 1], 'attempt_0', '1')
+        os.makedirs(d)
+        open(os.path.join(d, 'stderr.log'), 'w').write('Traceback ...\nVrgError: RCCL all-reduce of the slab statistics failed\n')
+        return 1
+    monkeypatch.setattr(bench.subprocess, 'call', failing)
+    monkeypatch.setattr(bench, 'visible_gpus', lambda: 4)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    err = capsys.readouterr().err
+    assert e.value.code == 1 and 'the 4-rank launch failed with exit code 1' in err and 'RCCL all-reduce of the slab statistics failed' in err
 
 
 def test_roofline_is_a_fraction_of_peak():

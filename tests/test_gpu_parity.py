@@ -189,6 +189,28 @@ def test_integer_class_goldens_and_tie_rate(lib, golden_loader):
     print(json.dumps(rep))
 
 
+def test_verify_every(lib, golden_loader):
+    """Option verify_every through the C-ABI on the GPU (the same case the host model runs), and through the drop-in function:
+    identical results with the dense pass on every sweep, every 4th, never."""
+    from test_hostmodel import _verify_every_case
+    from arterynetwork_amd import variationalRegionGrowing
+    _verify_every_case(lib, golden_loader)
+    g = golden_loader('int_torus')
+    data, vmap = g.inputs()
+    outs = []
+    for every in (1, 4, 0):
+        vm = vmap.copy()
+        tr = []
+        seg, segMap, vm2 = variationalRegionGrowing(data, vm, H=g.H, maxSegmentSize=g.maxSegmentSize, quiet=True, trace=tr, verify_every=every)
+        outs.append((seg, segMap, vm2.copy(), [t['nseg'] for t in tr]))
+        assert not np.isnan(tr[-1]['sum_in'])                      # the last sweep is always counted
+    for o in outs[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(o[:3], outs[0][:3])) and o[3] == outs[0][3]
+    assert np.array_equal(outs[0][2], g.z['final_labels'].reshape(g.shape))
+    with pytest.raises(ValueError):
+        variationalRegionGrowing(data, vmap.copy(), quiet=True, verify_every=-1)
+
+
 def test_skip_rule_closure_is_race_free(lib):
     """Regression: the skip-rule fix-point is computed by every workgroup of k_relabel for itself.  With a wrong
     termination test one workgroup could stop before another one's write became visible; this case then failed in

@@ -110,6 +110,50 @@ def test_hostmodel_fused_sweeps(hm, golden_loader):
     assert sweeps > 300
 
 
+def _verify_every_case(lib, golden_loader):
+    """Option verify_every (the dense pass on every n-th sweep only / never): labels, lists, densities and the integer trace are
+    the same for every value; the trace's intensity sums are there exactly for the sweeps that were counted (NaN elsewhere) -
+    and for the run's LAST sweep whatever the value (it is counted when the run ends); a handle keeps working when the value
+    changes between runs."""
+    from arterynetwork_amd._capi import Session
+    g = golden_loader('tube_q_small')
+    data, vmap = g.inputs()
+    ref = None
+    for every in (1, 3, 0):
+        for fused in (1, 0):
+            s = Session(g.shape, lib=lib)
+            s.set_option('fused', fused); s.set_option('verify_every', every); s.set_option('batch', 5)
+            s.set_volume(data); s.set_labels(vmap); s.init(g.H)
+            r1 = s.run(17, g.maxSegmentSize, None)
+            s.set_option('verify_every', 1 if every == 0 else every)      # (any time: the next run counts again)
+            r2 = s.run(25, g.maxSegmentSize, None)
+            assert r1.sweeps == 17 and r2.sweeps == 8
+            tr = s.trace()
+            out = (s.labels(), s.segmented(), s.band(0), s.band(1), [tr[f].copy() for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no')])
+            counted = ~np.isnan(tr['sum_in'])
+            want = np.zeros(len(tr), bool)
+            want[0] = True
+            for k in range(1, 26):
+                e = every if k <= 17 else (1 if every == 0 else every)
+                want[k] = (e == 1) or (e > 1 and k % e == 0) or k in (17, 25)
+            assert np.array_equal(counted, want), (every, fused, counted.nonzero()[0], want.nonzero()[0])
+            if ref is None:
+                ref = (out, tr['sum_in'].copy(), tr['sum_out'].copy())
+            else:
+                assert np.array_equal(out[0], ref[0][0]) and np.array_equal(out[1], ref[0][1]), (every, fused)
+                for a, b in zip(out[2] + out[3], ref[0][2] + ref[0][3]):
+                    assert np.array_equal(a, b) if a.dtype.kind == 'i' else np.allclose(a, b, rtol=1e-9, atol=1e-12), (every, fused)
+                for a, b in zip(out[4], ref[0][4]):
+                    assert np.array_equal(a, b)
+                np.testing.assert_allclose(tr['sum_in'][counted], ref[1][counted], rtol=1e-12)
+                np.testing.assert_allclose(tr['sum_out'][counted], ref[2][counted], rtol=1e-12)
+            s.close()
+
+
+def test_hostmodel_verify_every(hm, golden_loader):
+    _verify_every_case(hm, golden_loader)
+
+
 def test_hostmodel_arrays_grow_on_demand(hm):
     """Pool and marked-voxel arrays start tiny (capacity_floor 16) and grow when a trip is handed back (VBAIL_MARKS /
     VBAIL_POOL) or when init counts more band voxels than fit; small_flips 0/3/10^6 runs every sweep host-driven /
