@@ -50,6 +50,10 @@ int be_build_levels(VrgBackend* b, const VrgCtx& c, double** lev, uint32_t* L);
 bool be_build_lev_map(VrgBackend* b, const VrgCtx& c, uint16_t* map, uint32_t span);
 // ktab[a * L + b] = vrg_kern(lev[b] - lev[a]) for every pair of levels (L <= VRG_KTAB_LEVELS; c.H, c.A set)
 void be_build_ktab(VrgBackend* b, const VrgCtx& c, double* ktab);
+// binned exact densities (c.nb, c.bin_lo, c.bin_h, c.bm_in / c.bm_out set): the bins' moments from c.hin / c.hout; and - a
+// verification aid - how many moment words differ from the ones built from the class histograms rin / rout (device arrays)
+void be_build_bins(VrgBackend* b, const VrgCtx& c);
+long long be_check_bins(VrgBackend* b, const VrgCtx& c, const int32_t* rin, const int32_t* rout);
 // 16-bit storage: level index of every voxel (after be_build_levels), padded layout
 void be_build_lev16(VrgBackend* b, const VrgCtx& c, uint16_t* dst);
 

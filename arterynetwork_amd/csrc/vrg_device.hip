@@ -136,9 +136,27 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
 // Every lane sums its levels (lane, lane + 64, ...) in ascending order whatever the batching - the order of the
 // additions, and so the result, does not depend on EXQ.
 constexpr int EXQ = 8;      // levels per lane fetched together: 512 per wave and batch
+// (with bins - large level tables, vrg_items.h "binned exact densities" - the lanes stride over the bins within reach of the entry)
+__device__ void exact_wave_binned(const VrgCtx& c, const VrgState& s, uint32_t nfresh, uint32_t wid, uint32_t nw, bool then_decide) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t f = wid; f < nfresh; f += nw) {
+        const uint32_t slot = c.fresh[f];
+        const double v = c.lev[c.p_lev[slot]];
+        uint32_t b0, b1; vrg_bin_range(c, v, b0, b1);
+        double si = 0, so = 0;
+        for (uint32_t b = b0 + lane; b <= b1; b += 64u) { double ti, to; vrg_bin_terms(c, v, b, ti, to); si += ti; so += to; }
+        si = wave_sum(si); so = wave_sum(so);
+        if (lane == 0) {
+            c.p_ip[slot] = si; c.p_op[slot] = so;
+            if (then_decide && s.iter < s.iterMax)
+                vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot]);
+        }
+    }
+}
 __device__ void exact_wave(const VrgCtx& c, const VrgState& s, uint32_t nfresh, uint32_t wid, uint32_t nw, bool then_decide) {
     const int lane = threadIdx.x & 63;
     if (wid >= nfresh) return;
+    if (c.nb) { exact_wave_binned(c, s, nfresh, wid, nw, then_decide); return; }
     int32_t ha[EXQ], hb[EXQ]; double lv[EXQ];      // the first batch stays in registers for every entry of this wave
 #pragma unroll
     for (int q = 0; q < EXQ; q++) {
@@ -187,6 +205,10 @@ __device__ void exact_wg(const VrgCtx& c, const VrgState& s, uint32_t nfresh, ui
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr uint32_t NWV = TPB / 64, BATCH = 64u * EXQ;
     if (wg >= nfresh) return;
+    if (c.nb) {                                           // (with bins: a wave per entry does it - at most 2983 bins, 47 per lane)
+        exact_wave_binned(c, s, nfresh, wg * NWV + wv, nwg * NWV, true);
+        return;
+    }
     int32_t ha[EXQ], hb[EXQ]; double lv[EXQ];      // this wave's first batch stays in registers for every slot
 #pragma unroll
     for (int q = 0; q < EXQ; q++) {
@@ -432,65 +454,6 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
     }
     if (st0 && live) { VRG_STAMP(c, 40); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 2); }
 }
-
-// ---- exact densities when the level table is huge (continuous-valued volumes: about one level per voxel) -----
-// One wave per pending entry (exact_wave) leaves the chip idle when a few hundred entries each need 10^7 kernel
-// evaluations.  Here the LEVELS are spread over the chip: workgroup = 2048 levels held in registers (8 per thread), looped
-// over every pending entry; partial sums per (entry, workgroup) are added up in a fixed order by k_exact_sum, which
-// also decides the entry.  Host-driven trips only (the host has to know the number of pending entries).
-constexpr uint32_t XB_LEVELS = 2048;
-constexpr uint32_t EXACT_BIG_L = 262144;    // level tables beyond this take the route above
-__global__ void __launch_bounds__(TPB) k_exact_big(VrgCtx c, uint32_t nfx, double* part, uint32_t nchunks) {
-    __shared__ double sh[2][4];
-    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6, chunk = blockIdx.x;
-    double lv[8]; int32_t ha[8], hb[8];
-    bool any = false;
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const uint32_t l = chunk * XB_LEVELS + t + 256u * q;
-        const bool in = l < c.L;
-        lv[q] = in ? c.lev[l] : 0.0; ha[q] = in ? c.hin[l] : 0; hb[q] = in ? c.hout[l] : 0;
-        any |= (ha[q] | hb[q]) != 0;
-    }
-    const bool wg_any = __syncthreads_or(any);
-    for (uint32_t f = 0; f < nfx; f++) {
-        double si = 0, so = 0;
-        if (wg_any) {
-            const double v = c.lev[c.p_lev[c.fresh[f]]];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                if (!(ha[q] | hb[q])) continue;
-                const double k = vrg_kern(c, lv[q] - v);
-                si += (double)ha[q] * k; so += (double)hb[q] * k;
-            }
-            si = wave_sum(si); so = wave_sum(so);
-            if (lane == 0) { sh[0][wv] = si; sh[1][wv] = so; }
-            __syncthreads();
-            if (t == 0) { si = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3]; so = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3]; }
-            __syncthreads();
-        }
-        if (t == 0) { part[((size_t)f * nchunks + chunk) * 2] = si; part[((size_t)f * nchunks + chunk) * 2 + 1] = so; }
-    }
-}
-__global__ void __launch_bounds__(TPB) k_exact_sum(VrgCtx c, uint32_t nfx, const double* part, uint32_t nchunks) {
-    __shared__ double sh[2][4];
-    const VrgState s = *c.st;
-    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6, f = blockIdx.x;
-    if (f >= nfx) return;
-    double si = 0, so = 0;
-    for (uint32_t ch = t; ch < nchunks; ch += TPB) { si += part[((size_t)f * nchunks + ch) * 2]; so += part[((size_t)f * nchunks + ch) * 2 + 1]; }
-    si = wave_sum(si); so = wave_sum(so);
-    if (lane == 0) { sh[0][wv] = si; sh[1][wv] = so; }
-    __syncthreads();
-    if (t == 0) {
-        si = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3]; so = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3];
-        const uint32_t slot = c.fresh[f];
-        c.p_ip[slot] = si; c.p_op[slot] = so;        // (the pending flag is cleared by the slot's own thread in k_band)
-        if (s.iter < s.iterMax)
-            vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot]);
-    }
-}
-__global__ void k_exact_done(VrgCtx c) { c.stg->nfx = 0; }
 
 // ---- sorting inside one workgroup -------------------------------------------------------------------------
 // ascending sort of n (key, value) pairs, keys distinct; n <= capacity of the arrays rounded up to a power of two
@@ -1947,7 +1910,7 @@ uint32_t be_fuse_limit(VrgBackend*) { return VRG_FUSE_MAX; }
 // fused trips need the level table in the workgroup's LDS (or 16-bit level indices)
 bool be_fuse_ok(VrgBackend*, const VrgCtx& c) { return c.L <= (uint32_t)VRG_FUSE_LEVELS; }
 void be_fuse_enter(VrgBackend* b, const VrgCtx& c) { use_device(b); k_levels_clear<<<1, TPB, 0, b->sa>>>(c); }
-bool be_wants_sync(VrgBackend*, const VrgCtx& c) { return c.L > EXACT_BIG_L; }
+bool be_wants_sync(VrgBackend*, const VrgCtx&) { return false; }     // (every level-table size runs batched trips: large tables evaluate their exact densities through the bins)
 
 void* be_alloc(VrgBackend* b, size_t bytes) { use_device(b); void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
 void be_free(VrgBackend* b, void* p) { use_device(b); HIP_CHECK(hipFree(p)); }
@@ -2073,6 +2036,44 @@ __global__ void k_ktab(VrgCtx c, double* ktab) {
 }
 void be_build_ktab(VrgBackend* b, const VrgCtx& c, double* ktab) { use_device(b); k_ktab<<<1024, TPB, 0, b->sa>>>(c, ktab); }
 
+// the bins' moments from the per-level class histograms (init; fixed-point integer adds: any order gives the same bits)
+__global__ void k_bins_build(VrgCtx c) {
+    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < c.L; l += gridDim.x * blockDim.x) {
+        const int32_t a = c.hin[l], b = c.hout[l];
+        if (a | b) vrg_bin_add(c, c.lev[l], a, b);
+    }
+}
+// ... and how many of them differ from `ref_in` / `ref_out` built the same way from other histograms (verification aid)
+__global__ void k_bins_diff(VrgCtx c, const int64_t* ref_in, const int64_t* ref_out, unsigned long long* out) {
+    const uint64_t n = (uint64_t)c.nb * (VRG_BIN_K + 1);
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) bad += (c.bm_in[i] != ref_in[i]) + (c.bm_out[i] != ref_out[i]);
+    if (bad) atomicAdd(out, bad);
+}
+void be_build_bins(VrgBackend* b, const VrgCtx& c) {
+    use_device(b);
+    HIP_CHECK(hipMemsetAsync(c.bm_in, 0, (size_t)c.nb * (VRG_BIN_K + 1) * 8, b->sa)); HIP_CHECK(hipMemsetAsync(c.bm_out, 0, (size_t)c.nb * (VRG_BIN_K + 1) * 8, b->sa));
+    k_bins_build<<<2048, TPB, 0, b->sa>>>(c);
+}
+long long be_check_bins(VrgBackend* b, const VrgCtx& c, const int32_t* rin, const int32_t* rout) {
+    use_device(b);
+    if (!c.nb) return 0;
+    const size_t bytes = (size_t)c.nb * (VRG_BIN_K + 1) * 8;
+    int64_t *ri = nullptr, *ro = nullptr; unsigned long long* d = nullptr; unsigned long long bad = ~0ull;
+    if (hipMalloc(&ri, bytes) == hipSuccess && hipMalloc(&ro, bytes) == hipSuccess && hipMalloc(&d, 8) == hipSuccess) {
+        VrgCtx r = c;
+        r.bm_in = ri; r.bm_out = ro; r.hin = const_cast<int32_t*>(rin); r.hout = const_cast<int32_t*>(rout);
+        HIP_CHECK(hipMemsetAsync(ri, 0, bytes, b->sa)); HIP_CHECK(hipMemsetAsync(ro, 0, bytes, b->sa)); HIP_CHECK(hipMemsetAsync(d, 0, 8, b->sa));
+        k_bins_build<<<2048, TPB, 0, b->sa>>>(r);
+        k_bins_diff<<<256, TPB, 0, b->sa>>>(c, ri, ro, d);
+        HIP_CHECK(hipMemcpyAsync(&bad, d, 8, hipMemcpyDeviceToHost, b->sa));
+        HIP_CHECK(hipStreamSynchronize(b->sa));
+    }
+    (void)hipGetLastError();
+    if (ri) HIP_CHECK(hipFree(ri)); if (ro) HIP_CHECK(hipFree(ro)); if (d) HIP_CHECK(hipFree(d));
+    return (long long)bad;
+}
+
 void be_build_lev16(VrgBackend* b, const VrgCtx& c, uint16_t* dst) {
     use_device(b);
     HIP_CHECK(hipMemsetAsync(dst, 0, ((size_t)c.PV + 1023) / 1024 * 1024 * 2, b->sa));
@@ -2185,6 +2186,7 @@ void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
     k_init_entry<<<ITEM_BLOCKS, TPB, 0, b->sa>>>(c);
     if (c.I && c.L <= HIST_LDS_LEVELS) k_hist_lds<<<1024, TPB, 0, b->sa>>>(c);
     else k_hist_voxel<<<voxel_blocks(c), TPB, 0, b->sa>>>(c);
+    if (c.nb) be_build_bins(b, c);              // (large level table: the histograms also as bin moments, before the first exact densities)
     k_exact_init<<<1024, TPB, 0, b->sa>>>(c);
     k_cls_build<<<2048, TPB, 0, b->sa>>>(c);
     k_ulist_init<<<1, GATE_THREADS, 0, b->sa>>>(c);
@@ -2281,18 +2283,6 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
     if (ev && ev->chain_enabled > 0 && !(flags & VRG_SWEEP_SYNC) && trip % ev->chain_enabled == 0) {
         EvPair& p = take_pair(1);
         e_c0 = p.a; e_c1 = p.b;
-    }
-    if ((flags & VRG_SWEEP_SYNC) && c.L > EXACT_BIG_L) {     // huge level table: the pending entries' densities on the whole chip
-        VrgState s0;
-        HIP_CHECK(hipMemcpyAsync(&s0, c.st, sizeof(s0), hipMemcpyDeviceToHost, b->sa));
-        HIP_CHECK(hipStreamSynchronize(b->sa));
-        if (!s0.done && !s0.bail && s0.nfx) {
-            const uint32_t nchunks = (c.L + XB_LEVELS - 1) / XB_LEVELS;
-            if (!need_tmp(b, (size_t)s0.nfx * nchunks * 16)) { std::snprintf(b->err, sizeof(b->err), "out of device memory (exact densities)"); return; }
-            k_exact_big<<<nchunks, TPB, 0, b->sa>>>(c, s0.nfx, (double*)b->tmp, nchunks);
-            k_exact_sum<<<s0.nfx, TPB, 0, b->sa>>>(c, s0.nfx, (const double*)b->tmp, nchunks);
-            k_exact_done<<<1, 1, 0, b->sa>>>(c);
-        }
     }
     const uint32_t nbb = band_blocks(b);
     // (grid: the pool's workgroups, the exact-density ones, and - behind a fused trip - the ones that carry out what it deferred)

@@ -29,6 +29,8 @@ struct vrg_handle {
     bool have_vol = false, have_lab = false, inited = false;
     bool sync_mode = false;              // trips are driven one at a time from the host (many flips per sweep)
     int verify_every = 1;                // option "verify_every"
+    int64_t bin_above = 2048;            // option "bin_above": level tables larger than this evaluate their exact densities through bins
+    uint32_t nb_alloc = 0;
     int fused = 1;                       // option "fused": sweeps with few flips run update() as ONE launch (k_sweep)
     bool fuse_mode = false;              // ... and the trips being enqueued now are of that kind
     int variant = 0, batch = 8, storage16 = 0, dense_off = 0;
@@ -229,6 +231,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "dense_off") h->dense_off = value != 0;   // measurement aid: band chain alone; re-initialise afterwards
     else if (n == "batch") h->batch = (int)std::max<int64_t>(1, value);
     else if (n == "fused") h->fused = value != 0;
+    else if (n == "bin_above") { if (value < 0) return fail(h, VRG_E_ARG, "bin_above: a number of levels >= 0"); h->bin_above = value; h->inited = false; }
     else if (n == "verify_every") { if (value < 0) return fail(h, VRG_E_ARG, "verify_every: 0 (never), 1 (every sweep: the default) or n > 1 (every n-th sweep)"); h->verify_every = (int)std::min<int64_t>(value, 1 << 20); be_set_tuning(h->be, name, value); }
     else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "fuse_max" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads" || n == "dense_pipe") be_set_tuning(h->be, name, value);
     else if (n == "storage16") h->storage16 = value != 0;      // takes effect at the next vrg_init
@@ -325,6 +328,25 @@ int API(init)(vrg_handle* h, double H) {
         if (!c.ktab) c.ktab = alloc<double>(h, (size_t)L * L);
         if (!c.ktab) return fail(h, VRG_E_MEM, "vrg_init: kernel table");
         be_build_ktab(be, c, const_cast<double*>(c.ktab));
+    }
+    // large level tables: the exact densities (:252-255) through bin moments (vrg_items.h "binned exact densities"); the bin width
+    // follows from H, so the bins are laid out by every init
+    c.nb = 0;
+    if ((int64_t)L > h->bin_above) {
+        double ends[2] = {0, 0};
+        be_download(be, &ends[0], c.lev, sizeof(double)); be_download(be, &ends[1], c.lev + (L - 1), sizeof(double));
+        const double hh = VRG_BIN_THETA / std::sqrt(2.0 * VRG_BIN_T * H), nbd = std::floor((ends[1] - ends[0]) / (2.0 * hh)) + 1.0;
+        if (H > 0 && nbd >= 1.0 && nbd <= 4194304.0) {    // (more bins than that - a range of > 70 000 kernel widths: the sums over the levels stay)
+            const uint32_t nb = (uint32_t)nbd;
+            if (nb > h->nb_alloc) {
+                if (c.bm_in) release(h, c.bm_in);
+                if (c.bm_out) release(h, c.bm_out);
+                c.bm_in = alloc<int64_t>(h, (size_t)nb * (VRG_BIN_K + 1)); c.bm_out = alloc<int64_t>(h, (size_t)nb * (VRG_BIN_K + 1));
+                h->nb_alloc = (c.bm_in && c.bm_out) ? nb : 0;
+                if (!h->nb_alloc) return fail(h, VRG_E_MEM, "vrg_init: bin moments");
+            }
+            c.nb = nb; c.bin_lo = ends[0]; c.bin_h = hh;
+        }
     }
     c.lev16 = nullptr;
     if (h->storage16) {                             // 16-bit intensity storage: level indices + LDS value table
@@ -546,7 +568,9 @@ int API(get_levels)(vrg_handle* h, double* values, int32_t* hin, int32_t* hout, 
         be_fill(h->be, di, 0, (size_t)L * 4); be_fill(h->be, dout, 0, (size_t)L * 4);
         be_recount_hist(h->be, h->c, di, dout);
         be_download(h->be, rin, di, (size_t)L * 4); be_download(h->be, rout, dout, (size_t)L * 4);
+        const long long bad = be_check_bins(h->be, h->c, di, dout);     // (with bins: the moments against ones built from the recount - integers: exactly equal)
         be_free(h->be, di); be_free(h->be, dout);
+        if (bad) return fail(h, VRG_E_INTERNAL, "get_levels: " + std::to_string(bad) + " bin moment word(s) differ from the dense recount");
     }
     return VRG_OK;
 }
@@ -566,6 +590,7 @@ int API(get_stats)(vrg_handle* h, int64_t* outp, int64_t cap) {
         if (h->inited) { be_sync(h->be); outp[8] = (int64_t)be_dense_bytes(h->be, h->c); }
     }
     if (cap >= 17) { outp[15] = h->fused_trips; outp[16] = h->bails[4]; }
+    if (cap >= 18) outp[17] = h->inited ? h->c.nb : 0;
     if (cap >= 14) {
         int64_t di[5] = {0, 0, 0, 0, 0};
         uint32_t uc[2] = {0, 0};

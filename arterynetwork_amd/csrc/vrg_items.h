@@ -312,10 +312,77 @@ VRG_HD void vrg_item_band(const VrgCtx& c, const VrgState& s, uint32_t slot, con
     const int64_t n_in = c.inc[VC_NIN], n_out = c.inc[VC_NOUT];
     vrg_item_band_fields(c, s, slot, fl, ip, op, lev, idx, key, n_in, n_out, nz_val, nz_cin, nz_cout, nz_cconv, tab, tab_n);
 }
-// exact densities over the whole inner / outer regions (:152-155, :252-255), regrouped by level
+// ------------------------------------------------------------------ binned exact densities (large level tables)
+// The exact densities of an entry that (re-)enters the band (:252-255) are sums over the whole inner / outer regions:
+//     S(v) = sum over voxels q of the class   A * exp(-0.5 * H * (x_q - v)^2).
+// The reference evaluates them voxel by voxel; regrouped by distinct value that is (new entries x L) kernel evaluations - fine for
+// quantised data, 4 ms per sweep for a continuous-valued 512x512x170 volume (L = 3e7).  Here the intensity axis is cut into uniform
+// bins of half width h; for a voxel with x = c + delta in the bin centred at c, and d = c - v,
+//     exp(-0.5*H*(d + delta)^2) = exp(-0.5*H*d^2) * exp(-0.5*H*delta^2) * exp(-H*d*delta),
+// exactly.  The first factor is per bin; the second (w) goes into the bin's moments; only the third is expanded:
+//     exp(t) = sum_{k <= K} t^k / k! + R,   t = -H*d*delta,   |R| <= |t|^(K+1) / (K+1)! * max(1, e^t).
+// With |t| <= theta the truncation error relative to the TRUE term is <= theta^(K+1)/(K+1)! * e^(2*theta) (the true factor is
+// >= e^-theta, the remainder <= theta^(K+1)/(K+1)! * e^theta).  Every term of S is positive, so that is also the bound on
+// the relative error of the whole sum.  K = 8, theta = 0.5:  0.5^9 / 9! * e = 1.46e-8 - two orders inside 1e-6, three inside north_star's
+// 1e-5.  |t| <= theta has to hold for every bin that contributes at all: a bin with 0.5*H*d^2 > T = 745.2 contributes exactly 0.0 in
+// double arithmetic (exp underflows, in the reference too), so d ranges up to D = sqrt(2T/H) and h = theta / (H * D) = theta /
+// sqrt(2*T*H) (H = 2.25: h = 0.00863).  An evaluation visits at most 2*D / (2*h) + 2 = 2T/theta + 2 = 2983 bins whatever H and the data's scale are.
+// The moments sum_q w_q * (delta_q / h)^k are 64-bit fixed-point integers (2^-30 per unit; |w * (delta/h)^k| <= 1): adding and
+// removing voxels commutes exactly - no drift, bit-reproducible - at a rounding of 2^-31 per voxel and moment, i.e. <= 5e-10 of the
+// class's count in the bin, times (theta^k / k!) in the sum: below the truncation bound.  Total: <= 2e-8 relative (VRG_TIE_NEAR_REL is 2e-5).
+VRG_HD uint32_t vrg_bin_of(const VrgCtx& c, double v) {
+    const double q = (v - c.bin_lo) / (2.0 * c.bin_h);
+    const uint32_t b = q <= 0.0 ? 0u : (uint32_t)q;
+    return b < c.nb ? b : c.nb - 1u;
+}
+VRG_HD double vrg_bin_centre(const VrgCtx& c, uint32_t b) { return c.bin_lo + (2.0 * (double)b + 1.0) * c.bin_h; }
+// a voxel of value v joins (n > 0) or leaves (n < 0) the inner / outer class n_in / n_out times: its terms into the bin's moments
+VRG_HD void vrg_bin_add(const VrgCtx& c, double v, int64_t n_in, int64_t n_out) {
+    const uint32_t b = vrg_bin_of(c, v);
+    const double delta = v - vrg_bin_centre(c, b), u = delta / c.bin_h;
+    double term = exp(-0.5 * c.H * (delta * delta));
+    for (int k = 0; k <= VRG_BIN_K; k++) {
+        const int64_t q = (int64_t)llrint(term * VRG_BIN_SCALE);
+        if (n_in) vrg_atomic_add64(&c.bm_in[(size_t)b * (VRG_BIN_K + 1) + k], q * n_in);
+        if (n_out) vrg_atomic_add64(&c.bm_out[(size_t)b * (VRG_BIN_K + 1) + k], q * n_out);
+        term *= u;
+    }
+}
+// first / last bin that can contribute to an entry of value v (those with 0.5*H*d^2 <= T, a bin of margin either side)
+VRG_HD void vrg_bin_range(const VrgCtx& c, double v, uint32_t& b0, uint32_t& b1) {
+    const double D = sqrt(2.0 * VRG_BIN_T / c.H) + 2.0 * c.bin_h;
+    b0 = vrg_bin_of(c, v - D); b1 = vrg_bin_of(c, v + D);
+}
+// contribution of bin b to the two exact densities of an entry of value v (0 for an empty or too distant bin)
+VRG_HD void vrg_bin_terms(const VrgCtx& c, double v, uint32_t b, double& ti, double& to) {
+    ti = 0; to = 0;
+    const int64_t* mi = c.bm_in + (size_t)b * (VRG_BIN_K + 1);
+    const int64_t* mo = c.bm_out + (size_t)b * (VRG_BIN_K + 1);
+    if (!(mi[0] | mo[0])) return;                          // (moment 0 is a sum of positive terms: zero means nobody is there)
+    const double d = vrg_bin_centre(c, b) - v, g = vrg_kern(c, d);
+    if (g == 0.0) return;
+    const double t = -c.H * d * c.bin_h;                   // exp(-H*d*delta) = sum_k (t * delta/h)^k / k!
+    double pi = 0, po = 0, f = 1.0;                        // f = t^k / k!
+    for (int k = 0; k <= VRG_BIN_K; k++) {
+        pi += f * (double)mi[k]; po += f * (double)mo[k];
+        f *= t / (double)(k + 1);
+    }
+    ti = g * (pi / VRG_BIN_SCALE); to = g * (po / VRG_BIN_SCALE);
+}
+// a voxel's class histogram entry changes: the per-level histograms and - with bins - the moments
+VRG_HD void vrg_hist_change(const VrgCtx& c, uint32_t lev, int din, int dout) {
+    if (din) vrg_atomic_add(&c.hin[lev], din);
+    if (dout) vrg_atomic_add(&c.hout[lev], dout);
+    if (c.nb) vrg_bin_add(c, c.lev[lev], din, dout);
+}
+// exact densities over the whole inner / outer regions (:152-155, :252-255), regrouped by level - or, with bins, by bin
 VRG_HD void vrg_exact_serial(const VrgCtx& c, const VrgState& s, uint32_t slot, bool then_decide) {
     double v = c.lev[c.p_lev[slot]];
     double si = 0, so = 0;
+    if (c.nb) {
+        uint32_t b0, b1; vrg_bin_range(c, v, b0, b1);
+        for (uint32_t b = b0; b <= b1; b++) { double ti, to; vrg_bin_terms(c, v, b, ti, to); si += ti; so += to; }
+    } else
     for (uint32_t l = 0; l < c.L; l++) {
         int32_t a = c.hin[l], b = c.hout[l];
         if (!(a | b)) continue;
@@ -557,7 +624,7 @@ VRG_HD uint8_t vrg_sweep_cases(const VrgCtx& c, uint32_t idx, uint8_t cb, const 
     if (cb & VB_S) {
         if (cb & VB_L) {                              // flip-out (:170-175), always applied
             const uint32_t r = pre.rank, slot = pre.vent, lev = c.lev_fast ? lev_here : c.f_lev[r];   // (a flip is a band entry: its slot is the voxel's)
-            vrg_atomic_add(&c.hin[lev], -1); vrg_atomic_add(&c.hout[lev], 1);
+            vrg_hist_change(c, lev, -1, 1);
             const bool to3 = !nSegA && q.maxFO > r;   // re-examined by a later flip-out neighbour? (:183-190)
             if (!to3) {                               // stays 2, carried to the outer list (by rank)
                 c.f_res[r] = FR_WRITTEN | 2;
@@ -589,7 +656,7 @@ VRG_HD uint8_t vrg_sweep_cases(const VrgCtx& c, uint32_t idx, uint8_t cb, const 
     if (cb & VB_B) {
         if ((cb & VB_L) && (cb & VB_P)) {             // applied flip-in (:198-204)
             const uint32_t r = pre.rank, slot = pre.vent, lev = c.lev_fast ? lev_here : c.f_lev[r];   // (a flip is a band entry: its slot is the voxel's)
-            vrg_atomic_add(&c.hin[lev], 1); vrg_atomic_add(&c.hout[lev], -1);
+            vrg_hist_change(c, lev, 1, -1);
             const bool to0 = !nNonSegB && q.maxAP > r;   // re-examined by a later applied flip-in nbr? (:219-228)
             bool fresh = nFO && !nSegA;               // had dropped to 3 in phase A: exact density (:212,:251)
             c.f_res[r] = (uint8_t)(FR_WRITTEN | (to0 ? 0 : 1) | (fresh ? FR_FRESH : 0));
@@ -620,7 +687,7 @@ VRG_HD uint8_t vrg_sweep_cases(const VrgCtx& c, uint32_t idx, uint8_t cb, const 
         if (conv) {                                   // addedPoints (:235); the voxel joins the outer region
             lev = c.lev_fast ? lev_here : vrg_pre_level(c, pre);
             vrg_note_level(c, c.dConv, lev);
-            vrg_atomic_add(&c.hout[lev], 1);
+            vrg_hist_change(c, lev, 0, 1);
         }
     }
     if (nAP) {                                        // 3 -> 2 (:210-213)

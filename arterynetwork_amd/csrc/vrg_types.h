@@ -47,6 +47,11 @@ enum { VBAIL_FLIPS = 1, VBAIL_MARKS = 2, VBAIL_POOL = 3, VBAIL_FUSE = 4 };   // 
 // flip per workgroup of VRG_FUSE_THREADS threads (thread p < 125 = place p of the flip's 5x5x5 cube, thread t < 81 = row t of
 // its 9x9x9 label tile, thread t < nf = flip t of the sweep's list).
 enum { VRG_KTAB_LEVELS = 2048 };
+// binned exact densities: Taylor order, and the bound on |H * d * delta| (d = distance of the bin centre) the bin width is chosen for
+enum { VRG_BIN_K = 8 };
+#define VRG_BIN_THETA 0.5
+#define VRG_BIN_T 745.2          // exp(-T) is 0.0 in double arithmetic beyond this: a bin further than sqrt(2T/H) contributes exactly nothing
+#define VRG_BIN_SCALE 1073741824.0   // 2^30
 enum { VRG_FUSE_MAX = 128, VRG_FUSE_THREADS = 128, VRG_FUSE_LEVELS = 2048, VRG_FUSE_PLACES = 125 };
 
 struct VrgTrace {            // one record per update() call (0 = init)
@@ -184,6 +189,14 @@ struct VrgCtx {
     // small level tables (L <= VRG_KTAB_LEVELS): the kernel between every pair of levels, ktab[a * L + b] = A*exp(-0.5*H*(lev[b]-lev[a])^2),
     // built by vrg_init with the very expression the sweeps evaluate - a correction then costs a load where it cost an exp
     const double* ktab;
+    // LARGE level tables (L > option bin_above; vrg_items.h "binned exact densities"): the class histograms also as MOMENTS over
+    // uniform intensity bins - per bin and class VRG_BIN_K + 1 sums of w * (delta / h)^k over the bin's voxels (delta = value - bin
+    // centre, h = half the bin width, w = exp(-0.5*H*delta^2)), kept as 64-bit FIXED-POINT integers (scale 2^30) so that atomic
+    // updates commute exactly: bit-reproducible whatever order the voxels arrive in, and a voxel that leaves a class takes out
+    // exactly what it put in.  nb = 0: no bins (the exact densities sum over the levels).
+    uint32_t nb;
+    double bin_lo, bin_h;      // lower edge of bin 0; half width (bin b covers [bin_lo + 2*h*b, bin_lo + 2*h*(b+1)))
+    int64_t* bm_in; int64_t* bm_out;   // [nb][VRG_BIN_K + 1]
     // band pool, SoA; capacity bcap slots
     uint32_t bcap;
     uint32_t* p_idx;           // voxel

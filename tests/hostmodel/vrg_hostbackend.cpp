@@ -122,6 +122,22 @@ void be_build_ktab(VrgBackend*, const VrgCtx& c, double* ktab) {
     for (uint32_t a = 0; a < c.L; a++) for (uint32_t b = 0; b < c.L; b++) ktab[(size_t)a * c.L + b] = vrg_kern(c, c.lev[b] - c.lev[a]);
 }
 
+void be_build_bins(VrgBackend*, const VrgCtx& c) {
+    std::memset(c.bm_in, 0, (size_t)c.nb * (VRG_BIN_K + 1) * 8); std::memset(c.bm_out, 0, (size_t)c.nb * (VRG_BIN_K + 1) * 8);
+    for (uint32_t l = 0; l < c.L; l++) if (c.hin[l] | c.hout[l]) vrg_bin_add(c, c.lev[l], c.hin[l], c.hout[l]);
+}
+long long be_check_bins(VrgBackend* b, const VrgCtx& c, const int32_t* rin, const int32_t* rout) {
+    if (!c.nb) return 0;
+    const size_t n = (size_t)c.nb * (VRG_BIN_K + 1);
+    std::vector<int64_t> ri(n, 0), ro(n, 0);
+    VrgCtx r = c;
+    r.bm_in = ri.data(); r.bm_out = ro.data(); r.hin = const_cast<int32_t*>(rin); r.hout = const_cast<int32_t*>(rout);
+    for (uint32_t l = 0; l < c.L; l++) if (r.hin[l] | r.hout[l]) vrg_bin_add(r, c.lev[l], r.hin[l], r.hout[l]);
+    long long bad = 0;
+    for (size_t i = 0; i < n; i++) bad += (c.bm_in[i] != ri[i]) + (c.bm_out[i] != ro[i]);
+    return bad;
+}
+
 void be_build_lev16(VrgBackend*, const VrgCtx& c, uint16_t* dst) {
     std::memset(dst, 0, (size_t)c.PV * 2);
     for_real_voxels(c, [&](uint32_t idx, int, int, int) { dst[idx] = (uint16_t)vrg_level_of(c, vrg_voxel_value(c, idx)); });
@@ -171,6 +187,7 @@ void be_init_finish(VrgBackend*, const VrgCtx& c, be_reduce_fn cb, void* user) {
     uint32_t n = s.ni + s.no;
     for (uint32_t e = 0; e < n; e++) vrg_item_init_entry(c, e);
     for_real_voxels(c, [&](uint32_t idx, int, int, int) { vrg_item_hist_voxel(c, idx); });
+    if (c.nb) be_build_bins(nullptr, c);
     for (uint32_t i = 0; i < n; i++) vrg_exact_serial(c, s, c.fresh[i], false);
     for (uint32_t d = 0; d < (((c.PV + 1023u) >> 10) << 6); d++) vrg_item_cls_build(c, d);
     vrg_ulist_rebuild_serial(c);

@@ -154,6 +154,48 @@ def test_hostmodel_verify_every(hm, golden_loader):
     _verify_every_case(hm, golden_loader)
 
 
+def _binned_case(lib, golden_loader, tag):
+    import json
+    from arterynetwork_amd._capi import Session
+    rep = {}
+    for name in ('adv_noise0', 'adv_noise2', 'adv_scattered', 'adv_shell', 'adv_noise_q', 'tube_q_small'):
+        g = golden_loader(name)
+        data, vmap = g.inputs()
+        iterMax = g.max_sweeps if g.max_sweeps >= 0 else 200
+        res, k = parity.run_stepwise(lib, data, vmap, g.H, g.maxSegmentSize, iterMax, density_mode=1, check_hist=True, options={'bin_above': 0})
+        assert res is not None and k == g.ncalls - 1, name
+        res, k = parity.run_batched(lib, data, vmap, g.H, g.maxSegmentSize, iterMax, density_mode=1, options={'bin_above': 0, 'batch': 6})
+        assert res is not None, name
+        dev = 0.0
+        outs = []
+        for above in (0, 1 << 30):                            # bins / sums over the levels, same library
+            s = Session(g.shape, lib=lib)
+            s.set_option('bin_above', above)
+            s.set_volume(data); s.set_labels(vmap); s.init(g.H)
+            assert (s.stats()['density_bins'] > 0) == (above == 0)
+            s.run(iterMax, g.maxSegmentSize, None)
+            outs.append((s.labels(), s.band(0), s.band(1)))
+            s.close()
+        assert np.array_equal(outs[0][0], outs[1][0]), name
+        for w in (1, 2):
+            assert np.array_equal(outs[0][w][0], outs[1][w][0]), name
+            for q in (1, 2):
+                a, b = outs[0][w][q], outs[1][w][q]
+                scale = max(1e-300, float(np.max(np.abs(b)))) if len(b) else 1.0
+                if len(b):
+                    dev = max(dev, float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3 * scale))))
+        assert dev <= 1e-7, (name, dev)                       # (bound 2e-8 on the exact sums; entries that went through corrections since carry it on)
+        rep[name] = {'levels': int(len(np.unique(data))), 'max_relative_deviation_bins_vs_level_sums': dev}
+    d = os.path.join(ROOT, 'gpurun_out')
+    if tag == 'gpu' and os.path.isdir(d):
+        json.dump(rep, open(os.path.join(d, 'binned_deviation.json'), 'w'), indent=1)
+    print(json.dumps(rep))
+
+
+def test_hostmodel_binned_exact_densities(hm, golden_loader):
+    _binned_case(hm, golden_loader, 'cpu')
+
+
 def test_hostmodel_arrays_grow_on_demand(hm):
     """Pool and marked-voxel arrays start tiny (capacity_floor 16) and grow when a trip is handed back (VBAIL_MARKS /
     VBAIL_POOL) or when init counts more band voxels than fit; small_flips 0/3/10^6 runs every sweep host-driven /
