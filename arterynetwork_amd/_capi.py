@@ -243,10 +243,10 @@ class Session:
 
     def stats(self):
         """Diagnostics: how often a trip was handed back to the host and why, array capacities."""
-        a = (C.c_int64 * 18)()
-        self._check(self.lib.get_stats(self._h, a, 18))
+        a = (C.c_int64 * 19)()
+        self._check(self.lib.get_stats(self._h, a, 19))
         return {'bail_flips': a[1], 'grow_marks': a[2], 'grow_pool': a[3], 'host_driven_trips': a[4],
-                'fused_trips': a[15], 'bail_fuse': a[16], 'density_bins': a[17],
+                'fused_trips': a[15], 'bail_fuse': a[16], 'density_bins': a[17], 'memo_trips': a[18],
                 'pool_capacity': a[5], 'mark_capacity': a[6], 'pool_slots': a[7], 'dense_bytes': a[8],
                 'dense_kernel': ('k_recount_pipe<3,{}>'.format('true' if a[9] else 'false') if a[14] else
                                  'k_recount_bits<{},{},{},{}>'.format(2 if a[10] == 2 else 3, 'true' if a[9] else 'false', a[10], 'true' if a[12] else 'false')),

@@ -60,6 +60,8 @@ struct VrgBackend {
     int verify_every = 1;                             // option "verify_every": the dense pass on every n-th sweep only (0: never)
     int dense_pipe = 1;                               // option "dense_pipe": fp32 storage + skip_excluded run the two-trips-deep recount (k_recount_pipe)
     uint64_t pass_bytes = 0;                          // bytes a dense pass fetches, counted at the end of init (0: not known yet)
+    uint32_t memo_above = 32768;                      // option "memo_above": band entries above which a fused trip keeps the per-level memo (k_memo)
+    long long memo_trips = 0;                         // fused trips that did
     bool fused_memo = false;                          // ... and it kept the per-level memo (k_memo)
     bool fused_prev = false;                          // the trip enqueued last was a fused one: the dense pass of the sweep it applied is not enqueued yet
                                                       // (its request comes from THIS trip's k_band; if that trip stopped or handed itself back, the stop word makes the gate leave)
@@ -297,7 +299,6 @@ template <int LPE> __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 constexpr uint32_t TAB_LDS = 832;     // levels whose memo entries k_band stages in LDS (the room of the entry-by-entry path's arrays)
-constexpr uint32_t FUSE_MEMO_ABOVE = 32768;   // band entries above which a fused trip keeps the per-level memo (k_memo behind k_sweep)
 constexpr uint32_t DEFER_WGS = 32;    // pool workgroups of k_band that carry out what a fused sweep deferred (label bytes, class bits, free list)
 template <int LPE>
 __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, int dense_on, int direct_hint) {
@@ -965,7 +966,7 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     if (st0) VRG_STAMP(cg, 19);
     vrg_fuse_stencil(c, sh, th, t, r);
     __syncthreads();
-    if (st0) { VRG_STAMP(cg, 22); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 20); }
+    if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 20); }
     vrg_fuse_reserve(c, sh, t);
     __syncthreads();
     vrg_fuse_commit(c, sh, th, t, r);
@@ -1517,22 +1518,27 @@ __global__ void __launch_bounds__(TPB) k_recount_pipe(VrgCtx c, int check_done) 
 // its stretch of bitmap words, a block scan gives its place, it writes its units.  Bitmap words are read past L1 / a
 // stale L2 line (sc1): band kernels of the other stream set bits with device-scope atomics.
 constexpr int GATE_THREADS = 1024;
-__device__ void ulist_refresh(const VrgCtx& c, bool force) {
+// (p = parity of the pass being prepared: the units its sweep listed for the first time are merged into the bitmap first -
+// VrgCtx::unew; the sweep's labels are in place, and no other sweep of that parity can be writing)
+__device__ void ulist_refresh(const VrgCtx& c, bool force, int p) {
     __shared__ uint32_t s_part[GATE_THREADS / 64];
     __shared__ uint32_t s_gen;
     const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if (t == 0) s_gen = vrg_load_u32(&c.uctl[UC_GEN]);
+    if (t == 0) s_gen = vrg_load_u32(&c.uctl[UC_GEN + p * UC_GEN_STRIDE]);
     __syncthreads();
-    const uint32_t g = s_gen;
-    if (!force && c.uctl[UC_LGEN] == g) return;                // (only this stream writes UC_LGEN; uniform)
+    if (!force && s_gen == 0u) return;                         // (uniform)
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX, lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
     uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10;
     if (f_hi < f_lo) f_hi = f_lo;
     const uint32_t w0 = f_lo >> 5, w1 = (f_hi + 31u) >> 5, nwords = w1 - w0;
     const uint32_t per = (nwords + GATE_THREADS - 1) / GATE_THREADS;
     const uint32_t a = w0 + t * per, b = min(a + per, w1);
+    for (uint32_t wi = a; wi < b; wi++) {                      // merge this sweep's new units (whole words; the slab's range is cut out below)
+        const uint32_t nw = vrg_load_u32(&c.unew[p][wi]);
+        if (nw) { c.ubits[wi] = c.ubits[wi] | nw; c.unew[p][wi] = 0u; }
+    }
     auto word = [&](uint32_t wi) -> uint32_t {
-        uint32_t bits = vrg_load_u32(&c.ubits[wi]);
+        uint32_t bits = c.ubits[wi];
         const uint32_t u0 = wi << 5;
         if (u0 < f_lo) bits &= 0xffffffffu << (f_lo - u0);
         if (f_hi - u0 < 32u) bits &= (1u << (f_hi - u0)) - 1u;
@@ -1550,27 +1556,29 @@ __device__ void ulist_refresh(const VrgCtx& c, bool force) {
         uint32_t bits = word(wi);
         while (bits) { c.ulist[q++] = (wi << 5) + vrg_ctz(bits); bits &= bits - 1u; }
     }
-    if (t == 0) { c.uctl[UC_N] = total; c.uctl[UC_LGEN] = g; }
+    if (t == 0) { c.uctl[UC_N] = total; c.uctl[UC_GEN + p * UC_GEN_STRIDE] = 0u; }
 }
-__global__ void __launch_bounds__(GATE_THREADS) k_ulist_init(VrgCtx c) { ulist_refresh(c, true); }
+__global__ void __launch_bounds__(GATE_THREADS) k_ulist_init(VrgCtx c) { ulist_refresh(c, true, 0); }
 // in front of every recount (dense stream): wait for the sweep's labels, then bring the unit list up to date if that sweep
 // (or an earlier one) listed a new unit - rare: label 4 turns into 3 only next to the band
 // ... or, with option verify_every, close the sweep's pass without a count (fin = 2: one GPU, the pass is closed here; 1: the
 // marker travels through the staged all-reduce like a slab's sums).  VD_GO tells the recount behind the gate what to do.
 __global__ void __launch_bounds__(GATE_THREADS) k_gate(VrgCtx c, int every, int fin) {
-    __shared__ int s_go;
+    __shared__ int s_due, s_par;
     if (threadIdx.x == 0) {
-        int go = gate_dense_due(c) ? 1 : 0;
-        if (go && every != 1 && vrg_dense_skipped(c.dctl[VD_RSEQ] + 1, every)) {
+        const int due = gate_dense_due(c) ? 1 : 0;
+        const int64_t seq = c.dctl[VD_RSEQ] + 1;               // the pass this gate stands in front of
+        int go = due;
+        if (due && every != 1 && vrg_dense_skipped(seq, every)) {
             vrg_recount_done(c, vrg_dense_skip_marker());
             if (fin == 2) vrg_dense_fin_one(c, vrg_dense_skip_marker());
             go = 0;
         }
         c.dctl[VD_GO] = go;
-        s_go = go;
+        s_due = due; s_par = (int)(seq & 1);
     }
     __syncthreads();
-    if (s_go) ulist_refresh(c, false);
+    if (s_due) ulist_refresh(c, false, s_par);                 // (also for a pass that is left out: its sweep's new units join the bitmap at THEIR gate)
 }
 __global__ void k_verify_last(VrgCtx c) { vrg_dense_verify_last(c, c.world == 1 ? *c.dn_part : *c.dn); }
 __global__ void k_cls_build(VrgCtx c) {
@@ -1901,6 +1909,7 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "band_hint") == 0) b->band_hint = (uint32_t)std::min<long long>(std::max<long long>(v, 0), 0x7fffffff);
     if (std::strcmp(name, "direct_hint") == 0) b->direct_hint = v != 0;
     if (std::strcmp(name, "dense_pipe") == 0) b->dense_pipe = (int)v;
+    if (std::strcmp(name, "memo_above") == 0 && v >= 0) b->memo_above = (uint32_t)std::min<long long>(v, 0x7fffffff);
     if (std::strcmp(name, "verify_every") == 0 && v >= 0) b->verify_every = (int)std::min<long long>(v, 1 << 20);
     if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)std::min<long long>(v, NF_SMALL);
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != b->prio_mode) { b->prio_mode = (int)v; make_streams(b); }
@@ -2304,7 +2313,8 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
     b->fused_prev = false;
     if ((flags & VRG_SWEEP_FUSED) && !(flags & (VRG_SWEEP_SYNC | VRG_SWEEP_FULL))) {
         // update() as ONE launch; on a large band a second one memoises the sweep's corrections per level
-        const bool memo = !b->direct_hint && b->band_hint > FUSE_MEMO_ABOVE && c.ktab;
+        const bool memo = !b->direct_hint && b->band_hint > b->memo_above && c.ktab;
+        b->memo_trips += memo;
         hipExtLaunchKernelGGL(k_sweep, dim3(VRG_FUSE_MAX), dim3(VRG_FUSE_THREADS), 0, b->sa, nullptr, memo ? nullptr : e_c1, 0, c, memo ? 1 : 0);
         if (memo) hipExtLaunchKernelGGL(k_memo, dim3(MEMO_BLOCKS), dim3(TPB), 0, b->sa, nullptr, e_c1, 0, c);
         b->fused_prev = true; b->fused_memo = memo;
@@ -2391,6 +2401,7 @@ void be_recount_hist(VrgBackend* b, const VrgCtx& c, int32_t* rin, int32_t* rout
 // what the dense pass of this handle is launched as: {non-temporal loads, storage mode (0 fp32, 1 u16 level index, 2 f64),
 // workgroups, skip_excluded, k_recount_pipe instead of k_recount_bits}
 static bool dense_is_pipe(VrgBackend* b, const VrgCtx& c) { return b->dense_pipe && c.I && !c.lev16 && b->skip; }
+long long be_memo_trips(VrgBackend* b) { return b->memo_trips; }
 void be_dense_info(VrgBackend* b, const VrgCtx& c, int64_t out[5]) {
     out[0] = dense_nt(b, c) ? 1 : 0; out[1] = c.lev16 ? (c.L <= TAB64_LEVELS ? 3 : 1) : (c.I ? 0 : 2); out[2] = dense_blocks(b, c); out[3] = b->skip ? 1 : 0;
     out[4] = dense_is_pipe(b, c) ? 1 : 0;

@@ -171,6 +171,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.clsb[0] = alloc<uint32_t>(h, PVu / 16); c.clsb[1] = alloc<uint32_t>(h, PVu / 16);
     c.nchg = alloc<uint32_t>(h, 32);
     c.ubits = alloc<uint32_t>(h, PVu / 1024 / 32 + 64);
+    c.unew[0] = alloc<uint32_t>(h, PVu / 1024 / 32 + 64); c.unew[1] = alloc<uint32_t>(h, PVu / 1024 / 32 + 64);
     c.ulist = alloc<uint32_t>(h, PVu / 1024 + 64);
     c.uctl = alloc<uint32_t>(h, 64);
     c.vent = alloc<uint32_t>(h, PVu);
@@ -194,7 +195,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.trace = alloc<VrgTrace>(h, c.trace_cap);
     c.world = 1;
     if (!c.lab[0] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.gate || !c.dn_ring || !c.exp_ring || !c.stage_in || !c.stage_out || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
-        !c.nchg || !c.ubits || !c.ulist || !c.uctl || !c.vent || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace) { API(destroy)(h); return VRG_E_MEM; }
+        !c.nchg || !c.ubits || !c.unew[0] || !c.unew[1] || !c.ulist || !c.uctl || !c.vent || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace) { API(destroy)(h); return VRG_E_MEM; }
     be_fill(be, c.inc, 0, 32 * sizeof(int64_t)); be_fill(be, c.dctl, 0, 32 * sizeof(int64_t)); be_fill(be, c.gate, 0, 32 * sizeof(int64_t));
     be_fill(be, c.clsb[0], 0, PVu / 4); be_fill(be, c.clsb[1], 0, PVu / 4);
     be_fill(be, c.nchg, 0, 32 * sizeof(uint32_t));
@@ -233,7 +234,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "fused") h->fused = value != 0;
     else if (n == "bin_above") { if (value < 0) return fail(h, VRG_E_ARG, "bin_above: a number of levels >= 0"); h->bin_above = value; h->inited = false; }
     else if (n == "verify_every") { if (value < 0) return fail(h, VRG_E_ARG, "verify_every: 0 (never), 1 (every sweep: the default) or n > 1 (every n-th sweep)"); h->verify_every = (int)std::min<int64_t>(value, 1 << 20); be_set_tuning(h->be, name, value); }
-    else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "fuse_max" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads" || n == "dense_pipe") be_set_tuning(h->be, name, value);
+    else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "fuse_max" || n == "memo_above" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads" || n == "dense_pipe") be_set_tuning(h->be, name, value);
     else if (n == "storage16") h->storage16 = value != 0;      // takes effect at the next vrg_init
     else return fail(h, VRG_E_ARG, "unknown option " + n);
     return VRG_OK;
@@ -385,6 +386,7 @@ int API(init)(vrg_handle* h, double H) {
     put_state(h, s);
     be_fill(be, c.p_flag, 0, c.bcap);
     be_fill(be, c.ubits, 0, (h->PVu / 1024 / 32 + 64) * sizeof(uint32_t));     // rebuilt from the labels by be_init_finish
+    be_fill(be, c.unew[0], 0, (h->PVu / 1024 / 32 + 64) * sizeof(uint32_t)); be_fill(be, c.unew[1], 0, (h->PVu / 1024 / 32 + 64) * sizeof(uint32_t));
     be_fill(be, c.uctl, 0, 64 * sizeof(uint32_t));
     be_init_finish(be, c, h->reduce_fn, h->reduce_user);
     s = get_state(h);
@@ -591,6 +593,7 @@ int API(get_stats)(vrg_handle* h, int64_t* outp, int64_t cap) {
     }
     if (cap >= 17) { outp[15] = h->fused_trips; outp[16] = h->bails[4]; }
     if (cap >= 18) outp[17] = h->inited ? h->c.nb : 0;
+    if (cap >= 19) outp[18] = be_memo_trips(h->be);
     if (cap >= 14) {
         int64_t di[5] = {0, 0, 0, 0, 0};
         uint32_t uc[2] = {0, 0};

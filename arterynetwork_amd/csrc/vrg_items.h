@@ -728,6 +728,13 @@ VRG_HD void vrg_cls_pos(uint32_t idx, uint32_t& dw, uint32_t& sh) {
     dw = ((idx >> 10) << 6) | ((o & 255u) >> 2);
     sh = 2u * (((o >> 8) << 2) | (o & 3u));
 }
+// a voxel of a unit that held no included voxel so far becomes an outer one (sweep parity p): the unit goes onto the list of
+// units the dense pass walks - through the bitmap of THIS sweep's new units (VrgCtx::unew), which the gate of the sweep's own
+// pass merges; the first lister says that the list is out of date
+VRG_HD void vrg_list_unit(const VrgCtx& c, uint32_t idx, int p, uint32_t bit) {
+    if (c.ubits[idx >> 15] & bit) return;                  // (listed by an earlier sweep)
+    if (!(vrg_atomic_or(&c.unew[p][idx >> 15], bit) & bit)) vrg_atomic_add(&c.uctl[UC_GEN + p * UC_GEN_STRIDE], 1u);
+}
 // a label byte changes during sweep iter+1: keep the region sizes and that sweep's copy of the class bits in step,
 // and note the change for the other copy
 VRG_HD void vrg_count_change(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t nw) {
@@ -738,7 +745,7 @@ VRG_HD void vrg_count_change(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t
     const uint32_t x = (a ^ b) << sh;
     if (a == 0u) {             // (before the class bits: a listed unit may read as empty, never the reverse)
         const uint32_t bit = 1u << ((idx >> 10) & 31u);
-        if (!(vrg_atomic_or(&c.ubits[idx >> 15], bit) & bit)) vrg_atomic_add(&c.uctl[UC_GEN], 1u);   // first to list the unit: the unit list is out of date
+        vrg_list_unit(c, idx, p, bit);
     }
     vrg_atomic_xor(&c.clsb[p][dw], x);
     uint32_t q = vrg_atomic_add(&c.nchg[p], 1u);
@@ -759,7 +766,7 @@ VRG_HD void vrg_count_change_at(const VrgCtx& c, uint32_t idx, uint8_t old, uint
     const uint32_t x = (a ^ b) << sh;
     if (a == 0u) {
         const uint32_t bit = 1u << ((idx >> 10) & 31u);
-        if (!(vrg_atomic_or(&c.ubits[idx >> 15], bit) & bit)) vrg_atomic_add(&c.uctl[UC_GEN], 1u);
+        vrg_list_unit(c, idx, p, bit);
     }
     vrg_atomic_xor(&c.clsb[p][dw], x);
     c.chg_dw[p][pos] = dw; c.chg_x[p][pos] = x;
@@ -817,9 +824,8 @@ VRG_HD void vrg_item_cls_build(const VrgCtx& c, uint32_t d) {
 VRG_HD void vrg_ulist_rebuild_serial(const VrgCtx& c) {
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX, lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
     uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10, n = 0;
-    const uint32_t g = c.uctl[UC_GEN];
     for (uint32_t u = f_lo; u < f_hi; u++) if ((c.ubits[u >> 5] >> (u & 31u)) & 1u) c.ulist[n++] = u;
-    c.uctl[UC_N] = n; c.uctl[UC_LGEN] = g;
+    c.uctl[UC_N] = n;
 }
 // one caller per applied sweep: the labels of sweep iter+1 are in place, a dense pass over them is due
 // (the expected sizes and every class bit of the sweep have reached memory before the request does)
@@ -1145,11 +1151,6 @@ VRG_HD void vrg_fuse_annotate(const VrgCtx& c, VrgFuseLds& sh, uint32_t t, uint3
     vrg_lds_or(&sh.tile[4 * vrg_fuse_tile_row(dy, dz) + (o >> 2)], bits << (8u * (o & 3u)));
     sh.rank[vrg_fuse_tile_pos(dx, dy, dz)] = (uint16_t)t;
 }
-#if defined(VRG_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
-#define VRG_ISTAMP(c, cond, k) do { if (cond) (c).dbg[k] = wall_clock64(); } while (0)
-#else
-#define VRG_ISTAMP(c, cond, k) do { } while (0)
-#endif
 // cube place t: is this workgroup's flip (rank r) the owner of the voxel - the flip of smallest rank that wants it
 // (vrg_mark_wanted: 1-ring of a listed flip; 2-ring too for an excluded voxel)?  Then the relabel stencil from the tile.
 VRG_HD void vrg_fuse_stencil(const VrgCtx& c, VrgFuseLds& sh, VrgFuseThread& th, uint32_t t, uint32_t r) {
@@ -1178,7 +1179,6 @@ VRG_HD void vrg_fuse_stencil(const VrgCtx& c, VrgFuseLds& sh, VrgFuseThread& th,
                     for (int ex = 0; ex < 5; ex++) owner = row[ex] < owner ? row[ex] : owner;
                 }
     }
-    VRG_ISTAMP(c, r == 0 && t == 62, 12); VRG_ISTAMP(c, r == 0 && t == 87, 35);
     if (owner != r) { c.mk_idx[place] = VRG_NONE; return; }
     const uint32_t m = (uint32_t)((int64_t)sh.f_idx[r] + ((int64_t)dz * c.PY + dy) * c.PX + dx);
     // the voxel's 3x3x3 masks from the tile rows (bytes x-1 .. x+2 of the nine rows: vrg_preload's layout)
@@ -1201,7 +1201,6 @@ VRG_HD void vrg_fuse_stencil(const VrgCtx& c, VrgFuseLds& sh, VrgFuseThread& th,
         if ((FO >> n) & 1u) { if (rk[n] < q.minFO) { q.minFO = rk[n]; q.kFO = kk; } if (rk[n] > q.maxFO) q.maxFO = rk[n]; }
         if ((AP >> n) & 1u) { if (rk[n] < q.minAP) { q.minAP = rk[n]; q.kAP = kk; } if (rk[n] > q.maxAP) q.maxAP = rk[n]; }
     }
-    VRG_ISTAMP(c, r == 0 && t == 62, 13); VRG_ISTAMP(c, r == 0 && t == 87, 36);
     bool ring2 = false;
     if (vrg_wants_ring2(mb, nb)) {                                     // an applied flip (P and not OOB) within the 2-ring? (vrg_ring2_applied)
         uint64_t any = 0;
@@ -1222,9 +1221,7 @@ VRG_HD void vrg_fuse_stencil(const VrgCtx& c, VrgFuseLds& sh, VrgFuseThread& th,
     uint32_t lev_here = 0xffffffffu;
     if (mb & VB_L) lev_here = sh.f_lev[th.pre.rank];
     else if (!(mb & VB_B) && ((mb & VB_S) ? FO != 0u : (AP != 0u || (mb & VB_X)))) lev_here = c.lev16 ? th.pre.lev16 : vrg_fuse_level_of(sh, c.L, th.pre.val);
-    VRG_ISTAMP(c, r == 0 && t == 62, 14); VRG_ISTAMP(c, r == 0 && t == 87, 37);
     const uint8_t nw = vrg_sweep_cases(c, m, mb, th.pre, nb, q, ring2, lev_here, th.ev);
-    VRG_ISTAMP(c, r == 0 && t == 62, 15); VRG_ISTAMP(c, r == 0 && t == 87, 38);
     c.mk_idx[place] = m; c.mk_new[place] = nw; c.mk_old[place] = mb;
     if (mb & VB_L) vrg_lds_add(&sh.nvis, 1u);
     const uint32_t a = vrg_cls_of(mb), b = vrg_cls_of(nw);             // region sizes (:113-116): kept by increments
@@ -1238,8 +1235,6 @@ VRG_HD void vrg_fuse_stencil(const VrgCtx& c, VrgFuseLds& sh, VrgFuseThread& th,
     const int di = vrg_ev_dni(th.ev), dq = vrg_ev_dno(th.ev);
     if (di) vrg_lds_add(&sh.d[0], di);
     if (dq) vrg_lds_add(&sh.d[1], dq);
-    VRG_ISTAMP(c, r == 0 && t == 62, 16);
-    VRG_ISTAMP(c, r == 0 && t == 87, 17);
 }
 // the workgroup reserves its stretch of every list with ONE atomic each (threads 0..8)
 VRG_HD void vrg_fuse_reserve(const VrgCtx& c, VrgFuseLds& sh, uint32_t t) {
@@ -1313,7 +1308,7 @@ VRG_HD void vrg_deferred_apply_vals(const VrgCtx& c, uint32_t i, int k, uint32_t
     const uint32_t x = (a ^ b) << sh;
     if (a == 0u) {
         const uint32_t bit = 1u << ((idx >> 10) & 31u);
-        if (!(vrg_atomic_or(&c.ubits[idx >> 15], bit) & bit)) vrg_atomic_add(&c.uctl[UC_GEN], 1u);
+        vrg_list_unit(c, idx, p, bit);
     }
     vrg_atomic_xor(&c.clsb[p][dw], x);
     c.chg_dw[p][i] = dw; c.chg_x[p][i] = x;

@@ -129,7 +129,7 @@ enum { VG_REQ = 0, VG_STOP = 1 };
 // VD_GO: written by the gate in front of a recount - 1: count the sweep now; 0: nothing to count (the run has stopped) or the
 // sweep's pass is left out (option verify_every)
 enum { VD_SEQ = 0, VD_ERR = 1, VD_RSEQ = 2, VD_NST = 3, VD_GO = 4 };
-enum { UC_N = 0, UC_LGEN = 1, UC_GEN = 16 };       // VrgCtx::uctl
+enum { UC_N = 0, UC_GEN = 16, UC_GEN_STRIDE = 16 };       // VrgCtx::uctl: list length; units newly listed by the sweeps of parity p at UC_GEN + p * UC_GEN_STRIDE (own cache lines)
 enum { VRG_RING = 64, VRG_STAGE = 16 };           // sweeps a recount result / expected size is kept for; slab sums per all-reduce
 
 struct VrgCtx {
@@ -154,9 +154,14 @@ struct VrgCtx {
     // one copy serves both class copies (a unit listed too early is read as all-excluded and adds nothing).  The dense
     // pass visits only the listed units: the 54 % of the bench volume outside the brain mask cost it one bit per KiB.
     uint32_t* ubits;
+    // ... and the units a sweep lists for the first time, by the sweep's parity: the dense stream's gate merges unew[k & 1] into
+    // ubits when it prepares pass k - the labels of sweep k are in place then, and sweep k + 2 cannot have started writing
+    // (it waits for pass k) - so pass k's list holds exactly the units listed up to sweep k, whatever the timing: which
+    // wave sums which unit, and with it the rounding of the intensity sums, is the same in every run
+    uint32_t* unew[2];
     // The listed units of this device's slab (whole units only) in ascending order: what the dense pass walks, all its
     // waves in formation (trip t of wave w takes entries (t * nwaves + w) * UNITS ...).  Rebuilt from the bitmap by the
-    // dense stream's gate kernel whenever a sweep listed a new unit (uctl[UC_GEN] != uctl[UC_LGEN]): always sorted, so the
+    // dense stream's gate kernel whenever the sweep listed a new unit (uctl[UC_GEN + parity]): always sorted, so the
     // order of the sums does not depend on which thread listed a unit first.
     uint32_t* ulist;
     uint32_t* uctl;            // UC_*: list length, generation the list was built at | generation of the bitmap (own cache line)

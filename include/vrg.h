@@ -106,6 +106,11 @@ const char* vrg_last_error(const vrg_handle* h);
  *                    (a mismatch surfaces as VRG_E_INTERNAL), so no run returns unchecked.  The handle stays valid.
  *   "fused"          any time; 1 (default): a sweep with at most 128 flips runs update() (:156-259) as ONE launch (k_sweep);
  *                    0: always the four-launch chain (k_order, k_mark_relabel, k_close).  Same results.
+ *   "bin_above"      before vrg_init; level tables (distinct intensity values) larger than this evaluate the exact densities of
+ *                    new band entries (:252-255) through intensity bins - proved relative error 2e-8, DESIGN.md section 4 -
+ *                    instead of summing over every level (default 2048; a huge value switches the bins off)
+ *   "memo_above"     any time; band entries above which a fused trip keeps the per-level memo of the density corrections
+ *                    (a launch of its own, k_memo; default 32768 - below that every entry sums its correction itself)
  *   "dense_off"      any time; measurement aid: the dense recount is not launched (the band chain alone);
  *                    the handle has to be initialised again afterwards
  *   "sweep_blocks", "prio_mode"

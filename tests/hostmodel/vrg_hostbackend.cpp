@@ -161,7 +161,14 @@ void be_init_sort(VrgBackend*, const VrgCtx& c, uint32_t n_in, uint32_t n_out) {
 static void dense_stats(const VrgCtx& c, const uint8_t* lab, be_reduce_fn cb, void* user, int last = 0) {
     int64_t a = 0, b = 0; double sa = 0, sb = 0;
     const uint32_t* cls = c.clsb[(c.dctl[VD_RSEQ] + (last ? 0 : 1)) & 1];
-    if (c.uctl[UC_LGEN] != c.uctl[UC_GEN]) vrg_ulist_rebuild_serial(c);          // (the device: k_gate, before every recount)
+    {   // (the device: k_gate, before every recount) the units this pass's sweep listed for the first time join the bitmap, then the list
+        const int p = (int)((c.dctl[VD_RSEQ] + (last ? 0 : 1)) & 1);
+        if (c.uctl[UC_GEN + p * UC_GEN_STRIDE]) {
+            for (size_t w = 0, nw = (((size_t)c.PV + 1023) >> 10) / 32 + 1; w < nw; w++) { c.ubits[w] |= c.unew[p][w]; c.unew[p][w] = 0; }
+            c.uctl[UC_GEN + p * UC_GEN_STRIDE] = 0;
+            vrg_ulist_rebuild_serial(c);
+        }
+    }
     std::vector<uint8_t> in_list((((size_t)c.PV + 1023) >> 10) + 1, 0);
     for (uint32_t i = 0; i < c.uctl[UC_N]; i++) { if (i && c.ulist[i] <= c.ulist[i - 1]) c.st->error = 6; in_list[c.ulist[i]] = 1; }
     const uint32_t plane_ = (uint32_t)c.PY * (uint32_t)c.PX, lo_ = (2u + (uint32_t)c.z0) * plane_, hi_ = (2u + (uint32_t)c.z1) * plane_;
@@ -367,6 +374,7 @@ void be_events_collect(VrgBackend*, VrgEvents*, long long) {}
 void be_sweep_batch(VrgBackend* b, const VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user) { for (int i = 0; i < n; i++) be_sweep_once(b, c, flags, ev, cb, user); }
 void be_dense_info(VrgBackend*, const VrgCtx& c, int64_t out[5]) { out[0] = 0; out[1] = c.lev16 ? 1 : (c.I ? 0 : 2); out[2] = 1; out[3] = 1; out[4] = 0; }
 void be_dense_flush(VrgBackend*, const VrgCtx&, be_reduce_fn, void*) {}
+long long be_memo_trips(VrgBackend*) { return 0; }
 
 void be_recount_hist(VrgBackend*, const VrgCtx& c, int32_t* rin, int32_t* rout) {
     for_real_voxels(c, [&](uint32_t idx, int, int, int) {

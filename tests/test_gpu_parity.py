@@ -222,6 +222,38 @@ def test_binned_exact_densities(lib, golden_loader):
     _binned_case(lib, golden_loader, 'gpu')
 
 
+def test_fused_trips_with_and_without_memo(lib, golden_loader):
+    """Fused trips (k_band -> k_sweep) against the oracle with the per-level memo of the corrections forced on (option
+    memo_above = 0: k_memo behind every fused sweep, what large bands get) and off, stepwise and in one call; the two must
+    also agree with each other and with the four-launch chain (fused = 0) in every label and list, densities to 1e-12."""
+    from arterynetwork_amd._capi import Session
+    for name in ('tube_q_small', 'adv_noise_q', 'int_torus', 'int_three_level', 'kat_sphere'):
+        g = golden_loader(name)
+        data, vmap = g.inputs()
+        iterMax = g.max_sweeps if g.max_sweeps >= 0 else 200
+        outs = []
+        for opts in ({'memo_above': 0}, {'memo_above': 1 << 30}, {'fused': 0}):
+            res, k = parity.run_stepwise(lib, data, vmap, g.H, g.maxSegmentSize, iterMax, density_mode=1, check_hist=True, options=opts)
+            assert res is not None and k == g.ncalls - 1, (name, opts)
+            s = Session(g.shape, lib=lib)
+            for kk, v in dict(opts, batch=7).items():
+                s.set_option(kk, v)
+            s.set_volume(data); s.set_labels(vmap); s.init(g.H)
+            s.run(iterMax, g.maxSegmentSize, None)
+            st = s.stats()
+            if 'fused' in opts:
+                assert st['fused_trips'] == 0
+            else:
+                assert st['fused_trips'] > 0 and (st['memo_trips'] > 0) == (opts['memo_above'] == 0), (name, opts, st)
+            outs.append((s.labels(), s.segmented(), s.band(0), s.band(1)))
+            s.close()
+        for o in outs[1:]:
+            assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]), name
+            for w in (2, 3):
+                assert np.array_equal(o[w][0], outs[0][w][0]), name
+                np.testing.assert_allclose(o[w][1], outs[0][w][1], rtol=1e-12, atol=1e-15); np.testing.assert_allclose(o[w][2], outs[0][w][2], rtol=1e-12, atol=1e-15)
+
+
 def test_skip_rule_closure_is_race_free(lib):
     """Regression: the skip-rule fix-point is computed by every workgroup of k_relabel for itself.  With a wrong
     termination test one workgroup could stop before another one's write became visible; this case then failed in

@@ -38,7 +38,7 @@ if FUSED:      # update() as one launch (k_sweep)
     NAMES = {0: 'k_band entry (wg 0)', 1: 'k_band state loaded', 2: 'k_band pool wg 0 done', 3: 'k_band first exact wg entry', 4: 'k_band first exact wg done',
              7: 'k_band touched levels staged (wg 0)', 40: 'k_band slots decided (wg 0, before the drain)',
              8: 'k_sweep entry (wg 0)', 9: 'k_sweep state + flip records back, gate passed', 10: 'k_sweep flips ranked', 18: 'k_sweep tile + fields + flip rows back, skip rule done',
-             19: 'k_sweep tile annotated', 12: 'k_sweep  (wg 0 thread 62) owner known', 13: 'k_sweep  (wg 0 thread 62) masks + ranks', 14: 'k_sweep  (wg 0 thread 62) ring2 done', 15: 'k_sweep  (wg 0 thread 62) cases done', 16: 'k_sweep  (wg 0 thread 62) stencil function left', 17: 'k_sweep  (wg 0 thread 87, other wave) stencil function left', 22: 'k_sweep stencil barrier passed (wg 0)', 35: 'k_sweep  (wg 0 thread 87) owner known', 36: 'k_sweep  (wg 0 thread 87) masks + ranks', 37: 'k_sweep  (wg 0 thread 87) ring2 + level done', 38: 'k_sweep  (wg 0 thread 87) cases done', 11: 'k_sweep listed neighbours found', 20: 'k_sweep stencils done, stores drained', 21: 'k_sweep events committed, drained (wg 0)',
+             19: 'k_sweep tile annotated', 11: 'k_sweep listed neighbours found', 20: 'k_sweep stencils done, stores drained', 21: 'k_sweep events committed, drained (wg 0)',
              28: 'k_sweep last ticket taken', 29: 'k_sweep sweep closed'}
 acc = {k: [] for k in NAMES}
 period = []

@@ -12,7 +12,7 @@ n_gpus = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 storage16 = bool(int(sys.argv[6])) if len(sys.argv) > 6 else False
 src = 'gpurun_out/prof_' + tag
 os.makedirs('profiles', exist_ok=True)
-KERNELS = ('k_recount_pipe', 'k_recount_bits', 'k_band', 'k_order', 'k_mark_relabel', 'k_close', 'k_gate')
+KERNELS = ('k_recount_pipe', 'k_recount_bits', 'k_band', 'k_sweep', 'k_memo', 'k_order', 'k_mark_relabel', 'k_close', 'k_gate')
 
 
 def short(n):
