@@ -56,6 +56,7 @@ void be_build_bins(VrgBackend* b, const VrgCtx& c);
 long long be_check_bins(VrgBackend* b, const VrgCtx& c, const int32_t* rin, const int32_t* rout);
 // 16-bit storage: level index of every voxel (after be_build_levels), padded layout
 void be_build_lev16(VrgBackend* b, const VrgCtx& c, uint16_t* dst);
+void be_build_lidx(VrgBackend* b, const VrgCtx& c, uint32_t* dst);    // large level tables: the level index of every voxel as 32 bits (c.lidx must be null during the call)
 
 // init mode (:129-155): labels by morphology + staged band entries; then order them and finish
 void be_init_band(VrgBackend* b, const VrgCtx& c);

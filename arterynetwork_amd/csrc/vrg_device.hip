@@ -646,7 +646,7 @@ __global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
     const uint32_t p = t;
     const int dx = (int)(p % 5) - 2, dy = (int)((p / 5) % 5) - 2, dz = (int)(p / 25) - 2;     // vrg_mark_pos
     const int ry = (int)(t % 9) - 4, rz = (int)(t / 9) - 4;                                   // the tile row thread t < 81 fetches
-    c.lev_fast = (cg.L <= LEV_LDS || cg.lev16 || cg.lev_map) ? 1 : 0;   // (the direct map: one load, requested with the mark and the ranks)
+    c.lev_fast = (cg.L <= LEV_LDS || cg.lev16 || cg.lev_map || cg.lidx) ? 1 : 0;   // (the direct map / the per-voxel level index: one load, requested with the rest)
     if (cg.L <= LEV_LDS) c.lev_map = nullptr;                              // (a table in LDS needs no load at all)
     // (every thread of the workgroup makes the same number of trips: the commit below needs its barriers)
     for (uint32_t r = blockIdx.x; r < nf; r += gridDim.x) {
@@ -666,8 +666,8 @@ __global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
         if (p < 125u) {
             const uint32_t ms = (uint32_t)(m < (int64_t)idx_lo ? (int64_t)idx_lo : (m > (int64_t)idx_hi ? (int64_t)idx_hi : m));
             pre.rank = (uint32_t)c.stamp[ms]; pre.vent = c.vent[ms];
-            pre.lev16 = c.lev16 ? (uint32_t)c.lev16[ms] : 0u;
-            pre.val = c.lev16 ? 0.0 : vrg_voxel_value(c, ms);
+            pre.lev16 = c.lev16 ? (uint32_t)c.lev16[ms] : c.lidx ? c.lidx[ms] : 0u;
+            pre.val = (c.lev16 || c.lidx) ? 0.0 : vrg_voxel_value(c, ms);
         }
         if (r == blockIdx.x && cg.L <= LEV_LDS && !cg.lev16) {           // (its loads queue behind those: one wait covers both)
             for (uint32_t l = t; l < cg.L; l += KM_THREADS) s_lev[l] = cg.lev[l];
@@ -2083,6 +2083,14 @@ long long be_check_bins(VrgBackend* b, const VrgCtx& c, const int32_t* rin, cons
     return (long long)bad;
 }
 
+__global__ void k_build_lidx(VrgCtx c, uint32_t* dst) {
+    VOXEL_LOOP(c) { int x, y, z; uint32_t idx = real_idx(c, t, x, y, z); dst[idx] = vrg_level_of(c, vrg_voxel_value(c, idx)); }
+}
+void be_build_lidx(VrgBackend* b, const VrgCtx& c, uint32_t* dst) {
+    use_device(b);
+    HIP_CHECK(hipMemsetAsync(dst, 0, ((size_t)c.PV + 1023) / 1024 * 1024 * 4, b->sa));
+    k_build_lidx<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, dst);
+}
 void be_build_lev16(VrgBackend* b, const VrgCtx& c, uint16_t* dst) {
     use_device(b);
     HIP_CHECK(hipMemsetAsync(dst, 0, ((size_t)c.PV + 1023) / 1024 * 1024 * 2, b->sa));

@@ -35,6 +35,7 @@ struct vrg_handle {
     bool fuse_mode = false;              // ... and the trips being enqueued now are of that kind
     int variant = 0, batch = 8, storage16 = 0, dense_off = 0;
     uint16_t* lev16_buf = nullptr;
+    uint32_t* lidx_buf = nullptr; bool lidx_valid = false;   // per-voxel level index of a large level table (VrgCtx::lidx)
     float* I32 = nullptr; double* I64 = nullptr;
     uint64_t band_capacity = 0;
     uint64_t cap_floor = 1u << 16;       // smallest pool / marked-list capacity (tests lower it to exercise the growth paths)
@@ -92,7 +93,7 @@ VrgDense get_dense(vrg_handle* h) {     // region sizes as the band side keeps t
 VrgState get_state(vrg_handle* h) {
     VrgState s; be_download(h->be, &s, h->c.st, sizeof(s));
     be_set_tuning(h->be, "band_hint", s.np);
-    be_set_tuning(h->be, "direct_hint", (uint64_t)h->c.L > (uint64_t)s.ni + s.no);
+    be_set_tuning(h->be, "direct_hint", !vrg_tab_pays(h->c.L, s.ni + s.no));
     return s;
 }
 void put_state(vrg_handle* h, const VrgState& s) {
@@ -260,6 +261,7 @@ int API(set_volume)(vrg_handle* h, const void* data, int dtype, const int64_t st
         release(h, (void*)c.lev); c.lev = nullptr;
         if (c.lev_map) { release(h, (void*)c.lev_map); c.lev_map = nullptr; }
         if (c.ktab) { release(h, (void*)c.ktab); c.ktab = nullptr; }
+        h->lidx_valid = false; c.lidx = nullptr;
         release(h, c.hin); release(h, c.hout); release(h, c.dIn); release(h, c.dOut); release(h, c.dConv); release(h, c.ltouch);
         release(h, c.nz_key); release(h, c.nz_val); release(h, c.nz_cin); release(h, c.nz_cout); release(h, c.nz_cconv); release(h, c.tabC);
         c.hin = c.hout = nullptr; c.dIn = c.dOut = c.dConv = c.ltouch = nullptr; c.nz_key = nullptr; c.nz_val = nullptr;
@@ -349,7 +351,13 @@ int API(init)(vrg_handle* h, double H) {
             c.nb = nb; c.bin_lo = ends[0]; c.bin_h = hh;
         }
     }
-    c.lev16 = nullptr;
+    c.lev16 = nullptr; c.lidx = nullptr;
+    if (!h->storage16 && L > (uint32_t)VRG_KTAB_LEVELS) {   // large level table: every voxel's level index once, instead of a search whenever a voxel enters the band
+        if (!h->lidx_buf) h->lidx_buf = alloc<uint32_t>(h, h->PVu);
+        if (!h->lidx_buf) return fail(h, VRG_E_MEM, "vrg_init: level-index volume");
+        if (!h->lidx_valid) { be_build_lidx(be, c, h->lidx_buf); h->lidx_valid = true; }
+        c.lidx = h->lidx_buf;
+    }
     if (h->storage16) {                             // 16-bit intensity storage: level indices + LDS value table
         if (L > 16384) return fail(h, VRG_E_ARG, "storage16: more than 16384 distinct intensity values");
         if (!h->lev16_buf) h->lev16_buf = alloc<uint16_t>(h, h->PVu);

@@ -159,7 +159,7 @@ VRG_HD uint32_t vrg_level_of(const VrgCtx& c, double v) {   // index of v in the
 }
 // level index of a voxel's intensity: stored (16-bit mode) or looked up in the sorted level table
 VRG_HD uint32_t vrg_voxel_level(const VrgCtx& c, uint32_t idx) {
-    return c.lev16 ? (uint32_t)c.lev16[idx] : vrg_level_of(c, vrg_voxel_value(c, idx));
+    return c.lev16 ? (uint32_t)c.lev16[idx] : c.lidx ? c.lidx[idx] : vrg_level_of(c, vrg_voxel_value(c, idx));
 }
 
 // The 3x3x3 neighbourhood of a voxel as four 27-bit masks (S, L, P, OOB bit of every neighbour).  The labels are
@@ -196,10 +196,10 @@ VRG_HD void vrg_preload(const VrgCtx& c, const uint8_t* lab, uint32_t idx, VrgPr
 #endif
     for (int j = 0; j < 9; j++) p.w[j] = vrg_load_row(lab + ((int64_t)idx + ((j % 3 - 1) * c.PY + (j / 3 - 1)) * c.PX - 1));
     p.rank = (uint32_t)c.stamp[idx]; p.vent = c.vent[idx];
-    p.lev16 = c.lev16 ? (uint32_t)c.lev16[idx] : 0u;
-    p.val = c.lev16 ? 0.0 : vrg_voxel_value(c, idx);
+    p.lev16 = c.lev16 ? (uint32_t)c.lev16[idx] : c.lidx ? c.lidx[idx] : 0u;
+    p.val = (c.lev16 || c.lidx) ? 0.0 : vrg_voxel_value(c, idx);
 }
-VRG_HD uint32_t vrg_pre_level(const VrgCtx& c, const VrgPre& p) { return c.lev16 ? p.lev16 : vrg_level_of(c, p.val); }
+VRG_HD uint32_t vrg_pre_level(const VrgCtx& c, const VrgPre& p) { return (c.lev16 || c.lidx) ? p.lev16 : vrg_level_of(c, p.val); }
 VRG_HD VrgNbr vrg_masks_of(const uint32_t* w) {
     VrgNbr m = {0u, 0u, 0u, 0u};
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -414,7 +414,12 @@ VRG_HD int32_t vrg_capacity_test(const VrgCtx& c, uint64_t nf) {
 // the trip stops (or is handed back): nothing pending for the next k_band
 VRG_HD void vrg_close_without_update(const VrgCtx& c) { c.stg->corr = 0; c.stg->nfx = 0; vrg_store_i64(&c.gate[VG_STOP], 1); }
 // update() begins: k_band has consumed the touched-level list of the sweep before
-VRG_HD void vrg_open_update(const VrgCtx& c) { c.stg->nnz = 0; c.stg->tab_ok = c.L <= c.st->ni + c.st->no; }
+// (memoise the corrections per level when there are at least VRG_TAB_RATIO band entries per level: the memo is built by 256
+// workgroups on the sweep's critical path, the entries sum their own corrections chip-wide in the shadow of the decisions -
+// 512x512x170, 6111 levels, 20 000 entries: 0.0464 ms/step with the memo, measured against the entry-by-entry rule)
+#define VRG_TAB_RATIO 4u
+VRG_HD bool vrg_tab_pays(uint32_t L, uint32_t band) { return (uint64_t)L * VRG_TAB_RATIO <= (uint64_t)band; }
+VRG_HD void vrg_open_update(const VrgCtx& c) { c.stg->nnz = 0; c.stg->tab_ok = vrg_tab_pays(c.L, c.st->ni + c.st->no); }
 
 // flip r of the ordered list: L bit (+P for flip-outs, which are always applied), stamp = (sweep, rank)
 VRG_HD void vrg_item_list_rec(const VrgCtx& c, uint32_t r, uint32_t slot, uint32_t idx, uint32_t lev, bool inner) {

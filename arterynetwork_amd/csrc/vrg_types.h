@@ -142,6 +142,10 @@ struct VrgCtx {
     const double* I64;         // ... or float64, when the volume has values fp32 cannot hold (then I is null)
     const uint16_t* lev16;     // optional 16-bit storage: level index per voxel (same layout); the dense pass then
                                // streams 2 B instead of 4 B of intensity per voxel (values come from an LDS table)
+    // large level tables (L > VRG_KTAB_LEVELS) without 16-bit storage: the level index of every voxel (same layout, built by
+    // vrg_init together with the class histograms) - the band kernels need a voxel's level when it enters the band or the outer
+    // region, and a search through a table of millions of values is 20+ dependent loads in the middle of the relabel stencil
+    const uint32_t* lidx;
     uint8_t* lab[2];           // lab[0]: label bytes, updated in place; lab[1]: scratch of the full-stencil check variant
     // class bits: what the dense pass needs of a label - inner (S) / outer (not S, not excluded) - 2 bits per voxel;
     // lane l of a wave owns dword l of each 1024-voxel unit (its 16 voxels 256*j + 4*l + b), so a unit is one coalesced

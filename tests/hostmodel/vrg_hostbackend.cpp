@@ -138,6 +138,10 @@ long long be_check_bins(VrgBackend* b, const VrgCtx& c, const int32_t* rin, cons
     return bad;
 }
 
+void be_build_lidx(VrgBackend*, const VrgCtx& c, uint32_t* dst) {
+    std::memset(dst, 0, (size_t)c.PV * 4);
+    for_real_voxels(c, [&](uint32_t idx, int, int, int) { dst[idx] = vrg_level_of(c, vrg_voxel_value(c, idx)); });
+}
 void be_build_lev16(VrgBackend*, const VrgCtx& c, uint16_t* dst) {
     std::memset(dst, 0, (size_t)c.PV * 2);
     for_real_voxels(c, [&](uint32_t idx, int, int, int) { dst[idx] = (uint16_t)vrg_level_of(c, vrg_voxel_value(c, idx)); });
@@ -274,7 +278,7 @@ static void fused_update(VrgBackend* b, const VrgCtx& c0) {
     for (uint32_t l = 0; l < c0.L; l++) { uint32_t ci, co, cc; if (vrg_fuse_level_touched(c0, l, ci, co, cc)) vrg_fuse_level_file(c0, q++, l, c0.lev[l], ci, co, cc); }
     int64_t n_in, n_out;
     const VrgState fin = vrg_fuse_close_load(c0, n_in, n_out);
-    const bool use_tab = c0.L <= snap.ni + snap.no && c0.ktab != nullptr;
+    const bool use_tab = vrg_tab_pays(c0.L, snap.ni + snap.no) && c0.ktab != nullptr;
     if (use_tab) {                                     // (the memo workgroups: one wave per level, lanes striding over the list, a fixed butterfly)
         std::vector<uint32_t> nzl(q);
         for (uint32_t j = 0; j < q; j++) nzl[j] = (uint32_t)c0.nz_key[j];
