@@ -90,7 +90,7 @@ bool be_wants_sync(VrgBackend* b, const VrgCtx& c);
 uint32_t be_small_flip_limit(VrgBackend* b);
 // fused trips: flips per sweep they take (more -> VBAIL_FUSE), whether this volume can run them at all, and what has to
 // happen when the engine switches to them after trips of another kind (the stream is idle then)
-uint32_t be_fuse_limit(VrgBackend* b);
+uint32_t be_fuse_limit(VrgBackend* b, const VrgCtx& c);
 bool be_fuse_ok(VrgBackend* b, const VrgCtx& c);
 void be_fuse_enter(VrgBackend* b, const VrgCtx& c);
 

@@ -905,8 +905,12 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
 // workgroup whose ticket comes last lists the sweep's touched levels and closes it.
 constexpr uint32_t FUSE_MEMO_NNZ = 1024;  // touched levels k_memo keeps in LDS; a sweep that touches more keeps no memo (corrections entry by entry)
 // memo_follows: the launch behind this one is k_memo (large bands: the corrections of the sweep memoised per level)
+// BIGL: a level table of more than VRG_FUSE_LEVELS values (never searched here: every voxel's level index is kept, VrgCtx::lidx):
+// the touched levels are listed by their first toucher and sorted by the closing workgroup instead of found by a scan.
+template <bool BIGL>
 __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_follows) {
-    __shared__ VrgFuseLds sh;
+    __shared__ VrgFuseLdsT<BIGL ? 1 : VRG_FUSE_LEVELS> sh;
+    __shared__ uint32_t s_keys[BIGL ? VRG_FUSE_KEYS : 1];
     __shared__ uint32_t s_scan[VRG_FUSE_THREADS / 64];
     __shared__ int s_last;
     constexpr uint32_t T = VRG_FUSE_THREADS;
@@ -919,7 +923,7 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     const int64_t nin0 = cg.inc[VC_NIN];
     vrg_fuse_init(sh, t);
     if (s0.done || s0.bail) return;
-    const int32_t gate = vrg_fuse_gate(cg, s0, nin0);      // stop tests (:91-104) / can the sweep run fused: the same answer everywhere
+    const int32_t gate = vrg_fuse_gate(cg, s0, nin0, vrg_fuse_limit(cg));      // stop tests (:91-104) / can the sweep run fused: the same answer everywhere
     if (gate) {
         if (st0) {
             if (gate > 0) cg.stg->done = gate == 1000 ? -1 : gate; else cg.stg->bail = -gate;
@@ -932,7 +936,7 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     if (st0) { VRG_STAMP_PUT(cg, 8, t_entry); VRG_STAMP(cg, 9); }
     VrgState sl = s0;                                      // (what the item functions read of the state: registers, not memory)
     VrgCtx c = cg;
-    c.st = &sl; c.lev_fast = 1; c.lvl_scan = 1;
+    c.st = &sl; c.lev_fast = 1; c.lvl_scan = BIGL ? 2 : 1;
     vrg_fuse_keys(sh, th, t, nf);
     __syncthreads();
     vrg_fuse_rank(c, sh, th, t, nf);
@@ -941,11 +945,15 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     vrg_fuse_load2(c, sh, th, t, r, nf);
     constexpr uint32_t PER_MAX = VRG_FUSE_LEVELS / VRG_FUSE_THREADS;
     double lv[PER_MAX];                                    // the level table (a voxel that enters the band needs the level of its intensity): requested with the rest
+    if constexpr (!BIGL) {
 #pragma unroll
-    for (uint32_t k = 0; k < PER_MAX; k++) { const uint32_t l = t + k * T; lv[k] = cg.lev[l < cg.L ? l : cg.L - 1u]; }   // (unconditional, index clamped)
+        for (uint32_t k = 0; k < PER_MAX; k++) { const uint32_t l = t + k * T; lv[k] = cg.lev[l < cg.L ? l : cg.L - 1u]; }   // (unconditional, index clamped)
+    }
     vrg_fuse_listed_nbrs(sh, t, nf);                       // (LDS work while the loads travel)
+    if constexpr (!BIGL) {
 #pragma unroll
-    for (uint32_t k = 0; k < PER_MAX; k++) { const uint32_t l = t + k * T; if (!cg.lev16 && l < cg.L) sh.lev[l] = lv[k]; }
+        for (uint32_t k = 0; k < PER_MAX; k++) { const uint32_t l = t + k * T; if (!cg.lev16 && l < cg.L) sh.lev[l] = lv[k]; }
+    }
     __syncthreads();
     if (st0) VRG_STAMP(cg, 11);
     vrg_fuse_prepass(sh, th, t, nf);
@@ -982,10 +990,19 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     __syncthreads();
     if (!s_last) return;
     if (t == 0) VRG_STAMP(cg, 28);
-    // the touched levels in ascending order (thread t its stretch of levels, a block scan for the places), counters zeroed
-    const uint32_t per = (cg.L + T - 1u) / T, l0 = t * per;
     int64_t fin_nin, fin_nout;
     const VrgState fin = vrg_fuse_close_load(c, fin_nin, fin_nout);    // (every thread asks - the same words, one request -: no branch around the loads, they travel with the counters)
+    uint32_t total = 0;
+    if constexpr (BIGL) {
+        // the levels the sweep's first touchers listed (written through, read past L1), sorted in LDS, filed with their counts
+        total = min(min(fin.nnz_new, cg.zcap), (uint32_t)VRG_FUSE_KEYS);
+        for (uint32_t j = t; j < total; j += T) s_keys[j] = (uint32_t)vrg_load_u64(&cg.nz_key[j]);
+        __syncthreads();
+        wg_sort_pairs(s_keys, (uint32_t*)nullptr, total, false);
+        for (uint32_t j = t; j < total; j += T) vrg_fuse_level_file_listed(c, j, s_keys[j]);
+    } else {
+    // the touched levels in ascending order (thread t its stretch of levels, a block scan for the places), counters zeroed
+    const uint32_t per = (cg.L + T - 1u) / T, l0 = t * per;
     uint32_t ci[PER_MAX], co[PER_MAX], cc[PER_MAX], cnt = 0;
 #pragma unroll
     for (uint32_t k = 0; k < PER_MAX; k++) {
@@ -996,7 +1013,7 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     const uint32_t incl = wave_incl_scan(cnt);
     if ((t & 63u) == 63u) s_scan[t >> 6] = incl;
     __syncthreads();
-    uint32_t base = 0, total = 0;
+    uint32_t base = 0;
     for (uint32_t w = 0; w < T / 64; w++) { if (w < (t >> 6)) base += s_scan[w]; total += s_scan[w]; }
     uint32_t q = base + incl - cnt;
 #pragma unroll
@@ -1006,6 +1023,7 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
             if (cg.lev16) vrg_fuse_level_file(c, q++, l, cg.lev[l], ci[k], co[k], cc[k]);     // (two calls: one pointer into LDS, one into memory - never a generic one)
             else vrg_fuse_level_file(c, q++, l, sh.lev[l], ci[k], co[k], cc[k]);
         }
+    }
     if (t == 0) { vrg_fuse_close(c, fin, fin_nin, fin_nout, total, memo_follows && total <= FUSE_MEMO_NNZ); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 29); }
 }
 // (entering fused trips after trips of another kind: the per-level counters of the last sweep are still listed, not yet zero)
@@ -1915,9 +1933,9 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != b->prio_mode) { b->prio_mode = (int)v; make_streams(b); }
 }
 uint32_t be_small_flip_limit(VrgBackend* b) { return b->small_flips; }
-uint32_t be_fuse_limit(VrgBackend*) { return VRG_FUSE_MAX; }
+uint32_t be_fuse_limit(VrgBackend*, const VrgCtx& c) { return vrg_fuse_limit(c); }
 // fused trips need the level table in the workgroup's LDS (or 16-bit level indices)
-bool be_fuse_ok(VrgBackend*, const VrgCtx& c) { return c.L <= (uint32_t)VRG_FUSE_LEVELS; }
+bool be_fuse_ok(VrgBackend*, const VrgCtx& c) { return c.L <= (uint32_t)VRG_FUSE_LEVELS || c.lidx != nullptr; }     // (a large level table: with every voxel's level index at hand)
 void be_fuse_enter(VrgBackend* b, const VrgCtx& c) { use_device(b); k_levels_clear<<<1, TPB, 0, b->sa>>>(c); }
 bool be_wants_sync(VrgBackend*, const VrgCtx&) { return false; }     // (every level-table size runs batched trips: large tables evaluate their exact densities through the bins)
 
@@ -2323,7 +2341,8 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
         // update() as ONE launch; on a large band a second one memoises the sweep's corrections per level
         const bool memo = !b->direct_hint && b->band_hint > b->memo_above && c.ktab;
         b->memo_trips += memo;
-        hipExtLaunchKernelGGL(k_sweep, dim3(VRG_FUSE_MAX), dim3(VRG_FUSE_THREADS), 0, b->sa, nullptr, memo ? nullptr : e_c1, 0, c, memo ? 1 : 0);
+        if (c.L > (uint32_t)VRG_FUSE_LEVELS) hipExtLaunchKernelGGL(k_sweep<true>, dim3(VRG_FUSE_MAX_BIG), dim3(VRG_FUSE_THREADS), 0, b->sa, nullptr, memo ? nullptr : e_c1, 0, c, 0);
+        else hipExtLaunchKernelGGL(k_sweep<false>, dim3(VRG_FUSE_MAX), dim3(VRG_FUSE_THREADS), 0, b->sa, nullptr, memo ? nullptr : e_c1, 0, c, memo ? 1 : 0);
         if (memo) hipExtLaunchKernelGGL(k_memo, dim3(MEMO_BLOCKS), dim3(TPB), 0, b->sa, nullptr, e_c1, 0, c);
         b->fused_prev = true; b->fused_memo = memo;
         return;

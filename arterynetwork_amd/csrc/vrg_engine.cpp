@@ -423,7 +423,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     double cms0 = h->ev.chain_ms_total; long long cl0 = h->ev.chain_launches;
     auto t_begin = std::chrono::steady_clock::now();
     const int base_flags = ((h->variant & 1) ? VRG_SWEEP_FULL : 0) | (h->dense_off ? VRG_SWEEP_NODENSE : 0);
-    const uint32_t small = be_small_flip_limit(be), fuse_max = be_fuse_limit(be);
+    const uint32_t small = be_small_flip_limit(be), fuse_max = be_fuse_limit(be, c);
     const bool can_fuse = h->fused && !(base_flags & VRG_SWEEP_FULL) && be_fuse_ok(be, c);
     // (a run starts fused when the sweep before - if any - had few flips; the switch is made with the streams idle)
     if (can_fuse && !h->fuse_mode && !h->sync_mode && 2 * (uint64_t)s.last_nf <= fuse_max) { be_fuse_enter(be, c); h->fuse_mode = true; get_state(h); }

@@ -498,10 +498,11 @@ VRG_HD void vrg_item_scatter_marks(const VrgCtx& c, uint32_t r, uint32_t p) {
 // this sweep's innerAdded / outerAdded / addedPoints (:232-235), by level; the first toucher lists the level
 VRG_HD void vrg_note_level(const VrgCtx& c, uint32_t* cnt, uint32_t lev) {
     vrg_atomic_add(&cnt[lev], 1u);
-    if (c.lvl_scan) return;                           // (whoever closes the sweep scans the counters: no returning atomics here)
+    if (c.lvl_scan == 1) return;                      // (whoever closes the sweep scans the counters: no returning atomics here)
     if (vrg_atomic_or(&c.ltouch[lev], 1u) == 0u) {
-        uint32_t q = vrg_atomic_add(&c.stg->nnz, 1u);
-        if (q < c.zcap) c.nz_key[q] = lev; else c.stg->error = 8;
+        // (the entry is written THROUGH: in a fused sweep the workgroup that closes the sweep - another CU, another XCD - reads it)
+        uint32_t q = vrg_atomic_add(c.lvl_scan == 2 ? &c.stg->nnz_new : &c.stg->nnz, 1u);
+        if (q < c.zcap) vrg_store_u64(&c.nz_key[q], (uint64_t)lev); else c.stg->error = 8;
     }
 }
 // What the relabel of one voxel means for the band pool: at most one event per voxel.  The stencil only DESCRIBES it;
@@ -943,7 +944,7 @@ VRG_HD void vrg_finalize_update(const VrgCtx& c, VrgState& s, int64_t n_in, int6
     s.nf = 0; s.npend = 0; s.nmk = 0; s.nalloc = 0; s.ndead = 0; s.d_ni = 0; s.d_no = 0;
     s.nfx = s.nfresh; s.nfresh = 0;                   // exact densities of the new entries: first thing next trip
     s.corr = 1; s.use_tab = use_tab ? 1 : 0;          // nnz stays: the next k_band reads the touched-level list
-    s.apply_pending = 0; s.ap_n = 0; s.fr_n = 0; s.d_nin = 0; s.d_nout = 0; s.nvisit = 0;   // (the fused sweep's closing thread sets its own afterwards)
+    s.apply_pending = 0; s.ap_n = 0; s.fr_n = 0; s.d_nin = 0; s.d_nout = 0; s.nvisit = 0; s.nnz_new = 0;   // (the fused sweep's closing thread sets its own afterwards)
     if (s.error) { s.done = -1; vrg_store_i64(&c.gate[VG_STOP], 1); }
 }
 VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
@@ -986,7 +987,7 @@ VRG_HD void vrg_close_sweep(const VrgCtx& c, int64_t nchg_at, bool use_tab) {
 //    levels for the next k_band's corrections and closes the sweep (vrg_fuse_close).
 // Same data structures as the four-launch chain, so a trip can go either way (k_sweep hands a sweep with more flips back:
 // VBAIL_FUSE) and both are checked against the oracle by the same tests.
-struct VrgFuseLds {
+template <int NLEV> struct VrgFuseLdsT {
     uint64_t key[VRG_FUSE_MAX];                                        // sort keys as appended (place = append order)
     uint32_t f_idx[VRG_FUSE_MAX], f_slot[VRG_FUSE_MAX], f_lev[VRG_FUSE_MAX];   // by rank: voxel, slot, level
     uint32_t f_L[VRG_FUSE_MAX], f_FI[VRG_FUSE_MAX];                     // ... which of its 26 neighbours are listed flips / listed flip-ins (27-bit masks)
@@ -996,24 +997,27 @@ struct VrgFuseLds {
     uint16_t rank[729];                                                // ... rank of the flip sitting there (0xffff: none)
     uint32_t any_pend, changed;
     uint32_t n[3], base[3], nvis; int32_t d[4];                        // this workgroup's new / dead / pending events, visited flips, list and size changes
-    double lev[VRG_FUSE_LEVELS];                                       // the level table
+    double lev[NLEV];                                                  // the level table (small level tables; a large one is never searched: VrgCtx::lidx)
 };
+typedef VrgFuseLdsT<VRG_FUSE_LEVELS> VrgFuseLds;
 struct VrgFuseThread {                                                 // what a thread keeps in registers between the phases
     uint64_t key; uint32_t slot, idx, lev;                             // the flip record k_band appended at place t
     uint32_t row[4];                                                   // tile row t
     uint32_t frow[9];                                                  // the nine label rows around flip t (by rank)
     VrgPre pre;                                                        // per-voxel fields of cube place t
-    float valf; double val64; uint16_t l16;                            // ... its intensity as loaded (whichever storage the volume has: converted when used)
+    float valf; double val64; uint16_t l16; uint32_t l32;              // ... its intensity as loaded (whichever storage the volume has: converted when used), its level index
     VrgEvent ev; uint32_t rn, rd, rf;
 };
-VRG_HD uint32_t vrg_fuse_level_of(const VrgFuseLds& sh, uint32_t L, double v) {   // vrg_level_of on the LDS copy of the table
+template <class LDS>
+VRG_HD uint32_t vrg_fuse_level_of(const LDS& sh, uint32_t L, double v) {   // vrg_level_of on the LDS copy of the table
     uint32_t lo = 0, hi = L - 1u;
     while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (sh.lev[m] < v) lo = m + 1u; else hi = m; }
     return lo;
 }
 VRG_HD uint32_t vrg_fuse_tile_row(int dy, int dz) { return (uint32_t)((dz + 4) * 9 + (dy + 4)); }
 VRG_HD uint32_t vrg_fuse_tile_pos(int dx, int dy, int dz) { return (uint32_t)(((dz + 4) * 9 + (dy + 4)) * 9 + (dx + 4)); }
-VRG_HD uint8_t vrg_fuse_tile_byte(const VrgFuseLds& sh, int dx, int dy, int dz) {
+template <class LDS>
+VRG_HD uint8_t vrg_fuse_tile_byte(const LDS& sh, int dx, int dy, int dz) {
     const uint32_t o = (uint32_t)(dx + 4);
     return (uint8_t)(sh.tile[4 * vrg_fuse_tile_row(dy, dz) + (o >> 2)] >> (8u * (o & 3u)));
 }
@@ -1027,7 +1031,8 @@ VRG_HD void vrg_load_row16(const uint8_t* p, uint32_t out[4]) {
 #endif
 }
 // can this trip run fused?  0: yes; > 0: stop reason; < 0: -(bail reason).  The same answer in every workgroup (same inputs).
-VRG_HD int32_t vrg_fuse_gate(const VrgCtx& c, const VrgState& s0, int64_t n_in, uint32_t fuse_max = VRG_FUSE_MAX) {
+VRG_HD uint32_t vrg_fuse_limit(const VrgCtx& c) { return c.L > (uint32_t)VRG_FUSE_LEVELS ? (uint32_t)VRG_FUSE_MAX_BIG : (uint32_t)VRG_FUSE_MAX; }
+VRG_HD int32_t vrg_fuse_gate(const VrgCtx& c, const VrgState& s0, int64_t n_in, uint32_t fuse_max) {
     const int32_t stop = vrg_stop_test_v(s0, n_in);
     if (stop) return stop;
     if (s0.error) return 1000;
@@ -1036,7 +1041,8 @@ VRG_HD int32_t vrg_fuse_gate(const VrgCtx& c, const VrgState& s0, int64_t n_in, 
     return bail ? -bail : 0;
 }
 // phase 0: LDS arrays that must start empty (runs while the first loads travel)
-VRG_HD void vrg_fuse_init(VrgFuseLds& sh, uint32_t t) {
+template <class LDS>
+VRG_HD void vrg_fuse_init(LDS& sh, uint32_t t) {
     for (uint32_t i = t; i < 729u; i += VRG_FUSE_THREADS) sh.rank[i] = 0xffffu;
     if (t < (uint32_t)VRG_FUSE_MAX) { sh.f_L[t] = 0; sh.f_FI[t] = 0; }
     if (t < 3) sh.n[t] = 0;
@@ -1050,10 +1056,12 @@ VRG_HD void vrg_fuse_load1(const VrgCtx& c, VrgFuseThread& th, uint32_t t) {
     const uint32_t q = t < c.fcap ? t : c.fcap - 1u;
     th.key = c.f_key[q]; th.slot = c.flist[q]; th.idx = c.fr_idx[q]; th.lev = c.fr_lev[q];
 }
-VRG_HD void vrg_fuse_keys(VrgFuseLds& sh, const VrgFuseThread& th, uint32_t t, uint32_t nf) { if (t < nf) sh.key[t] = th.key; }
+template <class LDS>
+VRG_HD void vrg_fuse_keys(LDS& sh, const VrgFuseThread& th, uint32_t t, uint32_t nf) { if (t < nf) sh.key[t] = th.key; }
 // rank of record t = number of smaller keys (keys are distinct): the reference's flip order (:48, :88); the records by rank,
 // the voxel -> rank hash set
-VRG_HD void vrg_fuse_rank(const VrgCtx& c, VrgFuseLds& sh, const VrgFuseThread& th, uint32_t t, uint32_t nf) {
+template <class LDS>
+VRG_HD void vrg_fuse_rank(const VrgCtx& c, LDS& sh, const VrgFuseThread& th, uint32_t t, uint32_t nf) {
     if (t >= nf) return;
     uint32_t r = 0;
     for (uint32_t j = 0; j < nf; j++) r += sh.key[j] < th.key;
@@ -1063,7 +1071,8 @@ VRG_HD void vrg_fuse_rank(const VrgCtx& c, VrgFuseLds& sh, const VrgFuseThread& 
 }
 // second batch of loads (addresses follow from the ranked records): tile row t of the workgroup's flip, the per-voxel
 // fields of cube place t, the nine label rows around flip t
-VRG_HD void vrg_fuse_load2(const VrgCtx& c, const VrgFuseLds& sh, VrgFuseThread& th, uint32_t t, uint32_t r, uint32_t nf) {
+template <class LDS>
+VRG_HD void vrg_fuse_load2(const VrgCtx& c, const LDS& sh, VrgFuseThread& th, uint32_t t, uint32_t r, uint32_t nf) {
     const uint8_t* lab = c.lab[0];
     const uint32_t fidx = sh.f_idx[r];
     {   // tile row (t < 81; the other threads re-read row 80).  A row that is not wholly inside the allocation - 16 guard bytes at
@@ -1090,7 +1099,8 @@ VRG_HD void vrg_fuse_load2(const VrgCtx& c, const VrgFuseLds& sh, VrgFuseThread&
         const float* pf = c.I ? c.I : reinterpret_cast<const float*>(c.I64);
         const double* pd = c.I64 ? c.I64 : reinterpret_cast<const double*>(c.I);
         const uint16_t* p16 = c.lev16 ? c.lev16 : reinterpret_cast<const uint16_t*>(c.I ? (const void*)c.I : (const void*)c.I64);
-        th.valf = pf[ms]; th.val64 = pd[c.I64 ? ms : (ms >> 1)]; th.l16 = p16[ms];
+        const uint32_t* p32 = c.lidx ? c.lidx : reinterpret_cast<const uint32_t*>(c.I ? (const void*)c.I : (const void*)c.I64);
+        th.valf = pf[ms]; th.val64 = pd[c.I64 ? ms : (ms >> 1)]; th.l16 = p16[ms]; th.l32 = p32[ms];
     }
     {   // the nine label rows around flip t (t < nf; only a flip-in's are looked at - flip-outs are always applied)
         const uint32_t idx = sh.f_idx[t < nf ? t : nf - 1u];
@@ -1104,7 +1114,8 @@ VRG_HD void vrg_fuse_load2(const VrgCtx& c, const VrgFuseLds& sh, VrgFuseThread&
 // `parts` threads sharing a flip-in's partners.  (Pairs, not a voxel -> flip hash set probed 26 times per flip: a probe is a
 // chain of dependent LDS reads of ~100 cycles each, while the partners' coordinates are read one after the other, independent
 // of each other.)  Neighbour n of the masks = 3 * j + (dx + 1) with j = 3 * (dy + 1) + (dz + 1).
-VRG_HD void vrg_fuse_listed_nbrs(VrgFuseLds& sh, uint32_t t, uint32_t nf) {
+template <class LDS>
+VRG_HD void vrg_fuse_listed_nbrs(LDS& sh, uint32_t t, uint32_t nf) {
     const uint32_t parts = nf >= (uint32_t)VRG_FUSE_THREADS ? 1u : (uint32_t)VRG_FUSE_THREADS / nf;
     const uint32_t f = t / parts, part = t - f * parts;
     if (f >= nf || sh.f_inner[f]) return;                  // (flip-outs are always applied: only a flip-in's neighbourhood is looked at)
@@ -1122,7 +1133,8 @@ VRG_HD void vrg_fuse_listed_nbrs(VrgFuseLds& sh, uint32_t t, uint32_t nf) {
 }
 // the tile into LDS; the skip rule for flip t (:183-190, :198): a flip-in that dropped to 3 in phase A (a flip-out neighbour and
 // no segmented neighbour left) is pending, every other flip is applied
-VRG_HD void vrg_fuse_prepass(VrgFuseLds& sh, const VrgFuseThread& th, uint32_t t, uint32_t nf) {
+template <class LDS>
+VRG_HD void vrg_fuse_prepass(LDS& sh, const VrgFuseThread& th, uint32_t t, uint32_t nf) {
     if (t < 81u) { sh.tile[4 * t] = th.row[0]; sh.tile[4 * t + 1] = th.row[1]; sh.tile[4 * t + 2] = th.row[2]; sh.tile[4 * t + 3] = th.row[3]; }
     if (t >= nf) return;
     if (sh.f_inner[t]) { sh.f_P[t] = 1; sh.f_pend[t] = 0; return; }
@@ -1138,7 +1150,8 @@ VRG_HD void vrg_fuse_prepass(VrgFuseLds& sh, const VrgFuseThread& th, uint32_t t
     if (pend) vrg_lds_or(&sh.any_pend, 1u);
 }
 // one relaxation of the skip rule's fix-point (vrg_item_fix): applied if an applied flip-in neighbour of smaller rank exists
-VRG_HD void vrg_fuse_fix(const VrgCtx& c, VrgFuseLds& sh, uint32_t t, uint32_t nf) {
+template <class LDS>
+VRG_HD void vrg_fuse_fix(const VrgCtx& c, LDS& sh, uint32_t t, uint32_t nf) {
     if (t >= nf || !sh.f_pend[t] || sh.f_P[t]) return;
     const int x = sh.f_x[t], y = sh.f_y[t], z = sh.f_z[t];
     for (uint32_t g = 0; g < t; g++) {
@@ -1148,7 +1161,8 @@ VRG_HD void vrg_fuse_fix(const VrgCtx& c, VrgFuseLds& sh, uint32_t t, uint32_t n
     }
 }
 // flip t, if it lies inside the workgroup's tile: its L (+ P) bits into the tile, its rank into the rank tile
-VRG_HD void vrg_fuse_annotate(const VrgCtx& c, VrgFuseLds& sh, uint32_t t, uint32_t r, uint32_t nf) {
+template <class LDS>
+VRG_HD void vrg_fuse_annotate(const VrgCtx& c, LDS& sh, uint32_t t, uint32_t r, uint32_t nf) {
     if (t >= nf) return;
     const int dx = (int)sh.f_x[t] - (int)sh.f_x[r], dy = (int)sh.f_y[t] - (int)sh.f_y[r], dz = (int)sh.f_z[t] - (int)sh.f_z[r];
     if (dx < -4 || dx > 4 || dy < -4 || dy > 4 || dz < -4 || dz > 4) return;
@@ -1158,7 +1172,8 @@ VRG_HD void vrg_fuse_annotate(const VrgCtx& c, VrgFuseLds& sh, uint32_t t, uint3
 }
 // cube place t: is this workgroup's flip (rank r) the owner of the voxel - the flip of smallest rank that wants it
 // (vrg_mark_wanted: 1-ring of a listed flip; 2-ring too for an excluded voxel)?  Then the relabel stencil from the tile.
-VRG_HD void vrg_fuse_stencil(const VrgCtx& c, VrgFuseLds& sh, VrgFuseThread& th, uint32_t t, uint32_t r) {
+template <class LDS>
+VRG_HD void vrg_fuse_stencil(const VrgCtx& c, LDS& sh, VrgFuseThread& th, uint32_t t, uint32_t r) {
     th.ev.kind = VE_NONE; th.ev.pend = 0; th.rn = th.rd = th.rf = 0;
     if (t >= 125u) return;
     const uint32_t place = r * (uint32_t)VRG_FUSE_PLACES + t;
@@ -1219,13 +1234,13 @@ VRG_HD void vrg_fuse_stencil(const VrgCtx& c, VrgFuseLds& sh, VrgFuseThread& th,
         ring2 = any != 0;
     }
     th.pre.rank = sh.rank[vrg_fuse_tile_pos(dx, dy, dz)];              // (its own rank, if the voxel is a listed flip)
-    th.pre.lev16 = th.l16; th.pre.val = c.I ? (double)th.valf : th.val64;
+    th.pre.lev16 = c.lev16 ? (uint32_t)th.l16 : th.l32; th.pre.val = c.I ? (double)th.valf : th.val64;
     // the voxel's level, where the cases will ask for it (c.lev_fast = 1): a flip's from its record; a voxel that may enter the
     // band or the outer region searches the level table in LDS (through sh, not through the context's generic pointer: a
     // flat load waits for every atomic the wave has in flight); nobody else pays for a search
     uint32_t lev_here = 0xffffffffu;
     if (mb & VB_L) lev_here = sh.f_lev[th.pre.rank];
-    else if (!(mb & VB_B) && ((mb & VB_S) ? FO != 0u : (AP != 0u || (mb & VB_X)))) lev_here = c.lev16 ? th.pre.lev16 : vrg_fuse_level_of(sh, c.L, th.pre.val);
+    else if (!(mb & VB_B) && ((mb & VB_S) ? FO != 0u : (AP != 0u || (mb & VB_X)))) lev_here = (c.lev16 || c.lidx) ? th.pre.lev16 : vrg_fuse_level_of(sh, c.L, th.pre.val);
     const uint8_t nw = vrg_sweep_cases(c, m, mb, th.pre, nb, q, ring2, lev_here, th.ev);
     c.mk_idx[place] = m; c.mk_new[place] = nw; c.mk_old[place] = mb;
     if (mb & VB_L) vrg_lds_add(&sh.nvis, 1u);
@@ -1242,13 +1257,15 @@ VRG_HD void vrg_fuse_stencil(const VrgCtx& c, VrgFuseLds& sh, VrgFuseThread& th,
     if (dq) vrg_lds_add(&sh.d[1], dq);
 }
 // the workgroup reserves its stretch of every list with ONE atomic each (threads 0..8)
-VRG_HD void vrg_fuse_reserve(const VrgCtx& c, VrgFuseLds& sh, uint32_t t) {
+template <class LDS>
+VRG_HD void vrg_fuse_reserve(const VrgCtx& c, LDS& sh, uint32_t t) {
     if (t < 3u) { if (sh.n[t]) sh.base[t] = vrg_atomic_add(t == 0 ? &c.stg->nalloc : t == 1 ? &c.stg->ndead : &c.stg->nfresh, sh.n[t]); }
     else if (t < 7u) { if (sh.d[t - 3u]) vrg_atomic_add(t == 3 ? &c.stg->d_ni : t == 4 ? &c.stg->d_no : t == 5 ? &c.stg->d_nin : &c.stg->d_nout, sh.d[t - 3u]); }
     else if (t == 7u) { if (sh.nvis) vrg_atomic_add(&c.stg->nvisit, sh.nvis); }
 }
 // ... and every event is written at its place; the workgroup's flip gets its stamp = (sweep, rank) (:200: segmented's list order)
-VRG_HD void vrg_fuse_commit(const VrgCtx& c, const VrgFuseLds& sh, const VrgFuseThread& th, uint32_t t, uint32_t r) {
+template <class LDS>
+VRG_HD void vrg_fuse_commit(const VrgCtx& c, const LDS& sh, const VrgFuseThread& th, uint32_t t, uint32_t r) {
     if (th.ev.kind != VE_NONE) {
         const int dx = (int)(t % 5u) - 2, dy = (int)((t / 5u) % 5u) - 2, dz = (int)(t / 25u) - 2;
         const uint32_t m = (uint32_t)((int64_t)sh.f_idx[r] + ((int64_t)dz * c.PY + dy) * c.PX + dx);
@@ -1265,6 +1282,12 @@ VRG_HD bool vrg_fuse_level_touched(const VrgCtx& c, uint32_t l, uint32_t& ci, ui
 VRG_HD void vrg_fuse_level_file(const VrgCtx& c, uint32_t q, uint32_t l, double v, uint32_t ci, uint32_t co, uint32_t cc) {
     c.nz_key[q] = l; c.nz_val[q] = v; c.nz_cin[q] = ci; c.nz_cout[q] = co; c.nz_cconv[q] = cc;
     c.dIn[l] = 0; c.dOut[l] = 0; c.dConv[l] = 0;
+}
+// (large level table: entry q of the SORTED list of the levels the sweep's first touchers listed)
+VRG_HD void vrg_fuse_level_file_listed(const VrgCtx& c, uint32_t q, uint32_t l) {
+    uint32_t ci, co, cc; (void)vrg_fuse_level_touched(c, l, ci, co, cc);
+    vrg_fuse_level_file(c, q, l, c.lev[l], ci, co, cc);
+    c.ltouch[l] = 0;
 }
 // the per-level memo of the three corrections (:236-247) for level l from the touched-level list (in LDS: levels' indices and
 // counts), lanes striding over the list, the kernel between two levels from the table - the same terms in the same order as
@@ -1284,6 +1307,7 @@ VRG_HD void vrg_fuse_memo_terms(const VrgCtx& c, uint32_t l, uint32_t lane, uint
 VRG_HD VrgState vrg_fuse_close_load(const VrgCtx& c, int64_t& n_in, int64_t& n_out) {
     VrgState s = vrg_finalize_load(c, n_in, n_out);
     s.d_nin = vrg_load_i32(&c.stg->d_nin); s.d_nout = vrg_load_i32(&c.stg->d_nout); s.nvisit = vrg_load_u32(&c.stg->nvisit);
+    s.nnz_new = vrg_load_u32(&c.stg->nnz_new);
     return s;
 }
 VRG_HD void vrg_fuse_close(const VrgCtx& c, VrgState s, int64_t n_in, int64_t n_out, uint32_t nnz, bool use_tab) {

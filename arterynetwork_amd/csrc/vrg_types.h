@@ -53,6 +53,10 @@ enum { VRG_BIN_K = 8 };
 #define VRG_BIN_T 745.2          // exp(-T) is 0.0 in double arithmetic beyond this: a bin further than sqrt(2T/H) contributes exactly nothing
 #define VRG_BIN_SCALE 1073741824.0   // 2^30
 enum { VRG_FUSE_MAX = 128, VRG_FUSE_THREADS = 128, VRG_FUSE_LEVELS = 2048, VRG_FUSE_PLACES = 125 };
+// ... on a LARGE level table (more than VRG_FUSE_LEVELS values; needs the per-voxel level index VrgCtx::lidx): the touched levels
+// are listed by their first toucher and sorted by whoever closes the sweep - in LDS, VRG_FUSE_KEYS of them at most; a voxel
+// touches one level, a flip owns at most 125 voxels: VRG_FUSE_MAX_BIG flips can never list more
+enum { VRG_FUSE_KEYS = 8192, VRG_FUSE_MAX_BIG = VRG_FUSE_KEYS / VRG_FUSE_PLACES };      // (a power of two: sorted in place)
 
 struct VrgTrace {            // one record per update() call (0 = init)
     int64_t nflip, nseg, n_in, n_out, ni, no;
@@ -105,6 +109,8 @@ struct VrgState {
     uint32_t fr_base, fr_n;            // ... and the dead slots still to be put onto the free list: freel[fr_base + j] = dead[j], j < fr_n
     int32_t d_nin, d_nout;             // region size changes of the sweep in progress (k_sweep adds them up; the closing thread moves them into VrgCtx::inc)
     uint32_t nvisit;                   // listed flips the fused stencil visited (must equal nf)
+    uint32_t nnz_new;                  // fused sweep on a large level table: levels listed so far by the sweep in progress (nnz still says what the
+                                       // sweep before left for this trip's k_band)
 };
 
 // results of the dense recount; written by the dense stream only (own allocation, own cache lines).
@@ -250,6 +256,7 @@ struct VrgCtx {
     // per-launch modes of the batched kernels (a kernel gets its own copy of this struct):
     int32_t lvl_scan;          // 1: the levels a sweep touched are found by scanning the per-level counters when it closes
                                //    (small level tables); vrg_note_level then only counts - no list-building atomics
+                               // 2: (fused sweep, large level table) listed by the first toucher, counted in VrgState::nnz_new
     int32_t lev_fast;          // 1: a voxel's level index is cheap here (16-bit storage, or the level table in LDS): a flip's
                                //    level is looked up from its intensity instead of fetched through its rank
     uint32_t* counters;        // arrival tickets of the last-workgroup reductions (zero between launches)

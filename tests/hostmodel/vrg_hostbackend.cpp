@@ -34,8 +34,8 @@ void be_sync(VrgBackend*) {}
 const char* be_last_error(VrgBackend*) { return nullptr; }
 void be_clear_error(VrgBackend*) {}
 uint32_t be_small_flip_limit(VrgBackend* b) { return b->small_flips; }
-uint32_t be_fuse_limit(VrgBackend* b) { return b->fuse_max; }
-bool be_fuse_ok(VrgBackend*, const VrgCtx& c) { return c.L <= (uint32_t)VRG_FUSE_LEVELS; }
+uint32_t be_fuse_limit(VrgBackend* b, const VrgCtx& c) { return std::min(b->fuse_max, vrg_fuse_limit(c)); }
+bool be_fuse_ok(VrgBackend*, const VrgCtx& c) { return c.L <= (uint32_t)VRG_FUSE_LEVELS || c.lidx != nullptr; }
 void be_fuse_enter(VrgBackend*, const VrgCtx& c) { if (!c.st->done && !c.st->bail) for (uint32_t j = 0; j < c.st->nnz && j < c.zcap; j++) vrg_item_level_clear(c, j); }
 bool be_wants_sync(VrgBackend*, const VrgCtx&) { return false; }
 
@@ -239,7 +239,8 @@ void be_verify_last(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
 static void fused_update(VrgBackend* b, const VrgCtx& c0) {
     VrgState& g = *c0.st;
     const VrgState snap = g;                           // the state as it was when the sweep opened (the kernel's LDS copy)
-    const int32_t gate = vrg_fuse_gate(c0, snap, c0.inc[VC_NIN], b->fuse_max);
+    const bool bigl = c0.L > (uint32_t)VRG_FUSE_LEVELS;
+    const int32_t gate = vrg_fuse_gate(c0, snap, c0.inc[VC_NIN], std::min(b->fuse_max, vrg_fuse_limit(c0)));
     if (gate) {
         if (gate > 0) g.done = gate == 1000 ? -1 : gate; else g.bail = -gate;
         vrg_close_without_update(c0);
@@ -252,13 +253,13 @@ static void fused_update(VrgBackend* b, const VrgCtx& c0) {
     VrgFuseLds& sh = *shp;
     for (uint32_t r = 0; r < nf; r++) {
         VrgCtx c = c0;
-        c.st = &st; c.lev_fast = 1; c.lvl_scan = 1;
+        c.st = &st; c.lev_fast = 1; c.lvl_scan = bigl ? 2 : 1;
         for (uint32_t t = 0; t < T; t++) vrg_fuse_load1(c, th[t], t);
         for (uint32_t t = 0; t < T; t++) vrg_fuse_init(sh, t);
         for (uint32_t t = 0; t < T; t++) vrg_fuse_keys(sh, th[t], t, nf);
         for (uint32_t t = 0; t < T; t++) vrg_fuse_rank(c, sh, th[t], t, nf);
         for (uint32_t t = 0; t < T; t++) vrg_fuse_load2(c, sh, th[t], t, r, nf);
-        if (!c.lev16) for (uint32_t l = 0; l < c.L; l++) sh.lev[l] = c0.lev[l];
+        if (!c.lev16 && !bigl) for (uint32_t l = 0; l < c.L; l++) sh.lev[l] = c0.lev[l];
         for (uint32_t t = 0; t < T; t++) vrg_fuse_listed_nbrs(sh, t, nf);
         for (uint32_t t = 0; t < T; t++) vrg_fuse_prepass(sh, th[t], t, nf);
         if (sh.any_pend)
@@ -275,6 +276,13 @@ static void fused_update(VrgBackend* b, const VrgCtx& c0) {
     delete shp;
     // the workgroup that finishes last: touched levels in ascending order, counters zeroed, the sweep closed
     uint32_t q = 0;
+    if (bigl) {                                        // (large level table: the first touchers' list, sorted)
+        q = std::min(std::min(g.nnz_new, c0.zcap), (uint32_t)VRG_FUSE_KEYS);
+        std::vector<uint32_t> keys(q);
+        for (uint32_t j = 0; j < q; j++) keys[j] = (uint32_t)c0.nz_key[j];
+        std::sort(keys.begin(), keys.end());
+        for (uint32_t j = 0; j < q; j++) vrg_fuse_level_file_listed(c0, j, keys[j]);
+    } else
     for (uint32_t l = 0; l < c0.L; l++) { uint32_t ci, co, cc; if (vrg_fuse_level_touched(c0, l, ci, co, cc)) vrg_fuse_level_file(c0, q++, l, c0.lev[l], ci, co, cc); }
     int64_t n_in, n_out;
     const VrgState fin = vrg_fuse_close_load(c0, n_in, n_out);

@@ -254,6 +254,11 @@ def test_fused_trips_with_and_without_memo(lib, golden_loader):
                 np.testing.assert_allclose(o[w][1], outs[0][w][1], rtol=1e-12, atol=1e-15); np.testing.assert_allclose(o[w][2], outs[0][w][2], rtol=1e-12, atol=1e-15)
 
 
+def test_fused_sweeps_on_large_level_tables(lib):
+    from test_hostmodel import _fused_large_table_case
+    _fused_large_table_case(lib)
+
+
 def test_skip_rule_closure_is_race_free(lib):
     """Regression: the skip-rule fix-point is computed by every workgroup of k_relabel for itself.  With a wrong
     termination test one workgroup could stop before another one's write became visible; this case then failed in

@@ -196,6 +196,33 @@ def test_hostmodel_binned_exact_densities(hm, golden_loader):
     _binned_case(hm, golden_loader, 'cpu')
 
 
+def _fused_large_table_case(lib, extra=None):
+    """Fused sweeps on LARGE level tables (continuous-valued and 12-bit tubes: 46 059 / 3 109 distinct values - bins for the
+    exact densities, every voxel's level index kept, the touched levels listed by their first toucher and sorted by the
+    workgroup that closes the sweep): stepwise and in one call against the oracle, and the trips really ran fused."""
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session
+    for lv in (None, 4095):
+        data, vmap = phantoms.tube_phantom(shape=(48, 40, 24), radius=2.5, seed=5, seed_planes=3, amp_y=8.0, amp_z=4.0, levels=lv, brain_mask=True)
+        opts = dict(extra or {})
+        res, k = parity.run_stepwise(lib, data, vmap, 2.25, None, 30, density_mode=1, check_hist=True, options=opts)
+        assert res is not None and k == 30
+        res, k = parity.run_batched(lib, data, vmap, 2.25, None, 30, density_mode=1, options=dict(opts, small_flips=4096, batch=7))
+        assert res is not None
+        s = Session(data.shape, lib=lib)
+        for kk, v in dict(opts, small_flips=4096).items():
+            s.set_option(kk, v)
+        s.set_volume(data); s.set_labels(vmap); s.init(2.25)
+        s.run(30, 10 ** 9, None)
+        st = s.stats()
+        assert st['fused_trips'] >= 30 and st['bail_fuse'] == 0 and st['density_bins'] > 0, st
+        s.close()
+
+
+def test_hostmodel_fused_sweeps_on_large_level_tables(hm):
+    _fused_large_table_case(hm, {'fuse_max': 128})
+
+
 def test_hostmodel_arrays_grow_on_demand(hm):
     """Pool and marked-voxel arrays start tiny (capacity_floor 16) and grow when a trip is handed back (VBAIL_MARKS /
     VBAIL_POOL) or when init counts more band voxels than fit; small_flips 0/3/10^6 runs every sweep host-driven /
