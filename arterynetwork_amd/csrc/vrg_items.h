@@ -1098,9 +1098,10 @@ VRG_HD void vrg_fuse_load2(const VrgCtx& c, const LDS& sh, VrgFuseThread& th, ui
         // make the compiler wait for every load in flight
         const float* pf = c.I ? c.I : reinterpret_cast<const float*>(c.I64);
         const double* pd = c.I64 ? c.I64 : reinterpret_cast<const double*>(c.I);
+        // (a form that is not there reads the cache line the intensity itself comes from: no extra line leaves memory)
         const uint16_t* p16 = c.lev16 ? c.lev16 : reinterpret_cast<const uint16_t*>(c.I ? (const void*)c.I : (const void*)c.I64);
         const uint32_t* p32 = c.lidx ? c.lidx : reinterpret_cast<const uint32_t*>(c.I ? (const void*)c.I : (const void*)c.I64);
-        th.valf = pf[ms]; th.val64 = pd[c.I64 ? ms : (ms >> 1)]; th.l16 = p16[ms]; th.l32 = p32[ms];
+        th.valf = pf[ms]; th.val64 = pd[c.I64 ? ms : (ms >> 1)]; th.l16 = p16[c.lev16 ? ms : 2u * ms]; th.l32 = p32[ms];
     }
     {   // the nine label rows around flip t (t < nf; only a flip-in's are looked at - flip-outs are always applied)
         const uint32_t idx = sh.f_idx[t < nf ? t : nf - 1u];

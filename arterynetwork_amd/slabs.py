@@ -91,11 +91,12 @@ def one_gpu_step_ms(shape, world, planes, args):
     want = '{}x{}x{}'.format(shape[0], shape[1], nz)
     if getattr(args, 'storage16', False) or getattr(args, 'no_brain_mask', False) or getattr(args, 'levels', 255) != 255:
         return None
-    for f in sorted(glob.glob(os.path.join(root, 'profiles', 'r*_bench_*.json')), reverse=True):
+    # (the headline line of a round is profiles/r<NN>_bench_<nx>.json - the variants carry a suffix)
+    for f in sorted(glob.glob(os.path.join(root, 'profiles', 'r[0-9][0-9]_bench_{}.json'.format(shape[0]))), reverse=True):
         try:
             d = json.loads(open(f).read().strip().splitlines()[-1])
             if d.get('n_gpus') == 1 and d.get('valid') and want in d.get('metric', '') and 'single GPU' in d['config'].get('parallelism', '') \
-                    and 'fp32' in d['config'].get('intensity_storage', ''):
+                    and 'fp32' in d['config'].get('intensity_storage', '') and 'no excluded' not in d['config'].get('workload', ''):
                 return d['ms_per_step']
         except Exception:
             continue

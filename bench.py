@@ -387,9 +387,9 @@ def main():
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'f64',                # region sums, densities and decisions in float64; labels u8
         'data': 'synthetic', 'valid': bool(valid),
-        'config': {'workload': '{} synthetic MRA tube volume ({} stored {}, brain-mask excluded '
-                               'voxels), H={}, {} incremental VRG sweeps'.format(
-                                   args.shape, lev_note, 'as u16 level indices' if args.storage16 else 'fp32', args.H, r.sweeps),
+        'config': {'workload': '{} synthetic MRA tube volume ({} stored {}, {}), H={}, {} incremental VRG sweeps'.format(
+                                   args.shape, lev_note, 'as u16 level indices' if args.storage16 else 'fp32',
+                                   'no excluded voxels' if args.no_brain_mask else 'brain-mask excluded voxels', args.H, r.sweeps),
                    'parallelism': 'single GPU', 'sweep_variant': args.variant,
                    'intensity_storage': 'u16 level index (2 B/voxel)' if args.storage16 else 'fp32 (4 B/voxel)',
                    'init_seconds': round(t_init, 3), 'nseg_start': int(tr['nseg'][args.warmup]),
