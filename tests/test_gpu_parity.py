@@ -729,15 +729,16 @@ def test_host_driven_and_one_workgroup_sweeps_identical(lib, golden_loader):
     for opts in ({'small_flips': 0}, {'small_flips': 25, 'capacity_floor': 32}, {'small_flips': 4096, 'capacity_floor': 32}):
         res, k = parity.run_stepwise(lib, data, vmap, g.H, g.maxSegmentSize, 200, density_mode=1, check_hist=True, options=opts)
         assert res is not None and k == g.ncalls - 1
-    # whole runs against the reference's recorded results: config 1 (continuous-valued: its level table is so large
-    # that every trip is host-driven) and a quantised tube that starts with 16-entry arrays and never leaves the
-    # batched path
+    # whole runs against the reference's recorded results: config 1 (continuous-valued; fused sweeps switched off and at most 10
+    # flips for the four-launch chain, so that its sweeps are host-driven) and a quantised tube that starts with 16-entry
+    # arrays and never leaves the batched path
     for name, small, floor in (('config1_tube', 10, 1 << 16), ('tube_q_small', 4096, 16)):
         g2 = golden_loader(name)
         d2, v2 = g2.inputs()
         iterMax = g2.max_sweeps if g2.max_sweeps >= 0 else 200
         s = Session(g2.shape, lib=lib)
         s.set_option('small_flips', small); s.set_option('batch', 16); s.set_option('capacity_floor', floor)
+        s.set_option('fused', 0 if small == 10 else 1)
         s.set_volume(d2); s.set_labels(v2); s.init(g2.H)
         s.run(iterMax, g2.maxSegmentSize, None)
         assert np.array_equal(s.labels(), g2.z['final_labels'])
