@@ -69,8 +69,8 @@ void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
 //          VRG_SWEEP_NODENSE  the dense recount is not launched (measurement aid)
 //          VRG_SWEEP_SYNC   host-driven trip: the backend synchronises after the decisions, may grow nothing itself,
 //                           but runs update() with device-wide kernels and sorts - any number of flips
-// Without VRG_SWEEP_SYNC the trip is four launches (k_band, k_order, k_mark_relabel, k_close) and is enqueued without
-// synchronising; k_order hands a trip it cannot order in one workgroup's LDS back through st->bail.
+// Without VRG_SWEEP_SYNC the trip is two (VRG_SWEEP_FUSED: k_band, k_sweep) or four launches (k_band, k_order, k_mark_relabel,
+// k_close) and is enqueued without synchronising; a trip its kind cannot take is handed back untouched through st->bail.
 //          VRG_SWEEP_FUSED  update() as ONE launch (k_sweep, vrg_items.h "fused sweep"): sweeps with at most be_fuse_limit()
 //                           flips; a sweep with more is handed back (VBAIL_FUSE) and the engine repeats the trip unfused
 enum { VRG_SWEEP_FULL = 1, VRG_SWEEP_NODENSE = 4, VRG_SWEEP_SYNC = 8, VRG_SWEEP_FUSED = 16 };

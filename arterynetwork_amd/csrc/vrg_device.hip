@@ -1,16 +1,18 @@
 // vrg_device.hip - the product backend: HIP kernels for MI355X (gfx950, wave64).
 //
-// One while-loop trip of variationalRegionGrowing.py:58-117 (be_sweep_once) is FOUR launches on stream A (k_band, then
-// update() as k_order / k_mark_relabel / k_close, see there) plus the dense pass on stream B:
-//   k_band  (many workgroups, one thread per band-pool slot): adds the density corrections of the sweep before
-//           (:236-247) to the surviving entries, decides every entry (:79-88) and appends the flips to an unordered
-//           list; extra workgroups compute the exact densities (:252-255) of the entries the sweep before added
-//           (one wave per entry) and decide those.
-//   k_order -> k_mark_relabel -> k_close: update() (:156-259); a sweep with more flips than one workgroup should
-//           order in LDS (or one that needs larger arrays) is handed back untouched (VrgState::bail); the engine then
-//           drives such trips from the host (be_sweep_once with VRG_SWEEP_SYNC: the same item functions as
-//           device-wide kernels, rocPRIM sorts).
-//   stream B, the dense pass, forked after k_close:
+// One while-loop trip of variationalRegionGrowing.py:58-117 (be_sweep_once) is k_band + update() on stream A, plus the dense
+// pass on stream B.  update() (:156-259) comes in three kinds, all running the item functions of vrg_items.h on the same data:
+//   k_band  (many workgroups, one thread - or 16 / 8 / 4 lanes - per band-pool slot): adds the density corrections of the
+//           sweep before (:236-247) to the surviving entries, decides every entry (:79-88) and appends the flips to an
+//           unordered list; extra workgroups compute the exact densities (:252-255) of the entries the sweep before added
+//           and decide those; behind a fused sweep 32 more write its label bytes, class bits and free list.
+//   FUSED   k_sweep: ONE launch, one flip per workgroup, for sweeps with at most 128 flips (65 on a large level table) -
+//           every workgroup ranks the flips and resolves the skip rule itself; nothing is applied inside the sweep
+//           (-> k_memo on large bands).  A sweep with more flips hands itself back untouched (VBAIL_FUSE).
+//   CHAIN   k_order -> k_mark_relabel -> k_close: up to 4096 flips; a sweep with more (or one that needs larger arrays) is
+//           handed back untouched (VrgState::bail) and
+//   HOST-DRIVEN (be_sweep_once with VRG_SWEEP_SYNC): the same item functions as device-wide kernels, rocPRIM sorts.
+//   stream B, the dense pass (enqueued behind the kernel that raises its request: k_close, or the k_band after a fused sweep):
 //     k_recount_bits : the dense kernel (every voxel, HBM-bound, read-only: 4 B intensity + 2 class bits per
 //        voxel): region sizes and intensity sums (:113-116, :249-250), reduced by its last workgroup, checked
 //        against the sizes the band side keeps by increments

@@ -268,7 +268,7 @@ def spawn_ranks(args_list, n):
         port = sk.getsockname()[1]
     logdir = tempfile.mkdtemp(prefix='bench_ranks_')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
-           '--master-port', str(port), '--log-dir', logdir, '--tee', '3', os.path.abspath(__file__)] + args_list
+           '--master-port', str(port), '--log-dir', logdir, '--tee', '2', os.path.abspath(__file__)] + args_list
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     rc = subprocess.call(cmd, env=env)
     if rc != 0:

@@ -26,7 +26,7 @@ def test_gpus_n_spawns_a_launcher(monkeypatch):
     assert cmd[cmd.index('--nproc-per-node') + 1] == '8' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
     assert cmd[-6:] == ['--gpus', '8', '--steps', '7', '--warmup', '3'] and os.path.basename(cmd[-7]) == 'bench.py'
     assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
-    assert '--log-dir' in cmd and cmd[cmd.index('--tee') + 1] == '3'          # every rank's stderr is shown and kept
+    assert '--log-dir' in cmd and cmd[cmd.index('--tee') + 1] == '2'          # every rank's stderr is shown and kept (stdout - the JSON line - passes through untouched)
 
 
 def test_gpus_n_preflight_and_rank_stderr(monkeypatch, capsys):
