@@ -936,6 +936,7 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     const uint32_t nf = s0.nf;
     if (r >= nf) return;                                   // (no flip for this workgroup)
     if (st0) { VRG_STAMP_PUT(cg, 8, t_entry); VRG_STAMP(cg, 9); }
+    vrg_fuse_load_rows(cg, th);                            // (the label rows around this thread's record: in flight while the flips are ranked)
     VrgState sl = s0;                                      // (what the item functions read of the state: registers, not memory)
     VrgCtx c = cg;
     c.st = &sl; c.lev_fast = 1; c.lvl_scan = BIGL ? 2 : 1;
@@ -1872,6 +1873,8 @@ void make_streams(VrgBackend* b) {
     if (b->sa) { HIP_CHECK(hipStreamSynchronize(b->sa)); HIP_CHECK(hipStreamDestroy(b->sa)); }
     if (b->sb) { HIP_CHECK(hipStreamSynchronize(b->sb)); HIP_CHECK(hipStreamDestroy(b->sb)); }
     // prio_mode 0: equal; 1: band stream A high; 2: dense stream B high
+    // (keeping the dense pass off 1-8 CUs of every XCD with a CU-masked stream - free places for the band chain - was measured in
+    // round 4: the chain beside a pass stays at 37 us, the pass gets 3-20 % slower: what the chain waits for is memory, not a place)
     HIP_CHECK(hipStreamCreateWithPriority(&b->sa, hipStreamNonBlocking, b->prio_mode == 1 ? hi : (b->prio_mode == 2 ? lo : 0)));
     HIP_CHECK(hipStreamCreateWithPriority(&b->sb, hipStreamNonBlocking, b->prio_mode == 2 ? hi : (b->prio_mode == 1 ? lo : 0)));
 }

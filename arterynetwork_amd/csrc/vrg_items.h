@@ -1003,7 +1003,7 @@ typedef VrgFuseLdsT<VRG_FUSE_LEVELS> VrgFuseLds;
 struct VrgFuseThread {                                                 // what a thread keeps in registers between the phases
     uint64_t key; uint32_t slot, idx, lev;                             // the flip record k_band appended at place t
     uint32_t row[4];                                                   // tile row t
-    uint32_t frow[9];                                                  // the nine label rows around flip t (by rank)
+    uint32_t frow[9]; uint32_t r;                                      // the nine label rows around the flip of RECORD t (requested as soon as the record is there), its rank
     VrgPre pre;                                                        // per-voxel fields of cube place t
     float valf; double val64; uint16_t l16; uint32_t l32;              // ... its intensity as loaded (whichever storage the volume has: converted when used), its level index
     VrgEvent ev; uint32_t rn, rd, rf;
@@ -1056,15 +1056,28 @@ VRG_HD void vrg_fuse_load1(const VrgCtx& c, VrgFuseThread& th, uint32_t t) {
     const uint32_t q = t < c.fcap ? t : c.fcap - 1u;
     th.key = c.f_key[q]; th.slot = c.flist[q]; th.idx = c.fr_idx[q]; th.lev = c.fr_lev[q];
 }
+// ... and, as soon as the record is there - before the flips are ranked: nothing here depends on the order -, the nine label rows
+// around the record's voxel (only a flip-in's are looked at - flip-outs are always applied; unconditional: see above)
+VRG_HD void vrg_fuse_load_rows(const VrgCtx& c, VrgFuseThread& th) {
+    const uint8_t* lab = c.lab[0];
+    // (a record beyond the sweep's flips is stale: any index - kept inside the padded volume, its rows are never looked at)
+    const uint32_t lo = (uint32_t)((c.PY + 1) * c.PX + 1), hi = c.PV - lo - 4u;
+    const uint32_t idx = th.idx < lo ? lo : th.idx > hi ? hi : th.idx;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 9; j++) th.frow[j] = vrg_load_row(lab + ((int64_t)idx + ((j % 3 - 1) * c.PY + (j / 3 - 1)) * c.PX - 1));
+}
 template <class LDS>
 VRG_HD void vrg_fuse_keys(LDS& sh, const VrgFuseThread& th, uint32_t t, uint32_t nf) { if (t < nf) sh.key[t] = th.key; }
 // rank of record t = number of smaller keys (keys are distinct): the reference's flip order (:48, :88); the records by rank,
 // the voxel -> rank hash set
 template <class LDS>
-VRG_HD void vrg_fuse_rank(const VrgCtx& c, LDS& sh, const VrgFuseThread& th, uint32_t t, uint32_t nf) {
+VRG_HD void vrg_fuse_rank(const VrgCtx& c, LDS& sh, VrgFuseThread& th, uint32_t t, uint32_t nf) {
     if (t >= nf) return;
     uint32_t r = 0;
     for (uint32_t j = 0; j < nf; j++) r += sh.key[j] < th.key;
+    th.r = r;
     int x, y, z; vrg_coords(c, th.idx, x, y, z);
     sh.f_idx[r] = th.idx; sh.f_slot[r] = th.slot; sh.f_lev[r] = th.lev; sh.f_inner[r] = (uint8_t)!(th.key >> 63);
     sh.f_x[r] = (uint16_t)x; sh.f_y[r] = (uint16_t)(y + 2); sh.f_z[r] = (uint16_t)(z + 2);    // (+2: never negative, differences unchanged)
@@ -1103,13 +1116,6 @@ VRG_HD void vrg_fuse_load2(const VrgCtx& c, const LDS& sh, VrgFuseThread& th, ui
         const uint32_t* p32 = c.lidx ? c.lidx : reinterpret_cast<const uint32_t*>(c.I ? (const void*)c.I : (const void*)c.I64);
         th.valf = pf[ms]; th.val64 = pd[c.I64 ? ms : (ms >> 1)]; th.l16 = p16[c.lev16 ? ms : 2u * ms]; th.l32 = p32[ms];
     }
-    {   // the nine label rows around flip t (t < nf; only a flip-in's are looked at - flip-outs are always applied)
-        const uint32_t idx = sh.f_idx[t < nf ? t : nf - 1u];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int j = 0; j < 9; j++) th.frow[j] = vrg_load_row(lab + ((int64_t)idx + ((j % 3 - 1) * c.PY + (j / 3 - 1)) * c.PX - 1));
-    }
 }
 // which neighbours of a flip-in are listed flips (f_L), and which of those flip-ins (f_FI): every pair of flips is looked at,
 // `parts` threads sharing a flip-in's partners.  (Pairs, not a voxel -> flip hash set probed 26 times per flip: a probe is a
@@ -1138,16 +1144,17 @@ template <class LDS>
 VRG_HD void vrg_fuse_prepass(LDS& sh, const VrgFuseThread& th, uint32_t t, uint32_t nf) {
     if (t < 81u) { sh.tile[4 * t] = th.row[0]; sh.tile[4 * t + 1] = th.row[1]; sh.tile[4 * t + 2] = th.row[2]; sh.tile[4 * t + 3] = th.row[3]; }
     if (t >= nf) return;
-    if (sh.f_inner[t]) { sh.f_P[t] = 1; sh.f_pend[t] = 0; return; }
+    const uint32_t r = th.r;                               // (thread t holds the rows of RECORD t: its flip has rank r)
+    if (sh.f_inner[r]) { sh.f_P[r] = 1; sh.f_pend[r] = 0; return; }
     uint32_t S = 0, O = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int j = 0; j < 9; j++) { S |= vrg_gather3(th.frow[j]) << (3 * j); O |= vrg_gather3(th.frow[j] >> 5) << (3 * j); }
-    const uint32_t ex = ~O & 0x7ffdfffu, L = sh.f_L[t];
+    const uint32_t ex = ~O & 0x7ffdfffu, L = sh.f_L[r];
     const bool nFO = (S & L & ex) != 0, nSegA = (S & ~L & ex) != 0;     // (a listed segmented neighbour is a flip-out)
     const bool pend = nFO && !nSegA;
-    sh.f_P[t] = (uint8_t)!pend; sh.f_pend[t] = (uint8_t)pend;
+    sh.f_P[r] = (uint8_t)!pend; sh.f_pend[r] = (uint8_t)pend;
     if (pend) vrg_lds_or(&sh.any_pend, 1u);
 }
 // one relaxation of the skip rule's fix-point (vrg_item_fix): applied if an applied flip-in neighbour of smaller rank exists

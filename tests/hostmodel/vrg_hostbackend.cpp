@@ -254,7 +254,7 @@ static void fused_update(VrgBackend* b, const VrgCtx& c0) {
     for (uint32_t r = 0; r < nf; r++) {
         VrgCtx c = c0;
         c.st = &st; c.lev_fast = 1; c.lvl_scan = bigl ? 2 : 1;
-        for (uint32_t t = 0; t < T; t++) vrg_fuse_load1(c, th[t], t);
+        for (uint32_t t = 0; t < T; t++) { vrg_fuse_load1(c, th[t], t); vrg_fuse_load_rows(c, th[t]); }
         for (uint32_t t = 0; t < T; t++) vrg_fuse_init(sh, t);
         for (uint32_t t = 0; t < T; t++) vrg_fuse_keys(sh, th[t], t, nf);
         for (uint32_t t = 0; t < T; t++) vrg_fuse_rank(c, sh, th[t], t, nf);
