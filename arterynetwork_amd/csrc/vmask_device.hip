@@ -8,7 +8,8 @@
 //   Phase 1 along axis 0 (two scans), then the lower-envelope pass along axis 1 and along axis 2,
 //   one thread per line with the wave's lanes on neighbouring lines (coalesced), the envelope stack in registers /
 //   LDS / a chunked spill area (k_edt_envelope); for axis 2 the volume is transposed i1 <-> i2 in 64 x 64 LDS tiles
-//   before and after.  HBM-bound.
+//   before and after (the second of them takes the root: float64 out, no pass of its own).  The scans and transposes
+//   run at 4.3-5 TB/s; the envelope pass is bound by instruction issue.
 // Labelling: union-find with compare-and-swap linking (root = smallest raster index of the component), one
 //   union pass over the 3/9/13 forward neighbours, path flattening, component sizes by atomics, and
 //   raster-order numbering = exclusive scan of the root flags (what skimage / scipy number by).
@@ -38,23 +39,72 @@ struct Dims { int32_t n0, n1, n2; };
 int grid_for(uint64_t n) { return (int)std::min<uint64_t>(65535u * 16u, (n + TPB - 1) / TPB); }
 
 // ---------------------------------------------------------------- EDT
-// phase 1: squared distance to the nearest zero voxel along axis 0; one thread per (i1,i2) column
-__global__ void k_edt_axis0(const uint8_t* __restrict__ mask, int32_t* __restrict__ G, Dims d) {
-    const uint32_t ncol = (uint32_t)d.n1 * (uint32_t)d.n2;
+// phase 1: squared distance to the nearest zero voxel along axis 0; one thread per VEC neighbouring (i1,i2) columns (VEC = 4
+// when the row length allows aligned 4-voxel accesses: 256 B of mask and 1 KB of G per wave and row).  The downward scan
+// leaves its distance in F as 16 bits (65535 = no zero above; anything >= 32768 ends as EDT_INF anyway), the upward scan
+// reads that back - it is 0 exactly where the mask is, so the mask is not read again - and writes min(down, up)^2:
+// 9 bytes per voxel (round 3: 14), the loads of 32 / 16 rows in flight together (round 3: one row at a time, each waited for;
+// with 4 columns per thread a 880x880x640 volume has only ~2 waves per SIMD: the depth of the batches is what fills the bus).
+#ifndef EDT_AX0_DOWN
+#define EDT_AX0_DOWN 32
+#define EDT_AX0_UP 16
+#endif
+template <int VEC> struct Ax0;
+template <> struct Ax0<1> { using M = uint8_t; using F = uint16_t; using G = int32_t; };
+template <> struct Ax0<4> { using M = uchar4; using F = ushort4; using G = int4; };
+template <int VEC>
+__global__ void __launch_bounds__(TPB) k_edt_axis0(const uint8_t* __restrict__ mask, uint16_t* __restrict__ F, int32_t* __restrict__ G, Dims d) {
+    using MT = typename Ax0<VEC>::M; using FT = typename Ax0<VEC>::F; using GT = typename Ax0<VEC>::G;
+    const uint32_t ncol = (uint32_t)d.n1 * (uint32_t)d.n2 / VEC;           // (columns in units of VEC)
+    const MT* __restrict__ mk = reinterpret_cast<const MT*>(mask);
+    FT* __restrict__ fo = reinterpret_cast<FT*>(F);
+    GT* __restrict__ go = reinterpret_cast<GT*>(G);
     for (uint32_t col = blockIdx.x * blockDim.x + threadIdx.x; col < ncol; col += gridDim.x * blockDim.x) {
-        int32_t dist = EDT_INF;
-        for (int32_t i = 0; i < d.n0; i++) {                     // forward
-            size_t p = (size_t)i * ncol + col;
-            dist = mask[p] ? (dist >= EDT_INF ? EDT_INF : dist + 1) : 0;
-            G[p] = dist;
+        uint32_t dist[VEC];
+        auto down = [&](const MT& m, int32_t i) {
+            uint8_t mb[VEC]; uint16_t fb[VEC];
+            __builtin_memcpy(mb, &m, VEC);
+#pragma unroll
+            for (int v = 0; v < VEC; v++) { dist[v] = mb[v] ? min(dist[v] + 1u, 65535u) : 0u; fb[v] = (uint16_t)dist[v]; }
+            FT fv; __builtin_memcpy(&fv, fb, 2 * VEC);
+            fo[(size_t)i * ncol + col] = fv;
+        };
+        auto up = [&](const FT& f, int32_t i) {
+            uint16_t fb[VEC]; int32_t gb[VEC];
+            __builtin_memcpy(fb, &f, 2 * VEC);
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+                dist[v] = fb[v] ? min(dist[v] + 1u, 65535u) : 0u;
+                const uint32_t g = min((uint32_t)fb[v], dist[v]);
+                gb[v] = g >= 32768u ? EDT_INF : (int32_t)(g * g);
+            }
+            GT gv; __builtin_memcpy(&gv, gb, 4 * VEC);
+            go[(size_t)i * ncol + col] = gv;
+        };
+        // (whole batches without a branch inside - a branch between the requests and their uses makes the compiler move every
+        // request down to its use, one waited-for load at a time -, the last rows one by one)
+#pragma unroll
+        for (int v = 0; v < VEC; v++) dist[v] = 65535u;
+        int32_t i = 0;
+        for (; i + EDT_AX0_DOWN <= d.n0; i += EDT_AX0_DOWN) {               // downward
+            MT mv[EDT_AX0_DOWN];
+#pragma unroll
+            for (int k = 0; k < EDT_AX0_DOWN; k++) mv[k] = mk[(size_t)(i + k) * ncol + col];
+#pragma unroll
+            for (int k = 0; k < EDT_AX0_DOWN; k++) down(mv[k], i + k);
         }
-        dist = EDT_INF;
-        for (int32_t i = d.n0 - 1; i >= 0; i--) {                // backward
-            size_t p = (size_t)i * ncol + col;
-            dist = mask[p] ? (dist >= EDT_INF ? EDT_INF : dist + 1) : 0;
-            int32_t g = min(G[p], dist);
-            G[p] = (g >= 32768) ? EDT_INF : g * g;
+        for (; i < d.n0; i++) down(mk[(size_t)i * ncol + col], i);
+#pragma unroll
+        for (int v = 0; v < VEC; v++) dist[v] = 65535u;
+        i = d.n0 - 1;
+        for (; i - EDT_AX0_UP + 1 >= 0; i -= EDT_AX0_UP) {                  // upward
+            FT fv[EDT_AX0_UP];
+#pragma unroll
+            for (int k = 0; k < EDT_AX0_UP; k++) fv[k] = fo[(size_t)(i - k) * ncol + col];
+#pragma unroll
+            for (int k = 0; k < EDT_AX0_UP; k++) up(fv[k], i - k);
         }
+        for (; i >= 0; i--) up(fo[(size_t)i * ncol + col], i);
     }
 }
 
@@ -64,23 +114,32 @@ __global__ void k_edt_axis0(const uint8_t* __restrict__ mask, int32_t* __restric
 __device__ __forceinline__ long long floordiv(long long a, long long b) {
     return (long long)floor((double)a / (double)b);
 }
-// the same for volumes whose squared diagonal is below EDT_INF, in 32-bit arithmetic (every square and sum stays under 2^30 there;
-// the kernel is bound by its instruction count, and 64-bit integer arithmetic is 2-4 instructions per operation): a float
-// quotient, exact to +-1 while it is below 2^15, set right by one multiplication; a quotient of 2^15 or more only has to
-// come out >= m (the entry is then not pushed)
+// the same for volumes whose squared diagonal is below EDT_INF, in 32-bit arithmetic (every square and sum stays under 2^30 there,
+// every factor under 2^24: the full-rate 24-bit multiplier serves; the kernel is bound by its instruction count): a float
+// quotient from the hardware reciprocal (1 ulp; a correctly rounded one is a 12-instruction sequence) - a, the reciprocal and
+// the product each off by at most 2^-23 relative, so the quotient by less than 2^-6 while it is below 2^15: its truncation is
+// the floor or one beside it, set right by one multiplication.  A quotient of 2^15 or more only has to come out >= m (the
+// entry is then not pushed).  No branch.
 __device__ __forceinline__ int32_t floordiv(int32_t a, int32_t b) {
-    const float qf = (float)a * __frcp_rn((float)b);
-    if (fabsf(qf) >= 32768.f) return qf > 0 ? (1 << 20) : -(1 << 20);
-    int32_t q = (int32_t)qf;
-    const int32_t r = a - q * b;
-    if (r < 0) q--; else if (r >= b) q++;
-    return q;
+    const float qf = (float)a * __builtin_amdgcn_rcpf((float)b);
+    const bool big = fabsf(qf) >= 32768.f;
+    int32_t q = big ? 0 : (int32_t)qf;
+    const int32_t r = a - __mul24(q, b);
+    q += (int32_t)(r >= b) - (int32_t)(r < 0);
+    return big ? (qf > 0 ? (1 << 20) : -(1 << 20)) : q;
 }
+// d * d + g
+__device__ __forceinline__ int32_t sq_add(int32_t d, int32_t g) { return __mul24(d, d) + g; }
+__device__ __forceinline__ long long sq_add(long long d, long long g) { return d * d + g; }
+__device__ __forceinline__ int32_t mul_(int32_t a, int32_t b) { return __mul24(a, b); }
+__device__ __forceinline__ long long mul_(long long a, long long b) { return a * b; }
 
-// Meijster phase 2 along axis 1: Gout(u) = min_i (u-i)^2 + Gin(i), one thread per line, the lanes of a wave on
-// neighbouring lines (i2 consecutive: every row access is one 256-byte request).  The lower envelope is a per-line
-// stack of (site | start << 16, G(site)).  Its top sits in registers and its topmost <= EDT_RING entries in LDS (a ring
-// per thread, [slot][thread]: conflict-free).  Deeper entries live in a spill area in global memory, one contiguous
+// Meijster phase 2 along axis 1: Gout(u) = min_i (u-i)^2 + Gin(i), one thread per line, the 64 lanes of a wave on 64
+// neighbouring lines of ONE i0 slab (i2 consecutive: every row access is one 256-byte request, at a wave-uniform base
+// plus a 32-bit offset - no 64-bit address arithmetic per access; lanes past the end of a row repeat its last line).
+// The lower envelope is a per-line stack of (site | start << 16, G(site)).  Its top sits in registers and its topmost
+// <= EDT_RING entries in LDS (a ring per thread, [slot][thread], one 8-byte access per entry: conflict-free).  Deeper entries
+// live in a spill area in global memory, one contiguous
 // region per line (padded to EDT_CHUNK entries), and move between the two in aligned chunks of EDT_CHUNK entries =
 // 64 bytes: a full ring sheds its oldest chunk, a pop below the ring brings one back (leaving room for as many pushes
 // before the next move).  The line's values are fetched EDT_AHEAD rows ahead of the scan.
@@ -95,31 +154,47 @@ __device__ __forceinline__ int32_t floordiv(int32_t a, int32_t b) {
 // for long.  What was spilled there is written out from the spill area once it is final (the oldest chunk first, all lanes
 // of the wave together), so that the ring's bottom can leave again behind it.
 // Measured (profiles/r03_mask_pmc.csv, brain-sized ellipsoid): 10.7 -> 6.8 GB and 4.53 -> 3.07 ms per pass; the pass is
-// then bound by its ~150 VALU instructions per site (SQ counters: VALU busy 0.6), not by HBM.
+// then bound by its ~150 VALU instructions per site (SQ counters: VALU busy 0.6), not by HBM.  Round 4 cut those: hardware
+// reciprocal and 24-bit multiplies, the top's value at its start kept in a register, unsigned ring slots, uniform bases.
 // (Round 1: every push wrote and every pop read global memory in the data's layout, 4 bytes at a time at addresses
 // that differ from lane to lane, and every step waited for its own load - 12.4 ms per pass at 880x880x640.)
-constexpr int EDT_RING = 16;
-constexpr int EDT_CHUNK = 8;
-constexpr int EDT_AHEAD = 8;
+#ifndef EDT_RING_N            // (-D overrides: tuning experiments only)
+#define EDT_RING_N 16
+#define EDT_CHUNK_N 8
+#endif
+constexpr int EDT_RING = EDT_RING_N;
+constexpr int EDT_CHUNK = EDT_CHUNK_N;
+#ifndef EDT_AHEAD_N
+#define EDT_AHEAD_N 8
+#endif
+#ifndef EDT_TPB_N
+#define EDT_TPB_N 64
+#endif
+constexpr int EDT_AHEAD = EDT_AHEAD_N;
+constexpr int EDT_TPB = EDT_TPB_N;
+__host__ __device__ inline uint32_t edt_chunks(int32_t n2) { return ((uint32_t)n2 + 63u) / 64u; }     // 64-line groups per i0 slab
 template <typename I>      // int32_t for volumes whose squared diagonal is below EDT_INF (edt_squared), else long long
-__global__ void __launch_bounds__(TPB) k_edt_envelope(const int32_t* __restrict__ Gin, int32_t* __restrict__ Gout, uint2* __restrict__ SP, Dims d) {
-    __shared__ uint32_t r_st[EDT_RING][TPB];
-    __shared__ int32_t r_g[EDT_RING][TPB];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t nlines = (uint32_t)d.n0 * d.n2;
+__global__ void __launch_bounds__(EDT_TPB) k_edt_envelope(const int32_t* __restrict__ Gin, int32_t* __restrict__ Gout, uint2* __restrict__ SP, Dims d) {
+    __shared__ uint2 ring[EDT_RING][EDT_TPB];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t cpl = edt_chunks(d.n2), nitems = (uint32_t)d.n0 * cpl;
     const int32_t m = d.n1;
     const size_t mp = ((size_t)m + EDT_CHUNK - 1) / EDT_CHUNK * EDT_CHUNK;
-    const size_t stride = (size_t)d.n2;
-    for (uint32_t line = blockIdx.x * blockDim.x + threadIdx.x; line < nlines; line += gridDim.x * blockDim.x) {
-        const size_t base = (size_t)(line / d.n2) * d.n1 * d.n2 + (line % d.n2);
-        uint2* __restrict__ spill = SP + (size_t)line * mp;
-#define AT(u) (base + (size_t)(u) * stride)
+    const uint32_t stride = (uint32_t)d.n2;
+    for (uint32_t item0 = blockIdx.x * (EDT_TPB / 64) + (tid >> 6); item0 < nitems; item0 += gridDim.x * (EDT_TPB / 64)) {
+        const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item0);      // (the same in every lane of the wave)
+        const uint32_t i0 = item / cpl, i2 = min((item - i0 * cpl) * 64u + lane, (uint32_t)d.n2 - 1u);
+        const int32_t* __restrict__ gin = Gin + (size_t)i0 * d.n1 * d.n2;
+        int32_t* __restrict__ gout = Gout + (size_t)i0 * d.n1 * d.n2;
+        uint2* __restrict__ spill = SP + ((size_t)i0 * d.n2 + i2) * mp;
+#define AT(u) (i2 + (uint32_t)(u) * stride)
+#define SLOT(i) ((uint32_t)(i) % (uint32_t)EDT_RING)
         // entries [low, q] of the stack are in the ring (entry i in slot i % EDT_RING), entries [eb, low) in the spill
         // area (low - eb a multiple of EDT_CHUNK), entries [0, eb) are final and written: rows [0, ue) of the output
         int32_t q = 0, low = 0, eb = 0, ue = 0;
-        I ts = 0, tt = 0, tg = Gin[AT(0)];               // top of the stack: site, start, G(site)
+        I ts = 0, tt = 0, tg = gin[AT(0)], tv = tg;      // top of the stack: site, start, G(site), its value at its start
         I dn_t = 0, dn_v = 0;                            // while low > eb: start of entry eb + EDT_CHUNK (the one above the oldest spilled chunk) and its value there
-        r_st[0][tid] = 0; r_g[0][tid] = (int32_t)tg;
+        ring[0][tid] = make_uint2(0u, (uint32_t)tg);
         auto pop = [&]() {                                        // q was decremented and is >= eb: its entry becomes the top
             if (q < low) {                                        // (q == low - 1: the chunk below the ring comes back)
                 low -= EDT_CHUNK;
@@ -127,19 +202,26 @@ __global__ void __launch_bounds__(TPB) k_edt_envelope(const int32_t* __restrict_
 #pragma unroll
                 for (int i = 0; i < EDT_CHUNK; i++) e[i] = spill[low + i];
 #pragma unroll
-                for (int i = 0; i < EDT_CHUNK; i++) { r_st[(low + i) % EDT_RING][tid] = e[i].x; r_g[(low + i) % EDT_RING][tid] = (int32_t)e[i].y; }
+                for (int i = 0; i < EDT_CHUNK; i++) ring[SLOT(low + i)][tid] = e[i];
             }
-            const uint32_t p = r_st[q % EDT_RING][tid];
-            ts = p & 0xffffu; tt = p >> 16; tg = r_g[q % EDT_RING][tid];
+            const uint2 p = ring[SLOT(q)][tid];
+            ts = p.x & 0xffffu; tt = p.x >> 16; tg = (int32_t)p.y; tv = sq_add(tt - ts, tg);
         };
-        for (int32_t u0 = 1; u0 < m; u0 += EDT_AHEAD) {
-            int32_t gv[EDT_AHEAD];                                // (requested before the bottom of the stack is written out: in flight meanwhile)
+        auto rows_out = [&](I s0, I g0, I r0, I r1) {             // rows [r0, r1) of the output from entry (site s0, G g0)
+            for (I r = r0; r < r1; r++) {
+                const I v = sq_add(r - s0, g0);
+                gout[AT(r)] = v >= EDT_INF ? EDT_INF : (int32_t)v;
+            }
+        };
+        auto fetch = [&](int32_t (&gv)[EDT_AHEAD], int32_t u0) {  // the line's values of a batch (rows past the end repeat the last one)
 #pragma unroll
-            for (int k = 0; k < EDT_AHEAD; k++) gv[k] = u0 + k < m ? Gin[AT(u0 + k)] : 0;
+            for (int k = 0; k < EDT_AHEAD; k++) gv[k] = gin[AT(min(u0 + k, m - 1))];
+        };
+        auto batch = [&](const int32_t u0, const int32_t (&gv)[EDT_AHEAD]) {
             // (once per batch of EDT_AHEAD sites: everything below is about sites >= u0)
             for (;;) {                                            // final entries that had to be spilled: the oldest chunk [eb, eb + EDT_CHUNK)
                 const I dd = u0 - dn_t;                           // ... is final when the entry above it (start dn_t, value dn_v there) is
-                const bool has = low > eb, fin = has && dd >= 0 && dn_v <= dd * dd;
+                const bool has = low > eb, fin = has && dd >= 0 && dn_v <= mul_(dd, dd);
                 // (the lanes of a wave - neighbouring lines - write their chunks out TOGETHER: a lane on its own would leave
                 // 4 bytes in each of its rows' cache lines long before or after its neighbours do, every one a write of its own)
                 const unsigned long long wh = __ballot(has), wf = __ballot(fin);
@@ -149,36 +231,27 @@ __global__ void __launch_bounds__(TPB) k_edt_envelope(const int32_t* __restrict_
 #pragma unroll
                 for (int i = 0; i < EDT_CHUNK; i++) e[i] = spill[eb + i];
 #pragma unroll
-                for (int i = 0; i < EDT_CHUNK; i++) {
-                    const I s0 = e[i].x & 0xffffu, g0 = (int32_t)e[i].y, t1 = i + 1 < EDT_CHUNK ? (I)(e[(i + 1) % EDT_CHUNK].x >> 16) : dn_t;
-                    for (I r = e[i].x >> 16; r < t1; r++) {
-                        const I v = (r - s0) * (r - s0) + g0;
-                        Gout[AT(r)] = v >= EDT_INF ? EDT_INF : (int32_t)v;
-                    }
-                }
+                for (int i = 0; i < EDT_CHUNK; i++)
+                    rows_out(e[i].x & 0xffffu, (int32_t)e[i].y, e[i].x >> 16, i + 1 < EDT_CHUNK ? (I)(e[(i + 1) % EDT_CHUNK].x >> 16) : dn_t);
                 ue = (int32_t)dn_t; eb += EDT_CHUNK;
                 if (low > eb) {                                   // the entry above the next chunk: spilled itself, or the bottom of the ring
-                    uint2 n;
-                    if (eb + EDT_CHUNK < low) n = spill[eb + EDT_CHUNK];
-                    else n = make_uint2(r_st[low % EDT_RING][tid], (uint32_t)r_g[low % EDT_RING][tid]);
+                    const uint2 n = eb + EDT_CHUNK < low ? spill[eb + EDT_CHUNK] : ring[SLOT(low)][tid];
                     const I sn = n.x & 0xffffu;
-                    dn_t = n.x >> 16; dn_v = (dn_t - sn) * (dn_t - sn) + (int32_t)n.y;
+                    dn_t = n.x >> 16; dn_v = sq_add(dn_t - sn, (I)(int32_t)n.y);
                 }
             }
-            for (;;) {                                        // the final bottom of the stack leaves (nothing of it is in the spill area)
-                const bool cand = low == eb && low < q;
-                const uint32_t p1 = cand ? r_st[(low + 1) % EDT_RING][tid] : 0u;
-                const I s1 = p1 & 0xffffu, t1 = p1 >> 16, v1 = cand ? (t1 - s1) * (t1 - s1) + r_g[(low + 1) % EDT_RING][tid] : 0;
-                const I dd = u0 - t1;
-                const bool fin = cand && dd >= 0 && v1 <= dd * dd;   // (else entry low + 1 can still be popped: entry low may become the top again)
-                if (!fin) break;
-                const uint32_t p0 = r_st[low % EDT_RING][tid];
-                const I s0 = p0 & 0xffffu, g0 = r_g[low % EDT_RING][tid];
-                for (I r = p0 >> 16; r < t1; r++) {
-                    const I v = (r - s0) * (r - s0) + g0;
-                    Gout[AT(r)] = v >= EDT_INF ? EDT_INF : (int32_t)v;
+            if (low == eb && low < q) {                       // the final bottom of the stack leaves (nothing of it is in the spill area)
+                uint2 p0 = ring[SLOT(low)][tid];
+                for (;;) {
+                    const uint2 p1 = ring[SLOT(low + 1)][tid];
+                    const I s1 = p1.x & 0xffffu, t1 = p1.x >> 16, v1 = sq_add(t1 - s1, (I)(int32_t)p1.y);
+                    const I dd = u0 - t1;
+                    if (!(dd >= 0 && v1 <= mul_(dd, dd))) break;   // (else entry low + 1 can still be popped: entry low may become the top again)
+                    rows_out(p0.x & 0xffffu, (int32_t)p0.y, p0.x >> 16, t1);
+                    ue = (int32_t)t1; low++; eb++;
+                    p0 = p1;
+                    if (low >= q) break;
                 }
-                ue = (int32_t)t1; low++; eb++;
             }
 #pragma unroll
             for (int k = 0; k < EDT_AHEAD; k++) {
@@ -186,48 +259,47 @@ __global__ void __launch_bounds__(TPB) k_edt_envelope(const int32_t* __restrict_
                 if (u >= m) break;
                 const I Gu = gv[k];
                 while (q >= eb) {
-                    const I f1 = (tt - ts) * (tt - ts) + tg;
-                    const I f2 = (tt - u) * (tt - u) + Gu;
-                    if (f1 <= f2) break;
+                    if (tv <= sq_add(tt - u, Gu)) break;
                     if (--q >= eb) pop();
                 }
-                if (q < eb) { q = 0; low = 0; ts = u; tt = 0; tg = Gu; r_st[0][tid] = (uint32_t)u; r_g[0][tid] = (int32_t)Gu; }   // (eb == 0: a final entry is never popped)
+                if (q < eb) { q = 0; low = 0; ts = u; tt = 0; tg = Gu; tv = sq_add((I)u, Gu); ring[0][tid] = make_uint2((uint32_t)u, (uint32_t)(int32_t)Gu); }   // (eb == 0: a final entry is never popped)
                 else {
-                    const I w = 1 + floordiv((I)u * u - ts * ts + Gu - tg, (I)2 * (u - ts));
+                    const I w = 1 + floordiv(mul_((I)u + ts, (I)u - ts) + Gu - tg, (I)2 * (u - ts));
                     if (w < m) {                                  // w >= 1 here: the top still wins at its own start
                         q++;
                         if (q - low >= EDT_RING) {                // the ring is full: its oldest chunk moves to the spill area
 #pragma unroll
-                            for (int i = 0; i < EDT_CHUNK; i++)
-                                spill[low + i] = make_uint2(r_st[(low + i) % EDT_RING][tid], (uint32_t)r_g[(low + i) % EDT_RING][tid]);
+                            for (int i = 0; i < EDT_CHUNK; i++) spill[low + i] = ring[SLOT(low + i)][tid];
                             low += EDT_CHUNK;
                             if (low - eb == EDT_CHUNK) {          // the first spilled chunk: the entry above it is the ring's bottom now
-                                const uint32_t pn = r_st[low % EDT_RING][tid];
-                                const I sn = pn & 0xffffu;
-                                dn_t = pn >> 16; dn_v = (dn_t - sn) * (dn_t - sn) + r_g[low % EDT_RING][tid];
+                                const uint2 pn = ring[SLOT(low)][tid];
+                                const I sn = pn.x & 0xffffu;
+                                dn_t = pn.x >> 16; dn_v = sq_add(dn_t - sn, (I)(int32_t)pn.y);
                             }
                         }
-                        ts = u; tt = w; tg = Gu;
-                        r_st[q % EDT_RING][tid] = (uint32_t)u | ((uint32_t)w << 16); r_g[q % EDT_RING][tid] = (int32_t)Gu;
+                        ts = u; tt = w; tg = Gu; tv = sq_add(w - u, Gu);
+                        ring[SLOT(q)][tid] = make_uint2((uint32_t)u | ((uint32_t)w << 16), (uint32_t)(int32_t)Gu);
                     }
                 }
             }
-        }
+        };
+        // (Requesting a batch's values one or two batches ahead - the memory counter retires loads and stores in order, so a load
+        // used in its own batch also waits for the row stores issued after it - was measured in round 4: 24 more registers, a
+        // wave less per SIMD, 5 % slower.  The waves beside this one cover the wait.)
+        for (int32_t u0 = 1; u0 < m; u0 += EDT_AHEAD) { int32_t gv[EDT_AHEAD]; fetch(gv, u0); batch(u0, gv); }
         for (int32_t u = m - 1; u >= ue; u--) {
-            const I v = (u - ts) * (u - ts) + tg;
-            Gout[AT(u)] = v >= EDT_INF ? EDT_INF : (int32_t)v;
+            const I v = sq_add(u - ts, tg);
+            gout[AT(u)] = v >= EDT_INF ? EDT_INF : (int32_t)v;
             if (u == tt && --q >= eb) pop();
         }
 #undef AT
+#undef SLOT
     }
 }
-__global__ void k_edt_sqrt(const int32_t* __restrict__ G, double* __restrict__ out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = sqrt((double)G[i]);
-}
-
 // out[i0][b][a] = in[i0][a][b] for every i0-slab (na x nb -> nb x na), 64 x 64 tiles through LDS: both sides coalesced
-__global__ void __launch_bounds__(256) k_transpose12(const int32_t* __restrict__ in, int32_t* __restrict__ out, int32_t n0, int32_t na, int32_t nb) {
+// (OUT = double: the squared distances leave as distances, scipy's float64 - no pass of its own for the root)
+template <typename OUT>
+__global__ void __launch_bounds__(256) k_transpose12(const int32_t* __restrict__ in, OUT* __restrict__ out, int32_t n0, int32_t na, int32_t nb) {
     __shared__ int32_t tile[64][65];
     const uint32_t ta = (na + 63) / 64, tb = (nb + 63) / 64;
     const uint64_t ntiles = (uint64_t)n0 * ta * tb;
@@ -243,7 +315,10 @@ __global__ void __launch_bounds__(256) k_transpose12(const int32_t* __restrict__
         __syncthreads();
         for (int j = ty; j < 64; j += 4) {
             int b = b0 + j, a = a0 + tx;
-            if (a < na && b < nb) out[slab + (size_t)b * na + a] = tile[tx][j];
+            if (a < na && b < nb) {
+                if constexpr (sizeof(OUT) == 8) out[slab + (size_t)b * na + a] = sqrt((double)tile[tx][j]);
+                else out[slab + (size_t)b * na + a] = tile[tx][j];
+            }
         }
         __syncthreads();
     }
@@ -254,7 +329,8 @@ __global__ void __launch_bounds__(256) k_transpose12(const int32_t* __restrict__
 // The lower-envelope pass runs one thread per line with the lanes of a wave on neighbouring lines, which is
 // coalesced only when the lines are NOT along the fastest axis: the axis-2 pass therefore runs on the i1 <-> i2
 // transposed volume (two tiled transposes, ~4 GB of traffic each at 880x880x640, instead of a 20x slower pass).
-int edt_squared(const uint8_t* dmask, Dims d, int32_t* G) {
+// (dist != nullptr: the distances themselves, float64, into dist - G is scratch then)
+int edt_squared(const uint8_t* dmask, Dims d, int32_t* G, double* dist = nullptr) {
     const size_t V = (size_t)d.n0 * d.n1 * d.n2;
     auto padded = [](size_t m) { return (m + EDT_CHUNK - 1) / EDT_CHUNK * EDT_CHUNK; };
     const size_t spill_entries = std::max((size_t)d.n0 * d.n2 * padded((size_t)d.n1), (size_t)d.n0 * d.n1 * padded((size_t)d.n2));
@@ -263,15 +339,19 @@ int edt_squared(const uint8_t* dmask, Dims d, int32_t* G) {
     if (hipMalloc(&SP, spill_entries * sizeof(uint2)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(G2); g_err = "out of device memory (EDT scratch)"; return VRG_E_MEM; }
     // (every finite squared distance, and so every square and sum of the envelope pass, below EDT_INF = 2^29)
     const bool small = (int64_t)d.n0 * d.n0 + (int64_t)d.n1 * d.n1 + (int64_t)d.n2 * d.n2 < (int64_t)EDT_INF;
-    k_edt_axis0<<<grid_for((uint64_t)d.n1 * d.n2), TPB>>>(dmask, G, d);
-    if (small) k_edt_envelope<int32_t><<<grid_for((uint64_t)d.n0 * d.n2), TPB>>>(G, G2, SP, d);
-    else k_edt_envelope<long long><<<grid_for((uint64_t)d.n0 * d.n2), TPB>>>(G, G2, SP, d);
+    // (G2 holds the downward scan's 16-bit distances first)
+    if (((size_t)d.n1 * d.n2) % 4 == 0 && (reinterpret_cast<uintptr_t>(dmask) & 3u) == 0) k_edt_axis0<4><<<grid_for((uint64_t)d.n1 * d.n2 / 4), TPB>>>(dmask, reinterpret_cast<uint16_t*>(G2), G, d);
+    else k_edt_axis0<1><<<grid_for((uint64_t)d.n1 * d.n2), TPB>>>(dmask, reinterpret_cast<uint16_t*>(G2), G, d);
+    auto egrid = [](Dims e) { return (int)std::min<uint64_t>(65535u * 16u, ((uint64_t)e.n0 * edt_chunks(e.n2) * 64u + EDT_TPB - 1) / EDT_TPB); };
+    if (small) k_edt_envelope<int32_t><<<egrid(d), EDT_TPB>>>(G, G2, SP, d);
+    else k_edt_envelope<long long><<<egrid(d), EDT_TPB>>>(G, G2, SP, d);
     const int tgrid = (int)std::min<uint64_t>(65535u * 4u, (uint64_t)d.n0 * ((d.n1 + 63) / 64) * ((d.n2 + 63) / 64));
-    k_transpose12<<<tgrid, 256>>>(G2, G, d.n0, d.n1, d.n2);                 // G = [n0][n2][n1]
+    k_transpose12<int32_t><<<tgrid, 256>>>(G2, G, d.n0, d.n1, d.n2);        // G = [n0][n2][n1]
     Dims dt = {d.n0, d.n2, d.n1};
-    if (small) k_edt_envelope<int32_t><<<grid_for((uint64_t)d.n0 * d.n1), TPB>>>(G, G2, SP, dt);
-    else k_edt_envelope<long long><<<grid_for((uint64_t)d.n0 * d.n1), TPB>>>(G, G2, SP, dt);
-    k_transpose12<<<tgrid, 256>>>(G2, G, d.n0, d.n2, d.n1);                 // back to [n0][n1][n2]
+    if (small) k_edt_envelope<int32_t><<<egrid(dt), EDT_TPB>>>(G, G2, SP, dt);
+    else k_edt_envelope<long long><<<egrid(dt), EDT_TPB>>>(G, G2, SP, dt);
+    if (dist) k_transpose12<double><<<tgrid, 256>>>(G2, dist, d.n0, d.n2, d.n1);
+    else k_transpose12<int32_t><<<tgrid, 256>>>(G2, G, d.n0, d.n2, d.n1);   // back to [n0][n1][n2]
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(G2); (void)hipFree(SP);
@@ -479,14 +559,12 @@ int vmask_edt(int device, const uint8_t* mask, int64_t n0, int64_t n1, int64_t n
     if (rc) return rc;
     int32_t* G = nullptr; double* dout = nullptr;
     VM_TRY(hipMalloc(&G, V * 4));
-    rc = edt_squared(dm, d, G);
-    if (!rc) {
-        bool od = is_dev(out);
-        if (od) dout = out; else VM_TRY(hipMalloc(&dout, V * 8));
-        k_edt_sqrt<<<grid_for(V), TPB>>>(G, dout, V);
-        if (!od) { rc = deliver(out, (const double*)dout, V); (void)hipFree(dout); }
-        else VM_TRY(hipDeviceSynchronize());
-    }
+    const bool od = is_dev(out);
+    if (od) dout = out;
+    else if (hipMalloc(&dout, V * 8) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(G); if (own) (void)hipFree(own); g_err = "out of device memory (EDT output)"; return VRG_E_MEM; }
+    rc = edt_squared(dm, d, G, dout);                                  // (the last transpose writes the roots: synchronised inside)
+    if (!rc && !od) rc = deliver(out, (const double*)dout, V);
+    if (!od) (void)hipFree(dout);
     (void)hipFree(G); if (own) (void)hipFree(own);
     return rc;
 }
