@@ -36,6 +36,8 @@ def test_oracle_pipeline_properties():
 # ------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(40, 36, 30), (17, 64, 9), (1, 50, 33), (96, 80, 72), (3, 700, 5), (2, 6, 900), (130, 150, 140),
+                                   (37, 9, 7), (70, 5, 6),       # (rows of 63 / 30 voxels: the axis-0 scans one column per thread, whole batches + a tail)
+                                   (2, 3, 20000), (2, 20000, 3), # (the longest lines of the 32-bit envelope pass: quotients near 2^15, numerators near 2^30)
                                    (2, 5, 23200)])      # (squared diagonal >= 2^29: the envelope pass in 64-bit arithmetic)
 def test_edt_bit_exact(shape):
     from arterynetwork_amd.generateVesselVolume import distance_transform_edt
@@ -44,6 +46,8 @@ def test_edt_bit_exact(shape):
     # (long lines with few zeros: the envelope stacks get deeper than the part of them the kernel keeps in LDS)
     for mask in (brain, (rng.random(shape) < 0.97).astype(np.uint8), (rng.random(shape) < 0.5).astype(np.uint8),
                  (rng.random(shape) < 0.9995).astype(np.uint8), np.ones(shape, np.uint8) * (np.arange(shape[1])[None, :, None] > 0)):
+        if mask.all():                  # (a volume without a zero voxel has no distance transform: scipy's answer is arbitrary)
+            mask = mask.copy(); mask.flat[mask.size // 3] = 0
         got = distance_transform_edt(mask)
         ref = MO.distance_transform_edt(mask)
         assert got.dtype == np.float64 and np.array_equal(got, ref)      # sqrt of the exact integer squared distance
@@ -147,6 +151,13 @@ assert lab_d.is_cuda and np.array_equal(lab_d.cpu().numpy().astype(np.int64), la
 d_h = G.distance_transform_edt(m_host)
 d_d = G.distance_transform_edt(m_dev)
 assert d_d.is_cuda and np.array_equal(d_d.cpu().numpy(), d_h)
+# (a mask that starts at an odd device address: the 4-voxel accesses of the axis-0 scans do not apply)
+flat = torch.zeros(m_dev.numel() + 1, dtype=torch.uint8, device=dev)
+odd = flat[1:].view(m_dev.shape); odd.copy_(m_dev)
+out = torch.empty(odd.shape, dtype=torch.float64, device=dev)
+torch.cuda.synchronize()
+assert odd.data_ptr() % 4 != 0 and G._lib().vmask_edt(0, odd.data_ptr(), *odd.shape, out.data_ptr()) == 0
+assert np.array_equal(out.cpu().numpy(), d_h)
 print('DEVICE RESIDENT OK')
 """
 
