@@ -129,6 +129,21 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
 #define VRG_STAMP_PUT(c, k, v) do { (void)(v); } while (0)
 #define VRG_STAMP_MAX(c, k) do { } while (0)
 #endif
+// random delays at the entry of every concurrent kernel and in front of every hand-off (diagnostic build -DVRG_CHAOS only,
+// tools/build_chaos.sh; in the product build nothing executes): one wave in four sleeps for up to ~110 us, so workgroups,
+// kernels and the two streams meet in orders a quiet machine never produces - the results must not change
+// (tools/gpu.sh <tag> chaos)
+#if defined(VRG_CHAOS)
+__device__ __forceinline__ void vrg_chaos_delay(uint32_t salt) {
+    uint32_t h = ((uint32_t)wall_clock64() * 2654435761u) ^ (blockIdx.x * 40503u + (threadIdx.x >> 6) * 9973u + salt * 7919u);
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+    if ((h & 3u) == 0u) { const uint32_t n = (h >> 2) & 63u; for (uint32_t i = 0; i < n; i++) __builtin_amdgcn_s_sleep(64); }
+}
+#define VRG_CHAOS_POINT(salt) vrg_chaos_delay(salt)
+#else
+#define VRG_CHAOS_POINT(salt) do { } while (0)
+#endif
 #define ITEM_LOOP(n) for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += gridDim.x * blockDim.x)
 // same with a 64-bit item index: (listed flips) x (positions) can exceed 2^32 on adversarial volumes
 #define ITEM_LOOP64(n) for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_ = (n); i < n_; i += (uint64_t)gridDim.x * blockDim.x)
@@ -273,8 +288,14 @@ __device__ __forceinline__ void band_deferred_done(const VrgCtx& c, int k, uint3
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
+        VRG_CHAOS_POINT(10);
         const uint32_t q = __hip_atomic_fetch_add(&c.counters[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(VRG_MUTANT)      // (tools/mutant_check.py: a deliberately broken hand-off - the FIRST workgroup to arrive asks for the dense pass - that the campaigns must catch)
+        if (q == n - 1u) c.counters[32] = 0;
+        if (q == 0u) vrg_deferred_done(c, k);
+#else
         if (q == n - 1u) { c.counters[32] = 0; vrg_deferred_done(c, k); }
+#endif
     }
 }
 // First kernel of a trip.  Workgroups [0, BAND_BLOCKS): the pool slots - correction of the sweep before, then the sign
@@ -304,6 +325,7 @@ constexpr uint32_t TAB_LDS = 832;     // levels whose memo entries k_band stages
 constexpr uint32_t DEFER_WGS = 32;    // pool workgroups of k_band that carry out what a fused sweep deferred (label bytes, class bits, free list)
 template <int LPE>
 __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, int dense_on, int direct_hint) {
+    VRG_CHAOS_POINT(1);
     // One LDS block, two uses: the touched-level list (entry-by-entry corrections) or the head of the per-level memo.
     __shared__ double s_raw[NZ_LDS + NZ_LDS * 3 / 2];
     double* s_val = s_raw;
@@ -539,6 +561,7 @@ constexpr int TAB_BLOCKS = 256;     // k_close: memo workgroups (1024 waves, one
 constexpr uint32_t NZ_SORT = 2048;  // touched levels one workgroup sorts in LDS
 
 __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_limit) {
+    VRG_CHAOS_POINT(2);
 
     constexpr uint32_t REC_LDS = 1024;
     __shared__ uint64_t s_key[NF_SMALL];
@@ -625,6 +648,7 @@ typedef uint32_t km_u4 __attribute__((ext_vector_type(4)));
 constexpr int KM_ROWS = 81;         // (dy, dz) in [-4, 4]^2; row bytes 0..8 = dx -4..+4 (16 bytes are fetched)
 __device__ __forceinline__ uint32_t km_row(int dy, int dz) { return (uint32_t)((dz + 4) * 9 + (dy + 4)); }
 __global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
+    VRG_CHAOS_POINT(3);
     // (the first flip's voxel travels with the state: k_order has written the list, whatever the state says)
     const uint32_t t = threadIdx.x, lane = t & 63;
     const bool st0 = blockIdx.x == 0 && t == 0;
@@ -769,6 +793,7 @@ __global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
 // device-scope atomics / write-through stores) files the sizes, asks for the dense pass and closes the sweep.
 constexpr int CLOSE_APPLY = 8;
 __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
+    VRG_CHAOS_POINT(4);
     constexpr uint32_t T = KC_THREADS;
     const uint32_t t = threadIdx.x;
     const bool st0 = blockIdx.x == 0 && t == 0, stm = blockIdx.x == CLOSE_APPLY && t == 0;
@@ -888,6 +913,7 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
     __syncthreads();
     if (stm) VRG_STAMP(c, 34);
     if (t == 0) {
+        VRG_CHAOS_POINT(11);
         const uint32_t k = __hip_atomic_fetch_add(&c.counters[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (k == gridDim.x - 1);
         if (s_last) {
@@ -911,6 +937,7 @@ constexpr uint32_t FUSE_MEMO_NNZ = 1024;  // touched levels k_memo keeps in LDS;
 // the touched levels are listed by their first toucher and sorted by the closing workgroup instead of found by a scan.
 template <bool BIGL>
 __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_follows) {
+    VRG_CHAOS_POINT(5);
     __shared__ VrgFuseLdsT<BIGL ? 1 : VRG_FUSE_LEVELS> sh;
     __shared__ uint32_t s_keys[BIGL ? VRG_FUSE_KEYS : 1];
     __shared__ uint32_t s_scan[VRG_FUSE_THREADS / 64];
@@ -975,6 +1002,7 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     vrg_fuse_annotate(c, sh, t, r, nf);
     __syncthreads();
     if (st0) VRG_STAMP(cg, 19);
+    VRG_CHAOS_POINT(14);
     vrg_fuse_stencil(c, sh, th, t, r);
     __syncthreads();
     if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 20); }
@@ -986,6 +1014,7 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     __syncthreads();
     if (st0) VRG_STAMP(cg, 21);
     if (t == 0) {
+        VRG_CHAOS_POINT(12);
         const uint32_t k = __hip_atomic_fetch_add(&cg.counters[16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (k == nf - 1u);
         if (s_last) cg.counters[16] = 0;                   // every workgroup with a flip has arrived: reset for the next launch
@@ -1042,6 +1071,7 @@ __global__ void __launch_bounds__(TPB) k_levels_clear(VrgCtx c) {
 // slowed the dense pass beside them by 15 % and the sweep's tail by 5 us - a launch of its own costs 2.5.)
 constexpr int MEMO_BLOCKS = 128;
 __global__ void __launch_bounds__(TPB) k_memo(VrgCtx c) {
+    VRG_CHAOS_POINT(6);
     __shared__ uint32_t s_nzl[FUSE_MEMO_NNZ], s_ci[FUSE_MEMO_NNZ], s_co[FUSE_MEMO_NNZ], s_cc[FUSE_MEMO_NNZ];
     const uint32_t t = threadIdx.x;
     // (the head of the list travels with the state)
@@ -1207,6 +1237,7 @@ __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a, int fi
         st_sc1(&c.st_sin[blockIdx.x], ((sh_s[0][0] + sh_s[0][1]) + sh_s[0][2]) + sh_s[0][3]);
         st_sc1(&c.st_sout[blockIdx.x], ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VRG_CHAOS_POINT(13);
         uint32_t t = __hip_atomic_fetch_add(&c.counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = (t == gridDim.x - 1);
         if (is_last) c.counters[0] = 0;              // every workgroup has arrived: reset for the next launch
@@ -1385,6 +1416,7 @@ __device__ __forceinline__ void load_vals(const VrgCtx& c, uint32_t u, uint32_t 
 // not listed are streamed afterwards for their bytes only.
 template <int UNITS, bool NT, int MODE, bool SKIP>
 __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) {
+    VRG_CHAOS_POINT(7);
     if (check_done && check_done != 3 && !c.dctl[VD_GO]) return;     // the gate says: no sweep to count (the run has stopped) or this sweep's pass is left out
     extern __shared__ __attribute__((aligned(16))) float s_val[];   // 16-bit storage: the level values (c.L floats - MODE 3: doubles -, sized at launch)
     const uint32_t lane = threadIdx.x & 63;
@@ -1482,6 +1514,7 @@ __device__ __forceinline__ void load_vals_uncond(const VrgCtx& c, uint32_t u, ui
 }
 template <int UNITS, bool NT>
 __global__ void __launch_bounds__(TPB) k_recount_pipe(VrgCtx c, int check_done) {
+    VRG_CHAOS_POINT(8);
     if (check_done && check_done != 3 && !c.dctl[VD_GO]) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -1585,6 +1618,7 @@ __global__ void __launch_bounds__(GATE_THREADS) k_ulist_init(VrgCtx c) { ulist_r
 // ... or, with option verify_every, close the sweep's pass without a count (fin = 2: one GPU, the pass is closed here; 1: the
 // marker travels through the staged all-reduce like a slab's sums).  VD_GO tells the recount behind the gate what to do.
 __global__ void __launch_bounds__(GATE_THREADS) k_gate(VrgCtx c, int every, int fin) {
+    VRG_CHAOS_POINT(9);
     __shared__ int s_due, s_par;
     if (threadIdx.x == 0) {
         const int due = gate_dense_due(c) ? 1 : 0;

@@ -9,6 +9,8 @@
 #   slabs            only the slab lines + 512
 #   levels           only the level-regime lines
 #   repeat           rare-race hunt: tools/repeat_case.py 8 seeds x 500, repeat_batched, repeat_stress
+#   chaos            interleaving campaign on the -DVRG_CHAOS build (tools/build_chaos.sh: random delays at every kernel entry and
+#                    hand-off): the parity tests of the GPU suite, repeat_case / repeat_batched / repeat_stress, a fuzz campaign
 #   stamps[:shape]   in-kernel stamps of the band chain (diagnostic build, tools/build_stamps.sh)
 #   prof:<tag2>:<bench args,comma separated>   rocprofv3 kernel stats + PMC passes (tools/profile_r3.sh)
 #   traffic:<tag2>:<bench args>                FETCH_SIZE / WRITE_SIZE passes only
@@ -49,6 +51,13 @@ for step in "$@"; do
       for sd in 3 11 19 27 42 77; do timeout 600 python tools/repeat_batched.py $sd 300 4096 8 2>&1 | grep -v amdgpu.ids | tail -1; done >> "$out/repeat_case.log" 2>&1
       timeout 900 python tools/repeat_stress.py 30 2>&1 | grep -v amdgpu.ids | tail -2 >> "$out/repeat_case.log"
       cat "$out/repeat_case.log" ;;
+    chaos)
+      bash tools/build_chaos.sh > /dev/null && ( export VRG_HIP_LIB=$PWD/arterynetwork_amd/csrc/libvrg_hip_chaos.so
+        ( time timeout 3000 python -m pytest tests/test_gpu_parity.py tests/test_float32_input.py -m gpu -x -q -k "not event_sampling and not bench and not litmus" ) 2>&1 | tail -6 | cut -c1-200 > "$out/chaos.log"
+        for sd in 3 11 19 27 42 77 101 202; do timeout 900 python tools/repeat_case.py $sd 150 2>&1 | grep -v amdgpu.ids | tail -1; done >> "$out/chaos.log" 2>&1
+        for sd in 3 11 19 27; do timeout 900 python tools/repeat_batched.py $sd 100 4096 8 2>&1 | grep -v amdgpu.ids | tail -1; done >> "$out/chaos.log" 2>&1
+        timeout 900 python tools/repeat_stress.py 10 2>&1 | grep -v amdgpu.ids | tail -2 >> "$out/chaos.log"
+        timeout 1500 python tests/fuzz_gpu.py 1000 100 4000 2>&1 | grep -v amdgpu.ids | tail -1 >> "$out/chaos.log" ); cat "$out/chaos.log" ;;
     stamps*) shp=${step#stamps}; shp=${shp#:}; shp=${shp:-512x512x170}
       bash tools/build_stamps.sh > /dev/null && ( export VRG_HIP_LIB=$PWD/arterynetwork_amd/csrc/libvrg_hip_stamps.so
         python tools/chain_stamps.py $shp 1 60 2>&1 | grep -v amdgpu.ids > "$out/chain_stamps.log"
