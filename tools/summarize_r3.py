@@ -6,11 +6,26 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 tag = sys.argv[1]
 name = sys.argv[2] if len(sys.argv) > 2 else tag
-shape = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else '880x880x640').split('x')]
+src = 'gpurun_out/prof_' + tag
+
+
+def profiled_shape():
+    """The volume the profiled bench lines were run on (their `metric` names it): the default when no shape is given, so that
+    a call with the tag alone can never file one volume's bytes under another's shape."""
+    import re
+    for log in ('bench_fetch.log', 'bench.json', 'bench_trace.log'):
+        try:
+            line = [l for l in open(os.path.join(src, log)) if l.startswith('{')][-1]
+            return re.search(r'(\d+x\d+x\d+) volume', json.loads(line)['metric']).group(1)
+        except Exception:
+            continue
+    return '880x880x640'
+
+
+shape = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else profiled_shape()).split('x')]
 planes = int(sys.argv[4]) if len(sys.argv) > 4 else shape[2]
 n_gpus = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 storage16 = bool(int(sys.argv[6])) if len(sys.argv) > 6 else False
-src = 'gpurun_out/prof_' + tag
 os.makedirs('profiles', exist_ok=True)
 KERNELS = ('k_recount_pipe', 'k_recount_bits', 'k_band', 'k_sweep', 'k_memo', 'k_order', 'k_mark_relabel', 'k_close', 'k_gate')
 
@@ -31,7 +46,7 @@ if st:
         a[0] += int(r['Calls']); a[1] += int(r['TotalDurationNs'])
     tot = sum(a[1] for a in agg.values())
     with open('profiles/%s_kernel_stats.csv' % name, 'w') as f:
-        f.write('# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline (%s)\n' % ' '.join(sys.argv[3:4] or ['880x880x640']))
+        f.write('# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline (%s)\n' % 'x'.join(map(str, shape)))
         f.write('Name,Calls,TotalDurationNs,AverageNs,Percentage\n')
         for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             f.write('"%s",%d,%d,%.1f,%.3f\n' % (k, a[0], a[1], a[1] / a[0], 100.0 * a[1] / tot))
