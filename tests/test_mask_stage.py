@@ -54,6 +54,36 @@ def test_edt_bit_exact(shape):
 
 
 @pytest.mark.gpu
+def test_edt_random_shapes():
+    """Sixty random small volumes (every dimension 1..70, zero fractions from one voxel to most of the volume, solid blocks
+    with holes): the distances are scipy's, bit for bit - row lengths of every residue modulo 4 and 64, lines shorter and
+    longer than a batch of the envelope pass, columns with and without a zero."""
+    from arterynetwork_amd.generateVesselVolume import distance_transform_edt
+    rng = np.random.default_rng(77)
+    for case in range(60):
+        shape = tuple(int(v) for v in rng.integers(1, 71, 3))
+        kind = case % 4
+        if kind == 0:
+            mask = (rng.random(shape) < rng.choice([0.3, 0.8, 0.97, 0.995])).astype(np.uint8)
+        elif kind == 1:
+            mask = np.ones(shape, np.uint8)
+            for _ in range(int(rng.integers(1, 4))):
+                mask[tuple(int(rng.integers(0, n)) for n in shape)] = 0
+        elif kind == 2:
+            mask = np.zeros(shape, np.uint8)
+            lo = [int(rng.integers(0, max(1, n // 2))) for n in shape]
+            mask[lo[0]:, lo[1]:, lo[2]:] = 1                       # a solid block against three faces of the volume
+            mask[rng.random(shape) < 0.002] = 0
+        else:
+            mask = (rng.random(shape) < 0.9).astype(np.uint8)
+            mask[:, :, shape[2] // 2] = 1                          # a plane without a zero
+        if mask.all():
+            mask.flat[mask.size // 3] = 0
+        got = distance_transform_edt(mask)
+        assert np.array_equal(got, MO.distance_transform_edt(mask)), (case, shape, kind)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('maxHop', [1, 2, 3])
 def test_label_volume_matches_raster_numbering(maxHop):
     from arterynetwork_amd.generateVesselVolume import labelVolume
