@@ -158,6 +158,8 @@ __device__ __forceinline__ long long mul_(long long a, long long b) { return a *
 // reciprocal and 24-bit multiplies, the top's value at its start kept in a register, unsigned ring slots, uniform bases.
 // (Round 1: every push wrote and every pop read global memory in the data's layout, 4 bytes at a time at addresses
 // that differ from lane to lane, and every step waited for its own load - 12.4 ms per pass at 880x880x640.)
+// (Round 4, per mask at 880x880x640: a 12-entry ring - 26 instead of 20 waves per CU - is 4-8 % faster where the stack stays
+// shallow, a tube, and 8-15 % slower inside the solid ellipsoid, more spills; 32 entries - 10 waves per CU - 1.4-1.6 x slower)
 #ifndef EDT_RING_N            // (-D overrides: tuning experiments only)
 #define EDT_RING_N 16
 #define EDT_CHUNK_N 8
