@@ -176,8 +176,10 @@ def cpu_baseline(I_t, vm_t, H, levels_note, min_free_gb=48.0, crop_vox=70e6):
     t_prep = time.perf_counter() - t_prep
     sweeps = 0
 
-    def timed(threads, min_sweeps, min_s, cap_s):
-        """>= min_sweeps sweeps and >= min_s seconds (one discarded sweep first), at most cap_s seconds."""
+    def timed(threads, min_sweeps, min_s, cap_s, max_sweeps):
+        """>= min_sweeps sweeps and >= min_s seconds (one discarded sweep first), at most cap_s seconds and max_sweeps sweeps
+        (on a small volume a second is hundreds of sweeps: the probes together must not use up the run - the region stops
+        growing at some point, and a sampled rate has to be the rate of sweeps that still do work)."""
         nonlocal sweeps
         got = o.set_threads(threads)
         if o.step(10 ** 6, 10 ** 12, -1.0) != 0:
@@ -187,19 +189,19 @@ def cpu_baseline(I_t, vm_t, H, levels_note, min_free_gb=48.0, crop_vox=70e6):
         n = 0
         while True:
             el = time.perf_counter() - t0
-            if (n >= min_sweeps and el >= min_s) or el >= cap_s:
+            if (n >= min_sweeps and el >= min_s) or el >= cap_s or n >= max_sweeps:
                 break
             if o.step(10 ** 6, 10 ** 12, -1.0) != 0:
                 break
             n += 1
         sweeps += n
         return got, n, time.perf_counter() - t0
-    t1 = timed(1, 3, 1.0, 6.0)
+    t1 = timed(1, 3, 1.0, 6.0, 10)
     cands = sorted({t for t in (8, 16, 32, 64, 128, navail) if t <= navail})
-    probe = {t: timed(t, 10, 1.0, 5.0) for t in cands}
+    probe = {t: timed(t, 10, 1.0, 5.0, 40) for t in cands}
     rate = {t: (n / dt if n and dt > 0 else 0.0) for t, (got, n, dt) in probe.items()}
     best = max(rate, key=rate.get) if rate else 1
-    tn = timed(best, 20, 2.0, 10.0)
+    tn = timed(best, 20, 2.0, 10.0, 80)
     if sweeps == 0 or tn[1] == 0:
         o.close()
         return None
@@ -228,7 +230,7 @@ def cpu_baseline(I_t, vm_t, H, levels_note, min_free_gb=48.0, crop_vox=70e6):
             'probe_to_final': round(value / best_probe, 3) if best_probe else None,
             'whole_volume': bool(whole), 'prepare_seconds': round(t_prep, 1),
             'parity': parity, 'parity_sweeps': sweeps,
-            'sample': '{} sweeps with 1 thread ({:.1f} s), >= 10-sweep probes of {} threads, then {} sweeps with {} threads ({:.1f} s) of '
+            'sample': '{} sweeps with 1 thread ({:.1f} s), 10- to 40-sweep probes of {} threads, then {} sweeps with {} threads ({:.1f} s) of '
                       'the oracle (C port of the reference, level-histogram mode, OpenMP build) on {} ({}); the HIP path repeated the {} '
                       'sweeps on the same volume and was compared with it'.format(n1, d1, '/'.join(str(t) for t in cands), nn, gn, dn, what, levels_note, sweeps),
             'reference_itself': REFERENCE_ITSELF}
