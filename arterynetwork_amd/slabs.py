@@ -178,7 +178,7 @@ def bench_slabs(shape, args, dev, rank, world, roofline, configure, load_traffic
                    'dense_pass_loads': 'non-temporal' if st['dense_nt_loads'] else 'ordinary', 'dense_workgroups': st['dense_workgroups'],
                    'scaling_floor': scaling_floor,
                    'ranks': per_rank},
-        'roofline': roofline(shape, z1 - z0, kern_ms, int(r.sweep_launches), load_traffic(shape, world, args.storage16, z1 - z0),
+        'roofline': roofline(shape, z1 - z0, kern_ms, int(r.sweep_launches), load_traffic(shape, world, args.storage16, z1 - z0, dense_bytes),
                              args.storage16, dense_bytes, st['dense_kernel']),
     }
     s.close()

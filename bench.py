@@ -43,15 +43,19 @@ def device_source_sha():
     return h.hexdigest()[:16]
 
 
-def load_traffic(shape, n_gpus, storage16, planes=None):
+def load_traffic(shape, n_gpus, storage16, planes=None, design_bytes=None):
     """HBM bytes per dense launch from the committed rocprofv3 PMC passes (profiles/traffic.json) - only when an entry was
-    measured on these very kernel sources (src_sha) and workload (shape, ranks, storage, slab planes); None otherwise
-    (never a stale figure)."""
+    measured on these very kernel sources (src_sha) and workload (shape, ranks, storage, slab planes - and, `design_bytes`
+    given, a pass that has to fetch the same bytes within 2 %: a volume without its brain mask, say, is another workload);
+    None otherwise (never a stale or foreign figure)."""
     try:
         t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
         for e in t.get('entries', [t]):
             if (e.get('shape') == list(shape) and e.get('n_gpus', 1) == n_gpus and bool(e.get('storage16', False)) == bool(storage16)
                     and e.get('planes', shape[2]) == (planes if planes is not None else shape[2]) and e.get('src_sha') == device_source_sha()):
+                ref = e.get('design_bytes_per_launch_counted_on_device')
+                if design_bytes and ref and abs(float(design_bytes) / float(ref) - 1.0) > 0.02:
+                    continue
                 return e.get('hbm_bytes_per_launch')
     except Exception:
         pass
@@ -405,7 +409,7 @@ def main():
                    # (vrg.h option nt_loads: a pass of up to ~300 MB is read with ordinary loads and stays in the Infinity Cache)
                    'dense_pass_loads': 'non-temporal' if st['dense_nt_loads'] else 'ordinary', 'dense_workgroups': st['dense_workgroups'],
                    'dense_listed_units': st['dense_listed_units']},
-        'roofline': roofline(shape, shape[2], kern_ms, int(r.sweep_launches), load_traffic(shape, 1, args.storage16), args.storage16, dense_bytes, st['dense_kernel']),
+        'roofline': roofline(shape, shape[2], kern_ms, int(r.sweep_launches), load_traffic(shape, 1, args.storage16, None, dense_bytes), args.storage16, dense_bytes, st['dense_kernel']),
     }
     out['config']['engine'] = st                            # trips handed back to the host / array growth during the run
     out['config'].update(s.chain_timing(args.H))
