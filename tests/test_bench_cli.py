@@ -76,6 +76,12 @@ def test_traffic_only_for_the_sources_it_was_measured_on():
         got = bench.load_traffic(tuple(e['shape']), e.get('n_gpus', 1), bool(e.get('storage16')), e.get('planes'))
         assert got == (e['hbm_bytes_per_launch'] if e.get('src_sha') == bench.device_source_sha() else None)
         assert bench.load_traffic(tuple(e['shape']), e.get('n_gpus', 1), not e.get('storage16'), e.get('planes')) is None or len(entries) > 1
+        # ... and only for a pass that has to fetch the same bytes (within 2 %): the same shape without its brain mask is another workload
+        ref = e.get('design_bytes_per_launch_counted_on_device')
+        if ref and e.get('src_sha') == bench.device_source_sha():
+            args = (tuple(e['shape']), e.get('n_gpus', 1), bool(e.get('storage16')), e.get('planes'))
+            assert bench.load_traffic(*args, design_bytes=ref * 1.01) == e['hbm_bytes_per_launch']
+            assert bench.load_traffic(*args, design_bytes=ref * 2.0) is None
     assert bench.load_traffic((1, 2, 3), 1, False) is None
 
 
