@@ -434,26 +434,38 @@ __device__ __forceinline__ uint32_t cc_rank(CcRank k, uint32_t r) {
     return k.off[r >> 6] + (uint32_t)__popcll(k.bits[r >> 6] & ((1ull << (r & 63u)) - 1ull));
 }
 struct PopcU64 { __host__ __device__ uint32_t operator()(unsigned long long w) const { return (uint32_t)__builtin_popcountll(w); } };
-__global__ void k_cc_sizes(const int32_t* __restrict__ root, CcRank rk, unsigned long long* __restrict__ sizes, uint32_t V) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
-        int32_t r = root[i];
-        if (r >= 0) atomicAdd(&sizes[cc_rank(rk, (uint32_t)r)], 1ull);
-    }
+__global__ void __launch_bounds__(TPB) k_cc_sizes(const int32_t* __restrict__ root, CcRank rk, unsigned long long* __restrict__ sizes, uint32_t V) {
+    const int4* __restrict__ r4 = reinterpret_cast<const int4*>(root);      // (root is this library's own array: hipMalloc-aligned)
+    const uint32_t nq = V / 4u;
+    auto count = [&](int32_t r) { if (r >= 0) atomicAdd(&sizes[cc_rank(rk, (uint32_t)r)], 1ull); };
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) { const int4 r = r4[i]; count(r.x); count(r.y); count(r.z); count(r.w); }
+    for (uint32_t i = nq * 4u + blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) count(root[i]);
 }
-__global__ void k_cc_labels(const int32_t* __restrict__ root, CcRank rk, int32_t* __restrict__ labels, uint32_t V) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
-        int32_t r = root[i];
-        labels[i] = r >= 0 ? (int32_t)cc_rank(rk, (uint32_t)r) + 1 : 0;
+// (vec: four voxels per thread and turn - the caller's array, when it is a device pointer, need not be 16-byte aligned)
+__global__ void __launch_bounds__(TPB) k_cc_labels(const int32_t* __restrict__ root, CcRank rk, int32_t* __restrict__ labels, uint32_t V, int vec) {
+    const int4* __restrict__ r4 = reinterpret_cast<const int4*>(root);
+    int4* __restrict__ l4 = reinterpret_cast<int4*>(labels);
+    const uint32_t nq = vec ? V / 4u : 0u;
+    auto lab = [&](int32_t r) { return r >= 0 ? (int32_t)cc_rank(rk, (uint32_t)r) + 1 : 0; };
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) {
+        const int4 r = r4[i];
+        l4[i] = make_int4(lab(r.x), lab(r.y), lab(r.z), lab(r.w));
     }
+    for (uint32_t i = nq * 4u + blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) labels[i] = lab(root[i]);
 }
-__global__ void k_cc_filter(const int32_t* __restrict__ root, CcRank rk, const unsigned long long* __restrict__ sizes,
-                            unsigned long long min_size, uint8_t* __restrict__ out, unsigned long long* kept, uint32_t V) {
+__global__ void __launch_bounds__(TPB) k_cc_filter(const int32_t* __restrict__ root, CcRank rk, const unsigned long long* __restrict__ sizes,
+                                                   unsigned long long min_size, uint8_t* __restrict__ out, unsigned long long* kept, uint32_t V, int vec) {
     unsigned long long local = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
-        int32_t r = root[i];
-        uint8_t keep = (r >= 0 && sizes[cc_rank(rk, (uint32_t)r)] > min_size) ? 1 : 0;    // labelSize <= 150 is removed (:197-199)
-        out[i] = keep; local += keep;
+    const int4* __restrict__ r4 = reinterpret_cast<const int4*>(root);
+    uchar4* __restrict__ o4 = reinterpret_cast<uchar4*>(out);
+    const uint32_t nq = vec ? V / 4u : 0u;
+    auto keep = [&](int32_t r) -> uint8_t { return (r >= 0 && sizes[cc_rank(rk, (uint32_t)r)] > min_size) ? 1 : 0; };    // labelSize <= 150 is removed (:197-199)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) {
+        const int4 r = r4[i];
+        const uchar4 k = make_uchar4(keep(r.x), keep(r.y), keep(r.z), keep(r.w));
+        o4[i] = k; local += (unsigned)k.x + k.y + k.z + k.w;
     }
+    for (uint32_t i = nq * 4u + blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) { const uint8_t k = keep(root[i]); out[i] = k; local += k; }
     if (local) atomicAdd(kept, local);
 }
 
@@ -480,7 +492,7 @@ int cc_run(const uint8_t* dvol, Dims d, int connectivity, CC& c) {
     c.ncomp = last_off + (uint32_t)__builtin_popcountll(last_bits);
     VM_TRY(hipMalloc(&c.sizes, ((size_t)c.ncomp + 1) * 8));
     VM_TRY(hipMemset(c.sizes, 0, ((size_t)c.ncomp + 1) * 8));
-    k_cc_sizes<<<grid_for(V), TPB>>>(c.root, c.rank(), c.sizes, V);
+    k_cc_sizes<<<grid_for(((uint64_t)V + 3) / 4), TPB>>>(c.root, c.rank(), c.sizes, V);
     VM_TRY(hipGetLastError());
     return VRG_OK;
 }
@@ -580,7 +592,7 @@ template <class T> int vessel_mask_impl(const uint8_t* dbrain, const T* dves, Di
     if (rc) { cc_free(c); (void)hipFree(fg); return rc; }
     unsigned long long* dk = nullptr;
     VM_TRY(hipMalloc(&dk, 8)); VM_TRY(hipMemset(dk, 0, 8));
-    k_cc_filter<<<grid_for(V), TPB>>>(c.root, c.rank(), c.sizes, (unsigned long long)min_size, dout, dk, (uint32_t)V);
+    k_cc_filter<<<grid_for(((uint64_t)V + 3) / 4), TPB>>>(c.root, c.rank(), c.sizes, (unsigned long long)min_size, dout, dk, (uint32_t)V, (reinterpret_cast<uintptr_t>(dout) & 3u) == 0 ? 1 : 0);
     unsigned long long k = 0;
     VM_TRY(hipMemcpy(&k, dk, 8, hipMemcpyDeviceToHost));
     if (kept) *kept = (int64_t)k;
@@ -631,7 +643,7 @@ int vmask_label(int device, const uint8_t* volume, int64_t n0, int64_t n1, int64
         bool od = is_dev(labels);
         int32_t* dl = labels;
         if (!od) VM_TRY(hipMalloc(&dl, V * 4));
-        k_cc_labels<<<grid_for(V), TPB>>>(c.root, c.rank(), dl, (uint32_t)V);
+        k_cc_labels<<<grid_for(((uint64_t)V + 3) / 4), TPB>>>(c.root, c.rank(), dl, (uint32_t)V, (reinterpret_cast<uintptr_t>(dl) & 15u) == 0 ? 1 : 0);
         if (!od) { rc = deliver(labels, (const int32_t*)dl, V); (void)hipFree(dl); }
         else VM_TRY(hipDeviceSynchronize());
         if (n) *n = c.ncomp;
