@@ -38,6 +38,8 @@ TRACE_DTYPE = np.dtype([('nflip', 'i8'), ('nseg', 'i8'), ('n_in', 'i8'), ('n_out
 
 
 REDUCE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_void_p)
+BCAST_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+ALLSUM_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
 
 
 class VrgError(RuntimeError):
@@ -80,6 +82,12 @@ class VrgLib:
         self.comm_unique_id = fn('comm_unique_id', [p])
         self.comm_init = fn('comm_init', [p, C.c_int, C.c_int, p])
         self.set_reduce_callback = fn('set_reduce_callback', [p, REDUCE_FN, p])
+        self.repl_init = fn('repl_init', [p, C.c_int, C.c_int, C.c_int])
+        self.repl_set_callbacks = fn('repl_set_callbacks', [p, BCAST_FN, ALLSUM_FN, p])
+        self.repl_use_rccl = fn('repl_use_rccl', [p])
+        self.repl_ipc_export = fn('repl_ipc_export', [p, p, C.c_int64, i64p])
+        self.repl_ipc_import = fn('repl_ipc_import', [p, p, C.c_int64])
+        self.repl_stats = fn('repl_stats', [p, i64p, C.c_int64])
 
 
 _product = None
@@ -193,6 +201,41 @@ class Session:
                 ptr[i] = float(out[i])
         self._reduce_thunk = REDUCE_FN(thunk)
         self._check(self.lib.set_reduce_callback(self._h, self._reduce_thunk, None))
+
+    # ---- multi-GPU, leader / follower replication (include/vrg.h) -----------------------------------
+    def repl_init(self, nranks, rank, leader_verifies=True):
+        self._check(self.lib.repl_init(self._h, int(nranks), int(rank), 1 if leader_verifies else 0))
+
+    def repl_set_callbacks(self, bcast, allsum):
+        """bcast(bytearray-like memoryview, root) fills / sends the buffer in place; allsum(list of floats) -> summed list."""
+        def b_thunk(ptr, nbytes, root, _user):
+            bcast((C.c_uint8 * nbytes).from_address(ptr), int(root))
+
+        def s_thunk(ptr, n, _user):
+            out = allsum([ptr[i] for i in range(n)])
+            for i in range(n):
+                ptr[i] = float(out[i])
+        self._repl_thunks = (BCAST_FN(b_thunk), ALLSUM_FN(s_thunk))
+        self._check(self.lib.repl_set_callbacks(self._h, self._repl_thunks[0], self._repl_thunks[1], None))
+
+    def repl_use_rccl(self):
+        self._check(self.lib.repl_use_rccl(self._h))
+
+    def repl_ipc_export(self):
+        buf = C.create_string_buffer(256)
+        n = C.c_int64()
+        self._check(self.lib.repl_ipc_export(self._h, buf, 256, C.byref(n)))
+        return buf.raw[:n.value]
+
+    def repl_ipc_import(self, blob):
+        buf = C.create_string_buffer(bytes(blob), len(blob))
+        self._check(self.lib.repl_ipc_import(self._h, buf, len(blob)))
+
+    def repl_stats(self):
+        a = (C.c_int64 * 8)()
+        self._check(self.lib.repl_stats(self._h, a, 8))
+        return {'batches': a[0], 'records': a[1], 'sweeps': a[2], 'verified': a[3], 'last_verified': a[4],
+                'transport': {0: 'none', 1: 'callback', 2: 'rccl', 3: 'ipc'}[a[5]], 'verifiers': a[6], 'slot': a[7]}
 
     def init(self, H=2.25):
         self._check(self.lib.init(self._h, float(H)))

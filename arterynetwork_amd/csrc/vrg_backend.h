@@ -98,6 +98,27 @@ void be_fuse_enter(VrgBackend* b, const VrgCtx& c);
 int be_comm_unique_id(void* id128);
 int be_comm_init(VrgBackend* b, int nranks, int rank, const void* id128);
 
+// ---- leader / follower replication (vrg_repl.h): what a FOLLOWER does with the leader's change log ------------------------------------
+// apply the nrec records of sweep k (device array `recs`, this handle's device) to this handle's labels, class bits, unit bitmap and
+// stamps, in stream order; `hdr` (host memory) is the sweep's header: its trace record is filed.  A record whose `old` byte is not what
+// this handle holds raises dctl[VD_ERR] = 12.
+void be_follow_apply(VrgBackend* b, const VrgCtx& c, const VrgLogRec* recs, const VrgLogSweep* hdr);
+// ... and count sweep k (every voxel: this handle's dense pass with the unit list brought up to date) against the sizes the leader filed
+// for it; a mismatch raises dctl[VD_ERR] = 5; the intensity sums go into the sweep's trace record.  ev: optional HIP-event timing of the pass.
+void be_follow_verify(VrgBackend* b, const VrgCtx& c, const VrgLogSweep* hdr, VrgEvents* ev);
+// a follower's two staging buffers: mark = everything enqueued so far (the kernels that read buffer `slot`); wait = that has finished
+void be_follow_mark(VrgBackend* b, int slot);
+void be_follow_wait(VrgBackend* b, int slot);
+// transports of the log between the ranks' devices.  RCCL (device backend, after be_comm_init): broadcast from rank `root` / sum over
+// the ranks, enqueued on the backend's transport stream; be_repl_wait waits for that stream.  Return 0, or -1: not available.
+int be_repl_bcast(VrgBackend* b, void* dev_buf, size_t bytes, int root);
+int be_repl_allsum(VrgBackend* b, double* dev_buf, size_t n);
+void be_repl_wait(VrgBackend* b);
+// inter-process handles of device allocations (ranks on one node: the follower copies straight out of the leader's buffers)
+int be_ipc_export(VrgBackend* b, void* dev_ptr, void* handle64);
+void* be_ipc_open(VrgBackend* b, const void* handle64);        // nullptr: failed
+void be_ipc_close(VrgBackend* b, void* mapped);
+
 // fold the HIP-event pairs recorded since the last call into ev (only the first n_valid were real sweeps)
 void be_events_collect(VrgBackend* b, VrgEvents* ev, long long n_valid);
 

@@ -45,6 +45,9 @@ struct VrgBackend {
     int device = 0;
     hipStream_t sa = nullptr;            // stream A: the band kernels of every trip in program order, copies
     hipStream_t sb = nullptr;            // stream B: the dense pass (recount, slab all-reduce, k_dense_fin); trails stream A by up to one sweep
+    hipStream_t sc = nullptr;            // stream C: the change log's transport (leader / follower replication: RCCL broadcasts), created on first use
+    int repl = 0;                        // this handle is a rank of a leader / follower group: the communicator carries the log, not slab sums
+    hipEvent_t mark[2] = {nullptr, nullptr};   // a follower's staging buffers: the kernels that read buffer j have been enqueued up to here
     int sweep_blocks = 0;                // 0 = auto (dense_blocks)
     int prio_mode = 2;                   // the dense stream gets the higher priority (measured: -1..2 % step time)
     uint32_t small_flips = 4096;         // flips per sweep k_order takes on (<= NF_SMALL)
@@ -166,9 +169,10 @@ __device__ void exact_wave_binned(const VrgCtx& c, const VrgState& s, uint32_t n
         for (uint32_t b = b0 + lane; b <= b1; b += 64u) { double ti, to; vrg_bin_terms(c, v, b, ti, to); si += ti; so += to; }
         si = wave_sum(si); so = wave_sum(so);
         if (lane == 0) {
-            c.p_ip[slot] = si; c.p_op[slot] = so;
+            const float err = vrg_exact_err(c, si, so);
+            c.p_ip[slot] = si; c.p_op[slot] = so; c.p_err[slot] = err;
             if (then_decide && s.iter < s.iterMax)
-                vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot]);
+                vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot], (double)err);
         }
     }
 }
@@ -209,7 +213,7 @@ __device__ void exact_wave(const VrgCtx& c, const VrgState& s, uint32_t nfresh, 
         }
         si = wave_sum(si); so = wave_sum(so);
         if (lane == 0) {
-            c.p_ip[slot] = si; c.p_op[slot] = so;        // (the pending flag is cleared by the slot's own thread in the other half)
+            c.p_ip[slot] = si; c.p_op[slot] = so; c.p_err[slot] = 0.0f;   // (the pending flag is cleared by the slot's own thread in the other half; sums over the levels: no binning error)
             if (then_decide && s.iter < s.iterMax)       // while iterNum <= iterMax (:58)
                 vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot]);
         }
@@ -265,7 +269,7 @@ __device__ void exact_wg(const VrgCtx& c, const VrgState& s, uint32_t nfresh, ui
         if (threadIdx.x == 0) {
             si = sh_i[0]; so = sh_o[0];
             for (uint32_t w = 1; w < NWV; w++) { si += sh_i[w]; so += sh_o[w]; }
-            c.p_ip[slot] = si; c.p_op[slot] = so;        // (the pending flag is cleared by the slot's own thread in the other half)
+            c.p_ip[slot] = si; c.p_op[slot] = so; c.p_err[slot] = 0.0f;   // (the pending flag is cleared by the slot's own thread in the other half; sums over the levels: no binning error)
             if (s.iter < s.iterMax)                      // while iterNum <= iterMax (:58)
                 vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot]);
         }
@@ -284,7 +288,7 @@ __device__ __forceinline__ void wait_dense_read_for(const VrgCtx& c, int64_t nee
     }
 }
 // the deferred work of this workgroup has reached memory; the LAST of the `n` workgroups to say so closes it (vrg_deferred_done)
-__device__ __forceinline__ void band_deferred_done(const VrgCtx& c, int k, uint32_t n) {
+__device__ __forceinline__ void band_deferred_done(const VrgCtx& c, const VrgState& s, int k, uint32_t n) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -292,9 +296,9 @@ __device__ __forceinline__ void band_deferred_done(const VrgCtx& c, int k, uint3
         const uint32_t q = __hip_atomic_fetch_add(&c.counters[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(VRG_MUTANT)      // (tools/mutant_check.py: a deliberately broken hand-off - the FIRST workgroup to arrive asks for the dense pass - that the campaigns must catch)
         if (q == n - 1u) c.counters[32] = 0;
-        if (q == 0u) vrg_deferred_done(c, k);
+        if (q == 0u) vrg_deferred_done(c, s, k);
 #else
-        if (q == n - 1u) { c.counters[32] = 0; vrg_deferred_done(c, k); }
+        if (q == n - 1u) { c.counters[32] = 0; vrg_deferred_done(c, s, k); }
 #endif
     }
 }
@@ -345,7 +349,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
     const uint32_t dtid = (blockIdx.x - (band_blocks + EXACT_BLOCKS)) * TPB + tid;      // (deferred workgroups: their thread number)
     const bool use_ktab = c.ktab != nullptr;           // (uniform) the kernel between two levels is a table look-up
     const uint32_t slot0 = direct_hint ? gtid / LPE : gtid;
-    uint8_t fl0 = 0; double ip0 = 0, op0 = 0; uint32_t lev0 = 0, idx0 = 0; uint64_t key0 = 0; int64_t nin0 = 0, nout0 = 0;
+    uint8_t fl0 = 0; double ip0 = 0, op0 = 0; float err0 = 0; uint32_t lev0 = 0, idx0 = 0; uint64_t key0 = 0; int64_t nin0 = 0, nout0 = 0;
     const uint32_t tab_n = c.L < TAB_LDS ? c.L : TAB_LDS;
     constexpr uint32_t NZQ = 1;                           // touched levels per thread fetched with the state (256 per workgroup; a longer list: the rest once its length is known)
     double zv[NZQ]; uint32_t zi[NZQ], zo[NZQ], zc[NZQ], zl[NZQ];
@@ -354,7 +358,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
     if (pool_wg) {
         // (every load of this batch is unconditional with its index clamped into the array: a load under a divergent branch makes
         // the compiler wait for all loads in flight before the next one)
-        { const uint32_t q = slot0 < c.bcap ? slot0 : c.bcap - 1u; fl0 = c.p_flag[q]; ip0 = c.p_ip[q]; op0 = c.p_op[q]; lev0 = c.p_lev[q]; idx0 = c.p_idx[q]; key0 = c.p_key[q]; }
+        { const uint32_t q = slot0 < c.bcap ? slot0 : c.bcap - 1u; fl0 = c.p_flag[q]; ip0 = c.p_ip[q]; op0 = c.p_op[q]; err0 = c.p_err[q]; lev0 = c.p_lev[q]; idx0 = c.p_idx[q]; key0 = c.p_key[q]; }
         nin0 = c.inc[VC_NIN]; nout0 = c.inc[VC_NOUT];
         if (!direct_hint) { for (uint32_t j = tid; j < 3 * tab_n; j += TPB) s_raw[j] = c.tabC[j]; }
         else {
@@ -381,14 +385,14 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
         const int k = s.iter;
         if (tid == 0 && dense_on && (int64_t)k - 2 > rseq0) wait_dense_read_for(c, (int64_t)k - 2);   // (the pass of two sweeps ago has read the class copy this sweep rewrites)
         __syncthreads();
-        if (dtid < s.ap_n) vrg_deferred_apply_vals(c, dtid, k, mxa, moa, mna);
-        if (dtid + G < s.ap_n) vrg_deferred_apply_vals(c, dtid + G, k, mxb, mob, mnb);
-        for (uint32_t i = dtid + 2u * G; i < s.ap_n; i += G) vrg_deferred_apply(c, i, k);
+        if (dtid < s.ap_n) vrg_deferred_apply_vals(c, dtid, k, mxa, moa, mna, s.log_pos);
+        if (dtid + G < s.ap_n) vrg_deferred_apply_vals(c, dtid + G, k, mxb, mob, mnb, s.log_pos);
+        for (uint32_t i = dtid + 2u * G; i < s.ap_n; i += G) vrg_deferred_apply(c, i, k, s.log_pos);
         const uint32_t nc = vrg_deferred_catchup_count(c, k), pp = ((uint32_t)k & 1u) ^ 1u;
         if (dtid < nc) { const uint32_t dw = pp ? cda1 : cda0, x = pp ? cxa1 : cxa0; if (dw != VRG_NOCHG) vrg_atomic_xor(&c.clsb[pp ^ 1u][dw], x); }
         for (uint32_t i = dtid + G; i < nc; i += G) vrg_deferred_catchup(c, i, k);
         for (uint32_t j = dtid; j < s.fr_n; j += G) vrg_deferred_free(c, s, j);
-        band_deferred_done(c, k, defer_wgs);
+        band_deferred_done(c, s, k, defer_wgs);
         return;
     }
     if (!pool_wg) {
@@ -402,7 +406,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
         __syncthreads();                                  // (the memo head is in LDS)
         if (!direct_hint) {
             if (slot0 < s.np)
-                vrg_item_band_fields(c, s, slot0, fl0, ip0, op0, lev0, idx0, key0, nin0, nout0, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n);
+                vrg_item_band_fields(c, s, slot0, fl0, ip0, op0, lev0, idx0, key0, nin0, nout0, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n, (double)err0);
             for (uint32_t slot = slot0 + band_blocks * TPB; slot < s.np; slot += band_blocks * TPB)
                 vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n);
         } else
@@ -428,11 +432,11 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
     const uint32_t np_pad = (s.np + (TPB / LPE) - 1) / (TPB / LPE) * (TPB / LPE);      // whole waves stay in the loop together
     const uint32_t first = gtid / LPE;
     for (uint32_t slot = first; slot < np_pad; slot += band_blocks * TPB / LPE) {
-        uint8_t fl = 0; double ip = 0, op = 0, v = 0; uint32_t lev = 0, idx = 0; uint64_t key = 0;
+        uint8_t fl = 0; double ip = 0, op = 0, v = 0; float err = 0; uint32_t lev = 0, idx = 0; uint64_t key = 0;
         const bool in_pool = slot < s.np, pre = direct_hint && slot == first;
         if (in_pool) {
-            if (pre) { fl = fl0; ip = ip0; op = op0; lev = lev0; idx = idx0; key = key0; }
-            else { fl = c.p_flag[slot]; ip = c.p_ip[slot]; op = c.p_op[slot]; lev = c.p_lev[slot]; idx = c.p_idx[slot]; key = c.p_key[slot]; }   // one batch
+            if (pre) { fl = fl0; ip = ip0; op = op0; err = err0; lev = lev0; idx = idx0; key = key0; }
+            else { fl = c.p_flag[slot]; ip = c.p_ip[slot]; op = c.p_op[slot]; err = c.p_err[slot]; lev = c.p_lev[slot]; idx = c.p_idx[slot]; key = c.p_key[slot]; }   // one batch
         }
         const bool work = in_pool && (fl & PF_ALIVE) && !(fl & PF_PEND);
         const bool by_table = use_ktab && nz_lds;
@@ -473,7 +477,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
                 vrg_add_correction(a, bb, d, ip, op);
                 c.p_ip[slot] = ip; c.p_op[slot] = op;
                 if (s.iter < s.iterMax)              // while iterNum <= iterMax (:58)
-                    vrg_decide_core(c, s, nin0, nout0, slot, fl & PF_INNER, ip, op, key, idx, lev);
+                    vrg_decide_core(c, s, nin0, nout0, slot, fl & PF_INNER, ip, op, key, idx, lev, (double)err);
             }
         }
     }
@@ -833,8 +837,8 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
         __syncthreads();
         if (st0) VRG_STAMP(c, 26);
         // the sweep's label bytes (+ class bits, region sizes; the change filed at the voxel's place of the marked list)
-        if (g < nmk) vrg_apply_at(c, g, mk0, old0, mn0);
-        for (uint32_t i = g + G; i < nmk; i += G) vrg_apply_at(c, i, c.mk_idx[i], c.mk_old[i], c.mk_new[i]);
+        if (g < nmk) vrg_apply_at(c, g, mk0, old0, mn0, s0.log_pos);
+        for (uint32_t i = g + G; i < nmk; i += G) vrg_apply_at(c, i, c.mk_idx[i], c.mk_old[i], c.mk_new[i], s0.log_pos);
         // the class changes of the sweep before go into this sweep's copy of the class bits
         if (g < nc) vrg_catchup_entry(c, cdw0, cx0);
         for (uint32_t i = g + G; i < nc; i += G) vrg_item_catchup(c, i);
@@ -1624,7 +1628,7 @@ __global__ void __launch_bounds__(GATE_THREADS) k_gate(VrgCtx c, int every, int 
         const int due = gate_dense_due(c) ? 1 : 0;
         const int64_t seq = c.dctl[VD_RSEQ] + 1;               // the pass this gate stands in front of
         int go = due;
-        if (due && every != 1 && vrg_dense_skipped(seq, every)) {
+        if (due && vrg_dense_skipped(seq, every, c.ver_n, c.ver_me)) {
             vrg_recount_done(c, vrg_dense_skip_marker());
             if (fin == 2) vrg_dense_fin_one(c, vrg_dense_skip_marker());
             go = 0;
@@ -1951,16 +1955,19 @@ void be_destroy(VrgBackend* b) {
     if (b->sb) (void)hipStreamSynchronize(b->sb);
     if (b->comm) { ncclCommDestroy(b->comm); b->comm = nullptr; }
     for (auto& p : b->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (int j = 0; j < 2; j++) if (b->mark[j]) (void)hipEventDestroy(b->mark[j]);
     if (b->tmp) (void)hipFree(b->tmp);
     if (b->keys2) (void)hipFree(b->keys2);
     if (b->sa) (void)hipStreamDestroy(b->sa);
     if (b->sb) (void)hipStreamDestroy(b->sb);
+    if (b->sc) { (void)hipStreamSynchronize(b->sc); (void)hipStreamDestroy(b->sc); }
     delete b;
 }
 void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     use_device(b);
     if (std::strcmp(name, "sweep_blocks") == 0 && v >= 0 && v <= 4096) b->sweep_blocks = (int)v;
     if (std::strcmp(name, "serial_streams") == 0) b->serial = v != 0;
+    if (std::strcmp(name, "repl") == 0) b->repl = v != 0;
     if (std::strcmp(name, "skip_excluded") == 0) b->skip = v != 0;
     if (std::strcmp(name, "nt_loads") == 0) b->nt_loads = v < 0 ? -1 : (v != 0);
     if (std::strcmp(name, "band_hint") == 0) b->band_hint = (uint32_t)std::min<long long>(std::max<long long>(v, 0), 0x7fffffff);
@@ -2176,6 +2183,7 @@ void be_init_sort(VrgBackend* b, const VrgCtx& c, uint32_t n_in, uint32_t n_out)
 
 // sum the slab statistics over the ranks: RCCL on the stream, or the host callback (synchronises)
 static void reduce_dense(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user, hipStream_t st) {
+    if (b->repl) return;                             // (every rank of a leader / follower group counts whole volumes: nothing to sum)
     if (b->comm) {
         ncclResult_t r = ncclAllReduce(c.dn_part, c.dn, 4, ncclDouble, ncclSum, b->comm, st);
         if (r != ncclSuccess && !b->err[0]) {        // sticky: the engine turns it into VRG_E_INTERNAL at its next synchronisation point
@@ -2405,10 +2413,10 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
 // device for another one could then wait for ever, so the host orders the two streams instead.)
 static void enqueue_dense(VrgBackend* b, const VrgCtx& c, hipEvent_t e_start, hipEvent_t e_stop, be_reduce_fn cb, void* user) {
     if (b->serial) HIP_CHECK(hipStreamSynchronize(b->sa));
-    const bool ranks = c.world > 1 || b->comm || cb;
+    const bool ranks = !b->repl && (c.world > 1 || b->comm || cb);
     if (b->dense_pipe && c.I && !c.lev16 && b->skip) {
         const int check = ranks ? 1 : 2;
-        k_gate<<<1, GATE_THREADS, 0, b->sb>>>(c, b->verify_every, check);
+        k_gate<<<1, GATE_THREADS, 0, b->sb>>>(c, b->verify_every, check);        // (also when every pass is counted: with several verifiers this handle counts its share)
         if (dense_nt(b, c)) hipExtLaunchKernelGGL((k_recount_pipe<3, true>), dim3(dense_blocks(b, c)), dim3(TPB), 0, b->sb, e_start, e_stop, 0, c, check);
         else hipExtLaunchKernelGGL((k_recount_pipe<3, false>), dim3(dense_blocks(b, c)), dim3(TPB), 0, b->sb, e_start, e_stop, 0, c, check);
     } else
@@ -2429,7 +2437,6 @@ void be_sweep_batch(VrgBackend* b, const VrgCtx& c, int flags, int n, VrgEvents*
 // after all and compared with the sizes kept by increments (collective on several ranks)
 void be_verify_last(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
     use_device(b);
-    if (b->verify_every == 1) return;
     launch_recount(c, dense_blocks(b, c), 3, b->sa, b->skip != 0, dense_nt(b, c));      // (check 3: no gate - launch_recount puts one in front of checks 1 and 2 only)
     reduce_dense(b, c, cb, user, b->sa);
     k_verify_last<<<1, 1, 0, b->sa>>>(c);
@@ -2438,9 +2445,79 @@ void be_verify_last(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
 
 void be_dense_flush(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
     use_device(b);
-    const bool ranks = c.world > 1 || b->comm || cb;
+    const bool ranks = !b->repl && (c.world > 1 || b->comm || cb);
     if (ranks && b->dense_pending) reduce_staged(b, c, cb, user);
 }
+
+// ---- leader / follower replication: the follower's side, and the transports -----------------------------------------------------
+__global__ void __launch_bounds__(TPB) k_follow_apply(VrgCtx c, const VrgLogRec* __restrict__ recs, VrgLogSweep hdr) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) vrg_follow_trace(c, hdr);
+    ITEM_LOOP(hdr.nrec) vrg_follow_apply_rec(c, recs[i], hdr.sweep);
+}
+__global__ void __launch_bounds__(GATE_THREADS) k_follow_gate(VrgCtx c) { ulist_refresh(c, false, 0); }
+__global__ void k_follow_check(VrgCtx c, VrgLogSweep hdr) { vrg_follow_check(c, *c.dn_part, hdr.sweep, hdr.n_in, hdr.n_out); }
+
+void be_follow_apply(VrgBackend* b, const VrgCtx& c, const VrgLogRec* recs, const VrgLogSweep* hdr) {
+    use_device(b);
+    const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>(ITEM_BLOCKS, (hdr->nrec + TPB - 1) / TPB));
+    k_follow_apply<<<blocks, TPB, 0, b->sa>>>(c, recs, *hdr);
+}
+void be_follow_verify(VrgBackend* b, const VrgCtx& c, const VrgLogSweep* hdr, VrgEvents* ev) {
+    use_device(b);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ev && ev->enabled > 0) {
+        if (b->ev_used == b->ev_pool.size())
+            for (int k = 0; k < 32; k++) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); n.trip = 0; n.kind = 0; n.ntrips = 1; b->ev_pool.push_back(n); }
+        EvPair& p = b->ev_pool[b->ev_used++];
+        p.trip = 0; p.kind = 0; p.ntrips = 1; e0 = p.a; e1 = p.b;
+    }
+    k_follow_gate<<<1, GATE_THREADS, 0, b->sa>>>(c);            // the units the applied sweeps listed join the list the pass walks
+    // the very pass a single GPU runs for this sweep (same kernel, same workgroups, same unit list: the same sums bit for bit), its totals into dn_part
+    if (b->dense_pipe && c.I && !c.lev16 && b->skip) {
+        if (dense_nt(b, c)) hipExtLaunchKernelGGL((k_recount_pipe<3, true>), dim3(dense_blocks(b, c)), dim3(TPB), 0, b->sa, e0, e1, 0, c, 3);
+        else hipExtLaunchKernelGGL((k_recount_pipe<3, false>), dim3(dense_blocks(b, c)), dim3(TPB), 0, b->sa, e0, e1, 0, c, 3);
+    } else launch_recount(c, dense_blocks(b, c), 3, b->sa, b->skip != 0, dense_nt(b, c), e0, e1);
+    k_follow_check<<<1, 1, 0, b->sa>>>(c, *hdr);
+}
+void be_follow_mark(VrgBackend* b, int slot) {
+    use_device(b);
+    if (!b->mark[slot]) HIP_CHECK(hipEventCreateWithFlags(&b->mark[slot], hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(b->mark[slot], b->sa));
+}
+void be_follow_wait(VrgBackend* b, int slot) { use_device(b); if (b->mark[slot]) HIP_CHECK(hipEventSynchronize(b->mark[slot])); }
+static hipStream_t repl_stream(VrgBackend* b) {
+    if (!b->sc) HIP_CHECK(hipStreamCreateWithFlags(&b->sc, hipStreamNonBlocking));
+    return b->sc;
+}
+int be_repl_bcast(VrgBackend* b, void* dev_buf, size_t bytes, int root) {
+    use_device(b);
+    if (!b->comm) return -1;
+    const ncclResult_t r = ncclBroadcast(dev_buf, dev_buf, bytes, ncclChar, root, b->comm, repl_stream(b));
+    if (r != ncclSuccess) { if (!b->err[0]) std::snprintf(b->err, sizeof(b->err), "RCCL broadcast of the change log failed: %s", ncclGetErrorString(r)); return -1; }
+    return 0;
+}
+int be_repl_allsum(VrgBackend* b, double* dev_buf, size_t n) {
+    use_device(b);
+    if (!b->comm) return -1;
+    const ncclResult_t r = ncclAllReduce(dev_buf, dev_buf, n, ncclDouble, ncclSum, b->comm, repl_stream(b));
+    if (r != ncclSuccess) { if (!b->err[0]) std::snprintf(b->err, sizeof(b->err), "RCCL all-reduce of the trace sums failed: %s", ncclGetErrorString(r)); return -1; }
+    return 0;
+}
+void be_repl_wait(VrgBackend* b) { use_device(b); if (b->sc) HIP_CHECK(hipStreamSynchronize(b->sc)); }
+int be_ipc_export(VrgBackend* b, void* dev_ptr, void* handle64) {
+    use_device(b);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "ipc handle size");
+    if (hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, dev_ptr) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return 0;
+}
+void* be_ipc_open(VrgBackend* b, const void* handle64) {
+    use_device(b);
+    hipIpcMemHandle_t h; std::memcpy(&h, handle64, sizeof(h));
+    void* p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void be_ipc_close(VrgBackend* b, void* mapped) { use_device(b); if (mapped && hipIpcCloseMemHandle(mapped) != hipSuccess) (void)hipGetLastError(); }
 
 void be_events_collect(VrgBackend* b, VrgEvents* ev, long long n_valid) {
     if (!ev) return;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vrg.h"
@@ -20,8 +21,26 @@
 #define VRG_CAT(a, b) VRG_CAT2(a, b)
 #define API(name) VRG_CAT(VRG_API_PREFIX, name)
 
+// leader / follower replication (vrg_repl.h)
+struct VrgRepl {
+    int nranks = 0, rank = 0, leader_verifies = 1;      // nranks 0: off
+    int transport = 0;                                  // TR_*
+    vrg_bcast_fn bcast = nullptr; vrg_allsum_fn allsum = nullptr; void* user = nullptr;
+    uint32_t cap = 1u << 20, swcap = 258;               // records / sweep headers a batch buffer holds
+    uint8_t* buf[2] = {nullptr, nullptr};               // leader: the two batch buffers it fills in turn; follower: its two staging buffers
+    size_t buf_bytes = 0;
+    uint64_t seq = 0;                                   // batches published (leader) / taken (follower) since the handle was created
+    std::vector<uint8_t> host;                          // callback transport: host copy of a batch
+    uint8_t* ctl = nullptr;                             // ipc transport: the leader's control block (its own allocation on the leader, mapped on a follower)
+    uint8_t* peer_buf[2] = {nullptr, nullptr};          // ... and, on a follower, the leader's two batch buffers, mapped
+    bool ctl_mapped = false;
+    uint64_t sum_round = 0;
+    long long batches = 0, records = 0, sweeps = 0, verified = 0, last_verified = 0;   // diagnostics
+};
+
 struct vrg_handle {
     VrgCtx c;
+    VrgRepl repl;
     VrgBackend* be = nullptr;
     std::string err;
     std::vector<void*> owned;
@@ -46,7 +65,7 @@ struct vrg_handle {
     uint8_t* lab_base[2] = {nullptr, nullptr};
     vrg_reduce_fn reduce_fn = nullptr;
     void* reduce_user = nullptr;
-    long long bails[5] = {0, 0, 0, 0, 0};   // how often a trip came back, by VBAIL_* reason
+    long long bails[6] = {0, 0, 0, 0, 0, 0};   // how often a trip came back, by VBAIL_* reason
     long long fused_trips = 0;
     long long sync_trips = 0;
 };
@@ -112,6 +131,9 @@ int check_state_error(vrg_handle* h, const VrgState& s) {
     if (s.error == 1) return fail(h, VRG_E_CAPACITY, "band pool capacity exceeded");
     if (s.error == 2) return fail(h, VRG_E_CAPACITY, "flip list capacity exceeded");
     if (s.error == 4 || s.error == 7) return fail(h, VRG_E_CAPACITY, "marked-voxel list capacity exceeded");
+    if (s.error == 11) return fail(h, VRG_E_CAPACITY, "change log capacity exceeded");
+    if (s.error == 12) return fail(h, VRG_E_INTERNAL, "replication: a rank's labels have drifted from the leader's change log (code 12)");
+    if (s.error == 13) return fail(h, VRG_E_INTERNAL, "replication: another rank of the group failed (code 13)");
     if (s.error) return fail(h, VRG_E_INTERNAL, "internal consistency check failed (code " + std::to_string(s.error) + ")");
     return VRG_OK;
 }
@@ -122,7 +144,7 @@ bool size_pool(vrg_handle* h, uint64_t want, uint32_t keep, uint32_t keep_free) 
     VrgCtx& c = h->c;
     uint64_t cap = pow2_at_least(std::max<uint64_t>(want, h->cap_floor));
     if (cap > 0x80000000ull) return false;
-    bool ok = grow(h, c.p_idx, keep, cap) && grow(h, c.p_lev, keep, cap) && grow(h, c.p_ip, keep, cap) && grow(h, c.p_op, keep, cap) &&
+    bool ok = grow(h, c.p_idx, keep, cap) && grow(h, c.p_lev, keep, cap) && grow(h, c.p_ip, keep, cap) && grow(h, c.p_op, keep, cap) && grow(h, c.p_err, keep, cap) &&
               grow(h, c.p_key, keep, cap) && grow(h, c.p_flag, keep, cap) && grow(h, c.freel, keep_free, cap) &&
               grow(h, c.flist, 0, cap) && grow(h, c.f_key, 0, cap) && grow(h, c.fr_idx, 0, cap) && grow(h, c.fr_lev, 0, cap) && grow(h, c.f_slot, 0, cap) && grow(h, c.f_idx, 0, cap) && grow(h, c.f_lev, 0, cap) &&
               grow(h, c.f_res, 0, cap) && grow(h, c.pend, 0, cap) && grow(h, c.fresh, keep, cap) &&
@@ -143,6 +165,45 @@ bool size_marks(vrg_handle* h, uint64_t want, bool keep) {
     if (!ok) return false;
     c.mcap = (uint32_t)cap;
     return true;
+}
+
+#include "vrg_repl.h"
+
+// vrg_run on a follower: take the leader's batches until the one that ends the run; then the collective finish
+int run_follower(vrg_handle* h, const VrgState& s0, vrg_result* out) {
+    const VrgCtx& c = h->c;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const double ms0 = h->ev.ms_total; const long long l0 = h->ev.launches;
+    VrgLogBatch last; std::memset(&last, 0, sizeof(last));
+    int rc = repl_follow(h, last);
+    if (rc) return rc;
+    be_sync(h->be);
+    be_events_collect(h->be, &h->ev, 1ll << 60);
+    // the state a leader's run would have left: what the results (trace length, `segmented`, sizes) are read from
+    VrgState s = get_state(h);
+    s.iter = last.iter; s.done = last.stop_reason; s.ni = last.ni; s.no = last.no; s.ties = last.ties; s.near_ties = last.near_ties;
+    s.ties_filed = s.ties; s.near_filed = s.near_ties; s.error = last.error;
+    put_state(h, s);
+    int64_t sizes[2] = {last.n_in, last.n_out};
+    be_upload(h->be, c.inc, sizes, sizeof(sizes));
+    const int64_t k = last.iter;
+    be_upload(h->be, c.dctl + VD_SEQ, &k, 8); be_upload(h->be, c.dctl + VD_RSEQ, &k, 8); be_upload(h->be, c.gate + VG_REQ, &k, 8);
+    int32_t error = last.error;
+    rc = repl_finish(h, s0.iter, last.iter, last.n_in, last.n_out, error);
+    if (rc) return rc;
+    if (error != s.error) { s.error = error; put_state(h, s); }
+    rc = check_state_error(h, s);
+    if (rc) return rc;
+    if (out) {
+        std::memset(out, 0, sizeof(*out));
+        out->stop_reason = last.stop_reason; out->iter_num = last.iter + 1; out->sweeps = last.iter - s0.iter;
+        out->nseg = last.n_in; out->n_in = last.n_in; out->n_out = last.n_out; out->ni = last.ni; out->no = last.no;
+        if (last.iter > s0.iter) { VrgTrace t; be_download(h->be, &t, c.trace + last.iter, sizeof(t)); out->sum_in = t.sum_in; out->sum_out = t.sum_out; }
+        out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        out->sweep_kernel_ms = h->ev.ms_total - ms0; out->sweep_launches = h->ev.launches - l0;
+        out->ties = (int64_t)(uint32_t)(last.ties - s0.ties); out->near_ties = (int64_t)(uint32_t)(last.near_ties - s0.near_ties);
+    }
+    return VRG_OK;
 }
 
 }  // namespace
@@ -194,7 +255,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.st_sin = alloc<double>(h, c.nstat); c.st_sout = alloc<double>(h, c.nstat);
     c.trace_cap = 1u << 16;
     c.trace = alloc<VrgTrace>(h, c.trace_cap);
-    c.world = 1;
+    c.world = 1; c.ver_n = 1; c.ver_me = 0;
     if (!c.lab[0] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.gate || !c.dn_ring || !c.exp_ring || !c.stage_in || !c.stage_out || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
         !c.nchg || !c.ubits || !c.unew[0] || !c.unew[1] || !c.ulist || !c.uctl || !c.vent || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace) { API(destroy)(h); return VRG_E_MEM; }
     be_fill(be, c.inc, 0, 32 * sizeof(int64_t)); be_fill(be, c.dctl, 0, 32 * sizeof(int64_t)); be_fill(be, c.gate, 0, 32 * sizeof(int64_t));
@@ -215,6 +276,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
 void API(destroy)(vrg_handle* h) {
     if (!h) return;
     be_sync(h->be);
+    if (h->repl.ctl_mapped) { be_ipc_close(h->be, h->repl.ctl); be_ipc_close(h->be, h->repl.peer_buf[0]); be_ipc_close(h->be, h->repl.peer_buf[1]); }
     for (void* p : h->owned) be_free(h->be, p);
     be_destroy(h->be);
     delete h;
@@ -237,6 +299,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "verify_every") { if (value < 0) return fail(h, VRG_E_ARG, "verify_every: 0 (never), 1 (every sweep: the default) or n > 1 (every n-th sweep)"); h->verify_every = (int)std::min<int64_t>(value, 1 << 20); be_set_tuning(h->be, name, value); }
     else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "fuse_max" || n == "memo_above" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads" || n == "dense_pipe") be_set_tuning(h->be, name, value);
     else if (n == "storage16") h->storage16 = value != 0;      // takes effect at the next vrg_init
+    else if (n == "log_capacity") { if (h->repl.buf[0] || value < 1024 || value > 0x20000000ll) return fail(h, VRG_E_STATE, "log_capacity: 1024 .. 2^29 records, before the first vrg_run of a replicated handle"); h->repl.cap = (uint32_t)value; }
     else return fail(h, VRG_E_ARG, "unknown option " + n);
     return VRG_OK;
 }
@@ -414,6 +477,14 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     VrgState s = get_state(h);
     int rc = check_state_error(h, s);
     if (rc) return rc;
+    VrgRepl& rp = h->repl;
+    const bool replicated = rp.nranks > 0;
+    if (replicated) {
+        if (rp.transport == TR_NONE && rp.nranks > 1) return fail(h, VRG_E_STATE, "vrg_run: replicated handle without a transport (vrg_repl_set_callbacks / vrg_repl_use_rccl / vrg_repl_ipc_*)");
+        if (h->variant & 1) return fail(h, VRG_E_STATE, "vrg_run: the full-stencil check variant keeps no change log");
+        if (!rp.buf[0] && !repl_alloc_buffers(h, rp.cap)) return fail(h, VRG_E_MEM, "vrg_run: change log buffers");
+        if (rp.rank > 0) return run_follower(h, s, out);
+    }
     int32_t iter0 = s.iter;
     const uint32_t ties0 = s.ties, near0 = s.near_ties;
     s.done = 0; s.time_up = 0; s.bail = 0; s.iterMax = (int32_t)iterMax; s.maxSegmentSize = maxSegmentSize;
@@ -422,7 +493,9 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     double ms0 = h->ev.ms_total; long long l0 = h->ev.launches;
     double cms0 = h->ev.chain_ms_total; long long cl0 = h->ev.chain_launches;
     auto t_begin = std::chrono::steady_clock::now();
-    const int base_flags = ((h->variant & 1) ? VRG_SWEEP_FULL : 0) | (h->dense_off ? VRG_SWEEP_NODENSE : 0);
+    const bool no_dense = h->dense_off || (replicated && !rp.leader_verifies);      // (a leader that counts nothing enqueues no dense pass at all)
+    c.dense_none = (replicated && !rp.leader_verifies) ? 1 : 0;
+    const int base_flags = ((h->variant & 1) ? VRG_SWEEP_FULL : 0) | (no_dense ? VRG_SWEEP_NODENSE : 0);
     const uint32_t small = be_small_flip_limit(be), fuse_max = be_fuse_limit(be, c);
     const bool can_fuse = h->fused && !(base_flags & VRG_SWEEP_FULL) && be_fuse_ok(be, c);
     // (a run starts fused when the sweep before - if any - had few flips; the switch is made with the streams idle)
@@ -433,6 +506,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
         const bool fuse = h->fuse_mode && !sync;
         int64_t remaining = iterMax - s.iter;
         int nb = sync ? 1 : (int)std::min<int64_t>(h->batch, std::max<int64_t>(remaining, 0) + 1);   // +1: the trip that sets the stop flag
+        if (replicated) { nb = std::min<int>(nb, (int)rp.swcap - 2); rc = repl_open_batch(h, s); if (rc) return rc; }   // (the batch's change log: one buffer)
         if (maxSeconds >= 0 && s.iter < iterMax) {   // wall-clock cap (:97): tested after the no-flip test, before update()
             double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->t0).count();
             if (el >= maxSeconds) { s.time_up = 1; put_state(h, s); nb = 1; }
@@ -443,10 +517,11 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
         if (fuse) h->fused_trips += nb;
         s = get_state(h);
         be_events_collect(be, &h->ev, s.iter - before);
+        if (replicated) { rc = repl_publish(h, s, s.done || s.error); if (rc) return rc; }     // (the followers apply it and count their sweeps meanwhile)
         if (s.done || s.error) break;
         if (s.bail) {                                // the trip was handed back untouched: make room / change mode, do it again
             const uint64_t nf = s.nf;
-            h->bails[std::min(s.bail, 4)]++;
+            h->bails[std::min(s.bail, 5)]++;
             // The rest of the batch was enqueued behind the trip that came back: its k_gate + recount pairs may still sit
             // in the dense stream.  They have to run out while the device's stop word (gate[VG_STOP]) is still set -
             // put_state below clears it; a leftover gate would then wait for the NEXT sweep's request and shift which
@@ -454,6 +529,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
             be_sync(be);
             if (s.bail == VBAIL_FLIPS) h->sync_mode = true;
             else if (s.bail == VBAIL_FUSE) h->fuse_mode = false;
+            else if (s.bail == VBAIL_LOG) { rc = repl_log_full(h, s); if (rc) return rc; }
             else if (s.bail == VBAIL_MARKS) {
                 if (nf * 125u > 0x3fffffffull || !size_marks(h, 2 * nf * 125u, true)) return fail(h, VRG_E_MEM, "vrg_run: marked-voxel arrays");
             } else {
@@ -471,16 +547,22 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
             get_state(h);                                // (k_band's grid is sized for corrections evaluated entry by entry)
         }
     }
-    if (!h->dense_off) be_dense_flush(be, c, h->reduce_fn, h->reduce_user);   // Z-slabs: close the passes still waiting for their all-reduce
+    if (!no_dense) be_dense_flush(be, c, h->reduce_fn, h->reduce_user);   // Z-slabs: close the passes still waiting for their all-reduce
     be_sync(be);
     // passes were left out (option verify_every): the run's last sweep is counted after all, so that the sizes kept by
     // increments never leave a run unchecked
-    if (!h->dense_off && h->verify_every != 1 && s.iter > iter0 && !s.error) be_verify_last(be, c, h->reduce_fn, h->reduce_user);
+    if (!replicated && !h->dense_off && h->verify_every != 1 && s.iter > iter0 && !s.error) be_verify_last(be, c, h->reduce_fn, h->reduce_user);
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     int64_t dense_err = 0;                           // raised by the dense stream, possibly after the band side stopped
     be_download(be, &dense_err, c.dctl + VD_ERR, sizeof(dense_err));
     if (h->dense_off) { dense_err = 0; h->inited = false; }   // the dense pass sequence is broken on purpose: init again
     if (dense_err) s.error = (int32_t)dense_err;
+    if (replicated) {                                // the sums the verifiers filed, every rank's status (collective)
+        int64_t sizes[2]; be_download(be, sizes, c.inc, sizeof(sizes));
+        rc = repl_finish(h, iter0, s.iter, sizes[0], sizes[1], s.error);
+        if (rc) return rc;
+        secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    }
     rc = check_state_error(h, s);
     if (rc) return rc;
     if (out) {
@@ -488,6 +570,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
         VrgDense d = get_dense(h);
         out->nseg = (int64_t)d.n_in; out->n_in = (int64_t)d.n_in; out->n_out = (int64_t)d.n_out; out->ni = s.ni; out->no = s.no;
         out->sum_in = d.sum_in; out->sum_out = d.sum_out; out->seconds = secs;
+        if (replicated && s.iter > iter0) { VrgTrace t; be_download(be, &t, c.trace + s.iter, sizeof(t)); out->sum_in = t.sum_in; out->sum_out = t.sum_out; }
         out->sweep_kernel_ms = h->ev.ms_total - ms0; out->sweep_launches = h->ev.launches - l0;
         out->chain_kernel_ms = h->ev.chain_ms_total - cms0; out->chain_launches = h->ev.chain_launches - cl0;
         out->ties = (int64_t)(uint32_t)(s.ties - ties0); out->near_ties = (int64_t)(uint32_t)(s.near_ties - near0);
@@ -639,6 +722,90 @@ int API(comm_init)(vrg_handle* h, int nranks, int rank, const void* id128) {
         return fail(h, VRG_E_INTERNAL, msg);
     }
     h->c.world = nranks;
+    return VRG_OK;
+}
+
+int API(repl_init)(vrg_handle* h, int nranks, int rank, int leader_verifies) {
+    if (!h || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks) return fail(h, VRG_E_ARG, "repl_init: need 1 <= nranks <= 64, 0 <= rank < nranks");
+    if (h->inited) return fail(h, VRG_E_STATE, "repl_init: call before vrg_init");
+    if (h->reduce_fn || h->c.world > 1) return fail(h, VRG_E_STATE, "repl_init: the handle is already a Z-slab rank");
+    VrgRepl& r = h->repl;
+    r.nranks = nranks; r.rank = rank; r.leader_verifies = (leader_verifies || nranks == 1) ? 1 : 0;
+    if (nranks == 1 && !leader_verifies) r.leader_verifies = 0;      // (measurement aid: a leader alone that counts nothing; its last sweep is still counted when a run ends)
+    h->c.ver_n = std::max(1, repl_verifiers(r));
+    h->c.ver_me = rank == 0 ? (r.leader_verifies ? 0 : -1) : -1;     // (a follower's own dense stream stays idle: it counts in its apply stream)
+    be_set_tuning(h->be, "repl", 1);
+    return VRG_OK;
+}
+
+int API(repl_set_callbacks)(vrg_handle* h, vrg_bcast_fn bcast, vrg_allsum_fn allsum, void* user) {
+    if (!h || !bcast || !allsum) return fail(h, VRG_E_ARG, "repl_set_callbacks: both callbacks are needed");
+    if (!h->repl.nranks) return fail(h, VRG_E_STATE, "repl_set_callbacks: vrg_repl_init first");
+    h->repl.bcast = bcast; h->repl.allsum = allsum; h->repl.user = user; h->repl.transport = TR_CALLBACK;
+    return VRG_OK;
+}
+
+int API(repl_use_rccl)(vrg_handle* h) {
+    if (!h) return VRG_E_ARG;
+    if (!h->repl.nranks) return fail(h, VRG_E_STATE, "repl_use_rccl: vrg_repl_init first");
+    double probe = 0.0;                               // (is there a communicator?  a one-word all-reduce says so - collective like everything here)
+    double* d = alloc<double>(h, 1);
+    if (!d) return fail(h, VRG_E_MEM, "repl_use_rccl");
+    be_upload(h->be, d, &probe, 8);
+    const int rc = be_repl_allsum(h->be, d, 1);
+    be_repl_wait(h->be);
+    release(h, d);
+    if (rc) { be_clear_error(h->be); return fail(h, VRG_E_STATE, "repl_use_rccl: no RCCL communicator (vrg_comm_init first)"); }
+    h->c.world = 1;                                   // (vrg_comm_init marks the handle as a Z-slab rank: it is not - every rank counts whole volumes)
+    h->repl.transport = TR_RCCL;
+    return VRG_OK;
+}
+
+// blob: [ctl handle 64][buf0 handle 64][buf1 handle 64][cap u32][swcap u32]
+int API(repl_ipc_export)(vrg_handle* h, void* blob, int64_t cap, int64_t* bytes) {
+    if (!h || !blob || !bytes || cap < 256) return fail(h, VRG_E_ARG, "repl_ipc_export: need a blob of at least 256 bytes");
+    VrgRepl& r = h->repl;
+    if (!r.nranks || r.rank != 0) return fail(h, VRG_E_STATE, "repl_ipc_export: the leader (rank 0) of a replicated handle exports");
+    if (!r.buf[0] && !repl_alloc_buffers(h, r.cap)) return fail(h, VRG_E_MEM, "repl_ipc_export: change log buffers");
+    if (!r.ctl) {
+        const size_t cb = 8 * IPC_WORDS + (size_t)r.nranks * IPC_SUMCAP * 8;
+        r.ctl = alloc<uint8_t>(h, cb);
+        if (!r.ctl) return fail(h, VRG_E_MEM, "repl_ipc_export: control block");
+        be_fill(h->be, r.ctl, 0, cb);
+        be_sync(h->be);
+    }
+    uint8_t* o = (uint8_t*)blob;
+    std::memset(o, 0, 256);
+    if (be_ipc_export(h->be, r.ctl, o) || be_ipc_export(h->be, r.buf[0], o + 64) || be_ipc_export(h->be, r.buf[1], o + 128))
+        return fail(h, VRG_E_INTERNAL, "repl_ipc_export: hipIpcGetMemHandle failed");
+    std::memcpy(o + 192, &r.cap, 4); std::memcpy(o + 196, &r.swcap, 4);
+    *bytes = 256;
+    r.transport = TR_IPC;
+    return VRG_OK;
+}
+
+int API(repl_ipc_import)(vrg_handle* h, const void* blob, int64_t bytes) {
+    if (!h || !blob || bytes < 256) return fail(h, VRG_E_ARG, "repl_ipc_import: the leader's 256-byte blob");
+    VrgRepl& r = h->repl;
+    if (!r.nranks || r.rank == 0) return fail(h, VRG_E_STATE, "repl_ipc_import: a follower (rank > 0) of a replicated handle imports");
+    if (r.ctl_mapped) return fail(h, VRG_E_STATE, "repl_ipc_import: already mapped");
+    const uint8_t* o = (const uint8_t*)blob;
+    uint32_t cap = 0, swcap = 0; std::memcpy(&cap, o + 192, 4); std::memcpy(&swcap, o + 196, 4);
+    if (swcap != r.swcap) return fail(h, VRG_E_ARG, "repl_ipc_import: the leader's log layout differs from this library's");
+    r.ctl = (uint8_t*)be_ipc_open(h->be, o);
+    r.peer_buf[0] = (uint8_t*)be_ipc_open(h->be, o + 64); r.peer_buf[1] = (uint8_t*)be_ipc_open(h->be, o + 128);
+    if (!r.ctl || !r.peer_buf[0] || !r.peer_buf[1]) return fail(h, VRG_E_INTERNAL, "repl_ipc_import: hipIpcOpenMemHandle failed");
+    r.ctl_mapped = true;
+    if (cap != r.cap) { if (r.buf[0]) return fail(h, VRG_E_STATE, "repl_ipc_import: staging buffers already sized"); r.cap = cap; }
+    r.transport = TR_IPC;
+    return VRG_OK;
+}
+
+int API(repl_stats)(vrg_handle* h, int64_t* out, int64_t cap) {
+    if (!h || !out || cap < 8) return VRG_E_ARG;
+    const VrgRepl& r = h->repl;
+    out[0] = r.batches; out[1] = r.records; out[2] = r.sweeps; out[3] = r.verified; out[4] = r.last_verified; out[5] = r.transport;
+    out[6] = r.nranks ? repl_verifiers(r) : 0; out[7] = r.nranks ? repl_my_slot(r) : 0;
     return VRG_OK;
 }
 

@@ -265,14 +265,16 @@ VRG_HD void vrg_add_correction(double ic, double oc, double ac, double& ip, doub
 }
 // A flip is listed by an unordered append of its record (slot, sort key, voxel, level); k_order orders the list.
 // n_in / n_out: the region sizes (VrgCtx::inc), read once per thread by the caller
+// err: bound on the absolute error of ip and of op (binned exact densities, VrgCtx::p_err; 0 without bins)
 VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, int64_t n_in, int64_t n_out, uint32_t slot, bool inner, double ip, double op,
-                            uint64_t key, uint32_t idx, uint32_t lev) {
+                            uint64_t key, uint32_t idx, uint32_t lev, double err = 0.0) {
     double inN = ip / (double)n_in;                       // :81
     double outN = op / (double)n_out;                     // :82
     bool ge = inN >= outN;
-    {   // a decision at rounding level is the reference's summation order's to make, not ours: count it (VRG_TIE_REL)
+    {   // a decision at rounding level is the reference's summation order's to make, not ours: count it (VRG_TIE_REL) - and so is
+        // one the error of a binned evaluation could turn
         const double d = fabs(inN - outN), m = fmax(fabs(inN), fabs(outN));
-        if (n_in == 0 || n_out == 0 || !(d > VRG_TIE_REL * m)) vrg_atomic_add(&c.stg->ties, 1u);
+        if (n_in == 0 || n_out == 0 || !(d > VRG_TIE_REL * m + (err / (double)n_in + err / (double)n_out))) vrg_atomic_add(&c.stg->ties, 1u);
         else if (!(d > VRG_TIE_NEAR_REL * m)) vrg_atomic_add(&c.stg->near_ties, 1u);
     }
     if (inner == ge) return;                              // :87 xor(segmentedMap, inner >= outer)
@@ -285,7 +287,7 @@ VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, int64_t n_in, in
 // device), tab = the per-level memo (the device may pass an LDS copy of its first tab_n levels; the rest comes from c.tabC)
 VRG_HD void vrg_item_band_fields(const VrgCtx& c, const VrgState& s, uint32_t slot, uint8_t fl, double ip, double op, uint32_t lev, uint32_t idx,
                                  uint64_t key, int64_t n_in, int64_t n_out, const double* nz_val, const uint32_t* nz_cin,
-                                 const uint32_t* nz_cout, const uint32_t* nz_cconv, const double* tab, uint32_t tab_n) {
+                                 const uint32_t* nz_cout, const uint32_t* nz_cconv, const double* tab, uint32_t tab_n, double err = 0.0) {
     if (!(fl & PF_ALIVE)) return;
     // an entry that (re-)entered the band in the sweep before takes no correction; it is decided by whoever computes
     // its exact densities (the other half of this launch, which reads only the list bit of the flag)
@@ -300,7 +302,7 @@ VRG_HD void vrg_item_band_fields(const VrgCtx& c, const VrgState& s, uint32_t sl
         vrg_add_correction(ic, oc, ac, ip, op);
         c.p_ip[slot] = ip; c.p_op[slot] = op;
     }
-    if (s.iter < s.iterMax) vrg_decide_core(c, s, n_in, n_out, slot, fl & PF_INNER, ip, op, key, idx, lev);   // while iterNum <= iterMax (:58)
+    if (s.iter < s.iterMax) vrg_decide_core(c, s, n_in, n_out, slot, fl & PF_INNER, ip, op, key, idx, lev, err);   // while iterNum <= iterMax (:58)
 }
 VRG_HD void vrg_item_band(const VrgCtx& c, const VrgState& s, uint32_t slot, const double* nz_val, const uint32_t* nz_cin,
                           const uint32_t* nz_cout, const uint32_t* nz_cconv, const double* tab = nullptr, uint32_t tab_n = 0) {
@@ -310,7 +312,8 @@ VRG_HD void vrg_item_band(const VrgCtx& c, const VrgState& s, uint32_t slot, con
     const uint32_t lev = c.p_lev[slot], idx = c.p_idx[slot];
     const uint64_t key = c.p_key[slot];
     const int64_t n_in = c.inc[VC_NIN], n_out = c.inc[VC_NOUT];
-    vrg_item_band_fields(c, s, slot, fl, ip, op, lev, idx, key, n_in, n_out, nz_val, nz_cin, nz_cout, nz_cconv, tab, tab_n);
+    const double err = (double)c.p_err[slot];
+    vrg_item_band_fields(c, s, slot, fl, ip, op, lev, idx, key, n_in, n_out, nz_val, nz_cin, nz_cout, nz_cconv, tab, tab_n, err);
 }
 // ------------------------------------------------------------------ binned exact densities (large level tables)
 // The exact densities of an entry that (re-)enters the band (:252-255) are sums over the whole inner / outer regions:
@@ -375,6 +378,12 @@ VRG_HD void vrg_hist_change(const VrgCtx& c, uint32_t lev, int din, int dout) {
     if (dout) vrg_atomic_add(&c.hout[lev], dout);
     if (c.nb) vrg_bin_add(c, c.lev[lev], din, dout);
 }
+// what an exact evaluation leaves in VrgCtx::p_err: nothing without bins (sums over the levels: rounding only), the proved bound with them
+VRG_HD float vrg_exact_err(const VrgCtx& c, double si, double so) {
+    if (!c.nb) return 0.0f;
+    const float e = (float)(VRG_BIN_REL_ERR * fmax(si, so));
+    return e * 1.000001f + 1e-37f;                          // (the float rounding goes up)
+}
 // exact densities over the whole inner / outer regions (:152-155, :252-255), regrouped by level - or, with bins, by bin
 VRG_HD void vrg_exact_serial(const VrgCtx& c, const VrgState& s, uint32_t slot, bool then_decide) {
     double v = c.lev[c.p_lev[slot]];
@@ -389,9 +398,10 @@ VRG_HD void vrg_exact_serial(const VrgCtx& c, const VrgState& s, uint32_t slot, 
         double k = vrg_kern(c, c.lev[l] - v);
         si += (double)a * k; so += (double)b * k;
     }
-    c.p_ip[slot] = si; c.p_op[slot] = so;
+    const float err = vrg_exact_err(c, si, so);
+    c.p_ip[slot] = si; c.p_op[slot] = so; c.p_err[slot] = err;
     if (then_decide && s.iter < s.iterMax)
-        vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot]);
+        vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot], (double)err);
 }
 
 // ------------------------------------------------------------------ the sweep (update(), :156-259)
@@ -409,6 +419,7 @@ VRG_HD int32_t vrg_capacity_test(const VrgCtx& c, uint64_t nf) {
     const VrgState& s = *c.st;
     if (nf * 125u > (uint64_t)c.mcap) return VBAIL_MARKS;                // 5x5x5 marks per flip, as many class changes at most
     if ((uint64_t)s.np + nf * 27u > (uint64_t)c.bcap) return VBAIL_POOL; // a flip promotes at most its 26 neighbours
+    if (c.log_rec && (uint64_t)(s.log_pos - c.log_pos0) + nf * 125u > (uint64_t)c.log_cap) return VBAIL_LOG;   // the sweep's records (one per place of its marked list)
     return 0;
 }
 // the trip stops (or is handed back): nothing pending for the next k_band
@@ -530,7 +541,7 @@ VRG_HD void vrg_ev_write(const VrgCtx& c, uint32_t idx, const VrgEvent& e, uint3
     if (e.kind == VE_NEW) {                               // a voxel enters the band (newInnerBndList / newOuterBndList, :196, :213)
         slot = q < s.nfree ? c.freel[s.nfree - 1u - q] : s.np + (q - s.nfree);
         if (slot >= c.bcap) { c.stg->error = 1; return; }
-        c.p_idx[slot] = idx; c.p_lev[slot] = e.lev; c.p_ip[slot] = 0; c.p_op[slot] = 0; c.p_key[slot] = e.key;
+        c.p_idx[slot] = idx; c.p_lev[slot] = e.lev; c.p_ip[slot] = 0; c.p_op[slot] = 0; c.p_err[slot] = 0; c.p_key[slot] = e.key;
         c.p_flag[slot] = (uint8_t)(PF_ALIVE | PF_PEND | (e.to_inner ? PF_INNER : 0));
         c.vent[idx] = slot;
     } else if (e.kind == VE_DIE) {                        // ... leaves it (list.remove, :171-172, :188, :199, :226)
@@ -718,6 +729,16 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
     return vrg_sweep_core_pre(c, lab, idx, cb, pre, ev);
 }
 
+// ---- the change log (leader / follower replication, vrg_types.h VrgLogRec): written where a label byte is written
+// place i of the sweep being applied (its records start at log position `base` = VrgState::log_pos when the apply began)
+VRG_HD void vrg_log_record(const VrgCtx& c, uint32_t base, uint32_t i, uint32_t idx, uint8_t old, uint8_t nw) {
+    if (!c.log_rec) return;
+    const uint32_t q = base - c.log_pos0 + i;
+    if (q >= c.log_cap) { vrg_store_i32(&c.stg->error, 11); return; }
+    VrgLogRec r; r.idx = idx; r.rank = 0; r.old = (uint8_t)(old & (VB_LABEL | VB_OOB)); r.nw = (uint8_t)(nw & (VB_LABEL | VB_OOB)); r.pad = 0; r.pad2 = 0;
+    if (idx != VRG_NONE && (nw & VB_S) && !(old & VB_S)) r.rank = (uint32_t)c.stamp[idx];      // an applied flip-in: its rank (stamped when the flips were ordered)
+    c.log_rec[q] = r;
+}
 // sparse relabel, phase 1: new byte of every marked voxel from the OLD labels
 VRG_HD void vrg_item_relabel(const VrgCtx& c, uint32_t i) {
     const uint32_t idx = c.mk_idx[i];
@@ -795,10 +816,13 @@ VRG_HD void vrg_apply_voxel(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t 
 }
 VRG_HD void vrg_item_apply(const VrgCtx& c, uint32_t i) {
     const uint32_t idx = c.mk_idx[i];
-    vrg_apply_voxel(c, idx, vrg_load_coherent(c.lab[0] + idx), c.mk_new[i]);
+    const uint8_t old = vrg_load_coherent(c.lab[0] + idx), nw = c.mk_new[i];
+    vrg_log_record(c, c.st->log_pos, i, idx, old, nw);
+    vrg_apply_voxel(c, idx, old, nw);
 }
 // ... with the class change filed at place i of the change list (see vrg_count_change_at)
-VRG_HD void vrg_apply_at(const VrgCtx& c, uint32_t i, uint32_t idx, uint8_t old, uint8_t nw) {
+VRG_HD void vrg_apply_at(const VrgCtx& c, uint32_t i, uint32_t idx, uint8_t old, uint8_t nw, uint32_t log_base) {
+    vrg_log_record(c, log_base, i, idx, old, nw);
     c.lab[0][idx] = nw;
     vrg_count_change_at(c, idx, old, nw, i);
 }
@@ -840,7 +864,14 @@ VRG_HD bool vrg_dense_due(const VrgCtx& c) { return vrg_load_i64(&c.gate[VG_REQ]
 // Option verify_every = n: the dense pass (:113-116 - here a CHECK of the sizes kept by increments, and the source of the trace's
 // intensity sums) runs on every n-th sweep only (0: never; the run's last sweep is then checked when it ends).  Is sweep number k's
 // pass left out?
-VRG_HD bool vrg_dense_skipped(int64_t k, int64_t every) { return every == 0 || (every > 1 && k % every != 0); }
+// With several verifiers (leader / follower replication) the passes that are due go round robin: pass number q = k / every - 1 is counted by
+// verifier q % ver_n; ver_me < 0: this handle counts none.
+VRG_HD bool vrg_dense_skipped(int64_t k, int64_t every, int32_t ver_n = 1, int32_t ver_me = 0) {
+    if (every == 0 || ver_me < 0 || (every > 1 && k % every != 0)) return true;
+    if (ver_n <= 1) return false;
+    const int64_t q = (every > 1 ? k / every : k) - 1;
+    return (int32_t)(q % ver_n) != ver_me;
+}
 // ... then the pass is closed without a count: a marker (negative sizes) takes the place of the slab sums, so that the sequence
 // of passes - which class copy the next one reads, what k_close / k_band wait for - stays what it is
 VRG_HD VrgDense vrg_dense_skip_marker() { VrgDense d; d.n_in = -1.0; d.n_out = -1.0; d.sum_in = 0.0; d.sum_out = 0.0; return d; }
@@ -889,6 +920,56 @@ VRG_HD void vrg_dense_fin_staged(const VrgCtx& c) {
 VRG_HD void vrg_init_counts(const VrgCtx& c) {
     c.inc[VC_NIN] = (int64_t)c.dn->n_in; c.inc[VC_NOUT] = (int64_t)c.dn->n_out; c.gate[VG_REQ] = 0; c.gate[VG_STOP] = 0;
     c.dctl[VD_SEQ] = 0; c.dctl[VD_ERR] = 0; c.dctl[VD_RSEQ] = 0; c.dctl[VD_NST] = 0; c.dctl[VD_GO] = 0; c.nchg[0] = 0; c.nchg[1] = 0;
+}
+
+// ------------------------------------------------------------------ the change log (leader / follower replication)
+// the header of sweep k (its labels are in place, its nrec records written), by ONE caller; the state's log counters move on
+VRG_HD void vrg_log_sweep(const VrgCtx& c, int64_t k, uint32_t base, uint32_t nsw, uint32_t nrec, int64_t n_in, int64_t n_out) {
+    if (!c.log_rec) return;
+    const uint32_t q = nsw - c.log_nsw0;
+    if (q >= c.log_swcap) { vrg_store_i32(&c.stg->error, 11); return; }
+    VrgLogSweep w;
+    const VrgTrace& t = c.trace[(uint64_t)k < c.trace_cap ? k : 0];
+    w.nflip = t.nflip; w.nseg = n_in; w.n_in = n_in; w.n_out = n_out; w.ni = t.ni; w.no = t.no; w.ties = t.ties; w.near_ties = t.near_ties;
+    w.sweep = (uint32_t)k; w.nrec = nrec; w.rec0 = base - c.log_pos0; w.pad = 0;
+    c.log_sw[q] = w;
+    c.stg->log_pos = base + nrec; c.stg->log_nsw = nsw + 1u;
+}
+// (a leader that enqueues no dense pass at all: the pass counters follow the sweeps, so that the handle stays consistent - which class copy
+// is current, what a later pass would wait for - and the sweep's trace record says that nobody here summed its intensities)
+VRG_HD void vrg_dense_none_step(const VrgCtx& c, int64_t k) {
+    if (!c.dense_none) return;
+    vrg_store_i64(&c.dctl[VD_RSEQ], k); vrg_store_i64(&c.dctl[VD_SEQ], k);
+    if ((uint64_t)k < c.trace_cap) { c.trace[k].sum_in = __builtin_nan(""); c.trace[k].sum_out = __builtin_nan(""); }
+}
+
+// ---- a follower applies record r of sweep k: label byte, stamp of a voxel that became segmented, class bits (BOTH copies: a follower's
+// passes and applies are in stream order, so the copies never differ), the unit bitmap through unew[0] (merged by the next refresh)
+VRG_HD void vrg_follow_apply_rec(const VrgCtx& c, const VrgLogRec& r, uint32_t k) {
+    if (r.idx == VRG_NONE) return;
+    const uint8_t have = (uint8_t)(c.lab[0][r.idx] & (VB_LABEL | VB_OOB));
+    if (have != r.old) { c.dctl[VD_ERR] = 12; return; }       // this rank's labels have drifted from the leader's: nothing it counts can be trusted
+    c.lab[0][r.idx] = r.nw;
+    if ((r.nw & VB_S) && !(r.old & VB_S)) c.stamp[r.idx] = ((uint64_t)k << 32) | r.rank;
+    const uint32_t a = vrg_cls_of(r.old), b = vrg_cls_of(r.nw);
+    if (a == b) return;
+    uint32_t dw, sh; vrg_cls_pos(r.idx, dw, sh);
+    const uint32_t x = (a ^ b) << sh;
+    if (a == 0u) vrg_list_unit(c, r.idx, 0, 1u << ((r.idx >> 10) & 31u));
+    vrg_atomic_xor(&c.clsb[0][dw], x); vrg_atomic_xor(&c.clsb[1][dw], x);
+}
+// ... and files the sweep's trace record from its header (one caller); the sums come from whoever counts the sweep
+VRG_HD void vrg_follow_trace(const VrgCtx& c, const VrgLogSweep& w) {
+    if ((uint64_t)w.sweep >= c.trace_cap) return;
+    VrgTrace& t = c.trace[w.sweep];
+    t.nflip = w.nflip; t.nseg = w.nseg; t.n_in = w.n_in; t.n_out = w.n_out; t.ni = w.ni; t.no = w.no; t.ties = w.ties; t.near_ties = w.near_ties;
+    t.sum_in = __builtin_nan(""); t.sum_out = __builtin_nan("");
+}
+// the pass over sweep k's labels is done (totals d): against the sizes the leader filed; the sums into the trace
+VRG_HD void vrg_follow_check(const VrgCtx& c, const VrgDense& d, uint32_t k, int64_t n_in, int64_t n_out) {
+    if ((int64_t)d.n_in != n_in || (int64_t)d.n_out != n_out) c.dctl[VD_ERR] = 5;
+    if ((uint64_t)k < c.trace_cap) { c.trace[k].sum_in = d.sum_in; c.trace[k].sum_out = d.sum_out; }
+    *c.dn = d;
 }
 
 // ------------------------------------------------------------------ closing the sweep
@@ -950,8 +1031,11 @@ VRG_HD void vrg_finalize_update(const VrgCtx& c, VrgState& s, int64_t n_in, int6
 VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
     int64_t n_in, n_out;
     VrgState s = vrg_finalize_load(c, n_in, n_out);
+    const uint32_t nrec = s.nmk < c.mcap ? s.nmk : c.mcap;
     vrg_finalize_update(c, s, n_in, n_out, use_tab);
     *c.stg = s;
+    vrg_log_sweep(c, (int64_t)s.iter, s.log_pos, s.log_nsw, nrec, n_in, n_out);
+    vrg_dense_none_step(c, (int64_t)s.iter);
 }
 // vrg_post_apply + vrg_request_dense + vrg_finalize by the ONE thread that closes a sweep in a kernel, as two round trips
 // instead of three: what they read in one batch; the expected sizes, the change lists' lengths and the new state out
@@ -960,11 +1044,14 @@ VRG_HD void vrg_close_sweep(const VrgCtx& c, int64_t nchg_at, bool use_tab) {
     int64_t n_in, n_out;
     VrgState s = vrg_finalize_load(c, n_in, n_out);
     const int64_t k = (int64_t)s.iter + 1;
+    const uint32_t nrec = s.nmk < c.mcap ? s.nmk : c.mcap;   // (the sweep's marked list = its change log records)
     vrg_store_i64(&c.exp_ring[2 * (k % VRG_RING)], n_in); vrg_store_i64(&c.exp_ring[2 * (k % VRG_RING) + 1], n_out);
     c.nchg[(k & 1) ^ 1] = 0;
     if (nchg_at >= 0) c.nchg[k & 1] = (uint32_t)nchg_at;
     vrg_finalize_update(c, s, n_in, n_out, use_tab);
     *c.stg = s;
+    vrg_log_sweep(c, k, s.log_pos, s.log_nsw, nrec, n_in, n_out);
+    vrg_dense_none_step(c, k);
     vrg_drain(); vrg_store_i64(&c.gate[VG_REQ], k);
 }
 
@@ -1335,8 +1422,9 @@ VRG_HD void vrg_fuse_close(const VrgCtx& c, VrgState s, int64_t n_in, int64_t n_
 
 // ---- what the fused sweep left for the next trip's k_band (sweep k = the state's iter: already counted)
 // (place i of the marked list, its three fields fetched by the caller - several places in one batch)
-VRG_HD void vrg_deferred_apply_vals(const VrgCtx& c, uint32_t i, int k, uint32_t idx, uint8_t old, uint8_t nw) {
+VRG_HD void vrg_deferred_apply_vals(const VrgCtx& c, uint32_t i, int k, uint32_t idx, uint8_t old, uint8_t nw, uint32_t log_base) {
     const int p = k & 1;
+    vrg_log_record(c, log_base, i, idx, old, nw);
     if (idx == VRG_NONE) { c.chg_dw[p][i] = VRG_NOCHG; return; }
     c.lab[0][idx] = nw;                                    // (clean: no L / P / mark bits - the fused sweep never wrote any)
     const uint32_t a = vrg_cls_of(old), b = vrg_cls_of(nw);
@@ -1350,7 +1438,7 @@ VRG_HD void vrg_deferred_apply_vals(const VrgCtx& c, uint32_t i, int k, uint32_t
     vrg_atomic_xor(&c.clsb[p][dw], x);
     c.chg_dw[p][i] = dw; c.chg_x[p][i] = x;
 }
-VRG_HD void vrg_deferred_apply(const VrgCtx& c, uint32_t i, int k) { vrg_deferred_apply_vals(c, i, k, c.mk_idx[i], c.mk_old[i], c.mk_new[i]); }
+VRG_HD void vrg_deferred_apply(const VrgCtx& c, uint32_t i, int k, uint32_t log_base) { vrg_deferred_apply_vals(c, i, k, c.mk_idx[i], c.mk_old[i], c.mk_new[i], log_base); }
 VRG_HD void vrg_deferred_catchup(const VrgCtx& c, uint32_t i, int k) {   // change i of sweep k-1: class copy k & 1 sat that sweep out
     const int p = k & 1;
     const uint32_t dw = c.chg_dw[p ^ 1][i], x = c.chg_x[p ^ 1][i];
@@ -1360,9 +1448,12 @@ VRG_HD uint32_t vrg_deferred_catchup_count(const VrgCtx& c, int k) { const uint3
 VRG_HD void vrg_deferred_free(const VrgCtx& c, const VrgState& s, uint32_t j) { c.freel[s.fr_base + j] = c.dead[j]; }
 // one caller, once all of the above has reached memory: the list of sweep k-1 is consumed, the labels of sweep k are in place -
 // its dense pass is due
-VRG_HD void vrg_deferred_done(const VrgCtx& c, int k) {
+// (s: the state as the trip found it - what the sweep's closing thread left)
+VRG_HD void vrg_deferred_done(const VrgCtx& c, const VrgState& s, int k) {
     c.nchg[(k & 1) ^ 1] = 0;
     c.stg->apply_pending = 0; c.stg->fr_n = 0;
+    vrg_log_sweep(c, k, s.log_pos, s.log_nsw, s.ap_n, vrg_load_i64(&c.exp_ring[2 * (k % VRG_RING)]), vrg_load_i64(&c.exp_ring[2 * (k % VRG_RING) + 1]));
+    vrg_dense_none_step(c, k);
     vrg_drain(); vrg_store_i64(&c.gate[VG_REQ], (int64_t)k);
 }
 
@@ -1424,7 +1515,7 @@ VRG_HD void vrg_item_init_entry(const VrgCtx& c, uint32_t e) {
     c.p_lev[e] = vrg_voxel_level(c, idx);
     c.p_key[e] = e;
     c.p_flag[e] = (uint8_t)(PF_ALIVE | (e < c.st->ni ? PF_INNER : 0));     // (init computes its densities at once: not pending)
-    c.p_ip[e] = 0; c.p_op[e] = 0;
+    c.p_ip[e] = 0; c.p_op[e] = 0; c.p_err[e] = 0;
     c.fresh[e] = e;
     c.vent[idx] = e;
 }

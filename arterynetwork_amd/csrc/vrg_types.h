@@ -41,7 +41,7 @@ enum : uint8_t { PF_ALIVE = 1, PF_INNER = 2, PF_PEND = 4 };   // PEND: densities
 enum : uint8_t { FR_FINAL = 3, FR_FRESH = 4, FR_WRITTEN = 8 };
 
 // why the one-workgroup sweep kernel handed a trip back to the host (VrgState::bail); nothing was modified
-enum { VBAIL_FLIPS = 1, VBAIL_MARKS = 2, VBAIL_POOL = 3, VBAIL_FUSE = 4 };   // FUSE: more flips than the fused sweep kernel takes (k_sweep)
+enum { VBAIL_FLIPS = 1, VBAIL_MARKS = 2, VBAIL_POOL = 3, VBAIL_FUSE = 4, VBAIL_LOG = 5 };   // FUSE: more flips than the fused sweep kernel takes (k_sweep); LOG: the batch's change log is full
 
 // The fused sweep (k_sweep, vrg_items.h "fused sweep"): update() of a sweep with at most VRG_FUSE_MAX flips as ONE launch, one
 // flip per workgroup of VRG_FUSE_THREADS threads (thread p < 125 = place p of the flip's 5x5x5 cube, thread t < 81 = row t of
@@ -72,6 +72,10 @@ struct VrgTrace {            // one record per update() call (0 = init)
 // r03_float32_divergence_gpu.json) or this library's binned evaluation of the exact densities (<= 2e-8, vrg_items.h
 // "binned mode") could decide differently.  The threshold is twice that tolerance.
 #define VRG_TIE_REL 1e-11
+// binned exact densities (large level tables): proved relative error of an evaluation (vrg_items.h "binned exact densities": 1.46e-8 truncation + fixed-point
+// rounding), rounded up.  The ABSOLUTE error of an entry's two densities stays with it through every later correction (VrgCtx::p_err), and a sign test
+// it could turn is counted as a tie - so "labels are bit-exact unless ties > 0" holds with bins too
+#define VRG_BIN_REL_ERR 2.0e-8
 #define VRG_TIE_NEAR_REL 2e-5
 
 // device-resident scalars; every kernel reads them at entry (no host round trip per sweep)
@@ -111,7 +115,37 @@ struct VrgState {
     uint32_t nvisit;                   // listed flips the fused stencil visited (must equal nf)
     uint32_t nnz_new;                  // fused sweep on a large level table: levels listed so far by the sweep in progress (nnz still says what the
                                        // sweep before left for this trip's k_band)
+    // the change log (leader / follower replication, VrgCtx::log_rec): records and sweep headers written since init - monotone
+    // counters; a launch knows where its batch's buffer starts (VrgCtx::log_pos0 / log_nsw0)
+    uint32_t log_pos, log_nsw;
 };
+
+// ---- the change log: what a sweep did to the label volume, for the ranks that do not run the band chain themselves ------------------
+// One record per place of the sweep's marked list (a fused sweep: 125 places per flip, most of them VRG_NONE), written where the
+// label byte is written (the apply step of every kind of trip), 16 bytes = one store; one header per sweep, written by whoever
+// declares the sweep's labels in place.  A batch of trips writes into one buffer: [VrgLogBatch][VrgLogSweep x log_swcap][VrgLogRec x log_cap].
+struct VrgLogRec {
+    uint32_t idx;                      // voxel (padded layout), or VRG_NONE: nothing at this place
+    uint32_t rank;                     // a voxel that becomes segmented: its rank in the sweep's flip list (stamp = sweep << 32 | rank: the list order of `segmented`, :200)
+    uint8_t old, nw; uint16_t pad;     // label byte before / after (clean: no L / P / mark bits)
+    uint32_t pad2;
+};
+struct VrgLogSweep {                   // = the sweep's trace record + where its records are
+    int64_t nflip, nseg, n_in, n_out, ni, no, ties, near_ties;   // (VrgTrace without the sums; n_in / n_out: what the sweep's dense pass must reproduce)
+    uint32_t sweep, nrec;              // sweep number (1-based, = VrgState::iter after it); records
+    uint32_t rec0, pad;                // first record, relative to the batch buffer's records
+};
+struct VrgLogBatch {                   // written by the leader's host when the batch is complete
+    uint64_t seq;                      // batch number, from 1
+    uint32_t nsw, nrec;                // sweeps and records in it
+    int32_t final;                     // the run has ended with this batch ...
+    int32_t stop_reason, iter, error;  // ... this way (VrgState::done, iter, error)
+    int64_t n_in, n_out;               // region sizes at the end of the batch
+    uint32_t ni, no;
+    uint32_t ties, near_ties;          // VrgState counters at the end of the batch
+    uint32_t pad[2];
+};
+
 
 // results of the dense recount; written by the dense stream only (own allocation, own cache lines).
 // The dense pass of sweep k runs on its own stream while the band kernels already prepare sweep k+1: the region
@@ -218,6 +252,7 @@ struct VrgCtx {
     uint32_t* p_lev;           // level index of its intensity
     double* p_ip;              // innerProb / outerProb (:132-133)
     double* p_op;
+    float* p_err;              // bound on the absolute error p_ip / p_op carry since their exact evaluation (binned densities: VRG_BIN_REL_ERR of the sums; 0 without bins)
     uint64_t* p_key;           // list-order key (vrg_items.h)
     uint8_t* p_flag;           // PF_*
     uint32_t* vent;            // per voxel: slot of the band entry sitting there (valid while the B bit is set)
@@ -259,6 +294,14 @@ struct VrgCtx {
                                // 2: (fused sweep, large level table) listed by the first toucher, counted in VrgState::nnz_new
     int32_t lev_fast;          // 1: a voxel's level index is cheap here (16-bit storage, or the level table in LDS): a flip's
                                //    level is looked up from its intensity instead of fetched through its rank
+    // leader / follower replication (vrg_engine.cpp "replication"): the change log of the batch of trips being enqueued (null: no log)
+    VrgLogRec* log_rec; VrgLogSweep* log_sw;
+    uint32_t log_cap, log_swcap;       // capacities of the two arrays
+    uint32_t log_pos0, log_nsw0;       // VrgState::log_pos / log_nsw when the batch's buffer was opened
+    // which dense passes this handle counts: sweep k is counted by verifier ((k / every) - 1) % ver_n (vrg_dense_skipped); ver_me = this
+    // handle's place among the verifiers, -1: it counts none.  One GPU: ver_n = 1, ver_me = 0.
+    int32_t ver_n, ver_me;
+    int32_t dense_none;        // no dense pass is enqueued at all (a leader that verifies nothing): the band side keeps the pass counters in step itself
     uint32_t* counters;        // arrival tickets of the last-workgroup reductions (zero between launches)
     uint64_t* dbg;             // diagnostic build only (-DVRG_STAMPS): in-kernel time stamps of the band chain, see tools/chain_stamps.py
     VrgTrace* trace;

@@ -196,10 +196,32 @@ def bench_volume(shape, seed, levels=255, radius=4.0, noise=0.1, seed_planes=3):
                         dtype=np.float32, noise_dtype=np.float32)
 
 
-def bench_volume_torch(shape, device, seed=3, levels=255, radius=4.0, noise=0.1, seed_planes=3, brain_mask=True, integer_values=False):
+def tube_lattice(shape, tubes):
+    """Centres (cy, cz), radius and wiggle amplitude of `tubes` disjoint tubes running along x (SURVEY.md 8(d), config 5:
+    "several disjoint tubes"): a gy x gz lattice over the central 60 % of the (y, z) cross-section - inside the brain
+    ellipsoid for the central third of the x range.  Radius 4 where the pitch allows it (at least 3 voxels stay between
+    two tubes: their one-voxel bands never touch), smaller on a dense lattice; the wiggle keeps that gap."""
+    import math
+    nx, ny, nz = shape
+    gy = max(1, int(round(math.sqrt(tubes * (0.6 * ny) / (0.6 * nz)))))
+    gz = (tubes + gy - 1) // gy
+    py, pz = 0.6 * ny / gy, 0.6 * nz / gz
+    radius = min(4.0, (min(py, pz) - 3.0) / 2.0)
+    if radius < 1.5:
+        raise ValueError('{} tubes do not fit a {}x{} cross-section'.format(tubes, ny, nz))
+    amp = max(0.0, (min(py, pz) - 3.0 - 2.0 * radius) / 2.0)
+    cen = [(0.2 * ny + (j % gy + 0.5) * py, 0.2 * nz + (j // gy + 0.5) * pz) for j in range(tubes)]
+    return cen, radius, min(amp, 0.18 * min(ny, nz))
+
+
+def bench_volume_torch(shape, device, seed=3, levels=255, radius=4.0, noise=0.1, seed_planes=3, brain_mask=True, integer_values=False,
+                       tubes=1, seed_mode='planes'):
     """The configs 2-4 recipe generated directly in HBM with torch (plumbing only), x-fastest
     layout.  Returns (I, vm) as torch tensors of logical shape (nx,ny,nz) with element strides (1,nx,nx*ny).
-    ``levels=None`` keeps the continuous float32 noise (one distinct value per voxel, nearly)."""
+    ``levels=None`` keeps the continuous float32 noise (one distinct value per voxel, nearly).
+    ``tubes`` > 1: that many disjoint tubes on a lattice (tube_lattice), seeded at the central x planes so that every tube
+    grows both ways - about 100 flips per tube and sweep: the many-flip regime.  ``seed_mode='whole'``: every tube voxel
+    is a seed (what refine() does with a stage-1 mask: all vessels at once)."""
     import math
     import torch
     nx, ny, nz = shape
@@ -208,9 +230,23 @@ def bench_volume_torch(shape, device, seed=3, levels=255, radius=4.0, noise=0.1,
     xs = torch.arange(nx, device=device, dtype=torch.float32)[None, None, :]
     ys = torch.arange(ny, device=device, dtype=torch.float32)[None, :, None]
     zs = torch.arange(nz, device=device, dtype=torch.float32)[:, None, None]
-    cy = ny / 2.0 + 0.18 * ny * torch.sin(2 * math.pi * xs / nx)
-    cz = nz / 2.0 + 0.18 * nz * torch.cos(2 * math.pi * xs / nx)
-    tube = ((ys - cy) ** 2 + (zs - cz) ** 2) <= radius ** 2            # (nz,ny,nx)
+    if tubes <= 1:
+        cy = ny / 2.0 + 0.18 * ny * torch.sin(2 * math.pi * xs / nx)
+        cz = nz / 2.0 + 0.18 * nz * torch.cos(2 * math.pi * xs / nx)
+        tube = ((ys - cy) ** 2 + (zs - cz) ** 2) <= radius ** 2            # (nz,ny,nx)
+        seeds = tube & (xs < seed_planes)
+    else:
+        cen, rad, amp = tube_lattice(shape, tubes)
+        tube = torch.zeros((nz, ny, nx), dtype=torch.bool, device=device)
+        wy, wz = amp * torch.sin(2 * math.pi * xs / nx * 3.0), amp * torch.cos(2 * math.pi * xs / nx * 3.0)
+        r1 = int(math.ceil(rad + amp)) + 1
+        for (c_y, c_z) in cen:                                            # (each tube only touches its own box of the volume)
+            y0, y1 = max(0, int(c_y) - r1), min(ny, int(c_y) + r1 + 2)
+            z0, z1 = max(0, int(c_z) - r1), min(nz, int(c_z) + r1 + 2)
+            tube[z0:z1, y0:y1, :] |= ((ys[:, y0:y1] - (c_y + wy)) ** 2 + (zs[z0:z1] - (c_z + wz)) ** 2) <= rad ** 2
+        seeds = tube & (xs >= nx // 2 - (seed_planes + 1) // 2) & (xs < nx // 2 + seed_planes // 2)
+    if seed_mode == 'whole':
+        seeds = tube
     I = torch.randn((nz, ny, nx), generator=g, device=device, dtype=torch.float32)
     I.mul_(noise).add_(tube.to(torch.float32))
     if levels:
@@ -222,5 +258,5 @@ def bench_volume_torch(shape, device, seed=3, levels=255, radius=4.0, noise=0.1,
     vm = torch.full((nz, ny, nx), 3, dtype=torch.uint8, device=device)
     if brain_mask:
         vm[~ell.expand(nz, ny, nx)] = 4
-    vm[tube & (xs < seed_planes)] = 0
+    vm[seeds] = 0
     return I.permute(2, 1, 0), vm.permute(2, 1, 0)

@@ -111,7 +111,8 @@ def bench_slabs(shape, args, dev, rank, world, roofline, configure, load_traffic
     import torch.distributed as dist
     from . import phantoms
     I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels, brain_mask=not args.no_brain_mask,
-                                        integer_values=getattr(args, 'integer_values', False))   # (H already scaled by bench.main)
+                                        integer_values=getattr(args, 'integer_values', False),   # (H already scaled by bench.main)
+                                        tubes=getattr(args, 'tubes', 1), seed_mode=getattr(args, 'seed_mode', 'planes'))
     torch.cuda.synchronize()
     V = shape[0] * shape[1] * shape[2]
     s = make_slab_session(shape, rank, world, device=dev.index, reduce='rccl-always')

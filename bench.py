@@ -310,6 +310,8 @@ def main():
     ap.add_argument('--dense-pipe', type=int, default=1, help='0: the dense pass as k_recount_bits instead of the two-trips-deep k_recount_pipe (A/B)')
     ap.add_argument('--serial', type=int, default=0, help='1: option serial_streams (needed under rocprofv3 --pmc, which runs one kernel at a time)')
     ap.add_argument('--storage16', action='store_true', help='16-bit intensity storage (level indices): config 5 style; 4 B/voxel-iter algorithmic')
+    ap.add_argument('--tubes', type=int, default=1, help='disjoint tubes of the synthetic volume (SURVEY 8(d) config 5: "several disjoint tubes"): about 100 flips per tube and sweep')
+    ap.add_argument('--seed-mode', default='planes', choices=['planes', 'whole'], help="'whole': every tube voxel is a seed (what refine() does with a stage-1 mask)")
     ap.add_argument('--force-dist', action='store_true', help='use the N>1 code path (RCCL comm) even with one rank')
     args = ap.parse_args()
     shape = tuple(int(s) for s in args.shape.lower().split('x'))
@@ -358,7 +360,8 @@ def main():
         return
 
     from arterynetwork_amd._capi import Session
-    I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels, brain_mask=not args.no_brain_mask, integer_values=args.integer_values)
+    I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels, brain_mask=not args.no_brain_mask, integer_values=args.integer_values,
+                                        tubes=args.tubes, seed_mode=args.seed_mode)
     torch.cuda.synchronize()
     V = shape[0] * shape[1] * shape[2]
     s = Session(shape, device=local_rank)

@@ -57,7 +57,10 @@ typedef struct {
     int64_t chain_launches;
     int64_t ties;             /* sign tests (:87) of this call whose two sides agreed to a relative 1e-11, or that divided by an
                                  empty region: the reference decides those by the rounding of np.sum's pairwise order, which
-                                 no regrouped summation reproduces - labels are bit-exact unless ties > 0 */
+                                 no regrouped summation reproduces - labels are bit-exact unless ties > 0.  With binned exact
+                                 densities (more than "bin_above" distinct values) every band entry also carries the absolute error
+                                 bound of its last exact evaluation (2e-8 of the sums, proved) through all later corrections, and a
+                                 sign test that error could turn is counted here too: the statement holds for every level table */
     int64_t near_ties;        /* ... whose relative margin was below 2e-5 (twice the float tolerance of 1e-5): a heuristic
                                  indicator of decisions the reference's float32 arithmetic (float32 dataArray under numpy 2) or a
                                  differently ordered / binned summation could make differently.  near_ties == 0 does not
@@ -177,6 +180,33 @@ int vrg_comm_init(vrg_handle* h, int nranks, int rank, const void* id128);
  * in place; called once per sweep (and once by vrg_init).  Costs a host synchronisation per sweep. */
 typedef void (*vrg_reduce_fn)(double partial_to_total[4], void* user);
 int vrg_set_reduce_callback(vrg_handle* h, vrg_reduce_fn fn, void* user);
+
+/* ---- multi-GPU, leader / follower replication (one process per GPU) ---------------------------------
+ * Rank 0 (the leader) runs the whole band chain - decisions, update(), densities (:58-117) - exactly as one GPU does and
+ * logs what every sweep did to the labels; the other ranks (followers) hold the intensities and the labels, apply the log
+ * and COUNT the sweeps assigned to them - the reference's dense recount of innerSize / outerSize (:113-116), here the check
+ * of the sizes the decisions read - round robin, each over the whole volume with the very pass one GPU runs.  The
+ * leader counts a share too when leader_verifies != 0 (small groups).  vrg_create / vrg_set_volume / vrg_set_labels / vrg_init
+ * / vrg_run are then COLLECTIVE: every rank makes the same calls with the same arguments (use maxSeconds < 0 or expect the
+ * leader's clock to decide).  After vrg_run every rank holds the same labels, `segmented` order, trace and vrg_result; the
+ * band (vrg_get_band) lives on the leader only.  A count that disagrees, or a rank whose labels have drifted from the log,
+ * fails the run on every rank (VRG_E_INTERNAL).  Call vrg_repl_init before vrg_init, then choose ONE transport for the log. */
+int vrg_repl_init(vrg_handle* h, int nranks, int rank, int leader_verifies);
+/* transport 1 - host callbacks (any fabric; the CPU tests use torch.distributed / gloo): bcast broadcasts `bytes` bytes of
+ * `buf` (host memory) from rank `root` to every rank, allsum sums n doubles over the ranks in place; both blocking, collective */
+typedef void (*vrg_bcast_fn)(void* buf, int64_t bytes, int root, void* user);
+typedef void (*vrg_allsum_fn)(double* buf, int64_t n, void* user);
+int vrg_repl_set_callbacks(vrg_handle* h, vrg_bcast_fn bcast, vrg_allsum_fn allsum, void* user);
+/* transport 2 - RCCL: the communicator of vrg_comm_init carries the log (ncclBroadcast on a stream of its own) */
+int vrg_repl_use_rccl(vrg_handle* h);
+/* transport 3 - hipIpc between the ranks of one node: the leader exports its log buffers (a blob of *bytes <= cap bytes, cap >= 256)
+ * that the caller hands to every follower, which maps them and copies each batch out itself - device to device, over xGMI
+ * between GPUs; the leader never waits for a follower unless one falls two batches behind */
+int vrg_repl_ipc_export(vrg_handle* h, void* blob, int64_t cap, int64_t* bytes);
+int vrg_repl_ipc_import(vrg_handle* h, const void* blob, int64_t bytes);
+/* diagnostics: out[0] = batches published / taken, out[1] = log records, out[2] = sweeps in them, out[3] = sweeps this rank counted,
+ * out[4] = the last of them, out[5] = transport (1 callback, 2 rccl, 3 ipc), out[6] = verifiers, out[7] = this rank's place among them (-1: none) */
+int vrg_repl_stats(vrg_handle* h, int64_t* out, int64_t cap);
 
 #ifdef __cplusplus
 }

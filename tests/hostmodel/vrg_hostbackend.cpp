@@ -218,7 +218,7 @@ int be_comm_init(VrgBackend*, int, int, const void*) { return -1; }
 
 // the dense pass of the sweep just applied - or, with option verify_every, its marker (k_gate)
 static void dense_pass(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
-    if (b->verify_every != 1 && vrg_dense_skipped(c.dctl[VD_RSEQ] + 1, b->verify_every)) {
+    if (vrg_dense_skipped(c.dctl[VD_RSEQ] + 1, b->verify_every, c.ver_n, c.ver_me)) {
         vrg_recount_done(c, vrg_dense_skip_marker());
         vrg_dense_fin_one(c, vrg_dense_skip_marker());
         return;
@@ -229,7 +229,6 @@ static void dense_pass(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* us
     vrg_dense_fin_one(c, tot);
 }
 void be_verify_last(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user) {
-    if (b->verify_every == 1) return;
     dense_stats(c, c.lab[0], cb, user, 1);
     vrg_dense_verify_last(c, *c.dn);
 }
@@ -307,10 +306,10 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c0, int flags, VrgEvents*, be_re
     if (s.apply_pending) {                             // (k_band: what the fused sweep before this trip left to do)
         const int k = s.iter;
         const VrgState snap0 = s;
-        for (uint32_t i = 0; i < snap0.ap_n; i++) vrg_deferred_apply(c0, i, k);
+        for (uint32_t i = 0; i < snap0.ap_n; i++) vrg_deferred_apply(c0, i, k, snap0.log_pos);
         for (uint32_t i = 0, nc = vrg_deferred_catchup_count(c0, k); i < nc; i++) vrg_deferred_catchup(c0, i, k);
         for (uint32_t j = 0; j < snap0.fr_n; j++) vrg_deferred_free(c0, snap0, j);
-        vrg_deferred_done(c0, k);
+        vrg_deferred_done(c0, snap0, k);
         if (!(flags & VRG_SWEEP_NODENSE)) dense_pass(b, c0, cb, user);   // its dense pass (the device: gate + recount on the other stream, asked for by vrg_deferred_done)
     }
     // the per-launch modes of the batched kernels, alternated so that both forms of every item function run here: the
@@ -355,7 +354,7 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c0, int flags, VrgEvents*, be_re
         if (s.nmk > c.mcap) { s.error = 4; s.done = -1; return; }
         for (uint32_t i = 0; i < s.nmk; i++) vrg_item_relabel(c, i);
         // (as k_close does: the class change filed at the voxel's place of the marked list, no counter)
-        for (uint32_t i = 0; i < s.nmk; i++) { const uint32_t idx = c.mk_idx[i]; vrg_apply_at(c, i, idx, lab[idx], c.mk_new[i]); }
+        for (uint32_t i = 0; i < s.nmk; i++) { const uint32_t idx = c.mk_idx[i]; vrg_apply_at(c, i, idx, lab[idx], c.mk_new[i], s.log_pos); }
         for (uint32_t i = 0, nc = vrg_catchup_count(c); i < nc; i++) vrg_item_catchup(c, i);
     } else {
         // full-stencil check variant: every voxel, through the scratch volume
@@ -381,6 +380,30 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c0, int flags, VrgEvents*, be_re
             vrg_corrections(c, s.nnz, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, c.lev[l], c.tabC[3 * (size_t)l], c.tabC[3 * (size_t)l + 1], c.tabC[3 * (size_t)l + 2]);
     vrg_finalize(c, use_tab);
 }
+
+// ---- leader / follower replication: a follower's apply and verify steps, sequentially (the transports are the engine's callbacks) ----
+void be_follow_apply(VrgBackend*, const VrgCtx& c, const VrgLogRec* recs, const VrgLogSweep* hdr) {
+    vrg_follow_trace(c, *hdr);
+    for (uint32_t i = 0; i < hdr->nrec; i++) vrg_follow_apply_rec(c, recs[i], hdr->sweep);
+}
+void be_follow_verify(VrgBackend*, const VrgCtx& c, const VrgLogSweep* hdr, VrgEvents*) {
+    for (int p = 0; p < 2; p++)                          // (k_follow_gate) the units the applied sweeps listed join the bitmap, then the list
+        if (c.uctl[UC_GEN + p * UC_GEN_STRIDE]) {
+            for (size_t w = 0, nw = (((size_t)c.PV + 1023) >> 10) / 32 + 1; w < nw; w++) { c.ubits[w] |= c.unew[p][w]; c.unew[p][w] = 0; }
+            c.uctl[UC_GEN + p * UC_GEN_STRIDE] = 0;
+            vrg_ulist_rebuild_serial(c);
+        }
+    dense_stats(c, c.lab[0], nullptr, nullptr, 1);
+    vrg_follow_check(c, *c.dn_part, hdr->sweep, hdr->n_in, hdr->n_out);
+}
+void be_follow_mark(VrgBackend*, int) {}
+void be_follow_wait(VrgBackend*, int) {}
+int be_repl_bcast(VrgBackend*, void*, size_t, int) { return -1; }
+int be_repl_allsum(VrgBackend*, double*, size_t) { return -1; }
+void be_repl_wait(VrgBackend*) {}
+int be_ipc_export(VrgBackend*, void*, void*) { return -1; }
+void* be_ipc_open(VrgBackend*, const void*) { return nullptr; }
+void be_ipc_close(VrgBackend*, void*) {}
 
 void be_events_collect(VrgBackend*, VrgEvents*, long long) {}
 void be_sweep_batch(VrgBackend* b, const VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user) { for (int i = 0; i < n; i++) be_sweep_once(b, c, flags, ev, cb, user); }
