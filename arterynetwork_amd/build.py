@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libvrg_hip.so')
 SOURCES = ['vrg_device.hip', 'vrg_engine.cpp', 'vmask_device.hip']
-HEADERS = ['vrg_types.h', 'vrg_items.h', 'vrg_backend.h', os.path.join('..', '..', 'include', 'vrg.h'),
+HEADERS = ['vrg_types.h', 'vrg_items.h', 'vrg_backend.h', 'vrg_repl.h', os.path.join('..', '..', 'include', 'vrg.h'),
            os.path.join('..', '..', 'include', 'vmask.h')]
 
 

@@ -102,10 +102,13 @@ int be_comm_init(VrgBackend* b, int nranks, int rank, const void* id128);
 // apply the nrec records of sweep k (device array `recs`, this handle's device) to this handle's labels, class bits, unit bitmap and
 // stamps, in stream order; `hdr` (host memory) is the sweep's header: its trace record is filed.  A record whose `old` byte is not what
 // this handle holds raises dctl[VD_ERR] = 12.
-void be_follow_apply(VrgBackend* b, const VrgCtx& c, const VrgLogRec* recs, const VrgLogSweep* hdr);
-// ... and count sweep k (every voxel: this handle's dense pass with the unit list brought up to date) against the sizes the leader filed
+// (n consecutive sweeps, headers hdr[0..n), their records at recs + hdr[i].rec0; count_last: the last of them is counted next -
+// be_follow_count - so the unit list is brought up to date and its expected sizes are filed.)  The label bytes / stamps are written on a
+// stream of their own, beside a dense pass; the class bits - all a pass reads - on the stream the passes run on.
+void be_follow_apply(VrgBackend* b, const VrgCtx& c, const VrgLogRec* recs, const VrgLogSweep* hdr, int n, int count_last);
+// ... and count the sweep be_follow_apply announced (every voxel: this handle's dense pass) against the sizes the leader filed
 // for it; a mismatch raises dctl[VD_ERR] = 5; the intensity sums go into the sweep's trace record.  ev: optional HIP-event timing of the pass.
-void be_follow_verify(VrgBackend* b, const VrgCtx& c, const VrgLogSweep* hdr, VrgEvents* ev);
+void be_follow_count(VrgBackend* b, const VrgCtx& c, VrgEvents* ev);
 // a follower's two staging buffers: mark = everything enqueued so far (the kernels that read buffer `slot`); wait = that has finished
 void be_follow_mark(VrgBackend* b, int slot);
 void be_follow_wait(VrgBackend* b, int slot);
@@ -114,6 +117,12 @@ void be_follow_wait(VrgBackend* b, int slot);
 int be_repl_bcast(VrgBackend* b, void* dev_buf, size_t bytes, int root);
 int be_repl_allsum(VrgBackend* b, double* dev_buf, size_t n);
 void be_repl_wait(VrgBackend* b);
+// a copy (any direction: host, device, another process's mapped device memory) on the transport stream, waited for - a follower's band
+// stream is busy applying and counting the batch before while the next one arrives
+void be_repl_copy(VrgBackend* b, void* dst, const void* src, size_t bytes);
+// page-locked host memory (the callback transport's copy of a batch: copies to and from the device run at the link's speed)
+void* be_host_alloc(VrgBackend* b, size_t bytes);
+void be_host_free(VrgBackend* b, void* p);
 // inter-process handles of device allocations (ranks on one node: the follower copies straight out of the leader's buffers)
 int be_ipc_export(VrgBackend* b, void* dev_ptr, void* handle64);
 void* be_ipc_open(VrgBackend* b, const void* handle64);        // nullptr: failed

@@ -47,7 +47,8 @@ struct VrgBackend {
     hipStream_t sb = nullptr;            // stream B: the dense pass (recount, slab all-reduce, k_dense_fin); trails stream A by up to one sweep
     hipStream_t sc = nullptr;            // stream C: the change log's transport (leader / follower replication: RCCL broadcasts), created on first use
     int repl = 0;                        // this handle is a rank of a leader / follower group: the communicator carries the log, not slab sums
-    hipEvent_t mark[2] = {nullptr, nullptr};   // a follower's staging buffers: the kernels that read buffer j have been enqueued up to here
+    hipStream_t sd = nullptr;            // stream D: a follower's label bytes and stamps (beside its dense passes, which read the class bits only)
+    hipEvent_t mark[4] = {nullptr, nullptr, nullptr, nullptr};   // a follower's staging buffers: the kernels that read buffer j have been enqueued up to here (per stream)
     int sweep_blocks = 0;                // 0 = auto (dense_blocks)
     int prio_mode = 2;                   // the dense stream gets the higher priority (measured: -1..2 % step time)
     uint32_t small_flips = 4096;         // flips per sweep k_order takes on (<= NF_SMALL)
@@ -288,7 +289,7 @@ __device__ __forceinline__ void wait_dense_read_for(const VrgCtx& c, int64_t nee
     }
 }
 // the deferred work of this workgroup has reached memory; the LAST of the `n` workgroups to say so closes it (vrg_deferred_done)
-__device__ __forceinline__ void band_deferred_done(const VrgCtx& c, const VrgState& s, int k, uint32_t n) {
+__device__ __forceinline__ void band_deferred_done(const VrgCtx& c, int k, uint32_t n) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -296,9 +297,9 @@ __device__ __forceinline__ void band_deferred_done(const VrgCtx& c, const VrgSta
         const uint32_t q = __hip_atomic_fetch_add(&c.counters[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(VRG_MUTANT)      // (tools/mutant_check.py: a deliberately broken hand-off - the FIRST workgroup to arrive asks for the dense pass - that the campaigns must catch)
         if (q == n - 1u) c.counters[32] = 0;
-        if (q == 0u) vrg_deferred_done(c, s, k);
+        if (q == 0u) vrg_deferred_done(c, k);
 #else
-        if (q == n - 1u) { c.counters[32] = 0; vrg_deferred_done(c, s, k); }
+        if (q == n - 1u) { c.counters[32] = 0; vrg_deferred_done(c, k); }
 #endif
     }
 }
@@ -385,14 +386,14 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
         const int k = s.iter;
         if (tid == 0 && dense_on && (int64_t)k - 2 > rseq0) wait_dense_read_for(c, (int64_t)k - 2);   // (the pass of two sweeps ago has read the class copy this sweep rewrites)
         __syncthreads();
-        if (dtid < s.ap_n) vrg_deferred_apply_vals(c, dtid, k, mxa, moa, mna, s.log_pos);
-        if (dtid + G < s.ap_n) vrg_deferred_apply_vals(c, dtid + G, k, mxb, mob, mnb, s.log_pos);
-        for (uint32_t i = dtid + 2u * G; i < s.ap_n; i += G) vrg_deferred_apply(c, i, k, s.log_pos);
+        if (dtid < s.ap_n) vrg_deferred_apply_vals(c, dtid, k, mxa, moa, mna);
+        if (dtid + G < s.ap_n) vrg_deferred_apply_vals(c, dtid + G, k, mxb, mob, mnb);
+        for (uint32_t i = dtid + 2u * G; i < s.ap_n; i += G) vrg_deferred_apply(c, i, k);
         const uint32_t nc = vrg_deferred_catchup_count(c, k), pp = ((uint32_t)k & 1u) ^ 1u;
         if (dtid < nc) { const uint32_t dw = pp ? cda1 : cda0, x = pp ? cxa1 : cxa0; if (dw != VRG_NOCHG) vrg_atomic_xor(&c.clsb[pp ^ 1u][dw], x); }
         for (uint32_t i = dtid + G; i < nc; i += G) vrg_deferred_catchup(c, i, k);
         for (uint32_t j = dtid; j < s.fr_n; j += G) vrg_deferred_free(c, s, j);
-        band_deferred_done(c, s, k, defer_wgs);
+        band_deferred_done(c, k, defer_wgs);
         return;
     }
     if (!pool_wg) {
@@ -1263,6 +1264,7 @@ __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a, int fi
         d.sum_in = ((sh_s[0][0] + sh_s[0][1]) + sh_s[0][2]) + sh_s[0][3];
         d.sum_out = ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3];
         if (fin == 0) { *c.dn_part = d; if (c.world == 1) *c.dn = d; }   // init: the sizes found the incremental counts
+        else if (fin == 4) vrg_follow_check(c, d, (uint32_t)c.fexp[0], c.fexp[1], c.fexp[2]);   // a follower's count of the sweep its apply step announced
         else {
             vrg_recount_done(c, d);                  // this device's slab sums of the recount
             if (fin == 2) vrg_dense_fin_one(c, d);   // nothing to sum over ranks: close the pass here
@@ -1421,7 +1423,7 @@ __device__ __forceinline__ void load_vals(const VrgCtx& c, uint32_t u, uint32_t 
 template <int UNITS, bool NT, int MODE, bool SKIP>
 __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) {
     VRG_CHAOS_POINT(7);
-    if (check_done && check_done != 3 && !c.dctl[VD_GO]) return;     // the gate says: no sweep to count (the run has stopped) or this sweep's pass is left out
+    if (check_done && check_done < 3 && !c.dctl[VD_GO]) return;     // the gate says: no sweep to count (the run has stopped) or this sweep's pass is left out
     extern __shared__ __attribute__((aligned(16))) float s_val[];   // 16-bit storage: the level values (c.L floats - MODE 3: doubles -, sized at launch)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -1442,7 +1444,7 @@ __global__ void __launch_bounds__(TPB) k_recount_bits(VrgCtx c, int check_done) 
         for (uint32_t k = threadIdx.x; k < c.L; k += TPB) s_dv[k] = (double)(float)c.lev[k];
         __syncthreads();
     }
-    const uint32_t* __restrict__ cls = c.clsb[(vrg_load_i64(&c.dctl[VD_RSEQ]) + (check_done == 3 ? 0 : 1)) & 1];   // (3: the run's last sweep, counted after all)
+    const uint32_t* __restrict__ cls = c.clsb[(vrg_load_i64(&c.dctl[VD_RSEQ]) + (check_done >= 3 ? 0 : 1)) & 1];   // (3: the run's last sweep, counted after all)
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
     const uint32_t lo = (2u + (uint32_t)c.z0) * plane;         // this device's Z-slab [z0, z1) as a voxel range
     const uint32_t hi = (2u + (uint32_t)c.z1) * plane;
@@ -1519,14 +1521,14 @@ __device__ __forceinline__ void load_vals_uncond(const VrgCtx& c, uint32_t u, ui
 template <int UNITS, bool NT>
 __global__ void __launch_bounds__(TPB) k_recount_pipe(VrgCtx c, int check_done) {
     VRG_CHAOS_POINT(8);
-    if (check_done && check_done != 3 && !c.dctl[VD_GO]) return;
+    if (check_done && check_done < 3 && !c.dctl[VD_GO]) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t* __restrict__ ulist = c.ulist;
     const uint32_t n = c.uctl[UC_N];
     const uint32_t last = n ? n - 1u : 0u, stride = nwaves * UNITS;
     uint32_t i = __builtin_amdgcn_readfirstlane(wave * UNITS);     // (wave-uniform: the list is read through the scalar cache)
-    const uint32_t* __restrict__ cls = c.clsb[(vrg_load_i64(&c.dctl[VD_RSEQ]) + (check_done == 3 ? 0 : 1)) & 1];   // (3: the run's last sweep, counted after all)
+    const uint32_t* __restrict__ cls = c.clsb[(vrg_load_i64(&c.dctl[VD_RSEQ]) + (check_done >= 3 ? 0 : 1)) & 1];   // (3: the run's last sweep, counted after all)
     const uint32_t plane = (uint32_t)c.PY * (uint32_t)c.PX;
     const uint32_t lo = (2u + (uint32_t)c.z0) * plane, hi = (2u + (uint32_t)c.z1) * plane;
     uint32_t f_lo = (uint32_t)(((uint64_t)lo + 1023u) >> 10), f_hi = hi >> 10;
@@ -1955,12 +1957,13 @@ void be_destroy(VrgBackend* b) {
     if (b->sb) (void)hipStreamSynchronize(b->sb);
     if (b->comm) { ncclCommDestroy(b->comm); b->comm = nullptr; }
     for (auto& p : b->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    for (int j = 0; j < 2; j++) if (b->mark[j]) (void)hipEventDestroy(b->mark[j]);
+    for (int j = 0; j < 4; j++) if (b->mark[j]) (void)hipEventDestroy(b->mark[j]);
     if (b->tmp) (void)hipFree(b->tmp);
     if (b->keys2) (void)hipFree(b->keys2);
     if (b->sa) (void)hipStreamDestroy(b->sa);
     if (b->sb) (void)hipStreamDestroy(b->sb);
     if (b->sc) { (void)hipStreamSynchronize(b->sc); (void)hipStreamDestroy(b->sc); }
+    if (b->sd) { (void)hipStreamSynchronize(b->sd); (void)hipStreamDestroy(b->sd); }
     delete b;
 }
 void be_set_tuning(VrgBackend* b, const char* name, long long v) {
@@ -1997,7 +2000,7 @@ const char* be_last_error(VrgBackend* b) {
 }
 void be_clear_error(VrgBackend* b) { b->err[0] = 0; }
 // (the engine synchronises when a run ends or a trip was handed back: no fused sweep is waiting for its dense pass then)
-void be_sync(VrgBackend* b) { use_device(b); HIP_CHECK(hipStreamSynchronize(b->sa)); HIP_CHECK(hipStreamSynchronize(b->sb)); b->fused_prev = false; }
+void be_sync(VrgBackend* b) { use_device(b); HIP_CHECK(hipStreamSynchronize(b->sa)); HIP_CHECK(hipStreamSynchronize(b->sb)); if (b->sd) HIP_CHECK(hipStreamSynchronize(b->sd)); b->fused_prev = false; }
 
 // A device-resident input is read on the library's own stream: the caller's producer must have finished (vrg.h).
 static const void* stage_in(VrgBackend* b, const VrgCtx& c, const void* src, int dtype, void** tmp) {
@@ -2450,19 +2453,78 @@ void be_dense_flush(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
 }
 
 // ---- leader / follower replication: the follower's side, and the transports -----------------------------------------------------
-__global__ void __launch_bounds__(TPB) k_follow_apply(VrgCtx c, const VrgLogRec* __restrict__ recs, VrgLogSweep hdr) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) vrg_follow_trace(c, hdr);
-    ITEM_LOOP(hdr.nrec) vrg_follow_apply_rec(c, recs[i], hdr.sweep);
+struct FollowGroup { VrgLogSweep h[8]; int n; int count_last; };
+// label bytes and stamps: ONE workgroup, the sweeps in order (a voxel may change in consecutive sweeps) with a barrier between them.
+// Runs beside a dense pass, where every dependent load takes 2-3 us: a thread's records of a sweep are fetched together, then the label
+// bytes they name, then the stores go out - two round trips per sweep whatever its length (up to FQ x 1024 records; more: another turn).
+constexpr int FQ = 8;
+typedef uint32_t fu4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ VrgLogRec follow_rec(const VrgLogRec* p) {
+    const fu4 v = *reinterpret_cast<const fu4*>(p);
+    VrgLogRec r; r.idx = v.x; r.rank = v.y; r.old = (uint8_t)v.z; r.nw = (uint8_t)(v.z >> 8); r.pad = 0; r.pad2 = 0;
+    return r;
 }
-__global__ void __launch_bounds__(GATE_THREADS) k_follow_gate(VrgCtx c) { ulist_refresh(c, false, 0); }
-__global__ void k_follow_check(VrgCtx c, VrgLogSweep hdr) { vrg_follow_check(c, *c.dn_part, hdr.sweep, hdr.n_in, hdr.n_out); }
+__global__ void __launch_bounds__(GATE_THREADS) k_follow_labels(VrgCtx c, const VrgLogRec* __restrict__ recs, FollowGroup g) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t safe = vrg_idx(c, 0, 0, 0);
+    for (int s = 0; s < g.n; s++) {
+        const VrgLogRec* r = recs + g.h[s].rec0;
+        const uint32_t n = g.h[s].nrec, k = g.h[s].sweep;
+        for (uint32_t i0 = 0; i0 < n; i0 += FQ * GATE_THREADS) {
+            VrgLogRec q[FQ]; uint8_t have[FQ];
+#pragma unroll
+            for (int j = 0; j < FQ; j++) { const uint32_t i = i0 + j * GATE_THREADS + t; q[j] = follow_rec(r + (i < n ? i : n - 1u)); if (i >= n) q[j].idx = VRG_NONE; }
+#pragma unroll
+            for (int j = 0; j < FQ; j++) have[j] = vrg_load_coherent(c.lab[0] + (q[j].idx != VRG_NONE ? q[j].idx : safe));      // (unconditional: a load under a branch would wait for the ones before it; past L1: another wave of this workgroup may have written the byte a sweep ago)
+#pragma unroll
+            for (int j = 0; j < FQ; j++) {
+                if (q[j].idx == VRG_NONE) continue;
+                if ((uint8_t)(have[j] & (VB_LABEL | VB_OOB)) != q[j].old) {      // this rank's labels have drifted from the leader's
+                    if (c.dctl[VD_ERR] == 0) { c.dctl[VD_ERR] = 12; c.fexp[3] = (int64_t)k; c.fexp[4] = (int64_t)q[j].idx; c.fexp[5] = (int64_t)have[j]; c.fexp[6] = (int64_t)q[j].old; c.fexp[7] = (int64_t)q[j].nw; }
+                    continue;
+                }
+                c.lab[0][q[j].idx] = q[j].nw;
+                if ((q[j].nw & VB_S) && !(q[j].old & VB_S)) c.stamp[q[j].idx] = ((uint64_t)k << 32) | q[j].rank;
+            }
+        }
+        __syncthreads();
+    }
+}
+// class bits (their changes commute: no order between the sweeps - the group's records are one stretch of the batch), trace records;
+// then - when the last sweep of the group is counted next - the unit list and what the count has to reproduce
+__global__ void __launch_bounds__(GATE_THREADS) k_follow_classes(VrgCtx c, const VrgLogRec* __restrict__ recs, FollowGroup g) {
+    const uint32_t t = threadIdx.x;
+    if (t < (uint32_t)g.n) vrg_follow_trace(c, g.h[t]);
+    const uint32_t first = g.h[0].rec0, n = g.h[g.n - 1].rec0 + g.h[g.n - 1].nrec - first;
+    const VrgLogRec* r = recs + first;
+    for (uint32_t i0 = 0; i0 < n; i0 += FQ * GATE_THREADS) {
+        VrgLogRec q[FQ];
+#pragma unroll
+        for (int j = 0; j < FQ; j++) { const uint32_t i = i0 + j * GATE_THREADS + t; q[j] = follow_rec(r + (i < n ? i : n - 1u)); if (i >= n) q[j].idx = VRG_NONE; }
+#pragma unroll
+        for (int j = 0; j < FQ; j++) vrg_follow_class_rec(c, q[j]);
+    }
+    if (!g.count_last) return;
+    if (t == 0) vrg_follow_expect(c, g.h[g.n - 1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ulist_refresh(c, false, 0);
+}
 
-void be_follow_apply(VrgBackend* b, const VrgCtx& c, const VrgLogRec* recs, const VrgLogSweep* hdr) {
-    use_device(b);
-    const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>(ITEM_BLOCKS, (hdr->nrec + TPB - 1) / TPB));
-    k_follow_apply<<<blocks, TPB, 0, b->sa>>>(c, recs, *hdr);
+static hipStream_t label_stream(VrgBackend* b) {
+    if (!b->sd) HIP_CHECK(hipStreamCreateWithFlags(&b->sd, hipStreamNonBlocking));
+    return b->sd;
 }
-void be_follow_verify(VrgBackend* b, const VrgCtx& c, const VrgLogSweep* hdr, VrgEvents* ev) {
+void be_follow_apply(VrgBackend* b, const VrgCtx& c, const VrgLogRec* recs, const VrgLogSweep* hdr, int n, int count_last) {
+    use_device(b);
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        FollowGroup g; g.n = std::min(8, n - i0); g.count_last = (count_last && i0 + g.n == n) ? 1 : 0;
+        for (int i = 0; i < g.n; i++) g.h[i] = hdr[i0 + i];
+        k_follow_labels<<<1, GATE_THREADS, 0, label_stream(b)>>>(c, recs, g);
+        k_follow_classes<<<1, GATE_THREADS, 0, b->sa>>>(c, recs, g);
+    }
+}
+void be_follow_count(VrgBackend* b, const VrgCtx& c, VrgEvents* ev) {
     use_device(b);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ev && ev->enabled > 0) {
@@ -2471,20 +2533,23 @@ void be_follow_verify(VrgBackend* b, const VrgCtx& c, const VrgLogSweep* hdr, Vr
         EvPair& p = b->ev_pool[b->ev_used++];
         p.trip = 0; p.kind = 0; p.ntrips = 1; e0 = p.a; e1 = p.b;
     }
-    k_follow_gate<<<1, GATE_THREADS, 0, b->sa>>>(c);            // the units the applied sweeps listed join the list the pass walks
-    // the very pass a single GPU runs for this sweep (same kernel, same workgroups, same unit list: the same sums bit for bit), its totals into dn_part
+    // the very pass a single GPU runs for this sweep (same kernel, same workgroups, same unit list: the same sums bit for bit); its closing
+    // workgroup compares the totals with what the leader filed (check 4)
     if (b->dense_pipe && c.I && !c.lev16 && b->skip) {
-        if (dense_nt(b, c)) hipExtLaunchKernelGGL((k_recount_pipe<3, true>), dim3(dense_blocks(b, c)), dim3(TPB), 0, b->sa, e0, e1, 0, c, 3);
-        else hipExtLaunchKernelGGL((k_recount_pipe<3, false>), dim3(dense_blocks(b, c)), dim3(TPB), 0, b->sa, e0, e1, 0, c, 3);
-    } else launch_recount(c, dense_blocks(b, c), 3, b->sa, b->skip != 0, dense_nt(b, c), e0, e1);
-    k_follow_check<<<1, 1, 0, b->sa>>>(c, *hdr);
+        if (dense_nt(b, c)) hipExtLaunchKernelGGL((k_recount_pipe<3, true>), dim3(dense_blocks(b, c)), dim3(TPB), 0, b->sa, e0, e1, 0, c, 4);
+        else hipExtLaunchKernelGGL((k_recount_pipe<3, false>), dim3(dense_blocks(b, c)), dim3(TPB), 0, b->sa, e0, e1, 0, c, 4);
+    } else launch_recount(c, dense_blocks(b, c), 4, b->sa, b->skip != 0, dense_nt(b, c), e0, e1);
 }
 void be_follow_mark(VrgBackend* b, int slot) {
     use_device(b);
-    if (!b->mark[slot]) HIP_CHECK(hipEventCreateWithFlags(&b->mark[slot], hipEventDisableTiming));
-    HIP_CHECK(hipEventRecord(b->mark[slot], b->sa));
+    for (int q = 0; q < 2; q++) {                      // (both streams read the staging buffer: the class bits' and the label bytes')
+        hipEvent_t& e = b->mark[2 * slot + q];
+        if (q == 1 && !b->sd) continue;
+        if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(e, q ? b->sd : b->sa));
+    }
 }
-void be_follow_wait(VrgBackend* b, int slot) { use_device(b); if (b->mark[slot]) HIP_CHECK(hipEventSynchronize(b->mark[slot])); }
+void be_follow_wait(VrgBackend* b, int slot) { use_device(b); for (int q = 0; q < 2; q++) if (b->mark[2 * slot + q]) HIP_CHECK(hipEventSynchronize(b->mark[2 * slot + q])); }
 static hipStream_t repl_stream(VrgBackend* b) {
     if (!b->sc) HIP_CHECK(hipStreamCreateWithFlags(&b->sc, hipStreamNonBlocking));
     return b->sc;
@@ -2504,6 +2569,13 @@ int be_repl_allsum(VrgBackend* b, double* dev_buf, size_t n) {
     return 0;
 }
 void be_repl_wait(VrgBackend* b) { use_device(b); if (b->sc) HIP_CHECK(hipStreamSynchronize(b->sc)); }
+void be_repl_copy(VrgBackend* b, void* dst, const void* src, size_t bytes) {
+    use_device(b);
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, repl_stream(b)));
+    HIP_CHECK(hipStreamSynchronize(b->sc));
+}
+void* be_host_alloc(VrgBackend* b, size_t bytes) { use_device(b); void* p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; }
+void be_host_free(VrgBackend* b, void* p) { use_device(b); if (p) (void)hipHostFree(p); }
 int be_ipc_export(VrgBackend* b, void* dev_ptr, void* handle64) {
     use_device(b);
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "ipc handle size");

@@ -30,7 +30,7 @@ struct VrgRepl {
     uint8_t* buf[2] = {nullptr, nullptr};               // leader: the two batch buffers it fills in turn; follower: its two staging buffers
     size_t buf_bytes = 0;
     uint64_t seq = 0;                                   // batches published (leader) / taken (follower) since the handle was created
-    std::vector<uint8_t> host;                          // callback transport: host copy of a batch
+    uint8_t* host = nullptr; size_t host_bytes = 0;     // callback transport: host copy of a batch (page-locked)
     uint8_t* ctl = nullptr;                             // ipc transport: the leader's control block (its own allocation on the leader, mapped on a follower)
     uint8_t* peer_buf[2] = {nullptr, nullptr};          // ... and, on a follower, the leader's two batch buffers, mapped
     bool ctl_mapped = false;
@@ -250,13 +250,14 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.stage_in = alloc<VrgDense>(h, VRG_STAGE); c.stage_out = alloc<VrgDense>(h, VRG_STAGE);
     c.inc = alloc<int64_t>(h, 32); c.dctl = alloc<int64_t>(h, 32);   // one allocation each: written from different streams
     c.gate = alloc<int64_t>(h, 32);
+    c.fexp = alloc<int64_t>(h, 8);
     c.nstat = 4096;
     c.st_nin = alloc<int64_t>(h, c.nstat); c.st_nout = alloc<int64_t>(h, c.nstat);
     c.st_sin = alloc<double>(h, c.nstat); c.st_sout = alloc<double>(h, c.nstat);
     c.trace_cap = 1u << 16;
     c.trace = alloc<VrgTrace>(h, c.trace_cap);
     c.world = 1; c.ver_n = 1; c.ver_me = 0;
-    if (!c.lab[0] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.gate || !c.dn_ring || !c.exp_ring || !c.stage_in || !c.stage_out || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
+    if (!c.lab[0] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.gate || !c.fexp || !c.dn_ring || !c.exp_ring || !c.stage_in || !c.stage_out || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
         !c.nchg || !c.ubits || !c.unew[0] || !c.unew[1] || !c.ulist || !c.uctl || !c.vent || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace) { API(destroy)(h); return VRG_E_MEM; }
     be_fill(be, c.inc, 0, 32 * sizeof(int64_t)); be_fill(be, c.dctl, 0, 32 * sizeof(int64_t)); be_fill(be, c.gate, 0, 32 * sizeof(int64_t));
     be_fill(be, c.clsb[0], 0, PVu / 4); be_fill(be, c.clsb[1], 0, PVu / 4);
@@ -276,6 +277,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
 void API(destroy)(vrg_handle* h) {
     if (!h) return;
     be_sync(h->be);
+    if (h->repl.host) be_host_free(h->be, h->repl.host);
     if (h->repl.ctl_mapped) { be_ipc_close(h->be, h->repl.ctl); be_ipc_close(h->be, h->repl.peer_buf[0]); be_ipc_close(h->be, h->repl.peer_buf[1]); }
     for (void* p : h->owned) be_free(h->be, p);
     be_destroy(h->be);
@@ -493,6 +495,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     double ms0 = h->ev.ms_total; long long l0 = h->ev.launches;
     double cms0 = h->ev.chain_ms_total; long long cl0 = h->ev.chain_launches;
     auto t_begin = std::chrono::steady_clock::now();
+    VrgLogBatch pending; bool have_pending = false;        // (replicated: the batch whose trips are done, not yet sent)
     const bool no_dense = h->dense_off || (replicated && !rp.leader_verifies);      // (a leader that counts nothing enqueues no dense pass at all)
     c.dense_none = (replicated && !rp.leader_verifies) ? 1 : 0;
     const int base_flags = ((h->variant & 1) ? VRG_SWEEP_FULL : 0) | (no_dense ? VRG_SWEEP_NODENSE : 0);
@@ -513,11 +516,17 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
         }
         int32_t before = s.iter;
         be_sweep_batch(be, c, base_flags | (sync ? VRG_SWEEP_SYNC : 0) | (fuse ? VRG_SWEEP_FUSED : 0), nb, &h->ev, h->reduce_fn, h->reduce_user);
+        if (have_pending) { rc = repl_send(h, pending); have_pending = false; if (rc) return rc; }     // (the batch before, while this one runs)
         if (sync) h->sync_trips++;
         if (fuse) h->fused_trips += nb;
         s = get_state(h);
         be_events_collect(be, &h->ev, s.iter - before);
-        if (replicated) { rc = repl_publish(h, s, s.done || s.error); if (rc) return rc; }     // (the followers apply it and count their sweeps meanwhile)
+        if (replicated) {                                // the batch's change log: sent once the next batch is enqueued - or now, when there is none
+            rc = repl_close_batch(h, s, s.done || s.error, pending);
+            if (rc) return rc;
+            have_pending = true;
+            if (s.done || s.error || s.bail) { rc = repl_send(h, pending); have_pending = false; if (rc) return rc; }
+        }
         if (s.done || s.error) break;
         if (s.bail) {                                // the trip was handed back untouched: make room / change mode, do it again
             const uint64_t nf = s.nf;

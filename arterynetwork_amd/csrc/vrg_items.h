@@ -731,12 +731,13 @@ VRG_HD uint8_t vrg_sweep_core(const VrgCtx& c, const uint8_t* lab, uint32_t idx,
 
 // ---- the change log (leader / follower replication, vrg_types.h VrgLogRec): written where a label byte is written
 // place i of the sweep being applied (its records start at log position `base` = VrgState::log_pos when the apply began)
-VRG_HD void vrg_log_record(const VrgCtx& c, uint32_t base, uint32_t i, uint32_t idx, uint8_t old, uint8_t nw) {
+// (rank: the voxel's rank in the sweep's flip list where the caller has it at hand - VRG_NONE: look it up in the voxel's stamp)
+VRG_HD void vrg_log_record(const VrgCtx& c, uint32_t base, uint32_t i, uint32_t idx, uint8_t old, uint8_t nw, uint32_t rank = VRG_NONE) {
     if (!c.log_rec) return;
     const uint32_t q = base - c.log_pos0 + i;
     if (q >= c.log_cap) { vrg_store_i32(&c.stg->error, 11); return; }
     VrgLogRec r; r.idx = idx; r.rank = 0; r.old = (uint8_t)(old & (VB_LABEL | VB_OOB)); r.nw = (uint8_t)(nw & (VB_LABEL | VB_OOB)); r.pad = 0; r.pad2 = 0;
-    if (idx != VRG_NONE && (nw & VB_S) && !(old & VB_S)) r.rank = (uint32_t)c.stamp[idx];      // an applied flip-in: its rank (stamped when the flips were ordered)
+    if (idx != VRG_NONE && (nw & VB_S) && !(old & VB_S)) r.rank = rank != VRG_NONE ? rank : (uint32_t)c.stamp[idx];      // an applied flip-in: its rank (stamped when the flips were ordered)
     c.log_rec[q] = r;
 }
 // sparse relabel, phase 1: new byte of every marked voxel from the OLD labels
@@ -924,12 +925,12 @@ VRG_HD void vrg_init_counts(const VrgCtx& c) {
 
 // ------------------------------------------------------------------ the change log (leader / follower replication)
 // the header of sweep k (its labels are in place, its nrec records written), by ONE caller; the state's log counters move on
-VRG_HD void vrg_log_sweep(const VrgCtx& c, int64_t k, uint32_t base, uint32_t nsw, uint32_t nrec, int64_t n_in, int64_t n_out) {
+// (t: the sweep's trace record as the caller has just filed it)
+VRG_HD void vrg_log_sweep(const VrgCtx& c, int64_t k, uint32_t base, uint32_t nsw, uint32_t nrec, int64_t n_in, int64_t n_out, const VrgTrace& t) {
     if (!c.log_rec) return;
     const uint32_t q = nsw - c.log_nsw0;
     if (q >= c.log_swcap) { vrg_store_i32(&c.stg->error, 11); return; }
     VrgLogSweep w;
-    const VrgTrace& t = c.trace[(uint64_t)k < c.trace_cap ? k : 0];
     w.nflip = t.nflip; w.nseg = n_in; w.n_in = n_in; w.n_out = n_out; w.ni = t.ni; w.no = t.no; w.ties = t.ties; w.near_ties = t.near_ties;
     w.sweep = (uint32_t)k; w.nrec = nrec; w.rec0 = base - c.log_pos0; w.pad = 0;
     c.log_sw[q] = w;
@@ -945,12 +946,17 @@ VRG_HD void vrg_dense_none_step(const VrgCtx& c, int64_t k) {
 
 // ---- a follower applies record r of sweep k: label byte, stamp of a voxel that became segmented, class bits (BOTH copies: a follower's
 // passes and applies are in stream order, so the copies never differ), the unit bitmap through unew[0] (merged by the next refresh)
-VRG_HD void vrg_follow_apply_rec(const VrgCtx& c, const VrgLogRec& r, uint32_t k) {
+// (two halves: the label byte and stamp - sweeps in order, a voxel may change in consecutive sweeps - and the class bits, whose
+// changes commute; a follower's dense pass reads the class bits only, so the first half may run beside a pass)
+VRG_HD void vrg_follow_label_rec(const VrgCtx& c, const VrgLogRec& r, uint32_t k) {
     if (r.idx == VRG_NONE) return;
     const uint8_t have = (uint8_t)(c.lab[0][r.idx] & (VB_LABEL | VB_OOB));
     if (have != r.old) { c.dctl[VD_ERR] = 12; return; }       // this rank's labels have drifted from the leader's: nothing it counts can be trusted
     c.lab[0][r.idx] = r.nw;
     if ((r.nw & VB_S) && !(r.old & VB_S)) c.stamp[r.idx] = ((uint64_t)k << 32) | r.rank;
+}
+VRG_HD void vrg_follow_class_rec(const VrgCtx& c, const VrgLogRec& r) {
+    if (r.idx == VRG_NONE) return;
     const uint32_t a = vrg_cls_of(r.old), b = vrg_cls_of(r.nw);
     if (a == b) return;
     uint32_t dw, sh; vrg_cls_pos(r.idx, dw, sh);
@@ -958,6 +964,8 @@ VRG_HD void vrg_follow_apply_rec(const VrgCtx& c, const VrgLogRec& r, uint32_t k
     if (a == 0u) vrg_list_unit(c, r.idx, 0, 1u << ((r.idx >> 10) & 31u));
     vrg_atomic_xor(&c.clsb[0][dw], x); vrg_atomic_xor(&c.clsb[1][dw], x);
 }
+// the sweep whose count is next: what it has to reproduce (read by the pass's closing workgroup)
+VRG_HD void vrg_follow_expect(const VrgCtx& c, const VrgLogSweep& w) { c.fexp[0] = (int64_t)w.sweep; c.fexp[1] = w.n_in; c.fexp[2] = w.n_out; }
 // ... and files the sweep's trace record from its header (one caller); the sums come from whoever counts the sweep
 VRG_HD void vrg_follow_trace(const VrgCtx& c, const VrgLogSweep& w) {
     if ((uint64_t)w.sweep >= c.trace_cap) return;
@@ -967,7 +975,9 @@ VRG_HD void vrg_follow_trace(const VrgCtx& c, const VrgLogSweep& w) {
 }
 // the pass over sweep k's labels is done (totals d): against the sizes the leader filed; the sums into the trace
 VRG_HD void vrg_follow_check(const VrgCtx& c, const VrgDense& d, uint32_t k, int64_t n_in, int64_t n_out) {
-    if ((int64_t)d.n_in != n_in || (int64_t)d.n_out != n_out) c.dctl[VD_ERR] = 5;
+    if (((int64_t)d.n_in != n_in || (int64_t)d.n_out != n_out) && c.dctl[VD_ERR] == 0) {      // (the first mismatch is kept for the error message)
+        c.dctl[VD_ERR] = 5; c.fexp[3] = (int64_t)k; c.fexp[4] = (int64_t)d.n_in; c.fexp[5] = (int64_t)d.n_out; c.fexp[6] = n_in; c.fexp[7] = n_out;
+    }
     if ((uint64_t)k < c.trace_cap) { c.trace[k].sum_in = d.sum_in; c.trace[k].sum_out = d.sum_out; }
     *c.dn = d;
 }
@@ -1010,15 +1020,18 @@ VRG_HD VrgState vrg_finalize_load(const VrgCtx& c, int64_t& n_in, int64_t& n_out
     n_in = vrg_load_i64(&c.inc[VC_NIN]); n_out = vrg_load_i64(&c.inc[VC_NOUT]);
     return s;
 }
-VRG_HD void vrg_finalize_update(const VrgCtx& c, VrgState& s, int64_t n_in, int64_t n_out, bool use_tab) {
+// (tr: the integer fields of the sweep's trace record, for the caller's change log)
+VRG_HD void vrg_finalize_update(const VrgCtx& c, VrgState& s, int64_t n_in, int64_t n_out, bool use_tab, VrgTrace& tr) {
     const uint32_t used = vrg_free_used(s.nalloc, s.nfree);
     s.np += s.nalloc - used; s.nfree = s.nfree - used + s.ndead;
     s.ni = (uint32_t)((int32_t)s.ni + s.d_ni); s.no = (uint32_t)((int32_t)s.no + s.d_no);
     s.iter++;
+    tr.nflip = s.nf; tr.nseg = n_in; tr.n_in = n_in; tr.n_out = n_out; tr.ni = s.ni; tr.no = s.no;
+    tr.ties = s.ties - s.ties_filed; tr.near_ties = s.near_ties - s.near_filed; tr.sum_in = 0; tr.sum_out = 0;
     if ((uint32_t)s.iter < c.trace_cap) {
         VrgTrace& t = c.trace[s.iter];                // the intensity sums are filed by the dense pass (vrg_dense_fin)
-        t.nflip = s.nf; t.nseg = n_in; t.n_in = n_in; t.n_out = n_out; t.ni = s.ni; t.no = s.no;
-        t.ties = s.ties - s.ties_filed; t.near_ties = s.near_ties - s.near_filed;
+        t.nflip = tr.nflip; t.nseg = n_in; t.n_in = n_in; t.n_out = n_out; t.ni = tr.ni; t.no = tr.no;
+        t.ties = tr.ties; t.near_ties = tr.near_ties;
     }
     s.ties_filed = s.ties; s.near_filed = s.near_ties;
     s.last_nf = s.nf;
@@ -1032,9 +1045,10 @@ VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
     int64_t n_in, n_out;
     VrgState s = vrg_finalize_load(c, n_in, n_out);
     const uint32_t nrec = s.nmk < c.mcap ? s.nmk : c.mcap;
-    vrg_finalize_update(c, s, n_in, n_out, use_tab);
+    VrgTrace tr;
+    vrg_finalize_update(c, s, n_in, n_out, use_tab, tr);
     *c.stg = s;
-    vrg_log_sweep(c, (int64_t)s.iter, s.log_pos, s.log_nsw, nrec, n_in, n_out);
+    vrg_log_sweep(c, (int64_t)s.iter, s.log_pos, s.log_nsw, nrec, n_in, n_out, tr);
     vrg_dense_none_step(c, (int64_t)s.iter);
 }
 // vrg_post_apply + vrg_request_dense + vrg_finalize by the ONE thread that closes a sweep in a kernel, as two round trips
@@ -1048,9 +1062,10 @@ VRG_HD void vrg_close_sweep(const VrgCtx& c, int64_t nchg_at, bool use_tab) {
     vrg_store_i64(&c.exp_ring[2 * (k % VRG_RING)], n_in); vrg_store_i64(&c.exp_ring[2 * (k % VRG_RING) + 1], n_out);
     c.nchg[(k & 1) ^ 1] = 0;
     if (nchg_at >= 0) c.nchg[k & 1] = (uint32_t)nchg_at;
-    vrg_finalize_update(c, s, n_in, n_out, use_tab);
+    VrgTrace tr;
+    vrg_finalize_update(c, s, n_in, n_out, use_tab, tr);
     *c.stg = s;
-    vrg_log_sweep(c, k, s.log_pos, s.log_nsw, nrec, n_in, n_out);
+    vrg_log_sweep(c, k, s.log_pos, s.log_nsw, nrec, n_in, n_out, tr);
     vrg_dense_none_step(c, k);
     vrg_drain(); vrg_store_i64(&c.gate[VG_REQ], k);
 }
@@ -1083,7 +1098,7 @@ template <int NLEV> struct VrgFuseLdsT {
     uint32_t tile[81 * 4];                                             // 9x9x9 label bytes around the workgroup's flip (rows of 16 bytes)
     uint16_t rank[729];                                                // ... rank of the flip sitting there (0xffff: none)
     uint32_t any_pend, changed;
-    uint32_t n[3], base[3], nvis; int32_t d[4];                        // this workgroup's new / dead / pending events, visited flips, list and size changes
+    uint32_t n[4], base[4], nvis; int32_t d[4];                        // this workgroup's new / dead / pending events / change-log records, visited flips, list and size changes
     double lev[NLEV];                                                  // the level table (small level tables; a large one is never searched: VrgCtx::lidx)
 };
 typedef VrgFuseLdsT<VRG_FUSE_LEVELS> VrgFuseLds;
@@ -1094,6 +1109,7 @@ struct VrgFuseThread {                                                 // what a
     VrgPre pre;                                                        // per-voxel fields of cube place t
     float valf; double val64; uint16_t l16; uint32_t l32;              // ... its intensity as loaded (whichever storage the volume has: converted when used), its level index
     VrgEvent ev; uint32_t rn, rd, rf;
+    uint32_t lg_idx, lg_rank, lg_at; uint8_t lg_old, lg_new, lg_on;    // this place's change-log record (a label byte that changes), its number inside the workgroup
 };
 template <class LDS>
 VRG_HD uint32_t vrg_fuse_level_of(const LDS& sh, uint32_t L, double v) {   // vrg_level_of on the LDS copy of the table
@@ -1132,7 +1148,7 @@ template <class LDS>
 VRG_HD void vrg_fuse_init(LDS& sh, uint32_t t) {
     for (uint32_t i = t; i < 729u; i += VRG_FUSE_THREADS) sh.rank[i] = 0xffffu;
     if (t < (uint32_t)VRG_FUSE_MAX) { sh.f_L[t] = 0; sh.f_FI[t] = 0; }
-    if (t < 3) sh.n[t] = 0;
+    if (t < 4) sh.n[t] = 0;
     if (t < 4) sh.d[t] = 0;
     if (t == 0) { sh.any_pend = 0; sh.changed = 0; sh.nvis = 0; }
 }
@@ -1269,7 +1285,7 @@ VRG_HD void vrg_fuse_annotate(const VrgCtx& c, LDS& sh, uint32_t t, uint32_t r, 
 // (vrg_mark_wanted: 1-ring of a listed flip; 2-ring too for an excluded voxel)?  Then the relabel stencil from the tile.
 template <class LDS>
 VRG_HD void vrg_fuse_stencil(const VrgCtx& c, LDS& sh, VrgFuseThread& th, uint32_t t, uint32_t r) {
-    th.ev.kind = VE_NONE; th.ev.pend = 0; th.rn = th.rd = th.rf = 0;
+    th.ev.kind = VE_NONE; th.ev.pend = 0; th.rn = th.rd = th.rf = 0; th.lg_on = 0;
     if (t >= 125u) return;
     const uint32_t place = r * (uint32_t)VRG_FUSE_PLACES + t;
     const int dx = (int)(t % 5u) - 2, dy = (int)((t / 5u) % 5u) - 2, dz = (int)(t / 25u) - 2;
@@ -1338,6 +1354,12 @@ VRG_HD void vrg_fuse_stencil(const VrgCtx& c, LDS& sh, VrgFuseThread& th, uint32
     else if (!(mb & VB_B) && ((mb & VB_S) ? FO != 0u : (AP != 0u || (mb & VB_X)))) lev_here = (c.lev16 || c.lidx) ? th.pre.lev16 : vrg_fuse_level_of(sh, c.L, th.pre.val);
     const uint8_t nw = vrg_sweep_cases(c, m, mb, th.pre, nb, q, ring2, lev_here, th.ev);
     c.mk_idx[place] = m; c.mk_new[place] = nw; c.mk_old[place] = mb;
+    // the change log of a fused sweep: only label bytes that change, compacted - the record takes a number inside the workgroup here, the
+    // workgroup's stretch of the log is reserved with its event lists (vrg_fuse_reserve), the record written with them (vrg_fuse_commit)
+    if (c.log_rec && ((mb ^ nw) & (VB_LABEL | VB_OOB))) {
+        th.lg_on = 1; th.lg_idx = m; th.lg_rank = th.pre.rank; th.lg_old = mb; th.lg_new = nw;
+        th.lg_at = vrg_lds_add(&sh.n[3], 1u);
+    }
     if (mb & VB_L) vrg_lds_add(&sh.nvis, 1u);
     const uint32_t a = vrg_cls_of(mb), b = vrg_cls_of(nw);             // region sizes (:113-116): kept by increments
     const int din = (int)(b == 1u) - (int)(a == 1u), dout = (int)(b == 2u) - (int)(a == 2u);
@@ -1357,6 +1379,7 @@ VRG_HD void vrg_fuse_reserve(const VrgCtx& c, LDS& sh, uint32_t t) {
     if (t < 3u) { if (sh.n[t]) sh.base[t] = vrg_atomic_add(t == 0 ? &c.stg->nalloc : t == 1 ? &c.stg->ndead : &c.stg->nfresh, sh.n[t]); }
     else if (t < 7u) { if (sh.d[t - 3u]) vrg_atomic_add(t == 3 ? &c.stg->d_ni : t == 4 ? &c.stg->d_no : t == 5 ? &c.stg->d_nin : &c.stg->d_nout, sh.d[t - 3u]); }
     else if (t == 7u) { if (sh.nvis) vrg_atomic_add(&c.stg->nvisit, sh.nvis); }
+    else if (t == 8u) { if (sh.n[3]) sh.base[3] = c.st->log_pos + vrg_atomic_add(&c.stg->log_n, sh.n[3]); }     // (log_pos: the same in every workgroup's snapshot - only the closing thread moves it)
 }
 // ... and every event is written at its place; the workgroup's flip gets its stamp = (sweep, rank) (:200: segmented's list order)
 template <class LDS>
@@ -1366,6 +1389,7 @@ VRG_HD void vrg_fuse_commit(const VrgCtx& c, const LDS& sh, const VrgFuseThread&
         const uint32_t m = (uint32_t)((int64_t)sh.f_idx[r] + ((int64_t)dz * c.PY + dy) * c.PX + dx);
         vrg_ev_write(c, m, th.ev, sh.base[0] + th.rn, sh.base[1] + th.rd, sh.base[2] + th.rf);
     }
+    if (th.lg_on) vrg_log_record(c, sh.base[3], th.lg_at, th.lg_idx, th.lg_old, th.lg_new, th.lg_rank);
     if (t == 0) c.stamp[sh.f_idx[r]] = ((uint64_t)(uint32_t)(c.st->iter + 1) << 32) | r;
 }
 // the touched levels of the sweep in ascending order with their counts (for the next k_band's corrections, :236-247), the
@@ -1402,9 +1426,10 @@ VRG_HD void vrg_fuse_memo_terms(const VrgCtx& c, uint32_t l, uint32_t lane, uint
 VRG_HD VrgState vrg_fuse_close_load(const VrgCtx& c, int64_t& n_in, int64_t& n_out) {
     VrgState s = vrg_finalize_load(c, n_in, n_out);
     s.d_nin = vrg_load_i32(&c.stg->d_nin); s.d_nout = vrg_load_i32(&c.stg->d_nout); s.nvisit = vrg_load_u32(&c.stg->nvisit);
-    s.nnz_new = vrg_load_u32(&c.stg->nnz_new);
+    s.nnz_new = vrg_load_u32(&c.stg->nnz_new); s.log_n = vrg_load_u32(&c.stg->log_n);
     return s;
 }
+// (the sweep's change-log records, compacted by the workgroups' reservations: s.log_n of them from s.log_pos on)
 VRG_HD void vrg_fuse_close(const VrgCtx& c, VrgState s, int64_t n_in, int64_t n_out, uint32_t nnz, bool use_tab) {
     n_in += s.d_nin; n_out += s.d_nout;
     if (s.nvisit != s.nf && !s.error) s.error = 3;        // a listed flip the stencils never visited
@@ -1415,16 +1440,20 @@ VRG_HD void vrg_fuse_close(const VrgCtx& c, VrgState s, int64_t n_in, int64_t n_
     c.nchg[k & 1] = places;                               // (filed by the deferred apply: a change sits at its voxel's place)
     const uint32_t used = vrg_free_used(s.nalloc, s.nfree), fr_base = s.nfree - used, fr_n = s.ndead;
     s.nnz = nnz;
-    vrg_finalize_update(c, s, n_in, n_out, use_tab);
+    VrgTrace tr;
+    vrg_finalize_update(c, s, n_in, n_out, use_tab, tr);
     s.apply_pending = 1; s.ap_n = places; s.fr_base = fr_base; s.fr_n = fr_n;
+    const uint32_t log_open = s.log_pos, log_n = s.log_n;
+    if (c.log_rec) { s.log_pos += log_n; s.log_nsw += 1u; }     // (with the state's one store; vrg_log_sweep files the header)
+    s.log_n = 0;
     *c.stg = s;
+    vrg_log_sweep(c, k, log_open, s.log_nsw - (c.log_rec ? 1u : 0u), log_n, n_in, n_out, tr);
 }
 
 // ---- what the fused sweep left for the next trip's k_band (sweep k = the state's iter: already counted)
 // (place i of the marked list, its three fields fetched by the caller - several places in one batch)
-VRG_HD void vrg_deferred_apply_vals(const VrgCtx& c, uint32_t i, int k, uint32_t idx, uint8_t old, uint8_t nw, uint32_t log_base) {
+VRG_HD void vrg_deferred_apply_vals(const VrgCtx& c, uint32_t i, int k, uint32_t idx, uint8_t old, uint8_t nw) {
     const int p = k & 1;
-    vrg_log_record(c, log_base, i, idx, old, nw);
     if (idx == VRG_NONE) { c.chg_dw[p][i] = VRG_NOCHG; return; }
     c.lab[0][idx] = nw;                                    // (clean: no L / P / mark bits - the fused sweep never wrote any)
     const uint32_t a = vrg_cls_of(old), b = vrg_cls_of(nw);
@@ -1438,7 +1467,7 @@ VRG_HD void vrg_deferred_apply_vals(const VrgCtx& c, uint32_t i, int k, uint32_t
     vrg_atomic_xor(&c.clsb[p][dw], x);
     c.chg_dw[p][i] = dw; c.chg_x[p][i] = x;
 }
-VRG_HD void vrg_deferred_apply(const VrgCtx& c, uint32_t i, int k, uint32_t log_base) { vrg_deferred_apply_vals(c, i, k, c.mk_idx[i], c.mk_old[i], c.mk_new[i], log_base); }
+VRG_HD void vrg_deferred_apply(const VrgCtx& c, uint32_t i, int k) { vrg_deferred_apply_vals(c, i, k, c.mk_idx[i], c.mk_old[i], c.mk_new[i]); }
 VRG_HD void vrg_deferred_catchup(const VrgCtx& c, uint32_t i, int k) {   // change i of sweep k-1: class copy k & 1 sat that sweep out
     const int p = k & 1;
     const uint32_t dw = c.chg_dw[p ^ 1][i], x = c.chg_x[p ^ 1][i];
@@ -1448,11 +1477,9 @@ VRG_HD uint32_t vrg_deferred_catchup_count(const VrgCtx& c, int k) { const uint3
 VRG_HD void vrg_deferred_free(const VrgCtx& c, const VrgState& s, uint32_t j) { c.freel[s.fr_base + j] = c.dead[j]; }
 // one caller, once all of the above has reached memory: the list of sweep k-1 is consumed, the labels of sweep k are in place -
 // its dense pass is due
-// (s: the state as the trip found it - what the sweep's closing thread left)
-VRG_HD void vrg_deferred_done(const VrgCtx& c, const VrgState& s, int k) {
+VRG_HD void vrg_deferred_done(const VrgCtx& c, int k) {
     c.nchg[(k & 1) ^ 1] = 0;
     c.stg->apply_pending = 0; c.stg->fr_n = 0;
-    vrg_log_sweep(c, k, s.log_pos, s.log_nsw, s.ap_n, vrg_load_i64(&c.exp_ring[2 * (k % VRG_RING)]), vrg_load_i64(&c.exp_ring[2 * (k % VRG_RING) + 1]));
     vrg_dense_none_step(c, k);
     vrg_drain(); vrg_store_i64(&c.gate[VG_REQ], (int64_t)k);
 }

@@ -48,12 +48,23 @@ static bool repl_alloc_buffers(vrg_handle* h, uint32_t cap) {
     return true;
 }
 
+static uint8_t* repl_host(vrg_handle* h, size_t bytes) {       // the callback transport's page-locked buffer, at least `bytes` long
+    VrgRepl& r = h->repl;
+    if (bytes > r.host_bytes) {
+        if (r.host) be_host_free(h->be, r.host);
+        r.host_bytes = pow2_at_least(std::max<size_t>(bytes, 1u << 16));
+        r.host = (uint8_t*)be_host_alloc(h->be, r.host_bytes);
+        if (!r.host) r.host_bytes = 0;
+    }
+    return r.host;
+}
+
 // bounded polling of a 64-bit counter in device memory (possibly another process's, mapped): true once *word >= want
 static bool repl_poll(vrg_handle* h, const uint8_t* base, size_t word, uint64_t want, double timeout_s) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; spins++) {
         uint64_t v = 0;
-        be_download(h->be, &v, base + 8 * word, 8);
+        be_repl_copy(h->be, &v, base + 8 * word, 8);
         if (v >= want) return true;
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
         if (spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(50));
@@ -75,33 +86,39 @@ static int repl_open_batch(vrg_handle* h, const VrgState& s) {
     c.log_pos0 = s.log_pos; c.log_nsw0 = s.log_nsw;
     return VRG_OK;
 }
-// after the batch (the band stream is idle: the engine has read the state): header, then off it goes
-static int repl_publish(vrg_handle* h, const VrgState& s, bool final) {
+// after the batch (the band stream is idle: the engine has read the state): its header
+static int repl_close_batch(vrg_handle* h, const VrgState& s, bool final, VrgLogBatch& hb) {
     VrgRepl& r = h->repl;
     const VrgCtx& c = h->c;
-    const uint64_t n = ++r.seq;
-    uint8_t* buf = r.buf[(n - 1) & 1];
-    VrgLogBatch hb; std::memset(&hb, 0, sizeof(hb));
-    hb.seq = n; hb.nsw = s.log_nsw - c.log_nsw0; hb.nrec = s.log_pos - c.log_pos0;
+    std::memset(&hb, 0, sizeof(hb));
+    hb.seq = ++r.seq; hb.nsw = s.log_nsw - c.log_nsw0; hb.nrec = s.log_pos - c.log_pos0;
     hb.final = final ? 1 : 0; hb.stop_reason = s.done; hb.iter = s.iter; hb.error = s.error;
     int64_t sizes[2]; be_download(h->be, sizes, c.inc, sizeof(sizes));
     hb.n_in = sizes[0]; hb.n_out = sizes[1]; hb.ni = s.ni; hb.no = s.no; hb.ties = s.ties; hb.near_ties = s.near_ties;
     if (hb.nsw > r.swcap || hb.nrec > r.cap) return fail(h, VRG_E_INTERNAL, "replication: the batch overran its change log");
-    be_upload(h->be, buf, &hb, sizeof(hb));
-    const size_t hbb = repl_hb_bytes(r.swcap), rb = (size_t)hb.nrec * sizeof(VrgLogRec);
     r.batches++; r.records += hb.nrec; r.sweeps += hb.nsw;
+    return VRG_OK;
+}
+// ... and off it goes - while the NEXT batch's trips already run: everything here uses the transport stream (the band stream is busy)
+static int repl_send(vrg_handle* h, const VrgLogBatch& hb) {
+    VrgRepl& r = h->repl;
+    const uint64_t n = hb.seq;
+    uint8_t* buf = r.buf[(n - 1) & 1];
+    be_repl_copy(h->be, buf, &hb, sizeof(hb));
+    const size_t hbb = repl_hb_bytes(r.swcap), rb = (size_t)hb.nrec * sizeof(VrgLogRec);
     switch (r.transport) {
-    case TR_CALLBACK:
-        r.host.resize(hbb + rb);
-        be_download(h->be, r.host.data(), buf, hbb);
-        r.bcast(r.host.data(), (int64_t)hbb, 0, r.user);
-        if (rb) { be_download(h->be, r.host.data() + hbb, buf + hbb, rb); r.bcast(r.host.data() + hbb, (int64_t)rb, 0, r.user); }
-        break;
+    case TR_CALLBACK: {
+        uint8_t* hp = repl_host(h, hbb + rb);
+        if (!hp) return fail(h, VRG_E_MEM, "replication: host buffer");
+        be_repl_copy(h->be, hp, buf, hbb);
+        r.bcast(hp, (int64_t)hbb, 0, r.user);
+        if (rb) { be_repl_copy(h->be, hp + hbb, buf + hbb, rb); r.bcast(hp + hbb, (int64_t)rb, 0, r.user); }
+        break; }
     case TR_RCCL:
         if (be_repl_bcast(h->be, buf, hbb, 0) || (rb && be_repl_bcast(h->be, buf + hbb, rb, 0))) return fail(h, VRG_E_INTERNAL, "replication: RCCL broadcast failed");
         break;
     case TR_IPC:
-        be_upload(h->be, r.ctl + 8 * IPC_READY, &n, 8);
+        be_repl_copy(h->be, r.ctl + 8 * IPC_READY, &n, 8);
         break;
     default: break;
     }
@@ -139,12 +156,16 @@ static int repl_receive(vrg_handle* h, VrgLogBatch& hb, std::vector<uint8_t>& hb
         std::memcpy(&hb, hblock.data(), sizeof(hb));
         if (!grow_for(hb.nrec)) return fail(h, VRG_E_MEM, "replication: staging buffers");
         const size_t rb = (size_t)hb.nrec * sizeof(VrgLogRec);
-        if (rb) { r.host.resize(rb); r.bcast(r.host.data(), (int64_t)rb, 0, r.user); be_upload(h->be, staging + hbb, r.host.data(), rb); }
+        if (rb) {
+            uint8_t* hp = repl_host(h, rb);
+            if (!hp) return fail(h, VRG_E_MEM, "replication: host buffer");
+            r.bcast(hp, (int64_t)rb, 0, r.user); be_repl_copy(h->be, staging + hbb, hp, rb);
+        }
         break; }
     case TR_RCCL: {
         if (be_repl_bcast(h->be, staging, hbb, 0)) return fail(h, VRG_E_INTERNAL, "replication: RCCL broadcast failed");
         be_repl_wait(h->be);
-        be_download(h->be, hblock.data(), staging, hbb);
+        be_repl_copy(h->be, hblock.data(), staging, hbb);
         std::memcpy(&hb, hblock.data(), sizeof(hb));
         uint8_t* first = staging;
         if (!grow_for(hb.nrec)) return fail(h, VRG_E_MEM, "replication: staging buffers");
@@ -155,12 +176,12 @@ static int repl_receive(vrg_handle* h, VrgLogBatch& hb, std::vector<uint8_t>& hb
     case TR_IPC: {
         if (!repl_poll(h, r.ctl, IPC_READY, n, 300.0)) return fail(h, VRG_E_INTERNAL, "replication: the leader did not publish batch " + std::to_string(n) + " of the change log");
         const uint8_t* src = r.peer_buf[(n - 1) & 1];
-        be_download(h->be, hblock.data(), src, hbb);
+        be_repl_copy(h->be, hblock.data(), src, hbb);
         std::memcpy(&hb, hblock.data(), sizeof(hb));
         if (hb.nrec > r.cap) return fail(h, VRG_E_CAPACITY, "replication: the leader's batch does not fit this rank's staging buffer");
         const size_t rb = (size_t)hb.nrec * sizeof(VrgLogRec);
-        if (rb) { be_copy(h->be, staging + hbb, src + hbb, rb); be_sync(h->be); }
-        be_upload(h->be, r.ctl + 8 * (IPC_ACK + r.rank), &n, 8);     // (copied out: the leader may write that buffer again)
+        if (rb) be_repl_copy(h->be, staging + hbb, src + hbb, rb);
+        be_repl_copy(h->be, r.ctl + 8 * (IPC_ACK + r.rank), &n, 8);     // (copied out: the leader may write that buffer again)
         break; }
     default: return fail(h, VRG_E_STATE, "replication: no transport set");
     }
@@ -181,10 +202,15 @@ static int repl_follow(vrg_handle* h, VrgLogBatch& last) {
         if (rc) return rc;
         const VrgLogSweep* sw = reinterpret_cast<const VrgLogSweep*>(hblock.data() + sizeof(VrgLogBatch));
         VrgLogRec* recs = repl_rec_of(r, staging);
+        // the sweeps up to the next one this rank counts go in one step (the sweeps between two counts: N - 2 of them)
+        uint32_t first = 0;
         for (uint32_t i = 0; i < hb.nsw; i++) {
             if ((uint64_t)sw[i].rec0 + sw[i].nrec > hb.nrec) return fail(h, VRG_E_INTERNAL, "replication: a sweep's records lie outside its batch");
-            be_follow_apply(h->be, c, recs + sw[i].rec0, &sw[i]);
-            if (!vrg_dense_skipped((int64_t)sw[i].sweep, h->verify_every, nver, me)) { be_follow_verify(h->be, c, &sw[i], &h->ev); r.verified++; r.last_verified = sw[i].sweep; }
+            const bool mine = !vrg_dense_skipped((int64_t)sw[i].sweep, h->verify_every, nver, me);
+            if (!mine && i + 1 < hb.nsw) continue;
+            be_follow_apply(h->be, c, recs, sw + first, (int)(i + 1 - first), mine ? 1 : 0);
+            if (mine) { be_follow_count(h->be, c, &h->ev); r.verified++; r.last_verified = sw[i].sweep; }
+            first = i + 1;
         }
         be_follow_mark(h->be, (int)((hb.seq - 1) & 1));
         last = hb;
@@ -238,21 +264,29 @@ static int repl_finish(vrg_handle* h, int32_t iter0, int32_t iter, int64_t n_in,
     VrgRepl& r = h->repl;
     const VrgCtx& c = h->c;
     const int nver = repl_verifiers(r);
-    if (iter > iter0 && !error && vrg_dense_skipped(iter, h->verify_every, 1, 0)) {
-        // left out by verify_every: the first verifier counts it after all, so that no run returns unchecked
-        if (r.leader_verifies ? r.rank == 0 : r.rank == 1) {
+    if (iter > iter0 && !error && (nver < 1 || vrg_dense_skipped(iter, h->verify_every, 1, 0))) {
+        // left out by verify_every (or a leader alone that counts nothing): the first verifier counts it after all, so that no run returns unchecked
+        if (r.rank == ((r.leader_verifies || r.nranks == 1) ? 0 : 1)) {
             if (r.rank == 0) be_verify_last(h->be, c, nullptr, nullptr);
             else {
                 VrgLogSweep w; std::memset(&w, 0, sizeof(w));
                 VrgTrace t; be_download(h->be, &t, c.trace + iter, sizeof(t));
                 w.nflip = t.nflip; w.nseg = t.nseg; w.n_in = n_in; w.n_out = n_out; w.ni = t.ni; w.no = t.no; w.ties = t.ties; w.near_ties = t.near_ties; w.sweep = (uint32_t)iter;
-                be_follow_verify(h->be, c, &w, nullptr);
+                be_follow_apply(h->be, c, nullptr, &w, 1, 1);             // (no records: the sweep is applied; its trace record again, the unit list, what to reproduce)
+                be_follow_count(h->be, c, nullptr);
             }
         }
     }
-    (void)nver;
     be_sync(h->be);
     int64_t derr = 0; be_download(h->be, &derr, c.dctl + VD_ERR, sizeof(derr));
+    if (derr == 12) {
+        int64_t f[8]; be_download(h->be, f, c.fexp, sizeof(f));
+        std::fprintf(stderr, "[vrg rank %d] sweep %lld: voxel %lld holds label byte %lld, the log says %lld -> %lld\n", r.rank, (long long)f[3], (long long)f[4], (long long)f[5], (long long)f[6], (long long)f[7]);
+    }
+    if (derr == 5 && r.rank > 0) {                    // (say which sweep, for whoever reads the log of this rank)
+        int64_t f[8]; be_download(h->be, f, c.fexp, sizeof(f));
+        std::fprintf(stderr, "[vrg rank %d] sweep %lld: counted n_in %lld n_out %lld, the leader filed %lld / %lld\n", r.rank, (long long)f[3], (long long)f[4], (long long)f[5], (long long)f[6], (long long)f[7]);
+    }
     const size_t ns = (size_t)std::max(0, iter - iter0);
     std::vector<VrgTrace> tr(ns + 1);
     if (ns) be_download(h->be, tr.data(), c.trace + iter0 + 1, ns * sizeof(VrgTrace));

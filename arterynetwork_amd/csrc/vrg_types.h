@@ -118,6 +118,7 @@ struct VrgState {
     // the change log (leader / follower replication, VrgCtx::log_rec): records and sweep headers written since init - monotone
     // counters; a launch knows where its batch's buffer starts (VrgCtx::log_pos0 / log_nsw0)
     uint32_t log_pos, log_nsw;
+    uint32_t log_n;                    // fused sweep in progress: records its workgroups have reserved so far (atomic count; log_pos itself moves when the sweep closes)
 };
 
 // ---- the change log: what a sweep did to the label volume, for the ranks that do not run the band chain themselves ------------------
@@ -301,6 +302,7 @@ struct VrgCtx {
     // which dense passes this handle counts: sweep k is counted by verifier ((k / every) - 1) % ver_n (vrg_dense_skipped); ver_me = this
     // handle's place among the verifiers, -1: it counts none.  One GPU: ver_n = 1, ver_me = 0.
     int32_t ver_n, ver_me;
+    int64_t* fexp;             // a follower's next count: {sweep, n_in, n_out} it has to reproduce
     int32_t dense_none;        // no dense pass is enqueued at all (a leader that verifies nothing): the band side keeps the pass counters in step itself
     uint32_t* counters;        // arrival tickets of the last-workgroup reductions (zero between launches)
     uint64_t* dbg;             // diagnostic build only (-DVRG_STAMPS): in-kernel time stamps of the band chain, see tools/chain_stamps.py

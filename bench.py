@@ -312,7 +312,14 @@ def main():
     ap.add_argument('--storage16', action='store_true', help='16-bit intensity storage (level indices): config 5 style; 4 B/voxel-iter algorithmic')
     ap.add_argument('--tubes', type=int, default=1, help='disjoint tubes of the synthetic volume (SURVEY 8(d) config 5: "several disjoint tubes"): about 100 flips per tube and sweep')
     ap.add_argument('--seed-mode', default='planes', choices=['planes', 'whole'], help="'whole': every tube voxel is a seed (what refine() does with a stage-1 mask)")
-    ap.add_argument('--force-dist', action='store_true', help='use the N>1 code path (RCCL comm) even with one rank')
+    ap.add_argument('--force-dist', action='store_true', help='one GPU: measure the roles of an N-rank group one after the other (replica partition), or run the '
+                    'N>1 code path with a one-rank communicator (zslab partition)')
+    ap.add_argument('--partition', default='replica', choices=['replica', 'zslab'], help="N > 1: 'replica' = one leader (band chain + change log), the other ranks apply the "
+                    "log and count the sweeps round robin over the whole volume (DESIGN.md section 7); 'zslab' = every rank repeats the band chain, the dense pass is cut into Z-slabs")
+    ap.add_argument('--transport', default='rccl', choices=['rccl', 'ipc', 'callback'], help='replica partition: how the change log travels')
+    ap.add_argument('--leader-verifies', type=int, default=-1, help='replica partition: 1 / 0 = the leader counts a share of the sweeps / only leads; -1 = by the number of ranks (<= 4: it counts)')
+    ap.add_argument('--repl-batch', type=int, default=32, help='replica partition: trips per batch of the change log')
+    ap.add_argument('--proxy-world', type=int, default=8, help='--force-dist with the replica partition: ranks of the group whose roles are measured')
     args = ap.parse_args()
     shape = tuple(int(s) for s in args.shape.lower().split('x'))
     assert len(shape) == 3
@@ -345,7 +352,14 @@ def main():
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=dev)
         try:
-            out = slabs.bench_slabs(shape, args, dev, rank, world, roofline, configure, load_traffic)
+            if args.partition == 'zslab':
+                out = slabs.bench_slabs(shape, args, dev, rank, world, roofline, configure, load_traffic)
+            elif world == 1:
+                from arterynetwork_amd import replica
+                out = replica.bench_proxy(shape, args, dev, roofline, configure, load_traffic)
+            else:
+                from arterynetwork_amd import replica
+                out = replica.bench_replicas(shape, args, dev, rank, world, roofline, configure, load_traffic)
         except Exception:
             import traceback
             sys.stderr.write('[rank {} of {}] bench_slabs failed:\n{}'.format(rank, world, traceback.format_exc()))
@@ -355,7 +369,7 @@ def main():
             print(json.dumps(out), flush=True)
         dist.barrier()
         dist.destroy_process_group()
-        if out['config']['rccl_ranks'] != world:            # the data path must be RCCL over all ranks, or the line is not the N-GPU line
+        if out['config']['rccl_ranks'] != world and not (args.partition == 'replica' and out['config'].get('transport') == 'ipc'):   # the data path must be RCCL (or hipIpc) over all ranks, or the line is not the N-GPU line
             raise SystemExit(3)
         return
 

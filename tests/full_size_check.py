@@ -208,7 +208,90 @@ def slabs_one_gpu(world, shape, sweeps):
           'slab counts add up every sweep (nseg %d -> %d)' % ('x'.join(map(str, shape)), world, sorted(set(planes)), sweeps, ref_tr['nseg'][0], ref_tr['nseg'][-1]))
 
 
+def replica_worker(rank, world, port, shape, sweeps, outdir, transport, leader_verifies):
+    """One rank of a leader / follower group, every rank on GPU 0 (own process, own HIP context)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from arterynetwork_amd import replica
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    I, vm = phantoms.bench_volume_torch(shape, dev)
+    torch.cuda.synchronize()
+    s = replica.make_replica_session(shape, rank, world, device=0, transport=transport, leader_verifies=bool(leader_verifies), options={'batch': 16})
+    s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
+    s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
+    s.init(2.25)
+    r = s.run(sweeps // 2, 10 ** 12, None)                  # two calls: the log goes on where the first run ended
+    r2 = s.run(sweeps, 10 ** 12, None)
+    assert r.sweeps + r2.sweeps == sweeps, (r.sweeps, r2.sweeps, r2.stop_reason)
+    digest, _ = label_digest(s, shape, dev)
+    st = s.repl_stats()
+    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), digest=np.str_(digest), seg=s.segmented(), tr=s.trace(), transport=np.str_(s.replica['transport']),
+             stats=np.array([st['batches'], st['records'], st['sweeps'], st['verified'], st['verifiers'], st['slot']], np.int64),
+             res=np.array([r2.stop_reason, r2.iter_num, r2.nseg, r2.n_in, r2.n_out, r2.ni, r2.no, r2.ties], np.int64))
+    s.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def replicas_one_gpu(world, shape, sweeps, transport, leader_verifies):
+    """Parent: the single-process run, then `world` rank processes of a leader / follower group on the same GPU; every rank's
+    labels, `segmented` order, whole trace (intensity sums bit for bit) and result must equal the single process's."""
+    import subprocess
+    import tempfile
+    import socket
+    dev = torch.device('cuda', 0)
+    I, vm = phantoms.bench_volume_torch(shape, dev)
+    torch.cuda.synchronize()
+    s = Session(shape)
+    s.set_option('batch', 16)
+    s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
+    s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
+    s.init(2.25)
+    r = s.run(sweeps, 10 ** 12, None)
+    assert r.sweeps == sweeps
+    ref_digest, _ = label_digest(s, shape, dev)
+    ref_seg, ref_tr = s.segmented(), s.trace()
+    ref_res = np.array([r.stop_reason, r.iter_num, r.nseg, r.n_in, r.n_out, r.ni, r.no, r.ties], np.int64)
+    s.close()
+    del I, vm
+    torch.cuda.empty_cache()
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    outdir = tempfile.mkdtemp(prefix='replicas_')
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--replica-worker', str(rk), str(world), str(port),
+                               'x'.join(map(str, shape)), str(sweeps), outdir, transport, str(int(leader_verifies))]) for rk in range(world)]
+    rcs = [p.wait() for p in procs]
+    assert all(rc == 0 for rc in rcs), rcs
+    counted = 0
+    for rk in range(world):
+        z = np.load(os.path.join(outdir, 'rank%d.npz' % rk))
+        assert str(z['transport']) == transport, (rk, str(z['transport']))
+        assert str(z['digest']) == ref_digest, 'rank %d: labels differ from the single-process run' % rk
+        assert np.array_equal(z['seg'], ref_seg), 'rank %d: segmented differs' % rk
+        assert z['tr'].tobytes() == ref_tr.tobytes(), 'rank %d: trace differs (integer fields or the bits of the intensity sums)' % rk
+        assert np.array_equal(z['res'][:7], ref_res[:7]), (rk, z['res'], ref_res)
+        st = z['stats']
+        assert st[2] == sweeps and st[4] == (world if leader_verifies else world - 1)
+        if rk > 0:
+            counted += int(st[3])
+            assert st[3] >= sweeps // st[4], (rk, st)                     # its share of the sweeps
+    assert counted == (sweeps - (sweeps + world - 1) // world if leader_verifies else sweeps), (counted, sweeps)   # every sweep counted exactly once (the leader's share: sweeps 1, 1 + N, ...)
+    print('REPLICAS OK: %s, %d ranks on one GPU over %s (leader %s), %d sweeps: labels / segmented / trace (sums bit for bit) / result identical '
+          'on every rank; the followers counted %d sweeps (nseg %d -> %d)' % ('x'.join(map(str, shape)), world, transport,
+          'counts a share' if leader_verifies else 'only leads', sweeps, counted, ref_tr['nseg'][0], ref_tr['nseg'][-1]))
+
+
 def main():
+    if '--replica-worker' in sys.argv:
+        a = sys.argv[sys.argv.index('--replica-worker') + 1:]
+        replica_worker(int(a[0]), int(a[1]), int(a[2]), tuple(int(v) for v in a[3].split('x')), int(a[4]), a[5], a[6], int(a[7]))
+        return
+    if '--replicas' in sys.argv:
+        a = sys.argv[sys.argv.index('--replicas') + 1:]
+        replicas_one_gpu(int(a[0]), tuple(int(v) for v in a[1].split('x')), int(a[2]), a[3], int(a[4]) if len(a) > 4 else 0)
+        return
     if '--slab-worker' in sys.argv:
         a = sys.argv[sys.argv.index('--slab-worker') + 1:]
         slab_worker(int(a[0]), int(a[1]), int(a[2]), tuple(int(v) for v in a[3].split('x')), int(a[4]), a[5])

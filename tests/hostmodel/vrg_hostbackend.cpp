@@ -306,10 +306,10 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c0, int flags, VrgEvents*, be_re
     if (s.apply_pending) {                             // (k_band: what the fused sweep before this trip left to do)
         const int k = s.iter;
         const VrgState snap0 = s;
-        for (uint32_t i = 0; i < snap0.ap_n; i++) vrg_deferred_apply(c0, i, k, snap0.log_pos);
+        for (uint32_t i = 0; i < snap0.ap_n; i++) vrg_deferred_apply(c0, i, k);
         for (uint32_t i = 0, nc = vrg_deferred_catchup_count(c0, k); i < nc; i++) vrg_deferred_catchup(c0, i, k);
         for (uint32_t j = 0; j < snap0.fr_n; j++) vrg_deferred_free(c0, snap0, j);
-        vrg_deferred_done(c0, snap0, k);
+        vrg_deferred_done(c0, k);
         if (!(flags & VRG_SWEEP_NODENSE)) dense_pass(b, c0, cb, user);   // its dense pass (the device: gate + recount on the other stream, asked for by vrg_deferred_done)
     }
     // the per-launch modes of the batched kernels, alternated so that both forms of every item function run here: the
@@ -382,25 +382,32 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c0, int flags, VrgEvents*, be_re
 }
 
 // ---- leader / follower replication: a follower's apply and verify steps, sequentially (the transports are the engine's callbacks) ----
-void be_follow_apply(VrgBackend*, const VrgCtx& c, const VrgLogRec* recs, const VrgLogSweep* hdr) {
-    vrg_follow_trace(c, *hdr);
-    for (uint32_t i = 0; i < hdr->nrec; i++) vrg_follow_apply_rec(c, recs[i], hdr->sweep);
-}
-void be_follow_verify(VrgBackend*, const VrgCtx& c, const VrgLogSweep* hdr, VrgEvents*) {
-    for (int p = 0; p < 2; p++)                          // (k_follow_gate) the units the applied sweeps listed join the bitmap, then the list
+void be_follow_apply(VrgBackend*, const VrgCtx& c, const VrgLogRec* recs, const VrgLogSweep* hdr, int n, int count_last) {
+    for (int s = 0; s < n; s++) {
+        vrg_follow_trace(c, hdr[s]);
+        for (uint32_t i = 0; i < hdr[s].nrec; i++) { vrg_follow_label_rec(c, recs[hdr[s].rec0 + i], hdr[s].sweep); vrg_follow_class_rec(c, recs[hdr[s].rec0 + i]); }
+    }
+    if (!count_last) return;
+    vrg_follow_expect(c, hdr[n - 1]);
+    for (int p = 0; p < 2; p++)                          // (k_follow_classes) the units the applied sweeps listed join the bitmap, then the list
         if (c.uctl[UC_GEN + p * UC_GEN_STRIDE]) {
             for (size_t w = 0, nw = (((size_t)c.PV + 1023) >> 10) / 32 + 1; w < nw; w++) { c.ubits[w] |= c.unew[p][w]; c.unew[p][w] = 0; }
             c.uctl[UC_GEN + p * UC_GEN_STRIDE] = 0;
             vrg_ulist_rebuild_serial(c);
         }
+}
+void be_follow_count(VrgBackend*, const VrgCtx& c, VrgEvents*) {
     dense_stats(c, c.lab[0], nullptr, nullptr, 1);
-    vrg_follow_check(c, *c.dn_part, hdr->sweep, hdr->n_in, hdr->n_out);
+    vrg_follow_check(c, *c.dn_part, (uint32_t)c.fexp[0], c.fexp[1], c.fexp[2]);
 }
 void be_follow_mark(VrgBackend*, int) {}
 void be_follow_wait(VrgBackend*, int) {}
 int be_repl_bcast(VrgBackend*, void*, size_t, int) { return -1; }
 int be_repl_allsum(VrgBackend*, double*, size_t) { return -1; }
 void be_repl_wait(VrgBackend*) {}
+void be_repl_copy(VrgBackend*, void* dst, const void* src, size_t bytes) { std::memmove(dst, src, bytes); }
+void* be_host_alloc(VrgBackend*, size_t bytes) { return std::malloc(bytes); }
+void be_host_free(VrgBackend*, void* p) { std::free(p); }
 int be_ipc_export(VrgBackend*, void*, void*) { return -1; }
 void* be_ipc_open(VrgBackend*, const void*) { return nullptr; }
 void be_ipc_close(VrgBackend*, void*) {}

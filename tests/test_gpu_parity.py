@@ -890,6 +890,89 @@ def test_config4_partition_8_ranks_one_gpu(shape, sweeps):
     assert out.returncode == 0 and 'SLABS OK' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+@pytest.mark.parametrize('world,shape,sweeps,transport,leader_verifies', [
+    (8, '880x880x640', 40, 'ipc', 0), (3, '512x512x170', 30, 'ipc', 1), (4, '512x512x170', 30, 'callback', 0)])
+def test_replicas_n_ranks_one_gpu(world, shape, sweeps, transport, leader_verifies):
+    """Leader / follower replication (BASELINE configs[3] re-partitioned) at FULL size on the one GPU of the
+    box: `world` rank processes share GPU 0; the leader runs the band chain and logs every sweep, the followers map its log
+    buffers (hipIpc - the transport ranks of one node use between GPUs) or receive them through gloo callbacks, apply them and
+    count their share of the sweeps over the whole volume.  Every rank's labels, `segmented` order, whole trace - the intensity
+    sums bit for bit - and result equal the single-process run.  (tests/full_size_check.py --replicas, own processes.)"""
+    import subprocess, sys, os
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'full_size_check.py'), '--replicas', str(world), shape, str(sweeps), transport, str(leader_verifies)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and 'REPLICAS OK' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def _replica_run(s, data, vmap, sweeps):
+    s.set_volume(data); s.set_labels(vmap); s.init(2.25)
+    r = s.run(sweeps, 10 ** 9, None)
+    return s.labels(), s.segmented(), s.trace(), r
+
+
+def test_replica_rccl_single_rank(lib):
+    """The RCCL transport of the change log with a one-rank communicator: broadcasts and the closing all-reduce run through
+    ncclBroadcast / ncclAllReduce on the transport stream; leader alone that counts everything, and one that counts nothing
+    (its last sweep is still counted when the run ends).  Results identical to the plain handle."""
+    from arterynetwork_amd import phantoms, replica
+    from arterynetwork_amd._capi import Session
+    data, vmap = phantoms.tube_phantom(shape=(96, 64, 40), radius=3.0, seed=4, seed_planes=3, amp_y=10.0, amp_z=5.0, levels=32, brain_mask=True)
+    ref = _replica_run(Session(data.shape, lib=lib), data, vmap, 25)
+    for lv in (True, False):
+        s = replica.make_replica_session(data.shape, 0, 1, lib=lib, transport='rccl', leader_verifies=lv, options={'batch': 4})
+        assert s.replica['transport'] == 'rccl'
+        out = _replica_run(s, data, vmap, 25)
+        st = s.repl_stats()
+        s.close()
+        assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
+        for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no', 'ties'):
+            assert np.array_equal(out[2][f], ref[2][f]), f
+        if lv:
+            assert out[2].tobytes() == ref[2].tobytes()
+        else:                                                           # nobody summed the intensities but for the last sweep
+            assert np.isnan(out[2]['sum_in'][1:-1]).all() and out[2]['sum_in'][-1] == ref[2]['sum_in'][-1]
+        assert st['sweeps'] == 25 and st['transport'] == 'rccl'
+
+
+def _rccl_replica_worker(rank, world, port, sweeps, outdir):
+    import os, sys
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from arterynetwork_amd import replica, phantoms
+    torch.cuda.set_device(rank)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    data, vmap = phantoms.tube_phantom(shape=(96, 64, 40), radius=3.0, seed=4, seed_planes=3, amp_y=10.0, amp_z=5.0, levels=32, brain_mask=True)
+    s = replica.make_replica_session(data.shape, rank, world, device=rank, transport='rccl', leader_verifies=(rank % 2 == 0 or True), options={'batch': 4})
+    out = _replica_run(s, data, vmap, sweeps)
+    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), labels=out[0], seg=out[1], tr=out[2], transport=np.str_(s.replica['transport']))
+    s.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_rccl_world2(lib, tmp_path):
+    """RCCL with MORE THAN ONE rank: two processes, one GPU each, the change log over ncclBroadcast (xGMI between the two).
+    Skipped on a box with one GPU (the driver's multi-GPU node runs it)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    import torch.multiprocessing as mp
+    from test_slabs_gloo import free_port
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session
+    data, vmap = phantoms.tube_phantom(shape=(96, 64, 40), radius=3.0, seed=4, seed_planes=3, amp_y=10.0, amp_z=5.0, levels=32, brain_mask=True)
+    ref = _replica_run(Session(data.shape, lib=lib), data, vmap, 25)
+    mp.spawn(_rccl_replica_worker, args=(2, free_port(), 25, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        z = np.load(str(tmp_path / ('rank%d.npz' % r)))
+        assert str(z['transport']) == 'rccl'
+        assert np.array_equal(z['labels'], ref[0]) and np.array_equal(z['seg'], ref[1]) and z['tr'].tobytes() == ref[2].tobytes()
+
+
 def test_reports_ties(lib):
     """An integer volume with proportional class histograms (constant intensity): every sign test (:87) is an exact tie,
     which the reference decides by np.sum's rounding.  The library counts them (vrg_result.ties, trace field `ties`) and

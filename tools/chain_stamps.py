@@ -19,7 +19,12 @@ samples = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 dev = torch.device('cuda', 0)
 I, vm = phantoms.bench_volume_torch(shape, dev, levels=int(os.environ.get('VRG_STAMP_LEVELS', '255')))   # (env: another quantisation)
 torch.cuda.synchronize()
-s = Session(shape)
+LEADER = os.environ.get('VRG_LEADER', '0') != '0'        # the leader of a leader / follower group that only leads (band chain + change log, no dense pass)
+if LEADER:
+    from arterynetwork_amd import replica
+    s = replica.make_replica_session(shape, 0, 1, transport='rccl', leader_verifies=False)
+else:
+    s = Session(shape)
 s.set_option('batch', 64)
 s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
 s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
@@ -44,17 +49,17 @@ acc = {k: [] for k in NAMES}
 period = []
 buf = (C.c_uint64 * 64)()
 for _ in range(samples):
-    if dense_off:                                          # (the handle has to be initialised again after a dense_off run)
-        s.set_option('dense_off', 0)
+    if dense_off or LEADER:                                # (the handle has to be initialised again after a dense_off run)
+        if not LEADER: s.set_option('dense_off', 0)
         s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride())); s.init(2.25)
-        s.set_option('dense_off', 1)
+        if not LEADER: s.set_option('dense_off', 1)
         done = 0
     done += s.run(done + 48, 10 ** 15, None).sweeps        # whole batches: the last sweep's stamps are of a chain in steady state
     s._check(s.lib.debug_stamps(s._h, buf))
     t0 = buf[0]
     if not t0:
         raise SystemExit('no stamps: not the -DVRG_STAMPS build (set VRG_HIP_LIB)')
-    if buf[6] and dense_off:      # (beside a dense pass the stamp of the sweep before is read stale more often than not)
+    if buf[6] and (dense_off or LEADER):      # (beside a dense pass the stamp of the sweep before is read stale more often than not)
         period.append((t0 - buf[6]) * 0.01)
     for k in NAMES:
         if buf[k] >= t0:
