@@ -74,9 +74,12 @@ void be_init_finish(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
 //          VRG_SWEEP_FUSED  update() as ONE launch (k_sweep, vrg_items.h "fused sweep"): sweeps with at most be_fuse_limit()
 //                           flips; a sweep with more is handed back (VBAIL_FUSE) and the engine repeats the trip unfused
 enum { VRG_SWEEP_FULL = 1, VRG_SWEEP_NODENSE = 4, VRG_SWEEP_SYNC = 8, VRG_SWEEP_FUSED = 16 };
-void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_reduce_fn cb, void* user);
+// (c is the engine's context: a fused trip swaps the two state buffers - c.st / c.stg say where the state is afterwards.  first / last:
+// the trip's place in its batch - the last fused trip of a batch closes its sweep itself, so that the host only ever reads closed states;
+// the others may be open-ended, vrg_items.h "open-ended sweeps")
+void be_sweep_once(VrgBackend* b, VrgCtx& c, int flags, VrgEvents* ev, be_reduce_fn cb, void* user, bool first, bool last);
 // n trips in a row (what the engine enqueues between two looks at the state)
-void be_sweep_batch(VrgBackend* b, const VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user);
+void be_sweep_batch(VrgBackend* b, VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user);
 // Z-slabs: all-reduce and close the dense passes whose slab sums are still waiting (they are reduced a few sweeps at a
 // time); collective - every rank calls it at the same point.  The engine calls it before it reads results.
 void be_dense_flush(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user);

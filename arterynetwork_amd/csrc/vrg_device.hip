@@ -71,6 +71,10 @@ struct VrgBackend {
     bool fused_memo = false;                          // ... and it kept the per-level memo (k_memo)
     bool fused_prev = false;                          // the trip enqueued last was a fused one: the dense pass of the sweep it applied is not enqueued yet
                                                       // (its request comes from THIS trip's k_band; if that trip stopped or handed itself back, the stop word makes the gate leave)
+    bool prev_open = false;                           // ... and its sweep was open-ended: this trip's k_band derives the closed state (and lists the touched levels itself)
+    int open_par = 0;                                 // ... the set of per-level counters it filled
+    int open_sweeps = 1;                              // option "open_sweeps": fused sweeps inside a batch end at their commit, without a closing workgroup
+    int iter_hint = 0;                                // sweeps applied when the engine last read the state + trips enqueued since
     uint32_t band_hint = 0;                           // pool slots in use when the engine last read the state (0: unknown)
     int direct_hint = 1;                              // ... and whether corrections are then evaluated entry by entry (8 lanes per slot)
 };
@@ -160,7 +164,7 @@ __device__ __forceinline__ void vrg_chaos_delay(uint32_t salt) {
 // additions, and so the result, does not depend on EXQ.
 constexpr int EXQ = 8;      // levels per lane fetched together: 512 per wave and batch
 // (with bins - large level tables, vrg_items.h "binned exact densities" - the lanes stride over the bins within reach of the entry)
-__device__ void exact_wave_binned(const VrgCtx& c, const VrgState& s, uint32_t nfresh, uint32_t wid, uint32_t nw, bool then_decide) {
+__device__ void exact_wave_binned(const VrgCtx& c, const VrgState& s, uint32_t nfresh, uint32_t wid, uint32_t nw, bool then_decide, int64_t n_in, int64_t n_out) {
     const uint32_t lane = threadIdx.x & 63;
     for (uint32_t f = wid; f < nfresh; f += nw) {
         const uint32_t slot = c.fresh[f];
@@ -173,14 +177,14 @@ __device__ void exact_wave_binned(const VrgCtx& c, const VrgState& s, uint32_t n
             const float err = vrg_exact_err(c, si, so);
             c.p_ip[slot] = si; c.p_op[slot] = so; c.p_err[slot] = err;
             if (then_decide && s.iter < s.iterMax)
-                vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot], (double)err);
+                vrg_decide_core(c, s, n_in, n_out, slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot], (double)err);
         }
     }
 }
 __device__ void exact_wave(const VrgCtx& c, const VrgState& s, uint32_t nfresh, uint32_t wid, uint32_t nw, bool then_decide) {
     const int lane = threadIdx.x & 63;
     if (wid >= nfresh) return;
-    if (c.nb) { exact_wave_binned(c, s, nfresh, wid, nw, then_decide); return; }
+    if (c.nb) { exact_wave_binned(c, s, nfresh, wid, nw, then_decide, c.inc[VC_NIN], c.inc[VC_NOUT]); return; }
     int32_t ha[EXQ], hb[EXQ]; double lv[EXQ];      // the first batch stays in registers for every entry of this wave
 #pragma unroll
     for (int q = 0; q < EXQ; q++) {
@@ -224,13 +228,14 @@ __device__ void exact_wave(const VrgCtx& c, const VrgState& s, uint32_t nfresh, 
 // batch of 512 levels (with a wave per slot most of the chip idles while each wave walks the whole table: 38 us of
 // k_band at 6111 levels).  Wave partial sums are added in the order 0..3; a table of <= 512 levels is wave 0's alone,
 // which then makes exactly exact_wave's additions.
-__device__ void exact_wg(const VrgCtx& c, const VrgState& s, uint32_t nfresh, uint32_t wg, uint32_t nwg) {
+// (n_in / n_out: the region sizes the decisions read - the caller's, which may have derived them from an open-ended sweep)
+__device__ void exact_wg(const VrgCtx& c, const VrgState& s, uint32_t nfresh, uint32_t wg, uint32_t nwg, int64_t n_in, int64_t n_out) {
     __shared__ double sh_i[TPB / 64], sh_o[TPB / 64];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr uint32_t NWV = TPB / 64, BATCH = 64u * EXQ;
     if (wg >= nfresh) return;
     if (c.nb) {                                           // (with bins: a wave per entry does it - at most 2983 bins, 47 per lane)
-        exact_wave_binned(c, s, nfresh, wg * NWV + wv, nwg * NWV, true);
+        exact_wave_binned(c, s, nfresh, wg * NWV + wv, nwg * NWV, true, n_in, n_out);
         return;
     }
     int32_t ha[EXQ], hb[EXQ]; double lv[EXQ];      // this wave's first batch stays in registers for every slot
@@ -272,7 +277,7 @@ __device__ void exact_wg(const VrgCtx& c, const VrgState& s, uint32_t nfresh, ui
             for (uint32_t w = 1; w < NWV; w++) { si += sh_i[w]; so += sh_o[w]; }
             c.p_ip[slot] = si; c.p_op[slot] = so; c.p_err[slot] = 0.0f;   // (the pending flag is cleared by the slot's own thread in the other half; sums over the levels: no binning error)
             if (s.iter < s.iterMax)                      // while iterNum <= iterMax (:58)
-                vrg_decide_core(c, s, c.inc[VC_NIN], c.inc[VC_NOUT], slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot]);
+                vrg_decide_core(c, s, n_in, n_out, slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], c.p_lev[slot]);
         }
         __syncthreads();
     }
@@ -356,13 +361,24 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
     double zv[NZQ]; uint32_t zi[NZQ], zo[NZQ], zc[NZQ], zl[NZQ];
     constexpr uint32_t defer_wgs = DEFER_WGS, G = DEFER_WGS * TPB;
     uint32_t mxa = VRG_NONE, mxb = VRG_NONE, cda0 = VRG_NOCHG, cxa0 = 0, cda1 = VRG_NOCHG, cxa1 = 0; uint8_t moa = 0, mna = 0, mob = 0, mnb = 0; int64_t rseq0 = 0;
+    // (an open-ended sweep before this trip - c.lvl_par says which counter set it filled: this thread's stretch of the per-level counters,
+    // from which the workgroup lists the touched levels itself; at most OPEN_PER levels per thread, i.e. OPEN_LEVELS in all)
+    constexpr uint32_t OPEN_PER = 4;
+    const int lpar = c.lvl_par >= 0 ? (c.lvl_par & 1) : 0;
+    const uint32_t lper = (c.L + TPB - 1) / TPB;
+    uint32_t lci[OPEN_PER], lco[OPEN_PER], lcc[OPEN_PER];
+#pragma unroll
+    for (uint32_t k = 0; k < OPEN_PER; k++) lci[k] = lco[k] = lcc[k] = 0;
+    nin0 = c.inc[VC_NIN]; nout0 = c.inc[VC_NOUT];
     if (pool_wg) {
         // (every load of this batch is unconditional with its index clamped into the array: a load under a divergent branch makes
         // the compiler wait for all loads in flight before the next one)
         { const uint32_t q = slot0 < c.bcap ? slot0 : c.bcap - 1u; fl0 = c.p_flag[q]; ip0 = c.p_ip[q]; op0 = c.p_op[q]; err0 = c.p_err[q]; lev0 = c.p_lev[q]; idx0 = c.p_idx[q]; key0 = c.p_key[q]; }
-        nin0 = c.inc[VC_NIN]; nout0 = c.inc[VC_NOUT];
         if (!direct_hint) { for (uint32_t j = tid; j < 3 * tab_n; j += TPB) s_raw[j] = c.tabC[j]; }
-        else {
+        else if (c.lvl_par >= 0) {
+#pragma unroll
+            for (uint32_t k = 0; k < OPEN_PER; k++) { const uint32_t l0 = tid * lper + k, l = l0 < c.L ? l0 : c.L - 1u; lci[k] = c.dInS[lpar][l]; lco[k] = c.dOutS[lpar][l]; lcc[k] = c.dConvS[lpar][l]; }
+        } else {
 #pragma unroll
             for (uint32_t k = 0; k < NZQ; k++) { const uint32_t j0 = tid + k * TPB, j = j0 < c.zcap ? j0 : c.zcap - 1u; zv[k] = c.nz_val[j]; zl[k] = (uint32_t)c.nz_key[j]; zi[k] = c.nz_cin[j]; zo[k] = c.nz_cout[j]; zc[k] = c.nz_cconv[j]; }
         }
@@ -373,15 +389,46 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
         mxb = c.mk_idx[qb]; mob = c.mk_old[qb]; mnb = c.mk_new[qb];
         if (dense_on) rseq0 = vrg_load_i64(&c.dctl[VD_RSEQ]);
     }
-    const VrgState s = *c.st;                             // a copy (nf is only ever bumped atomically)
-    if (s.done || s.bail) return;
+    VrgState s_ = *c.st;                                  // a copy (nf is only ever bumped atomically)
+    if (s_.done || s_.bail) {
+        if (st0 && c.st != c.stg) *c.stg = s_;            // (a fused trip swaps the state buffers whether it does anything or not)
+        return;
+    }
+    // An OPEN-ENDED sweep ran on this state (vrg_items.h "open-ended sweeps"): what it ran on + what its workgroups added up.  Every
+    // workgroup derives the closed state for itself - arithmetic on what it has just loaded; the pool's workgroups also list the levels
+    // the sweep touched, each from the counters into its own LDS.
+    const bool was_open = s_.open != 0;
+    VrgFuseClosed fcl;
+    uint32_t open_nnz = 0;
+    if (was_open) {
+        if (pool_wg) {
+            __shared__ uint32_t s_oscan[TPB / 64];
+            uint32_t cnt = 0;
+            const int apar = (s_.iter + 1) & 1;           // (the set the sweep really filled: a wrong hint costs a round trip, never correctness)
+            if (c.lvl_par < 0 || !direct_hint || lpar != apar) {
+#pragma unroll
+                for (uint32_t k = 0; k < OPEN_PER; k++) { const uint32_t l0 = tid * lper + k, l = l0 < c.L ? l0 : c.L - 1u; lci[k] = c.dInS[apar][l]; lco[k] = c.dOutS[apar][l]; lcc[k] = c.dConvS[apar][l]; }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < OPEN_PER; k++) { if (k >= lper || tid * lper + k >= c.L) lci[k] = lco[k] = lcc[k] = 0; cnt += (lci[k] | lco[k] | lcc[k]) ? 1u : 0u; }
+            uint32_t q = block_excl_scan(cnt, open_nnz, s_oscan);
+#pragma unroll
+            for (uint32_t k = 0; k < OPEN_PER; k++)
+                if (lci[k] | lco[k] | lcc[k]) { s_nzl[q] = tid * lper + k; s_cin[q] = lci[k]; s_cout[q] = lco[k]; s_cconv[q] = lcc[k]; q++; }
+        }
+        vrg_fuse_close_core(c, s_, nin0, nout0, open_nnz, false, fcl);
+        nin0 = fcl.n_in; nout0 = fcl.n_out;
+    }
+    const VrgState& s = s_;
     const bool live = s.iter < s.iterMax;
     if (st0 && live) { VRG_STAMP_PUT(c, 6, c.dbg[0]); VRG_STAMP_PUT(c, 0, t_entry); VRG_STAMP(c, 1); }    // (6: the sweep before this one)
     // What the fused sweep before this trip (k_sweep) left to do - nothing in this kernel reads a label: its label bytes in
     // place (+ the class bits the dense pass reads, the class changes of the sweep before that), its dead slots onto the
     // free list - by workgroups of their own (the last DEFER_WGS of the grid), beside the ones that decide the slots.
-    // Whichever of them finishes last (ticket) asks for the sweep's dense pass.
+    // Whichever of them finishes last (ticket) asks for the sweep's dense pass.  Their first thread files the state this trip
+    // works on (vrg_fuse_persist) - before its workgroup's ticket: the sizes the dense pass has to reproduce are filed with it.
     if (defer_wg) {
+        if (dtid == 0) vrg_fuse_persist(c, s, fcl, was_open);
         if (!s.apply_pending) return;
         const int k = s.iter;
         if (tid == 0 && dense_on && (int64_t)k - 2 > rseq0) wait_dense_read_for(c, (int64_t)k - 2);   // (the pass of two sweeps ago has read the class copy this sweep rewrites)
@@ -397,7 +444,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
         return;
     }
     if (!pool_wg) {
-        exact_wg(c, s, s.nfx, blockIdx.x - band_blocks, EXACT_BLOCKS);
+        exact_wg(c, s, s.nfx, blockIdx.x - band_blocks, EXACT_BLOCKS, nin0, nout0);
         if (stx && live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP_PUT(c, 3, t_entry); VRG_STAMP(c, 4); }
         return;
     }
@@ -419,7 +466,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
     __syncthreads();                                      // (everyone is done staging the memo head: the block changes hands)
     const double* nzv = c.nz_val; const uint32_t* nzi = c.nz_cin; const uint32_t* nzo = c.nz_cout; const uint32_t* nzc = c.nz_cconv;
     const bool nz_lds = s.nnz <= NZ_LDS;
-    if (nz_lds) {
+    if (nz_lds && !was_open) {                            // (an open-ended sweep's list is in LDS already: this workgroup has just built it)
         if (direct_hint) {
 #pragma unroll
             for (uint32_t k = 0; k < NZQ; k++) { const uint32_t j = tid + k * TPB; if (j < s.nnz) { if (use_ktab) s_nzl[j] = zl[k]; else s_val[j] = zv[k]; s_cin[j] = zi[k]; s_cout[j] = zo[k]; s_cconv[j] = zc[k]; } }
@@ -940,8 +987,10 @@ constexpr uint32_t FUSE_MEMO_NNZ = 1024;  // touched levels k_memo keeps in LDS;
 // memo_follows: the launch behind this one is k_memo (large bands: the corrections of the sweep memoised per level)
 // BIGL: a level table of more than VRG_FUSE_LEVELS values (never searched here: every voxel's level index is kept, VrgCtx::lidx):
 // the touched levels are listed by their first toucher and sorted by the closing workgroup instead of found by a scan.
+// open_end: the sweep stops at its commit - no ticket, no closing workgroup; the next trip's k_band derives the closed state (vrg_items.h
+// "open-ended sweeps"; small level tables only)
 template <bool BIGL>
-__global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_follows) {
+__global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_follows, int open_end) {
     VRG_CHAOS_POINT(5);
     __shared__ VrgFuseLdsT<BIGL ? 1 : VRG_FUSE_LEVELS> sh;
     __shared__ uint32_t s_keys[BIGL ? VRG_FUSE_KEYS : 1];
@@ -957,6 +1006,9 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     const int64_t nin0 = cg.inc[VC_NIN];
     vrg_fuse_init(sh, t);
     if (s0.done || s0.bail) return;
+    const int lp = (s0.iter + 1) & 1;                      // this sweep's set of per-level counters; the other set - the sweep before's - goes back to zero
+    if constexpr (!BIGL) vrg_fuse_zero_other_levels(cg, lp, r, gridDim.x, t, T);
+    if (st0) vrg_fuse_prepare_other(cg, s0);               // (the next trip's k_band counts its flips and ties into the other state buffer)
     const int32_t gate = vrg_fuse_gate(cg, s0, nin0, vrg_fuse_limit(cg));      // stop tests (:91-104) / can the sweep run fused: the same answer everywhere
     if (gate) {
         if (st0) {
@@ -972,6 +1024,7 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     VrgState sl = s0;                                      // (what the item functions read of the state: registers, not memory)
     VrgCtx c = cg;
     c.st = &sl; c.lev_fast = 1; c.lvl_scan = BIGL ? 2 : 1;
+    if constexpr (!BIGL) { c.dIn = cg.dInS[lp]; c.dOut = cg.dOutS[lp]; c.dConv = cg.dConvS[lp]; }
     vrg_fuse_keys(sh, th, t, nf);
     __syncthreads();
     vrg_fuse_rank(c, sh, th, t, nf);
@@ -1018,6 +1071,10 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (st0) VRG_STAMP(cg, 21);
+    if (open_end) {                                        // nobody closes: the state keeps what the workgroups have added up, marked open
+        if (st0) { cg.stg->open = 1; VRG_STAMP(cg, 28); VRG_STAMP(cg, 29); }
+        return;
+    }
     if (t == 0) {
         VRG_CHAOS_POINT(12);
         const uint32_t k = __hip_atomic_fetch_add(&cg.counters[16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1973,6 +2030,8 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "repl") == 0) b->repl = v != 0;
     if (std::strcmp(name, "skip_excluded") == 0) b->skip = v != 0;
     if (std::strcmp(name, "nt_loads") == 0) b->nt_loads = v < 0 ? -1 : (v != 0);
+    if (std::strcmp(name, "iter_hint") == 0) b->iter_hint = (int)v;
+    if (std::strcmp(name, "open_sweeps") == 0) b->open_sweeps = v != 0;
     if (std::strcmp(name, "band_hint") == 0) b->band_hint = (uint32_t)std::min<long long>(std::max<long long>(v, 0), 0x7fffffff);
     if (std::strcmp(name, "direct_hint") == 0) b->direct_hint = v != 0;
     if (std::strcmp(name, "dense_pipe") == 0) b->dense_pipe = (int)v;
@@ -2000,7 +2059,7 @@ const char* be_last_error(VrgBackend* b) {
 }
 void be_clear_error(VrgBackend* b) { b->err[0] = 0; }
 // (the engine synchronises when a run ends or a trip was handed back: no fused sweep is waiting for its dense pass then)
-void be_sync(VrgBackend* b) { use_device(b); HIP_CHECK(hipStreamSynchronize(b->sa)); HIP_CHECK(hipStreamSynchronize(b->sb)); if (b->sd) HIP_CHECK(hipStreamSynchronize(b->sd)); b->fused_prev = false; }
+void be_sync(VrgBackend* b) { use_device(b); HIP_CHECK(hipStreamSynchronize(b->sa)); HIP_CHECK(hipStreamSynchronize(b->sb)); if (b->sd) HIP_CHECK(hipStreamSynchronize(b->sd)); b->fused_prev = false; b->prev_open = false; }
 
 // A device-resident input is read on the library's own stream: the caller's producer must have finished (vrg.h).
 static const void* stage_in(VrgBackend* b, const VrgCtx& c, const void* src, int dtype, void** tmp) {
@@ -2345,7 +2404,12 @@ static void small_update(VrgBackend* b, const VrgCtx& c0, bool dense, hipEvent_t
 
 static void enqueue_dense(VrgBackend* b, const VrgCtx& c, hipEvent_t e_start, hipEvent_t e_stop, be_reduce_fn cb, void* user);
 
-void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_reduce_fn cb, void* user) {
+// (before the first fused trip of a batch: the live counters of the buffer its k_band decides into - inside a run of fused trips every
+// k_sweep sets them up for the trip after it, vrg_fuse_prepare_other; the host may have rewritten the state in between)
+__global__ void k_state_prep(const VrgState* in, VrgState* out) { out->nf = 0; out->ties = in->ties; out->near_ties = in->near_ties; out->error = in->error; }
+constexpr uint32_t OPEN_LEVELS = 1024;               // level tables up to this size run open-ended sweeps (k_band lists the touched levels from 4 counters per thread)
+
+void be_sweep_once(VrgBackend* b, VrgCtx& c, int flags, VrgEvents* ev, be_reduce_fn cb, void* user, bool first, bool last) {
     use_device(b);
     hipEvent_t e_start = nullptr, e_stop = nullptr;
     const bool dense = !(flags & VRG_SWEEP_NODENSE);
@@ -2370,14 +2434,25 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
         e_c0 = p.a; e_c1 = p.b;
     }
     const uint32_t nbb = band_blocks(b);
-    // (grid: the pool's workgroups, the exact-density ones, and - behind a fused trip - the ones that carry out what it deferred)
+    const bool fused_trip = (flags & VRG_SWEEP_FUSED) && !(flags & (VRG_SWEEP_SYNC | VRG_SWEEP_FULL));
+    // a fused trip reads the state in one buffer and files it into the other (vrg_items.h "open-ended sweeps"); every other kind works in place
+    VrgState* const st_in = c.st;
+    VrgState* const st_out = fused_trip ? (c.st == c.stb[0] ? c.stb[1] : c.stb[0]) : c.st;
+    if (fused_trip && (first || !b->fused_prev)) k_state_prep<<<1, 1, 0, b->sa>>>(st_in, st_out);
+    // (grid: the pool's workgroups, the exact-density ones, and - in and behind a fused trip - the ones that file the state and carry out what the sweep before deferred)
     {
-        const dim3 grid(nbb + EXACT_BLOCKS + (b->fused_prev ? DEFER_WGS : 0));
+        VrgCtx cb_ = c;
+        cb_.st = st_in; cb_.stg = st_out; cb_.lvl_par = b->prev_open ? b->open_par : -1;
+        const dim3 grid(nbb + EXACT_BLOCKS + ((b->fused_prev || fused_trip) ? DEFER_WGS : 0));
         const int lanes = band_lanes(b), dh = band_direct(b) ? 1 : 0, don = dense ? 1 : 0;
-        if (lanes == 16) hipExtLaunchKernelGGL(k_band<16>, grid, dim3(TPB), 0, b->sa, e_c0, nullptr, 0, c, nbb, don, dh);
-        else if (lanes == 8) hipExtLaunchKernelGGL(k_band<8>, grid, dim3(TPB), 0, b->sa, e_c0, nullptr, 0, c, nbb, don, dh);
-        else hipExtLaunchKernelGGL(k_band<4>, grid, dim3(TPB), 0, b->sa, e_c0, nullptr, 0, c, nbb, don, dh);
+        if (lanes == 16) hipExtLaunchKernelGGL(k_band<16>, grid, dim3(TPB), 0, b->sa, e_c0, nullptr, 0, cb_, nbb, don, dh);
+        else if (lanes == 8) hipExtLaunchKernelGGL(k_band<8>, grid, dim3(TPB), 0, b->sa, e_c0, nullptr, 0, cb_, nbb, don, dh);
+        else hipExtLaunchKernelGGL(k_band<4>, grid, dim3(TPB), 0, b->sa, e_c0, nullptr, 0, cb_, nbb, don, dh);
     }
+    c.st = c.stg = st_out; c.st_other = st_in;             // (where the state is from here on; k_sweep sets up the buffer just read for the next trip's decisions)
+    const int sweep_par = (b->iter_hint + 1) & 1;          // the sweep this trip applies, if it applies one
+    b->iter_hint++;
+    b->prev_open = false;
     // A fused trip leaves the labels of the sweep it applies to the NEXT trip's k_band, which also asks for that sweep's dense
     // pass: the pass is therefore enqueued here, right behind the k_band that raises its request - never earlier: a gate that
     // waits for a request nobody has enqueued yet would block every host synchronisation of the dense stream.
@@ -2387,14 +2462,17 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c, int flags, VrgEvents* ev, be_
         e_start = e_stop = nullptr;
     }
     b->fused_prev = false;
-    if ((flags & VRG_SWEEP_FUSED) && !(flags & (VRG_SWEEP_SYNC | VRG_SWEEP_FULL))) {
+    if (fused_trip) {
         // update() as ONE launch; on a large band a second one memoises the sweep's corrections per level
         const bool memo = !b->direct_hint && b->band_hint > b->memo_above && c.ktab;
         b->memo_trips += memo;
-        if (c.L > (uint32_t)VRG_FUSE_LEVELS) hipExtLaunchKernelGGL(k_sweep<true>, dim3(VRG_FUSE_MAX_BIG), dim3(VRG_FUSE_THREADS), 0, b->sa, nullptr, memo ? nullptr : e_c1, 0, c, 0);
-        else hipExtLaunchKernelGGL(k_sweep<false>, dim3(VRG_FUSE_MAX), dim3(VRG_FUSE_THREADS), 0, b->sa, nullptr, memo ? nullptr : e_c1, 0, c, memo ? 1 : 0);
+        // open-ended: no closing workgroup - the next trip's k_band derives the closed state.  Not the last trip of a batch (the host reads
+        // closed states only), not in front of the memo kernel, small level tables only.
+        const bool open = b->open_sweeps && !last && !memo && c.L <= OPEN_LEVELS && c.ktab;
+        if (c.L > (uint32_t)VRG_FUSE_LEVELS) hipExtLaunchKernelGGL(k_sweep<true>, dim3(VRG_FUSE_MAX_BIG), dim3(VRG_FUSE_THREADS), 0, b->sa, nullptr, memo ? nullptr : e_c1, 0, c, 0, 0);
+        else hipExtLaunchKernelGGL(k_sweep<false>, dim3(VRG_FUSE_MAX), dim3(VRG_FUSE_THREADS), 0, b->sa, nullptr, memo ? nullptr : e_c1, 0, c, memo ? 1 : 0, open ? 1 : 0);
         if (memo) hipExtLaunchKernelGGL(k_memo, dim3(MEMO_BLOCKS), dim3(TPB), 0, b->sa, nullptr, e_c1, 0, c);
-        b->fused_prev = true; b->fused_memo = memo;
+        b->fused_prev = true; b->fused_memo = memo; b->prev_open = open; b->open_par = sweep_par;
         return;
     }
     if (flags & VRG_SWEEP_SYNC) {
@@ -2432,8 +2510,8 @@ static void enqueue_dense(VrgBackend* b, const VrgCtx& c, hipEvent_t e_start, hi
 }
 
 // n trips in a row: what the engine enqueues between two looks at the state
-void be_sweep_batch(VrgBackend* b, const VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user) {
-    for (int i = 0; i < n; i++) be_sweep_once(b, c, flags, ev, cb, user);
+void be_sweep_batch(VrgBackend* b, VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user) {
+    for (int i = 0; i < n; i++) be_sweep_once(b, c, flags, ev, cb, user, i == 0, i == n - 1);
 }
 
 // option verify_every != 1, at the end of a run (both streams idle, every pass closed): the labels of the last sweep counted

@@ -112,6 +112,7 @@ VrgDense get_dense(vrg_handle* h) {     // region sizes as the band side keeps t
 VrgState get_state(vrg_handle* h) {
     VrgState s; be_download(h->be, &s, h->c.st, sizeof(s));
     be_set_tuning(h->be, "band_hint", s.np);
+    be_set_tuning(h->be, "iter_hint", s.iter);
     be_set_tuning(h->be, "direct_hint", !vrg_tab_pays(h->c.L, s.ni + s.no));
     return s;
 }
@@ -241,7 +242,8 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     h->lab_base[0] = alloc<uint8_t>(h, (size_t)c.PV + 32);
     c.lab[0] = h->lab_base[0] ? h->lab_base[0] + 16 : nullptr;
     c.stamp = alloc<uint64_t>(h, c.PV);
-    c.st = alloc<VrgState>(h, 1); c.stg = c.st;
+    c.stb[0] = alloc<VrgState>(h, 1); c.stb[1] = alloc<VrgState>(h, 1);       // (fused trips swap them: vrg_items.h "open-ended sweeps")
+    c.st = c.stg = c.stb[0]; c.st_other = c.stb[1]; c.lvl_par = -1;
     c.dn = alloc<VrgDense>(h, 16);                   // own allocation: written by the dense kernel only
     c.counters = alloc<uint32_t>(h, 64);
     c.dbg = alloc<uint64_t>(h, 64);
@@ -257,13 +259,13 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.trace_cap = 1u << 16;
     c.trace = alloc<VrgTrace>(h, c.trace_cap);
     c.world = 1; c.ver_n = 1; c.ver_me = 0;
-    if (!c.lab[0] || !c.stamp || !c.st || !c.dn || !c.counters || !c.dn_part || !c.gate || !c.fexp || !c.dn_ring || !c.exp_ring || !c.stage_in || !c.stage_out || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
+    if (!c.lab[0] || !c.stamp || !c.stb[0] || !c.stb[1] || !c.dn || !c.counters || !c.dn_part || !c.gate || !c.fexp || !c.dn_ring || !c.exp_ring || !c.stage_in || !c.stage_out || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
         !c.nchg || !c.ubits || !c.unew[0] || !c.unew[1] || !c.ulist || !c.uctl || !c.vent || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace) { API(destroy)(h); return VRG_E_MEM; }
     be_fill(be, c.inc, 0, 32 * sizeof(int64_t)); be_fill(be, c.dctl, 0, 32 * sizeof(int64_t)); be_fill(be, c.gate, 0, 32 * sizeof(int64_t));
     be_fill(be, c.clsb[0], 0, PVu / 4); be_fill(be, c.clsb[1], 0, PVu / 4);
     be_fill(be, c.nchg, 0, 32 * sizeof(uint32_t));
     be_fill(be, h->lab_base[0], VB_OOB, (size_t)c.PV + 32);
-    be_fill(be, c.st, 0, sizeof(VrgState));
+    be_fill(be, c.stb[0], 0, sizeof(VrgState)); be_fill(be, c.stb[1], 0, sizeof(VrgState));
     be_fill(be, c.dn, 0, sizeof(VrgDense));
     be_fill(be, c.dn_part, 0, sizeof(VrgDense));
     be_fill(be, c.dn_ring, 0, VRG_RING * sizeof(VrgDense)); be_fill(be, c.exp_ring, 0, 2 * VRG_RING * sizeof(int64_t));
@@ -299,6 +301,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "fused") h->fused = value != 0;
     else if (n == "bin_above") { if (value < 0) return fail(h, VRG_E_ARG, "bin_above: a number of levels >= 0"); h->bin_above = value; h->inited = false; }
     else if (n == "verify_every") { if (value < 0) return fail(h, VRG_E_ARG, "verify_every: 0 (never), 1 (every sweep: the default) or n > 1 (every n-th sweep)"); h->verify_every = (int)std::min<int64_t>(value, 1 << 20); be_set_tuning(h->be, name, value); }
+    else if (n == "open_sweeps") be_set_tuning(h->be, name, value);
     else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "fuse_max" || n == "memo_above" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads" || n == "dense_pipe") be_set_tuning(h->be, name, value);
     else if (n == "storage16") h->storage16 = value != 0;      // takes effect at the next vrg_init
     else if (n == "log_capacity") { if (h->repl.buf[0] || value < 1024 || value > 0x20000000ll) return fail(h, VRG_E_STATE, "log_capacity: 1024 .. 2^29 records, before the first vrg_run of a replicated handle"); h->repl.cap = (uint32_t)value; }
@@ -329,7 +332,9 @@ int API(set_volume)(vrg_handle* h, const void* data, int dtype, const int64_t st
         h->lidx_valid = false; c.lidx = nullptr;
         release(h, c.hin); release(h, c.hout); release(h, c.dIn); release(h, c.dOut); release(h, c.dConv); release(h, c.ltouch);
         release(h, c.nz_key); release(h, c.nz_val); release(h, c.nz_cin); release(h, c.nz_cout); release(h, c.nz_cconv); release(h, c.tabC);
-        c.hin = c.hout = nullptr; c.dIn = c.dOut = c.dConv = c.ltouch = nullptr; c.nz_key = nullptr; c.nz_val = nullptr;
+        c.hin = c.hout = nullptr; c.dIn = c.dOut = c.dConv = c.ltouch = nullptr;
+        for (int p = 0; p < 2; p++) { c.dInS[p] = nullptr; c.dOutS[p] = nullptr; c.dConvS[p] = nullptr; }
+        c.nz_key = nullptr; c.nz_val = nullptr;
         c.nz_cin = c.nz_cout = c.nz_cconv = nullptr; c.tabC = nullptr; c.L = 0;
     }
     return VRG_OK;
@@ -363,12 +368,13 @@ int API(init)(vrg_handle* h, double H) {
         h->owned.push_back(lev);
         const uint32_t zcap = (uint32_t)pow2_at_least(L);
         int32_t* hin = alloc<int32_t>(h, L); int32_t* hout = alloc<int32_t>(h, L);
-        uint32_t* dIn = alloc<uint32_t>(h, L); uint32_t* dOut = alloc<uint32_t>(h, L); uint32_t* dConv = alloc<uint32_t>(h, L);
+        uint32_t* dIn = alloc<uint32_t>(h, 2 * (size_t)L); uint32_t* dOut = alloc<uint32_t>(h, 2 * (size_t)L); uint32_t* dConv = alloc<uint32_t>(h, 2 * (size_t)L);   // (two sets by sweep parity: open-ended sweeps)
         uint32_t* ltouch = alloc<uint32_t>(h, L);
         uint64_t* nz_key = alloc<uint64_t>(h, zcap); double* nz_val = alloc<double>(h, zcap);
         uint32_t* nz_cin = alloc<uint32_t>(h, zcap); uint32_t* nz_cout = alloc<uint32_t>(h, zcap); uint32_t* nz_cconv = alloc<uint32_t>(h, zcap);
         double* tabC = alloc<double>(h, 3 * (size_t)L);
         c.hin = hin; c.hout = hout; c.dIn = dIn; c.dOut = dOut; c.dConv = dConv; c.ltouch = ltouch;
+        c.dInS[0] = dIn; c.dInS[1] = dIn ? dIn + L : nullptr; c.dOutS[0] = dOut; c.dOutS[1] = dOut ? dOut + L : nullptr; c.dConvS[0] = dConv; c.dConvS[1] = dConv ? dConv + L : nullptr;
         c.nz_key = nz_key; c.nz_val = nz_val; c.nz_cin = nz_cin; c.nz_cout = nz_cout; c.nz_cconv = nz_cconv; c.tabC = tabC;
         c.zcap = zcap; c.L = L;
         if (!hin || !hout || !dIn || !dOut || !dConv || !ltouch || !nz_key || !nz_val || !nz_cin || !nz_cout || !nz_cconv || !tabC) {
@@ -437,7 +443,7 @@ int API(init)(vrg_handle* h, double H) {
         be_fill(be, h->lab_base[1], VB_OOB, (size_t)c.PV + 32);
     }
     be_fill(be, c.hin, 0, (size_t)L * 4); be_fill(be, c.hout, 0, (size_t)L * 4);
-    be_fill(be, c.dIn, 0, (size_t)L * 4); be_fill(be, c.dOut, 0, (size_t)L * 4); be_fill(be, c.dConv, 0, (size_t)L * 4);
+    be_fill(be, c.dIn, 0, (size_t)L * 8); be_fill(be, c.dOut, 0, (size_t)L * 8); be_fill(be, c.dConv, 0, (size_t)L * 8);
     be_fill(be, c.ltouch, 0, (size_t)L * 4);
     // band pool and work arrays: sized by demand (they grow when a trip reports that it needs more)
     if (!c.p_idx && !size_pool(h, h->band_capacity, 0, 0)) return fail(h, VRG_E_MEM, "vrg_init: band arrays");

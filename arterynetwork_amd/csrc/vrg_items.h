@@ -34,6 +34,7 @@
 //    (re-)entered it (newInnerBndList/newOuterBndList; slot flag PF_PEND).
 #pragma once
 #include <math.h>
+#include <stddef.h>
 #include "vrg_types.h"
 
 // ------------------------------------------------------------------ backend shims
@@ -1020,26 +1021,35 @@ VRG_HD VrgState vrg_finalize_load(const VrgCtx& c, int64_t& n_in, int64_t& n_out
     n_in = vrg_load_i64(&c.inc[VC_NIN]); n_out = vrg_load_i64(&c.inc[VC_NOUT]);
     return s;
 }
-// (tr: the integer fields of the sweep's trace record, for the caller's change log)
-VRG_HD void vrg_finalize_update(const VrgCtx& c, VrgState& s, int64_t n_in, int64_t n_out, bool use_tab, VrgTrace& tr) {
+// (tr: the integer fields of the sweep's trace record; no memory is touched here: vrg_finalize_store files what has to be filed)
+VRG_HD void vrg_finalize_core(VrgState& s, int64_t n_in, int64_t n_out, bool use_tab, VrgTrace& tr) {
     const uint32_t used = vrg_free_used(s.nalloc, s.nfree);
     s.np += s.nalloc - used; s.nfree = s.nfree - used + s.ndead;
     s.ni = (uint32_t)((int32_t)s.ni + s.d_ni); s.no = (uint32_t)((int32_t)s.no + s.d_no);
     s.iter++;
     tr.nflip = s.nf; tr.nseg = n_in; tr.n_in = n_in; tr.n_out = n_out; tr.ni = s.ni; tr.no = s.no;
     tr.ties = s.ties - s.ties_filed; tr.near_ties = s.near_ties - s.near_filed; tr.sum_in = 0; tr.sum_out = 0;
-    if ((uint32_t)s.iter < c.trace_cap) {
-        VrgTrace& t = c.trace[s.iter];                // the intensity sums are filed by the dense pass (vrg_dense_fin)
-        t.nflip = tr.nflip; t.nseg = n_in; t.n_in = n_in; t.n_out = n_out; t.ni = tr.ni; t.no = tr.no;
-        t.ties = tr.ties; t.near_ties = tr.near_ties;
-    }
     s.ties_filed = s.ties; s.near_filed = s.near_ties;
     s.last_nf = s.nf;
     s.nf = 0; s.npend = 0; s.nmk = 0; s.nalloc = 0; s.ndead = 0; s.d_ni = 0; s.d_no = 0;
     s.nfx = s.nfresh; s.nfresh = 0;                   // exact densities of the new entries: first thing next trip
     s.corr = 1; s.use_tab = use_tab ? 1 : 0;          // nnz stays: the next k_band reads the touched-level list
     s.apply_pending = 0; s.ap_n = 0; s.fr_n = 0; s.d_nin = 0; s.d_nout = 0; s.nvisit = 0; s.nnz_new = 0;   // (the fused sweep's closing thread sets its own afterwards)
-    if (s.error) { s.done = -1; vrg_store_i64(&c.gate[VG_STOP], 1); }
+    s.open = 0; s.log_n = 0;
+    if (s.error) s.done = -1;
+}
+// ... the sweep's trace record (the intensity sums are filed by the dense pass, vrg_dense_fin), the dense side's stop word
+VRG_HD void vrg_finalize_store(const VrgCtx& c, const VrgState& s, const VrgTrace& tr) {
+    if ((uint32_t)s.iter < c.trace_cap) {
+        VrgTrace& t = c.trace[s.iter];
+        t.nflip = tr.nflip; t.nseg = tr.nseg; t.n_in = tr.n_in; t.n_out = tr.n_out; t.ni = tr.ni; t.no = tr.no;
+        t.ties = tr.ties; t.near_ties = tr.near_ties;
+    }
+    if (s.error) vrg_store_i64(&c.gate[VG_STOP], 1);
+}
+VRG_HD void vrg_finalize_update(const VrgCtx& c, VrgState& s, int64_t n_in, int64_t n_out, bool use_tab, VrgTrace& tr) {
+    vrg_finalize_core(s, n_in, n_out, use_tab, tr);
+    vrg_finalize_store(c, s, tr);
 }
 VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
     int64_t n_in, n_out;
@@ -1430,24 +1440,78 @@ VRG_HD VrgState vrg_fuse_close_load(const VrgCtx& c, int64_t& n_in, int64_t& n_o
     return s;
 }
 // (the sweep's change-log records, compacted by the workgroups' reservations: s.log_n of them from s.log_pos on)
-VRG_HD void vrg_fuse_close(const VrgCtx& c, VrgState s, int64_t n_in, int64_t n_out, uint32_t nnz, bool use_tab) {
+// In two parts.  vrg_fuse_close_core: the state after the sweep from the state it ran on + what its workgroups added up - no memory
+// is touched, so EVERY workgroup of the next trip's k_band can do this for itself when the sweep was open-ended.  vrg_fuse_close_store:
+// what has to reach memory, by one thread - the sweep's own closing thread, or one thread of that k_band.
+struct VrgFuseClosed { VrgTrace tr; int64_t n_in, n_out; uint32_t places, log_open, log_n; };
+VRG_HD void vrg_fuse_close_core(const VrgCtx& c, VrgState& s, int64_t n_in, int64_t n_out, uint32_t nnz, bool use_tab, VrgFuseClosed& f) {
     n_in += s.d_nin; n_out += s.d_nout;
     if (s.nvisit != s.nf && !s.error) s.error = 3;        // a listed flip the stencils never visited
-    const int64_t k = (int64_t)s.iter + 1;
-    vrg_store_i64(&c.exp_ring[2 * (k % VRG_RING)], n_in); vrg_store_i64(&c.exp_ring[2 * (k % VRG_RING) + 1], n_out);
-    c.inc[VC_NIN] = n_in; c.inc[VC_NOUT] = n_out;
-    const uint32_t places = s.nf * (uint32_t)VRG_FUSE_PLACES;
-    c.nchg[k & 1] = places;                               // (filed by the deferred apply: a change sits at its voxel's place)
+    f.n_in = n_in; f.n_out = n_out;
+    f.places = s.nf * (uint32_t)VRG_FUSE_PLACES;
     const uint32_t used = vrg_free_used(s.nalloc, s.nfree), fr_base = s.nfree - used, fr_n = s.ndead;
     s.nnz = nnz;
-    VrgTrace tr;
-    vrg_finalize_update(c, s, n_in, n_out, use_tab, tr);
-    s.apply_pending = 1; s.ap_n = places; s.fr_base = fr_base; s.fr_n = fr_n;
-    const uint32_t log_open = s.log_pos, log_n = s.log_n;
-    if (c.log_rec) { s.log_pos += log_n; s.log_nsw += 1u; }     // (with the state's one store; vrg_log_sweep files the header)
-    s.log_n = 0;
+    f.log_open = s.log_pos; f.log_n = s.log_n;
+    vrg_finalize_core(s, n_in, n_out, use_tab, f.tr);
+    s.apply_pending = 1; s.ap_n = f.places; s.fr_base = fr_base; s.fr_n = fr_n;
+    if (c.log_rec) { s.log_pos += f.log_n; s.log_nsw += 1u; }     // (the state's words; vrg_log_sweep files the header)
+}
+// (s: the closed state, its `iter` the sweep's number; the state itself is stored by the caller - whole, or all but its live counters)
+VRG_HD void vrg_fuse_close_store(const VrgCtx& c, const VrgState& s, const VrgFuseClosed& f) {
+    const int64_t k = (int64_t)s.iter;
+    vrg_store_i64(&c.exp_ring[2 * (k % VRG_RING)], f.n_in); vrg_store_i64(&c.exp_ring[2 * (k % VRG_RING) + 1], f.n_out);
+    c.inc[VC_NIN] = f.n_in; c.inc[VC_NOUT] = f.n_out;
+    c.nchg[k & 1] = f.places;                             // (filed by the deferred apply: a change sits at its voxel's place)
+    vrg_finalize_store(c, s, f.tr);
+    vrg_log_sweep(c, k, f.log_open, s.log_nsw - (c.log_rec ? 1u : 0u), f.log_n, f.n_in, f.n_out, f.tr);
+}
+VRG_HD void vrg_fuse_close(const VrgCtx& c, VrgState s, int64_t n_in, int64_t n_out, uint32_t nnz, bool use_tab) {
+    VrgFuseClosed f;
+    vrg_fuse_close_core(c, s, n_in, n_out, nnz, use_tab, f);
     *c.stg = s;
-    vrg_log_sweep(c, k, log_open, s.log_nsw - (c.log_rec ? 1u : 0u), log_n, n_in, n_out, tr);
+    vrg_fuse_close_store(c, s, f);
+}
+
+// ---- open-ended sweeps ------------------------------------------------------------------------------------------------------------
+// The closing workgroup of k_sweep is a serial tail of the band chain: a ticket, a round trip for what the others added up, the state
+// out, the kernel's end - 4.5 us of a 29-us trip (in-kernel stamps).  An OPEN-ENDED sweep stops at its commit:
+// nobody takes a ticket, nobody closes.  The state then holds what the sweep ran on plus the sums its workgroups added (VrgState::open
+// = 1), its per-level counters stay where they are, and the NEXT trip's k_band - which loads the state anyway - derives the closed state
+// in every workgroup (vrg_fuse_close_core: arithmetic on registers), its pool workgroups list the touched levels from the counters into
+// LDS themselves, and ONE thread files the closed state, the expected sizes, the trace record and the change log's header
+// (vrg_fuse_persist).  Two rules keep that free of races without a fence:
+//  * a state is never filed into the buffer that workgroups of the same kernel still read: fused trips swap two state buffers
+//    (VrgCtx::stb) - k_band reads one and files into the other, where its decisions already count flips and ties (those four live words
+//    are not filed: k_sweep sets them up for the next trip, vrg_fuse_prepare_other);
+//  * the per-level counters come in two sets by sweep parity: the set an open-ended sweep filled is read by the next k_band and zeroed
+//    by the k_sweep after it, which fills the other one (vrg_fuse_zero_other_levels).
+// The host only ever meets closed states: the last trip of every batch closes its sweep in the old way (and so does a trip that is
+// followed by the memo kernel, or one on a level table too large for a workgroup's LDS list).
+VRG_HD void vrg_state_store_but_live(VrgState* dst, const VrgState& w) {       // all words but nf, ties, near_ties, error
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&w); uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    constexpr unsigned o_nf = offsetof(VrgState, nf) / 4, o_t = offsetof(VrgState, ties) / 4, o_n = offsetof(VrgState, near_ties) / 4, o_e = offsetof(VrgState, error) / 4;
+    for (unsigned i = 0; i < sizeof(VrgState) / 4; i++) if (i != o_nf && i != o_t && i != o_n && i != o_e) d[i] = src[i];
+    if (w.error) vrg_store_i32(&dst->error, w.error);
+}
+// k_band's one filing thread.  s: the state this trip works on (closed: as found, or derived from an open-ended sweep: f, was_open).
+// The label bytes of that sweep are applied by this very kernel, so the filed state says so.
+VRG_HD void vrg_fuse_persist(const VrgCtx& c, const VrgState& s, const VrgFuseClosed& f, bool was_open) {
+    if (c.st == c.stg && !was_open) return;               // (in place, nothing derived: the state is where it belongs)
+    VrgState w = s;
+    w.apply_pending = 0; w.fr_n = 0;
+    if (c.st == c.stg) { w.nf = 0; *c.stg = w; }         // (in place - the sequential test model: the sweep's flips are consumed, the decisions count from zero)
+    else vrg_state_store_but_live(c.stg, w);
+    if (was_open) vrg_fuse_close_store(c, s, f);
+}
+// k_sweep, before anything else: the NEXT trip's k_band will count its flips and ties into the other buffer
+VRG_HD void vrg_fuse_prepare_other(const VrgCtx& c, const VrgState& s0) {
+    if (!c.st_other || c.st_other == c.stg) return;
+    c.st_other->nf = 0; c.st_other->ties = s0.ties; c.st_other->near_ties = s0.near_ties; c.st_other->error = s0.error;
+}
+// ... and the per-level counters of the sweep before (parity p ^ 1) go back to zero: workgroup wg of nwg its stretch of the levels
+VRG_HD void vrg_fuse_zero_other_levels(const VrgCtx& c, int p, uint32_t wg, uint32_t nwg, uint32_t t, uint32_t nt) {
+    const uint32_t per = (c.L + nwg - 1u) / nwg, l0 = wg * per, l1 = l0 + per < c.L ? l0 + per : c.L;
+    for (uint32_t l = l0 + t; l < l1; l += nt) { c.dInS[p ^ 1][l] = 0; c.dOutS[p ^ 1][l] = 0; c.dConvS[p ^ 1][l] = 0; }
 }
 
 // ---- what the fused sweep left for the next trip's k_band (sweep k = the state's iter: already counted)
@@ -1479,7 +1543,7 @@ VRG_HD void vrg_deferred_free(const VrgCtx& c, const VrgState& s, uint32_t j) { 
 // its dense pass is due
 VRG_HD void vrg_deferred_done(const VrgCtx& c, int k) {
     c.nchg[(k & 1) ^ 1] = 0;
-    c.stg->apply_pending = 0; c.stg->fr_n = 0;
+    if (c.st == c.stg) { c.stg->apply_pending = 0; c.stg->fr_n = 0; }     // (fused trips file the state into the other buffer: vrg_fuse_persist says so there)
     vrg_dense_none_step(c, k);
     vrg_drain(); vrg_store_i64(&c.gate[VG_REQ], (int64_t)k);
 }

@@ -118,6 +118,8 @@ struct VrgState {
     // the change log (leader / follower replication, VrgCtx::log_rec): records and sweep headers written since init - monotone
     // counters; a launch knows where its batch's buffer starts (VrgCtx::log_pos0 / log_nsw0)
     uint32_t log_pos, log_nsw;
+    int32_t open;                      // an OPEN-ENDED fused sweep has run on this state and nobody has closed it yet (vrg_items.h "open-ended sweeps"): the next trip's
+                                       // k_band derives the closed state - every workgroup for itself - and one of its threads files it
     uint32_t log_n;                    // fused sweep in progress: records its workgroups have reserved so far (atomic count; log_pos itself moves when the sweep closes)
 };
 
@@ -276,6 +278,15 @@ struct VrgCtx {
     int64_t* st_nin; int64_t* st_nout; double* st_sin; double* st_sout;
     // init scratch
     uint64_t* init_key; uint32_t* init_idx;
+    // Fused trips keep the state in TWO buffers and swap them every trip: k_band reads stb[x] (what the sweep before left), decides into
+    // stb[x ^ 1] - the flip counter and the tie counters are live there while the closed state is being filed beside them - and k_sweep runs on
+    // stb[x ^ 1].  Nobody ever files a state into the buffer other workgroups of the same kernel are still reading.
+    VrgState* stb[2];
+    VrgState* st_other;        // k_sweep: the buffer the NEXT trip's k_band will decide into (its live counters are set up here)
+    // the per-level counters in two sets, by the parity of the sweep that fills them: an open-ended sweep's set is read by the next trip's
+    // k_band while nobody can zero it; the sweep after that does (dIn / dOut / dConv point at the set a kernel works on; the other trips: set 0)
+    uint32_t* dInS[2]; uint32_t* dOutS[2]; uint32_t* dConvS[2];
+    int32_t lvl_par;           // k_band: the set an open-ended sweep before this trip has filled (-1: the sweep before was closed by its own kernel)
     VrgState* st;              // the state as the item functions READ it (a kernel may point it at a snapshot of its own)
     VrgState* stg;             // ... and where it lives in global memory: every atomic and store to a state word goes here
     VrgDense* dn;              // global region statistics of the last closed pass (sum over all Z-slabs)

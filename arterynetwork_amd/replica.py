@@ -104,6 +104,9 @@ def bench_replicas(shape, args, dev, rank, world, roofline, configure, load_traf
     s = make_replica_session(shape, rank, world, device=dev.index, transport=args.transport, leader_verifies=lv)
     _setup(s, I, vm, args, configure)
     s.set_option('batch', args.repl_batch)
+    s.set_option('chain_events', 0)
+    if rank == 0 and not lv:
+        s.set_option('events', 0)
     t0 = time.perf_counter()
     s.init(args.H)
     t_init = time.perf_counter() - t0
@@ -194,6 +197,8 @@ def bench_proxy(shape, args, dev, roofline, configure, load_traffic):
     s = make_replica_session(shape, 0, 1, device=dev.index, transport='rccl', leader_verifies=False)
     _setup(s, I, vm, args, configure)
     s.set_option('batch', args.repl_batch)
+    s.set_option('events', 0)                          # (nothing is timed inside the leader's run: no dense pass, and the chain's time is the run's)
+    s.set_option('chain_events', 0)
     s.init(args.H)
     rl, dtl = timed(s)
     lst = s.repl_stats()

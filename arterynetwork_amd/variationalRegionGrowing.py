@@ -103,11 +103,8 @@ def variationalRegionGrowing(dataArray, valueMap, H=2.25, maxSegmentSize=5000, *
                           'float32 and may decide those differently (this library computes in float64); an indicator, not a '
                           'certificate'.format(r.near_ties),
                           RuntimeWarning, stacklevel=2)
-        elif r.near_ties and s.stats()['density_bins'] > 0:
-            warnings.warn('{} sign test(s) had a relative margin below 2e-5 on a volume whose exact densities are evaluated through '
-                          'intensity bins (more than 2048 distinct values; proved relative error 2e-8).  Decisions that error could '
-                          'turn are counted as ties (none unless the tie warning appears); this is the wider indicator'.format(r.near_ties),
-                          RuntimeWarning, stacklevel=2)
+        # (volumes with more than 2048 distinct values evaluate exact densities through intensity bins, proved relative error 2e-8: every
+        #  band entry carries that bound, and a sign test it could turn is counted in r.ties - the warning above covers it)
         segmented = s.segmented()
         s.labels(out=valueMap)               # in place, caller's dtype
         segmentedMap = (np.asarray(valueMap) <= 1).astype(np.int64)

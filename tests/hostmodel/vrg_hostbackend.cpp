@@ -15,7 +15,7 @@
 #include "../../arterynetwork_amd/csrc/vrg_items.h"
 
 // low limits, so that the hand-back protocols (VBAIL_FUSE: fused -> four-launch trips, VBAIL_FLIPS: -> host-driven) are exercised all the time
-struct VrgBackend { uint32_t small_flips = 8; uint32_t fuse_max = 5; int verify_every = 1; };
+struct VrgBackend { uint32_t small_flips = 8; uint32_t fuse_max = 5; int verify_every = 1; int open_sweeps = 1; };
 
 VrgBackend* be_create(int) { return new VrgBackend(); }
 void be_destroy(VrgBackend* b) { delete b; }
@@ -23,6 +23,7 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)v;
     if (std::strcmp(name, "fuse_max") == 0 && v >= 0 && v <= VRG_FUSE_MAX) b->fuse_max = (uint32_t)v;
     if (std::strcmp(name, "verify_every") == 0 && v >= 0) b->verify_every = (int)v;
+    if (std::strcmp(name, "open_sweeps") == 0) b->open_sweeps = v != 0;
 }
 void* be_alloc(VrgBackend*, size_t bytes) { return std::malloc(bytes); }
 void be_free(VrgBackend*, void* p) { std::free(p); }
@@ -235,8 +236,17 @@ void be_verify_last(VrgBackend* b, const VrgCtx& c, be_reduce_fn cb, void* user)
 
 // k_sweep (the fused sweep), workgroup by workgroup and - inside a workgroup - phase by phase over its 128 threads: the very
 // phase functions the kernel runs between its barriers
-static void fused_update(VrgBackend* b, const VrgCtx& c0) {
-    VrgState& g = *c0.st;
+// open_end: the sweep stops at its commit (vrg_items.h "open-ended sweeps"); the next trip's k_band part derives the closed state
+static void fused_update(VrgBackend* b, const VrgCtx& c00, bool open_end) {
+    VrgState& g = *c00.st;
+    const bool bigl0 = c00.L > (uint32_t)VRG_FUSE_LEVELS;
+    VrgCtx c0 = c00;
+    const int lp = (g.iter + 1) & 1;                   // this sweep's set of per-level counters; the other one goes back to zero (every workgroup its stretch)
+    if (!bigl0) {
+        for (uint32_t wg = 0; wg < (uint32_t)VRG_FUSE_MAX; wg++) vrg_fuse_zero_other_levels(c00, lp, wg, VRG_FUSE_MAX, 0, 1);
+        c0.dIn = c00.dInS[lp]; c0.dOut = c00.dOutS[lp]; c0.dConv = c00.dConvS[lp];
+    }
+    vrg_fuse_prepare_other(c00, g);                    // (a no-op here: this model keeps the state in place)
     const VrgState snap = g;                           // the state as it was when the sweep opened (the kernel's LDS copy)
     const bool bigl = c0.L > (uint32_t)VRG_FUSE_LEVELS;
     const int32_t gate = vrg_fuse_gate(c0, snap, c0.inc[VC_NIN], std::min(b->fuse_max, vrg_fuse_limit(c0)));
@@ -273,6 +283,7 @@ static void fused_update(VrgBackend* b, const VrgCtx& c0) {
         for (uint32_t t = 0; t < T; t++) vrg_fuse_commit(c, sh, th[t], t, r);
     }
     delete shp;
+    if (open_end) { g.open = 1; return; }
     // the workgroup that finishes last: touched levels in ascending order, counters zeroed, the sweep closed
     uint32_t q = 0;
     if (bigl) {                                        // (large level table: the first touchers' list, sorted)
@@ -300,12 +311,24 @@ static void fused_update(VrgBackend* b, const VrgCtx& c0) {
 }
 
 
-void be_sweep_once(VrgBackend* b, const VrgCtx& c0, int flags, VrgEvents*, be_reduce_fn cb, void* user) {
+void be_sweep_once(VrgBackend* b, VrgCtx& c0, int flags, VrgEvents*, be_reduce_fn cb, void* user, bool first, bool last) {
     VrgState& s = *c0.st;
     if (s.done || s.bail) return;
-    if (s.apply_pending) {                             // (k_band: what the fused sweep before this trip left to do)
-        const int k = s.iter;
-        const VrgState snap0 = s;
+    VrgState derived = s;
+    if (s.open) {                                      // (k_band after an open-ended sweep: the touched levels listed from the counters - the device: in every pool workgroup's
+        const int p = (s.iter + 1) & 1;                //  LDS -, the closed state derived, filed by one thread)
+        uint32_t q = 0;
+        for (uint32_t l = 0; l < c0.L; l++) {
+            const uint32_t ci = c0.dInS[p][l], co = c0.dOutS[p][l], cc = c0.dConvS[p][l];
+            if (ci | co | cc) { c0.nz_key[q] = l; c0.nz_val[q] = c0.lev[l]; c0.nz_cin[q] = ci; c0.nz_cout[q] = co; c0.nz_cconv[q] = cc; q++; }
+        }
+        VrgFuseClosed f;
+        vrg_fuse_close_core(c0, derived, c0.inc[VC_NIN], c0.inc[VC_NOUT], q, false, f);
+        vrg_fuse_persist(c0, derived, f, true);
+    }
+    if (derived.apply_pending) {                       // (k_band: what the fused sweep before this trip left to do)
+        const int k = derived.iter;
+        const VrgState snap0 = derived;
         for (uint32_t i = 0; i < snap0.ap_n; i++) vrg_deferred_apply(c0, i, k);
         for (uint32_t i = 0, nc = vrg_deferred_catchup_count(c0, k); i < nc; i++) vrg_deferred_catchup(c0, i, k);
         for (uint32_t j = 0; j < snap0.fr_n; j++) vrg_deferred_free(c0, snap0, j);
@@ -323,7 +346,11 @@ void be_sweep_once(VrgBackend* b, const VrgCtx& c0, int flags, VrgEvents*, be_re
         for (uint32_t slot = 0; slot < snap.np; slot++) vrg_item_band(c, snap, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv);
         for (uint32_t i = 0; i < snap.nfx; i++) vrg_exact_serial(c, snap, c.fresh[i], true);
     }
-    if ((flags & VRG_SWEEP_FUSED) && !(flags & (VRG_SWEEP_SYNC | VRG_SWEEP_FULL))) { fused_update(b, c0); return; }
+    if ((flags & VRG_SWEEP_FUSED) && !(flags & (VRG_SWEEP_SYNC | VRG_SWEEP_FULL))) {
+        // (as the device: not the last trip of a batch, small level tables with the kernel table only)
+        fused_update(b, c0, b->open_sweeps && !last && c0.L <= 1024 && c0.ktab != nullptr);
+        return;
+    }
     // ---- update() as the four-launch chain / host-driven
     if (int32_t stop = vrg_stop_test(c)) { s.done = stop; vrg_close_without_update(c); return; }
     if (s.error) { s.done = -1; return; }
@@ -413,7 +440,7 @@ void* be_ipc_open(VrgBackend*, const void*) { return nullptr; }
 void be_ipc_close(VrgBackend*, void*) {}
 
 void be_events_collect(VrgBackend*, VrgEvents*, long long) {}
-void be_sweep_batch(VrgBackend* b, const VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user) { for (int i = 0; i < n; i++) be_sweep_once(b, c, flags, ev, cb, user); }
+void be_sweep_batch(VrgBackend* b, VrgCtx& c, int flags, int n, VrgEvents* ev, be_reduce_fn cb, void* user) { for (int i = 0; i < n; i++) be_sweep_once(b, c, flags, ev, cb, user, i == 0, i == n - 1); }
 void be_dense_info(VrgBackend*, const VrgCtx& c, int64_t out[5]) { out[0] = 0; out[1] = c.lev16 ? 1 : (c.I ? 0 : 2); out[2] = 1; out[3] = 1; out[4] = 0; }
 void be_dense_flush(VrgBackend*, const VrgCtx&, be_reduce_fn, void*) {}
 long long be_memo_trips(VrgBackend*) { return 0; }
