@@ -122,7 +122,7 @@ def bench_replicas(shape, args, dev, rank, world, roofline, configure, load_traf
     dt = time.perf_counter() - t0
     st, rs = s.stats(), s.repl_stats()
     dense_ms = r.sweep_kernel_ms / max(1, r.sweep_launches)
-    t = torch.tensor([dt, dense_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, dense_ms], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else torch.device('cpu'))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max, kern_ms = float(t[0]), float(t[1])
     tr = s.trace()

@@ -240,6 +240,12 @@ def cpu_baseline(I_t, vm_t, H, levels_note, min_free_gb=48.0, crop_vox=70e6):
             'reference_itself': REFERENCE_ITSELF}
 
 
+# Test aid (tests/test_gpu_parity.py): VRG_BENCH_SHARE_GPU=1 puts every rank of --gpus N on GPU 0 - N processes on the one GPU of a test
+# box, so that the N-rank body of this file runs there; RCCL refuses two ranks on one device, so the change log travels over hipIpc or
+# host callbacks and torch.distributed runs on gloo.  Never a measurement.
+SHARE_GPU = os.environ.get('VRG_BENCH_SHARE_GPU') == '1'
+
+
 def visible_gpus():
     """Devices this process could use (torch.cuda.device_count() does not initialise the GPU on this image)."""
     try:
@@ -268,7 +274,8 @@ def spawn_ranks(args_list, n):
     import glob
     import socket
     import tempfile
-    preflight(n)
+    if not SHARE_GPU:
+        preflight(n)
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
@@ -333,10 +340,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
         raise SystemExit('--gpus {} but the launcher started {} ranks'.format(args.gpus, world))
-    if world > 1:
+    if world > 1 and not SHARE_GPU:
         preflight(world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU path)')
+    if SHARE_GPU:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     from arterynetwork_amd import phantoms
@@ -350,7 +359,12 @@ def main():
         from arterynetwork_amd import slabs
         if 'MASTER_ADDR' not in os.environ:
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
-        dist.init_process_group('nccl', device_id=dev)
+        if SHARE_GPU and world > 1:
+            dist.init_process_group('gloo')
+            if args.transport == 'rccl':
+                args.transport = 'ipc'
+        else:
+            dist.init_process_group('nccl', device_id=dev)
         try:
             if args.partition == 'zslab':
                 out = slabs.bench_slabs(shape, args, dev, rank, world, roofline, configure, load_traffic)
@@ -369,7 +383,7 @@ def main():
             print(json.dumps(out), flush=True)
         dist.barrier()
         dist.destroy_process_group()
-        if out['config']['rccl_ranks'] != world and not (args.partition == 'replica' and out['config'].get('transport') == 'ipc'):   # the data path must be RCCL (or hipIpc) over all ranks, or the line is not the N-GPU line
+        if out['config']['rccl_ranks'] != world and not (args.partition == 'replica' and out['config'].get('transport') == 'ipc') and not SHARE_GPU:   # the data path must be RCCL (or hipIpc) over all ranks, or the line is not the N-GPU line
             raise SystemExit(3)
         return
 

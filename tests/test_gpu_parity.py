@@ -843,9 +843,10 @@ def test_config3_full_size_vs_oracle():
     495 616 000 voxels, both band list orders and densities, `segmented` order, whole trace.  The oracle (all-cores build)
     needs ~25 GB of host memory and about a minute; skipped on a host with less than 64 GB available."""
     import subprocess, sys, os
-    import psutil
     from conftest import ROOT
-    if psutil.virtual_memory().available < 64 * 2 ** 30:
+    sys.path.insert(0, ROOT)
+    import bench
+    if bench.host_memory_available_gb() < 64:
         pytest.skip('needs 64 GB of host memory')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'full_size_check.py'), '--oracle3'], capture_output=True, text=True)
     assert out.returncode == 0 and 'ORACLE3 OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
@@ -903,6 +904,24 @@ def test_replicas_n_ranks_one_gpu(world, shape, sweeps, transport, leader_verifi
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'full_size_check.py'), '--replicas', str(world), shape, str(sweeps), transport, str(leader_verifies)],
                          capture_output=True, text=True)
     assert out.returncode == 0 and 'REPLICAS OK' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize('transport', ['ipc', 'callback'])
+def test_bench_n_rank_body_on_one_gpu(transport):
+    """bench.py --gpus 3 as the driver starts it (torch.distributed.run, one process per rank), its three ranks sharing GPU 0
+    (VRG_BENCH_SHARE_GPU: the box has one GPU; RCCL refuses two ranks on a device, so the log goes over hipIpc / callbacks): the
+    N-rank body runs to its JSON line, valid, every sweep counted."""
+    import subprocess, sys, os, json
+    from conftest import ROOT
+    env = dict(os.environ, VRG_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--shape', '256x256x128', '--steps', '40', '--warmup', '8',
+                          '--transport', transport, '--no-cpu-baseline', '--repl-batch', '8'], capture_output=True, text=True, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[-1])
+    assert d['valid'] and d['n_gpus'] == 3 and d['steps'] == 40 and d['config']['transport'] == transport
+    assert sum(r['sweeps_counted'] or 0 for r in d['config']['ranks']) + 16 >= 40      # (the leader counts a third of the 48 sweeps itself)
+    assert d['roofline']['frac'] and d['roofline']['kernel_ms_avg'] > 0
 
 
 def _replica_run(s, data, vmap, sweeps):

@@ -41,3 +41,14 @@ def test_handoff_litmus_and_its_negative_variants():
     print('negative litmus variants that showed the race this run: {} of {}'.format(seen, len(neg) + len(cross)))
     ok = [l for l in lines if l.startswith('LITMUS sc1 store')]
     assert ok and all('errors 0 of' in l for l in ok)
+    # ... but a box on which NO negative variant ever fails proves nothing about the positive result: one longer retry, then the test
+    # says so (xfail, with the count on record) instead of passing silently
+    if seen == 0:
+        again = subprocess.run([exe, '8000', '3000000'], capture_output=True, text=True, timeout=1500)
+        text2 = again.stdout + again.stderr
+        if os.path.isdir(d):
+            open(os.path.join(d, 'litmus.log'), 'a').write('\n---- retry (no negative variant showed the race) ----\n' + text2)
+        l2 = text2.splitlines()
+        seen = sum(' 0 wrong totals' not in l for l in l2 if l.startswith('TICKET PLAIN-stored')) + sum('errors 0 of' not in l for l in l2 if 'ALL XCDs (cross-XCD: expect errors)' in l)
+        if seen == 0:
+            pytest.xfail('no negative litmus variant showed its race in two runs on this box: the positive result is not shown to be falsifiable here')

@@ -12,7 +12,7 @@
 #   chaos            interleaving campaign on the -DVRG_CHAOS build (tools/build_chaos.sh: random delays at every kernel entry and
 #                    hand-off): the parity tests of the GPU suite, repeat_case / repeat_batched / repeat_stress, a fuzz campaign
 #   stamps[:shape]   in-kernel stamps of the band chain (diagnostic build, tools/build_stamps.sh)
-#   prof:<tag2>:<bench args,comma separated>   rocprofv3 kernel stats + PMC passes (tools/profile_r3.sh)
+#   prof:<tag2>:<bench args,comma separated>   rocprofv3 kernel stats + PMC passes (tools/profile_bench.sh)
 #   traffic:<tag2>:<bench args>                FETCH_SIZE / WRITE_SIZE passes only
 set -u
 tag=${1:?tag}; shift
@@ -62,7 +62,7 @@ for step in "$@"; do
       bash tools/build_stamps.sh > /dev/null && ( export VRG_HIP_LIB=$PWD/arterynetwork_amd/csrc/libvrg_hip_stamps.so
         python tools/chain_stamps.py $shp 1 60 2>&1 | grep -v amdgpu.ids > "$out/chain_stamps.log"
         python tools/chain_stamps.py $shp 0 60 2>&1 | grep -v amdgpu.ids >> "$out/chain_stamps.log" ); cat "$out/chain_stamps.log" ;;
-    prof:*) IFS=: read -r _ t2 args <<< "$step"; IFS=, read -r -a a <<< "$args"; bash tools/profile_r3.sh "$t2" "${a[@]}" 2>&1 | tail -14 ;;
+    prof:*) IFS=: read -r _ t2 args <<< "$step"; IFS=, read -r -a a <<< "$args"; bash tools/profile_bench.sh "$t2" "${a[@]}" 2>&1 | tail -14 ;;
     traffic:*) IFS=: read -r _ t2 args <<< "$step"; IFS=, read -r -a a <<< "$args"; bash tools/profile_traffic.sh "$t2" "${a[@]}" 2>&1 | tail -4 ;;
     *) echo "unknown step $step" ;;
   esac

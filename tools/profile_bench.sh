@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round 3 profile session (run on the GPU box through gpurun): kernel-trace stats + PMC passes (each counter set in a
+# Profile session (run on the GPU box through gpurun): kernel-trace stats + PMC passes (each counter set in a
 # run of its own, with --kernel-trace/--stats only in the first; the PMC runs use --serial 1: counter collection runs one
 # kernel at a time and two of the kernels wait on the device for a kernel of the other stream).
-# usage: tools/profile_r3.sh <tag> [bench args...]
+# usage: tools/profile_bench.sh <tag> [bench args...]
 set -u
-TAG=${1:?usage: profile_r3.sh <tag> [bench args...]}; shift
+TAG=${1:?usage: profile_bench.sh <tag> [bench args...]}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT="gpurun_out/prof_$TAG"
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -21,4 +21,4 @@ run_pmc tcp "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_GATE_EN1_sum 
 run_pmc grbm "GRBM_GUI_ACTIVE GRBM_COUNT" "$@"
 python3 bench.py --steps 500 --warmup 20 --no-cpu-baseline "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -1 "$OUT/bench.json" | cut -c1-300
-python3 tools/summarize_r3.py "$TAG" 2>&1 | tail -40
+python3 tools/summarize_profile.py "$TAG" 2>&1 | tail -40

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The two traffic passes of tools/profile_r3.sh alone (FETCH_SIZE, WRITE_SIZE), for profiles/traffic.json after a change
+# The two traffic passes of tools/profile_bench.sh alone (FETCH_SIZE, WRITE_SIZE), for profiles/traffic.json after a change
 # that left the kernels as they were.   usage: tools/profile_traffic.sh <tag> [bench args...]
 set -u
 TAG=${1:?usage: profile_traffic.sh <tag> [bench args...]}; shift

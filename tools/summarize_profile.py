@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_<tag> (tools/profile_r3.sh) into profiles/<name>_kernel_stats.csv, profiles/<name>_pmc.csv and
-an entry of profiles/traffic.json.   usage: summarize_r3.py <tag> [name] [shape] [planes] [n_gpus] [storage16]"""
+"""Condense gpurun_out/prof_<tag> (tools/profile_bench.sh) into profiles/<name>_kernel_stats.csv, profiles/<name>_pmc.csv and
+an entry of profiles/traffic.json.   usage: summarize_profile.py <tag> [name] [shape] [planes] [n_gpus] [storage16]"""
 import csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
