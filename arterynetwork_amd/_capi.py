@@ -73,6 +73,7 @@ class VrgLib:
         self.run = fn('run', [p, C.c_int64, C.c_int64, C.c_double, C.POINTER(Result)])
         self.get_labels = fn('get_labels', [p, p, C.c_int, i64p])
         self.get_segmented = fn('get_segmented', [p, p, C.c_int64, i64p])
+        self.get_segmented_map = fn('get_segmented_map', [p, p, C.c_int, i64p])
         self.get_band = fn('get_band', [p, C.c_int, p, p, p, C.c_int64, i64p])
         self.get_trace = fn('get_trace', [p, p, C.c_int64, i64p])
         self.get_levels = fn('get_levels', [p, p, p, p, p, p, C.c_int64, i64p])
@@ -258,6 +259,13 @@ class Session:
             out[...] = tmp
         return out
 
+    def segmented_map(self, out=None, dtype=np.int64):
+        """segmentedMap of the reference (:31-32): 1 where the label is 0 or 1; written into `out` when given."""
+        if out is None:
+            out = np.empty(self.shape, dtype=dtype)
+        self._check(self.lib.get_segmented_map(self._h, out.ctypes.data, DTYPE_CODES[out.dtype], _strides(out)))
+        return out
+
     def segmented(self):
         n = C.c_int64()
         self._check(self.lib.get_segmented(self._h, None, 0, C.byref(n)))
@@ -286,11 +294,11 @@ class Session:
 
     def stats(self):
         """Diagnostics: how often a trip was handed back to the host and why, array capacities."""
-        a = (C.c_int64 * 19)()
-        self._check(self.lib.get_stats(self._h, a, 19))
+        a = (C.c_int64 * 20)()
+        self._check(self.lib.get_stats(self._h, a, 20))
         return {'bail_flips': a[1], 'grow_marks': a[2], 'grow_pool': a[3], 'host_driven_trips': a[4],
                 'fused_trips': a[15], 'bail_fuse': a[16], 'density_bins': a[17], 'memo_trips': a[18],
-                'pool_capacity': a[5], 'mark_capacity': a[6], 'pool_slots': a[7], 'dense_bytes': a[8],
+                'data_nonzero': a[19], 'pool_capacity': a[5], 'mark_capacity': a[6], 'pool_slots': a[7], 'dense_bytes': a[8],
                 'dense_kernel': ('k_recount_pipe<3,{}>'.format('true' if a[9] else 'false') if a[14] else
                                  'k_recount_bits<{},{},{},{}>'.format(2 if a[10] == 2 else 3, 'true' if a[9] else 'false', a[10], 'true' if a[12] else 'false')),
                 'dense_nt_loads': bool(a[9]), 'dense_workgroups': a[11], 'dense_listed_units': a[13]}

@@ -38,9 +38,11 @@ void be_clear_error(VrgBackend* b);
 
 // repack caller arrays ([x][y][z] with element strides) into / out of the padded device layout; dstI (fp32) or dstI64
 // *inexact: some value is not representable in fp32 (only written when dstI is given)
-int be_pack_volume(VrgBackend* b, const VrgCtx& c, float* dstI, double* dstI64, const void* src, int dtype, const int64_t st[3], int* inexact);
+// *nonzero (may be null): the number of non-zero values (np.count_nonzero(dataArray), the reference's closing message)
+int be_pack_volume(VrgBackend* b, const VrgCtx& c, float* dstI, double* dstI64, const void* src, int dtype, const int64_t st[3], int* inexact, long long* nonzero);
 int be_pack_labels(VrgBackend* b, const VrgCtx& c, uint8_t* dst, const void* src, int dtype, const int64_t st[3], int* bad);
-int be_unpack_labels(VrgBackend* b, const VrgCtx& c, const uint8_t* lab, void* dst, int dtype, const int64_t st[3]);
+// what: 0 = labels 0..4, 1 = segmentedMap (1 where the label is 0 or 1)
+int be_unpack_labels(VrgBackend* b, const VrgCtx& c, const uint8_t* lab, void* dst, int dtype, const int64_t st[3], int what);
 
 // sorted distinct intensity values; allocates *lev (backend memory), returns the count in *L
 int be_build_levels(VrgBackend* b, const VrgCtx& c, double** lev, uint32_t* L);

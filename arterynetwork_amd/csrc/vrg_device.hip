@@ -28,9 +28,11 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -51,7 +53,7 @@ struct VrgBackend {
     hipEvent_t mark[4] = {nullptr, nullptr, nullptr, nullptr};   // a follower's staging buffers: the kernels that read buffer j have been enqueued up to here (per stream)
     int sweep_blocks = 0;                // 0 = auto (dense_blocks)
     int prio_mode = 2;                   // the dense stream gets the higher priority (measured: -1..2 % step time)
-    uint32_t small_flips = 4096;         // flips per sweep k_order takes on (<= NF_SMALL)
+    uint32_t small_flips = 65536;        // flips per sweep the device-resident four-launch chain takes on (<= NF_WIDE; above NF_SMALL its ordering step runs chip-wide)
     ncclComm_t comm = nullptr;           // per-sweep all-reduce of the slab statistics (multi-GPU)
     char err[256] = "";                  // first HIP / RCCL failure; the engine turns it into VRG_E_INTERNAL
     std::vector<EvPair> ev_pool;
@@ -76,6 +78,9 @@ struct VrgBackend {
     int open_sweeps = 1;                              // option "open_sweeps": fused sweeps inside a batch end at their commit, without a closing workgroup
     int iter_hint = 0;                                // sweeps applied when the engine last read the state + trips enqueued since
     uint32_t band_hint = 0;                           // pool slots in use when the engine last read the state (0: unknown)
+    void* xfer[2] = {nullptr, nullptr}; size_t xfer_bytes = 0;      // two page-locked buffers for host arrays on their way in / out
+    uint32_t flip_hint_min = 0;                       // (a trip came back with this many flips: the launches are sized for at least that until the engine reads a state again)
+    uint32_t flip_hint = 0;                           // ... and the flips of the sweep applied last (sizes the chip-wide launches of a four-launch trip)
     int direct_hint = 1;                              // ... and whether corrections are then evaluated entry by entry (8 lanes per slot)
 };
 
@@ -92,6 +97,7 @@ constexpr int SWEEP_BLOCKS = 256;   // 1 workgroup (4 waves) per CU, each wave w
                                     // flight: measured best for the HBM-bound recount while stream B's band kernels run beside
                                     // it (880x880x640: 256 -> 0.38 ms, 192/384 -> 0.42-0.43, 320 -> 0.49, 512 -> 0.40, 1024 -> 0.44)
 constexpr uint32_t NF_SMALL = 4096; // flips one workgroup sorts in LDS
+constexpr uint32_t NF_WIDE = 65536; // flips the device-resident chain takes: above NF_SMALL they are ranked chip-wide (k_rank_wide); more: host-driven trips
 constexpr uint32_t NZ_LDS = 1024;   // touched levels k_band keeps in LDS
 constexpr int KS_THREADS = 1024;    // k_fix (host-driven trips): one big workgroup
 constexpr int KC_THREADS = 256;     // k_close: one wave per SIMD, so that its workgroups fit on a CU beside the three recount waves
@@ -314,7 +320,7 @@ __device__ __forceinline__ void band_deferred_done(const VrgCtx& c, int k, uint3
 // exp per entry is what this kernel costs), a fixed butterfly adds the partial sums.  With the per-level memo (or
 // nothing to correct) it is one thread per slot.  Workgroups [BAND_BLOCKS, +EXACT_BLOCKS): the exact densities of the
 // slots that (re-)entered the band in the sweep before, then their sign tests (exact_wg).
-constexpr int BAND_BLOCKS = 2048;     // most workgroups k_band uses for the pool; fewer when the engine knows the pool is small (band_blocks())
+constexpr int BAND_BLOCKS = 8192;     // most workgroups k_band uses for the pool (a pool of millions of slots: one turn per thread, not four); fewer when the engine knows the pool is small (band_blocks())
 // Lanes that share a slot when its correction is summed entry by entry (LPE): 16, 8 or 4 by the size of the pool, so that the
 // pool's workgroups stay within one round of the chip (two workgroups per CU) - band_lanes().  Their partial sums are added
 // by a DPP butterfly inside the group (xor 1, xor 2, mirror of 8, mirror of 16: no LDS traffic, where a shuffle is two
@@ -369,7 +375,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
     uint32_t lci[OPEN_PER], lco[OPEN_PER], lcc[OPEN_PER];
 #pragma unroll
     for (uint32_t k = 0; k < OPEN_PER; k++) lci[k] = lco[k] = lcc[k] = 0;
-    nin0 = c.inc[VC_NIN]; nout0 = c.inc[VC_NOUT];
+    nin0 = c.inc_in[VC_NIN]; nout0 = c.inc_in[VC_NOUT];   // (the sizes that go with the state this kernel READS)
     if (pool_wg) {
         // (every load of this batch is unconditional with its index clamped into the array: a load under a divergent branch makes
         // the compiler wait for all loads in flight before the next one)
@@ -391,7 +397,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
     }
     VrgState s_ = *c.st;                                  // a copy (nf is only ever bumped atomically)
     if (s_.done || s_.bail) {
-        if (st0 && c.st != c.stg) *c.stg = s_;            // (a fused trip swaps the state buffers whether it does anything or not)
+        if (st0 && c.st != c.stg) { *c.stg = s_; c.inc[VC_NIN] = nin0; c.inc[VC_NOUT] = nout0; }     // (a fused trip swaps the state buffers whether it does anything or not)
         return;
     }
     // An OPEN-ENDED sweep ran on this state (vrg_items.h "open-ended sweeps"): what it ran on + what its workgroups added up.  Every
@@ -428,7 +434,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
     // Whichever of them finishes last (ticket) asks for the sweep's dense pass.  Their first thread files the state this trip
     // works on (vrg_fuse_persist) - before its workgroup's ticket: the sizes the dense pass has to reproduce are filed with it.
     if (defer_wg) {
-        if (dtid == 0) vrg_fuse_persist(c, s, fcl, was_open);
+        if (dtid == 0) vrg_fuse_persist(c, s, fcl, was_open, nin0, nout0);
         if (!s.apply_pending) return;
         const int k = s.iter;
         if (tid == 0 && dense_on && (int64_t)k - 2 > rseq0) wait_dense_read_for(c, (int64_t)k - 2);   // (the pass of two sweeps ago has read the class copy this sweep rewrites)
@@ -456,10 +462,10 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
             if (slot0 < s.np)
                 vrg_item_band_fields(c, s, slot0, fl0, ip0, op0, lev0, idx0, key0, nin0, nout0, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n, (double)err0);
             for (uint32_t slot = slot0 + band_blocks * TPB; slot < s.np; slot += band_blocks * TPB)
-                vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n);
+                vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n, nin0, nout0);
         } else
             for (uint32_t slot = gtid; slot < s.np; slot += band_blocks * TPB)
-                vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n);
+                vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n, nin0, nout0);
         if (st0 && live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 2); }
         return;
     }
@@ -648,6 +654,9 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
     const uint32_t nf = s0.nf;
     if (t < s0.nnz) { const uint32_t l = (uint32_t)zk0; c.dIn[l] = 0; c.dOut[l] = 0; c.dConv[l] = 0; c.ltouch[l] = 0; }   // level counters of the sweep before
     for (uint32_t j = t + T; j < s0.nnz; j += T) vrg_item_level_clear(c, j);
+    // more flips than this workgroup orders in LDS: the chip-wide kernels behind it do the ordering (they are no-ops otherwise)
+    if (nf > NF_SMALL) { if (t == 0) { vrg_open_update(c); c.stg->wide = 1; } return; }
+    if (t == 0) c.stg->wide = 0;
     // the flips' records as k_band appended them; sorted by key, the payload being the record's number
     if (t < nf) { s_key[t] = k0; s_slot[t] = t; }
     for (uint32_t q = t + T; q < nf; q += T) { s_key[q] = c.f_key[q]; s_slot[q] = q; }
@@ -682,6 +691,53 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
             __syncthreads();
             if (!s_changed) break;
         }
+    }
+}
+
+// ---- k_order's work chip-wide, for sweeps of NF_SMALL .. NF_WIDE flips (VrgState::wide) --------------------------------------------
+// rank of a flip = the number of smaller sort keys (the keys are distinct): every thread owns one record and looks at ALL keys, which
+// pass through LDS a tile at a time (broadcast reads) - n^2 comparisons, 4 * 10^9 at 65 536 flips: ~0.1 ms on the chip; 10^8 at 10^4
+// flips: a few microseconds.  No global sort, no host.  Then the flip's L (+P) bits, stamp and the ordered flip arrays (vrg_item_list_rec).
+constexpr int KR_THREADS = 256;
+constexpr uint32_t KR_TILE = 2048;
+__global__ void __launch_bounds__(KR_THREADS) k_rank_wide(VrgCtx c) {
+    __shared__ uint64_t s_k[KR_TILE];
+    const VrgState& s = *c.st;
+    if (s.done || s.bail || !s.wide) return;
+    const uint32_t nf = min(s.nf, c.fcap), t = threadIdx.x;
+    for (uint32_t i0 = blockIdx.x * KR_THREADS; i0 < nf; i0 += gridDim.x * KR_THREADS) {      // (whole workgroups stay in the loop together: the tile barriers)
+        const uint32_t i = i0 + t;
+        const uint64_t key = i < nf ? c.f_key[i] : ~0ull;
+        uint32_t r = 0;
+        for (uint32_t j0 = 0; j0 < nf; j0 += KR_TILE) {
+            __syncthreads();
+            for (uint32_t j = t; j < KR_TILE; j += KR_THREADS) s_k[j] = j0 + j < nf ? c.f_key[j0 + j] : ~0ull;
+            __syncthreads();
+            const uint32_t m = min(KR_TILE, nf - j0);
+#pragma unroll 8
+            for (uint32_t j = 0; j < m; j++) r += s_k[j] < key;
+        }
+        if (i < nf) vrg_item_list_rec(c, r, c.flist[i], c.fr_idx[i], c.fr_lev[i], !(key >> 63));
+    }
+}
+__global__ void __launch_bounds__(TPB) k_prepass_wide(VrgCtx c) {               // phase-A label of the flip-ins (every L bit is in place: a kernel boundary)
+    const VrgState& s = *c.st;
+    if (s.done || s.bail || !s.wide) return;
+    ITEM_LOOP(min(s.nf, c.fcap)) vrg_item_prepass(c, i);
+}
+__global__ void __launch_bounds__(1024) k_fix_wide(VrgCtx c) {                  // skip-rule fix-point (rare), one workgroup
+    __shared__ int changed;
+    const VrgState& s = *c.st;
+    if (s.done || s.bail || !s.wide) return;
+    const uint32_t np_ = s.npend;
+    if (np_ == 0) return;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < np_; j += blockDim.x) if (vrg_item_fix(c, j) == 2) changed = 1;
+        __syncthreads();
+        if (!changed) break;
     }
 }
 
@@ -844,19 +900,20 @@ __global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
 // workgroup that arrives last (a ticket; what it reads of the others' work - region sizes, error word - went through
 // device-scope atomics / write-through stores) files the sizes, asks for the dense pass and closes the sweep.
 constexpr int CLOSE_APPLY = 8;
-__global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
+// (napply: the workgroups that apply the sweep's label bytes - CLOSE_APPLY, more for a sweep with thousands of flips)
+__global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on, uint32_t napply) {
     VRG_CHAOS_POINT(4);
     constexpr uint32_t T = KC_THREADS;
     const uint32_t t = threadIdx.x;
-    const bool st0 = blockIdx.x == 0 && t == 0, stm = blockIdx.x == CLOSE_APPLY && t == 0;
+    const bool st0 = blockIdx.x == 0 && t == 0, stm = blockIdx.x == napply && t == 0;
     const unsigned long long t_entry = (st0 || stm) ? VRG_STAMP_NOW() : 0ull;
     // What a thread's FIRST item of every list needs travels with the state (the lists are complete, whatever the state
     // says; any index below a list's capacity is readable): the apply workgroups' marked voxel with its current byte, the
     // class change of the sweep before, a flip's result, a dead slot - one round trip, where a loop after a loop made five.
-    const uint32_t g = blockIdx.x * T + t, G = CLOSE_APPLY * T;
+    const uint32_t g = blockIdx.x * T + t, G = napply * T;
     uint32_t mk0 = 0, cdwA = VRG_NOCHG, cxA = 0, cdwB = VRG_NOCHG, cxB = 0, dead0 = 0, ncA = 0, ncB = 0; uint8_t mn0 = 0, old0 = 0, fres0 = FR_WRITTEN; uint64_t zk0 = 0;
     int64_t rseq0 = 0;
-    if (blockIdx.x < CLOSE_APPLY) {
+    if (blockIdx.x < napply) {
         if (g < c.mcap) {                              // (both parities of the change list: which one the sweep before filed follows from the state)
             mk0 = c.mk_idx[g]; mn0 = c.mk_new[g]; old0 = c.mk_old[g]; dead0 = c.dead[g];
             cdwA = c.chg_dw[0][g]; cxA = c.chg_x[0][g]; cdwB = c.chg_dw[1][g]; cxB = c.chg_x[1][g];
@@ -879,7 +936,7 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
     const uint32_t nmk = min(s0.nmk, c.mcap);
     if (st0) { VRG_STAMP_PUT(c, 24, t_entry); VRG_STAMP(c, 25); }
     if (stm) VRG_STAMP_PUT(c, 32, t_entry);
-    if (blockIdx.x < CLOSE_APPLY) {
+    if (blockIdx.x < napply) {
         const uint32_t nf = s0.nf, nd = s0.ndead, nalloc = s0.nalloc, nc = min(pc ? ncB : ncA, c.mcap);
         if (t == 0 && dense_on && (int64_t)s0.iter - 1 > rseq0) wait_dense_read(c);        // (the pass of two sweeps ago has read the class copy this sweep rewrites)
         __syncthreads();
@@ -900,7 +957,7 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
             __syncthreads();
             for (uint32_t j = t; j < nnz; j += T) vrg_item_level(c, j, false);
         }
-    } else if ((c.lvl_scan || nnz <= NZ_SORT) && (use_tab || blockIdx.x == CLOSE_APPLY)) {
+    } else if ((c.lvl_scan || nnz <= NZ_SORT) && (use_tab || blockIdx.x == napply)) {
         // this sweep's touched levels in ascending order (a fixed summation order), with their counts
         if (c.lvl_scan) {
             // small level table: every level's three counters are looked at - thread t its stretch of levels - and the
@@ -927,7 +984,7 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
             nnz = total;
             __syncthreads();
             if (stm) VRG_STAMP(c, 33);
-            if (blockIdx.x == CLOSE_APPLY) {                             // the list itself: the next k_order clears these counters, an entry-by-entry k_band sums over it
+            if (blockIdx.x == napply) {                             // the list itself: the next k_order clears these counters, an entry-by-entry k_band sums over it
                 for (uint32_t j = t; j < nnz; j += T) c.nz_key[j] = s_key[j];
                 if (t == 0) __hip_atomic_store(&c.stg->nnz, nnz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by whoever closes the sweep)
             }
@@ -943,11 +1000,11 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on) {
             }
             __syncthreads();
         }
-        if (blockIdx.x == CLOSE_APPLY)                                   // the ordered level list, for an entry-by-entry k_band
+        if (blockIdx.x == napply)                                   // the ordered level list, for an entry-by-entry k_band
             // (nz_key itself stays as it is: the other workgroups may still be reading it, and only the set matters later)
             for (uint32_t j = t; j < nnz; j += T) { c.nz_val[j] = s_val[j]; c.nz_cin[j] = s_cin[j]; c.nz_cout[j] = s_cout[j]; c.nz_cconv[j] = s_cconv[j]; }
         if (use_tab) {                                                   // the memo: one wave per level
-            const uint32_t lane = t & 63, wid = ((blockIdx.x - CLOSE_APPLY) * T + t) >> 6, nw = (TAB_BLOCKS * T) >> 6;
+            const uint32_t lane = t & 63, wid = ((blockIdx.x - napply) * T + t) >> 6, nw = (TAB_BLOCKS * T) >> 6;
             for (uint32_t l = wid; l < c.L; l += nw) {
                 const double v = c.lev[l];
                 double a = 0, bb = 0, d = 0;
@@ -1855,15 +1912,20 @@ __device__ __forceinline__ void store_int(void* p, int dtype, int64_t i, int v) 
         default: ((double*)p)[i] = v; break;
     }
 }
-__global__ void k_pack_volume(VrgCtx c, float* dst, double* dst64, const void* src, int dtype, int64_t s0, int64_t s1, int64_t s2, int* flag) {
+// (nz: the number of non-zero values - np.count_nonzero(dataArray) of the reference's closing message, :95 - counted on the way)
+__global__ void k_pack_volume(VrgCtx c, float* dst, double* dst64, const void* src, int dtype, int64_t s0, int64_t s1, int64_t s2, int* flag, unsigned long long* nz) {
+    unsigned long long mine = 0;
     VOXEL_LOOP(c) {
         int x, y, z; uint32_t idx = real_idx(c, t, x, y, z);
         double v = load_as_double(src, dtype, x * s0 + y * s1 + z * s2);
+        mine += v != 0.0;
         if (dst64) { dst64[idx] = v; continue; }
         float f = (float)v;
         if ((double)f != v) *flag = 1;
         dst[idx] = f;
     }
+    mine = (unsigned long long)wave_sum((long long)mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(nz, mine);
 }
 __global__ void k_pack_labels(VrgCtx c, uint8_t* dst, const void* src, int dtype, int64_t s0, int64_t s1, int64_t s2, int* flag) {
     VOXEL_LOOP(c) {
@@ -1874,10 +1936,11 @@ __global__ void k_pack_labels(VrgCtx c, uint8_t* dst, const void* src, int dtype
         dst[idx] = bb;
     }
 }
-__global__ void k_unpack_labels(VrgCtx c, const uint8_t* lab, void* dst, int dtype, int64_t s0, int64_t s1, int64_t s2) {
+__global__ void k_unpack_labels(VrgCtx c, const uint8_t* lab, void* dst, int dtype, int64_t s0, int64_t s1, int64_t s2, int what) {
     VOXEL_LOOP(c) {
         int x, y, z; uint32_t idx = real_idx(c, t, x, y, z);
-        store_int(dst, dtype, x * s0 + y * s1 + z * s2, vrg_dec(lab[idx]));
+        const int v = vrg_dec(lab[idx]);
+        store_int(dst, dtype, x * s0 + y * s1 + z * s2, what ? (v <= 1 ? 1 : 0) : v);
     }
 }
 __global__ void k_build_lev16(VrgCtx c, uint16_t* dst) {
@@ -2016,6 +2079,7 @@ void be_destroy(VrgBackend* b) {
     for (auto& p : b->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (int j = 0; j < 4; j++) if (b->mark[j]) (void)hipEventDestroy(b->mark[j]);
     if (b->tmp) (void)hipFree(b->tmp);
+    for (int j = 0; j < 2; j++) if (b->xfer[j]) (void)hipHostFree(b->xfer[j]);
     if (b->keys2) (void)hipFree(b->keys2);
     if (b->sa) (void)hipStreamDestroy(b->sa);
     if (b->sb) (void)hipStreamDestroy(b->sb);
@@ -2037,7 +2101,13 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "dense_pipe") == 0) b->dense_pipe = (int)v;
     if (std::strcmp(name, "memo_above") == 0 && v >= 0) b->memo_above = (uint32_t)std::min<long long>(v, 0x7fffffff);
     if (std::strcmp(name, "verify_every") == 0 && v >= 0) b->verify_every = (int)std::min<long long>(v, 1 << 20);
-    if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)std::min<long long>(v, NF_SMALL);
+    if (std::strcmp(name, "small_flips") == 0 && v >= 0) b->small_flips = (uint32_t)std::min<long long>(v, NF_WIDE);
+    if (std::strcmp(name, "flip_hint") == 0) {           // (a sweep as large as the one that came back has been applied: the floor has done its job)
+        const uint32_t f = (uint32_t)std::min<long long>(std::max<long long>(v, 0), 0x7fffffff);
+        if (f >= b->flip_hint_min) b->flip_hint_min = 0;
+        b->flip_hint = std::max(f, b->flip_hint_min);
+    }
+    if (std::strcmp(name, "flip_hint_min") == 0) { b->flip_hint_min = (uint32_t)std::min<long long>(std::max<long long>(v, 0), 0x7fffffff); b->flip_hint = std::max(b->flip_hint, b->flip_hint_min); }
     if (std::strcmp(name, "prio_mode") == 0 && v >= 0 && v <= 2 && v != b->prio_mode) { b->prio_mode = (int)v; make_streams(b); }
 }
 uint32_t be_small_flip_limit(VrgBackend* b) { return b->small_flips; }
@@ -2062,50 +2132,149 @@ void be_clear_error(VrgBackend* b) { b->err[0] = 0; }
 void be_sync(VrgBackend* b) { use_device(b); HIP_CHECK(hipStreamSynchronize(b->sa)); HIP_CHECK(hipStreamSynchronize(b->sb)); if (b->sd) HIP_CHECK(hipStreamSynchronize(b->sd)); b->fused_prev = false; b->prev_open = false; }
 
 // A device-resident input is read on the library's own stream: the caller's producer must have finished (vrg.h).
-static const void* stage_in(VrgBackend* b, const VrgCtx& c, const void* src, int dtype, void** tmp) {
-    *tmp = nullptr;
+// ---- host arrays in and out --------------------------------------------------------------------------------------------------------
+// The reference's own calling convention is int64 valueMap and int / float64 dataArray (variationalRegionGrowing.py:44-46, :288): 8 bytes per
+// voxel each way over PCIe from pageable memory.  A HOST array wider than what the device keeps is therefore narrowed on the host first -
+// labels to one byte, intensities to fp32 when every value survives that (else the raw array travels: the volume is kept as float64) - by a
+// few threads, a chunk at a time through two page-locked buffers, so that the narrowing of one chunk overlaps the copy of the chunk before;
+// results go the other way: one byte per voxel comes back and is widened into the caller's array on the host.
+constexpr size_t XFER_CHUNK = 32u << 20;              // elements per chunk
+static int host_threads() { const unsigned n = std::thread::hardware_concurrency(); return (int)std::min<unsigned>(16u, std::max<unsigned>(1u, n)); }
+template <class F> static void parallel_chunks(size_t n, F f) {                  // f(begin, end) on a few threads
+    const int nt = n < (1u << 20) ? 1 : host_threads();
+    if (nt == 1) { f((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; t++) { const size_t a = std::min(n, t * per), e = std::min(n, a + per); if (a < e) th.emplace_back([=] { f(a, e); }); }
+    for (auto& x : th) x.join();
+}
+static bool xfer_buffers(VrgBackend* b, size_t bytes) {
+    if (b->xfer_bytes >= bytes) return true;
+    for (int j = 0; j < 2; j++) { if (b->xfer[j]) (void)hipHostFree(b->xfer[j]); b->xfer[j] = nullptr; }
+    b->xfer_bytes = 0;
+    for (int j = 0; j < 2; j++) if (hipHostMalloc(&b->xfer[j], bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+    b->xfer_bytes = bytes;
+    return true;
+}
+template <class T> static double host_load(const void* p, size_t i) { return (double)((const T*)p)[i]; }
+static double host_load_as_double(const void* p, int dtype, size_t i) {
+    switch (dtype) { case 0: return host_load<uint8_t>(p, i); case 1: return host_load<int16_t>(p, i); case 2: return host_load<uint16_t>(p, i); case 3: return host_load<int32_t>(p, i);
+                     case 4: return host_load<int64_t>(p, i); case 5: return host_load<float>(p, i); default: return host_load<double>(p, i); }
+}
+// a host array of V elements narrowed to `out_elem`-byte elements (1: label bytes, 255 for a value that is no label; 4: fp32) and copied to
+// device memory `dev`, chunk by chunk; *flag: a value did not survive (labels: not 0 / 3 / 4; intensities: not exact in fp32 - the copy stops)
+static bool narrow_to_device(VrgBackend* b, void* dev, const void* src, int dtype, size_t V, int out_elem, int* flag) {
+    if (!xfer_buffers(b, XFER_CHUNK * 4)) return false;
+    *flag = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int j = 0; j < 2; j++) HIP_CHECK(hipEventCreateWithFlags(&ev[j], hipEventDisableTiming));
+    int k = 0;
+    for (size_t i0 = 0; i0 < V; i0 += XFER_CHUNK, k ^= 1) {
+        const size_t n = std::min(XFER_CHUNK, V - i0);
+        HIP_CHECK(hipEventSynchronize(ev[k]));           // (the copy that last used this buffer is done)
+        std::atomic<int> bad{0};
+        void* buf = b->xfer[k];
+        parallel_chunks(n, [&](size_t a, size_t e) {
+            int mine = 0;
+            if (out_elem == 1) { uint8_t* o = (uint8_t*)buf; for (size_t i = a; i < e; i++) { const double v = host_load_as_double(src, dtype, i0 + i); const bool ok = v == 0 || v == 3 || v == 4; o[i] = ok ? (uint8_t)v : 255; mine |= !ok; } }
+            else { float* o = (float*)buf; for (size_t i = a; i < e; i++) { const double v = host_load_as_double(src, dtype, i0 + i); const float f = (float)v; o[i] = f; mine |= ((double)f != v); } }
+            if (mine) bad.store(1);
+        });
+        if (bad.load()) { *flag = 1; if (out_elem == 4) break; }
+        HIP_CHECK(hipMemcpyAsync((uint8_t*)dev + i0 * out_elem, buf, n * out_elem, hipMemcpyHostToDevice, b->sa));
+        HIP_CHECK(hipEventRecord(ev[k], b->sa));
+    }
+    HIP_CHECK(hipStreamSynchronize(b->sa));
+    for (int j = 0; j < 2; j++) (void)hipEventDestroy(ev[j]);
+    return true;
+}
+// A device-resident input is read on the library's own stream: the caller's producer must have finished (vrg.h).
+// *dtype_dev: the element type of what is on the device (a narrowed host array: VRG_U8 / VRG_F32); *early: the narrowing already
+// answered the question the kernel would have answered (an intensity that fp32 cannot hold: nothing was copied)
+static const void* stage_in(VrgBackend* b, const VrgCtx& c, const void* src, int dtype, void** tmp, int* dtype_dev, int narrow_to, int* early) {
+    *tmp = nullptr; *dtype_dev = dtype; *early = 0;
     if (is_device_ptr(src)) return src;
-    size_t bytes = (size_t)c.nx * c.ny * c.nz * kElem[dtype];
+    const size_t V = (size_t)c.nx * c.ny * c.nz;
+    if (narrow_to && (int)kElem[dtype] > narrow_to) {
+        if (hipMalloc(tmp, V * narrow_to) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        int flag = 0;
+        if (!narrow_to_device(b, *tmp, src, dtype, V, narrow_to, &flag)) { HIP_CHECK(hipFree(*tmp)); *tmp = nullptr; return nullptr; }
+        if (flag && narrow_to == 4) { *early = 1; return *tmp; }           // (the volume is kept as float64: the caller comes again for the raw array)
+        *dtype_dev = narrow_to == 1 ? VRG_U8 : VRG_F32;
+        return *tmp;
+    }
+    size_t bytes = V * kElem[dtype];
     if (hipMalloc(tmp, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     HIP_CHECK(hipMemcpyAsync(*tmp, src, bytes, hipMemcpyHostToDevice, b->sa));
     return *tmp;
 }
 
-int be_pack_volume(VrgBackend* b, const VrgCtx& c, float* dst, double* dst64, const void* src, int dtype, const int64_t st[3], int* inexact) {
+int be_pack_volume(VrgBackend* b, const VrgCtx& c, float* dst, double* dst64, const void* src, int dtype, const int64_t st[3], int* inexact, long long* nonzero) {
     use_device(b);
     if (!dense_strides(c, st)) return -1;
-    void* tmp; const void* d = stage_in(b, c, src, dtype, &tmp);
+    void* tmp; int dt = dtype, early = 0;
+    const void* d = stage_in(b, c, src, dtype, &tmp, &dt, dst64 ? 0 : 4, &early);     // (the fp32 attempt narrows a wide host array; the float64 pass takes it raw)
     if (!d) return -1;
-    int* flag; HIP_CHECK(hipMalloc(&flag, sizeof(int))); HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), b->sa));
-    k_pack_volume<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, dst, dst64, d, dtype, st[0], st[1], st[2], flag);
-    HIP_CHECK(hipMemcpyAsync(inexact, flag, sizeof(int), hipMemcpyDeviceToHost, b->sa));
+    if (early) { *inexact = 1; HIP_CHECK(hipFree(tmp)); return 0; }
+    struct { int flag; int pad; unsigned long long nz; } host = {0, 0, 0}, *dev = nullptr;
+    HIP_CHECK(hipMalloc(&dev, sizeof(host))); HIP_CHECK(hipMemsetAsync(dev, 0, sizeof(host), b->sa));
+    k_pack_volume<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, dst, dst64, d, dt, st[0], st[1], st[2], &dev->flag, &dev->nz);
+    HIP_CHECK(hipMemcpyAsync(&host, dev, sizeof(host), hipMemcpyDeviceToHost, b->sa));
     HIP_CHECK(hipStreamSynchronize(b->sa));
-    HIP_CHECK(hipFree(flag)); if (tmp) HIP_CHECK(hipFree(tmp));
+    *inexact = host.flag; if (nonzero) *nonzero = (long long)host.nz;
+    HIP_CHECK(hipFree(dev)); if (tmp) HIP_CHECK(hipFree(tmp));
     return 0;
 }
 int be_pack_labels(VrgBackend* b, const VrgCtx& c, uint8_t* dst, const void* src, int dtype, const int64_t st[3], int* bad) {
     use_device(b);
     if (!dense_strides(c, st)) return -1;
-    void* tmp; const void* d = stage_in(b, c, src, dtype, &tmp);
+    void* tmp; int dt = dtype, early = 0;
+    const void* d = stage_in(b, c, src, dtype, &tmp, &dt, 1, &early);
     if (!d) return -1;
     int* flag; HIP_CHECK(hipMalloc(&flag, sizeof(int))); HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), b->sa));
-    k_pack_labels<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, dst, d, dtype, st[0], st[1], st[2], flag);
+    k_pack_labels<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, dst, d, dt, st[0], st[1], st[2], flag);
     HIP_CHECK(hipMemcpyAsync(bad, flag, sizeof(int), hipMemcpyDeviceToHost, b->sa));
     HIP_CHECK(hipStreamSynchronize(b->sa));
     HIP_CHECK(hipFree(flag)); if (tmp) HIP_CHECK(hipFree(tmp));
     return 0;
 }
-int be_unpack_labels(VrgBackend* b, const VrgCtx& c, const uint8_t* lab, void* dst, int dtype, const int64_t st[3]) {
+template <class T> static void host_widen(void* dst, const uint8_t* src, size_t a, size_t e) { T* o = (T*)dst; for (size_t i = a; i < e; i++) o[i] = (T)src[i]; }
+// what: 0 = the labels 0..4 (valueMap on return, :33-36), 1 = segmentedMap (labels <= 1 -> 1, else 0: :31-32)
+int be_unpack_labels(VrgBackend* b, const VrgCtx& c, const uint8_t* lab, void* dst, int dtype, const int64_t st[3], int what) {
     use_device(b);
     if (!dense_strides(c, st)) return -1;
     bool dev = is_device_ptr(dst);
-    size_t bytes = (size_t)c.nx * c.ny * c.nz * kElem[dtype];
-    void* d = dst;
-    if (!dev && hipMalloc(&d, bytes) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    k_unpack_labels<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, lab, d, dtype, st[0], st[1], st[2]);
-    if (!dev) { HIP_CHECK(hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, b->sa)); }
-    HIP_CHECK(hipStreamSynchronize(b->sa));
-    if (!dev) HIP_CHECK(hipFree(d));
+    const size_t V = (size_t)c.nx * c.ny * c.nz;
+    if (dev) {
+        k_unpack_labels<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, lab, dst, dtype, st[0], st[1], st[2], what);
+        HIP_CHECK(hipStreamSynchronize(b->sa));
+        return 0;
+    }
+    // a host array: one byte per voxel in the caller's layout comes back, widened on the host chunk by chunk
+    void* d = nullptr;
+    if (hipMalloc(&d, V) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    k_unpack_labels<<<voxel_blocks(c), TPB, 0, b->sa>>>(c, lab, d, VRG_U8, st[0], st[1], st[2], what);
+    if (kElem[dtype] == 1) { HIP_CHECK(hipMemcpyAsync(dst, d, V, hipMemcpyDeviceToHost, b->sa)); HIP_CHECK(hipStreamSynchronize(b->sa)); HIP_CHECK(hipFree(d)); return 0; }
+    if (!xfer_buffers(b, XFER_CHUNK * 4)) { HIP_CHECK(hipFree(d)); return -1; }
+    int k = 0;
+    size_t prev0 = 0, prevn = 0; int prevk = -1;
+    auto widen = [&](size_t i0, size_t n, int kk) {
+        const uint8_t* srcb = (const uint8_t*)b->xfer[kk];
+        uint8_t* base = (uint8_t*)dst + i0 * kElem[dtype];
+        parallel_chunks(n, [&](size_t a, size_t e) {
+            switch (dtype) { case 1: host_widen<int16_t>(base, srcb, a, e); break; case 2: host_widen<uint16_t>(base, srcb, a, e); break; case 3: host_widen<int32_t>(base, srcb, a, e); break;
+                             case 4: host_widen<int64_t>(base, srcb, a, e); break; case 5: host_widen<float>(base, srcb, a, e); break; default: host_widen<double>(base, srcb, a, e); break; }
+        });
+    };
+    for (size_t i0 = 0; i0 < V; i0 += XFER_CHUNK, k ^= 1) {
+        const size_t n = std::min(XFER_CHUNK, V - i0);
+        HIP_CHECK(hipMemcpyAsync(b->xfer[k], (const uint8_t*)d + i0, n, hipMemcpyDeviceToHost, b->sa));
+        if (prevk >= 0) widen(prev0, prevn, prevk);        // (the chunk before, while this one travels)
+        HIP_CHECK(hipStreamSynchronize(b->sa));
+        prev0 = i0; prevn = n; prevk = k;
+    }
+    if (prevk >= 0) widen(prev0, prevn, prevk);
+    HIP_CHECK(hipFree(d));
     return 0;
 }
 
@@ -2396,10 +2565,20 @@ static void host_driven_update(VrgBackend* b, const VrgCtx& c, int flags) {
 static void small_update(VrgBackend* b, const VrgCtx& c0, bool dense, hipEvent_t e_chain_stop = nullptr) {
     VrgCtx c = c0;
     c.lvl_scan = c.L <= NZ_SORT ? 1 : 0;             // small level table: the touched levels are found by scanning the counters (k_close)
-    k_order<<<1, KO_THREADS, 0, b->sa>>>(c, b->small_flips);
-    k_mark_relabel<<<KM_BLOCKS, KM_THREADS, 0, b->sa>>>(c);
+    // (sized by the flips of the last sweep the engine saw: a sweep of thousands of flips gets a workgroup per flip, not a queue of them;
+    // a sweep with more flips than its launches can order is handed back - VBAIL_FLIPS - and enqueued again with launches that can)
+    const uint32_t fh = std::max<uint32_t>(b->flip_hint, 1u);
+    const bool wide = 2 * (uint64_t)fh > NF_SMALL;
+    k_order<<<1, KO_THREADS, 0, b->sa>>>(c, wide ? b->small_flips : std::min<uint32_t>(b->small_flips, NF_SMALL));
+    if (wide) {                  // its ordering step chip-wide (no-ops when k_order did the ordering itself)
+        k_rank_wide<<<std::min<uint32_t>(1024u, (2 * fh + KR_THREADS - 1) / KR_THREADS), KR_THREADS, 0, b->sa>>>(c);
+        k_prepass_wide<<<std::min<uint32_t>(1024u, (2 * fh + TPB - 1) / TPB), TPB, 0, b->sa>>>(c);
+        k_fix_wide<<<1, 1024, 0, b->sa>>>(c);
+    }
+    k_mark_relabel<<<std::max<uint32_t>(KM_BLOCKS, std::min<uint32_t>(2 * fh, NF_WIDE)), KM_THREADS, 0, b->sa>>>(c);
     // (waits on the device for the dense pass of two sweeps ago)
-    hipExtLaunchKernelGGL(k_close, dim3(CLOSE_APPLY + TAB_BLOCKS), dim3(KC_THREADS), 0, b->sa, nullptr, e_chain_stop, 0, c, dense ? 1 : 0);
+    const uint32_t napply = std::max<uint32_t>(CLOSE_APPLY, std::min<uint32_t>(1024u, fh / 8u));
+    hipExtLaunchKernelGGL(k_close, dim3(napply + TAB_BLOCKS), dim3(KC_THREADS), 0, b->sa, nullptr, e_chain_stop, 0, c, dense ? 1 : 0, napply);
 }
 
 static void enqueue_dense(VrgBackend* b, const VrgCtx& c, hipEvent_t e_start, hipEvent_t e_stop, be_reduce_fn cb, void* user);
@@ -2443,6 +2622,7 @@ void be_sweep_once(VrgBackend* b, VrgCtx& c, int flags, VrgEvents* ev, be_reduce
     {
         VrgCtx cb_ = c;
         cb_.st = st_in; cb_.stg = st_out; cb_.lvl_par = b->prev_open ? b->open_par : -1;
+        cb_.inc_in = c.inc; cb_.inc = fused_trip ? (c.inc == c.incb[0] ? c.incb[1] : c.incb[0]) : c.inc;
         const dim3 grid(nbb + EXACT_BLOCKS + ((b->fused_prev || fused_trip) ? DEFER_WGS : 0));
         const int lanes = band_lanes(b), dh = band_direct(b) ? 1 : 0, don = dense ? 1 : 0;
         if (lanes == 16) hipExtLaunchKernelGGL(k_band<16>, grid, dim3(TPB), 0, b->sa, e_c0, nullptr, 0, cb_, nbb, don, dh);
@@ -2450,6 +2630,8 @@ void be_sweep_once(VrgBackend* b, VrgCtx& c, int flags, VrgEvents* ev, be_reduce
         else hipExtLaunchKernelGGL(k_band<4>, grid, dim3(TPB), 0, b->sa, e_c0, nullptr, 0, cb_, nbb, don, dh);
     }
     c.st = c.stg = st_out; c.st_other = st_in;             // (where the state is from here on; k_sweep sets up the buffer just read for the next trip's decisions)
+    if (fused_trip) c.inc = c.inc == c.incb[0] ? c.incb[1] : c.incb[0];
+    c.inc_in = c.inc;
     const int sweep_par = (b->iter_hint + 1) & 1;          // the sweep this trip applies, if it applies one
     b->iter_hint++;
     b->prev_open = false;

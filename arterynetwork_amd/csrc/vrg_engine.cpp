@@ -68,6 +68,7 @@ struct vrg_handle {
     long long bails[6] = {0, 0, 0, 0, 0, 0};   // how often a trip came back, by VBAIL_* reason
     long long fused_trips = 0;
     long long sync_trips = 0;
+    long long data_nonzero = 0;          // np.count_nonzero(dataArray), counted while the volume was packed
 };
 
 extern "C" void API(destroy)(vrg_handle* h);
@@ -113,6 +114,7 @@ VrgState get_state(vrg_handle* h) {
     VrgState s; be_download(h->be, &s, h->c.st, sizeof(s));
     be_set_tuning(h->be, "band_hint", s.np);
     be_set_tuning(h->be, "iter_hint", s.iter);
+    be_set_tuning(h->be, "flip_hint", s.last_nf);
     be_set_tuning(h->be, "direct_hint", !vrg_tab_pays(h->c.L, s.ni + s.no));
     return s;
 }
@@ -250,7 +252,8 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.dn_part = alloc<VrgDense>(h, 16);
     c.dn_ring = alloc<VrgDense>(h, VRG_RING); c.exp_ring = alloc<int64_t>(h, 2 * VRG_RING);
     c.stage_in = alloc<VrgDense>(h, VRG_STAGE); c.stage_out = alloc<VrgDense>(h, VRG_STAGE);
-    c.inc = alloc<int64_t>(h, 32); c.dctl = alloc<int64_t>(h, 32);   // one allocation each: written from different streams
+    c.incb[0] = alloc<int64_t>(h, 32); c.incb[1] = alloc<int64_t>(h, 32); c.inc = c.inc_in = c.incb[0];
+    c.dctl = alloc<int64_t>(h, 32);   // one allocation each: written from different streams
     c.gate = alloc<int64_t>(h, 32);
     c.fexp = alloc<int64_t>(h, 8);
     c.nstat = 4096;
@@ -259,9 +262,9 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.trace_cap = 1u << 16;
     c.trace = alloc<VrgTrace>(h, c.trace_cap);
     c.world = 1; c.ver_n = 1; c.ver_me = 0;
-    if (!c.lab[0] || !c.stamp || !c.stb[0] || !c.stb[1] || !c.dn || !c.counters || !c.dn_part || !c.gate || !c.fexp || !c.dn_ring || !c.exp_ring || !c.stage_in || !c.stage_out || !c.inc || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
+    if (!c.lab[0] || !c.stamp || !c.stb[0] || !c.stb[1] || !c.dn || !c.counters || !c.dn_part || !c.gate || !c.fexp || !c.dn_ring || !c.exp_ring || !c.stage_in || !c.stage_out || !c.incb[0] || !c.incb[1] || !c.dctl || !c.clsb[0] || !c.clsb[1] ||
         !c.nchg || !c.ubits || !c.unew[0] || !c.unew[1] || !c.ulist || !c.uctl || !c.vent || !c.st_nin || !c.st_nout || !c.st_sin || !c.st_sout || !c.trace) { API(destroy)(h); return VRG_E_MEM; }
-    be_fill(be, c.inc, 0, 32 * sizeof(int64_t)); be_fill(be, c.dctl, 0, 32 * sizeof(int64_t)); be_fill(be, c.gate, 0, 32 * sizeof(int64_t));
+    be_fill(be, c.incb[0], 0, 32 * sizeof(int64_t)); be_fill(be, c.incb[1], 0, 32 * sizeof(int64_t)); be_fill(be, c.dctl, 0, 32 * sizeof(int64_t)); be_fill(be, c.gate, 0, 32 * sizeof(int64_t));
     be_fill(be, c.clsb[0], 0, PVu / 4); be_fill(be, c.clsb[1], 0, PVu / 4);
     be_fill(be, c.nchg, 0, 32 * sizeof(uint32_t));
     be_fill(be, h->lab_base[0], VB_OOB, (size_t)c.PV + 32);
@@ -316,11 +319,11 @@ int API(set_volume)(vrg_handle* h, const void* data, int dtype, const int64_t st
     // wider integers that happen to be); float64 storage otherwise (the dense pass then streams 8 B per voxel)
     if (!h->I32) { h->I32 = alloc<float>(h, h->PVu); if (!h->I32) return fail(h, VRG_E_MEM, "set_volume: intensity volume"); be_fill(h->be, h->I32, 0, h->PVu * 4); }
     int inexact = 0;
-    int rc = be_pack_volume(h->be, c, h->I32, nullptr, data, dtype, st, &inexact);
+    int rc = be_pack_volume(h->be, c, h->I32, nullptr, data, dtype, st, &inexact, &h->data_nonzero);
     if (rc) return fail(h, VRG_E_ARG, "set_volume: unsupported strides");
     if (inexact) {
         if (!h->I64) { h->I64 = alloc<double>(h, h->PVu); if (!h->I64) return fail(h, VRG_E_MEM, "set_volume: float64 intensity volume"); be_fill(h->be, h->I64, 0, h->PVu * 8); }
-        rc = be_pack_volume(h->be, c, nullptr, h->I64, data, dtype, st, &inexact);
+        rc = be_pack_volume(h->be, c, nullptr, h->I64, data, dtype, st, &inexact, &h->data_nonzero);
         if (rc) return fail(h, VRG_E_ARG, "set_volume: unsupported strides");
         c.I = nullptr; c.I64 = h->I64;
     } else { c.I = h->I32; c.I64 = nullptr; }
@@ -542,7 +545,12 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
             // put_state below clears it; a leftover gate would then wait for the NEXT sweep's request and shift which
             // launch counts which sweep (and, on Z-slabs, let ranks pack different numbers of recounts into one all-reduce).
             be_sync(be);
-            if (s.bail == VBAIL_FLIPS) h->sync_mode = true;
+            if (s.bail == VBAIL_FLIPS) {
+                // more flips than the trip's launches were sized for: up to the device-resident limit the trip is simply enqueued again
+                // with launches sized for them (the chip-wide ordering kernels); beyond it the host drives the trips
+                if (nf <= small) be_set_tuning(be, "flip_hint_min", (long long)nf);
+                else h->sync_mode = true;
+            }
             else if (s.bail == VBAIL_FUSE) h->fuse_mode = false;
             else if (s.bail == VBAIL_LOG) { rc = repl_log_full(h, s); if (rc) return rc; }
             else if (s.bail == VBAIL_MARKS) {
@@ -595,7 +603,13 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
 
 int API(get_labels)(vrg_handle* h, void* outp, int dtype, const int64_t st[3]) {
     if (!h || !outp || !st || dtype < VRG_U8 || dtype > VRG_F64) return fail(h, VRG_E_ARG, "get_labels: bad argument");
-    if (be_unpack_labels(h->be, h->c, h->c.lab[0], outp, dtype, st)) return fail(h, VRG_E_ARG, "get_labels: unsupported strides");
+    if (be_unpack_labels(h->be, h->c, h->c.lab[0], outp, dtype, st, 0)) return fail(h, VRG_E_ARG, "get_labels: unsupported strides");
+    return VRG_OK;
+}
+
+int API(get_segmented_map)(vrg_handle* h, void* outp, int dtype, const int64_t st[3]) {
+    if (!h || !outp || !st || dtype < VRG_U8 || dtype > VRG_F64) return fail(h, VRG_E_ARG, "get_segmented_map: bad argument");
+    if (be_unpack_labels(h->be, h->c, h->c.lab[0], outp, dtype, st, 1)) return fail(h, VRG_E_ARG, "get_segmented_map: unsupported strides");
     return VRG_OK;
 }
 
@@ -700,6 +714,7 @@ int API(get_stats)(vrg_handle* h, int64_t* outp, int64_t cap) {
     if (cap >= 17) { outp[15] = h->fused_trips; outp[16] = h->bails[4]; }
     if (cap >= 18) outp[17] = h->inited ? h->c.nb : 0;
     if (cap >= 19) outp[18] = be_memo_trips(h->be);
+    if (cap >= 20) outp[19] = h->data_nonzero;
     if (cap >= 14) {
         int64_t di[5] = {0, 0, 0, 0, 0};
         uint32_t uc[2] = {0, 0};

@@ -306,13 +306,15 @@ VRG_HD void vrg_item_band_fields(const VrgCtx& c, const VrgState& s, uint32_t sl
     if (s.iter < s.iterMax) vrg_decide_core(c, s, n_in, n_out, slot, fl & PF_INNER, ip, op, key, idx, lev, err);   // while iterNum <= iterMax (:58)
 }
 VRG_HD void vrg_item_band(const VrgCtx& c, const VrgState& s, uint32_t slot, const double* nz_val, const uint32_t* nz_cin,
-                          const uint32_t* nz_cout, const uint32_t* nz_cconv, const double* tab = nullptr, uint32_t tab_n = 0) {
+                          const uint32_t* nz_cout, const uint32_t* nz_cconv, const double* tab = nullptr, uint32_t tab_n = 0, int64_t sizes_in = -1, int64_t sizes_out = -1) {
     // the slot's fields in one batch (a dead slot's are read for nothing): the kernel is bound by dependent loads
     const uint8_t fl = c.p_flag[slot];
     const double ip = c.p_ip[slot], op = c.p_op[slot];
     const uint32_t lev = c.p_lev[slot], idx = c.p_idx[slot];
     const uint64_t key = c.p_key[slot];
-    const int64_t n_in = c.inc[VC_NIN], n_out = c.inc[VC_NOUT];
+    // (the region sizes: the caller's - k_band has them in registers, possibly derived from an open-ended sweep - or the ones that go with the
+    // state the kernel READS; never c.inc there: k_band files into the other buffer while it decides)
+    const int64_t n_in = sizes_in >= 0 ? sizes_in : c.inc_in[VC_NIN], n_out = sizes_in >= 0 ? sizes_out : c.inc_in[VC_NOUT];
     const double err = (double)c.p_err[slot];
     vrg_item_band_fields(c, s, slot, fl, ip, op, lev, idx, key, n_in, n_out, nz_val, nz_cin, nz_cout, nz_cconv, tab, tab_n, err);
 }
@@ -1495,8 +1497,10 @@ VRG_HD void vrg_state_store_but_live(VrgState* dst, const VrgState& w) {       /
 }
 // k_band's one filing thread.  s: the state this trip works on (closed: as found, or derived from an open-ended sweep: f, was_open).
 // The label bytes of that sweep are applied by this very kernel, so the filed state says so.
-VRG_HD void vrg_fuse_persist(const VrgCtx& c, const VrgState& s, const VrgFuseClosed& f, bool was_open) {
+// (n_in / n_out: the region sizes that go with s - as read beside the state, or derived)
+VRG_HD void vrg_fuse_persist(const VrgCtx& c, const VrgState& s, const VrgFuseClosed& f, bool was_open, int64_t n_in, int64_t n_out) {
     if (c.st == c.stg && !was_open) return;               // (in place, nothing derived: the state is where it belongs)
+    if (c.inc != c.inc_in) { c.inc[VC_NIN] = n_in; c.inc[VC_NOUT] = n_out; }     // (the sizes swap buffers with the state)
     VrgState w = s;
     w.apply_pending = 0; w.fr_n = 0;
     if (c.st == c.stg) { w.nf = 0; *c.stg = w; }         // (in place - the sequential test model: the sweep's flips are consumed, the decisions count from zero)

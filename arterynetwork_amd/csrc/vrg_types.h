@@ -118,6 +118,7 @@ struct VrgState {
     // the change log (leader / follower replication, VrgCtx::log_rec): records and sweep headers written since init - monotone
     // counters; a launch knows where its batch's buffer starts (VrgCtx::log_pos0 / log_nsw0)
     uint32_t log_pos, log_nsw;
+    int32_t wide;                      // four-launch trip: more flips than one workgroup orders in LDS - k_rank_wide / k_prepass_wide / k_fix_wide do k_order's work chip-wide
     int32_t open;                      // an OPEN-ENDED fused sweep has run on this state and nobody has closed it yet (vrg_items.h "open-ended sweeps"): the next trip's
                                        // k_band derives the closed state - every workgroup for itself - and one of its threads files it
     uint32_t log_n;                    // fused sweep in progress: records its workgroups have reserved so far (atomic count; log_pos itself moves when the sweep closes)
@@ -295,6 +296,10 @@ struct VrgCtx {
     int64_t* exp_ring;         // [2 * VRG_RING] region sizes after sweep k at k % VRG_RING: what dense pass k must reproduce
     VrgDense* stage_in;        // [VRG_STAGE] partials of the recounts not yet closed, packed for ONE all-reduce ...
     VrgDense* stage_out;       // ... and their totals
+    // (the region sizes live beside the state and swap with it: incb[j] belongs to stb[j].  `inc` = the sizes of the buffer a kernel files
+    // into / works on (stg), `inc_in` = those of the buffer it reads (st) - k_band after an open-ended sweep reads inc_in + the sweep's
+    // increments in every workgroup while ONE thread files the new sizes into inc: never into what the others still read)
+    int64_t* incb[2]; int64_t* inc_in;
     int64_t* inc;              // band side (own cache line): region sizes kept by increments as labels are applied -
                                // what the decisions and stop tests read - and the sweep number of the last apply
     int64_t* dctl;             // dense side (own cache line): dense passes closed since init

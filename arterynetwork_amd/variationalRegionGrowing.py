@@ -107,12 +107,13 @@ def variationalRegionGrowing(dataArray, valueMap, H=2.25, maxSegmentSize=5000, *
         #  band entry carries that bound, and a sign test it could turn is counted in r.ties - the warning above covers it)
         segmented = s.segmented()
         s.labels(out=valueMap)               # in place, caller's dtype
-        segmentedMap = (np.asarray(valueMap) <= 1).astype(np.int64)
+        segmentedMap = s.segmented_map(np.empty(dataArray.shape, np.int64, order='F' if (valueMap.flags.f_contiguous and not valueMap.flags.c_contiguous) else 'C'))
+        nonzero = s.stats()['data_nonzero']  # np.count_nonzero(dataArray), counted on the device when the volume went in
         if trace is not None:
             tr = s.trace()
             trace.extend({k: tr[k][i].item() for k in tr.dtype.names} for i in range(len(tr)))
     if not quiet:
         for line in _finish_messages(r.stop_reason, r.iter_num, segmented.shape[0],
-                                     int(np.count_nonzero(dataArray)), segmented):
+                                     int(nonzero), segmented):
             print(line)
     return segmented, segmentedMap, valueMap

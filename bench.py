@@ -43,6 +43,54 @@ def device_source_sha():
     return h.hexdigest()[:16]
 
 
+def side_line(shape, dev, args, configure, roofline, kind):
+    """Two more workloads measured inside the default one-GPU run, so that the driver's line carries them itself:
+    'nomask' - the headline volume WITHOUT its brain mask (nothing for the dense pass to skip: every voxel's intensity is fetched): the
+    dense kernel's bytes counted on the device, its HIP-event time, the fraction of peak;
+    'many_flip' - 128 disjoint tubes at 512x512x170 (SURVEY 8(d) config 5's "several disjoint tubes": ~13 000 flips per sweep, the regime
+    a whole-mask seeding as refine() does creates): ms per sweep, and how the trips ran (fused / four-launch / host-driven)."""
+    import torch
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session
+    if kind == 'nomask':
+        shp, kw, W, K = shape, dict(brain_mask=False), 10, 100
+    else:
+        shp, kw, W, K = (512, 512, 170), dict(tubes=128), 10, 60
+    I, vm = phantoms.bench_volume_torch(shp, dev, levels=args.levels, **kw)
+    torch.cuda.synchronize()
+    s = Session(shp, device=dev.index)
+    configure(s, args)
+    s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
+    s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
+    s.init(args.H)
+    r0 = s.run(W, 10 ** 15, None)
+    db0 = s.stats()['dense_bytes']
+    st0 = s.stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = s.run(W + K, 10 ** 15, None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = s.stats()
+    tr = s.trace()
+    kern_ms = r.sweep_kernel_ms / max(1, r.sweep_launches)
+    out = {'workload': '{}x{}x{}, {}'.format(shp[0], shp[1], shp[2], 'no brain mask' if kind == 'nomask' else '128 disjoint tubes'), 'sweeps': int(r.sweeps),
+           'valid': bool(r.sweeps == K and r0.sweeps == W), 'ms_per_step': round(dt / max(1, r.sweeps) * 1e3, 4), 'dense_ms': round(kern_ms, 4)}
+    if kind == 'nomask':
+        db = (db0 + st['dense_bytes']) / 2.0
+        rf = roofline(shp, shp[2], kern_ms, int(r.sweep_launches), None, False, db, st['dense_kernel'])
+        out.update({k: rf[k] for k in ('kernel', 'achieved', 'peak', 'unit', 'frac', 'kernel_ms_avg', 'launches', 'bytes_per_launch', 'bytes_counted_on_device')})
+        out['value'] = round(shp[0] * shp[1] * shp[2] * r.sweeps / dt / 1e6, 1)
+    else:
+        out.update({'flips_per_sweep_mean': round(float(tr['nflip'][W + 1:].mean()), 1), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
+                    'host_driven_trips': st['host_driven_trips'] - st0['host_driven_trips'], 'fused_trips': st['fused_trips'] - st0['fused_trips'],
+                    'value': round(shp[0] * shp[1] * shp[2] * r.sweeps / dt / 1e6, 1), 'unit': 'Mvoxel-iter/s'})
+    s.close()
+    del I, vm
+    torch.cuda.empty_cache()
+    return out
+
+
 def load_traffic(shape, n_gpus, storage16, planes=None, design_bytes=None):
     """HBM bytes per dense launch from the committed rocprofv3 PMC passes (profiles/traffic.json) - only when an entry was
     measured on these very kernel sources (src_sha) and workload (shape, ranks, storage, slab planes - and, `design_bytes`
@@ -306,6 +354,7 @@ def main():
     ap.add_argument('--integer-values', action='store_true', help='the same volume with integer intensities 0..levels (as a scanner delivers them) and H / levels^2: the same run, '
                     'with the level of a voxel looked up directly instead of searched for')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-side-lines', action='store_true', help='skip the two extra workloads of the default line (roofline_nomask, many_flip)')
     ap.add_argument('--variant', type=int, default=0)
     ap.add_argument('--sweep-blocks', type=int, default=0)
     ap.add_argument('--prio-mode', type=int, default=-1)
@@ -451,6 +500,14 @@ def main():
     s.init(args.H)
     out['config']['reinit_seconds'] = round(time.perf_counter() - t0, 4)
     s.close()
+    if out['roofline'].get('traffic') is not None:
+        out['roofline']['traffic_source'] = 'profiles/traffic.json@{} (rocprofv3 PMC passes of these kernel sources, FETCH_SIZE x 2 + WRITE_SIZE; not measured by this run)'.format(device_source_sha())
+    if not args.no_side_lines and args.shape == '880x880x640' and not (args.storage16 or args.no_brain_mask or args.tubes > 1):
+        del I, vm
+        torch.cuda.empty_cache()
+        out['roofline_nomask'] = side_line(shape, dev, args, configure, roofline, 'nomask')
+        out['many_flip'] = side_line(shape, dev, args, configure, roofline, 'many_flip')
+        I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels, brain_mask=not args.no_brain_mask, integer_values=args.integer_values)   # (the cpu_baseline's volume)
     if not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(I, vm, args.H, lev_note)
     print(json.dumps(out), flush=True)

@@ -139,7 +139,9 @@ int vrg_run(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxSe
 
 /* valueMap on return (:33-36), written with the reference's label values 0..4. */
 int vrg_get_labels(vrg_handle* h, void* out, int dtype, const int64_t strides_xyz[3]);
-/* segmentedMap (:31-32) is labels <= 1; `segmented` (:29-30) in the reference's list order. */
+/* segmentedMap (:31-32): 1 where the label is 0 or 1, else 0, written like vrg_get_labels writes (any dtype, host or device memory);
+ * `segmented` (:29-30) in the reference's list order. */
+int vrg_get_segmented_map(vrg_handle* h, void* out, int dtype, const int64_t strides_xyz[3]);
 int vrg_get_segmented(vrg_handle* h, int64_t* coords_xyz, int64_t cap, int64_t* n);
 /* innerBnd (which = 0) / outerBnd (1) in list order with innerProb / outerProb at those voxels. */
 int vrg_get_band(vrg_handle* h, int which, int64_t* coords_xyz, double* inner_prob, double* outer_prob,
@@ -157,7 +159,8 @@ int vrg_get_levels(vrg_handle* h, double* values, int32_t* hist_in, int32_t* his
  * that hold an included voxel; every line of the slab with option skip_excluded = 0) - the roofline's numerator.
  * With cap >= 14 also how the dense pass is launched: out[9] = 1 for non-temporal loads, out[10] = intensity storage
  * (0 fp32, 1 u16 level index, 2 float64, 3 u16 level index with the value table of the dense pass held as doubles: up to 4096 levels), out[11] = workgroups, out[12] = skip_excluded, out[13] = units on its list.  With cap >= 15 also out[14] = 1 when the
- * pass is the two-trips-deep kernel k_recount_pipe (option dense_pipe; fp32 storage with skip_excluded), 0 for k_recount_bits. */
+ * pass is the two-trips-deep kernel k_recount_pipe (option dense_pipe; fp32 storage with skip_excluded), 0 for k_recount_bits.
+ * With cap >= 20 also out[19] = the number of non-zero values of dataArray (np.count_nonzero, the reference's closing message :95), counted when the volume was set. */
 int vrg_get_stats(vrg_handle* h, int64_t* out, int64_t cap);
 
 /* Diagnostic builds only (compiled with -DVRG_STAMPS, tools/chain_stamps.py): 64 in-kernel time stamps (100-MHz ticks) of

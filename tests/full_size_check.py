@@ -75,15 +75,16 @@ def run_and_check(shape, I, vm, dev, sweeps, storage16):
     return lab, seg, tr, bands
 
 
-def oracle_full_size(dev, sweeps=100):
+def oracle_full_size(dev, sweeps=100, shape=(880, 880, 640), storage16=False, seed=3, tag='ORACLE3'):
     import time
     import parity
     from oracle import vrg_oracle as O
-    shape = (880, 880, 640)
-    I, vm = phantoms.bench_volume_torch(shape, dev)
+    I, vm = phantoms.bench_volume_torch(shape, dev, seed=seed)
     torch.cuda.synchronize()
     s = Session(shape)
     s.set_option('batch', 32)
+    if storage16:
+        s.set_option('storage16', 1)
     s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
     s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
     s.init(2.25)
@@ -114,8 +115,8 @@ def oracle_full_size(dev, sweeps=100):
         assert np.array_equal(tr[f], otr[f]), f
     np.testing.assert_allclose(tr['sum_in'], otr['sum_in'], rtol=1e-9, atol=1e-6)
     np.testing.assert_allclose(tr['sum_out'], otr['sum_out'], rtol=1e-9, atol=1e-6)
-    print('ORACLE3 OK: 880x880x640 x %d sweeps identical to the oracle (nseg %d -> %d, band %d); oracle init %.0f s, sweeps %.0f s'
-          % (sweeps, tr['nseg'][0], tr['nseg'][-1], tr['ni'][-1] + tr['no'][-1], t1 - t0, t2 - t1))
+    print('%s OK: %s%s x %d sweeps identical to the oracle (nseg %d -> %d, band %d); oracle init %.0f s, sweeps %.0f s'
+          % (tag, 'x'.join(map(str, shape)), ' (16-bit storage)' if storage16 else '', sweeps, tr['nseg'][0], tr['nseg'][-1], tr['ni'][-1] + tr['no'][-1], t1 - t0, t2 - t1))
     s.close(); o.close()
 
 
@@ -301,8 +302,13 @@ def main():
         slabs_one_gpu(int(a[0]), tuple(int(v) for v in a[1].split('x')), int(a[2]))
         return
     dev = torch.device('cuda', 0)
-    if '--oracle3' in sys.argv:
-        oracle_full_size(dev)
+    if '--oracle3' in sys.argv:                            # [sweeps]: BASELINE configs[2] states 500
+        a = sys.argv[sys.argv.index('--oracle3') + 1:]
+        oracle_full_size(dev, int(a[0]) if a and a[0].isdigit() else 100)
+        return
+    if '--config5-oracle' in sys.argv:                     # configs[4]'s family at a size the oracle runs: a 1024x1024x128 volume, 16-bit storage
+        a = sys.argv[sys.argv.index('--config5-oracle') + 1:]
+        oracle_full_size(dev, int(a[0]) if a and a[0].isdigit() else 100, shape=(1024, 1024, 128), storage16=True, seed=5, tag='CONFIG5-ORACLE')
         return
     if '--config5' in sys.argv:
         shape = (1024, 1024, 1024)

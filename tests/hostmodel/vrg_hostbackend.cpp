@@ -70,15 +70,18 @@ template <class F> void for_real_voxels(const VrgCtx& c, F f) {
 }
 }  // namespace
 
-int be_pack_volume(VrgBackend*, const VrgCtx& c, float* dst, double* dst64, const void* src, int dtype, const int64_t st[3], int* inexact) {
+int be_pack_volume(VrgBackend*, const VrgCtx& c, float* dst, double* dst64, const void* src, int dtype, const int64_t st[3], int* inexact, long long* nonzero) {
     *inexact = 0;
+    long long nz = 0;
     for_real_voxels(c, [&](uint32_t idx, int x, int y, int z) {
         double v = load_as_double(src, dtype, x * st[0] + y * st[1] + z * st[2]);
+        nz += v != 0.0;
         if (dst64) { dst64[idx] = v; return; }
         float f = (float)v;
         if ((double)f != v) *inexact = 1;
         dst[idx] = f;
     });
+    if (nonzero) *nonzero = nz;
     return 0;
 }
 int be_pack_labels(VrgBackend*, const VrgCtx& c, uint8_t* dst, const void* src, int dtype, const int64_t st[3], int* bad) {
@@ -90,9 +93,10 @@ int be_pack_labels(VrgBackend*, const VrgCtx& c, uint8_t* dst, const void* src, 
     });
     return 0;
 }
-int be_unpack_labels(VrgBackend*, const VrgCtx& c, const uint8_t* lab, void* dst, int dtype, const int64_t st[3]) {
+int be_unpack_labels(VrgBackend*, const VrgCtx& c, const uint8_t* lab, void* dst, int dtype, const int64_t st[3], int what) {
     for_real_voxels(c, [&](uint32_t idx, int x, int y, int z) {
-        store_int(dst, dtype, x * st[0] + y * st[1] + z * st[2], vrg_dec(lab[idx]));
+        const int v = vrg_dec(lab[idx]);
+        store_int(dst, dtype, x * st[0] + y * st[1] + z * st[2], what ? (v <= 1 ? 1 : 0) : v);
     });
     return 0;
 }
@@ -324,7 +328,7 @@ void be_sweep_once(VrgBackend* b, VrgCtx& c0, int flags, VrgEvents*, be_reduce_f
         }
         VrgFuseClosed f;
         vrg_fuse_close_core(c0, derived, c0.inc[VC_NIN], c0.inc[VC_NOUT], q, false, f);
-        vrg_fuse_persist(c0, derived, f, true);
+        vrg_fuse_persist(c0, derived, f, true, f.n_in, f.n_out);
     }
     if (derived.apply_pending) {                       // (k_band: what the fused sweep before this trip left to do)
         const int k = derived.iter;

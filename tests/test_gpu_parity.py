@@ -570,6 +570,32 @@ def test_layouts_dtypes_and_stop_order(lib):
     s.close()
 
 
+def test_reference_dtypes_host_arrays_cross_chunks():
+    """The reference's own calling convention - int64 valueMap, float64 dataArray, C order (:44-46, :288) - on a volume large enough
+    for the host-side narrowing / widening to work in several chunks (40 M voxels > 32 M per chunk): same labels, `segmented`,
+    segmentedMap (int64, built on the device) as the uint8 / fp32 Fortran-order call; valueMap is updated in place."""
+    from arterynetwork_amd import variationalRegionGrowing, phantoms
+    shape = (352, 352, 320)
+    data, vmap = phantoms.bench_volume(shape, seed=2)
+    a_d, a_v = np.asfortranarray(data), np.asfortranarray(vmap.astype(np.uint8))
+    b_d, b_v = np.ascontiguousarray(data, dtype=np.float64), np.ascontiguousarray(vmap, dtype=np.int64)
+    sa, ma, va = variationalRegionGrowing(a_d, a_v, iterMax=20, maxSegmentSize=10 ** 12, maxTime=None, quiet=True)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        sb, mb, vb = variationalRegionGrowing(b_d, b_v, iterMax=20, maxSegmentSize=10 ** 12, maxTime=None)
+    assert vb is b_v and vb.dtype == np.int64 and mb.dtype == np.int64 and ma.dtype == np.int64
+    assert np.array_equal(sa, sb) and np.array_equal(va, vb) and np.array_equal(ma, mb)
+    assert np.array_equal(mb, (vb <= 1).astype(np.int64)) and int(mb.sum()) == len(sb)
+    assert 'Total segmented voxels: {}/{}'.format(len(sb), int(np.count_nonzero(b_d))) in buf.getvalue()
+    # a float64 volume that fp32 cannot hold goes through as float64 (the narrowing notices and hands the raw array over)
+    c_d = b_d[:96, :96, :64].copy() + 1e-9
+    c_v = b_v[:96, :96, :64].copy(); c_v[c_v <= 1] = 0; c_v[(c_v != 0) & (c_v != 4)] = 3
+    if (c_v == 0).any():
+        s1 = variationalRegionGrowing(c_d, c_v.copy(), iterMax=5, maxSegmentSize=10 ** 12, maxTime=None, quiet=True)[0]
+        s2 = variationalRegionGrowing(np.asfortranarray(c_d), np.asfortranarray(c_v), iterMax=5, maxSegmentSize=10 ** 12, maxTime=None, quiet=True)[0]
+        assert np.array_equal(s1, s2)
+
+
 def test_16bit_storage_identical(lib, golden_loader):
     """storage16: the dense pass streams 2 B level indices (values from an LDS table) - same results and sums."""
     from arterynetwork_amd import phantoms
@@ -850,6 +876,20 @@ def test_config3_full_size_vs_oracle():
         pytest.skip('needs 64 GB of host memory')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'full_size_check.py'), '--oracle3'], capture_output=True, text=True)
     assert out.returncode == 0 and 'ORACLE3 OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_config5_family_vs_oracle():
+    """BASELINE configs[4]'s family against the ORACLE at a size it runs: a 1024x1024x128 volume (seed 5, as the 1024^3 test), 16-bit
+    intensity storage, 60 sweeps - labels of all 134 217 728 voxels, both band list orders and densities, `segmented` order, trace.
+    (The 1024^3 volume itself is compared with the fp32-storage run of the same library: test_config5_size_storage16.)"""
+    import subprocess, sys, os
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    if bench.host_memory_available_gb() < 24:
+        pytest.skip('needs 24 GB of host memory')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'full_size_check.py'), '--config5-oracle', '60'], capture_output=True, text=True)
+    assert out.returncode == 0 and 'CONFIG5-ORACLE OK' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_drop_in_messages_and_trace(golden_loader, capsys):

@@ -13,10 +13,11 @@ lo, hi = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (1, 13)
 I, vm, H, variant, dmode = random_case(sd, lo, hi)
 if max(I.shape) > 16: dmode = 1
 print('seed', sd, 'shape', I.shape, 'variant', variant, 'levels', len(np.unique(I)), 'dmode', dmode, flush=True)
+extra = {k: int(v) for k, v in (kv.split('=') for kv in os.environ.get('VRG_REPEAT_OPTS', '').split(',') if kv)}      # e.g. VRG_REPEAT_OPTS=open_sweeps=0
 fails = 0
 for r in range(reps):
     try:
-        res, k = parity.run_batched(lib, I, vm, H, None, 40, density_mode=dmode, options={'sweep_variant': variant, 'batch': batch, 'small_flips': small})
+        res, k = parity.run_batched(lib, I, vm, H, None, 40, density_mode=dmode, options=dict({'sweep_variant': variant, 'batch': batch, 'small_flips': small}, **extra))
         if r == 0: print('sweeps', k, 'res', None if res is None else res.stop_reason)
     except AssertionError as e:
         fails += 1
