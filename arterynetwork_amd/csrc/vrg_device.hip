@@ -869,7 +869,7 @@ __global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
             vrg_ranks_take(FO, n0, r0, qr);
             while (cand) { vrg_rank_batch(c, cand, (uint32_t)m, n0, r0); vrg_ranks_take(FO, n0, r0, qr); }     // (more than four listed neighbours: rare)
             const uint8_t nw = vrg_sweep_cases(c, (uint32_t)m, mb, pre, nb, qr, ring2, lev_here, ev);   // (L / P bits date from k_order: mb is current)
-            if (q < c.mcap) { c.mk_idx[q] = (uint32_t)m; c.mk_new[q] = nw; c.mk_old[q] = mb; } else c.stg->error = 4;
+            if (q < c.mcap) { c.mk_idx[q] = (uint32_t)m; c.mk_new[q] = nw; c.mk_old[q] = mb; } else vrg_store_i32(&c.stg->error, 4);
             // its event takes a number inside the workgroup ...
             if (ev.kind == VE_NEW) rn = atomicAdd(&s_n[0], 1u);
             if (ev.kind == VE_DIE) rd = atomicAdd(&s_n[1], 1u);
@@ -1047,7 +1047,7 @@ constexpr uint32_t FUSE_MEMO_NNZ = 1024;  // touched levels k_memo keeps in LDS;
 // open_end: the sweep stops at its commit - no ticket, no closing workgroup; the next trip's k_band derives the closed state (vrg_items.h
 // "open-ended sweeps"; small level tables only)
 template <bool BIGL>
-__global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_follows, int open_end) {
+__global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_follows, int open_end, int zero_par) {
     VRG_CHAOS_POINT(5);
     __shared__ VrgFuseLdsT<BIGL ? 1 : VRG_FUSE_LEVELS> sh;
     __shared__ uint32_t s_keys[BIGL ? VRG_FUSE_KEYS : 1];
@@ -1062,9 +1062,14 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     const VrgState s0 = *cg.st;
     const int64_t nin0 = cg.inc[VC_NIN];
     vrg_fuse_init(sh, t);
-    if (s0.done || s0.bail) return;
     const int lp = (s0.iter + 1) & 1;                      // this sweep's set of per-level counters; the other set - the sweep before's - goes back to zero
-    if constexpr (!BIGL) vrg_fuse_zero_other_levels(cg, lp, r, gridDim.x, t, T);
+    // (BEFORE anything can make this workgroup leave, and by the HOST's count of the sweeps (zero_par = the set the sweep before this trip
+    // filled), not by the state this workgroup has loaded: a workgroup that starts late may find the stop or hand-back flag another one has
+    // just raised - or, without a flip of its own, the state the closing workgroup has already written: sweep number advanced - and its
+    // stretch of the counters still has to be zeroed, or the next sweep would add to stale counts.  Found by the interleaving campaign,
+    // 2 cases in 2200.  After a stop or a hand-back the host's count runs ahead: both sets are empty then, zeroing either is harmless.)
+    if constexpr (!BIGL) vrg_fuse_zero_other_levels(cg, zero_par ^ 1, r, gridDim.x, t, T);
+    if (s0.done || s0.bail) return;
     if (st0) vrg_fuse_prepare_other(cg, s0);               // (the next trip's k_band counts its flips and ties into the other state buffer)
     const int32_t gate = vrg_fuse_gate(cg, s0, nin0, vrg_fuse_limit(cg));      // stop tests (:91-104) / can the sweep run fused: the same answer everywhere
     if (gate) {
@@ -1129,7 +1134,7 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     __syncthreads();
     if (st0) VRG_STAMP(cg, 21);
     if (open_end) {                                        // nobody closes: the state keeps what the workgroups have added up, marked open
-        if (st0) { cg.stg->open = 1; VRG_STAMP(cg, 28); VRG_STAMP(cg, 29); }
+        if (st0) { vrg_store_i32(&cg.stg->open, 1); VRG_STAMP(cg, 28); VRG_STAMP(cg, 29); }     // (written through: the line takes the other workgroups' atomics)
         return;
     }
     if (t == 0) {
@@ -2651,8 +2656,8 @@ void be_sweep_once(VrgBackend* b, VrgCtx& c, int flags, VrgEvents* ev, be_reduce
         // open-ended: no closing workgroup - the next trip's k_band derives the closed state.  Not the last trip of a batch (the host reads
         // closed states only), not in front of the memo kernel, small level tables only.
         const bool open = b->open_sweeps && !last && !memo && c.L <= OPEN_LEVELS && c.ktab;
-        if (c.L > (uint32_t)VRG_FUSE_LEVELS) hipExtLaunchKernelGGL(k_sweep<true>, dim3(VRG_FUSE_MAX_BIG), dim3(VRG_FUSE_THREADS), 0, b->sa, nullptr, memo ? nullptr : e_c1, 0, c, 0, 0);
-        else hipExtLaunchKernelGGL(k_sweep<false>, dim3(VRG_FUSE_MAX), dim3(VRG_FUSE_THREADS), 0, b->sa, nullptr, memo ? nullptr : e_c1, 0, c, memo ? 1 : 0, open ? 1 : 0);
+        if (c.L > (uint32_t)VRG_FUSE_LEVELS) hipExtLaunchKernelGGL(k_sweep<true>, dim3(VRG_FUSE_MAX_BIG), dim3(VRG_FUSE_THREADS), 0, b->sa, nullptr, memo ? nullptr : e_c1, 0, c, 0, 0, sweep_par ^ 1);
+        else hipExtLaunchKernelGGL(k_sweep<false>, dim3(VRG_FUSE_MAX), dim3(VRG_FUSE_THREADS), 0, b->sa, nullptr, memo ? nullptr : e_c1, 0, c, memo ? 1 : 0, open ? 1 : 0, sweep_par ^ 1);
         if (memo) hipExtLaunchKernelGGL(k_memo, dim3(MEMO_BLOCKS), dim3(TPB), 0, b->sa, nullptr, e_c1, 0, c);
         b->fused_prev = true; b->fused_memo = memo; b->prev_open = open; b->open_par = sweep_par;
         return;

@@ -281,7 +281,7 @@ VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, int64_t n_in, in
     if (inner == ge) return;                              // :87 xor(segmentedMap, inner >= outer)
     uint32_t q = vrg_atomic_add(&c.stg->nf, 1u);
     if (s.time_up || n_in >= s.maxSegmentSize) return;    // :97 / :101 fire before update(): count only
-    if (q >= c.fcap) { c.stg->error = 2; return; }
+    if (q >= c.fcap) { vrg_store_i32(&c.stg->error, 2); return; }
     c.flist[q] = slot; c.f_key[q] = vrg_flip_key(inner, key); c.fr_idx[q] = idx; c.fr_lev[q] = lev;
 }
 // one pool slot whose fields the caller has fetched; nz_* = this trip's view of the touched-level list (LDS copy on the
@@ -504,7 +504,7 @@ VRG_HD void vrg_item_scatter_marks(const VrgCtx& c, uint32_t r, uint32_t p) {
     if (!vrg_mark_wanted(p, vrg_load_coherent(c.lab[0] + m))) return;
     if (vrg_mark_set(c, m)) {
         uint32_t q = vrg_atomic_add(&c.stg->nmk, 1u);
-        if (q < c.mcap) c.mk_idx[q] = (uint32_t)m; else c.stg->error = 4;
+        if (q < c.mcap) c.mk_idx[q] = (uint32_t)m; else vrg_store_i32(&c.stg->error, 4);
     }
 }
 
@@ -516,7 +516,7 @@ VRG_HD void vrg_note_level(const VrgCtx& c, uint32_t* cnt, uint32_t lev) {
     if (vrg_atomic_or(&c.ltouch[lev], 1u) == 0u) {
         // (the entry is written THROUGH: in a fused sweep the workgroup that closes the sweep - another CU, another XCD - reads it)
         uint32_t q = vrg_atomic_add(c.lvl_scan == 2 ? &c.stg->nnz_new : &c.stg->nnz, 1u);
-        if (q < c.zcap) vrg_store_u64(&c.nz_key[q], (uint64_t)lev); else c.stg->error = 8;
+        if (q < c.zcap) vrg_store_u64(&c.nz_key[q], (uint64_t)lev); else vrg_store_i32(&c.stg->error, 8);
     }
 }
 // What the relabel of one voxel means for the band pool: at most one event per voxel.  The stencil only DESCRIBES it;
@@ -543,7 +543,7 @@ VRG_HD void vrg_ev_write(const VrgCtx& c, uint32_t idx, const VrgEvent& e, uint3
     uint32_t slot = e.slot;
     if (e.kind == VE_NEW) {                               // a voxel enters the band (newInnerBndList / newOuterBndList, :196, :213)
         slot = q < s.nfree ? c.freel[s.nfree - 1u - q] : s.np + (q - s.nfree);
-        if (slot >= c.bcap) { c.stg->error = 1; return; }
+        if (slot >= c.bcap) { vrg_store_i32(&c.stg->error, 1); return; }
         c.p_idx[slot] = idx; c.p_lev[slot] = e.lev; c.p_ip[slot] = 0; c.p_op[slot] = 0; c.p_err[slot] = 0; c.p_key[slot] = e.key;
         c.p_flag[slot] = (uint8_t)(PF_ALIVE | PF_PEND | (e.to_inner ? PF_INNER : 0));
         c.vent[idx] = slot;
@@ -1489,10 +1489,9 @@ VRG_HD void vrg_fuse_close(const VrgCtx& c, VrgState s, int64_t n_in, int64_t n_
 //    by the k_sweep after it, which fills the other one (vrg_fuse_zero_other_levels).
 // The host only ever meets closed states: the last trip of every batch closes its sweep in the old way (and so does a trip that is
 // followed by the memo kernel, or one on a level table too large for a workgroup's LDS list).
-VRG_HD void vrg_state_store_but_live(VrgState* dst, const VrgState& w) {       // all words but nf, ties, near_ties, error
+VRG_HD void vrg_state_store_but_live(VrgState* dst, const VrgState& w) {       // all words but the live line (nf, ties, near_ties, error: vrg_types.h)
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&w); uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-    constexpr unsigned o_nf = offsetof(VrgState, nf) / 4, o_t = offsetof(VrgState, ties) / 4, o_n = offsetof(VrgState, near_ties) / 4, o_e = offsetof(VrgState, error) / 4;
-    for (unsigned i = 0; i < sizeof(VrgState) / 4; i++) if (i != o_nf && i != o_t && i != o_n && i != o_e) d[i] = src[i];
+    for (unsigned i = 0; i < offsetof(VrgState, nf) / 4; i++) d[i] = src[i];
     if (w.error) vrg_store_i32(&dst->error, w.error);
 }
 // k_band's one filing thread.  s: the state this trip works on (closed: as found, or derived from an open-ended sweep: f, was_open).

@@ -17,6 +17,7 @@
 // the order in which flips are applied - is carried by a 64-bit key per slot (vrg_items.h, "list order"), so the
 // lists are never rebuilt: per sweep only the few flips are sorted by key.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include "../../include/vrg.h"
 
@@ -83,14 +84,12 @@ struct VrgState {
     int32_t iter;        // incremental sweeps applied so far (= reference iterNum - 1)
     int32_t done;        // stop reason, 0 while running
     int32_t iterMax;
-    int32_t error;       // capacity overflow etc.
     int32_t time_up;     // host: wall-clock cap reached (:97) - the next trip only decides and stops
     int32_t bail;        // VBAIL_*: the trip has to be redone by the host-driven path / with larger arrays
     int64_t maxSegmentSize;
     uint32_t ni, no;     // lengths of innerBndList / outerBndList
     uint32_t np;         // pool slots in use (high-water mark; dead slots below it sit on the free list)
     uint32_t nfree;      // free list length
-    uint32_t nf;         // listed flips of the sweep being processed (atomic count)
     uint32_t last_nf;    // ... of the sweep applied last
     uint32_t npend;      // flip-ins waiting in the skip-rule fix-point
     uint32_t nfresh;     // slots that (re-)entered the band this sweep: exact densities due
@@ -105,7 +104,6 @@ struct VrgState {
                          // entries: the next k_band does it on its way through the pool
     int32_t use_tab;     // ... from the per-level memo tabC instead of entry by entry
     int32_t tab_ok;      // decided when update() opens: fewer intensity levels than band entries, a memo pays
-    uint32_t ties, near_ties;          // tie / near-tie sign tests since init (atomic counts; see VRG_TIE_REL)
     uint32_t ties_filed, near_filed;   // ... as of the last trace record
     // the fused sweep defers what nothing on the band side waits for to the NEXT trip's k_band (which reads no labels):
     int32_t apply_pending;             // the label bytes of sweep `iter` are still to be written (+ class bits, the request for its dense pass)
@@ -122,7 +120,16 @@ struct VrgState {
     int32_t open;                      // an OPEN-ENDED fused sweep has run on this state and nobody has closed it yet (vrg_items.h "open-ended sweeps"): the next trip's
                                        // k_band derives the closed state - every workgroup for itself - and one of its threads files it
     uint32_t log_n;                    // fused sweep in progress: records its workgroups have reserved so far (atomic count; log_pos itself moves when the sweep closes)
+    // ---- the LIVE words, in a cache line of their own.  k_band's decisions bump them with device-scope atomics while ONE thread of the same
+    // kernel files the rest of the state with plain stores (open-ended sweeps): a line that takes both is written back whole by the storing
+    // CU's L2 and the atomics' results are lost - seen as lost flips under the interleaving campaign.  So: no line of the state ever takes
+    // plain stores and atomics of different workgroups in one kernel; these four never share a line with anything that is filed.
+    alignas(128) uint32_t nf;          // listed flips of the sweep being processed (atomic count)
+    uint32_t ties, near_ties;          // tie / near-tie sign tests since init (atomic counts; see VRG_TIE_REL)
+    int32_t error;                     // capacity overflow etc. (written through)
+    uint32_t live_pad[28];
 };
+static_assert(sizeof(VrgState) % 128 == 0 && offsetof(VrgState, nf) % 128 == 0, "the live words have a cache line of their own");
 
 // ---- the change log: what a sweep did to the label volume, for the ranks that do not run the band chain themselves ------------------
 // One record per place of the sweep's marked list (a fused sweep: 125 places per flip, most of them VRG_NONE), written where the

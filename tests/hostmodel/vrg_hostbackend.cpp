@@ -25,7 +25,7 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "verify_every") == 0 && v >= 0) b->verify_every = (int)v;
     if (std::strcmp(name, "open_sweeps") == 0) b->open_sweeps = v != 0;
 }
-void* be_alloc(VrgBackend*, size_t bytes) { return std::malloc(bytes); }
+void* be_alloc(VrgBackend*, size_t bytes) { return std::aligned_alloc(256, (bytes + 255) / 256 * 256); }     // (VrgState: a cache line of its own for the live words)
 void be_free(VrgBackend*, void* p) { std::free(p); }
 void be_fill(VrgBackend*, void* p, int byte, size_t bytes) { std::memset(p, byte, bytes); }
 void be_upload(VrgBackend*, void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
