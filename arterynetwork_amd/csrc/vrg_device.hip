@@ -53,7 +53,8 @@ struct VrgBackend {
     hipEvent_t mark[4] = {nullptr, nullptr, nullptr, nullptr};   // a follower's staging buffers: the kernels that read buffer j have been enqueued up to here (per stream)
     int sweep_blocks = 0;                // 0 = auto (dense_blocks)
     int prio_mode = 2;                   // the dense stream gets the higher priority (measured: -1..2 % step time)
-    uint32_t small_flips = 65536;        // flips per sweep the device-resident four-launch chain takes on (<= NF_WIDE; above NF_SMALL its ordering step runs chip-wide)
+    uint32_t small_flips = 4096;         // flips per sweep the device-resident four-launch chain takes on (option "small_flips", up to NF_WIDE = 65 536: measured, the host-driven
+                                         // trips are faster above a few thousand flips - both are bound by atomics on the same few words)
     ncclComm_t comm = nullptr;           // per-sweep all-reduce of the slab statistics (multi-GPU)
     char err[256] = "";                  // first HIP / RCCL failure; the engine turns it into VRG_E_INTERNAL
     std::vector<EvPair> ev_pool;
@@ -97,7 +98,8 @@ constexpr int SWEEP_BLOCKS = 256;   // 1 workgroup (4 waves) per CU, each wave w
                                     // flight: measured best for the HBM-bound recount while stream B's band kernels run beside
                                     // it (880x880x640: 256 -> 0.38 ms, 192/384 -> 0.42-0.43, 320 -> 0.49, 512 -> 0.40, 1024 -> 0.44)
 constexpr uint32_t NF_SMALL = 4096; // flips one workgroup sorts in LDS
-constexpr uint32_t NF_WIDE = 65536; // flips the device-resident chain takes: above NF_SMALL they are ranked chip-wide (k_rank_wide); more: host-driven trips
+constexpr uint32_t NF_WIDE = 65536; // flips the device-resident chain can take (option small_flips); more: host-driven trips
+constexpr uint32_t NF_ORDER = 512;  // ... above this many the ordering step runs chip-wide (k_rank_wide, k_prepass_wide, k_fix_wide) instead of in k_order's one workgroup (86 us at 1600 flips)
 constexpr uint32_t NZ_LDS = 1024;   // touched levels k_band keeps in LDS
 constexpr int KS_THREADS = 1024;    // k_fix (host-driven trips): one big workgroup
 constexpr int KC_THREADS = 256;     // k_close: one wave per SIMD, so that its workgroups fit on a CU beside the three recount waves
@@ -655,7 +657,7 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
     if (t < s0.nnz) { const uint32_t l = (uint32_t)zk0; c.dIn[l] = 0; c.dOut[l] = 0; c.dConv[l] = 0; c.ltouch[l] = 0; }   // level counters of the sweep before
     for (uint32_t j = t + T; j < s0.nnz; j += T) vrg_item_level_clear(c, j);
     // more flips than this workgroup orders in LDS: the chip-wide kernels behind it do the ordering (they are no-ops otherwise)
-    if (nf > NF_SMALL) { if (t == 0) { vrg_open_update(c); c.stg->wide = 1; } return; }
+    if (nf > NF_ORDER) { if (t == 0) { vrg_open_update(c); c.stg->wide = 1; } return; }
     if (t == 0) c.stg->wide = 0;
     // the flips' records as k_band appended them; sorted by key, the payload being the record's number
     if (t < nf) { s_key[t] = k0; s_slot[t] = t; }
@@ -2573,8 +2575,8 @@ static void small_update(VrgBackend* b, const VrgCtx& c0, bool dense, hipEvent_t
     // (sized by the flips of the last sweep the engine saw: a sweep of thousands of flips gets a workgroup per flip, not a queue of them;
     // a sweep with more flips than its launches can order is handed back - VBAIL_FLIPS - and enqueued again with launches that can)
     const uint32_t fh = std::max<uint32_t>(b->flip_hint, 1u);
-    const bool wide = 2 * (uint64_t)fh > NF_SMALL;
-    k_order<<<1, KO_THREADS, 0, b->sa>>>(c, wide ? b->small_flips : std::min<uint32_t>(b->small_flips, NF_SMALL));
+    const bool wide = 2 * (uint64_t)fh > NF_ORDER;
+    k_order<<<1, KO_THREADS, 0, b->sa>>>(c, wide ? b->small_flips : std::min<uint32_t>(b->small_flips, NF_ORDER));
     if (wide) {                  // its ordering step chip-wide (no-ops when k_order did the ordering itself)
         k_rank_wide<<<std::min<uint32_t>(1024u, (2 * fh + KR_THREADS - 1) / KR_THREADS), KR_THREADS, 0, b->sa>>>(c);
         k_prepass_wide<<<std::min<uint32_t>(1024u, (2 * fh + TPB - 1) / TPB), TPB, 0, b->sa>>>(c);

@@ -91,8 +91,10 @@ const char* vrg_last_error(const vrg_handle* h);
  *   "chain_events"   any time; n > 0: time the band chain (k_band's start to k_close's end, band stream) of every n-th
  *                    trip of a batch with HIP events (vrg_result.chain_kernel_ms / chain_launches)
  *   "batch"          any time; sweeps enqueued between host checks of the stop flag (default 8)
- *   "small_flips"    any time; flips per sweep up to which update() runs as ONE workgroup's kernel (default and
- *                    maximum 4096); sweeps with more are driven from the host with device-wide kernels
+ *   "small_flips"    any time; flips per sweep up to which update() stays on the device as the four-launch chain, without
+ *                    a host synchronisation (default 4096, maximum 65536; above 512 flips its ordering step runs chip-wide);
+ *                    sweeps with more are driven from the host with device-wide kernels and rocPRIM sorts - measured, the
+ *                    faster of the two above a few thousand flips
  *   "serial_streams" any time; the host orders the band and dense streams (a synchronisation per sweep) instead of the
  *                    kernels waiting for each other on the device - for tools that run one kernel at a time
  *                    (rocprofv3 --pmc), under which a device-side wait could never end

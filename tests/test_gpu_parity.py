@@ -774,6 +774,41 @@ def test_host_driven_and_one_workgroup_sweeps_identical(lib, golden_loader):
         s.close()
 
 
+def test_many_flip_sweeps_vs_oracle(lib):
+    """Several disjoint tubes growing at once (SURVEY.md 8(d), config 5's shape): 1 600 flips per sweep (16 tubes) and 4 800
+    (48 tubes).  The four-launch chain orders more than 512 flips chip-wide (k_rank_wide / k_prepass_wide / k_fix_wide) - by
+    default up to 4 096 flips, with "small_flips" 65 536 all of them; above the limit the trips are host-driven (rocPRIM sorts).
+    Every variant must reproduce the oracle's labels, band lists (order included) and trace, twelve sweeps in one call."""
+    import torch
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session
+    from oracle import vrg_oracle as O
+    for shape, tubes, fmin in (((160, 160, 64), 16, 1500), ((256, 192, 96), 48, 4097)):
+        I, vm = phantoms.bench_volume_torch(shape, torch.device('cpu'), tubes=tubes)
+        d = np.asfortranarray(I.numpy().astype(np.float64)); v = np.asfortranarray(vm.numpy())
+        o = O.Oracle(d, v, 2.25, 1); o.init()
+        k = 0
+        while o.step(12, 10 ** 9, -1.0) == 0:
+            k += 1
+        otr = o.trace()
+        assert k == 12 and int(otr['nflip'][1:].min()) >= fmin
+        for opts, host_driven in (({}, tubes == 48), ({'small_flips': 65536}, False), ({'small_flips': 65536, 'batch': 5, 'fused': 0}, False),
+                                  ({'small_flips': 600}, True)):
+            s = Session(shape, lib=lib)
+            for kk, vv in opts.items():
+                s.set_option(kk, vv)
+            s.set_volume(d.astype(np.float32)); s.set_labels(v); s.init(2.25)
+            r = s.run(12, 10 ** 9, None)
+            assert r.sweeps == k and r.ties == 0, (tubes, opts)
+            parity.compare_state(s, o, shape, parity.density_rtol(d), 'many flips, %d tubes, %r' % (tubes, opts))
+            tr = s.trace()
+            for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no'):
+                assert np.array_equal(tr[f], otr[f]), (f, tubes, opts)
+            assert (s.stats()['host_driven_trips'] > 0) == host_driven, (tubes, opts, s.stats())
+            s.close()
+        o.close()
+
+
 def test_two_live_sessions_are_independent(lib, golden_loader):
     """Two handles in one process (own streams, events and state each): their sweeps interleaved call by call, both
     must reproduce the oracle."""
