@@ -53,8 +53,7 @@ struct VrgBackend {
     hipEvent_t mark[4] = {nullptr, nullptr, nullptr, nullptr};   // a follower's staging buffers: the kernels that read buffer j have been enqueued up to here (per stream)
     int sweep_blocks = 0;                // 0 = auto (dense_blocks)
     int prio_mode = 2;                   // the dense stream gets the higher priority (measured: -1..2 % step time)
-    uint32_t small_flips = 4096;         // flips per sweep the device-resident four-launch chain takes on (option "small_flips", up to NF_WIDE = 65 536: measured, the host-driven
-                                         // trips are faster above a few thousand flips - both are bound by atomics on the same few words)
+    uint32_t small_flips = 65536;        // flips per sweep the device-resident four-launch chain takes on (option "small_flips", at most NF_WIDE); a sweep with more is driven from the host
     ncclComm_t comm = nullptr;           // per-sweep all-reduce of the slab statistics (multi-GPU)
     char err[256] = "";                  // first HIP / RCCL failure; the engine turns it into VRG_E_INTERNAL
     std::vector<EvPair> ev_pool;
@@ -237,13 +236,50 @@ __device__ void exact_wave(const VrgCtx& c, const VrgState& s, uint32_t nfresh, 
 // k_band at 6111 levels).  Wave partial sums are added in the order 0..3; a table of <= 512 levels is wave 0's alone,
 // which then makes exactly exact_wave's additions.
 // (n_in / n_out: the region sizes the decisions read - the caller's, which may have derived them from an open-ended sweep)
-__device__ void exact_wg(const VrgCtx& c, const VrgState& s, uint32_t nfresh, uint32_t wg, uint32_t nwg, int64_t n_in, int64_t n_out) {
+// (sink: where the many-slot branch lists the slots that flip - most of a large sweep's flips are entries the sweep before added)
+__device__ void exact_wg(const VrgCtx& c, const VrgState& s, uint32_t nfresh, uint32_t wg, uint32_t nwg, int64_t n_in, int64_t n_out, VrgFlipSink* sink = nullptr) {
     __shared__ double sh_i[TPB / 64], sh_o[TPB / 64];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr uint32_t NWV = TPB / 64, BATCH = 64u * EXQ;
     if (wg >= nfresh) return;
     if (c.nb) {                                           // (with bins: a wave per entry does it - at most 2983 bins, 47 per lane)
         exact_wave_binned(c, s, nfresh, wg * NWV + wv, nwg * NWV, true, n_in, n_out);
+        return;
+    }
+    if (c.L <= BATCH && nfresh > nwg) {
+        // Tens of thousands of pending slots (a sweep of thousands of flips) and a table that is one batch - wave 0's alone below, the other
+        // three waves idle while each workgroup walks ~100 slots one dependent chain after the other (0.2 ms at 12 900 flips): every WAVE
+        // takes slots of its own, two per turn so that their look-ups travel together.  The additions are wave 0's, in its order.
+        int32_t ha[EXQ], hb[EXQ]; double lv[EXQ];
+#pragma unroll
+        for (int q = 0; q < EXQ; q++) {
+            const uint32_t l = lane + 64u * q;
+            const bool in = l < c.L;
+            ha[q] = in ? c.hin[l] : 0; hb[q] = in ? c.hout[l] : 0; lv[q] = in ? c.lev[l] : 0.0;
+        }
+        const uint32_t W = nwg * NWV;
+        for (uint32_t f = wg * NWV + wv; f < nfresh; f += 2u * W) {
+            const bool two = f + W < nfresh;
+            const uint32_t slotA = c.fresh[f], slotB = c.fresh[two ? f + W : f];
+            const uint32_t levA = c.p_lev[slotA], levB = c.p_lev[slotB];
+            const double vA = c.lev[levA], vB = c.lev[levB];
+            double siA = 0, soA = 0, siB = 0, soB = 0;
+#pragma unroll
+            for (int q = 0; q < EXQ; q++) {
+                if (!(ha[q] | hb[q])) continue;
+                const double kA = vrg_kern(c, lv[q] - vA), kB = vrg_kern(c, lv[q] - vB);
+                siA += (double)ha[q] * kA; soA += (double)hb[q] * kA;
+                siB += (double)ha[q] * kB; soB += (double)hb[q] * kB;
+            }
+            siA = wave_sum(siA); soA = wave_sum(soA); siB = wave_sum(siB); soB = wave_sum(soB);
+            if (lane == 0 || (lane == 1 && two)) {
+                const uint32_t slot = lane ? slotB : slotA;
+                const double si = lane ? siB : siA, so = lane ? soB : soA;
+                c.p_ip[slot] = si; c.p_op[slot] = so; c.p_err[slot] = 0.0f;
+                if (s.iter < s.iterMax)
+                    vrg_decide_core(c, s, n_in, n_out, slot, c.p_flag[slot] & PF_INNER, si, so, c.p_key[slot], c.p_idx[slot], lane ? levB : levA, 0.0, sink);
+            }
+        }
         return;
     }
     int32_t ha[EXQ], hb[EXQ]; double lv[EXQ];      // this wave's first batch stays in registers for every slot
@@ -322,7 +358,8 @@ __device__ __forceinline__ void band_deferred_done(const VrgCtx& c, int k, uint3
 // exp per entry is what this kernel costs), a fixed butterfly adds the partial sums.  With the per-level memo (or
 // nothing to correct) it is one thread per slot.  Workgroups [BAND_BLOCKS, +EXACT_BLOCKS): the exact densities of the
 // slots that (re-)entered the band in the sweep before, then their sign tests (exact_wg).
-constexpr int BAND_BLOCKS = 8192;     // most workgroups k_band uses for the pool (a pool of millions of slots: one turn per thread, not four); fewer when the engine knows the pool is small (band_blocks())
+constexpr int BAND_BLOCKS = 2048;     // most workgroups k_band uses for the pool (above 2048 x 256 slots a thread takes several turns: every workgroup files its flips with one bump of the
+                                      // flip counter, and those bumps run one after the other); fewer when the engine knows the pool is small (band_blocks())
 // Lanes that share a slot when its correction is summed entry by entry (LPE): 16, 8 or 4 by the size of the pool, so that the
 // pool's workgroups stay within one round of the chip (two workgroups per CU) - band_lanes().  Their partial sums are added
 // by a DPP butterfly inside the group (xor 1, xor 2, mirror of 8, mirror of 16: no LDS traffic, where a shuffle is two
@@ -341,6 +378,19 @@ template <int LPE> __device__ __forceinline__ double group_sum(double v) {
 }
 constexpr uint32_t TAB_LDS = 832;     // levels whose memo entries k_band stages in LDS (the room of the entry-by-entry path's arrays)
 constexpr uint32_t DEFER_WGS = 32;    // pool workgroups of k_band that carry out what a fused sweep deferred (label bytes, class bits, free list)
+constexpr uint32_t SINK_ABOVE = 1u << 17;   // pool slots above which a workgroup of k_band lists its flips together (VrgFlipSink)
+// all threads of the workgroup, once its decisions are made: the sink's records into the flip list
+__device__ void band_sink_file(const VrgCtx& c, VrgFlipSink& sk, uint32_t tid) {
+    __syncthreads();
+    const uint32_t n = min(sk.n, VRG_SINK_CAP);
+    if (tid == 0 && n) sk.base = vrg_atomic_add(&c.stg->nf, n);
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += TPB) {
+        const uint32_t q = sk.base + i;
+        if (q >= c.fcap) { vrg_store_i32(&c.stg->error, 2); continue; }
+        c.flist[q] = sk.slot[i]; c.f_key[q] = sk.key[i]; c.fr_idx[q] = sk.idx[i]; c.fr_lev[q] = sk.lev[i];
+    }
+}
 template <int LPE>
 __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, int dense_on, int direct_hint) {
     VRG_CHAOS_POINT(1);
@@ -451,23 +501,32 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
         band_deferred_done(c, k, defer_wgs);
         return;
     }
+    // (many flips - a pool of hundreds of thousands of entries, thousands of pending slots: a workgroup lists its flips together, one bump of the flip
+    // counter, vrg_decide_core)
+    __shared__ VrgFlipSink s_sink;
     if (!pool_wg) {
-        exact_wg(c, s, s.nfx, blockIdx.x - band_blocks, EXACT_BLOCKS, nin0, nout0);
+        const bool sunk = s.nfx > EXACT_BLOCKS;           // (uniform; the branch of exact_wg that uses the sink)
+        if (sunk) { if (tid == 0) s_sink.n = 0; __syncthreads(); }
+        exact_wg(c, s, s.nfx, blockIdx.x - band_blocks, EXACT_BLOCKS, nin0, nout0, sunk ? &s_sink : nullptr);
+        if (sunk) band_sink_file(c, s_sink, tid);
         if (stx && live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP_PUT(c, 3, t_entry); VRG_STAMP(c, 4); }
         return;
     }
     const bool direct = s.corr && !s.use_tab;
+    VrgFlipSink* const sink = s.np > SINK_ABOVE ? &s_sink : nullptr;
+    if (tid == 0) s_sink.n = 0;                           // (in place before any decision: the barriers below)
     if (!direct) {
         if (direct_hint) for (uint32_t j = tid; j < 3 * tab_n; j += TPB) s_raw[j] = c.tabC[j];      // (the hint was wrong: the memo head now)
         __syncthreads();                                  // (the memo head is in LDS)
         if (!direct_hint) {
             if (slot0 < s.np)
-                vrg_item_band_fields(c, s, slot0, fl0, ip0, op0, lev0, idx0, key0, nin0, nout0, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n, (double)err0);
+                vrg_item_band_fields(c, s, slot0, fl0, ip0, op0, lev0, idx0, key0, nin0, nout0, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n, (double)err0, sink);
             for (uint32_t slot = slot0 + band_blocks * TPB; slot < s.np; slot += band_blocks * TPB)
-                vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n, nin0, nout0);
+                vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n, nin0, nout0, sink);
         } else
             for (uint32_t slot = gtid; slot < s.np; slot += band_blocks * TPB)
-                vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n, nin0, nout0);
+                vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n, nin0, nout0, sink);
+        if (sink) band_sink_file(c, s_sink, tid);
         if (st0 && live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 2); }
         return;
     }
@@ -533,10 +592,11 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
                 vrg_add_correction(a, bb, d, ip, op);
                 c.p_ip[slot] = ip; c.p_op[slot] = op;
                 if (s.iter < s.iterMax)              // while iterNum <= iterMax (:58)
-                    vrg_decide_core(c, s, nin0, nout0, slot, fl & PF_INNER, ip, op, key, idx, lev, (double)err);
+                    vrg_decide_core(c, s, nin0, nout0, slot, fl & PF_INNER, ip, op, key, idx, lev, (double)err, sink);
             }
         }
     }
+    if (sink) band_sink_file(c, s_sink, tid);
     if (st0 && live) { VRG_STAMP(c, 40); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 2); }
 }
 
@@ -701,25 +761,36 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
 // pass through LDS a tile at a time (broadcast reads) - n^2 comparisons, 4 * 10^9 at 65 536 flips: ~0.1 ms on the chip; 10^8 at 10^4
 // flips: a few microseconds.  No global sort, no host.  Then the flip's L (+P) bits, stamp and the ordered flip arrays (vrg_item_list_rec).
 constexpr int KR_THREADS = 256;
-constexpr uint32_t KR_TILE = 2048;
+constexpr uint32_t KR_TILE = 512;
+// A workgroup = 256 records x one tile of 512 keys; the tiles of a record block run side by side on the chip and add what they find
+// to the record's count (rk_part - distinct words, nothing returns).  (One workgroup per record block walking ALL tiles: 51 workgroups
+// at 12 900 flips, each issuing 12 900 broadcast LDS reads per wave - 0.19 ms on a fifth of the chip.)
 __global__ void __launch_bounds__(KR_THREADS) k_rank_wide(VrgCtx c) {
     __shared__ uint64_t s_k[KR_TILE];
     const VrgState& s = *c.st;
     if (s.done || s.bail || !s.wide) return;
     const uint32_t nf = min(s.nf, c.fcap), t = threadIdx.x;
-    for (uint32_t i0 = blockIdx.x * KR_THREADS; i0 < nf; i0 += gridDim.x * KR_THREADS) {      // (whole workgroups stay in the loop together: the tile barriers)
-        const uint32_t i = i0 + t;
-        const uint64_t key = i < nf ? c.f_key[i] : ~0ull;
+    const uint32_t nib = (nf + KR_THREADS - 1) / KR_THREADS, ntl = (nf + KR_TILE - 1) / KR_TILE;
+    for (uint32_t w = blockIdx.x; w < nib * ntl; w += gridDim.x) {        // (whole workgroups stay in the loop together: the tile barriers)
+        const uint32_t i = (w / ntl) * KR_THREADS + t, j0 = (w % ntl) * KR_TILE;
+        const uint64_t key = i < nf ? c.f_key[i] : 0ull;
+        __syncthreads();
+        for (uint32_t j = t; j < KR_TILE; j += KR_THREADS) s_k[j] = j0 + j < nf ? c.f_key[j0 + j] : ~0ull;
+        __syncthreads();
         uint32_t r = 0;
-        for (uint32_t j0 = 0; j0 < nf; j0 += KR_TILE) {
-            __syncthreads();
-            for (uint32_t j = t; j < KR_TILE; j += KR_THREADS) s_k[j] = j0 + j < nf ? c.f_key[j0 + j] : ~0ull;
-            __syncthreads();
-            const uint32_t m = min(KR_TILE, nf - j0);
-#pragma unroll 8
-            for (uint32_t j = 0; j < m; j++) r += s_k[j] < key;
-        }
-        if (i < nf) vrg_item_list_rec(c, r, c.flist[i], c.fr_idx[i], c.fr_lev[i], !(key >> 63));
+#pragma unroll 16
+        for (uint32_t j = 0; j < KR_TILE; j++) r += s_k[j] < key;         // (the padding keys are larger than every key)
+        if (i < nf && r) atomicAdd(&c.rk_part[i], r);
+    }
+}
+// ... and the flip's L (+P) bits, stamp and place in the ordered flip arrays, once every tile has reported (a kernel boundary)
+__global__ void __launch_bounds__(TPB) k_list_wide(VrgCtx c) {
+    const VrgState& s = *c.st;
+    if (s.done || s.bail || !s.wide) return;
+    ITEM_LOOP(min(s.nf, c.fcap)) {
+        const uint32_t r = c.rk_part[i];
+        c.rk_part[i] = 0;                                 // (all zero again for the next sweep)
+        vrg_item_list_rec(c, r, c.flist[i], c.fr_idx[i], c.fr_lev[i], !(c.f_key[i] >> 63));
     }
 }
 __global__ void __launch_bounds__(TPB) k_prepass_wide(VrgCtx c) {               // phase-A label of the flip-ins (every L bit is in place: a kernel boundary)
@@ -744,6 +815,7 @@ __global__ void __launch_bounds__(1024) k_fix_wide(VrgCtx c) {                  
 }
 
 constexpr uint32_t LEV_LDS = 2048;  // level values a workgroup of k_mark_relabel keeps in LDS
+constexpr uint32_t HIST_LDS = 1024; // ... and level tables up to this size: its changes to the five per-level counters
 // k_mark_relabel: ONE flip per workgroup and trip - thread p < 125 is place p of the flip's 5x5x5 cube.  Everything the
 // stencils of those 125 voxels read of the LABELS lies within 4 voxels of the flip: the workgroup fetches that 9x9x9
 // neighbourhood once - 81 rows of 16 bytes, one load each for 81 threads - into LDS, and the nine 3-byte rows of a voxel's
@@ -754,28 +826,44 @@ constexpr uint32_t LEV_LDS = 2048;  // level values a workgroup of k_mark_relabe
 // the tile; the ranks of its listed neighbours travel together with the marking atomic.
 constexpr int KM_THREADS = 128;
 constexpr int KM_BLOCKS = 512;
+constexpr int KM_BLOCKS_WIDE = 512;    // ... of a sweep with more flips than that (four flips at a time each: all resident, 2048 flips in flight)
 typedef uint32_t km_u4 __attribute__((ext_vector_type(4)));
 constexpr int KM_ROWS = 81;         // (dy, dz) in [-4, 4]^2; row bytes 0..8 = dx -4..+4 (16 bytes are fetched)
+constexpr uint32_t KM_MKBUF = 512, KM_EVBUF = 256;      // marked voxels / events a workgroup keeps in LDS between two filings, per flip it handles at a time (a flip adds at most 125 of each)
+struct KmEvRec { VrgEvent ev; uint32_t m, r1, rf; };    // a buffered event: its voxel, its number among the workgroup's events of its kind (new or dead) and among the pending ones
 __device__ __forceinline__ uint32_t km_row(int dy, int dz) { return (uint32_t)((dz + 4) * 9 + (dy + 4)); }
-__global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
+// G: the flips a workgroup handles side by side, 128 threads each (1: a sweep of up to KM_BLOCKS flips, a workgroup per flip; 4: thousands
+// of flips - every round trip of a flip's chain then serves four, and a workgroup files what ~25 flips add to the lists at once)
+template <int G>
+__global__ void __launch_bounds__(KM_THREADS * G) k_mark_relabel(VrgCtx cg) {
     VRG_CHAOS_POINT(3);
     // (the first flip's voxel travels with the state: k_order has written the list, whatever the state says)
-    const uint32_t t = threadIdx.x, lane = t & 63;
-    const bool st0 = blockIdx.x == 0 && t == 0;
+    const uint32_t tt = threadIdx.x, g = tt / KM_THREADS, t = tt % KM_THREADS;     // (tt: in the workgroup; t: among the 128 threads of flip g)
+    const bool st0 = blockIdx.x == 0 && tt == 0;
     const unsigned long long t_entry = st0 ? VRG_STAMP_NOW() : 0ull;
-    const uint32_t fidx_first = blockIdx.x < cg.fcap ? cg.f_idx[blockIdx.x] : 0u;
+    const uint32_t r_first = blockIdx.x * G + g;
+    const uint32_t fidx_first = r_first < cg.fcap ? cg.f_idx[r_first] : 0u;
     const int32_t st_done = cg.st->done, st_bail = cg.st->bail;
     const uint32_t nf = cg.st->nf;
     asm volatile("" :: "v"(fidx_first), "v"(st_done), "v"(st_bail), "v"(nf));     // one wait for the four
     if (st_done || st_bail) return;
     if (st0) { VRG_STAMP_PUT(cg, 16, t_entry); VRG_STAMP(cg, 17); }
-    if (blockIdx.x >= nf) return;                                         // (no flip for this workgroup)
+    if (blockIdx.x * G >= nf) return;                                     // (no flip for this workgroup)
     // a voxel that enters the band needs the level index of its intensity: a binary search, i.e. log2(L) DEPENDENT loads -
     // from LDS when the table fits
-    __shared__ double s_lev[LEV_LDS];
-    __shared__ uint32_t s_tile[KM_ROWS * 4];
-    __shared__ uint32_t s_n[3], s_base[3];                                // this workgroup's new / dead / pending events
-    __shared__ int32_t s_d[2];                                            // ... and list length changes
+    extern __shared__ double s_lev[];                                     // (L doubles when the table fits LEV_LDS - the launch sizes it - else nothing)
+    __shared__ uint32_t s_tile_all[G][KM_ROWS * 4];
+    uint32_t* const s_tile = s_tile_all[g];
+    // What the workgroup's flips add to the sweep's lists - marked voxels, new / dead / pending events, list length changes - is kept in
+    // LDS and filed in one go (km_flush): ONE reservation per list and workgroup, not one per flip.  Every reservation is an atomic on
+    // one of a few words of the state, and those execute one after the other in L2 (~8 ns each): at 12 900 flips per sweep and seven
+    // per flip they WERE the kernel (850 us).
+    __shared__ uint32_t s_n[3], s_base[4], s_cnt[2];                      // events by kind since the last flush; bases (new, dead, pending, marked); buffered marked voxels / events
+    __shared__ int32_t s_d[2];                                            // list length changes since the last flush
+    constexpr uint32_t MKBUF = KM_MKBUF * G, EVBUF = KM_EVBUF * G, NT = KM_THREADS * G;
+    __shared__ uint32_t s_mk_idx[MKBUF];
+    __shared__ uint8_t s_mk_nw[MKBUF], s_mk_old[MKBUF];
+    __shared__ KmEvRec s_ev[EVBUF];
     VrgCtx c = cg;
     uint8_t* lab = c.lab[0];
     const uint32_t idx_lo = vrg_idx(c, 0, 0, 0), idx_hi = vrg_idx(c, c.nx - 1, c.ny - 1, c.nz - 1);
@@ -784,9 +872,44 @@ __global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
     const int ry = (int)(t % 9) - 4, rz = (int)(t / 9) - 4;                                   // the tile row thread t < 81 fetches
     c.lev_fast = (cg.L <= LEV_LDS || cg.lev16 || cg.lev_map || cg.lidx) ? 1 : 0;   // (the direct map / the per-voxel level index: one load, requested with the rest)
     if (cg.L <= LEV_LDS) c.lev_map = nullptr;                              // (a table in LDS needs no load at all)
-    // (every thread of the workgroup makes the same number of trips: the commit below needs its barriers)
-    for (uint32_t r = blockIdx.x; r < nf; r += gridDim.x) {
-        const uint32_t fidx = r == blockIdx.x ? fidx_first : c.f_idx[r];
+    if (tt < 3) s_n[tt] = 0;
+    if (tt < 2) { s_d[tt] = 0; s_cnt[tt] = 0; }                           // (in place before anyone counts: the tile barrier of the first flip)
+    // The class histograms (vrg_hist_change) and this sweep's innerAdded / outerAdded / addedPoints by level (vrg_note_level): counted in
+    // LDS, added to the global counters when the workgroup is done - the voxels of a vessel share a handful of levels, and ten thousand
+    // flips bumping those few words one after the other in L2 is what this kernel would otherwise wait for (level tables up to HIST_LDS
+    // levels whose touched levels are found by scanning, lvl_scan 1; nothing in this kernel reads the counters)
+    const bool lds_hist = cg.lvl_scan == 1 && cg.L <= HIST_LDS;
+    uint32_t* const s_hist = reinterpret_cast<uint32_t*>(s_lev + ((cg.L <= LEV_LDS && !cg.lev16) ? cg.L : 0u));
+    if (lds_hist) {
+        for (uint32_t l = tt; l < 5u * cg.L; l += NT) s_hist[l] = 0;
+        c.dIn = s_hist; c.dOut = s_hist + cg.L; c.dConv = s_hist + 2u * cg.L;
+        c.hin = reinterpret_cast<int32_t*>(s_hist + 3u * cg.L); c.hout = reinterpret_cast<int32_t*>(s_hist + 4u * cg.L);
+    }
+    auto km_flush = [&]() {                                               // all threads; the buffers are complete (a barrier since the last entry)
+        if (tt < 3 && s_n[tt]) s_base[tt] = vrg_atomic_add(tt == 0 ? &c.st->nalloc : tt == 1 ? &c.st->ndead : &c.st->nfresh, s_n[tt]);
+        if (tt == 3 && s_cnt[0]) s_base[3] = vrg_atomic_add(&c.stg->nmk, s_cnt[0]);
+        if (tt >= 4 && tt < 6 && s_d[tt - 4]) vrg_atomic_add(tt == 4 ? &c.st->d_ni : &c.st->d_no, s_d[tt - 4]);
+        __syncthreads();
+        const uint32_t nm = s_cnt[0], ne = s_cnt[1];
+        for (uint32_t i = tt; i < nm; i += NT) {
+            const uint32_t q = s_base[3] + i;
+            if (q < c.mcap) { c.mk_idx[q] = s_mk_idx[i]; c.mk_new[q] = s_mk_nw[i]; c.mk_old[q] = s_mk_old[i]; } else vrg_store_i32(&c.stg->error, 4);
+        }
+        for (uint32_t i = tt; i < ne; i += NT) {
+            const KmEvRec& e = s_ev[i];
+            vrg_ev_write(c, e.m, e.ev, s_base[0] + e.r1, s_base[1] + e.r1, s_base[2] + e.rf);
+        }
+        __syncthreads();
+        if (tt < 3) s_n[tt] = 0;
+        if (tt < 2) { s_d[tt] = 0; s_cnt[tt] = 0; }
+        __syncthreads();
+    };
+    // (every thread of the workgroup makes the same number of trips: the barriers)
+    for (uint32_t rb = blockIdx.x * G; rb < nf; rb += gridDim.x * G) {
+        const uint32_t r = rb + g;
+        const bool have = r < nf;                                         // (the last round of a sweep may leave some of the G places empty)
+        const uint32_t fidx = r == r_first ? fidx_first : c.f_idx[have ? r : nf - 1u];
+        if (rb != blockIdx.x * G && (s_cnt[0] + 125u * G > MKBUF || s_cnt[1] + 125u * G > EVBUF)) km_flush();     // (uniform: read after the barrier that ended the round before)
         // the tile row (a row that is not wholly inside the allocation - 16 guard bytes at either end - belongs to no real
         // voxel's neighbourhood: it reads as out-of-bounds bytes)
         km_u4 row = {0x01010101u * VB_OOB, 0x01010101u * VB_OOB, 0x01010101u * VB_OOB, 0x01010101u * VB_OOB};
@@ -799,23 +922,21 @@ __global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
         const int64_t m = (int64_t)fidx + ((int64_t)dz * c.PY + dy) * c.PX + dx;
         VrgPre pre;
         pre.rank = 0; pre.vent = 0; pre.lev16 = 0; pre.val = 0.0;
-        if (p < 125u) {
+        if (p < 125u && have) {
             const uint32_t ms = (uint32_t)(m < (int64_t)idx_lo ? (int64_t)idx_lo : (m > (int64_t)idx_hi ? (int64_t)idx_hi : m));
             pre.rank = (uint32_t)c.stamp[ms]; pre.vent = c.vent[ms];
             pre.lev16 = c.lev16 ? (uint32_t)c.lev16[ms] : c.lidx ? c.lidx[ms] : 0u;
             pre.val = (c.lev16 || c.lidx) ? 0.0 : vrg_voxel_value(c, ms);
         }
-        if (r == blockIdx.x && cg.L <= LEV_LDS && !cg.lev16) {           // (its loads queue behind those: one wait covers both)
-            for (uint32_t l = t; l < cg.L; l += KM_THREADS) s_lev[l] = cg.lev[l];
+        if (rb == blockIdx.x * G && cg.L <= LEV_LDS && !cg.lev16) {      // (its loads queue behind those: one wait covers both)
+            for (uint32_t l = tt; l < cg.L; l += NT) s_lev[l] = cg.lev[l];
             c.lev = s_lev;
         }
         if (t < KM_ROWS) { s_tile[4 * t] = row.x; s_tile[4 * t + 1] = row.y; s_tile[4 * t + 2] = row.z; s_tile[4 * t + 3] = row.w; }
-        if (t < 3) s_n[t] = 0;
-        if (t < 2) s_d[t] = 0;
         __syncthreads();
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 18); }
         uint8_t mb = VB_OOB;
-        if (p < 125u) { const uint32_t o = (uint32_t)(dx + 4); mb = (uint8_t)(s_tile[4 * km_row(dy, dz) + (o >> 2)] >> (8u * (o & 3u))); }
+        if (p < 125u && have) { const uint32_t o = (uint32_t)(dx + 4); mb = (uint8_t)(s_tile[4 * km_row(dy, dz) + (o >> 2)] >> (8u * (o & 3u))); }
         const bool wanted = vrg_mark_wanted(p, mb);
         // the mark (its answer says whether this thread is the voxel's first marker) and the ranks of the listed neighbours
         // leave together; the tile work below runs while they travel
@@ -853,45 +974,38 @@ __global__ void __launch_bounds__(KM_THREADS) k_mark_relabel(VrgCtx cg) {
         const uint32_t lev_here = (wanted && c.lev_fast) ? vrg_pre_level(c, pre) : 0xffffffffu;
         const bool first = wanted && !((old >> sh) & VB_M);
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 19); }
-        // one reservation in the marked list per wave (every first marker of the chip bumping the same word would
-        // serialise in L2)
-        const unsigned long long fm = __ballot(first);
-        uint32_t q = 0;
-        if (fm) {
-            const int leader = __ffsll((long long)fm) - 1;
-            uint32_t b0 = 0;
-            if ((int)lane == leader) b0 = vrg_atomic_add(&c.stg->nmk, (uint32_t)__popcll(fm));
-            q = __shfl(b0, leader, 64) + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
-        }
-        if (st0) { asm volatile("" :: "v"(q)); VRG_STAMP(c, 23); }
-        VrgEvent ev; ev.kind = VE_NONE; ev.pend = 0;
-        uint32_t rn = 0, rd = 0, rf = 0;
+        // the first marker's voxel and its event take their places in the workgroup's buffers (one wave-wide count each: LDS atomics)
+        if (st0) VRG_STAMP(c, 23);
         if (first) {
+            VrgEvent ev; ev.kind = VE_NONE; ev.pend = 0;
             VrgRanks qr; vrg_ranks_none(qr);
             vrg_ranks_take(FO, n0, r0, qr);
             while (cand) { vrg_rank_batch(c, cand, (uint32_t)m, n0, r0); vrg_ranks_take(FO, n0, r0, qr); }     // (more than four listed neighbours: rare)
             const uint8_t nw = vrg_sweep_cases(c, (uint32_t)m, mb, pre, nb, qr, ring2, lev_here, ev);   // (L / P bits date from k_order: mb is current)
-            if (q < c.mcap) { c.mk_idx[q] = (uint32_t)m; c.mk_new[q] = nw; c.mk_old[q] = mb; } else vrg_store_i32(&c.stg->error, 4);
-            // its event takes a number inside the workgroup ...
-            if (ev.kind == VE_NEW) rn = atomicAdd(&s_n[0], 1u);
-            if (ev.kind == VE_DIE) rd = atomicAdd(&s_n[1], 1u);
-            if (ev.kind != VE_NONE && ev.kind != VE_DIE && ev.pend) rf = atomicAdd(&s_n[2], 1u);
-            const int di = vrg_ev_dni(ev), dq = vrg_ev_dno(ev);
-            if (di) atomicAdd(&s_d[0], di);
-            if (dq) atomicAdd(&s_d[1], dq);
+            const uint32_t qm = atomicAdd(&s_cnt[0], 1u);
+            s_mk_idx[qm] = (uint32_t)m; s_mk_nw[qm] = nw; s_mk_old[qm] = mb;
+            if (ev.kind != VE_NONE) {
+                uint32_t r1 = 0, rf = 0;
+                if (ev.kind == VE_NEW) r1 = atomicAdd(&s_n[0], 1u);
+                if (ev.kind == VE_DIE) r1 = atomicAdd(&s_n[1], 1u);
+                if (ev.kind != VE_DIE && ev.pend) rf = atomicAdd(&s_n[2], 1u);
+                const int di = vrg_ev_dni(ev), dq = vrg_ev_dno(ev);
+                if (di) atomicAdd(&s_d[0], di);
+                if (dq) atomicAdd(&s_d[1], dq);
+                KmEvRec& e = s_ev[atomicAdd(&s_cnt[1], 1u)];
+                e.ev = ev; e.m = (uint32_t)m; e.r1 = r1; e.rf = rf;
+            }
         }
-        __syncthreads();
+        __syncthreads();                                                  // (the buffers are consistent; the tile may be overwritten)
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 20); }
-        // ... the workgroup reserves its stretch of every list with ONE atomic each ...
-        if (t < 3 && s_n[t])
-            s_base[t] = vrg_atomic_add(t == 0 ? &c.st->nalloc : t == 1 ? &c.st->ndead : &c.st->nfresh, s_n[t]);
-        if (t >= 4 && t < 6 && s_d[t - 4]) vrg_atomic_add(t == 4 ? &c.st->d_ni : &c.st->d_no, s_d[t - 4]);
-        __syncthreads();
-        // ... and every event is written at its place
-        if (ev.kind != VE_NONE) vrg_ev_write(c, (uint32_t)m, ev, s_base[0] + rn, s_base[1] + rd, s_base[2] + rf);
-        __syncthreads();
-        if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 21); }
     }
+    km_flush();
+    if (lds_hist)                                                         // (km_flush ends with a barrier: the counts are complete)
+        for (uint32_t l = tt; l < 5u * cg.L; l += NT) {
+            const uint32_t n = s_hist[l];                                 // (the histograms' changes are signed: the same bits)
+            if (n) { const uint32_t k = l / cg.L, lv = l - k * cg.L; atomicAdd((k == 0 ? cg.dIn : k == 1 ? cg.dOut : k == 2 ? cg.dConv : k == 3 ? (uint32_t*)cg.hin : (uint32_t*)cg.hout) + lv, n); }
+        }
+    if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 21); }
     if (t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP_MAX(c, 22); }
 }
 
@@ -2578,11 +2692,18 @@ static void small_update(VrgBackend* b, const VrgCtx& c0, bool dense, hipEvent_t
     const bool wide = 2 * (uint64_t)fh > NF_ORDER;
     k_order<<<1, KO_THREADS, 0, b->sa>>>(c, wide ? b->small_flips : std::min<uint32_t>(b->small_flips, NF_ORDER));
     if (wide) {                  // its ordering step chip-wide (no-ops when k_order did the ordering itself)
-        k_rank_wide<<<std::min<uint32_t>(1024u, (2 * fh + KR_THREADS - 1) / KR_THREADS), KR_THREADS, 0, b->sa>>>(c);
+        const uint64_t nrec = (2 * (uint64_t)fh + KR_THREADS - 1) / KR_THREADS, ntile = (2 * (uint64_t)fh + KR_TILE - 1) / KR_TILE;
+        k_rank_wide<<<(uint32_t)std::min<uint64_t>(16384u, nrec * ntile), KR_THREADS, 0, b->sa>>>(c);
+        k_list_wide<<<std::min<uint32_t>(1024u, (2 * fh + TPB - 1) / TPB), TPB, 0, b->sa>>>(c);
         k_prepass_wide<<<std::min<uint32_t>(1024u, (2 * fh + TPB - 1) / TPB), TPB, 0, b->sa>>>(c);
         k_fix_wide<<<1, 1024, 0, b->sa>>>(c);
     }
-    k_mark_relabel<<<std::max<uint32_t>(KM_BLOCKS, std::min<uint32_t>(2 * fh, NF_WIDE)), KM_THREADS, 0, b->sa>>>(c);
+    // (a workgroup per flip up to KM_BLOCKS flips; beyond, every workgroup takes several and files what they add to the lists together)
+    const size_t lev_lds = ((c.L <= LEV_LDS && !c.lev16) ? (size_t)c.L * sizeof(double) : 0) + ((c.lvl_scan == 1 && c.L <= HIST_LDS) ? 5 * (size_t)c.L * sizeof(uint32_t) : 0);   // level table + per-level counts
+    // (measured at 12 900 flips, ms per sweep: 4 flips at a time x 256 / 512 / 1024 workgroups 0.340 / 0.348 / 0.380; 2 x 1024 / 2048: 0.40 / 0.50; 1 x 2048 / 4096:
+    // 0.52 / 0.70 - every workgroup more is six more reservations on the same few words)
+    if (2 * (uint64_t)fh > KM_BLOCKS) k_mark_relabel<4><<<KM_BLOCKS_WIDE, 4 * KM_THREADS, lev_lds, b->sa>>>(c);
+    else k_mark_relabel<1><<<KM_BLOCKS, KM_THREADS, lev_lds, b->sa>>>(c);
     // (waits on the device for the dense pass of two sweeps ago)
     const uint32_t napply = std::max<uint32_t>(CLOSE_APPLY, std::min<uint32_t>(1024u, fh / 8u));
     hipExtLaunchKernelGGL(k_close, dim3(napply + TAB_BLOCKS), dim3(KC_THREADS), 0, b->sa, nullptr, e_chain_stop, 0, c, dense ? 1 : 0, napply);

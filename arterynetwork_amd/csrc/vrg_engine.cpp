@@ -150,10 +150,11 @@ bool size_pool(vrg_handle* h, uint64_t want, uint32_t keep, uint32_t keep_free) 
     bool ok = grow(h, c.p_idx, keep, cap) && grow(h, c.p_lev, keep, cap) && grow(h, c.p_ip, keep, cap) && grow(h, c.p_op, keep, cap) && grow(h, c.p_err, keep, cap) &&
               grow(h, c.p_key, keep, cap) && grow(h, c.p_flag, keep, cap) && grow(h, c.freel, keep_free, cap) &&
               grow(h, c.flist, 0, cap) && grow(h, c.f_key, 0, cap) && grow(h, c.fr_idx, 0, cap) && grow(h, c.fr_lev, 0, cap) && grow(h, c.f_slot, 0, cap) && grow(h, c.f_idx, 0, cap) && grow(h, c.f_lev, 0, cap) &&
-              grow(h, c.f_res, 0, cap) && grow(h, c.pend, 0, cap) && grow(h, c.fresh, keep, cap) &&
+              grow(h, c.f_res, 0, cap) && grow(h, c.pend, 0, cap) && grow(h, c.rk_part, 0, cap) && grow(h, c.fresh, keep, cap) &&
               grow(h, c.init_key, 0, cap) && grow(h, c.init_idx, 0, cap);
     if (!ok) return false;
     if (cap > keep) be_fill(h->be, c.p_flag + keep, 0, cap - keep);
+    be_fill(h->be, c.rk_part, 0, cap * sizeof(uint32_t));
     c.bcap = (uint32_t)cap; c.fcap = c.bcap;
     return true;
 }
@@ -715,6 +716,11 @@ int API(get_stats)(vrg_handle* h, int64_t* outp, int64_t cap) {
     if (cap >= 18) outp[17] = h->inited ? h->c.nb : 0;
     if (cap >= 19) outp[18] = be_memo_trips(h->be);
     if (cap >= 20) outp[19] = h->data_nonzero;
+    // what a large level table costs in device memory: the bin moments (two classes x nb_alloc bins x 9 words) and the per-voxel level index
+    if (cap >= 22) {
+        outp[20] = (int64_t)h->nb_alloc * (VRG_BIN_K + 1) * 8 * 2;
+        outp[21] = (h->lidx_buf ? (int64_t)h->PVu * 4 : 0) + (h->lev16_buf ? (int64_t)h->PVu * 2 : 0);
+    }
     if (cap >= 14) {
         int64_t di[5] = {0, 0, 0, 0, 0};
         uint32_t uc[2] = {0, 0};

@@ -267,8 +267,12 @@ VRG_HD void vrg_add_correction(double ic, double oc, double ac, double& ip, doub
 // A flip is listed by an unordered append of its record (slot, sort key, voxel, level); k_order orders the list.
 // n_in / n_out: the region sizes (VrgCtx::inc), read once per thread by the caller
 // err: bound on the absolute error of ip and of op (binned exact densities, VrgCtx::p_err; 0 without bins)
+// sink: a workgroup's own list of flip records (LDS), filed with ONE bump of the flip counter when the workgroup is done (k_band, pools of
+// hundreds of thousands of entries: every flip bumping the same word - 12 900 of them, one after the other in L2 - was most of the kernel)
+constexpr uint32_t VRG_SINK_CAP = 512;
+struct VrgFlipSink { uint64_t key[VRG_SINK_CAP]; uint32_t slot[VRG_SINK_CAP], idx[VRG_SINK_CAP], lev[VRG_SINK_CAP]; uint32_t n, base; };
 VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, int64_t n_in, int64_t n_out, uint32_t slot, bool inner, double ip, double op,
-                            uint64_t key, uint32_t idx, uint32_t lev, double err = 0.0) {
+                            uint64_t key, uint32_t idx, uint32_t lev, double err = 0.0, VrgFlipSink* sink = nullptr) {
     double inN = ip / (double)n_in;                       // :81
     double outN = op / (double)n_out;                     // :82
     bool ge = inN >= outN;
@@ -279,8 +283,13 @@ VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, int64_t n_in, in
         else if (!(d > VRG_TIE_NEAR_REL * m)) vrg_atomic_add(&c.stg->near_ties, 1u);
     }
     if (inner == ge) return;                              // :87 xor(segmentedMap, inner >= outer)
+    const bool count_only = s.time_up || n_in >= s.maxSegmentSize;      // :97 / :101 fire before update()
+    if (sink && !count_only) {
+        const uint32_t l = vrg_lds_add(&sink->n, 1u);
+        if (l < VRG_SINK_CAP) { sink->slot[l] = slot; sink->key[l] = vrg_flip_key(inner, key); sink->idx[l] = idx; sink->lev[l] = lev; return; }
+    }                                                     // (a full sink: the record goes the direct way)
     uint32_t q = vrg_atomic_add(&c.stg->nf, 1u);
-    if (s.time_up || n_in >= s.maxSegmentSize) return;    // :97 / :101 fire before update(): count only
+    if (count_only) return;
     if (q >= c.fcap) { vrg_store_i32(&c.stg->error, 2); return; }
     c.flist[q] = slot; c.f_key[q] = vrg_flip_key(inner, key); c.fr_idx[q] = idx; c.fr_lev[q] = lev;
 }
@@ -288,7 +297,7 @@ VRG_HD void vrg_decide_core(const VrgCtx& c, const VrgState& s, int64_t n_in, in
 // device), tab = the per-level memo (the device may pass an LDS copy of its first tab_n levels; the rest comes from c.tabC)
 VRG_HD void vrg_item_band_fields(const VrgCtx& c, const VrgState& s, uint32_t slot, uint8_t fl, double ip, double op, uint32_t lev, uint32_t idx,
                                  uint64_t key, int64_t n_in, int64_t n_out, const double* nz_val, const uint32_t* nz_cin,
-                                 const uint32_t* nz_cout, const uint32_t* nz_cconv, const double* tab, uint32_t tab_n, double err = 0.0) {
+                                 const uint32_t* nz_cout, const uint32_t* nz_cconv, const double* tab, uint32_t tab_n, double err = 0.0, VrgFlipSink* sink = nullptr) {
     if (!(fl & PF_ALIVE)) return;
     // an entry that (re-)entered the band in the sweep before takes no correction; it is decided by whoever computes
     // its exact densities (the other half of this launch, which reads only the list bit of the flag)
@@ -303,10 +312,11 @@ VRG_HD void vrg_item_band_fields(const VrgCtx& c, const VrgState& s, uint32_t sl
         vrg_add_correction(ic, oc, ac, ip, op);
         c.p_ip[slot] = ip; c.p_op[slot] = op;
     }
-    if (s.iter < s.iterMax) vrg_decide_core(c, s, n_in, n_out, slot, fl & PF_INNER, ip, op, key, idx, lev, err);   // while iterNum <= iterMax (:58)
+    if (s.iter < s.iterMax) vrg_decide_core(c, s, n_in, n_out, slot, fl & PF_INNER, ip, op, key, idx, lev, err, sink);   // while iterNum <= iterMax (:58)
 }
 VRG_HD void vrg_item_band(const VrgCtx& c, const VrgState& s, uint32_t slot, const double* nz_val, const uint32_t* nz_cin,
-                          const uint32_t* nz_cout, const uint32_t* nz_cconv, const double* tab = nullptr, uint32_t tab_n = 0, int64_t sizes_in = -1, int64_t sizes_out = -1) {
+                          const uint32_t* nz_cout, const uint32_t* nz_cconv, const double* tab = nullptr, uint32_t tab_n = 0, int64_t sizes_in = -1, int64_t sizes_out = -1,
+                          VrgFlipSink* sink = nullptr) {
     // the slot's fields in one batch (a dead slot's are read for nothing): the kernel is bound by dependent loads
     const uint8_t fl = c.p_flag[slot];
     const double ip = c.p_ip[slot], op = c.p_op[slot];
@@ -316,7 +326,7 @@ VRG_HD void vrg_item_band(const VrgCtx& c, const VrgState& s, uint32_t slot, con
     // state the kernel READS; never c.inc there: k_band files into the other buffer while it decides)
     const int64_t n_in = sizes_in >= 0 ? sizes_in : c.inc_in[VC_NIN], n_out = sizes_in >= 0 ? sizes_out : c.inc_in[VC_NOUT];
     const double err = (double)c.p_err[slot];
-    vrg_item_band_fields(c, s, slot, fl, ip, op, lev, idx, key, n_in, n_out, nz_val, nz_cin, nz_cout, nz_cconv, tab, tab_n, err);
+    vrg_item_band_fields(c, s, slot, fl, ip, op, lev, idx, key, n_in, n_out, nz_val, nz_cin, nz_cout, nz_cconv, tab, tab_n, err, sink);
 }
 // ------------------------------------------------------------------ binned exact densities (large level tables)
 // The exact densities of an entry that (re-)enters the band (:252-255) are sums over the whole inner / outer regions:

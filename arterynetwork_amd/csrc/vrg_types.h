@@ -280,6 +280,7 @@ struct VrgCtx {
     uint32_t* f_lev;           // ... and intensity level of flip r
     uint8_t* f_res;            // FR_* result of flip r
     uint32_t* pend;            // ranks of the flip-ins in the skip-rule fix-point
+    uint32_t* rk_part;         // chip-wide ordering (k_rank_wide): the number of smaller keys found so far, per listed flip; all zero between sweeps
     uint32_t* fresh;           // slots needing exact densities
     // dense statistics partials (one slot per sweep workgroup)
     uint32_t nstat;

@@ -92,9 +92,8 @@ const char* vrg_last_error(const vrg_handle* h);
  *                    trip of a batch with HIP events (vrg_result.chain_kernel_ms / chain_launches)
  *   "batch"          any time; sweeps enqueued between host checks of the stop flag (default 8)
  *   "small_flips"    any time; flips per sweep up to which update() stays on the device as the four-launch chain, without
- *                    a host synchronisation (default 4096, maximum 65536; above 512 flips its ordering step runs chip-wide);
- *                    sweeps with more are driven from the host with device-wide kernels and rocPRIM sorts - measured, the
- *                    faster of the two above a few thousand flips
+ *                    a host synchronisation (default and maximum 65536; above 512 flips its ordering step runs chip-wide);
+ *                    sweeps with more are driven from the host with device-wide kernels and rocPRIM sorts
  *   "serial_streams" any time; the host orders the band and dense streams (a synchronisation per sweep) instead of the
  *                    kernels waiting for each other on the device - for tools that run one kernel at a time
  *                    (rocprofv3 --pmc), under which a device-side wait could never end
@@ -162,7 +161,9 @@ int vrg_get_levels(vrg_handle* h, double* values, int32_t* hist_in, int32_t* his
  * With cap >= 14 also how the dense pass is launched: out[9] = 1 for non-temporal loads, out[10] = intensity storage
  * (0 fp32, 1 u16 level index, 2 float64, 3 u16 level index with the value table of the dense pass held as doubles: up to 4096 levels), out[11] = workgroups, out[12] = skip_excluded, out[13] = units on its list.  With cap >= 15 also out[14] = 1 when the
  * pass is the two-trips-deep kernel k_recount_pipe (option dense_pipe; fp32 storage with skip_excluded), 0 for k_recount_bits.
- * With cap >= 20 also out[19] = the number of non-zero values of dataArray (np.count_nonzero, the reference's closing message :95), counted when the volume was set. */
+ * With cap >= 20 also out[19] = the number of non-zero values of dataArray (np.count_nonzero, the reference's closing message :95), counted when the volume was set.
+ * With cap >= 22 also what a large level table costs in device memory: out[20] = bytes of the bin moments (L > 2048 distinct values: up to 4 194 304 bins x 9
+ * 64-bit words x 2 classes = 604 MB), out[21] = bytes of the per-voxel level index (4 B per voxel; 2 B with 16-bit storage). */
 int vrg_get_stats(vrg_handle* h, int64_t* out, int64_t cap);
 
 /* Diagnostic builds only (compiled with -DVRG_STAMPS, tools/chain_stamps.py): 64 in-kernel time stamps (100-MHz ticks) of

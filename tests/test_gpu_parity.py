@@ -776,15 +776,16 @@ def test_host_driven_and_one_workgroup_sweeps_identical(lib, golden_loader):
 
 def test_many_flip_sweeps_vs_oracle(lib):
     """Several disjoint tubes growing at once (SURVEY.md 8(d), config 5's shape): 1 600 flips per sweep (16 tubes) and 4 800
-    (48 tubes).  The four-launch chain orders more than 512 flips chip-wide (k_rank_wide / k_prepass_wide / k_fix_wide) - by
-    default up to 4 096 flips, with "small_flips" 65 536 all of them; above the limit the trips are host-driven (rocPRIM sorts).
+    (48 tubes).  The four-launch chain orders more than 512 flips chip-wide (k_rank_wide / k_list_wide / k_prepass_wide /
+    k_fix_wide) and relabels four flips at a time per workgroup; above "small_flips" the trips are host-driven (rocPRIM sorts).
     Every variant must reproduce the oracle's labels, band lists (order included) and trace, twelve sweeps in one call."""
     import torch
     from arterynetwork_amd import phantoms
     from arterynetwork_amd._capi import Session
     from oracle import vrg_oracle as O
-    for shape, tubes, fmin in (((160, 160, 64), 16, 1500), ((256, 192, 96), 48, 4097)):
-        I, vm = phantoms.bench_volume_torch(shape, torch.device('cpu'), tubes=tubes)
+    # (levels=1300 -> 2035 distinct values: the level table and the per-level counts of k_mark_relabel's workgroups at the upper end of what they keep in LDS)
+    for shape, tubes, fmin, levels in (((160, 160, 64), 16, 1500, 255), ((256, 192, 96), 48, 4097, 255), ((160, 160, 64), 16, 1000, 1300)):
+        I, vm = phantoms.bench_volume_torch(shape, torch.device('cpu'), tubes=tubes, levels=levels)
         d = np.asfortranarray(I.numpy().astype(np.float64)); v = np.asfortranarray(vm.numpy())
         o = O.Oracle(d, v, 2.25, 1); o.init()
         k = 0
@@ -792,8 +793,7 @@ def test_many_flip_sweeps_vs_oracle(lib):
             k += 1
         otr = o.trace()
         assert k == 12 and int(otr['nflip'][1:].min()) >= fmin
-        for opts, host_driven in (({}, tubes == 48), ({'small_flips': 65536}, False), ({'small_flips': 65536, 'batch': 5, 'fused': 0}, False),
-                                  ({'small_flips': 600}, True)):
+        for opts, host_driven in (({}, False), ({'small_flips': 4096}, tubes == 48), ({'batch': 5, 'fused': 0}, False), ({'small_flips': 600}, True)):
             s = Session(shape, lib=lib)
             for kk, vv in opts.items():
                 s.set_option(kk, vv)

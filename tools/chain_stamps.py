@@ -17,7 +17,7 @@ shape = tuple(int(v) for v in sys.argv[1].split('x'))
 dense_off = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 samples = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 dev = torch.device('cuda', 0)
-I, vm = phantoms.bench_volume_torch(shape, dev, levels=int(os.environ.get('VRG_STAMP_LEVELS', '255')))   # (env: another quantisation)
+I, vm = phantoms.bench_volume_torch(shape, dev, levels=int(os.environ.get('VRG_STAMP_LEVELS', '255')), tubes=int(os.environ.get('VRG_STAMP_TUBES', '1')))   # (env: another quantisation; several tubes = many flips per sweep)
 torch.cuda.synchronize()
 LEADER = os.environ.get('VRG_LEADER', '0') != '0'        # the leader of a leader / follower group that only leads (band chain + change log, no dense pass)
 if LEADER:
