@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
     }
     VrgState s_ = *c.st;                                  // a copy (nf is only ever bumped atomically)
     if (s_.done || s_.bail) {
-        if (st0 && c.st != c.stg) { *c.stg = s_; c.inc[VC_NIN] = nin0; c.inc[VC_NOUT] = nout0; }     // (a fused trip swaps the state buffers whether it does anything or not)
+        if (st0 && c.st != c.stg) { vrg_state_store(c.stg, s_); c.inc[VC_NIN] = nin0; c.inc[VC_NOUT] = nout0; }     // (a fused trip swaps the state buffers whether it does anything or not)
         return;
     }
     // An OPEN-ENDED sweep ran on this state (vrg_items.h "open-ended sweeps"): what it ran on + what its workgroups added up.  Every
@@ -834,6 +834,8 @@ struct KmEvRec { VrgEvent ev; uint32_t m, r1, rf; };    // a buffered event: its
 __device__ __forceinline__ uint32_t km_row(int dy, int dz) { return (uint32_t)((dz + 4) * 9 + (dy + 4)); }
 // G: the flips a workgroup handles side by side, 128 threads each (1: a sweep of up to KM_BLOCKS flips, a workgroup per flip; 4: thousands
 // of flips - every round trip of a flip's chain then serves four, and a workgroup files what ~25 flips add to the lists at once)
+// (176 registers: one 512-thread workgroup - four flips - per CU at a time, and the kernel is bound by the latency of a flip's dependent round trips: 12 900 flips / 1024 in
+// flight x ~10 us; capping the registers at 128 for two workgroups per CU spills 168 bytes per thread and gains nothing: 0.353 vs 0.342 ms per sweep)
 template <int G>
 __global__ void __launch_bounds__(KM_THREADS * G) k_mark_relabel(VrgCtx cg) {
     VRG_CHAOS_POINT(3);

@@ -242,6 +242,16 @@ VRG_HD uint8_t vrg_dec(uint8_t b) {       // byte -> reference label
     return (b & VB_X) ? 4 : 3;
 }
 
+// The state out, field by field: everything in front of the padding and the four live words - never the 196 bytes of padding (a whole-struct
+// assignment copies them too: 96 words held across a kernel, which the compiler then keeps in scratch - k_band, 2 us per launch).
+VRG_HD void vrg_state_store(VrgState* dst, const VrgState& w) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&w); uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (unsigned i = 0; i < offsetof(VrgState, pad_live) / 4; i++) d[i] = src[i];
+    dst->nf = w.nf; dst->ties = w.ties; dst->near_ties = w.near_ties; dst->error = w.error;
+}
 // ------------------------------------------------------------------ list order
 VRG_HD uint64_t vrg_key(const VrgState& s, uint32_t phase, uint32_t rank, uint32_t k) {
     return ((uint64_t)(uint32_t)(s.iter + 1) << 40) | ((uint64_t)phase << 39) | ((uint64_t)rank << 5) | (uint64_t)k;
@@ -1069,7 +1079,7 @@ VRG_HD void vrg_finalize(const VrgCtx& c, bool use_tab) {
     const uint32_t nrec = s.nmk < c.mcap ? s.nmk : c.mcap;
     VrgTrace tr;
     vrg_finalize_update(c, s, n_in, n_out, use_tab, tr);
-    *c.stg = s;
+    vrg_state_store(c.stg, s);
     vrg_log_sweep(c, (int64_t)s.iter, s.log_pos, s.log_nsw, nrec, n_in, n_out, tr);
     vrg_dense_none_step(c, (int64_t)s.iter);
 }
@@ -1086,7 +1096,7 @@ VRG_HD void vrg_close_sweep(const VrgCtx& c, int64_t nchg_at, bool use_tab) {
     if (nchg_at >= 0) c.nchg[k & 1] = (uint32_t)nchg_at;
     VrgTrace tr;
     vrg_finalize_update(c, s, n_in, n_out, use_tab, tr);
-    *c.stg = s;
+    vrg_state_store(c.stg, s);
     vrg_log_sweep(c, k, s.log_pos, s.log_nsw, nrec, n_in, n_out, tr);
     vrg_dense_none_step(c, k);
     vrg_drain(); vrg_store_i64(&c.gate[VG_REQ], k);
@@ -1480,7 +1490,7 @@ VRG_HD void vrg_fuse_close_store(const VrgCtx& c, const VrgState& s, const VrgFu
 VRG_HD void vrg_fuse_close(const VrgCtx& c, VrgState s, int64_t n_in, int64_t n_out, uint32_t nnz, bool use_tab) {
     VrgFuseClosed f;
     vrg_fuse_close_core(c, s, n_in, n_out, nnz, use_tab, f);
-    *c.stg = s;
+    vrg_state_store(c.stg, s);
     vrg_fuse_close_store(c, s, f);
 }
 
@@ -1501,7 +1511,11 @@ VRG_HD void vrg_fuse_close(const VrgCtx& c, VrgState s, int64_t n_in, int64_t n_
 // followed by the memo kernel, or one on a level table too large for a workgroup's LDS list).
 VRG_HD void vrg_state_store_but_live(VrgState* dst, const VrgState& w) {       // all words but the live line (nf, ties, near_ties, error: vrg_types.h)
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&w); uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-    for (unsigned i = 0; i < offsetof(VrgState, nf) / 4; i++) d[i] = src[i];
+    // (the words in front of the padding only, the loop unrolled: a loop the compiler keeps indexes the caller's by-value state - which then lives in scratch)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (unsigned i = 0; i < offsetof(VrgState, pad_live) / 4; i++) d[i] = src[i];
     if (w.error) vrg_store_i32(&dst->error, w.error);
 }
 // k_band's one filing thread.  s: the state this trip works on (closed: as found, or derived from an open-ended sweep: f, was_open).
@@ -1512,7 +1526,7 @@ VRG_HD void vrg_fuse_persist(const VrgCtx& c, const VrgState& s, const VrgFuseCl
     if (c.inc != c.inc_in) { c.inc[VC_NIN] = n_in; c.inc[VC_NOUT] = n_out; }     // (the sizes swap buffers with the state)
     VrgState w = s;
     w.apply_pending = 0; w.fr_n = 0;
-    if (c.st == c.stg) { w.nf = 0; *c.stg = w; }         // (in place - the sequential test model: the sweep's flips are consumed, the decisions count from zero)
+    if (c.st == c.stg) { w.nf = 0; vrg_state_store(c.stg, w); }         // (in place - the sequential test model: the sweep's flips are consumed, the decisions count from zero)
     else vrg_state_store_but_live(c.stg, w);
     if (was_open) vrg_fuse_close_store(c, s, f);
 }

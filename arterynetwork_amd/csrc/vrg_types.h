@@ -124,7 +124,10 @@ struct VrgState {
     // kernel files the rest of the state with plain stores (open-ended sweeps): a line that takes both is written back whole by the storing
     // CU's L2 and the atomics' results are lost - seen as lost flips under the interleaving campaign.  So: no line of the state ever takes
     // plain stores and atomics of different workgroups in one kernel; these four never share a line with anything that is filed.
-    alignas(128) uint32_t nf;          // listed flips of the sweep being processed (atomic count)
+    // (explicit padding, not alignas: an over-aligned member makes every kernel's by-value copy of the state an over-aligned stack object - k_band
+    // then ran with 128 bytes of scratch and k_sweep with 188 instead of 140 VGPRs: +2 us per kernel.  The buffers themselves are 256-byte aligned.)
+    uint32_t pad_live[21];
+    uint32_t nf;                       // listed flips of the sweep being processed (atomic count)
     uint32_t ties, near_ties;          // tie / near-tie sign tests since init (atomic counts; see VRG_TIE_REL)
     int32_t error;                     // capacity overflow etc. (written through)
     uint32_t live_pad[28];

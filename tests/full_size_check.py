@@ -159,7 +159,7 @@ def slabs_one_gpu(world, shape, sweeps):
     import tempfile
     import socket
     dev = torch.device('cuda', 0)
-    I, vm = phantoms.bench_volume_torch(shape, dev)
+    I, vm = phantoms.bench_volume_torch(shape, dev, tubes=int(os.environ.get('VRG_CHECK_TUBES', '1')))     # (env: several tubes = thousands of flips per sweep)
     torch.cuda.synchronize()
     s = Session(shape)
     s.set_option('batch', 16)
@@ -216,7 +216,7 @@ def replica_worker(rank, world, port, shape, sweeps, outdir, transport, leader_v
     from arterynetwork_amd import replica
     dev = torch.device('cuda', 0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    I, vm = phantoms.bench_volume_torch(shape, dev)
+    I, vm = phantoms.bench_volume_torch(shape, dev, tubes=int(os.environ.get('VRG_CHECK_TUBES', '1')))
     torch.cuda.synchronize()
     s = replica.make_replica_session(shape, rank, world, device=0, transport=transport, leader_verifies=bool(leader_verifies), options={'batch': 16})
     s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
@@ -242,7 +242,7 @@ def replicas_one_gpu(world, shape, sweeps, transport, leader_verifies):
     import tempfile
     import socket
     dev = torch.device('cuda', 0)
-    I, vm = phantoms.bench_volume_torch(shape, dev)
+    I, vm = phantoms.bench_volume_torch(shape, dev, tubes=int(os.environ.get('VRG_CHECK_TUBES', '1')))     # (env: several tubes = thousands of flips per sweep)
     torch.cuda.synchronize()
     s = Session(shape)
     s.set_option('batch', 16)

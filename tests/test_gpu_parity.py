@@ -966,9 +966,10 @@ def test_config4_partition_8_ranks_one_gpu(shape, sweeps):
     assert out.returncode == 0 and 'SLABS OK' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-@pytest.mark.parametrize('world,shape,sweeps,transport,leader_verifies', [
-    (8, '880x880x640', 40, 'ipc', 0), (3, '512x512x170', 30, 'ipc', 1), (4, '512x512x170', 30, 'callback', 0)])
-def test_replicas_n_ranks_one_gpu(world, shape, sweeps, transport, leader_verifies):
+@pytest.mark.parametrize('world,shape,sweeps,transport,leader_verifies,tubes', [
+    (8, '880x880x640', 40, 'ipc', 0, 1), (3, '512x512x170', 30, 'ipc', 1, 1), (4, '512x512x170', 30, 'callback', 0, 1),
+    (3, '256x192x96', 24, 'ipc', 0, 48)])            # (48 tubes: 4 800 flips per sweep - the four-launch chain's log, tens of thousands of records per sweep)
+def test_replicas_n_ranks_one_gpu(world, shape, sweeps, transport, leader_verifies, tubes):
     """Leader / follower replication (BASELINE configs[3] re-partitioned) at FULL size on the one GPU of the
     box: `world` rank processes share GPU 0; the leader runs the band chain and logs every sweep, the followers map its log
     buffers (hipIpc - the transport ranks of one node use between GPUs) or receive them through gloo callbacks, apply them and
@@ -977,7 +978,7 @@ def test_replicas_n_ranks_one_gpu(world, shape, sweeps, transport, leader_verifi
     import subprocess, sys, os
     from conftest import ROOT
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'full_size_check.py'), '--replicas', str(world), shape, str(sweeps), transport, str(leader_verifies)],
-                         capture_output=True, text=True)
+                         capture_output=True, text=True, env=dict(os.environ, VRG_CHECK_TUBES=str(tubes)))
     assert out.returncode == 0 and 'REPLICAS OK' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 

@@ -5,7 +5,7 @@
 #   smoke            build() + smoke()
 #   tests            pytest -m gpu (whole suite)            tests:<expr>   pytest -m gpu -k <expr>
 #   bench:<name>:<bench.py args separated by commas>        one bench line -> gpurun_out/<tag>/bench_<name>.json
-#   lines            the round's standard bench lines (headline, driver args, 512, slabs 80/160/320, level regimes, 16-bit storage)
+#   lines            the round's standard bench lines (headline, driver args, 512, replica role proxies, Z-slabs 80/320, level regimes, 16-bit storage, tubes)
 #   slabs            only the slab lines + 512
 #   levels           only the level-regime lines
 #   repeat           rare-race hunt: tools/repeat_case.py 8 seeds x 500, repeat_batched, repeat_stress
@@ -37,11 +37,14 @@ for step in "$@"; do
     lines)
       run 880; run 880_driver --steps 20 --warmup 5
       run 512 --shape 512x512x170 --steps 200
-      for nz in 320 160 80; do run dist1_880x880x$nz --force-dist --shape 880x880x$nz --no-cpu-baseline --steps 300; done
-      for lv in 4095 65535 0; do run 512_levels$lv --no-cpu-baseline --shape 512x512x170 --steps 100 --levels $lv; done
-      run 880_s16 --storage16 --no-cpu-baseline
-      run 1024_s16 --shape 1024x1024x1024 --storage16 --no-cpu-baseline --steps 200
-      run 880_nomask --no-brain-mask --no-cpu-baseline --steps 300 ;;
+      run proxy8_880 --force-dist --no-cpu-baseline --steps 300                      # replica partition: the roles of an 8-rank group, one GPU
+      run proxy8_512 --force-dist --no-cpu-baseline --steps 300 --shape 512x512x170
+      run proxy4_880 --force-dist --no-cpu-baseline --steps 300 --proxy-world 4
+      for nz in 320 80; do run dist1_zslab_880x880x$nz --force-dist --partition zslab --shape 880x880x$nz --no-cpu-baseline --steps 300; done
+      for lv in 4095 65535 0; do run 512_levels$lv --no-cpu-baseline --no-side-lines --shape 512x512x170 --steps 100 --levels $lv; done
+      run 880_s16 --storage16 --no-cpu-baseline --no-side-lines
+      run 1024_s16 --shape 1024x1024x1024 --storage16 --no-cpu-baseline --no-side-lines --steps 200
+      for tb in 16 128; do run 880_tubes$tb --tubes $tb --no-cpu-baseline --no-side-lines --steps 100; done ;;
     slabs)
       run 512 --shape 512x512x170 --steps 200 --no-cpu-baseline
       for nz in 320 160 80; do run dist1_880x880x$nz --force-dist --shape 880x880x$nz --no-cpu-baseline --steps 300; done ;;
