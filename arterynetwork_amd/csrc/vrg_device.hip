@@ -834,8 +834,8 @@ struct KmEvRec { VrgEvent ev; uint32_t m, r1, rf; };    // a buffered event: its
 __device__ __forceinline__ uint32_t km_row(int dy, int dz) { return (uint32_t)((dz + 4) * 9 + (dy + 4)); }
 // G: the flips a workgroup handles side by side, 128 threads each (1: a sweep of up to KM_BLOCKS flips, a workgroup per flip; 4: thousands
 // of flips - every round trip of a flip's chain then serves four, and a workgroup files what ~25 flips add to the lists at once)
-// (176 registers: one 512-thread workgroup - four flips - per CU at a time, and the kernel is bound by the latency of a flip's dependent round trips: 12 900 flips / 1024 in
-// flight x ~10 us; capping the registers at 128 for two workgroups per CU spills 168 bytes per thread and gains nothing: 0.353 vs 0.342 ms per sweep)
+// (126 registers: two 512-thread workgroups - eight flips - per CU.  What bounds the kernel at 10^4 flips per sweep is not known: neither occupancy, nor the number of
+// workgroups, nor its loads' latency or count moved it - DESIGN.md section 4)
 template <int G>
 __global__ void __launch_bounds__(KM_THREADS * G) k_mark_relabel(VrgCtx cg) {
     VRG_CHAOS_POINT(3);
@@ -964,7 +964,7 @@ __global__ void __launch_bounds__(KM_THREADS * G) k_mark_relabel(VrgCtx cg) {
         if (wanted && vrg_wants_ring2(mb, nb)) {                          // an applied flip (P and not OOB) within the 2-ring? (vrg_ring2_applied)
             uint64_t any = 0;
             const uint32_t o2 = (uint32_t)(dx + 2);
-#pragma unroll
+#pragma unroll 5                                                       // (all 25 rows unrolled: 176 registers instead of 126 - one workgroup of four flips per CU instead of two)
             for (int j = 0; j < 25; j++) {
                 const uint32_t* rw = &s_tile[4 * km_row(dy + j % 5 - 2, dz + j / 5 - 2)];
                 const uint64_t lo8 = *reinterpret_cast<const uint64_t*>(rw);
