@@ -79,6 +79,7 @@ class VrgLib:
         self.get_levels = fn('get_levels', [p, p, p, p, p, p, C.c_int64, i64p])
         self.get_stats = fn('get_stats', [p, i64p, C.c_int64])
         self.debug_stamps = fn('debug_stamps', [p, p])
+        self.debug_stamps_wide = fn('debug_stamps_wide', [p, p, C.c_int64])
         self.set_slab = fn('set_slab', [p, C.c_int64, C.c_int64])
         self.comm_unique_id = fn('comm_unique_id', [p])
         self.comm_init = fn('comm_init', [p, C.c_int, C.c_int, p])
@@ -233,10 +234,10 @@ class Session:
         self._check(self.lib.repl_ipc_import(self._h, buf, len(blob)))
 
     def repl_stats(self):
-        a = (C.c_int64 * 8)()
-        self._check(self.lib.repl_stats(self._h, a, 8))
+        a = (C.c_int64 * 9)()
+        self._check(self.lib.repl_stats(self._h, a, 9))
         return {'batches': a[0], 'records': a[1], 'sweeps': a[2], 'verified': a[3], 'last_verified': a[4],
-                'transport': {0: 'none', 1: 'callback', 2: 'rccl', 3: 'ipc'}[a[5]], 'verifiers': a[6], 'slot': a[7]}
+                'transport': {0: 'none', 1: 'callback', 2: 'rccl', 3: 'ipc'}[a[5]], 'verifiers': a[6], 'slot': a[7], 'chunks': a[8]}
 
     def init(self, H=2.25):
         self._check(self.lib.init(self._h, float(H)))

@@ -33,6 +33,7 @@ void be_upload(VrgBackend* b, void* dst, const void* src, size_t bytes);     // 
 void be_download(VrgBackend* b, void* dst, const void* src, size_t bytes);   // dst may be host or device memory
 void be_copy(VrgBackend* b, void* dst, const void* src, size_t bytes);       // device to device, stream-ordered
 void be_sync(VrgBackend* b);
+bool be_band_busy(VrgBackend* b);              // the band stream still has work enqueued (never blocks)
 const char* be_last_error(VrgBackend* b);      // first backend (HIP / RCCL) failure of this handle, or nullptr
 void be_clear_error(VrgBackend* b);
 

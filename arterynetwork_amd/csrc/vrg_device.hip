@@ -138,7 +138,12 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
 #define VRG_STAMP_NOW() wall_clock64()
 #define VRG_STAMP_PUT(c, k, v) do { c.dbg[k] = (v); } while (0)
 #define VRG_STAMP_MAX(c, k) do { atomicMax(&c.dbg[k], (unsigned long long)wall_clock64()); } while (0)   // the last workgroup's exit
+// per-workgroup stamps (thread 0 of every workgroup; word k of the workgroup's VRG_DBG_PER)
+#define VRG_STAMP_WG(c, k) do { if (threadIdx.x == 0 && blockIdx.x < (uint32_t)VRG_DBG_WG && (k) < (uint32_t)VRG_DBG_PER) c.dbg[64 + blockIdx.x * VRG_DBG_PER + (k)] = wall_clock64(); } while (0)
+#define VRG_STAMP_WG_PUT(c, k, v) do { if (threadIdx.x == 0 && blockIdx.x < (uint32_t)VRG_DBG_WG) c.dbg[64 + blockIdx.x * VRG_DBG_PER + (k)] = (v); } while (0)
 #else
+#define VRG_STAMP_WG(c, k) do { } while (0)
+#define VRG_STAMP_WG_PUT(c, k, v) do { (void)(v); } while (0)
 #define VRG_STAMP(c, k) do { } while (0)
 #define VRG_STAMP_NOW() 0ull
 #define VRG_STAMP_PUT(c, k, v) do { (void)(v); } while (0)
@@ -480,13 +485,16 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
     const VrgState& s = s_;
     const bool live = s.iter < s.iterMax;
     if (st0 && live) { VRG_STAMP_PUT(c, 6, c.dbg[0]); VRG_STAMP_PUT(c, 0, t_entry); VRG_STAMP(c, 1); }    // (6: the sweep before this one)
+    if (st0 && c.log_ready && gridDim.x <= band_blocks + EXACT_BLOCKS) vrg_log_publish(c, s.log_nsw, s.log_pos);   // (a grid without deferred workgroups - four-launch trips: the sweep before was closed by its own kernels)
     // What the fused sweep before this trip (k_sweep) left to do - nothing in this kernel reads a label: its label bytes in
     // place (+ the class bits the dense pass reads, the class changes of the sweep before that), its dead slots onto the
     // free list - by workgroups of their own (the last DEFER_WGS of the grid), beside the ones that decide the slots.
     // Whichever of them finishes last (ticket) asks for the sweep's dense pass.  Their first thread files the state this trip
     // works on (vrg_fuse_persist) - before its workgroup's ticket: the sizes the dense pass has to reproduce are filed with it.
     if (defer_wg) {
-        if (dtid == 0) vrg_fuse_persist(c, s, fcl, was_open, nin0, nout0);
+        // (... and publishes how far the change log is complete - replication's per-sweep streaming: the sweep before this trip - its records
+        // written by kernels that have ended, its header by one of those or by this thread just now)
+        if (dtid == 0) { vrg_fuse_persist(c, s, fcl, was_open, nin0, nout0); vrg_log_publish(c, s.log_nsw, s.log_pos); }
         if (!s.apply_pending) return;
         const int k = s.iter;
         if (tid == 0 && dense_on && (int64_t)k - 2 > rseq0) wait_dense_read_for(c, (int64_t)k - 2);   // (the pass of two sweeps ago has read the class copy this sweep rewrites)
@@ -836,13 +844,18 @@ __device__ __forceinline__ uint32_t km_row(int dy, int dz) { return (uint32_t)((
 // of flips - every round trip of a flip's chain then serves four, and a workgroup files what ~25 flips add to the lists at once)
 // (126 registers: two 512-thread workgroups - eight flips - per CU.  What bounds the kernel at 10^4 flips per sweep is not known: neither occupancy, nor the number of
 // workgroups, nor its loads' latency or count moved it - DESIGN.md section 4)
+#if defined(VRG_STAMPS)
+#define KM_STAMP_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))     // (the stamps cost registers: keep the product's two 512-thread workgroups per CU, or the timeline is another kernel's)
+#else
+#define KM_STAMP_OCC
+#endif
 template <int G>
-__global__ void __launch_bounds__(KM_THREADS * G) k_mark_relabel(VrgCtx cg) {
+__global__ void __launch_bounds__(KM_THREADS * G) KM_STAMP_OCC k_mark_relabel(VrgCtx cg) {
     VRG_CHAOS_POINT(3);
     // (the first flip's voxel travels with the state: k_order has written the list, whatever the state says)
     const uint32_t tt = threadIdx.x, g = tt / KM_THREADS, t = tt % KM_THREADS;     // (tt: in the workgroup; t: among the 128 threads of flip g)
     const bool st0 = blockIdx.x == 0 && tt == 0;
-    const unsigned long long t_entry = st0 ? VRG_STAMP_NOW() : 0ull;
+    const unsigned long long t_entry = tt == 0 ? VRG_STAMP_NOW() : 0ull;
     const uint32_t r_first = blockIdx.x * G + g;
     const uint32_t fidx_first = r_first < cg.fcap ? cg.f_idx[r_first] : 0u;
     const int32_t st_done = cg.st->done, st_bail = cg.st->bail;
@@ -850,6 +863,11 @@ __global__ void __launch_bounds__(KM_THREADS * G) k_mark_relabel(VrgCtx cg) {
     asm volatile("" :: "v"(fidx_first), "v"(st_done), "v"(st_bail), "v"(nf));     // one wait for the four
     if (st_done || st_bail) return;
     if (st0) { VRG_STAMP_PUT(cg, 16, t_entry); VRG_STAMP(cg, 17); }
+#if defined(VRG_STAMPS)
+    VRG_STAMP_WG_PUT(cg, 0, t_entry); VRG_STAMP_WG(cg, 1);
+    VRG_STAMP_WG_PUT(cg, 15, ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(63492));   // XCC_ID | HW_ID
+    for (uint32_t k_ = 2; k_ < (uint32_t)VRG_DBG_PER; k_++) if (k_ != 15u) VRG_STAMP_WG_PUT(cg, k_, 0ull);
+#endif
     if (blockIdx.x * G >= nf) return;                                     // (no flip for this workgroup)
     // a voxel that enters the band needs the level index of its intensity: a binary search, i.e. log2(L) DEPENDENT loads -
     // from LDS when the table fits
@@ -937,6 +955,11 @@ __global__ void __launch_bounds__(KM_THREADS * G) k_mark_relabel(VrgCtx cg) {
         if (t < KM_ROWS) { s_tile[4 * t] = row.x; s_tile[4 * t + 1] = row.y; s_tile[4 * t + 2] = row.z; s_tile[4 * t + 3] = row.w; }
         __syncthreads();
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 18); }
+#if defined(VRG_STAMPS)
+        const uint32_t rnd_ = (rb - blockIdx.x * G) / (gridDim.x * G);          // (phases of rounds 0 and 2, every workgroup: words 16.. / 20..)
+        const uint32_t ph_ = rnd_ == 0u ? 16u : rnd_ == 2u ? 20u : 64u;
+        VRG_STAMP_WG(c, ph_);
+#endif
         uint8_t mb = VB_OOB;
         if (p < 125u && have) { const uint32_t o = (uint32_t)(dx + 4); mb = (uint8_t)(s_tile[4 * km_row(dy, dz) + (o >> 2)] >> (8u * (o & 3u))); }
         const bool wanted = vrg_mark_wanted(p, mb);
@@ -978,6 +1001,9 @@ __global__ void __launch_bounds__(KM_THREADS * G) k_mark_relabel(VrgCtx cg) {
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 19); }
         // the first marker's voxel and its event take their places in the workgroup's buffers (one wave-wide count each: LDS atomics)
         if (st0) VRG_STAMP(c, 23);
+#if defined(VRG_STAMPS)
+        VRG_STAMP_WG(c, ph_ + 1u);                                         // (wave 0 knows who is first: the mark atomics are back)
+#endif
         if (first) {
             VrgEvent ev; ev.kind = VE_NONE; ev.pend = 0;
             VrgRanks qr; vrg_ranks_none(qr);
@@ -998,10 +1024,16 @@ __global__ void __launch_bounds__(KM_THREADS * G) k_mark_relabel(VrgCtx cg) {
                 e.ev = ev; e.m = (uint32_t)m; e.r1 = r1; e.rf = rf;
             }
         }
+#if defined(VRG_STAMPS)
+        VRG_STAMP_WG(c, ph_ + 2u);                                         // (wave 0's own stencils are done)
+#endif
         __syncthreads();                                                  // (the buffers are consistent; the tile may be overwritten)
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 20); }
+        VRG_STAMP_WG(c, min(11u, 2u + (rb - blockIdx.x * G) / (gridDim.x * G)));
     }
+    VRG_STAMP_WG(c, 12);
     km_flush();
+    VRG_STAMP_WG(c, 13);
     if (lds_hist)                                                         // (km_flush ends with a barrier: the counts are complete)
         for (uint32_t l = tt; l < 5u * cg.L; l += NT) {
             const uint32_t n = s_hist[l];                                 // (the histograms' changes are signed: the same bits)
@@ -1009,6 +1041,10 @@ __global__ void __launch_bounds__(KM_THREADS * G) k_mark_relabel(VrgCtx cg) {
         }
     if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 21); }
     if (t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP_MAX(c, 22); }
+#if defined(VRG_STAMPS)
+    if (tt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    VRG_STAMP_WG(c, 14);
 }
 
 // Workgroups [0, CLOSE_APPLY): the sweep's label bytes in place (+ class bits, region sizes, the class changes of the
@@ -2252,6 +2288,7 @@ const char* be_last_error(VrgBackend* b) {
 }
 void be_clear_error(VrgBackend* b) { b->err[0] = 0; }
 // (the engine synchronises when a run ends or a trip was handed back: no fused sweep is waiting for its dense pass then)
+bool be_band_busy(VrgBackend* b) { use_device(b); const hipError_t e = hipStreamQuery(b->sa); if (e == hipErrorNotReady) { (void)hipGetLastError(); return true; } return false; }
 void be_sync(VrgBackend* b) { use_device(b); HIP_CHECK(hipStreamSynchronize(b->sa)); HIP_CHECK(hipStreamSynchronize(b->sb)); if (b->sd) HIP_CHECK(hipStreamSynchronize(b->sd)); b->fused_prev = false; b->prev_open = false; }
 
 // A device-resident input is read on the library's own stream: the caller's producer must have finished (vrg.h).

@@ -35,7 +35,14 @@ struct VrgRepl {
     uint8_t* peer_buf[2] = {nullptr, nullptr};          // ... and, on a follower, the leader's two batch buffers, mapped
     bool ctl_mapped = false;
     uint64_t sum_round = 0;
-    long long batches = 0, records = 0, sweeps = 0, verified = 0, last_verified = 0;   // diagnostics
+    bool stream = true;                                 // option "repl_stream": the log travels sweep by sweep (0: once per batch, as up to round 5)
+    bool open = false;                                  // leader: a batch is opened and not yet closed
+    uint32_t sent_sw = 0, sent_rec = 0;                 // leader (rccl / callback): sweeps / records of the open batch that have travelled
+    uint64_t chunk_seq = 0;                             // chunks sent since the handle was created
+    uint8_t* chunk_dev = nullptr;                       // rccl: the chunk struct's device slot
+    int64_t fault = 0;                                  // option "repl_fault" (tests): n > 0 - the leader fails on the host side when it opens its n-th batch; n < 0 - a follower cannot use its |n|-th chunk
+    int32_t failed = 0;                                 // follower: the log could not be used (the run goes on taking chunks, and fails at its end on every rank)
+    long long batches = 0, records = 0, sweeps = 0, verified = 0, last_verified = 0, chunks = 0;   // diagnostics
 };
 
 struct vrg_handle {
@@ -179,10 +186,19 @@ int run_follower(vrg_handle* h, const VrgState& s0, vrg_result* out) {
     const auto t_begin = std::chrono::steady_clock::now();
     const double ms0 = h->ev.ms_total; const long long l0 = h->ev.launches;
     VrgLogBatch last; std::memset(&last, 0, sizeof(last));
+    h->repl.failed = 0;
+    if (check_state_error(h, s0)) h->repl.failed = 13;  // (a follower that is in error already still takes the log - the run is collective - and fails at its end)
     int rc = repl_follow(h, last);
     if (rc) return rc;
     be_sync(h->be);
     be_events_collect(h->be, &h->ev, 1ll << 60);
+    if (h->repl.failed) {                               // this rank could not use the log: the group's closing all-reduce still needs it - every rank then fails
+        const std::string why = h->err;
+        int32_t error = h->repl.failed;
+        rc = repl_finish(h, s0.iter, last.iter, last.n_in, last.n_out, error);
+        h->inited = false;                              // (labels half applied: the handle has to be set up again)
+        return rc ? rc : fail(h, VRG_E_INTERNAL, why.empty() ? "replication: this rank could not use the leader's change log" : why);
+    }
     // the state a leader's run would have left: what the results (trace length, `segmented`, sizes) are read from
     VrgState s = get_state(h);
     s.iter = last.iter; s.done = last.stop_reason; s.ni = last.ni; s.no = last.no; s.ties = last.ties; s.near_ties = last.near_ties;
@@ -249,7 +265,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     c.st = c.stg = c.stb[0]; c.st_other = c.stb[1]; c.lvl_par = -1;
     c.dn = alloc<VrgDense>(h, 16);                   // own allocation: written by the dense kernel only
     c.counters = alloc<uint32_t>(h, 64);
-    c.dbg = alloc<uint64_t>(h, 64);
+    c.dbg = alloc<uint64_t>(h, 64 + VRG_DBG_WG * VRG_DBG_PER);
     c.dn_part = alloc<VrgDense>(h, 16);
     c.dn_ring = alloc<VrgDense>(h, VRG_RING); c.exp_ring = alloc<int64_t>(h, 2 * VRG_RING);
     c.stage_in = alloc<VrgDense>(h, VRG_STAGE); c.stage_out = alloc<VrgDense>(h, VRG_STAGE);
@@ -275,7 +291,7 @@ int API(create)(int64_t nx, int64_t ny, int64_t nz, int device, vrg_handle** out
     be_fill(be, c.dn_ring, 0, VRG_RING * sizeof(VrgDense)); be_fill(be, c.exp_ring, 0, 2 * VRG_RING * sizeof(int64_t));
     be_fill(be, c.stage_in, 0, VRG_STAGE * sizeof(VrgDense)); be_fill(be, c.stage_out, 0, VRG_STAGE * sizeof(VrgDense));
     be_fill(be, c.counters, 0, 64 * sizeof(uint32_t));
-    if (c.dbg) be_fill(be, c.dbg, 0, 64 * sizeof(uint64_t));
+    if (c.dbg) be_fill(be, c.dbg, 0, (64 + VRG_DBG_WG * VRG_DBG_PER) * sizeof(uint64_t));
     *out = h;
     return VRG_OK;
 }
@@ -308,6 +324,8 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "open_sweeps") be_set_tuning(h->be, name, value);
     else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "fuse_max" || n == "memo_above" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads" || n == "dense_pipe") be_set_tuning(h->be, name, value);
     else if (n == "storage16") h->storage16 = value != 0;      // takes effect at the next vrg_init
+    else if (n == "repl_fault") h->repl.fault = value;             // tests: a host-side failure in the middle of a replicated run (every rank must return an error, none may hang)
+    else if (n == "repl_stream") h->repl.stream = value != 0;      // any time between runs: 1 (default) the change log travels sweep by sweep; 0: once per batch of trips
     else if (n == "log_capacity") { if (h->repl.buf[0] || value < 1024 || value > 0x20000000ll) return fail(h, VRG_E_STATE, "log_capacity: 1024 .. 2^29 records, before the first vrg_run of a replicated handle"); h->repl.cap = (uint32_t)value; }
     else return fail(h, VRG_E_ARG, "unknown option " + n);
     return VRG_OK;
@@ -487,17 +505,33 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     VrgBackend* be = h->be;
     if (iterMax < 0 || iterMax + 1 >= (int64_t)c.trace_cap) return fail(h, VRG_E_ARG, "vrg_run: iterMax out of range");
     VrgState s = get_state(h);
-    int rc = check_state_error(h, s);
-    if (rc) return rc;
     VrgRepl& rp = h->repl;
     const bool replicated = rp.nranks > 0;
-    if (replicated) {
+    int rc = VRG_OK;
+    if (replicated) {                                   // (checks that come out the same on every rank: the same calls with the same arguments)
         if (rp.transport == TR_NONE && rp.nranks > 1) return fail(h, VRG_E_STATE, "vrg_run: replicated handle without a transport (vrg_repl_set_callbacks / vrg_repl_use_rccl / vrg_repl_ipc_*)");
         if (h->variant & 1) return fail(h, VRG_E_STATE, "vrg_run: the full-stencil check variant keeps no change log");
         if (!rp.buf[0] && !repl_alloc_buffers(h, rp.cap)) return fail(h, VRG_E_MEM, "vrg_run: change log buffers");
         if (rp.rank > 0) return run_follower(h, s, out);
     }
     int32_t iter0 = s.iter;
+    // A replicated run is collective: once the followers wait for the log, a leader that cannot go on still has to end the run for them -
+    // a final batch with the error set - and to join the closing all-reduce; every rank then returns an error instead of waiting for ever.
+    auto abort_group = [&](int code) -> int {
+        if (!replicated || rp.nranks <= 1 || rp.transport == TR_NONE) return code;
+        const std::string why = h->err;
+        be_sync(be);
+        VrgState sf = get_state(h);
+        if (rp.open || repl_open_batch(h, sf) == VRG_OK) {
+            (void)repl_close_batch(h, sf, true, 13);
+            int32_t e = 13;
+            (void)repl_finish(h, iter0, sf.iter, 0, 0, e);
+        }
+        h->err = why;
+        return code;
+    };
+    rc = check_state_error(h, s);
+    if (rc) return abort_group(rc);
     const uint32_t ties0 = s.ties, near0 = s.near_ties;
     s.done = 0; s.time_up = 0; s.bail = 0; s.iterMax = (int32_t)iterMax; s.maxSegmentSize = maxSegmentSize;
     s.nf = 0; s.npend = 0; s.nmk = 0;                    // counters of a trip that stopped before update()
@@ -505,7 +539,6 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
     double ms0 = h->ev.ms_total; long long l0 = h->ev.launches;
     double cms0 = h->ev.chain_ms_total; long long cl0 = h->ev.chain_launches;
     auto t_begin = std::chrono::steady_clock::now();
-    VrgLogBatch pending; bool have_pending = false;        // (replicated: the batch whose trips are done, not yet sent)
     const bool no_dense = h->dense_off || (replicated && !rp.leader_verifies);      // (a leader that counts nothing enqueues no dense pass at all)
     c.dense_none = (replicated && !rp.leader_verifies) ? 1 : 0;
     const int base_flags = ((h->variant & 1) ? VRG_SWEEP_FULL : 0) | (no_dense ? VRG_SWEEP_NODENSE : 0);
@@ -519,23 +552,28 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
         const bool fuse = h->fuse_mode && !sync;
         int64_t remaining = iterMax - s.iter;
         int nb = sync ? 1 : (int)std::min<int64_t>(h->batch, std::max<int64_t>(remaining, 0) + 1);   // +1: the trip that sets the stop flag
-        if (replicated) { nb = std::min<int>(nb, (int)rp.swcap - 2); rc = repl_open_batch(h, s); if (rc) return rc; }   // (the batch's change log: one buffer)
+        if (replicated) { nb = std::min<int>(nb, (int)rp.swcap - 2); rc = repl_open_batch(h, s); if (rc) return abort_group(rc); }   // (the batch's change log: one buffer)
+        if (replicated && rp.fault > 0 && (int64_t)rp.seq + 1 == rp.fault) return abort_group(fail(h, VRG_E_MEM, "vrg_run: injected host-side failure (option repl_fault)"));
         if (maxSeconds >= 0 && s.iter < iterMax) {   // wall-clock cap (:97): tested after the no-flip test, before update()
             double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - h->t0).count();
             if (el >= maxSeconds) { s.time_up = 1; put_state(h, s); nb = 1; }
         }
         int32_t before = s.iter;
         be_sweep_batch(be, c, base_flags | (sync ? VRG_SWEEP_SYNC : 0) | (fuse ? VRG_SWEEP_FUSED : 0), nb, &h->ev, h->reduce_fn, h->reduce_user);
-        if (have_pending) { rc = repl_send(h, pending); have_pending = false; if (rc) return rc; }     // (the batch before, while this one runs)
+        if (replicated) {                                // while the trips run, what the band chain publishes of their log goes out (rccl / callback; on ipc the followers look themselves)
+            do {
+                rc = repl_pump(h);
+                if (rc < 0) return abort_group(rc);
+                if (rc == 0 && be_band_busy(be)) std::this_thread::sleep_for(std::chrono::microseconds(15));
+            } while (be_band_busy(be));
+        }
         if (sync) h->sync_trips++;
         if (fuse) h->fused_trips += nb;
         s = get_state(h);
         be_events_collect(be, &h->ev, s.iter - before);
-        if (replicated) {                                // the batch's change log: sent once the next batch is enqueued - or now, when there is none
-            rc = repl_close_batch(h, s, s.done || s.error, pending);
-            if (rc) return rc;
-            have_pending = true;
-            if (s.done || s.error || s.bail) { rc = repl_send(h, pending); have_pending = false; if (rc) return rc; }
+        if (replicated) {                                // the batch is complete: its header, and whatever of it has not travelled yet (its last sweep at least)
+            rc = repl_close_batch(h, s, s.done || s.error, 0);
+            if (rc) return abort_group(rc);
         }
         if (s.done || s.error) break;
         if (s.bail) {                                // the trip was handed back untouched: make room / change mode, do it again
@@ -553,11 +591,11 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
                 else h->sync_mode = true;
             }
             else if (s.bail == VBAIL_FUSE) h->fuse_mode = false;
-            else if (s.bail == VBAIL_LOG) { rc = repl_log_full(h, s); if (rc) return rc; }
+            else if (s.bail == VBAIL_LOG) { rc = repl_log_full(h, s); if (rc) return abort_group(rc); }
             else if (s.bail == VBAIL_MARKS) {
-                if (nf * 125u > 0x3fffffffull || !size_marks(h, 2 * nf * 125u, true)) return fail(h, VRG_E_MEM, "vrg_run: marked-voxel arrays");
+                if (nf * 125u > 0x3fffffffull || !size_marks(h, 2 * nf * 125u, true)) return abort_group(fail(h, VRG_E_MEM, "vrg_run: marked-voxel arrays"));
             } else {
-                if (!size_pool(h, 2 * ((uint64_t)s.np + nf * 27u), s.np, s.nfree)) return fail(h, VRG_E_MEM, "vrg_run: band arrays");
+                if (!size_pool(h, 2 * ((uint64_t)s.np + nf * 27u), s.np, s.nfree)) return abort_group(fail(h, VRG_E_MEM, "vrg_run: band arrays"));
             }
             s.bail = 0; s.nf = 0;
             s.ties = s.ties_filed; s.near_ties = s.near_filed;   // the trip's sign tests are made again: count them once
@@ -738,6 +776,13 @@ int API(debug_stamps)(vrg_handle* h, uint64_t* out64) {
     be_download(h->be, out64, h->c.dbg, 64 * sizeof(uint64_t));
     return VRG_OK;
 }
+// ... and the per-workgroup stamps of k_mark_relabel's last launch: VRG_DBG_PER words for each of VRG_DBG_WG workgroups (tools/mark_stamps.py)
+int API(debug_stamps_wide)(vrg_handle* h, uint64_t* out, int64_t cap) {
+    if (!h || !out || !h->c.dbg || cap < (int64_t)(VRG_DBG_WG * VRG_DBG_PER)) return VRG_E_ARG;
+    be_sync(h->be);
+    be_download(h->be, out, h->c.dbg + 64, (size_t)VRG_DBG_WG * VRG_DBG_PER * sizeof(uint64_t));
+    return VRG_OK;
+}
 
 int API(set_slab)(vrg_handle* h, int64_t z0, int64_t z1) {
     if (!h) return VRG_E_ARG;
@@ -757,7 +802,7 @@ int API(comm_init)(vrg_handle* h, int nranks, int rank, const void* id128) {
         be_clear_error(h->be);
         return fail(h, VRG_E_INTERNAL, msg);
     }
-    h->c.world = nranks;
+    if (!h->repl.nranks) h->c.world = nranks;         // (a rank of a leader / follower group counts whole volumes: it is not a Z-slab rank, whatever carries its log)
     return VRG_OK;
 }
 
@@ -778,6 +823,7 @@ int API(repl_set_callbacks)(vrg_handle* h, vrg_bcast_fn bcast, vrg_allsum_fn all
     if (!h || !bcast || !allsum) return fail(h, VRG_E_ARG, "repl_set_callbacks: both callbacks are needed");
     if (!h->repl.nranks) return fail(h, VRG_E_STATE, "repl_set_callbacks: vrg_repl_init first");
     h->repl.bcast = bcast; h->repl.allsum = allsum; h->repl.user = user; h->repl.transport = TR_CALLBACK;
+    h->c.world = 1;                                   // (a vrg_comm_init before this call may have marked the handle as a Z-slab rank)
     return VRG_OK;
 }
 
@@ -803,20 +849,14 @@ int API(repl_ipc_export)(vrg_handle* h, void* blob, int64_t cap, int64_t* bytes)
     VrgRepl& r = h->repl;
     if (!r.nranks || r.rank != 0) return fail(h, VRG_E_STATE, "repl_ipc_export: the leader (rank 0) of a replicated handle exports");
     if (!r.buf[0] && !repl_alloc_buffers(h, r.cap)) return fail(h, VRG_E_MEM, "repl_ipc_export: change log buffers");
-    if (!r.ctl) {
-        const size_t cb = 8 * IPC_WORDS + (size_t)r.nranks * IPC_SUMCAP * 8;
-        r.ctl = alloc<uint8_t>(h, cb);
-        if (!r.ctl) return fail(h, VRG_E_MEM, "repl_ipc_export: control block");
-        be_fill(h->be, r.ctl, 0, cb);
-        be_sync(h->be);
-    }
+    if (!repl_alloc_ctl(h)) return fail(h, VRG_E_MEM, "repl_ipc_export: control block");
     uint8_t* o = (uint8_t*)blob;
     std::memset(o, 0, 256);
     if (be_ipc_export(h->be, r.ctl, o) || be_ipc_export(h->be, r.buf[0], o + 64) || be_ipc_export(h->be, r.buf[1], o + 128))
         return fail(h, VRG_E_INTERNAL, "repl_ipc_export: hipIpcGetMemHandle failed");
     std::memcpy(o + 192, &r.cap, 4); std::memcpy(o + 196, &r.swcap, 4);
     *bytes = 256;
-    r.transport = TR_IPC;
+    r.transport = TR_IPC; h->c.world = 1;
     return VRG_OK;
 }
 
@@ -833,7 +873,7 @@ int API(repl_ipc_import)(vrg_handle* h, const void* blob, int64_t bytes) {
     if (!r.ctl || !r.peer_buf[0] || !r.peer_buf[1]) return fail(h, VRG_E_INTERNAL, "repl_ipc_import: hipIpcOpenMemHandle failed");
     r.ctl_mapped = true;
     if (cap != r.cap) { if (r.buf[0]) return fail(h, VRG_E_STATE, "repl_ipc_import: staging buffers already sized"); r.cap = cap; }
-    r.transport = TR_IPC;
+    r.transport = TR_IPC; h->c.world = 1;
     return VRG_OK;
 }
 
@@ -842,6 +882,7 @@ int API(repl_stats)(vrg_handle* h, int64_t* out, int64_t cap) {
     const VrgRepl& r = h->repl;
     out[0] = r.batches; out[1] = r.records; out[2] = r.sweeps; out[3] = r.verified; out[4] = r.last_verified; out[5] = r.transport;
     out[6] = r.nranks ? repl_verifiers(r) : 0; out[7] = r.nranks ? repl_my_slot(r) : 0;
+    if (cap >= 9) out[8] = r.chunks;
     return VRG_OK;
 }
 

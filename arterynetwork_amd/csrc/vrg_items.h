@@ -956,8 +956,24 @@ VRG_HD void vrg_log_sweep(const VrgCtx& c, int64_t k, uint32_t base, uint32_t ns
     VrgLogSweep w;
     w.nflip = t.nflip; w.nseg = n_in; w.n_in = n_in; w.n_out = n_out; w.ni = t.ni; w.no = t.no; w.ties = t.ties; w.near_ties = t.near_ties;
     w.sweep = (uint32_t)k; w.nrec = nrec; w.rec0 = base - c.log_pos0; w.pad = 0;
-    c.log_sw[q] = w;
+    // (written through: a sweep's header may be published - vrg_log_publish - by the very kernel that files it, and is then read by another
+    // device, or a copy engine, while this kernel still runs)
+    static_assert(sizeof(VrgLogSweep) == 10 * sizeof(uint64_t), "sweep header: ten 64-bit words");
+    uint64_t words[10]; __builtin_memcpy(words, &w, sizeof(w));
+    uint64_t* dst = reinterpret_cast<uint64_t*>(&c.log_sw[q]);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 10; i++) vrg_store_u64(dst + i, words[i]);
     c.stg->log_pos = base + nrec; c.stg->log_nsw = nsw + 1u;
+}
+// The batch's log is complete up to `nsw` sweep headers / `pos` records (VrgState::log_nsw / log_pos of a CLOSED state): by ONE thread, when
+// every record up to there has been written by a kernel that has ended (a kernel's plain stores reach memory when it ends) and every header
+// by such a kernel or by this very thread (written through; drained here).  k_band's filing thread does it - for the sweep before its trip.
+VRG_HD void vrg_log_publish(const VrgCtx& c, uint32_t nsw, uint32_t pos) {
+    if (!c.log_ready || !c.log_rec) return;
+    vrg_drain();
+    vrg_store_u64(c.log_ready, vrg_log_progress(c.log_seq, nsw - c.log_nsw0, pos - c.log_pos0));
 }
 // (a leader that enqueues no dense pass at all: the pass counters follow the sweeps, so that the handle stays consistent - which class copy
 // is current, what a later pass would wait for - and the sweep's trace record says that nobody here summed its intensities)

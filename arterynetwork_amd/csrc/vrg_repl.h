@@ -7,25 +7,36 @@
 // inside that chain, on every GPU, every sweep.  What does cost O(V) per sweep is the reference's dense recount (:113-116, :249-250).
 // So the work is cut by ROLE and the recount by TIME:
 //   rank 0, the LEADER, runs the band chain exactly as one GPU does and logs what every sweep did to the labels: one 16-byte
-//       record per place of the sweep's marked list (~100 KB per sweep), one header with the sweep's trace record and the region
-//       sizes it produced;
+//       record per label byte that changes, one header with the sweep's trace record and the region sizes it produced;
 //   every other rank, a FOLLOWER, holds the intensities, the labels and the class bits, applies the log sweep by sweep (a record
 //       whose `old` byte is not what the follower holds is an error) and COUNTS the sweeps assigned to it - round robin over the
 //       verifiers - with the very dense pass one GPU runs (same kernel, same unit list, same workgroups: the same sums bit for bit),
 //       against the sizes in the sweep's header.  With N - 1 verifiers each counts every (N-1)-th sweep over the WHOLE volume at the
 //       full-volume pass's efficiency (0.77 of peak at 880x880x640 against 0.57 for an 80-plane slab + a gate per sweep).
 //   Small groups (N <= 4) let the leader count its share too (leader_verifies): its chain then runs beside a pass, as on one GPU.
-// The log moves once per batch of trips (option "batch"), off the decisions' path, through one of three transports:
-//   callback  host buffers through a caller-supplied broadcast (tests: torch.distributed / gloo; any other fabric)
-//   rccl      ncclBroadcast of the batch buffer on the leader's transport stream (vrg_comm_init's communicator)
-//   ipc       the followers map the leader's batch buffers (hipIpc) and copy them out themselves - device to device, over xGMI
-//             between GPUs; a `ready` / `ack` pair of counters in the leader's control block orders it
-// At the end of a run every rank holds the same labels, `segmented` order and trace; the intensity sums each verifier filed are
-// exchanged with one small all-reduce.
+//
+// THE LOG TRAVELS SWEEP BY SWEEP (round 6; it used to move once per batch of trips, so a follower started a batch late and the run ended
+// a batch late).  The trips are still enqueued in batches (option "batch") into one of two buffers, but the leader's band chain PUBLISHES
+// how far the batch's log is complete in a 64-bit progress word (VrgCtx::log_ready, vrg_log_publish): k_band of trip k+1 does it for sweep k
+// - its records were written by kernels that have ended, its header is written through and drained.  Only the last sweep of a batch waits
+// for the host, which closes the batch (VrgLogBatch) when its trips are done.  Three transports:
+//   ipc       the followers map the leader's batch buffers and control block (hipIpc) and poll the progress word themselves; what is new
+//             they copy out - headers to the host, records device to device, over xGMI between GPUs; an `ack` word per follower tells
+//             the leader when a buffer may be written again
+//   rccl      the leader's host polls its own progress word while the batch runs and broadcasts what is new as a CHUNK (VrgLogChunk, the
+//             sweep headers, the records: ncclBroadcast on the transport stream, straight out of the batch buffer)
+//   callback  the same chunks through a caller-supplied broadcast of host buffers (tests: torch.distributed / gloo; any other fabric)
+// A follower's lag is one poll + one copy, not one batch.  At the end of a run every rank holds the same labels, `segmented` order and
+// trace; the intensity sums each verifier filed are exchanged with one small all-reduce.
+//
+// A replicated vrg_run is COLLECTIVE, and so are its failures: a leader that fails on the host side (allocation, transport, a state in
+// error) still closes and publishes a final batch with the error set and joins the closing all-reduce; a follower that meets a log it
+// cannot use records its error, keeps taking chunks until the final one, and joins it too - every rank returns, none waits for ever.
 #pragma once
 
 enum { TR_NONE = 0, TR_CALLBACK = 1, TR_RCCL = 2, TR_IPC = 3 };
-enum { IPC_READY = 0, IPC_ACK = 8, IPC_SUM_READY = 8 + 64, IPC_SUM_IN = 8 + 64 + 8, IPC_WORDS = 8 + 64 + 8 + 64 };   // 64-bit words of the control block
+// 64-bit words of the control block (leader's device memory): batches closed; the open batch's progress word; per-rank acks; the all-reduce area's flags
+enum { IPC_READY = 0, IPC_SW = 1, IPC_ACK = 8, IPC_SUM_READY = 8 + 64, IPC_SUM_IN = 8 + 64 + 8, IPC_WORDS = 8 + 64 + 8 + 64 };
 constexpr size_t IPC_SUMCAP = 3 * 65536 + 16;         // doubles a rank contributes to an all-reduce (3 per sweep of the run + status)
 
 static size_t repl_hb_bytes(uint32_t swcap) { return (sizeof(VrgLogBatch) + (size_t)swcap * sizeof(VrgLogSweep) + 255) / 256 * 256; }
@@ -34,6 +45,16 @@ static VrgLogRec* repl_rec_of(const VrgRepl& r, uint8_t* buf) { return reinterpr
 static int repl_verifiers(const VrgRepl& r) { return r.leader_verifies ? r.nranks : r.nranks - 1; }
 static int repl_my_slot(const VrgRepl& r) { return r.leader_verifies ? r.rank : r.rank - 1; }     // (-1: a leader that counts nothing)
 
+static bool repl_alloc_ctl(vrg_handle* h) {            // the leader's control block (every transport: the progress word lives there)
+    VrgRepl& r = h->repl;
+    if (r.ctl) return true;
+    const size_t cb = 8 * IPC_WORDS + (size_t)std::max(1, r.nranks) * IPC_SUMCAP * 8;
+    r.ctl = alloc<uint8_t>(h, cb);
+    if (!r.ctl) return false;
+    be_fill(h->be, r.ctl, 0, cb);
+    be_sync(h->be);
+    return true;
+}
 static bool repl_alloc_buffers(vrg_handle* h, uint32_t cap) {
     VrgRepl& r = h->repl;
     const size_t bytes = repl_hb_bytes(r.swcap) + (size_t)cap * sizeof(VrgLogRec);
@@ -44,7 +65,9 @@ static bool repl_alloc_buffers(vrg_handle* h, uint32_t cap) {
         if (r.buf[j]) release(h, r.buf[j]);
         r.buf[j] = p;
     }
+    if (!r.chunk_dev) { r.chunk_dev = alloc<uint8_t>(h, 256); if (!r.chunk_dev) return false; }
     r.cap = cap; r.buf_bytes = bytes;
+    if (r.rank == 0 && !repl_alloc_ctl(h)) return false;
     return true;
 }
 
@@ -70,6 +93,12 @@ static bool repl_poll(vrg_handle* h, const uint8_t* base, size_t word, uint64_t 
         if (spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }
+// the open batch's progress as the progress word `w` states it for batch n: false when the word still belongs to another batch
+static bool repl_progress_of(uint64_t w, uint64_t n, uint32_t& nsw, uint32_t& nrec) {
+    if ((w >> 42) != (n & ((1ull << VRG_LOG_SEQ_BITS) - 1ull))) return false;
+    nsw = (uint32_t)(w >> 32) & ((1u << VRG_LOG_SW_BITS) - 1u); nrec = (uint32_t)w;
+    return true;
+}
 
 // ---- the leader's side -------------------------------------------------------------------------------------------------------
 // before a batch of trips is enqueued: its buffer is free again, the launches' context points at it
@@ -77,52 +106,79 @@ static int repl_open_batch(vrg_handle* h, const VrgState& s) {
     VrgRepl& r = h->repl;
     const uint64_t n = r.seq + 1;                      // the batch about to be written
     uint8_t* buf = r.buf[(n - 1) & 1];
-    if (r.transport == TR_RCCL) be_repl_wait(h->be);   // (batch n - 2's broadcast has read it)
+    if (r.transport == TR_RCCL) be_repl_wait(h->be);   // (batch n - 2's broadcasts have read it)
     if (r.transport == TR_IPC && n > 2)
         for (int q = 1; q < r.nranks; q++)
             if (!repl_poll(h, r.ctl, IPC_ACK + q, n - 2, 120.0)) return fail(h, VRG_E_INTERNAL, "replication: rank " + std::to_string(q) + " did not take batch " + std::to_string(n - 2) + " of the change log");
     VrgCtx& c = h->c;
     c.log_rec = repl_rec_of(r, buf); c.log_sw = repl_sw_of(buf); c.log_cap = r.cap; c.log_swcap = r.swcap;
     c.log_pos0 = s.log_pos; c.log_nsw0 = s.log_nsw;
+    c.log_ready = (r.stream && r.ctl) ? reinterpret_cast<uint64_t*>(r.ctl) + IPC_SW : nullptr;
+    c.log_seq = (uint32_t)(n & ((1ull << VRG_LOG_SEQ_BITS) - 1ull));
+    r.sent_sw = 0; r.sent_rec = 0; r.open = true;
     return VRG_OK;
 }
-// after the batch (the band stream is idle: the engine has read the state): its header
-static int repl_close_batch(vrg_handle* h, const VrgState& s, bool final, VrgLogBatch& hb) {
+// one chunk on its way (rccl / callback): the struct, its sweep headers, its records - everything on the transport stream
+static int repl_send_chunk(vrg_handle* h, uint64_t n, uint32_t nsw, uint32_t nrec, const VrgLogBatch* hb) {
+    VrgRepl& r = h->repl;
+    uint8_t* buf = r.buf[(n - 1) & 1];
+    VrgLogChunk ch; std::memset(&ch, 0, sizeof(ch));
+    ch.seq = ++r.chunk_seq; ch.batch = n; ch.sw0 = r.sent_sw; ch.nsw = nsw - r.sent_sw; ch.rec0 = r.sent_rec; ch.nrec = nrec - r.sent_rec; ch.cap = r.cap;
+    if (hb) { ch.closed = 1; ch.hb = *hb; }
+    const size_t so = sizeof(VrgLogBatch) + (size_t)ch.sw0 * sizeof(VrgLogSweep), sb = (size_t)ch.nsw * sizeof(VrgLogSweep);
+    const size_t ro = repl_hb_bytes(r.swcap) + (size_t)ch.rec0 * sizeof(VrgLogRec), rb = (size_t)ch.nrec * sizeof(VrgLogRec);
+    if (r.transport == TR_CALLBACK) {
+        uint8_t* hp = repl_host(h, std::max(sizeof(ch), std::max(sb, rb)));
+        if (!hp) return fail(h, VRG_E_MEM, "replication: host buffer");
+        std::memcpy(hp, &ch, sizeof(ch)); r.bcast(hp, (int64_t)sizeof(ch), 0, r.user);
+        if (sb) { be_repl_copy(h->be, hp, buf + so, sb); r.bcast(hp, (int64_t)sb, 0, r.user); }
+        if (rb) { be_repl_copy(h->be, hp, buf + ro, rb); r.bcast(hp, (int64_t)rb, 0, r.user); }
+    } else if (r.transport == TR_RCCL) {
+        be_repl_copy(h->be, r.chunk_dev, &ch, sizeof(ch));
+        if (be_repl_bcast(h->be, r.chunk_dev, sizeof(ch), 0) || (sb && be_repl_bcast(h->be, buf + so, sb, 0)) || (rb && be_repl_bcast(h->be, buf + ro, rb, 0)))
+            return fail(h, VRG_E_INTERNAL, "replication: RCCL broadcast failed");
+        be_repl_wait(h->be);                           // (the one chunk struct slot is written again by the next chunk)
+    }
+    r.sent_sw = nsw; r.sent_rec = nrec; r.chunks++;
+    return VRG_OK;
+}
+// while the batch's trips run (rccl / callback; on ipc the followers look for themselves): what the band chain has published since the
+// last look goes out.  Returns 1 when something was sent, 0 when not, < 0 on failure.
+static int repl_pump(vrg_handle* h) {
+    VrgRepl& r = h->repl;
+    if (!r.stream || !r.open || (r.transport != TR_RCCL && r.transport != TR_CALLBACK)) return 0;
+    uint64_t w = 0;
+    be_repl_copy(h->be, &w, r.ctl + 8 * IPC_SW, 8);
+    uint32_t nsw = 0, nrec = 0;
+    if (!repl_progress_of(w, r.seq + 1, nsw, nrec) || nsw <= r.sent_sw) return 0;
+    if (nsw > r.swcap || nrec > r.cap || nrec < r.sent_rec) return fail(h, VRG_E_INTERNAL, "replication: the change log's progress word is out of range");
+    const int rc = repl_send_chunk(h, r.seq + 1, nsw, nrec, nullptr);
+    return rc ? rc : 1;
+}
+// after the batch (the band stream is idle: the engine has read the state): its header, and off goes what has not travelled yet
+static int repl_close_batch(vrg_handle* h, const VrgState& s, bool final, int32_t error) {
     VrgRepl& r = h->repl;
     const VrgCtx& c = h->c;
-    std::memset(&hb, 0, sizeof(hb));
+    VrgLogBatch hb; std::memset(&hb, 0, sizeof(hb));
     hb.seq = ++r.seq; hb.nsw = s.log_nsw - c.log_nsw0; hb.nrec = s.log_pos - c.log_pos0;
-    hb.final = final ? 1 : 0; hb.stop_reason = s.done; hb.iter = s.iter; hb.error = s.error;
+    hb.final = final ? 1 : 0; hb.stop_reason = s.done; hb.iter = s.iter; hb.error = error ? error : s.error;
     int64_t sizes[2]; be_download(h->be, sizes, c.inc, sizeof(sizes));
     hb.n_in = sizes[0]; hb.n_out = sizes[1]; hb.ni = s.ni; hb.no = s.no; hb.ties = s.ties; hb.near_ties = s.near_ties;
-    if (hb.nsw > r.swcap || hb.nrec > r.cap) return fail(h, VRG_E_INTERNAL, "replication: the batch overran its change log");
+    r.open = false;
+    const bool overrun = hb.nsw > r.swcap || hb.nrec > r.cap || hb.nsw < r.sent_sw || hb.nrec < r.sent_rec;
+    if (overrun) {                                     // (the followers still have to be told: the run ends here, in error)
+        hb.nsw = r.sent_sw; hb.nrec = r.sent_rec; hb.final = 1; if (!hb.error) hb.error = 13;
+    }
     r.batches++; r.records += hb.nrec; r.sweeps += hb.nsw;
-    return VRG_OK;
-}
-// ... and off it goes - while the NEXT batch's trips already run: everything here uses the transport stream (the band stream is busy)
-static int repl_send(vrg_handle* h, const VrgLogBatch& hb) {
-    VrgRepl& r = h->repl;
     const uint64_t n = hb.seq;
     uint8_t* buf = r.buf[(n - 1) & 1];
-    be_repl_copy(h->be, buf, &hb, sizeof(hb));
-    const size_t hbb = repl_hb_bytes(r.swcap), rb = (size_t)hb.nrec * sizeof(VrgLogRec);
-    switch (r.transport) {
-    case TR_CALLBACK: {
-        uint8_t* hp = repl_host(h, hbb + rb);
-        if (!hp) return fail(h, VRG_E_MEM, "replication: host buffer");
-        be_repl_copy(h->be, hp, buf, hbb);
-        r.bcast(hp, (int64_t)hbb, 0, r.user);
-        if (rb) { be_repl_copy(h->be, hp + hbb, buf + hbb, rb); r.bcast(hp + hbb, (int64_t)rb, 0, r.user); }
-        break; }
-    case TR_RCCL:
-        if (be_repl_bcast(h->be, buf, hbb, 0) || (rb && be_repl_bcast(h->be, buf + hbb, rb, 0))) return fail(h, VRG_E_INTERNAL, "replication: RCCL broadcast failed");
-        break;
-    case TR_IPC:
+    int rc = VRG_OK;
+    if (r.transport == TR_IPC) {
+        be_repl_copy(h->be, buf, &hb, sizeof(hb));
         be_repl_copy(h->be, r.ctl + 8 * IPC_READY, &n, 8);
-        break;
-    default: break;
-    }
-    return VRG_OK;
+    } else rc = repl_send_chunk(h, n, hb.nsw, hb.nrec, &hb);
+    if (!rc && overrun) rc = fail(h, VRG_E_INTERNAL, "replication: the batch overran its change log");
+    return rc;
 }
 // the trip was handed back because its records would not fit the batch's log: an empty log that is still too small grows
 static int repl_log_full(vrg_handle* h, const VrgState& s) {
@@ -135,84 +191,114 @@ static int repl_log_full(vrg_handle* h, const VrgState& s) {
     return VRG_OK;
 }
 
-// ---- a follower's run: apply every batch, count the sweeps that are this rank's --------------------------------------------------
-static int repl_receive(vrg_handle* h, VrgLogBatch& hb, std::vector<uint8_t>& hblock, uint8_t*& staging) {
+// ---- a follower's run: apply every sweep as it arrives, count the sweeps that are this rank's -------------------------------------
+// the next chunk of batch n: its sweep headers into hdrs[sw_done ..] (host), its records into the staging buffer at their places
+static int repl_next_chunk(vrg_handle* h, uint64_t n, uint32_t sw_done, uint32_t rec_done, uint8_t*& staging, std::vector<VrgLogSweep>& hdrs, VrgLogChunk& ch) {
     VrgRepl& r = h->repl;
-    const uint64_t n = r.seq + 1;
     const size_t hbb = repl_hb_bytes(r.swcap);
-    staging = r.buf[(n - 1) & 1];
-    be_follow_wait(h->be, (int)((n - 1) & 1));         // (the kernels that read this staging buffer two batches ago are done)
-    hblock.resize(hbb);
-    auto grow_for = [&](uint32_t nrec) -> bool {        // a batch larger than the staging buffers: both grow (idle first: kernels may still read them)
-        if (nrec <= r.cap) return true;
+    std::memset(&ch, 0, sizeof(ch));
+    auto grow_for = [&](uint32_t cap) -> bool {         // the leader's buffers have grown: so do both staging buffers (idle first: kernels may still read them)
+        if (cap <= r.cap) return true;
+        if (sw_done || rec_done) return false;          // (only ever between two batches)
         be_sync(h->be);
-        if (!repl_alloc_buffers(h, (uint32_t)pow2_at_least(nrec))) return false;
+        if (!repl_alloc_buffers(h, cap)) return false;
         staging = r.buf[(n - 1) & 1];
         return true;
     };
-    switch (r.transport) {
-    case TR_CALLBACK: {
-        r.bcast(hblock.data(), (int64_t)hbb, 0, r.user);
-        std::memcpy(&hb, hblock.data(), sizeof(hb));
-        if (!grow_for(hb.nrec)) return fail(h, VRG_E_MEM, "replication: staging buffers");
-        const size_t rb = (size_t)hb.nrec * sizeof(VrgLogRec);
-        if (rb) {
-            uint8_t* hp = repl_host(h, rb);
-            if (!hp) return fail(h, VRG_E_MEM, "replication: host buffer");
-            r.bcast(hp, (int64_t)rb, 0, r.user); be_repl_copy(h->be, staging + hbb, hp, rb);
-        }
-        break; }
-    case TR_RCCL: {
-        if (be_repl_bcast(h->be, staging, hbb, 0)) return fail(h, VRG_E_INTERNAL, "replication: RCCL broadcast failed");
-        be_repl_wait(h->be);
-        be_repl_copy(h->be, hblock.data(), staging, hbb);
-        std::memcpy(&hb, hblock.data(), sizeof(hb));
-        uint8_t* first = staging;
-        if (!grow_for(hb.nrec)) return fail(h, VRG_E_MEM, "replication: staging buffers");
-        (void)first;
-        const size_t rb = (size_t)hb.nrec * sizeof(VrgLogRec);
-        if (rb) { if (be_repl_bcast(h->be, staging + hbb, rb, 0)) return fail(h, VRG_E_INTERNAL, "replication: RCCL broadcast failed"); be_repl_wait(h->be); }
-        break; }
-    case TR_IPC: {
-        if (!repl_poll(h, r.ctl, IPC_READY, n, 300.0)) return fail(h, VRG_E_INTERNAL, "replication: the leader did not publish batch " + std::to_string(n) + " of the change log");
+    if (r.transport == TR_IPC) {
         const uint8_t* src = r.peer_buf[(n - 1) & 1];
-        be_repl_copy(h->be, hblock.data(), src, hbb);
-        std::memcpy(&hb, hblock.data(), sizeof(hb));
-        if (hb.nrec > r.cap) return fail(h, VRG_E_CAPACITY, "replication: the leader's batch does not fit this rank's staging buffer");
-        const size_t rb = (size_t)hb.nrec * sizeof(VrgLogRec);
-        if (rb) be_repl_copy(h->be, staging + hbb, src + hbb, rb);
-        be_repl_copy(h->be, r.ctl + 8 * (IPC_ACK + r.rank), &n, 8);     // (copied out: the leader may write that buffer again)
-        break; }
-    default: return fail(h, VRG_E_STATE, "replication: no transport set");
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; spins++) {
+            uint64_t w[2] = {0, 0};
+            be_repl_copy(h->be, w, r.ctl + 8 * IPC_READY, 16);
+            uint32_t nsw = 0, nrec = 0;
+            if (w[0] >= n) {                            // the batch is closed: its header says what there is
+                be_repl_copy(h->be, &ch.hb, src, sizeof(VrgLogBatch));
+                ch.closed = 1; nsw = ch.hb.nsw; nrec = ch.hb.nrec;
+            } else if (!r.stream || !repl_progress_of(w[1], n, nsw, nrec)) { nsw = sw_done; nrec = rec_done; }
+            if (nsw > r.swcap || nrec > r.cap || nsw < sw_done || nrec < rec_done) return fail(h, VRG_E_INTERNAL, "replication: the leader's change log is out of range");
+            if (ch.closed || nsw > sw_done) { ch.batch = n; ch.sw0 = sw_done; ch.nsw = nsw - sw_done; ch.rec0 = rec_done; ch.nrec = nrec - rec_done; ch.cap = r.cap; break; }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 300.0) return fail(h, VRG_E_INTERNAL, "replication: the leader did not publish batch " + std::to_string(n) + " of the change log");
+            if (spins > 256) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        if (ch.nsw) be_repl_copy(h->be, hdrs.data() + ch.sw0, src + sizeof(VrgLogBatch) + (size_t)ch.sw0 * sizeof(VrgLogSweep), (size_t)ch.nsw * sizeof(VrgLogSweep));
+        if (ch.nrec) be_repl_copy(h->be, staging + hbb + (size_t)ch.rec0 * sizeof(VrgLogRec), src + hbb + (size_t)ch.rec0 * sizeof(VrgLogRec), (size_t)ch.nrec * sizeof(VrgLogRec));
+        if (ch.closed) be_repl_copy(h->be, r.ctl + 8 * (IPC_ACK + r.rank), &n, 8);     // (copied out: the leader may write that buffer again)
+        r.chunks++;
+        return VRG_OK;
     }
-    if (hb.seq != n) return fail(h, VRG_E_INTERNAL, "replication: batch " + std::to_string(hb.seq) + " arrived where batch " + std::to_string(n) + " was due");
-    r.seq = n;
-    r.batches++; r.records += hb.nrec; r.sweeps += hb.nsw;
+    if (r.transport != TR_CALLBACK && r.transport != TR_RCCL) return fail(h, VRG_E_STATE, "replication: no transport set");
+    if (r.transport == TR_CALLBACK) r.bcast(&ch, (int64_t)sizeof(ch), 0, r.user);
+    else {
+        if (be_repl_bcast(h->be, r.chunk_dev, sizeof(ch), 0)) return fail(h, VRG_E_INTERNAL, "replication: RCCL broadcast failed");
+        be_repl_wait(h->be);
+        be_repl_copy(h->be, &ch, r.chunk_dev, sizeof(ch));
+    }
+    // (sizes first: whatever else is wrong with the chunk, the broadcasts that follow it have to be matched)
+    const size_t sb = (size_t)ch.nsw * sizeof(VrgLogSweep), rb = (size_t)ch.nrec * sizeof(VrgLogRec);
+    bool ok = ch.batch == n && ch.sw0 == sw_done && ch.rec0 == rec_done && (uint64_t)ch.sw0 + ch.nsw <= r.swcap && grow_for(ch.cap) && (uint64_t)ch.rec0 + ch.nrec <= r.cap;
+    std::vector<uint8_t> sink;                          // (a chunk this rank cannot place is still received)
+    if (r.transport == TR_CALLBACK) {
+        if (sb) { if (ok) r.bcast(hdrs.data() + ch.sw0, (int64_t)sb, 0, r.user); else { sink.resize(sb); r.bcast(sink.data(), (int64_t)sb, 0, r.user); } }
+        if (rb) {
+            uint8_t* hp = ok ? repl_host(h, rb) : nullptr;
+            if (!hp) { ok = false; sink.resize(rb); hp = sink.data(); }
+            r.bcast(hp, (int64_t)rb, 0, r.user);
+            if (ok) be_repl_copy(h->be, staging + hbb + (size_t)ch.rec0 * sizeof(VrgLogRec), hp, rb);
+        }
+    } else {
+        uint8_t* scratch = nullptr;
+        if (!ok && (sb || rb)) { scratch = alloc<uint8_t>(h, std::max(sb, rb)); if (!scratch) return fail(h, VRG_E_MEM, "replication: receive buffer"); }
+        uint8_t* sdst = ok ? staging + sizeof(VrgLogBatch) + (size_t)ch.sw0 * sizeof(VrgLogSweep) : scratch;
+        uint8_t* rdst = ok ? staging + hbb + (size_t)ch.rec0 * sizeof(VrgLogRec) : scratch;
+        if ((sb && be_repl_bcast(h->be, sdst, sb, 0)) || (rb && be_repl_bcast(h->be, rdst, rb, 0))) return fail(h, VRG_E_INTERNAL, "replication: RCCL broadcast failed");
+        be_repl_wait(h->be);
+        if (ok && sb) be_repl_copy(h->be, hdrs.data() + ch.sw0, sdst, sb);
+        if (scratch) release(h, scratch);
+    }
+    r.chunks++;
+    if (!ok) { h->err = "replication: chunk " + std::to_string(ch.seq) + " of the change log does not continue batch " + std::to_string(n) + " where this rank stands (or its staging buffers could not grow)"; return 1; }
     return VRG_OK;
 }
 
 static int repl_follow(vrg_handle* h, VrgLogBatch& last) {
     VrgRepl& r = h->repl;
     const VrgCtx& c = h->c;
-    std::vector<uint8_t> hblock;
+    std::vector<VrgLogSweep> hdrs(r.swcap + 1);
     const int nver = repl_verifiers(r), me = repl_my_slot(r);
-    for (;;) {
-        VrgLogBatch hb; uint8_t* staging = nullptr;
-        int rc = repl_receive(h, hb, hblock, staging);
-        if (rc) return rc;
-        const VrgLogSweep* sw = reinterpret_cast<const VrgLogSweep*>(hblock.data() + sizeof(VrgLogBatch));
-        VrgLogRec* recs = repl_rec_of(r, staging);
-        // the sweeps up to the next one this rank counts go in one step (the sweeps between two counts: N - 2 of them)
-        uint32_t first = 0;
-        for (uint32_t i = 0; i < hb.nsw; i++) {
-            if ((uint64_t)sw[i].rec0 + sw[i].nrec > hb.nrec) return fail(h, VRG_E_INTERNAL, "replication: a sweep's records lie outside its batch");
-            const bool mine = !vrg_dense_skipped((int64_t)sw[i].sweep, h->verify_every, nver, me);
-            if (!mine && i + 1 < hb.nsw) continue;
-            be_follow_apply(h->be, c, recs, sw + first, (int)(i + 1 - first), mine ? 1 : 0);
-            if (mine) { be_follow_count(h->be, c, &h->ev); r.verified++; r.last_verified = sw[i].sweep; }
-            first = i + 1;
+    for (;;) {                                          // batches
+        const uint64_t n = r.seq + 1;
+        uint8_t* staging = r.buf[(n - 1) & 1];
+        be_follow_wait(h->be, (int)((n - 1) & 1));      // (the kernels that read this staging buffer two batches ago are done)
+        uint32_t sw_done = 0, rec_done = 0, first = 0;
+        VrgLogBatch hb; std::memset(&hb, 0, sizeof(hb));
+        for (;;) {                                      // chunks of the batch
+            VrgLogChunk ch;
+            const int rc = repl_next_chunk(h, n, sw_done, rec_done, staging, hdrs, ch);
+            if (rc < 0) return rc;                      // (the transport itself failed: nothing more can arrive)
+            if (r.fault < 0 && r.chunks == -r.fault && !r.failed) { r.failed = 13; h->err = "replication: injected failure of this rank (option repl_fault)"; }
+            if (rc > 0 && !r.failed) r.failed = 13;     // a log this rank cannot use: it keeps taking chunks - the run is collective - and reports at the end
+            if (!r.failed) {
+                VrgLogRec* recs = repl_rec_of(r, staging);
+                // the sweeps up to the next one this rank counts go in one step (the sweeps between two counts: N - 2 of them)
+                for (uint32_t i = sw_done; i < sw_done + ch.nsw; i++) {
+                    if ((uint64_t)hdrs[i].rec0 + hdrs[i].nrec > (uint64_t)rec_done + ch.nrec) { r.failed = 13; h->err = "replication: a sweep's records lie outside what has arrived"; break; }
+                    if (vrg_dense_skipped((int64_t)hdrs[i].sweep, h->verify_every, nver, me)) continue;
+                    be_follow_apply(h->be, c, recs, hdrs.data() + first, (int)(i + 1 - first), 1);
+                    be_follow_count(h->be, c, &h->ev); r.verified++; r.last_verified = hdrs[i].sweep;
+                    first = i + 1;
+                }
+            }
+            sw_done += ch.nsw; rec_done += ch.nrec;
+            if (!ch.closed) continue;
+            hb = ch.hb;
+            if (!r.failed && (hb.seq != n || hb.nsw != sw_done || hb.nrec != rec_done)) { r.failed = 13; h->err = "replication: batch " + std::to_string(hb.seq) + " closed where batch " + std::to_string(n) + " was due, or with other contents than arrived"; }
+            if (!r.failed && first < sw_done) be_follow_apply(h->be, c, repl_rec_of(r, staging), hdrs.data() + first, (int)(sw_done - first), 0);
+            break;
         }
-        be_follow_mark(h->be, (int)((hb.seq - 1) & 1));
+        be_follow_mark(h->be, (int)((n - 1) & 1));
+        r.seq = n;
+        r.batches++; r.records += rec_done; r.sweeps += sw_done;
         last = hb;
         if (hb.final) break;
     }
@@ -299,15 +385,16 @@ static int repl_finish(vrg_handle* h, int32_t iter0, int32_t iter, int64_t n_in,
     v[3 * ns + 3] = (double)iter;                      // (N x iter: every rank ended on the same sweep)
     int rc = repl_allsum(h, v);
     if (rc) return rc;
-    for (size_t i = 0; i < ns; i++) {
+    const bool any_error = v[3 * ns] > 0.5;
+    for (size_t i = 0; i < ns && !any_error; i++) {
         if (v[3 * i + 2] > 1.5) return fail(h, VRG_E_INTERNAL, "replication: sweep " + std::to_string(iter0 + 1 + (int)i) + " was counted by more than one rank");
         if (v[3 * i + 2] > 0.5) { tr[i].sum_in = v[3 * i]; tr[i].sum_out = v[3 * i + 1]; }
         else { tr[i].sum_in = std::nan(""); tr[i].sum_out = std::nan(""); }
     }
-    if (ns) be_upload(h->be, c.trace + iter0 + 1, tr.data(), ns * sizeof(VrgTrace));
-    if (v[3 * ns + 3] != (double)iter * r.nranks) return fail(h, VRG_E_INTERNAL, "replication: the ranks ended on different sweeps");
+    if (ns && !any_error) be_upload(h->be, c.trace + iter0 + 1, tr.data(), ns * sizeof(VrgTrace));
     if (derr == 5 || v[3 * ns + 1] > 0.5) error = 5;
     else if (derr == 12 || v[3 * ns + 2] > 0.5) error = 12;
-    else if (v[3 * ns] > 0.5 && !error) error = 13;     // another rank failed
+    else if (any_error && !error) error = 13;          // another rank failed
+    else if (!error && v[3 * ns + 3] != (double)iter * r.nranks) return fail(h, VRG_E_INTERNAL, "replication: the ranks ended on different sweeps");
     return VRG_OK;
 }

@@ -149,6 +149,13 @@ struct VrgLogSweep {                   // = the sweep's trace record + where its
     uint32_t sweep, nrec;              // sweep number (1-based, = VrgState::iter after it); records
     uint32_t rec0, pad;                // first record, relative to the batch buffer's records
 };
+// A batch's sweeps travel while the batch is still running (per-sweep streaming): the leader's band chain publishes how far the batch's log
+// is complete - sweeps whose header is filed and whose records have been written by a kernel that has ENDED - in one 64-bit progress word
+// (VrgCtx::log_ready): batch number (22 bits) << 42 | sweeps (10 bits) << 32 | records (32 bits); on the hipIpc transport the followers poll
+// that word themselves, on the others the leader's host does and sends what is new as a CHUNK: this struct, then the chunk's sweep headers,
+// then its records.  The chunk that completes a batch carries the batch header.
+enum { VRG_LOG_SEQ_BITS = 22, VRG_LOG_SW_BITS = 10 };
+VRG_HD uint64_t vrg_log_progress(uint64_t seq, uint32_t nsw, uint32_t nrec) { return ((seq & ((1ull << VRG_LOG_SEQ_BITS) - 1ull)) << 42) | ((uint64_t)(nsw & ((1u << VRG_LOG_SW_BITS) - 1u)) << 32) | (uint64_t)nrec; }
 struct VrgLogBatch {                   // written by the leader's host when the batch is complete
     uint64_t seq;                      // batch number, from 1
     uint32_t nsw, nrec;                // sweeps and records in it
@@ -159,6 +166,15 @@ struct VrgLogBatch {                   // written by the leader's host when the 
     uint32_t ties, near_ties;          // VrgState counters at the end of the batch
     uint32_t pad[2];
 };
+struct VrgLogChunk {                   // sweeps [sw0, sw0 + nsw) and records [rec0, rec0 + nrec) of batch `batch` (places inside the batch's buffer)
+    uint64_t seq, batch;               // chunk number since the handle was created (from 1); the batch it belongs to
+    uint32_t sw0, nsw, rec0, nrec;
+    int32_t closed;                    // the batch is complete with this chunk: hb is its header
+    uint32_t cap;                      // records the leader's batch buffers hold (a follower's staging buffers follow at the start of a batch)
+    uint32_t pad[4];
+    VrgLogBatch hb;
+};
+static_assert(sizeof(VrgLogBatch) == 72 && sizeof(VrgLogChunk) == 128, "change log message layout");
 
 
 // results of the dense recount; written by the dense stream only (own allocation, own cache lines).
@@ -184,7 +200,9 @@ enum { VG_REQ = 0, VG_STOP = 1 };
 // sweep's pass is left out (option verify_every)
 enum { VD_SEQ = 0, VD_ERR = 1, VD_RSEQ = 2, VD_NST = 3, VD_GO = 4 };
 enum { UC_N = 0, UC_GEN = 16, UC_GEN_STRIDE = 16 };       // VrgCtx::uctl: list length; units newly listed by the sweeps of parity p at UC_GEN + p * UC_GEN_STRIDE (own cache lines)
-enum { VRG_RING = 64, VRG_STAGE = 16 };           // sweeps a recount result / expected size is kept for; slab sums per all-reduce
+enum { VRG_RING = 64, VRG_STAGE = 16 };
+// diagnostic build (-DVRG_STAMPS): per-workgroup time stamps of one kernel behind the chain's 64 (VrgCtx::dbg): VRG_DBG_PER words for each of VRG_DBG_WG workgroups
+enum { VRG_DBG_WG = 1024, VRG_DBG_PER = 32 };           // sweeps a recount result / expected size is kept for; slab sums per all-reduce
 
 struct VrgCtx {
     int32_t nx, ny, nz;
@@ -326,6 +344,8 @@ struct VrgCtx {
     VrgLogRec* log_rec; VrgLogSweep* log_sw;
     uint32_t log_cap, log_swcap;       // capacities of the two arrays
     uint32_t log_pos0, log_nsw0;       // VrgState::log_pos / log_nsw when the batch's buffer was opened
+    uint64_t* log_ready;               // the batch's progress word (vrg_log_progress): written through by the band chain once a sweep's header and records are complete (null: nobody streams)
+    uint32_t log_seq;                  // ... and the batch's number
     // which dense passes this handle counts: sweep k is counted by verifier ((k / every) - 1) % ver_n (vrg_dense_skipped); ver_me = this
     // handle's place among the verifiers, -1: it counts none.  One GPU: ver_n = 1, ver_me = 0.
     int32_t ver_n, ver_me;

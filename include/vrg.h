@@ -169,6 +169,9 @@ int vrg_get_stats(vrg_handle* h, int64_t* out, int64_t cap);
 /* Diagnostic builds only (compiled with -DVRG_STAMPS, tools/chain_stamps.py): 64 in-kernel time stamps (100-MHz ticks) of
  * the band chain's last sweep; all zero in the product build. */
 int vrg_debug_stamps(vrg_handle* h, uint64_t* out64);
+/* ... and, per workgroup of k_mark_relabel's last launch (the four-launch trip's relabel kernel), 32 words for each of 1024 workgroups:
+ * entry, state loaded, end of rounds 1..10, filing started / ended, exit, hardware id, phases of rounds 0 and 2 (tools/mark_stamps.py); cap >= 32768 words. */
+int vrg_debug_stamps_wide(vrg_handle* h, uint64_t* out, int64_t cap);
 
 /* ---- multi-GPU (one process per GPU) --------------------------------------------------
  * Every rank holds the label volume and applies the O(band) relabel identically (it is deterministic),
@@ -198,6 +201,11 @@ int vrg_set_reduce_callback(vrg_handle* h, vrg_reduce_fn fn, void* user);
  * band (vrg_get_band) lives on the leader only.  A count that disagrees, or a rank whose labels have drifted from the log,
  * fails the run on every rank (VRG_E_INTERNAL).  Call vrg_repl_init before vrg_init, then choose ONE transport for the log. */
 int vrg_repl_init(vrg_handle* h, int nranks, int rank, int leader_verifies);
+/* Options of a replicated handle (vrg_set_option): "repl_stream" 1 (default) - the log travels sweep by sweep while a batch of trips
+ * runs (a follower lags by a poll and a copy); 0 - once per batch.  "log_capacity" - records a batch buffer holds (before the first
+ * vrg_run).  "repl_fault" - tests only: n > 0 makes the leader fail on the host side when it opens its n-th batch, n < 0 makes a
+ * follower unable to use its |n|-th chunk; either way EVERY rank's vrg_run returns an error (the run is collective: a failing
+ * rank still ends the run for the others and joins the closing all-reduce). */
 /* transport 1 - host callbacks (any fabric; the CPU tests use torch.distributed / gloo): bcast broadcasts `bytes` bytes of
  * `buf` (host memory) from rank `root` to every rank, allsum sums n doubles over the ranks in place; both blocking, collective */
 typedef void (*vrg_bcast_fn)(void* buf, int64_t bytes, int root, void* user);
@@ -211,7 +219,8 @@ int vrg_repl_use_rccl(vrg_handle* h);
 int vrg_repl_ipc_export(vrg_handle* h, void* blob, int64_t cap, int64_t* bytes);
 int vrg_repl_ipc_import(vrg_handle* h, const void* blob, int64_t bytes);
 /* diagnostics: out[0] = batches published / taken, out[1] = log records, out[2] = sweeps in them, out[3] = sweeps this rank counted,
- * out[4] = the last of them, out[5] = transport (1 callback, 2 rccl, 3 ipc), out[6] = verifiers, out[7] = this rank's place among them (-1: none) */
+ * out[4] = the last of them, out[5] = transport (1 callback, 2 rccl, 3 ipc), out[6] = verifiers, out[7] = this rank's place among them (-1: none);
+ * with cap >= 9 also out[8] = chunks of the log sent / taken (the log travels sweep by sweep: several chunks per batch of trips) */
 int vrg_repl_stats(vrg_handle* h, int64_t* out, int64_t cap);
 
 #ifdef __cplusplus

@@ -1030,7 +1030,7 @@ def test_replica_rccl_single_rank(lib):
         assert st['sweeps'] == 25 and st['transport'] == 'rccl'
 
 
-def _rccl_replica_worker(rank, world, port, sweeps, outdir):
+def _rccl_replica_worker(rank, world, port, sweeps, outdir, leader_verifies):
     import os, sys
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     from conftest import ROOT
@@ -1041,31 +1041,40 @@ def _rccl_replica_worker(rank, world, port, sweeps, outdir):
     torch.cuda.set_device(rank)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     data, vmap = phantoms.tube_phantom(shape=(96, 64, 40), radius=3.0, seed=4, seed_planes=3, amp_y=10.0, amp_z=5.0, levels=32, brain_mask=True)
-    s = replica.make_replica_session(data.shape, rank, world, device=rank, transport='rccl', leader_verifies=(rank % 2 == 0 or True), options={'batch': 4})
+    s = replica.make_replica_session(data.shape, rank, world, device=rank, transport='rccl', leader_verifies=leader_verifies, options={'batch': 4})
     out = _replica_run(s, data, vmap, sweeps)
-    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), labels=out[0], seg=out[1], tr=out[2], transport=np.str_(s.replica['transport']))
+    st = s.repl_stats()
+    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), labels=out[0], seg=out[1], tr=out[2], transport=np.str_(s.replica['transport']),
+             stats=np.array([st['batches'], st['chunks'], st['sweeps'], st['verified']], np.int64))
     s.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_replica_rccl_world2(lib, tmp_path):
-    """RCCL with MORE THAN ONE rank: two processes, one GPU each, the change log over ncclBroadcast (xGMI between the two).
-    Skipped on a box with one GPU (the driver's multi-GPU node runs it)."""
+@pytest.mark.parametrize('world,leader_verifies', [(2, True), (2, False), (4, True), (4, False), (8, True), (8, False)])
+def test_replica_rccl_world_n(lib, tmp_path, world, leader_verifies):
+    """RCCL with MORE THAN ONE rank: `world` processes, one GPU each, the change log streamed sweep by sweep over ncclBroadcast (xGMI
+    between the GPUs), the leader counting a share (leader_verifies) or only leading - the 8-rank configuration.  Every rank's labels,
+    `segmented` order and trace equal the single-process run (the sums bit for bit where somebody counted the sweep).
+    Skipped where fewer than `world` GPUs are visible (the driver's multi-GPU node runs it)."""
     import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip('needs two GPUs')
+    if torch.cuda.device_count() < world:
+        pytest.skip('needs {} GPUs'.format(world))
     import torch.multiprocessing as mp
     from test_slabs_gloo import free_port
     from arterynetwork_amd import phantoms
     from arterynetwork_amd._capi import Session
     data, vmap = phantoms.tube_phantom(shape=(96, 64, 40), radius=3.0, seed=4, seed_planes=3, amp_y=10.0, amp_z=5.0, levels=32, brain_mask=True)
     ref = _replica_run(Session(data.shape, lib=lib), data, vmap, 25)
-    mp.spawn(_rccl_replica_worker, args=(2, free_port(), 25, str(tmp_path)), nprocs=2, join=True)
-    for r in range(2):
+    mp.spawn(_rccl_replica_worker, args=(world, free_port(), 25, str(tmp_path), leader_verifies), nprocs=world, join=True)
+    counted = 0
+    for r in range(world):
         z = np.load(str(tmp_path / ('rank%d.npz' % r)))
         assert str(z['transport']) == 'rccl'
         assert np.array_equal(z['labels'], ref[0]) and np.array_equal(z['seg'], ref[1]) and z['tr'].tobytes() == ref[2].tobytes()
+        assert z['stats'][2] == 25 and z['stats'][1] >= z['stats'][0]      # every sweep of the log seen; at least a chunk per batch
+        counted += int(z['stats'][3])
+    assert counted >= (25 if not leader_verifies else 25 - 25 // world - 1)  # (the followers' shares; a verifying leader counts its own)
 
 
 def test_reports_ties(lib):

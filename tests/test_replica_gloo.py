@@ -87,3 +87,53 @@ def test_replicas_equal_single_process(tmp_path, world, leader_verifies, options
     due = sweeps if every == 1 else (0 if every == 0 else sweeps // every)
     if not leader_verifies:
         assert verified_total >= due                                 # (+1 when the run's last sweep is counted after all)
+
+
+def _worker_stream(rank, world, port, outdir, options, expect_error):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from arterynetwork_amd import replica
+    from arterynetwork_amd._capi import VrgLib, VrgError
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lib = VrgLib(HM, 'vrgm_')
+    data, vmap = _inputs()
+    s = replica.make_replica_session(data.shape, rank, world, lib=lib, transport='callback', leader_verifies=False, options=options)
+    err = ''
+    try:
+        _run(s, data, vmap, 14)
+    except VrgError as e:
+        err = str(e)
+    st = s.repl_stats()
+    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), err=np.str_(err), stats=np.array([st['batches'], st['chunks'], st['sweeps']], np.int64), labels=s.labels() if not err else np.zeros(1))
+    s.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('stream', [1, 0])
+def test_log_travels_in_chunks(tmp_path, stream):
+    """Per-sweep streaming: with trips enqueued four at a time the log of 14 sweeps travels in more chunks than batches (the band chain
+    publishes a sweep as soon as its records and header are complete); with repl_stream = 0 every batch is one chunk.  Same labels."""
+    mp.spawn(_worker_stream, args=(3, free_port(), str(tmp_path), {'batch': 4, 'repl_stream': stream, 'small_flips': 4096, 'fuse_max': 128}, False), nprocs=3, join=True)
+    z = [np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r)) for r in range(3)]
+    for r in range(3):
+        assert str(z[r]['err']) == '', (r, str(z[r]['err']))
+        assert z[r]['stats'][2] == 14
+        assert np.array_equal(z[r]['labels'], z[0]['labels'])
+        if stream:
+            assert z[r]['stats'][1] > z[r]['stats'][0], (r, z[r]['stats'])          # chunks > batches
+        else:
+            assert z[r]['stats'][1] == z[r]['stats'][0], (r, z[r]['stats'])
+    assert np.array_equal(z[0]['stats'], z[1]['stats']) and np.array_equal(z[1]['stats'], z[2]['stats'])
+
+
+@pytest.mark.parametrize('fault', [2, -3])
+def test_a_failing_rank_ends_the_run_for_every_rank(tmp_path, fault):
+    """A replicated vrg_run is collective, and so are its failures (round-5 advice): a leader that fails on the host side while the
+    followers wait for the log (fault > 0: when it opens its 2nd batch), or a follower that cannot use a chunk (fault < 0: its 3rd),
+    must not leave the other ranks waiting - every rank returns an error."""
+    mp.spawn(_worker_stream, args=(3, free_port(), str(tmp_path), {'batch': 4, 'repl_fault': fault, 'small_flips': 4096, 'fuse_max': 128}, True), nprocs=3, join=True)
+    for r in range(3):
+        z = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r))
+        assert str(z['err']) != '', 'rank %d returned without an error' % r
