@@ -75,6 +75,8 @@ struct VrgBackend {
                                                       // (its request comes from THIS trip's k_band; if that trip stopped or handed itself back, the stop word makes the gate leave)
     bool prev_open = false;                           // ... and its sweep was open-ended: this trip's k_band derives the closed state (and lists the touched levels itself)
     int open_par = 0;                                 // ... the set of per-level counters it filled
+    uint64_t* rsv = nullptr;                          // VrgCtx::rsv of this handle's four-launch trips (64 words, zero between sweeps)
+    int mark_compact = 1;                             // option "mark_compact": four-launch trips of thousands of flips relabel with k_mark_compact (+ k_mark_relabel for what it leaves)
     int open_sweeps = 1;                              // option "open_sweeps": fused sweeps inside a batch end at their commit, without a closing workgroup
     int iter_hint = 0;                                // sweeps applied when the engine last read the state + trips enqueued since
     uint32_t band_hint = 0;                           // pool slots in use when the engine last read the state (0: unknown)
@@ -485,16 +487,13 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
     const VrgState& s = s_;
     const bool live = s.iter < s.iterMax;
     if (st0 && live) { VRG_STAMP_PUT(c, 6, c.dbg[0]); VRG_STAMP_PUT(c, 0, t_entry); VRG_STAMP(c, 1); }    // (6: the sweep before this one)
-    if (st0 && c.log_ready && gridDim.x <= band_blocks + EXACT_BLOCKS) vrg_log_publish(c, s.log_nsw, s.log_pos);   // (a grid without deferred workgroups - four-launch trips: the sweep before was closed by its own kernels)
     // What the fused sweep before this trip (k_sweep) left to do - nothing in this kernel reads a label: its label bytes in
     // place (+ the class bits the dense pass reads, the class changes of the sweep before that), its dead slots onto the
     // free list - by workgroups of their own (the last DEFER_WGS of the grid), beside the ones that decide the slots.
     // Whichever of them finishes last (ticket) asks for the sweep's dense pass.  Their first thread files the state this trip
     // works on (vrg_fuse_persist) - before its workgroup's ticket: the sizes the dense pass has to reproduce are filed with it.
     if (defer_wg) {
-        // (... and publishes how far the change log is complete - replication's per-sweep streaming: the sweep before this trip - its records
-        // written by kernels that have ended, its header by one of those or by this thread just now)
-        if (dtid == 0) { vrg_fuse_persist(c, s, fcl, was_open, nin0, nout0); vrg_log_publish(c, s.log_nsw, s.log_pos); }
+        if (dtid == 0) vrg_fuse_persist(c, s, fcl, was_open, nin0, nout0);
         if (!s.apply_pending) return;
         const int k = s.iter;
         if (tid == 0 && dense_on && (int64_t)k - 2 > rseq0) wait_dense_read_for(c, (int64_t)k - 2);   // (the pass of two sweeps ago has read the class copy this sweep rewrites)
@@ -690,6 +689,7 @@ constexpr uint32_t NZ_SORT = 2048;  // touched levels one workgroup sorts in LDS
 
 __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_limit) {
     VRG_CHAOS_POINT(2);
+    if (threadIdx.x == 0) c.counters[48] = 0;             // (the flips k_mark_compact will leave to k_mark_relabel: none yet)
 
     constexpr uint32_t REC_LDS = 1024;
     __shared__ uint64_t s_key[NF_SMALL];
@@ -708,6 +708,9 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
     const int64_t nin0 = c.inc[VC_NIN];
     const uint64_t zk0 = t < c.zcap ? c.nz_key[t] : 0ull;
     if (s0.done || s0.bail) return;
+    // (replication's per-sweep streaming: a four-launch trip's k_band may have no deferred workgroups to publish the change log's progress -
+    // the sweep before this trip was closed by kernels that have ended: nothing to drain)
+    if (t == 0) vrg_log_publish(c, s0.log_nsw, s0.log_pos, false);
     if (t == 0) {
         int go = 1;
         const int32_t stop = vrg_stop_test_v(s0, nin0);                  // :91-104, in the reference's order
@@ -849,21 +852,38 @@ __device__ __forceinline__ uint32_t km_row(int dy, int dz) { return (uint32_t)((
 #else
 #define KM_STAMP_OCC
 #endif
+// A workgroup reserves its stretches of the sweep's lists: new / dead / pending events (s_n), marked voxels (s_cnt[0]), list length changes (s_d) - through VrgCtx::rsv
+// (two returning 64-bit adds and two plain ones, on four cache lines) or, without it, through the state's own six words.  Bases into s_base[0..3].
+__device__ __forceinline__ void km_reserve(const VrgCtx& c, uint32_t tt, const uint32_t* s_n, const uint32_t* s_cnt, const int32_t* s_d, uint32_t* s_base) {
+    if (c.rsv) {
+        if (tt == 0 && (s_n[0] | s_n[1])) { const unsigned long long o = atomicAdd((unsigned long long*)&c.rsv[0], (unsigned long long)s_n[0] | ((unsigned long long)s_n[1] << 32)); s_base[0] = (uint32_t)o; s_base[1] = (uint32_t)(o >> 32); }
+        if (tt == 1 && (s_n[2] | s_cnt[0])) { const unsigned long long o = atomicAdd((unsigned long long*)&c.rsv[16], (unsigned long long)s_n[2] | ((unsigned long long)s_cnt[0] << 32)); s_base[2] = (uint32_t)o; s_base[3] = (uint32_t)(o >> 32); }
+        if (tt == 2 && s_d[0]) atomicAdd((int*)&c.rsv[32], s_d[0]);
+        if (tt == 3 && s_d[1]) atomicAdd((int*)&c.rsv[48], s_d[1]);
+        return;
+    }
+    if (tt < 3 && s_n[tt]) s_base[tt] = vrg_atomic_add(tt == 0 ? &c.st->nalloc : tt == 1 ? &c.st->ndead : &c.st->nfresh, s_n[tt]);
+    if (tt == 3 && s_cnt[0]) s_base[3] = vrg_atomic_add(&c.stg->nmk, s_cnt[0]);
+    if (tt >= 4 && tt < 6 && s_d[tt - 4]) vrg_atomic_add(tt == 4 ? &c.st->d_ni : &c.st->d_no, s_d[tt - 4]);
+}
+// (list / list_n: null - every flip of the sweep, flip r = the r-th of the ordered list; else the flips k_mark_compact left to this kernel)
 template <int G>
-__global__ void __launch_bounds__(KM_THREADS * G) KM_STAMP_OCC k_mark_relabel(VrgCtx cg) {
+__global__ void __launch_bounds__(KM_THREADS * G) KM_STAMP_OCC k_mark_relabel(VrgCtx cg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_n) {
     VRG_CHAOS_POINT(3);
     // (the first flip's voxel travels with the state: k_order has written the list, whatever the state says)
     const uint32_t tt = threadIdx.x, g = tt / KM_THREADS, t = tt % KM_THREADS;     // (tt: in the workgroup; t: among the 128 threads of flip g)
     const bool st0 = blockIdx.x == 0 && tt == 0;
     const unsigned long long t_entry = tt == 0 ? VRG_STAMP_NOW() : 0ull;
-    const uint32_t r_first = blockIdx.x * G + g;
+    const uint32_t r_first = list ? 0xffffffffu : blockIdx.x * G + g;
     const uint32_t fidx_first = r_first < cg.fcap ? cg.f_idx[r_first] : 0u;
     const int32_t st_done = cg.st->done, st_bail = cg.st->bail;
-    const uint32_t nf = cg.st->nf;
-    asm volatile("" :: "v"(fidx_first), "v"(st_done), "v"(st_bail), "v"(nf));     // one wait for the four
+    const uint32_t nf_all = cg.st->nf, nlist = list ? *list_n : 0u;
+    asm volatile("" :: "v"(fidx_first), "v"(st_done), "v"(st_bail), "v"(nf_all), "v"(nlist));     // one wait for the five
+    const uint32_t nf = list ? (nlist < nf_all ? nlist : nf_all) : nf_all;
     if (st_done || st_bail) return;
     if (st0) { VRG_STAMP_PUT(cg, 16, t_entry); VRG_STAMP(cg, 17); }
 #if defined(VRG_STAMPS)
+    if (list) { if (blockIdx.x * G >= nf) return; }                  // (the compact kernel's stamps stay when this launch has nothing to do)
     VRG_STAMP_WG_PUT(cg, 0, t_entry); VRG_STAMP_WG(cg, 1);
     VRG_STAMP_WG_PUT(cg, 15, ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(63492));   // XCC_ID | HW_ID
     for (uint32_t k_ = 2; k_ < (uint32_t)VRG_DBG_PER; k_++) if (k_ != 15u) VRG_STAMP_WG_PUT(cg, k_, 0ull);
@@ -906,9 +926,7 @@ __global__ void __launch_bounds__(KM_THREADS * G) KM_STAMP_OCC k_mark_relabel(Vr
         c.hin = reinterpret_cast<int32_t*>(s_hist + 3u * cg.L); c.hout = reinterpret_cast<int32_t*>(s_hist + 4u * cg.L);
     }
     auto km_flush = [&]() {                                               // all threads; the buffers are complete (a barrier since the last entry)
-        if (tt < 3 && s_n[tt]) s_base[tt] = vrg_atomic_add(tt == 0 ? &c.st->nalloc : tt == 1 ? &c.st->ndead : &c.st->nfresh, s_n[tt]);
-        if (tt == 3 && s_cnt[0]) s_base[3] = vrg_atomic_add(&c.stg->nmk, s_cnt[0]);
-        if (tt >= 4 && tt < 6 && s_d[tt - 4]) vrg_atomic_add(tt == 4 ? &c.st->d_ni : &c.st->d_no, s_d[tt - 4]);
+        km_reserve(c, tt, s_n, s_cnt, s_d, s_base);
         __syncthreads();
         const uint32_t nm = s_cnt[0], ne = s_cnt[1];
         for (uint32_t i = tt; i < nm; i += NT) {
@@ -926,9 +944,10 @@ __global__ void __launch_bounds__(KM_THREADS * G) KM_STAMP_OCC k_mark_relabel(Vr
     };
     // (every thread of the workgroup makes the same number of trips: the barriers)
     for (uint32_t rb = blockIdx.x * G; rb < nf; rb += gridDim.x * G) {
-        const uint32_t r = rb + g;
-        const bool have = r < nf;                                         // (the last round of a sweep may leave some of the G places empty)
-        const uint32_t fidx = r == r_first ? fidx_first : c.f_idx[have ? r : nf - 1u];
+        const uint32_t ri = rb + g;
+        const bool have = ri < nf;                                        // (the last round of a sweep may leave some of the G places empty)
+        const uint32_t r = list ? list[have ? ri : nf - 1u] : (have ? ri : nf - 1u);
+        const uint32_t fidx = r == r_first ? fidx_first : c.f_idx[r];
         if (rb != blockIdx.x * G && (s_cnt[0] + 125u * G > MKBUF || s_cnt[1] + 125u * G > EVBUF)) km_flush();     // (uniform: read after the barrier that ended the round before)
         // the tile row (a row that is not wholly inside the allocation - 16 guard bytes at either end - belongs to no real
         // voxel's neighbourhood: it reads as out-of-bounds bytes)
@@ -1047,6 +1066,204 @@ __global__ void __launch_bounds__(KM_THREADS * G) KM_STAMP_OCC k_mark_relabel(Vr
     VRG_STAMP_WG(c, 14);
 }
 
+// ---- k_mark_relabel in its COMPACT form (round 6): sweeps of thousands of flips -------------------------------------------------
+// What the per-workgroup timeline of k_mark_relabel<4> showed at 12 900 flips per sweep (tools/mark_stamps.py, profiles/NOTES_r05.md): a
+// round of four flips takes ~10 us whatever its loads look like, 2048 flips are in flight chip-wide, and the kernel is bound by the NUMBER of
+// scattered requests a flip makes - 81 tile rows, 3 x 125 per-voxel fields, 125 marking atomics, the rank look-ups - of which most serve
+// places that are not wanted at all: only the 27 voxels of the flip's 1-ring are ever relabelled unless an EXCLUDED voxel lies in its 2-ring
+// (:177-179), and inside a brain mask none does.  So:
+//  * ONE FLIP PER HALF-WAVE: lane l < 27 is place l of the flip's 3x3x3 box, lane l < 25 fetches row l of its 5x5 rows (all the 27 stencils
+//    read: 5x5x5 voxels); a 256-thread workgroup handles eight flips side by side.  A flip with an excluded voxel anywhere in its 5x5x5 cube
+//    (found in the rows by a wave ballot) is left untouched and put on the `slow` list: k_mark_relabel<4> - the general form, launched behind
+//    this kernel over that list - takes it.
+//  * NOTHING A FLIP NEEDS IS SHARED BETWEEN WAVES: tile and rank tile belong to the half-wave, so a round has NO workgroup barrier - a wave
+//    runs through its rounds at its own pace.  The ranks of the listed flips in the cube (what the case analysis asks of a voxel's listed
+//    neighbours) are fetched once per listed voxel into the rank tile, not once per (voxel, neighbour) pair.
+//  * the workgroup's lists (marked voxels, events) are filed every two rounds and at the end, as k_mark_relabel<4> files them.
+// Requests per flip: 25 rows + 27 x 3 fields + the cube's listed stamps + 27 marks, against 81 + 375 + 125 + the rank batches.
+constexpr int KMC_GROUPS = 8;
+constexpr int KMC_THREADS = 32 * KMC_GROUPS;
+constexpr int KMC_ROWS = 25;                    // (dy, dz) in [-2, 2]^2; row bytes 0..15 = dx -4 .. +11 (bytes 2..6 are the cube's)
+constexpr uint32_t KMC_FLUSH_ROUNDS = 2;
+constexpr uint32_t KMC_BUF = KMC_FLUSH_ROUNDS * KMC_GROUPS * 27;     // marked voxels / events between two filings
+constexpr int KMC_BLOCKS = 768;                 // three workgroups per CU: 6144 flips in flight
+__global__ void __launch_bounds__(KMC_THREADS) k_mark_compact(VrgCtx cg, uint32_t* __restrict__ slow, uint32_t* __restrict__ slow_n) {
+    VRG_CHAOS_POINT(3);
+    const uint32_t tt = threadIdx.x, g = tt >> 5, l = tt & 31u;
+    const uint32_t r_first = blockIdx.x * KMC_GROUPS + g;
+    const uint32_t fidx_first = r_first < cg.fcap ? cg.f_idx[r_first] : 0u;
+    const int32_t st_done = cg.st->done, st_bail = cg.st->bail;
+    const uint32_t nf = cg.st->nf;
+    asm volatile("" :: "v"(fidx_first), "v"(st_done), "v"(st_bail), "v"(nf));     // one wait for the four
+    if (st_done || st_bail) return;
+#if defined(VRG_STAMPS)
+    VRG_STAMP_WG(cg, 0); VRG_STAMP_WG(cg, 1);
+    VRG_STAMP_WG_PUT(cg, 15, ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(63492));
+    for (uint32_t k_ = 2; k_ < (uint32_t)VRG_DBG_PER; k_++) if (k_ != 15u) VRG_STAMP_WG_PUT(cg, k_, 0ull);
+#endif
+    if (blockIdx.x * KMC_GROUPS >= nf) return;
+    extern __shared__ double s_lev[];                                     // (the level table + the per-level counts, as k_mark_relabel keeps them)
+    __shared__ uint32_t s_tile_all[KMC_GROUPS][KMC_ROWS * 4];
+    __shared__ uint32_t s_rank_all[KMC_GROUPS][128];                      // rank of the listed flip at place p of the 5x5x5 cube
+    __shared__ uint32_t s_n[3], s_base[4], s_cnt[2];
+    __shared__ int32_t s_d[2];
+    __shared__ uint32_t s_mk_idx[KMC_BUF];
+    __shared__ uint8_t s_mk_nw[KMC_BUF], s_mk_old[KMC_BUF];
+    __shared__ KmEvRec s_ev[KMC_BUF];
+    uint32_t* const s_tile = s_tile_all[g];
+    uint32_t* const s_rank = s_rank_all[g];
+    VrgCtx c = cg;
+    uint8_t* lab = c.lab[0];
+    const uint32_t idx_lo = vrg_idx(c, 0, 0, 0), idx_hi = vrg_idx(c, c.nx - 1, c.ny - 1, c.nz - 1);
+    const bool ring = l < 27u;
+    const int dx = (int)(l % 3u) - 1, dy = (int)((l / 3u) % 3u) - 1, dz = ring ? (int)(l / 9u) - 1 : 0;      // this lane's voxel of the 3x3x3 box
+    const int ry = (int)(l % 5u) - 2, rz = l < (uint32_t)KMC_ROWS ? (int)(l / 5u) - 2 : 0;                    // the row lane l < 25 fetches
+    c.lev_fast = (cg.L <= LEV_LDS || cg.lev16 || cg.lev_map || cg.lidx) ? 1 : 0;
+    if (cg.L <= LEV_LDS) c.lev_map = nullptr;
+    if (tt < 3) s_n[tt] = 0;
+    if (tt < 2) { s_d[tt] = 0; s_cnt[tt] = 0; }
+    const bool lds_hist = cg.lvl_scan == 1 && cg.L <= HIST_LDS;
+    uint32_t* const s_hist = reinterpret_cast<uint32_t*>(s_lev + ((cg.L <= LEV_LDS && !cg.lev16) ? cg.L : 0u));
+    if (lds_hist) {
+        for (uint32_t k = tt; k < 5u * cg.L; k += KMC_THREADS) s_hist[k] = 0;
+        c.dIn = s_hist; c.dOut = s_hist + cg.L; c.dConv = s_hist + 2u * cg.L;
+        c.hin = reinterpret_cast<int32_t*>(s_hist + 3u * cg.L); c.hout = reinterpret_cast<int32_t*>(s_hist + 4u * cg.L);
+    }
+    auto km_flush = [&]() {                                               // all threads (a barrier first: every wave has finished its rounds so far)
+        __syncthreads();
+        km_reserve(c, tt, s_n, s_cnt, s_d, s_base);
+        __syncthreads();
+        const uint32_t nm = s_cnt[0], ne = s_cnt[1];
+        for (uint32_t i = tt; i < nm; i += KMC_THREADS) {
+            const uint32_t q = s_base[3] + i;
+            if (q < c.mcap) { c.mk_idx[q] = s_mk_idx[i]; c.mk_new[q] = s_mk_nw[i]; c.mk_old[q] = s_mk_old[i]; } else vrg_store_i32(&c.stg->error, 4);
+        }
+        for (uint32_t i = tt; i < ne; i += KMC_THREADS) {
+            const KmEvRec& e = s_ev[i];
+            vrg_ev_write(c, e.m, e.ev, s_base[0] + e.r1, s_base[1] + e.r1, s_base[2] + e.rf);
+        }
+        __syncthreads();
+        if (tt < 3) s_n[tt] = 0;
+        if (tt < 2) { s_d[tt] = 0; s_cnt[tt] = 0; }
+        __syncthreads();
+    };
+    uint32_t round = 0;
+    for (uint32_t rb = blockIdx.x * KMC_GROUPS; rb < nf; rb += gridDim.x * KMC_GROUPS, round++) {      // (every wave of the workgroup makes the same number of trips)
+        const uint32_t r = rb + g;
+        const bool have = r < nf;
+        const uint32_t fidx = r == r_first ? fidx_first : c.f_idx[have ? r : nf - 1u];
+        if (round && round % KMC_FLUSH_ROUNDS == 0u) { VRG_STAMP_WG(c, 16); km_flush(); VRG_STAMP_WG(c, 17); }
+        // this lane's row of the cube and, for a lane of the 3x3x3 box, what is kept per voxel elsewhere - one batch
+        km_u4 row = {0x01010101u * VB_OOB, 0x01010101u * VB_OOB, 0x01010101u * VB_OOB, 0x01010101u * VB_OOB};
+        if (l < (uint32_t)KMC_ROWS) {
+            const int64_t a = (int64_t)fidx + ((int64_t)rz * c.PY + ry) * c.PX - 4;
+            if (a >= -16 && a + 16 <= (int64_t)c.PV + 16) row = __builtin_nontemporal_load(reinterpret_cast<const km_u4*>(lab + a));
+        }
+        const int64_t m = (int64_t)fidx + ((int64_t)dz * c.PY + dy) * c.PX + dx;
+        VrgPre pre;
+        pre.rank = 0; pre.vent = 0; pre.lev16 = 0; pre.val = 0.0;
+        if (ring && have) {
+            const uint32_t ms = (uint32_t)(m < (int64_t)idx_lo ? (int64_t)idx_lo : (m > (int64_t)idx_hi ? (int64_t)idx_hi : m));
+            pre.rank = (uint32_t)c.stamp[ms]; pre.vent = c.vent[ms];
+            pre.lev16 = c.lev16 ? (uint32_t)c.lev16[ms] : c.lidx ? c.lidx[ms] : 0u;
+            pre.val = (c.lev16 || c.lidx) ? 0.0 : vrg_voxel_value(c, ms);
+        }
+        if (round == 0u && cg.L <= LEV_LDS && !cg.lev16) {
+            for (uint32_t k = tt; k < cg.L; k += KMC_THREADS) s_lev[k] = cg.lev[k];
+            c.lev = s_lev;
+        }
+        if (l < (uint32_t)KMC_ROWS) { s_tile[4 * l] = row.x; s_tile[4 * l + 1] = row.y; s_tile[4 * l + 2] = row.z; s_tile[4 * l + 3] = row.w; }
+        if (round == 0u) __syncthreads();                                 // (the level table and the zeroed counts: once)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();     // (the tile is the half-wave's own: its lanes' LDS traffic is in order)
+        // the cube's 125 places, four per lane: an excluded voxel anywhere -> the flip goes to the general kernel; a listed voxel -> its rank
+        bool xf = false;
+        uint32_t rk[4] = {0u, 0u, 0u, 0u}, lst = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t p = l + 32u * (uint32_t)q;
+            if (p < 125u && have) {
+                const uint32_t o = p % 5u + 2u;
+                const uint8_t b = (uint8_t)(s_tile[4u * (p / 5u) + (o >> 2)] >> (8u * (o & 3u)));
+                if (!(b & VB_OOB)) {
+                    xf = xf || (b & VB_X);
+                    if (b & VB_L) {
+                        const int64_t mp = (int64_t)fidx + ((int64_t)((int)(p / 25u) - 2) * c.PY + ((int)((p / 5u) % 5u) - 2)) * c.PX + ((int)(p % 5u) - 2);
+                        rk[q] = (uint32_t)c.stamp[(uint32_t)mp]; lst |= 1u << q;
+                    }
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(xf);
+        const bool slowg = ((g & 1u) ? (uint32_t)(bal >> 32) : (uint32_t)bal) != 0u;
+        if (slowg && l == 0u && have) slow[vrg_atomic_add(slow_n, 1u)] = r;                       // (rare: nothing of this flip is touched here)
+        uint8_t mb = VB_OOB;
+        if (ring && have) { const uint32_t o = (uint32_t)(dx + 4); mb = (uint8_t)(s_tile[4 * ((dz + 2) * 5 + (dy + 2)) + (o >> 2)] >> (8u * (o & 3u))); }
+        const bool wanted = !slowg && !(mb & (VB_OOB | VB_M));             // (vrg_mark_wanted for a place of the 1-ring)
+        uint32_t old = 0xffffffffu;
+        const uint32_t sh = 8u * ((uint32_t)m & 3u);
+        if (wanted) old = vrg_atomic_or((uint32_t*)(lab + ((uint32_t)m & ~3u)), (uint32_t)VB_M << sh);
+#pragma unroll
+        for (int q = 0; q < 4; q++) if ((lst >> q) & 1u) s_rank[l + 32u * (uint32_t)q] = rk[q];
+        VrgNbr nb = {0u, 0u, 0u, 0u};
+        uint32_t FO = 0, AP = 0, cand = 0;
+        if (wanted) {
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                const uint64_t w8 = *reinterpret_cast<const uint64_t*>(&s_tile[4 * ((dz + j % 3 - 1 + 2) * 5 + (dy + j / 3 - 1 + 2))]);
+                pre.w[j] = (uint32_t)(w8 >> (8 * (dx + 3)));              // bytes x-1 .. x+2 of the row (vrg_preload)
+            }
+            nb = vrg_masks_of(pre.w);
+            uint32_t ex, segA; vrg_nbr_sets(nb, ex, segA, FO, AP);
+            cand = FO | AP;
+        }
+        const uint32_t lev_here = (wanted && c.lev_fast) ? vrg_pre_level(c, pre) : 0xffffffffu;
+        const bool first = wanted && !((old >> sh) & VB_M);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();     // (the rank tile is complete)
+        if (first) {
+            VrgEvent ev; ev.kind = VE_NONE; ev.pend = 0;
+            VrgRanks qr; vrg_ranks_none(qr);
+            while (cand) {                                                // the listed neighbours' ranks, from the rank tile
+                uint32_t n0[VRG_RANK_BATCH], r0[VRG_RANK_BATCH];
+#pragma unroll
+                for (int k = 0; k < VRG_RANK_BATCH; k++) {
+                    n0[k] = cand ? vrg_ctz(cand) : 32u; if (cand) cand &= cand - 1u;
+                    const uint32_t n = n0[k] < 27u ? n0[k] : 13u, j = n / 3u;           // neighbour n: ddx = n % 3 - 1, ddz = j % 3 - 1, ddy = j / 3 - 1 (vrg_noff)
+                    r0[k] = s_rank[(uint32_t)((dz + (int)(j % 3u) - 1 + 2) * 25 + (dy + (int)(j / 3u) - 1 + 2) * 5 + (dx + (int)(n % 3u) - 1 + 2))];
+                }
+                vrg_ranks_take(FO, n0, r0, qr);
+            }
+            const uint8_t nw = vrg_sweep_cases(c, (uint32_t)m, mb, pre, nb, qr, false, lev_here, ev);      // (no excluded voxel in the cube: nobody asks for the 2-ring)
+            const uint32_t qm = atomicAdd(&s_cnt[0], 1u);
+            s_mk_idx[qm] = (uint32_t)m; s_mk_nw[qm] = nw; s_mk_old[qm] = mb;
+            if (ev.kind != VE_NONE) {
+                uint32_t r1 = 0, rf = 0;
+                if (ev.kind == VE_NEW) r1 = atomicAdd(&s_n[0], 1u);
+                if (ev.kind == VE_DIE) r1 = atomicAdd(&s_n[1], 1u);
+                if (ev.kind != VE_DIE && ev.pend) rf = atomicAdd(&s_n[2], 1u);
+                const int di = vrg_ev_dni(ev), dq = vrg_ev_dno(ev);
+                if (di) atomicAdd(&s_d[0], di);
+                if (dq) atomicAdd(&s_d[1], dq);
+                KmEvRec& e = s_ev[atomicAdd(&s_cnt[1], 1u)];
+                e.ev = ev; e.m = (uint32_t)m; e.r1 = r1; e.rf = rf;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();     // (before the next round overwrites the tiles)
+        VRG_STAMP_WG(c, min(11u, 2u + round));
+    }
+    VRG_STAMP_WG(c, 12);
+    km_flush();
+    VRG_STAMP_WG(c, 13);
+    if (lds_hist)                                                         // (km_flush ends with a barrier: the counts are complete)
+        for (uint32_t k = tt; k < 5u * cg.L; k += KMC_THREADS) {
+            const uint32_t n = s_hist[k];
+            if (n) { const uint32_t w = k / cg.L, lv = k - w * cg.L; atomicAdd((w == 0 ? cg.dIn : w == 1 ? cg.dOut : w == 2 ? cg.dConv : w == 3 ? (uint32_t*)cg.hin : (uint32_t*)cg.hout) + lv, n); }
+        }
+#if defined(VRG_STAMPS)
+    if (tt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VRG_STAMP_WG(c, 14);
+#endif
+}
+
 // Workgroups [0, CLOSE_APPLY): the sweep's label bytes in place (+ class bits, region sizes, the class changes of the
 // sweep before), dead slots onto the free list - the marked voxels spread over all their threads, one round trip
 // instead of six in a single workgroup (5.6 of that workgroup's 10.7 us).  Workgroups [CLOSE_APPLY, +TAB_BLOCKS): the
@@ -1076,8 +1293,12 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on, ui
         ncA = c.nchg[0]; ncB = c.nchg[1];
         if (t == 0 && dense_on) rseq0 = vrg_load_i64(&c.dctl[VD_RSEQ]);
     } else if (!c.lvl_scan && t < c.zcap) zk0 = c.nz_key[t];
+    // (the relabel kernels reserved their list stretches through VrgCtx::rsv, not through the state's own words: what they counted, beside the state)
+    uint64_t rsvA = 0, rsvB = 0;
+    if (c.rsv) { rsvA = vrg_load_u64(&c.rsv[0]); rsvB = vrg_load_u64(&c.rsv[16]); }
     const VrgState s0 = *c.st;
     if (s0.done || s0.bail) return;                    // (the same for every workgroup: the state is written by the last one to finish)
+    const uint32_t k_nalloc = c.rsv ? (uint32_t)rsvA : s0.nalloc, k_ndead = c.rsv ? (uint32_t)(rsvA >> 32) : s0.ndead, k_nmk = c.rsv ? (uint32_t)(rsvB >> 32) : s0.nmk;
     const int pc = ((s0.iter + 1) & 1) ^ 1;                              // parity of the change list the sweep before filed
     const uint32_t cdw0 = pc ? cdwB : cdwA, cx0 = pc ? cxB : cxA;
     __shared__ uint64_t s_key[NZ_SORT];
@@ -1087,11 +1308,11 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on, ui
     __shared__ int s_last;
     uint32_t nnz = c.lvl_scan ? 0u : min(s0.nnz, c.zcap);
     const bool use_tab = (c.lvl_scan || nnz <= NZ_SORT) && s0.tab_ok;   // fewer levels than entries: memoise per level
-    const uint32_t nmk = min(s0.nmk, c.mcap);
+    const uint32_t nmk = min(k_nmk, c.mcap);
     if (st0) { VRG_STAMP_PUT(c, 24, t_entry); VRG_STAMP(c, 25); }
     if (stm) VRG_STAMP_PUT(c, 32, t_entry);
     if (blockIdx.x < napply) {
-        const uint32_t nf = s0.nf, nd = s0.ndead, nalloc = s0.nalloc, nc = min(pc ? ncB : ncA, c.mcap);
+        const uint32_t nf = s0.nf, nd = k_ndead, nalloc = k_nalloc, nc = min(pc ? ncB : ncA, c.mcap);
         if (t == 0 && dense_on && (int64_t)s0.iter - 1 > rseq0) wait_dense_read(c);        // (the pass of two sweeps ago has read the class copy this sweep rewrites)
         __syncthreads();
         if (st0) VRG_STAMP(c, 26);
@@ -1104,7 +1325,7 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on, ui
         if (g < nf && !(fres0 & FR_WRITTEN)) vrg_store_i32(&c.stg->error, 3);       // a listed flip the relabel never visited
         for (uint32_t r = g + G; r < nf; r += G) vrg_item_check_flip(c, r);
         if (g < nd) vrg_free_entry(c, g, dead0, s0.nfree, nalloc);
-        for (uint32_t j = g + G; j < nd; j += G) vrg_item_free(c, j);
+        for (uint32_t j = g + G; j < nd; j += G) vrg_free_entry(c, j, c.dead[j], s0.nfree, nalloc);
         if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 27); }
         if (blockIdx.x == 0 && !c.lvl_scan && nnz > NZ_SORT) {           // (rare: a long level list is sorted in place in global memory)
             wg_sort_pairs(c.nz_key, (uint32_t*)nullptr, nnz, false);
@@ -1225,6 +1446,11 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     if constexpr (!BIGL) vrg_fuse_zero_other_levels(cg, zero_par ^ 1, r, gridDim.x, t, T);
     if (s0.done || s0.bail) return;
     if (st0) vrg_fuse_prepare_other(cg, s0);               // (the next trip's k_band counts its flips and ties into the other state buffer)
+    // replication's per-sweep streaming: the change log is complete up to the sweep BEFORE this one - its records were written by the k_sweep
+    // before, its header by that kernel or by the k_band in between: both have ended, nothing to drain (k_order / k_trip_open do the same for the other kinds of trip)
+#if !defined(VRG_NO_PUBLISH)                                    // (A/B build of tools/ab_publish.sh: what the publishing costs a plain handle's chain)
+    if (st0) vrg_log_publish(cg, s0.log_nsw, s0.log_pos, false);
+#endif
     const int32_t gate = vrg_fuse_gate(cg, s0, nin0, vrg_fuse_limit(cg));      // stop tests (:91-104) / can the sweep run fused: the same answer everywhere
     if (gate) {
         if (st0) {
@@ -1375,6 +1601,7 @@ __global__ void __launch_bounds__(TPB) k_trip_open(VrgCtx c) {   // stop tests a
     __shared__ int s_go;
     if (c.st->done || c.st->bail) return;
     if (threadIdx.x == 0) {
+        vrg_log_publish(c, c.st->log_nsw, c.st->log_pos, false);      // (as k_order: the sweep before this trip was closed by kernels that have ended)
         int go = 1;
         const int32_t stop = vrg_stop_test(c);
         if (stop || c.st->error) { c.stg->done = stop ? stop : -1; vrg_close_without_update(c); go = 0; }
@@ -2232,6 +2459,7 @@ VrgBackend* be_create(int device) {
 void be_destroy(VrgBackend* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
+    if (b->rsv) (void)hipFree(b->rsv);
     if (b->sa) (void)hipStreamSynchronize(b->sa);
     if (b->sb) (void)hipStreamSynchronize(b->sb);
     if (b->comm) { ncclCommDestroy(b->comm); b->comm = nullptr; }
@@ -2255,6 +2483,7 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "nt_loads") == 0) b->nt_loads = v < 0 ? -1 : (v != 0);
     if (std::strcmp(name, "iter_hint") == 0) b->iter_hint = (int)v;
     if (std::strcmp(name, "open_sweeps") == 0) b->open_sweeps = v != 0;
+    if (std::strcmp(name, "mark_compact") == 0) b->mark_compact = v != 0;
     if (std::strcmp(name, "band_hint") == 0) b->band_hint = (uint32_t)std::min<long long>(std::max<long long>(v, 0), 0x7fffffff);
     if (std::strcmp(name, "direct_hint") == 0) b->direct_hint = v != 0;
     if (std::strcmp(name, "dense_pipe") == 0) b->dense_pipe = (int)v;
@@ -2724,6 +2953,8 @@ static void host_driven_update(VrgBackend* b, const VrgCtx& c, int flags) {
 // update() for a sweep with few flips: three launches, nothing from the host in between
 static void small_update(VrgBackend* b, const VrgCtx& c0, bool dense, hipEvent_t e_chain_stop = nullptr) {
     VrgCtx c = c0;
+    if (!b->rsv) { HIP_CHECK(hipMalloc((void**)&b->rsv, 64 * sizeof(uint64_t))); if (b->rsv) HIP_CHECK(hipMemsetAsync(b->rsv, 0, 64 * sizeof(uint64_t), b->sa)); }
+    c.rsv = b->rsv;                                  // (the relabel kernels' list reservations: lines of their own)
     c.lvl_scan = c.L <= NZ_SORT ? 1 : 0;             // small level table: the touched levels are found by scanning the counters (k_close)
     // (sized by the flips of the last sweep the engine saw: a sweep of thousands of flips gets a workgroup per flip, not a queue of them;
     // a sweep with more flips than its launches can order is handed back - VBAIL_FLIPS - and enqueued again with launches that can)
@@ -2741,8 +2972,15 @@ static void small_update(VrgBackend* b, const VrgCtx& c0, bool dense, hipEvent_t
     const size_t lev_lds = ((c.L <= LEV_LDS && !c.lev16) ? (size_t)c.L * sizeof(double) : 0) + ((c.lvl_scan == 1 && c.L <= HIST_LDS) ? 5 * (size_t)c.L * sizeof(uint32_t) : 0);   // level table + per-level counts
     // (measured at 12 900 flips, ms per sweep: 4 flips at a time x 256 / 512 / 1024 workgroups 0.340 / 0.348 / 0.380; 2 x 1024 / 2048: 0.40 / 0.50; 1 x 2048 / 4096:
     // 0.52 / 0.70 - every workgroup more is six more reservations on the same few words)
-    if (2 * (uint64_t)fh > KM_BLOCKS) k_mark_relabel<4><<<KM_BLOCKS_WIDE, 4 * KM_THREADS, lev_lds, b->sa>>>(c);
-    else k_mark_relabel<1><<<KM_BLOCKS, KM_THREADS, lev_lds, b->sa>>>(c);
+    // (thousands of flips: the compact form first - a flip per half-wave, everything but flips with an excluded voxel in their cube - then the general
+    // form over the flips it left; option "mark_compact" = 0: the general form alone, as up to round 5)
+    if (2 * (uint64_t)fh > KM_BLOCKS) {
+        if (b->mark_compact) {
+            k_mark_compact<<<KMC_BLOCKS, KMC_THREADS, lev_lds, b->sa>>>(c, c.slow, c.counters + 48);
+            k_mark_relabel<4><<<KM_BLOCKS_WIDE, 4 * KM_THREADS, lev_lds, b->sa>>>(c, c.slow, c.counters + 48);
+        } else k_mark_relabel<4><<<KM_BLOCKS_WIDE, 4 * KM_THREADS, lev_lds, b->sa>>>(c, nullptr, nullptr);
+    }
+    else k_mark_relabel<1><<<KM_BLOCKS, KM_THREADS, lev_lds, b->sa>>>(c, nullptr, nullptr);
     // (waits on the device for the dense pass of two sweeps ago)
     const uint32_t napply = std::max<uint32_t>(CLOSE_APPLY, std::min<uint32_t>(1024u, fh / 8u));
     hipExtLaunchKernelGGL(k_close, dim3(napply + TAB_BLOCKS), dim3(KC_THREADS), 0, b->sa, nullptr, e_chain_stop, 0, c, dense ? 1 : 0, napply);

@@ -40,6 +40,9 @@ struct VrgRepl {
     uint32_t sent_sw = 0, sent_rec = 0;                 // leader (rccl / callback): sweeps / records of the open batch that have travelled
     uint64_t chunk_seq = 0;                             // chunks sent since the handle was created
     uint8_t* chunk_dev = nullptr;                       // rccl: the chunk struct's device slot
+    uint64_t* host_ready = nullptr;                     // rccl / callback: the progress word in page-locked HOST memory - the band chain stores it there (a posted write), the leader's
+                                                        // host thread reads it without a single HIP call (polling a device word with small copies slowed the chain 4x: every copy is a kernel + cache flush)
+    int64_t chunk_min = -1;                             // option "repl_chunk": sweeps a chunk waits for while its batch runs (-1: 8 over RCCL - three broadcasts per chunk -, 1 through callbacks)
     int64_t fault = 0;                                  // option "repl_fault" (tests): n > 0 - the leader fails on the host side when it opens its n-th batch; n < 0 - a follower cannot use its |n|-th chunk
     int32_t failed = 0;                                 // follower: the log could not be used (the run goes on taking chunks, and fails at its end on every rank)
     long long batches = 0, records = 0, sweeps = 0, verified = 0, last_verified = 0, chunks = 0;   // diagnostics
@@ -157,7 +160,7 @@ bool size_pool(vrg_handle* h, uint64_t want, uint32_t keep, uint32_t keep_free) 
     bool ok = grow(h, c.p_idx, keep, cap) && grow(h, c.p_lev, keep, cap) && grow(h, c.p_ip, keep, cap) && grow(h, c.p_op, keep, cap) && grow(h, c.p_err, keep, cap) &&
               grow(h, c.p_key, keep, cap) && grow(h, c.p_flag, keep, cap) && grow(h, c.freel, keep_free, cap) &&
               grow(h, c.flist, 0, cap) && grow(h, c.f_key, 0, cap) && grow(h, c.fr_idx, 0, cap) && grow(h, c.fr_lev, 0, cap) && grow(h, c.f_slot, 0, cap) && grow(h, c.f_idx, 0, cap) && grow(h, c.f_lev, 0, cap) &&
-              grow(h, c.f_res, 0, cap) && grow(h, c.pend, 0, cap) && grow(h, c.rk_part, 0, cap) && grow(h, c.fresh, keep, cap) &&
+              grow(h, c.f_res, 0, cap) && grow(h, c.pend, 0, cap) && grow(h, c.slow, 0, cap) && grow(h, c.rk_part, 0, cap) && grow(h, c.fresh, keep, cap) &&
               grow(h, c.init_key, 0, cap) && grow(h, c.init_idx, 0, cap);
     if (!ok) return false;
     if (cap > keep) be_fill(h->be, c.p_flag + keep, 0, cap - keep);
@@ -300,6 +303,7 @@ void API(destroy)(vrg_handle* h) {
     if (!h) return;
     be_sync(h->be);
     if (h->repl.host) be_host_free(h->be, h->repl.host);
+    if (h->repl.host_ready) be_host_free(h->be, h->repl.host_ready);
     if (h->repl.ctl_mapped) { be_ipc_close(h->be, h->repl.ctl); be_ipc_close(h->be, h->repl.peer_buf[0]); be_ipc_close(h->be, h->repl.peer_buf[1]); }
     for (void* p : h->owned) be_free(h->be, p);
     be_destroy(h->be);
@@ -321,10 +325,11 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "fused") h->fused = value != 0;
     else if (n == "bin_above") { if (value < 0) return fail(h, VRG_E_ARG, "bin_above: a number of levels >= 0"); h->bin_above = value; h->inited = false; }
     else if (n == "verify_every") { if (value < 0) return fail(h, VRG_E_ARG, "verify_every: 0 (never), 1 (every sweep: the default) or n > 1 (every n-th sweep)"); h->verify_every = (int)std::min<int64_t>(value, 1 << 20); be_set_tuning(h->be, name, value); }
-    else if (n == "open_sweeps") be_set_tuning(h->be, name, value);
+    else if (n == "open_sweeps" || n == "mark_compact") be_set_tuning(h->be, name, value);
     else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "fuse_max" || n == "memo_above" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads" || n == "dense_pipe") be_set_tuning(h->be, name, value);
     else if (n == "storage16") h->storage16 = value != 0;      // takes effect at the next vrg_init
     else if (n == "repl_fault") h->repl.fault = value;             // tests: a host-side failure in the middle of a replicated run (every rank must return an error, none may hang)
+    else if (n == "repl_chunk") h->repl.chunk_min = value;
     else if (n == "repl_stream") h->repl.stream = value != 0;      // any time between runs: 1 (default) the change log travels sweep by sweep; 0: once per batch of trips
     else if (n == "log_capacity") { if (h->repl.buf[0] || value < 1024 || value > 0x20000000ll) return fail(h, VRG_E_STATE, "log_capacity: 1024 .. 2^29 records, before the first vrg_run of a replicated handle"); h->repl.cap = (uint32_t)value; }
     else return fail(h, VRG_E_ARG, "unknown option " + n);

@@ -60,6 +60,8 @@ VRG_HD void vrg_store_i64(int64_t* p, int64_t v) { __hip_atomic_store(p, v, __AT
 VRG_HD void vrg_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 VRG_HD void vrg_store_u32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 VRG_HD void vrg_store_u64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ... and a word the HOST (page-locked memory) or another device polls: system scope
+VRG_HD void vrg_store_u64_sys(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 VRG_HD uint64_t vrg_load_u64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // atomics on a workgroup's LDS arrays (fused sweep)
 VRG_HD uint32_t vrg_lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
@@ -82,6 +84,7 @@ VRG_HD void vrg_store_i64(int64_t* p, int64_t v) { *p = v; }
 VRG_HD void vrg_drain() {}
 VRG_HD void vrg_store_u32(uint32_t* p, uint32_t v) { *p = v; }
 VRG_HD void vrg_store_u64(uint64_t* p, uint64_t v) { *p = v; }
+VRG_HD void vrg_store_u64_sys(uint64_t* p, uint64_t v) { *p = v; }
 VRG_HD uint64_t vrg_load_u64(const uint64_t* p) { return *p; }
 VRG_HD uint32_t vrg_lds_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 VRG_HD int32_t vrg_lds_add(int32_t* p, int32_t v) { int32_t o = *p; *p = o + v; return o; }
@@ -104,6 +107,7 @@ VRG_HD void vrg_store_i64(int64_t*, int64_t) { __builtin_trap(); }
 VRG_HD void vrg_drain() { __builtin_trap(); }
 VRG_HD void vrg_store_u32(uint32_t*, uint32_t) { __builtin_trap(); }
 VRG_HD void vrg_store_u64(uint64_t*, uint64_t) { __builtin_trap(); }
+VRG_HD void vrg_store_u64_sys(uint64_t*, uint64_t) { __builtin_trap(); }
 VRG_HD uint64_t vrg_load_u64(const uint64_t*) { __builtin_trap(); }
 VRG_HD uint32_t vrg_lds_add(uint32_t*, uint32_t) { __builtin_trap(); }
 VRG_HD int32_t vrg_lds_add(int32_t*, int32_t) { __builtin_trap(); }
@@ -956,24 +960,18 @@ VRG_HD void vrg_log_sweep(const VrgCtx& c, int64_t k, uint32_t base, uint32_t ns
     VrgLogSweep w;
     w.nflip = t.nflip; w.nseg = n_in; w.n_in = n_in; w.n_out = n_out; w.ni = t.ni; w.no = t.no; w.ties = t.ties; w.near_ties = t.near_ties;
     w.sweep = (uint32_t)k; w.nrec = nrec; w.rec0 = base - c.log_pos0; w.pad = 0;
-    // (written through: a sweep's header may be published - vrg_log_publish - by the very kernel that files it, and is then read by another
-    // device, or a copy engine, while this kernel still runs)
-    static_assert(sizeof(VrgLogSweep) == 10 * sizeof(uint64_t), "sweep header: ten 64-bit words");
-    uint64_t words[10]; __builtin_memcpy(words, &w, sizeof(w));
-    uint64_t* dst = reinterpret_cast<uint64_t*>(&c.log_sw[q]);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int i = 0; i < 10; i++) vrg_store_u64(dst + i, words[i]);
+    c.log_sw[q] = w;
     c.stg->log_pos = base + nrec; c.stg->log_nsw = nsw + 1u;
 }
-// The batch's log is complete up to `nsw` sweep headers / `pos` records (VrgState::log_nsw / log_pos of a CLOSED state): by ONE thread, when
-// every record up to there has been written by a kernel that has ended (a kernel's plain stores reach memory when it ends) and every header
-// by such a kernel or by this very thread (written through; drained here).  k_band's filing thread does it - for the sweep before its trip.
-VRG_HD void vrg_log_publish(const VrgCtx& c, uint32_t nsw, uint32_t pos) {
+// The batch's log is complete up to `nsw` sweep headers / `pos` records (VrgState::log_nsw / log_pos of a CLOSED state as a kernel finds it
+// at its entry): by ONE thread of the FIRST kernel of a trip's update() - k_sweep, k_order, k_trip_open - for the sweep before its trip: every
+// record and header up to there was written by kernels that have ENDED (a kernel's plain stores reach memory when it ends), so nothing has
+// to be drained or written through but the word itself.  (Publishing from k_band's filing thread - one kernel earlier - cost k_band 984 bytes
+// of scratch per thread: it runs at the limit of its scalar registers.)
+VRG_HD void vrg_log_publish(const VrgCtx& c, uint32_t nsw, uint32_t pos, bool drain = true) {
     if (!c.log_ready || !c.log_rec) return;
-    vrg_drain();
-    vrg_store_u64(c.log_ready, vrg_log_progress(c.log_seq, nsw - c.log_nsw0, pos - c.log_pos0));
+    if (drain) vrg_drain();                            // (false: the caller has stored nothing the word announces - everything was written by kernels that have ended)
+    vrg_store_u64_sys(c.log_ready, vrg_log_progress(c.log_seq, nsw - c.log_nsw0, pos - c.log_pos0));
 }
 // (a leader that enqueues no dense pass at all: the pass counters follow the sweeps, so that the handle stays consistent - which class copy
 // is current, what a later pass would wait for - and the sweep's trace record says that nobody here summed its intensities)
@@ -1057,6 +1055,12 @@ VRG_HD VrgState vrg_finalize_load(const VrgCtx& c, int64_t& n_in, int64_t& n_out
     s.d_ni = vrg_load_i32(&c.stg->d_ni); s.d_no = vrg_load_i32(&c.stg->d_no); s.error = vrg_load_i32(&c.stg->error);
     s.ties = vrg_load_u32(&c.stg->ties); s.near_ties = vrg_load_u32(&c.stg->near_ties);
     n_in = vrg_load_i64(&c.inc[VC_NIN]); n_out = vrg_load_i64(&c.inc[VC_NOUT]);
+    if (c.rsv) {                                      // (four-launch trips: the relabel kernels reserved through VrgCtx::rsv; whoever closes the sweep zeroes it)
+        const uint64_t a = vrg_load_u64(&c.rsv[0]), b = vrg_load_u64(&c.rsv[16]);
+        s.nalloc = (uint32_t)a; s.ndead = (uint32_t)(a >> 32); s.nfresh = (uint32_t)b; s.nmk = (uint32_t)(b >> 32);
+        s.d_ni = (int32_t)(uint32_t)vrg_load_u64(&c.rsv[32]); s.d_no = (int32_t)(uint32_t)vrg_load_u64(&c.rsv[48]);
+        c.rsv[0] = 0; c.rsv[16] = 0; c.rsv[32] = 0; c.rsv[48] = 0;
+    }
     return s;
 }
 // (tr: the integer fields of the sweep's trace record; no memory is touched here: vrg_finalize_store files what has to be filed)

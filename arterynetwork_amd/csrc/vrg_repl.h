@@ -17,14 +17,15 @@
 //
 // THE LOG TRAVELS SWEEP BY SWEEP (round 6; it used to move once per batch of trips, so a follower started a batch late and the run ended
 // a batch late).  The trips are still enqueued in batches (option "batch") into one of two buffers, but the leader's band chain PUBLISHES
-// how far the batch's log is complete in a 64-bit progress word (VrgCtx::log_ready, vrg_log_publish): k_band of trip k+1 does it for sweep k
-// - its records were written by kernels that have ended, its header is written through and drained.  Only the last sweep of a batch waits
-// for the host, which closes the batch (VrgLogBatch) when its trips are done.  Three transports:
+// how far the batch's log is complete in a 64-bit progress word (VrgCtx::log_ready, vrg_log_publish): the first kernel of trip k+1's update()
+// (k_sweep, k_order, k_trip_open) does it for sweep k - its records and its header were written by kernels that have ended.  Only the last
+// sweep of a batch waits for the host, which closes the batch (VrgLogBatch) when its trips are done.  Three transports:
 //   ipc       the followers map the leader's batch buffers and control block (hipIpc) and poll the progress word themselves; what is new
 //             they copy out - headers to the host, records device to device, over xGMI between GPUs; an `ack` word per follower tells
 //             the leader when a buffer may be written again
-//   rccl      the leader's host polls its own progress word while the batch runs and broadcasts what is new as a CHUNK (VrgLogChunk, the
-//             sweep headers, the records: ncclBroadcast on the transport stream, straight out of the batch buffer)
+//   rccl      the progress word lives in page-locked HOST memory: the band chain posts it there, the leader's host thread reads it without
+//             touching the GPU and broadcasts what is new - eight sweeps or more - as a CHUNK (VrgLogChunk, the sweep headers, the
+//             records: ncclBroadcast on the transport stream, straight out of the batch buffer)
 //   callback  the same chunks through a caller-supplied broadcast of host buffers (tests: torch.distributed / gloo; any other fabric)
 // A follower's lag is one poll + one copy, not one batch.  At the end of a run every rank holds the same labels, `segmented` order and
 // trace; the intensity sums each verifier filed are exchanged with one small all-reduce.
@@ -113,7 +114,14 @@ static int repl_open_batch(vrg_handle* h, const VrgState& s) {
     VrgCtx& c = h->c;
     c.log_rec = repl_rec_of(r, buf); c.log_sw = repl_sw_of(buf); c.log_cap = r.cap; c.log_swcap = r.swcap;
     c.log_pos0 = s.log_pos; c.log_nsw0 = s.log_nsw;
-    c.log_ready = (r.stream && r.ctl) ? reinterpret_cast<uint64_t*>(r.ctl) + IPC_SW : nullptr;
+    // where the band chain publishes the batch's progress: the control block (device memory the followers have mapped) on ipc; page-locked
+    // host memory otherwise - this rank's host thread polls it while the batch runs, and must not touch the GPU to do so
+    c.log_ready = nullptr;
+    if (r.stream && r.transport == TR_IPC && r.ctl) c.log_ready = reinterpret_cast<uint64_t*>(r.ctl) + IPC_SW;
+    else if (r.stream && (r.transport == TR_RCCL || r.transport == TR_CALLBACK)) {
+        if (!r.host_ready) { r.host_ready = (uint64_t*)be_host_alloc(h->be, 64); if (r.host_ready) std::memset(r.host_ready, 0, 64); }
+        c.log_ready = r.host_ready;                    // (null: no streaming - the batch travels when it closes)
+    }
     c.log_seq = (uint32_t)(n & ((1ull << VRG_LOG_SEQ_BITS) - 1ull));
     r.sent_sw = 0; r.sent_rec = 0; r.open = true;
     return VRG_OK;
@@ -146,11 +154,11 @@ static int repl_send_chunk(vrg_handle* h, uint64_t n, uint32_t nsw, uint32_t nre
 // last look goes out.  Returns 1 when something was sent, 0 when not, < 0 on failure.
 static int repl_pump(vrg_handle* h) {
     VrgRepl& r = h->repl;
-    if (!r.stream || !r.open || (r.transport != TR_RCCL && r.transport != TR_CALLBACK)) return 0;
-    uint64_t w = 0;
-    be_repl_copy(h->be, &w, r.ctl + 8 * IPC_SW, 8);
+    if (!r.stream || !r.open || !r.host_ready || (r.transport != TR_RCCL && r.transport != TR_CALLBACK)) return 0;
+    const uint64_t w = *reinterpret_cast<volatile uint64_t*>(r.host_ready);
     uint32_t nsw = 0, nrec = 0;
-    if (!repl_progress_of(w, r.seq + 1, nsw, nrec) || nsw <= r.sent_sw) return 0;
+    const uint32_t least = r.chunk_min > 0 ? (uint32_t)r.chunk_min : (r.transport == TR_RCCL ? 8u : 1u);
+    if (!repl_progress_of(w, r.seq + 1, nsw, nrec) || nsw < r.sent_sw + least) return 0;
     if (nsw > r.swcap || nrec > r.cap || nrec < r.sent_rec) return fail(h, VRG_E_INTERNAL, "replication: the change log's progress word is out of range");
     const int rc = repl_send_chunk(h, r.seq + 1, nsw, nrec, nullptr);
     return rc ? rc : 1;

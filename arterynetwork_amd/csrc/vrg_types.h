@@ -301,6 +301,7 @@ struct VrgCtx {
     uint32_t* f_lev;           // ... and intensity level of flip r
     uint8_t* f_res;            // FR_* result of flip r
     uint32_t* pend;            // ranks of the flip-ins in the skip-rule fix-point
+    uint32_t* slow;            // four-launch trips with thousands of flips: the flips (ranks) k_mark_compact leaves to k_mark_relabel - an excluded voxel within their 5x5x5 cube (count: counters[48])
     uint32_t* rk_part;         // chip-wide ordering (k_rank_wide): the number of smaller keys found so far, per listed flip; all zero between sweeps
     uint32_t* fresh;           // slots needing exact densities
     // dense statistics partials (one slot per sweep workgroup)
@@ -344,7 +345,7 @@ struct VrgCtx {
     VrgLogRec* log_rec; VrgLogSweep* log_sw;
     uint32_t log_cap, log_swcap;       // capacities of the two arrays
     uint32_t log_pos0, log_nsw0;       // VrgState::log_pos / log_nsw when the batch's buffer was opened
-    uint64_t* log_ready;               // the batch's progress word (vrg_log_progress): written through by the band chain once a sweep's header and records are complete (null: nobody streams)
+    uint64_t* log_ready;               // the batch's progress word (vrg_log_progress): written (system scope) by the first kernel of the next trip's update(), when the sweep's header and records are complete (null: nobody streams)
     uint32_t log_seq;                  // ... and the batch's number
     // which dense passes this handle counts: sweep k is counted by verifier ((k / every) - 1) % ver_n (vrg_dense_skipped); ver_me = this
     // handle's place among the verifiers, -1: it counts none.  One GPU: ver_n = 1, ver_me = 0.
@@ -352,6 +353,11 @@ struct VrgCtx {
     int64_t* fexp;             // a follower's next count: {sweep, n_in, n_out} it has to reproduce
     int32_t dense_none;        // no dense pass is enqueued at all (a leader that verifies nothing): the band side keeps the pass counters in step itself
     uint32_t* counters;        // arrival tickets of the last-workgroup reductions (zero between launches)
+    // four-launch trips: where the relabel kernels' workgroups RESERVE their stretches of the sweep's lists - VrgState::nalloc / ndead / nfresh / nmk / d_ni / d_no kept
+    // outside the state, on cache lines of their own: [0] nalloc | ndead << 32, [16] nfresh | nmk << 32 (one returning 64-bit add each), [32] d_ni, [48] d_no (32-bit).
+    // Same-address atomics execute one after the other at the memory side (~10-17 ns each): six per workgroup on ONE line were 26-78 us of k_mark_relabel at 12 900
+    // flips per sweep (profiles/NOTES_r05.md).  k_close reads them beside the state and zeroes them when it closes the sweep.  null: the state's own words (every other kind of trip).
+    uint64_t* rsv;
     uint64_t* dbg;             // diagnostic build only (-DVRG_STAMPS): in-kernel time stamps of the band chain, see tools/chain_stamps.py
     VrgTrace* trace;
     uint32_t trace_cap;

@@ -221,7 +221,12 @@ def bench_volume_torch(shape, device, seed=3, levels=255, radius=4.0, noise=0.1,
     ``levels=None`` keeps the continuous float32 noise (one distinct value per voxel, nearly).
     ``tubes`` > 1: that many disjoint tubes on a lattice (tube_lattice), seeded at the central x planes so that every tube
     grows both ways - about 100 flips per tube and sweep: the many-flip regime.  ``seed_mode='whole'``: every tube voxel
-    is a seed (what refine() does with a stage-1 mask: all vessels at once)."""
+    is a seed (what refine() does with a stage-1 mask: all vessels at once).  ``seed_mode='noisy-mask'``: the seed is a
+    PERTURBED vessel mask, what a vesselness threshold hands to this stage (generateVesselVolume.py:187-199; README.md:69-71: VRG
+    smooths an existing mask) - the tube mask with a random half of its surface voxels (26-connected erosion) taken off, plus
+    everything within two voxels of 0.6 % of them ("bites"), plus salt: isolated false positives, 2 % of the mask's voxel count (a tenth of
+    them 3x3x3 blobs), anywhere in the volume - inside the brain mask or out of it (a seed overrides the excluded label).  The first
+    sweep then flips 10^4-10^5 voxels and the count decays over a few sweeps to convergence."""
     import math
     import torch
     nx, ny, nz = shape
@@ -247,6 +252,19 @@ def bench_volume_torch(shape, device, seed=3, levels=255, radius=4.0, noise=0.1,
         seeds = tube & (xs >= nx // 2 - (seed_planes + 1) // 2) & (xs < nx // 2 + seed_planes // 2)
     if seed_mode == 'whole':
         seeds = tube
+    elif seed_mode == 'noisy-mask':
+        import torch.nn.functional as F
+        outside = (~tube).to(torch.float32)[None, None]
+        eroded = F.max_pool3d(outside, kernel_size=3, stride=1, padding=1)[0, 0] < 0.5      # no non-tube voxel among the 26 neighbours (the volume's faces count as tube)
+        surface = tube & ~eroded
+        u = torch.rand((nz, ny, nx), generator=g, device=device, dtype=torch.float32)
+        salt_p = 0.02 * float(tube.sum().item()) / float(nx * ny * nz)
+        # bites: everything within two voxels of 0.6 % of the surface voxels is missing too (a threshold loses stretches of a thin vessel, not single
+        # voxels), and a tenth of the salt comes as 3x3x3 blobs - so the mask is several sweeps away from its fixed point, not one
+        bite = F.max_pool3d((surface & (u > 0.5) & (u < 0.506)).to(torch.float32)[None, None], kernel_size=5, stride=1, padding=2)[0, 0] > 0.5
+        blob = F.max_pool3d((~tube & (u > 1.0 - 0.1 * salt_p)).to(torch.float32)[None, None], kernel_size=3, stride=1, padding=1)[0, 0] > 0.5
+        seeds = (tube & ~(surface & (u < 0.5)) & ~bite) | (~tube & ((u > 1.0 - salt_p) | blob))
+        del outside, eroded, surface, u, bite, blob
     I = torch.randn((nz, ny, nx), generator=g, device=device, dtype=torch.float32)
     I.mul_(noise).add_(tube.to(torch.float32))
     if levels:

@@ -52,6 +52,8 @@ def side_line(shape, dev, args, configure, roofline, kind):
     import torch
     from arterynetwork_amd import phantoms
     from arterynetwork_amd._capi import Session
+    if kind == 'refine_like':
+        return refine_like_line(dev, args, configure)
     if kind == 'nomask':
         shp, kw, W, K = shape, dict(brain_mask=False), 10, 100
     else:
@@ -85,6 +87,50 @@ def side_line(shape, dev, args, configure, roofline, kind):
         out.update({'flips_per_sweep_mean': round(float(tr['nflip'][W + 1:].mean()), 1), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
                     'host_driven_trips': st['host_driven_trips'] - st0['host_driven_trips'], 'fused_trips': st['fused_trips'] - st0['fused_trips'],
                     'value': round(shp[0] * shp[1] * shp[2] * r.sweeps / dt / 1e6, 1), 'unit': 'Mvoxel-iter/s'})
+    s.close()
+    del I, vm
+    torch.cuda.empty_cache()
+    return out
+
+
+def refine_like_line(dev, args, configure, shp=(512, 512, 170), tubes=16, iter_max=400):
+    """What the pipeline uses this stage for (README.md:69-71, :209 of the reference: VRG smooths an existing vessel mask): the seed is a
+    perturbed mask of ALL vessels at once (phantoms.bench_volume_torch seed_mode='noisy-mask': half the surface eroded + 2 % salt), run
+    to CONVERGENCE (the reference's first stop test, :91).  Reported: flips of the first ten sweeps, sweeps and seconds to convergence
+    (vrg_init + the sweeps; inputs resident in HBM), how the trips ran.  Not the headline metric - a time-to-solution figure."""
+    import torch
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session
+    I, vm = phantoms.bench_volume_torch(shp, dev, levels=args.levels, tubes=tubes, seed_mode='noisy-mask')
+    nseed = int((vm == 0).sum().item())
+    torch.cuda.synchronize()
+    s = Session(shp, device=dev.index)
+    configure(s, args)
+    s.set_option('events', 0); s.set_option('chain_events', 0)
+    s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
+    s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.init(args.H)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t0
+    st0 = s.stats()
+    t0 = time.perf_counter()
+    r = s.run(iter_max, 10 ** 15, None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st, tr = s.stats(), s.trace()
+    nfl = tr['nflip'][1:]
+    sweeps = int(r.sweeps)
+    fused = st['fused_trips'] - st0['fused_trips']
+    host = st['host_driven_trips'] - st0['host_driven_trips']
+    out = {'workload': '{}x{}x{}, {} tubes, seed = perturbed mask of all of them (half the surface eroded + 2 % salt): {} seed voxels'.format(shp[0], shp[1], shp[2], tubes, nseed),
+           'stop_reason': {1: 'converged', 2: 'time', 3: 'size', 4: 'itermax'}.get(int(r.stop_reason), str(int(r.stop_reason))), 'converged': bool(r.stop_reason == 1),
+           'sweeps_to_convergence': sweeps, 'seconds_to_convergence': round(t_init + dt, 4), 'init_seconds': round(t_init, 4), 'sweeps_seconds': round(dt, 4),
+           'ms_per_sweep_mean': round(dt / max(1, sweeps) * 1e3, 4), 'flips_first_10_sweeps': [int(v) for v in nfl[:10]], 'flips_total': int(nfl.sum()),
+           'nseg_start': int(tr['nseg'][0]), 'nseg_end': int(tr['nseg'][-1]), 'band_end': int(tr['ni'][-1] + tr['no'][-1]),
+           'trips': {'fused': int(fused), 'host_driven': int(host), 'four_launch': int(max(0, sweeps - fused - host)), 'handed_back': int(st['bail_flips'] + st['bail_fuse'] - st0['bail_flips'] - st0['bail_fuse'])},
+           'ties': int(r.ties), 'valid': bool(r.stop_reason == 1)}
     s.close()
     del I, vm
     torch.cuda.empty_cache()
@@ -367,7 +413,9 @@ def main():
     ap.add_argument('--serial', type=int, default=0, help='1: option serial_streams (needed under rocprofv3 --pmc, which runs one kernel at a time)')
     ap.add_argument('--storage16', action='store_true', help='16-bit intensity storage (level indices): config 5 style; 4 B/voxel-iter algorithmic')
     ap.add_argument('--tubes', type=int, default=1, help='disjoint tubes of the synthetic volume (SURVEY 8(d) config 5: "several disjoint tubes"): about 100 flips per tube and sweep')
-    ap.add_argument('--seed-mode', default='planes', choices=['planes', 'whole'], help="'whole': every tube voxel is a seed (what refine() does with a stage-1 mask)")
+    ap.add_argument('--seed-mode', default='planes', choices=['planes', 'whole', 'noisy-mask'], help="'whole': every tube voxel is a seed; 'noisy-mask': a perturbed mask of all "
+                    "tubes (half the surface eroded + 2 %% salt) - what refine() hands this stage")
+    ap.add_argument('--refine-like', action='store_true', help='only the refine()-shaped workload: perturbed mask of 16 tubes at 512x512x170 run to convergence; prints its record')
     ap.add_argument('--force-dist', action='store_true', help='one GPU: measure the roles of an N-rank group one after the other (replica partition), or run the '
                     'N>1 code path with a one-rank communicator (zslab partition)')
     ap.add_argument('--partition', default='replica', choices=['replica', 'zslab'], help="N > 1: 'replica' = one leader (band chain + change log), the other ranks apply the "
@@ -437,6 +485,9 @@ def main():
         return
 
     from arterynetwork_amd._capi import Session
+    if args.refine_like:
+        print(json.dumps({'refine_like': refine_like_line(dev, args, configure, tubes=max(16, args.tubes) if args.tubes > 1 else 16)}), flush=True)
+        return
     I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels, brain_mask=not args.no_brain_mask, integer_values=args.integer_values,
                                         tubes=args.tubes, seed_mode=args.seed_mode)
     torch.cuda.synchronize()
@@ -507,6 +558,7 @@ def main():
         torch.cuda.empty_cache()
         out['roofline_nomask'] = side_line(shape, dev, args, configure, roofline, 'nomask')
         out['many_flip'] = side_line(shape, dev, args, configure, roofline, 'many_flip')
+        out['refine_like'] = side_line(shape, dev, args, configure, roofline, 'refine_like')
         I, vm = phantoms.bench_volume_torch(shape, dev, levels=args.levels, brain_mask=not args.no_brain_mask, integer_values=args.integer_values)   # (the cpu_baseline's volume)
     if not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(I, vm, args.H, lev_note)

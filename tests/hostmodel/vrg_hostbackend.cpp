@@ -340,7 +340,7 @@ void be_sweep_once(VrgBackend* b, VrgCtx& c0, int flags, VrgEvents*, be_reduce_f
         vrg_deferred_done(c0, k);
         if (!(flags & VRG_SWEEP_NODENSE)) dense_pass(b, c0, cb, user);   // its dense pass (the device: gate + recount on the other stream, asked for by vrg_deferred_done)
     }
-    vrg_log_publish(c0, derived.log_nsw, derived.log_pos);             // (k_band's filing thread: the change log is complete up to the sweep before this trip)
+    vrg_log_publish(c0, derived.log_nsw, derived.log_pos, false);      // (the first kernel of the trip's update(): the change log is complete up to the sweep before this trip)
     // the per-launch modes of the batched kernels, alternated so that both forms of every item function run here: the
     // touched levels listed by atomics / found by scanning the counters; a flip's level fetched through its rank / looked up
     VrgCtx c = c0;

@@ -809,6 +809,25 @@ def test_many_flip_sweeps_vs_oracle(lib):
         o.close()
 
 
+def test_refine_like_mask_to_convergence_vs_oracle(lib):
+    """What the pipeline uses this stage for (the reference's README.md:69-71, :209: VRG smooths an existing vessel mask): the seed is a
+    PERTURBED mask of all vessels at once (phantoms.bench_volume_torch seed_mode='noisy-mask': a random half of the mask's surface taken
+    off + 2 % salt, inside the brain mask and out of it), run to CONVERGENCE (:91) - thousands of flips in the first sweeps, then a
+    decaying count, so the run passes through every kind of trip.  Labels, both band lists (order and densities), `segmented` order and
+    the whole trace must equal the oracle's; so must the same run with the trips forced host-driven / never fused."""
+    import torch
+    from arterynetwork_amd import phantoms
+    shape = (256, 192, 96)
+    I, vm = phantoms.bench_volume_torch(shape, torch.device('cpu'), tubes=16, seed_mode='noisy-mask')
+    d = np.asfortranarray(I.numpy().astype(np.float64)); v = np.asfortranarray(vm.numpy())
+    res, k = parity.run_batched(lib, d, v, iterMax=300)
+    assert res is not None, 'the oracle met an exact tie at sweep %d: the workload does not pin parity' % k
+    assert res.stop_reason == 1 and k >= 3, (res.stop_reason, k)
+    for opts in ({'small_flips': 600}, {'fused': 0, 'batch': 3}):
+        r2, k2 = parity.run_batched(lib, d, v, iterMax=300, options=opts)
+        assert r2 is not None and k2 == k and r2.stop_reason == 1, (opts, k2, k)
+
+
 def test_two_live_sessions_are_independent(lib, golden_loader):
     """Two handles in one process (own streams, events and state each): their sweeps interleaved call by call, both
     must reproduce the oracle."""

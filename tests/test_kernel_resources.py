@@ -15,7 +15,7 @@ CSRC = os.path.join(ROOT, 'arterynetwork_amd', 'csrc')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # kernel name fragment (mangled) -> most VGPRs (arch + accumulation) it may use
 BUDGET = {'6k_bandILi4E': 170, '6k_bandILi8E': 170, '6k_bandILi16E': 170, '7k_sweepILb0E': 150, '7k_sweepILb1E': 130, '7k_orderE': 64, '14k_mark_relabelILi1E': 144,
-          '14k_mark_relabelILi4E': 128, '7k_closeE': 110, '6k_gateE': 64, '14k_recount_pipeILi3ELb0E': 144, '14k_recount_pipeILi3ELb1E': 144, '11k_rank_wideE': 64}
+          '14k_mark_relabelILi4E': 144, '14k_mark_compactE': 168, '7k_closeE': 110, '6k_gateE': 64, '14k_recount_pipeILi3ELb0E': 144, '14k_recount_pipeILi3ELb1E': 144, '11k_rank_wideE': 64}
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='no hipcc')

@@ -1,8 +1,16 @@
 #!/bin/bash
 # Per-kernel time of one command under rocprofv3 (kernel trace + stats only), top kernels printed and the stats CSV kept.
-# usage: tools/kstats.sh <tag> <program> [args...]      -> gpurun_out/kstats_<tag>/
+# usage: tools/kstats.sh <tag> python3 <script.py> [args...]   (or an ELF binary)   -> gpurun_out/kstats_<tag>/
+# The program right behind `rocprofv3 --` must be the interpreter or binary itself: a script with a `#!/usr/bin/env` line, `env`, `bash -c`
+# or any other launcher that re-execs is an exec from a process the profiler's preloaded library has already initialised the GPU in -
+# forbidden on this pool (it takes the machine down).  So: refuse anything that is not python3 / an ELF file.
 set -u
-TAG=${1:?usage: kstats.sh <tag> <program> [args...]}; shift
+TAG=${1:?usage: kstats.sh <tag> python3 <script.py> [args...]}; shift
+prog=${1:?program}
+case "$(basename "$prog")" in
+  python3|python3.*) ;;
+  *) if ! head -c 4 "$prog" 2>/dev/null | grep -q ELF; then echo "kstats.sh: '$prog' is neither python3 nor an ELF binary - run scripts as: kstats.sh <tag> python3 script.py ..." >&2; exit 2; fi ;;
+esac
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT="gpurun_out/kstats_$TAG"; rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- "$@" > "$OUT/run.log" 2>&1

@@ -49,7 +49,9 @@ for smp in range(samples):
     xcc = (hw >> 32) & 0xf; cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
     cuid = xcc * 1000 + se * 100 + sh * 10 + cu
     per_cu = np.bincount(np.unique(cuid, return_inverse=True)[1])
-    rec = {'workgroups': int(len(a)), 'with_flips': int(worked.sum()), 'rounds_mean': float(nround[worked].mean()),
+    mid = a[:, 16] > 0
+    rec = {'mid_flush_us_p50_p90 (compact kernel: the filing after two rounds)': [pct(((a[:, 17] - a[:, 16]) * 0.01)[mid], 50), pct(((a[:, 17] - a[:, 16]) * 0.01)[mid], 90), int(mid.sum())],
+           'workgroups': int(len(a)), 'with_flips': int(worked.sum()), 'rounds_mean': float(nround[worked].mean()),
            'entry_us_p50_p90_max': [pct(entry, 50), pct(entry, 90), float(entry.max())],
            'exit_us_p10_p50_p90_max': [pct(ex[worked], 10), pct(ex[worked], 50), pct(ex[worked], 90), float(ex[worked].max())],
            'round_us_first_p50_p90': [pct(rd[worked, 0], 50), pct(rd[worked, 0], 90)],
