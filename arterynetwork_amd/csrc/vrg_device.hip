@@ -75,6 +75,7 @@ struct VrgBackend {
                                                       // (its request comes from THIS trip's k_band; if that trip stopped or handed itself back, the stop word makes the gate leave)
     bool prev_open = false;                           // ... and its sweep was open-ended: this trip's k_band derives the closed state (and lists the touched levels itself)
     int open_par = 0;                                 // ... the set of per-level counters it filled
+    uint32_t band_blocks_max = 2048;                  // option "band_blocks_max": most workgroups k_band uses for the pool (BAND_BLOCKS)
     uint64_t* rsv = nullptr;                          // VrgCtx::rsv of this handle's four-launch trips (64 words, zero between sweeps)
     int mark_compact = 1;                             // option "mark_compact": four-launch trips of thousands of flips relabel with k_mark_compact (+ k_mark_relabel for what it leaves)
     int open_sweeps = 1;                              // option "open_sweeps": fused sweeps inside a batch end at their commit, without a closing workgroup
@@ -346,11 +347,11 @@ __device__ __forceinline__ void wait_dense_read_for(const VrgCtx& c, int64_t nee
 }
 // the deferred work of this workgroup has reached memory; the LAST of the `n` workgroups to say so closes it (vrg_deferred_done)
 __device__ __forceinline__ void band_deferred_done(const VrgCtx& c, int k, uint32_t n) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    vrg_drain();
     __syncthreads();
     if (threadIdx.x == 0) {
         VRG_CHAOS_POINT(10);
-        const uint32_t q = __hip_atomic_fetch_add(&c.counters[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t q = __hip_atomic_fetch_add(&c.counters[32], 1u, VRG_MO_TICKET, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(VRG_MUTANT)      // (tools/mutant_check.py: a deliberately broken hand-off - the FIRST workgroup to arrive asks for the dense pass - that the campaigns must catch)
         if (q == n - 1u) c.counters[32] = 0;
         if (q == 0u) vrg_deferred_done(c, k);
@@ -516,7 +517,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
         if (sunk) { if (tid == 0) s_sink.n = 0; __syncthreads(); }
         exact_wg(c, s, s.nfx, blockIdx.x - band_blocks, EXACT_BLOCKS, nin0, nout0, sunk ? &s_sink : nullptr);
         if (sunk) band_sink_file(c, s_sink, tid);
-        if (stx && live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP_PUT(c, 3, t_entry); VRG_STAMP(c, 4); }
+        if (stx && live) { vrg_drain(); VRG_STAMP_PUT(c, 3, t_entry); VRG_STAMP(c, 4); }
         return;
     }
     const bool direct = s.corr && !s.use_tab;
@@ -534,7 +535,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
             for (uint32_t slot = gtid; slot < s.np; slot += band_blocks * TPB)
                 vrg_item_band(c, s, slot, c.nz_val, c.nz_cin, c.nz_cout, c.nz_cconv, s_raw, tab_n, nin0, nout0, sink);
         if (sink) band_sink_file(c, s_sink, tid);
-        if (st0 && live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 2); }
+        if (st0 && live) { vrg_drain(); VRG_STAMP(c, 2); }
         return;
     }
     __syncthreads();                                      // (everyone is done staging the memo head: the block changes hands)
@@ -604,7 +605,7 @@ __global__ void __launch_bounds__(TPB) k_band(VrgCtx c, uint32_t band_blocks, in
         }
     }
     if (sink) band_sink_file(c, s_sink, tid);
-    if (st0 && live) { VRG_STAMP(c, 40); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 2); }
+    if (st0 && live) { VRG_STAMP(c, 40); vrg_drain(); VRG_STAMP(c, 2); }
 }
 
 // ---- sorting inside one workgroup -------------------------------------------------------------------------
@@ -753,7 +754,7 @@ __global__ void __launch_bounds__(KO_THREADS) k_order(VrgCtx c, uint32_t small_l
     if (t == 0) VRG_STAMP(c, 11);
     for (uint32_t r = t; r < nf; r += T) vrg_item_prepass(c, r);         // phase-A label of the flip-ins
     __syncthreads();
-    if (t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 12); }
+    if (t == 0) { vrg_drain(); VRG_STAMP(c, 12); }
     const uint32_t np_ = vrg_load_u32(&c.st->npend);
     if (np_) {                                                           // skip-rule fix-point (rare)
         for (;;) {
@@ -973,7 +974,7 @@ __global__ void __launch_bounds__(KM_THREADS * G) KM_STAMP_OCC k_mark_relabel(Vr
         }
         if (t < KM_ROWS) { s_tile[4 * t] = row.x; s_tile[4 * t + 1] = row.y; s_tile[4 * t + 2] = row.z; s_tile[4 * t + 3] = row.w; }
         __syncthreads();
-        if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 18); }
+        if (st0) { vrg_drain(); VRG_STAMP(c, 18); }
 #if defined(VRG_STAMPS)
         const uint32_t rnd_ = (rb - blockIdx.x * G) / (gridDim.x * G);          // (phases of rounds 0 and 2, every workgroup: words 16.. / 20..)
         const uint32_t ph_ = rnd_ == 0u ? 16u : rnd_ == 2u ? 20u : 64u;
@@ -1017,7 +1018,7 @@ __global__ void __launch_bounds__(KM_THREADS * G) KM_STAMP_OCC k_mark_relabel(Vr
         }
         const uint32_t lev_here = (wanted && c.lev_fast) ? vrg_pre_level(c, pre) : 0xffffffffu;
         const bool first = wanted && !((old >> sh) & VB_M);
-        if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 19); }
+        if (st0) { vrg_drain(); VRG_STAMP(c, 19); }
         // the first marker's voxel and its event take their places in the workgroup's buffers (one wave-wide count each: LDS atomics)
         if (st0) VRG_STAMP(c, 23);
 #if defined(VRG_STAMPS)
@@ -1047,7 +1048,7 @@ __global__ void __launch_bounds__(KM_THREADS * G) KM_STAMP_OCC k_mark_relabel(Vr
         VRG_STAMP_WG(c, ph_ + 2u);                                         // (wave 0's own stencils are done)
 #endif
         __syncthreads();                                                  // (the buffers are consistent; the tile may be overwritten)
-        if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 20); }
+        if (st0) { vrg_drain(); VRG_STAMP(c, 20); }
         VRG_STAMP_WG(c, min(11u, 2u + (rb - blockIdx.x * G) / (gridDim.x * G)));
     }
     VRG_STAMP_WG(c, 12);
@@ -1058,10 +1059,10 @@ __global__ void __launch_bounds__(KM_THREADS * G) KM_STAMP_OCC k_mark_relabel(Vr
             const uint32_t n = s_hist[l];                                 // (the histograms' changes are signed: the same bits)
             if (n) { const uint32_t k = l / cg.L, lv = l - k * cg.L; atomicAdd((k == 0 ? cg.dIn : k == 1 ? cg.dOut : k == 2 ? cg.dConv : k == 3 ? (uint32_t*)cg.hin : (uint32_t*)cg.hout) + lv, n); }
         }
-    if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 21); }
-    if (t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP_MAX(c, 22); }
+    if (st0) { vrg_drain(); VRG_STAMP(c, 21); }
+    if (t == 0) { vrg_drain(); VRG_STAMP_MAX(c, 22); }
 #if defined(VRG_STAMPS)
-    if (tt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tt == 0) vrg_drain();
 #endif
     VRG_STAMP_WG(c, 14);
 }
@@ -1259,7 +1260,7 @@ __global__ void __launch_bounds__(KMC_THREADS) k_mark_compact(VrgCtx cg, uint32_
             if (n) { const uint32_t w = k / cg.L, lv = k - w * cg.L; atomicAdd((w == 0 ? cg.dIn : w == 1 ? cg.dOut : w == 2 ? cg.dConv : w == 3 ? (uint32_t*)cg.hin : (uint32_t*)cg.hout) + lv, n); }
         }
 #if defined(VRG_STAMPS)
-    if (tt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tt == 0) vrg_drain();
     VRG_STAMP_WG(c, 14);
 #endif
 }
@@ -1317,8 +1318,20 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on, ui
         __syncthreads();
         if (st0) VRG_STAMP(c, 26);
         // the sweep's label bytes (+ class bits, region sizes; the change filed at the voxel's place of the marked list)
-        if (g < nmk) vrg_apply_at(c, g, mk0, old0, mn0, s0.log_pos);
-        for (uint32_t i = g + G; i < nmk; i += G) vrg_apply_at(c, i, c.mk_idx[i], c.mk_old[i], c.mk_new[i], s0.log_pos);
+        // (the region sizes: every thread adds up what its voxels change, the workgroup sends ONE pair of atomics - vrg_count_change_at)
+        int acc[2] = {0, 0};
+        if (g < nmk) vrg_apply_at(c, g, mk0, old0, mn0, s0.log_pos, acc);
+        for (uint32_t i = g + G; i < nmk; i += G) vrg_apply_at(c, i, c.mk_idx[i], c.mk_old[i], c.mk_new[i], s0.log_pos, acc);
+        {
+            int din = acc[0], dout = acc[1];
+            for (int o = 32; o > 0; o >>= 1) { din += __shfl_xor(din, o, 64); dout += __shfl_xor(dout, o, 64); }
+            __shared__ int s_acc[2];
+            if (t == 0) { s_acc[0] = 0; s_acc[1] = 0; }
+            __syncthreads();
+            if ((t & 63u) == 0u) { if (din) atomicAdd(&s_acc[0], din); if (dout) atomicAdd(&s_acc[1], dout); }
+            __syncthreads();
+            if (t == 0) { if (s_acc[0]) vrg_atomic_add64(&c.inc[VC_NIN], s_acc[0]); if (s_acc[1]) vrg_atomic_add64(&c.inc[VC_NOUT], s_acc[1]); }
+        }
         // the class changes of the sweep before go into this sweep's copy of the class bits
         if (g < nc) vrg_catchup_entry(c, cdw0, cx0);
         for (uint32_t i = g + G; i < nc; i += G) vrg_item_catchup(c, i);
@@ -1326,7 +1339,7 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on, ui
         for (uint32_t r = g + G; r < nf; r += G) vrg_item_check_flip(c, r);
         if (g < nd) vrg_free_entry(c, g, dead0, s0.nfree, nalloc);
         for (uint32_t j = g + G; j < nd; j += G) vrg_free_entry(c, j, c.dead[j], s0.nfree, nalloc);
-        if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 27); }
+        if (st0) { vrg_drain(); VRG_STAMP(c, 27); }
         if (blockIdx.x == 0 && !c.lvl_scan && nnz > NZ_SORT) {           // (rare: a long level list is sorted in place in global memory)
             wg_sort_pairs(c.nz_key, (uint32_t*)nullptr, nnz, false);
             __syncthreads();
@@ -1361,7 +1374,7 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on, ui
             if (stm) VRG_STAMP(c, 33);
             if (blockIdx.x == napply) {                             // the list itself: the next k_order clears these counters, an entry-by-entry k_band sums over it
                 for (uint32_t j = t; j < nnz; j += T) c.nz_key[j] = s_key[j];
-                if (t == 0) __hip_atomic_store(&c.stg->nnz, nnz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by whoever closes the sweep)
+                if (t == 0) __hip_atomic_store(&c.stg->nnz, nnz, VRG_MO_STORE, __HIP_MEMORY_SCOPE_AGENT);   // (read by whoever closes the sweep)
             }
         } else {
             if (t < nnz) s_key[t] = zk0;
@@ -1393,18 +1406,18 @@ __global__ void __launch_bounds__(KC_THREADS) k_close(VrgCtx c, int dense_on, ui
         }
     }
     // everything this workgroup sent to memory has arrived before it takes its ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    vrg_drain();
     __syncthreads();
     if (stm) VRG_STAMP(c, 34);
     if (t == 0) {
         VRG_CHAOS_POINT(11);
-        const uint32_t k = __hip_atomic_fetch_add(&c.counters[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t k = __hip_atomic_fetch_add(&c.counters[1], 1u, VRG_MO_TICKET, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (k == gridDim.x - 1);
         if (s_last) {
             VRG_STAMP(c, 28);
             c.counters[1] = 0;                                           // every workgroup has arrived: reset for the next launch
             vrg_close_sweep(c, (int64_t)nmk, use_tab);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(c, 29);
+            vrg_drain(); VRG_STAMP(c, 29);
         }
     }
 }
@@ -1488,7 +1501,7 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     if (st0) VRG_STAMP(cg, 11);
     vrg_fuse_prepass(sh, th, t, nf);
     __syncthreads();
-    if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 18); }
+    if (st0) { vrg_drain(); VRG_STAMP(cg, 18); }
     if (sh.any_pend)                                       // skip-rule fix-point (rare)
         for (;;) {
             vrg_fuse_fix(c, sh, t, nf);
@@ -1505,12 +1518,12 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     VRG_CHAOS_POINT(14);
     vrg_fuse_stencil(c, sh, th, t, r);
     __syncthreads();
-    if (st0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 20); }
+    if (st0) { vrg_drain(); VRG_STAMP(cg, 20); }
     vrg_fuse_reserve(c, sh, t);
     __syncthreads();
     vrg_fuse_commit(c, sh, th, t, r);
     // everything this workgroup sent to memory has arrived before it takes its ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    vrg_drain();
     __syncthreads();
     if (st0) VRG_STAMP(cg, 21);
     if (open_end) {                                        // nobody closes: the state keeps what the workgroups have added up, marked open
@@ -1519,7 +1532,7 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
     }
     if (t == 0) {
         VRG_CHAOS_POINT(12);
-        const uint32_t k = __hip_atomic_fetch_add(&cg.counters[16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t k = __hip_atomic_fetch_add(&cg.counters[16], 1u, VRG_MO_TICKET, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (k == nf - 1u);
         if (s_last) cg.counters[16] = 0;                   // every workgroup with a flip has arrived: reset for the next launch
     }
@@ -1560,7 +1573,7 @@ __global__ void __launch_bounds__(VRG_FUSE_THREADS) k_sweep(VrgCtx cg, int memo_
             else vrg_fuse_level_file(c, q++, l, sh.lev[l], ci[k], co[k], cc[k]);
         }
     }
-    if (t == 0) { vrg_fuse_close(c, fin, fin_nin, fin_nout, total, memo_follows && total <= FUSE_MEMO_NNZ); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); VRG_STAMP(cg, 29); }
+    if (t == 0) { vrg_fuse_close(c, fin, fin_nin, fin_nout, total, memo_follows && total <= FUSE_MEMO_NNZ); vrg_drain(); VRG_STAMP(cg, 29); }
 }
 // (entering fused trips after trips of another kind: the per-level counters of the last sweep are still listed, not yet zero)
 __global__ void __launch_bounds__(TPB) k_levels_clear(VrgCtx c) {
@@ -1724,10 +1737,10 @@ struct SweepAcc { long long nin, nout; double sin_, sout; };
 // workgroup's four values write-through (sc1), drains them (vmcnt(0)), takes a ticket with an agent-scope atomic add;
 // the workgroup whose add came last reads every slot with sc1 loads behind a workgroup barrier.  (An agent-scope release
 // + acquire pair costs ~1.7 us each - a tenth of a slab's recount.)
-__device__ __forceinline__ void st_sc1(long long* p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ long long ld_sc1(const long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_sc1(const double* p) { return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void st_sc1(long long* p, long long v) { __hip_atomic_store(p, v, VRG_MO_STORE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), VRG_MO_STORE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ long long ld_sc1(const long long* p) { return __hip_atomic_load(p, VRG_MO_LOAD, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_sc1(const double* p) { return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), VRG_MO_LOAD, __HIP_MEMORY_SCOPE_AGENT)); }
 __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a, int fin) {
     __shared__ long long sh_n[2][4];
     __shared__ double sh_s[2][4];
@@ -1741,9 +1754,9 @@ __device__ __forceinline__ void sweep_finish(const VrgCtx& c, SweepAcc a, int fi
         st_sc1((long long*)&c.st_nout[blockIdx.x], sh_n[1][0] + sh_n[1][1] + sh_n[1][2] + sh_n[1][3]);
         st_sc1(&c.st_sin[blockIdx.x], ((sh_s[0][0] + sh_s[0][1]) + sh_s[0][2]) + sh_s[0][3]);
         st_sc1(&c.st_sout[blockIdx.x], ((sh_s[1][0] + sh_s[1][1]) + sh_s[1][2]) + sh_s[1][3]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        vrg_drain();
         VRG_CHAOS_POINT(13);
-        uint32_t t = __hip_atomic_fetch_add(&c.counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t t = __hip_atomic_fetch_add(&c.counters[0], 1u, VRG_MO_TICKET, __HIP_MEMORY_SCOPE_AGENT);
         is_last = (t == gridDim.x - 1);
         if (is_last) c.counters[0] = 0;              // every workgroup has arrived: reset for the next launch
     }
@@ -2371,9 +2384,13 @@ int band_lanes(const VrgBackend* b) {       // lanes per slot of the entry-by-en
     return slots * 16 <= 512u * TPB ? 16 : slots * 8 <= 512u * TPB ? 8 : 4;
 }
 uint32_t band_blocks(const VrgBackend* b) {
-    if (!b->band_hint) return BAND_BLOCKS;
+    if (!b->band_hint) return b->band_blocks_max;
     const uint64_t threads = band_slots(b) * (band_direct(b) ? band_lanes(b) : 1);
-    return (uint32_t)std::min<uint64_t>(BAND_BLOCKS, std::max<uint64_t>(32, (threads + TPB - 1) / TPB));
+    // (a pool so large that every workgroup files its flips together - one bump of the flip counter per workgroup, SINK_ABOVE - is bound by those bumps: they
+    // execute one after the other at the memory side, ~15 ns each.  512x512x170 with 1.2 M slots, 12 900 flips per sweep: 2048 / 512 / 256 / 128 workgroups ->
+    // 0.253 / 0.244 / 0.226 / 0.231 ms per sweep; 880x880x640: 0.544 / 0.494 / 0.440)
+    const uint64_t most = (band_slots(b) > SINK_ABOVE && std::max(b->flip_hint, b->flip_hint_min) > 2048u) ? std::min<uint64_t>(b->band_blocks_max, 256) : b->band_blocks_max;   // (few flips: nothing queues, the pool's size decides)
+    return (uint32_t)std::min<uint64_t>(most, std::max<uint64_t>(32, (threads + TPB - 1) / TPB));
 }
 
 // Non-temporal loads for the dense pass?  By the bytes a pass fetches (counted when init has built the class bits): up
@@ -2484,6 +2501,7 @@ void be_set_tuning(VrgBackend* b, const char* name, long long v) {
     if (std::strcmp(name, "iter_hint") == 0) b->iter_hint = (int)v;
     if (std::strcmp(name, "open_sweeps") == 0) b->open_sweeps = v != 0;
     if (std::strcmp(name, "mark_compact") == 0) b->mark_compact = v != 0;
+    if (std::strcmp(name, "band_blocks_max") == 0 && v >= 32 && v <= BAND_BLOCKS) b->band_blocks_max = (uint32_t)v;
     if (std::strcmp(name, "band_hint") == 0) b->band_hint = (uint32_t)std::min<long long>(std::max<long long>(v, 0), 0x7fffffff);
     if (std::strcmp(name, "direct_hint") == 0) b->direct_hint = v != 0;
     if (std::strcmp(name, "dense_pipe") == 0) b->dense_pipe = (int)v;
@@ -3171,7 +3189,7 @@ __global__ void __launch_bounds__(GATE_THREADS) k_follow_classes(VrgCtx c, const
     }
     if (!g.count_last) return;
     if (t == 0) vrg_follow_expect(c, g.h[g.n - 1]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    vrg_drain();
     __syncthreads();
     ulist_refresh(c, false, 0);
 }

@@ -325,7 +325,7 @@ int API(set_option)(vrg_handle* h, const char* name, int64_t value) {
     else if (n == "fused") h->fused = value != 0;
     else if (n == "bin_above") { if (value < 0) return fail(h, VRG_E_ARG, "bin_above: a number of levels >= 0"); h->bin_above = value; h->inited = false; }
     else if (n == "verify_every") { if (value < 0) return fail(h, VRG_E_ARG, "verify_every: 0 (never), 1 (every sweep: the default) or n > 1 (every n-th sweep)"); h->verify_every = (int)std::min<int64_t>(value, 1 << 20); be_set_tuning(h->be, name, value); }
-    else if (n == "open_sweeps" || n == "mark_compact") be_set_tuning(h->be, name, value);
+    else if (n == "open_sweeps" || n == "mark_compact" || n == "band_blocks_max") be_set_tuning(h->be, name, value);
     else if (n == "sweep_blocks" || n == "prio_mode" || n == "small_flips" || n == "fuse_max" || n == "memo_above" || n == "serial_streams" || n == "skip_excluded" || n == "nt_loads" || n == "dense_pipe") be_set_tuning(h->be, name, value);
     else if (n == "storage16") h->storage16 = value != 0;      // takes effect at the next vrg_init
     else if (n == "repl_fault") h->repl.fault = value;             // tests: a host-side failure in the middle of a replicated run (every rank must return an error, none may hang)

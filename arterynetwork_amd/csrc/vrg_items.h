@@ -38,6 +38,20 @@
 #include "vrg_types.h"
 
 // ------------------------------------------------------------------ backend shims
+// The hand-offs between workgroups, kernels and streams are built from relaxed agent-scope atomics, write-through stores and an explicit drain
+// (s_waitcnt vmcnt(0)) - no acquire / release fence, each of which costs ~1.7 us on this part.  The FENCED TWIN of the same
+// sources (-DVRG_FENCES, tools/build_fenced.sh) gives every one of them its textbook ordering instead - polls and tickets acquire, announcing stores
+// and tickets release, a release fence where the product only drains: slow, and by the memory model right.  tools/gpu.sh <tag> fenced runs
+// the fuzz campaign on both builds: any difference in a result would be a hand-off the product gets wrong.
+#if defined(VRG_FENCES)
+#define VRG_MO_LOAD __ATOMIC_ACQUIRE
+#define VRG_MO_STORE __ATOMIC_RELEASE
+#define VRG_MO_TICKET __ATOMIC_ACQ_REL
+#else
+#define VRG_MO_LOAD __ATOMIC_RELAXED
+#define VRG_MO_STORE __ATOMIC_RELAXED
+#define VRG_MO_TICKET __ATOMIC_RELAXED
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 VRG_HD uint32_t vrg_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 VRG_HD int32_t vrg_atomic_add(int32_t* p, int32_t v) { return atomicAdd(p, v); }
@@ -47,22 +61,26 @@ VRG_HD void vrg_atomic_xor(uint32_t* p, uint32_t v) { atomicXor(p, v); }
 // loads that are served by L2: for bytes / counters that atomics of the SAME kernel may have changed (atomics execute
 // in L2; a plain load could be answered from a line this CU cached before)
 VRG_HD uint8_t vrg_load_coherent(const uint8_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, VRG_MO_LOAD, __HIP_MEMORY_SCOPE_AGENT);
 }
-VRG_HD uint32_t vrg_load_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-VRG_HD int32_t vrg_load_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-VRG_HD int64_t vrg_load_i64(const int64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VRG_HD uint32_t vrg_load_u32(const uint32_t* p) { return __hip_atomic_load(p, VRG_MO_LOAD, __HIP_MEMORY_SCOPE_AGENT); }
+VRG_HD int32_t vrg_load_i32(const int32_t* p) { return __hip_atomic_load(p, VRG_MO_LOAD, __HIP_MEMORY_SCOPE_AGENT); }
+VRG_HD int64_t vrg_load_i64(const int64_t* p) { return __hip_atomic_load(p, VRG_MO_LOAD, __HIP_MEMORY_SCOPE_AGENT); }
 // the error word is written through: another workgroup of the SAME kernel may be the one that reads it (k_close)
-VRG_HD void vrg_store_i32(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VRG_HD void vrg_store_i32(int32_t* p, int32_t v) { __hip_atomic_store(p, v, VRG_MO_STORE, __HIP_MEMORY_SCOPE_AGENT); }
 // words another STREAM's kernel polls or reads while this kernel is still running (the dense side's gate and expected
 // sizes): written through to memory, and drained before the word that announces them
-VRG_HD void vrg_store_i64(int64_t* p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VRG_HD void vrg_store_i64(int64_t* p, int64_t v) { __hip_atomic_store(p, v, VRG_MO_STORE, __HIP_MEMORY_SCOPE_AGENT); }
+#if defined(VRG_FENCES)
+VRG_HD void vrg_drain() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else
 VRG_HD void vrg_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-VRG_HD void vrg_store_u32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-VRG_HD void vrg_store_u64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+VRG_HD void vrg_store_u32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, VRG_MO_STORE, __HIP_MEMORY_SCOPE_AGENT); }
+VRG_HD void vrg_store_u64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, VRG_MO_STORE, __HIP_MEMORY_SCOPE_AGENT); }
 // ... and a word the HOST (page-locked memory) or another device polls: system scope
-VRG_HD void vrg_store_u64_sys(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-VRG_HD uint64_t vrg_load_u64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VRG_HD void vrg_store_u64_sys(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, VRG_MO_STORE, __HIP_MEMORY_SCOPE_SYSTEM); }
+VRG_HD uint64_t vrg_load_u64(const uint64_t* p) { return __hip_atomic_load(p, VRG_MO_LOAD, __HIP_MEMORY_SCOPE_AGENT); }
 // atomics on a workgroup's LDS arrays (fused sweep)
 VRG_HD uint32_t vrg_lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 VRG_HD int32_t vrg_lds_add(int32_t* p, int32_t v) { return atomicAdd(p, v); }
@@ -813,7 +831,10 @@ VRG_HD void vrg_count_change(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t
 // of appended through a counter - no returning atomic; a voxel whose class did not change files VRG_NOCHG.  Whoever closes
 // the sweep sets the list's length (vrg_post_apply).
 #define VRG_NOCHG 0xffffffffu
-VRG_HD void vrg_count_change_at(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t nw, uint32_t pos) {
+// (acc: null - the region sizes move at once, two atomics on the same cache line per change; else the caller adds acc[0] / acc[1] up over its items
+// and sends ONE pair per workgroup: same-address atomics execute one after the other at the memory side, and a sweep of 12 900 flips made
+// 8 000 of them in k_close - its whole 35 us)
+VRG_HD void vrg_count_change_at(const VrgCtx& c, uint32_t idx, uint8_t old, uint8_t nw, uint32_t pos, int* acc = nullptr) {
     uint32_t a = vrg_cls_of(old), b = vrg_cls_of(nw);
     const int p = (c.st->iter + 1) & 1;
     if (a == b) { c.chg_dw[p][pos] = VRG_NOCHG; return; }
@@ -826,6 +847,7 @@ VRG_HD void vrg_count_change_at(const VrgCtx& c, uint32_t idx, uint8_t old, uint
     vrg_atomic_xor(&c.clsb[p][dw], x);
     c.chg_dw[p][pos] = dw; c.chg_x[p][pos] = x;
     int din = (int)(b == 1u) - (int)(a == 1u), dout = (int)(b == 2u) - (int)(a == 2u);
+    if (acc) { acc[0] += din; acc[1] += dout; return; }
     if (din) vrg_atomic_add64(&c.inc[VC_NIN], din);
     if (dout) vrg_atomic_add64(&c.inc[VC_NOUT], dout);
 }
@@ -849,10 +871,10 @@ VRG_HD void vrg_item_apply(const VrgCtx& c, uint32_t i) {
     vrg_apply_voxel(c, idx, old, nw);
 }
 // ... with the class change filed at place i of the change list (see vrg_count_change_at)
-VRG_HD void vrg_apply_at(const VrgCtx& c, uint32_t i, uint32_t idx, uint8_t old, uint8_t nw, uint32_t log_base) {
+VRG_HD void vrg_apply_at(const VrgCtx& c, uint32_t i, uint32_t idx, uint8_t old, uint8_t nw, uint32_t log_base, int* acc = nullptr) {
     vrg_log_record(c, log_base, i, idx, old, nw);
     c.lab[0][idx] = nw;
-    vrg_count_change_at(c, idx, old, nw, i);
+    vrg_count_change_at(c, idx, old, nw, i, acc);
 }
 // one caller, after every label of sweep iter+1 is written and before anything of the next sweep: file the sizes
 // that sweep's dense pass has to reproduce; the change list just consumed becomes the next sweep's
