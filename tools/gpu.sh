@@ -11,6 +11,7 @@
 #   repeat           rare-race hunt: tools/repeat_case.py 8 seeds x 500, repeat_batched, repeat_stress
 #   chaos            interleaving campaign on the -DVRG_CHAOS build (tools/build_chaos.sh: random delays at every kernel entry and
 #                    hand-off): the parity tests of the GPU suite, repeat_case / repeat_batched / repeat_stress, a fuzz campaign
+#   fenced           product vs its fenced twin (-DVRG_FENCES): fuzz campaign on both, parity tests on the twin, the fences' cost
 #   stamps[:shape]   in-kernel stamps of the band chain (diagnostic build, tools/build_stamps.sh)
 #   prof:<tag2>:<bench args,comma separated>   rocprofv3 kernel stats + PMC passes (tools/profile_bench.sh)
 #   traffic:<tag2>:<bench args>                FETCH_SIZE / WRITE_SIZE passes only
@@ -61,6 +62,19 @@ for step in "$@"; do
         for sd in 3 11 19 27; do timeout 900 python tools/repeat_batched.py $sd 100 4096 8 2>&1 | grep -v amdgpu.ids | tail -1; done >> "$out/chaos.log" 2>&1
         timeout 900 python tools/repeat_stress.py 10 2>&1 | grep -v amdgpu.ids | tail -2 >> "$out/chaos.log"
         timeout 1500 python tests/fuzz_gpu.py 1000 100 4000 2>&1 | grep -v amdgpu.ids | tail -1 >> "$out/chaos.log" ); cat "$out/chaos.log" ;;
+    fenced)   # A/B of the product against its FENCED TWIN (tools/build_fenced.sh: acquire / release on every hand-off): the same fuzz ranges on both builds, the
+              # parity tests of the many-flip and replica paths on the twin, and what the fences cost (512x512x170 step, both builds)
+      bash tools/build_fenced.sh > /dev/null && {
+        : > "$out/fenced_ab.log"
+        for lib in libvrg_hip.so libvrg_hip_fenced.so; do
+          echo "---- $lib" >> "$out/fenced_ab.log"
+          ( export VRG_HIP_LIB=$PWD/arterynetwork_amd/csrc/$lib
+            timeout 1500 python tests/fuzz_gpu.py 2500 250 60000 2>&1 | grep -v amdgpu.ids | tail -3 >> "$out/fenced_ab.log"
+            timeout 600 python bench.py --shape 512x512x170 --steps 300 --no-cpu-baseline --no-side-lines 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('512x512x170: ms/step', d['ms_per_step'], 'band chain alone', d['config'].get('band_chain_ms'), 'dense', d['config'].get('dense_ms'))" >> "$out/fenced_ab.log" )
+        done
+        ( export VRG_HIP_LIB=$PWD/arterynetwork_amd/csrc/libvrg_hip_fenced.so
+          ( time timeout 2400 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "many_flip or refine_like or kinds or replica or n_rank or stepwise or golden" ) 2>&1 | tail -5 | cut -c1-200 >> "$out/fenced_ab.log" )
+        cat "$out/fenced_ab.log"; } ;;
     stamps*) shp=${step#stamps}; shp=${shp#:}; shp=${shp:-512x512x170}
       bash tools/build_stamps.sh > /dev/null && ( export VRG_HIP_LIB=$PWD/arterynetwork_amd/csrc/libvrg_hip_stamps.so
         python tools/chain_stamps.py $shp 1 60 2>&1 | grep -v amdgpu.ids > "$out/chain_stamps.log"
