@@ -75,6 +75,7 @@ struct VrgBackend {
                                                       // (its request comes from THIS trip's k_band; if that trip stopped or handed itself back, the stop word makes the gate leave)
     bool prev_open = false;                           // ... and its sweep was open-ended: this trip's k_band derives the closed state (and lists the touched levels itself)
     int open_par = 0;                                 // ... the set of per-level counters it filled
+    long long follow_counts = 0;                      // a follower's dense passes so far (which of them are timed: option "events")
     uint32_t band_blocks_max = 2048;                  // option "band_blocks_max": most workgroups k_band uses for the pool (BAND_BLOCKS)
     uint64_t* rsv = nullptr;                          // VrgCtx::rsv of this handle's four-launch trips (64 words, zero between sweeps)
     int mark_compact = 1;                             // option "mark_compact": four-launch trips of thousands of flips relabel with k_mark_compact (+ k_mark_relabel for what it leaves)
@@ -3210,7 +3211,7 @@ void be_follow_apply(VrgBackend* b, const VrgCtx& c, const VrgLogRec* recs, cons
 void be_follow_count(VrgBackend* b, const VrgCtx& c, VrgEvents* ev) {
     use_device(b);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ev && ev->enabled > 0) {
+    if (ev && ev->enabled > 0 && (b->follow_counts++ % ev->enabled) == 0) {     // (every enabled-th count, as on one GPU: an event pair costs the stream a few us)
         if (b->ev_used == b->ev_pool.size())
             for (int k = 0; k < 32; k++) { EvPair n; HIP_CHECK(hipEventCreate(&n.a)); HIP_CHECK(hipEventCreate(&n.b)); n.trip = 0; n.kind = 0; n.ntrips = 1; b->ev_pool.push_back(n); }
         EvPair& p = b->ev_pool[b->ev_used++];

@@ -39,7 +39,8 @@ struct VrgRepl {
     bool open = false;                                  // leader: a batch is opened and not yet closed
     uint32_t sent_sw = 0, sent_rec = 0;                 // leader (rccl / callback): sweeps / records of the open batch that have travelled
     uint64_t chunk_seq = 0;                             // chunks sent since the handle was created
-    uint8_t* chunk_dev = nullptr;                       // rccl: the chunk struct's device slot
+    uint8_t* chunk_dev = nullptr;                       // (a small device scratch area)
+    VrgLogChunk* chunk_ring = nullptr; uint32_t chunk_slot = 0;   // rccl: the chunk structs, a ring of 256 in page-locked host memory
     uint64_t* host_ready = nullptr;                     // rccl / callback: the progress word in page-locked HOST memory - the band chain stores it there (a posted write), the leader's
                                                         // host thread reads it without a single HIP call (polling a device word with small copies slowed the chain 4x: every copy is a kernel + cache flush)
     int64_t chunk_min = -1;                             // option "repl_chunk": sweeps a chunk waits for while its batch runs (-1: 8 over RCCL - three broadcasts per chunk -, 1 through callbacks)
@@ -304,6 +305,7 @@ void API(destroy)(vrg_handle* h) {
     be_sync(h->be);
     if (h->repl.host) be_host_free(h->be, h->repl.host);
     if (h->repl.host_ready) be_host_free(h->be, h->repl.host_ready);
+    if (h->repl.chunk_ring) be_host_free(h->be, h->repl.chunk_ring);
     if (h->repl.ctl_mapped) { be_ipc_close(h->be, h->repl.ctl); be_ipc_close(h->be, h->repl.peer_buf[0]); be_ipc_close(h->be, h->repl.peer_buf[1]); }
     for (void* p : h->owned) be_free(h->be, p);
     be_destroy(h->be);

@@ -83,6 +83,13 @@ static uint8_t* repl_host(vrg_handle* h, size_t bytes) {       // the callback t
     return r.host;
 }
 
+// rccl: the next slot of the chunk structs' ring in page-locked host memory (the broadcasts read / write it directly; a slot is reused 256 chunks later -
+// the leader waits for its transport stream whenever it opens a batch)
+static VrgLogChunk* repl_chunk_slot(vrg_handle* h) {
+    VrgRepl& r = h->repl;
+    if (!r.chunk_ring) { r.chunk_ring = (VrgLogChunk*)be_host_alloc(h->be, 256 * sizeof(VrgLogChunk)); if (!r.chunk_ring) return nullptr; }
+    return r.chunk_ring + (r.chunk_slot++ & 255u);
+}
 // bounded polling of a 64-bit counter in device memory (possibly another process's, mapped): true once *word >= want
 static bool repl_poll(vrg_handle* h, const uint8_t* base, size_t word, uint64_t want, double timeout_s) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -142,12 +149,16 @@ static int repl_send_chunk(vrg_handle* h, uint64_t n, uint32_t nsw, uint32_t nre
         if (sb) { be_repl_copy(h->be, hp, buf + so, sb); r.bcast(hp, (int64_t)sb, 0, r.user); }
         if (rb) { be_repl_copy(h->be, hp, buf + ro, rb); r.bcast(hp, (int64_t)rb, 0, r.user); }
     } else if (r.transport == TR_RCCL) {
-        be_repl_copy(h->be, r.chunk_dev, &ch, sizeof(ch));
-        if (be_repl_bcast(h->be, r.chunk_dev, sizeof(ch), 0) || (sb && be_repl_bcast(h->be, buf + so, sb, 0)) || (rb && be_repl_bcast(h->be, buf + ro, rb, 0)))
+        // (the chunk struct travels out of page-locked host memory, a ring of slots: no copy kernel, no wait - every kernel the transport puts on this GPU
+        // while the batch runs delays the band chain; measured on one GPU, 880x880x640: a chunk cost the chain ~40 us with a host-to-device copy and a wait in it)
+        VrgLogChunk* slot = repl_chunk_slot(h);
+        if (!slot) return fail(h, VRG_E_MEM, "replication: chunk ring");
+        *slot = ch;
+        if (be_repl_bcast(h->be, slot, sizeof(ch), 0) || (sb && be_repl_bcast(h->be, buf + so, sb, 0)) || (rb && be_repl_bcast(h->be, buf + ro, rb, 0)))
             return fail(h, VRG_E_INTERNAL, "replication: RCCL broadcast failed");
-        be_repl_wait(h->be);                           // (the one chunk struct slot is written again by the next chunk)
     }
     r.sent_sw = nsw; r.sent_rec = nrec; r.chunks++;
+    if (r.transport == TR_RCCL && (r.chunks & 127) == 0) be_repl_wait(h->be);     // (the ring: never more than half of it in flight)
     return VRG_OK;
 }
 // while the batch's trips run (rccl / callback; on ipc the followers look for themselves): what the band chain has published since the
@@ -238,9 +249,11 @@ static int repl_next_chunk(vrg_handle* h, uint64_t n, uint32_t sw_done, uint32_t
     if (r.transport != TR_CALLBACK && r.transport != TR_RCCL) return fail(h, VRG_E_STATE, "replication: no transport set");
     if (r.transport == TR_CALLBACK) r.bcast(&ch, (int64_t)sizeof(ch), 0, r.user);
     else {
-        if (be_repl_bcast(h->be, r.chunk_dev, sizeof(ch), 0)) return fail(h, VRG_E_INTERNAL, "replication: RCCL broadcast failed");
+        VrgLogChunk* slot = repl_chunk_slot(h);
+        if (!slot) return fail(h, VRG_E_MEM, "replication: chunk ring");
+        if (be_repl_bcast(h->be, slot, sizeof(ch), 0)) return fail(h, VRG_E_INTERNAL, "replication: RCCL broadcast failed");
         be_repl_wait(h->be);
-        be_repl_copy(h->be, &ch, r.chunk_dev, sizeof(ch));
+        ch = *slot;
     }
     // (sizes first: whatever else is wrong with the chunk, the broadcasts that follow it have to be matched)
     const size_t sb = (size_t)ch.nsw * sizeof(VrgLogSweep), rb = (size_t)ch.nrec * sizeof(VrgLogRec);
