@@ -295,11 +295,11 @@ class Session:
 
     def stats(self):
         """Diagnostics: how often a trip was handed back to the host and why, array capacities."""
-        a = (C.c_int64 * 22)()
-        self._check(self.lib.get_stats(self._h, a, 22))
+        a = (C.c_int64 * 23)()
+        self._check(self.lib.get_stats(self._h, a, 23))
         return {'bail_flips': a[1], 'grow_marks': a[2], 'grow_pool': a[3], 'host_driven_trips': a[4],
                 'fused_trips': a[15], 'bail_fuse': a[16], 'density_bins': a[17], 'memo_trips': a[18],
-                'data_nonzero': a[19], 'bin_bytes': a[20], 'level_index_bytes': a[21], 'pool_capacity': a[5], 'mark_capacity': a[6], 'pool_slots': a[7], 'dense_bytes': a[8],
+                'data_nonzero': a[19], 'slow_flips': a[22], 'bin_bytes': a[20], 'level_index_bytes': a[21], 'pool_capacity': a[5], 'mark_capacity': a[6], 'pool_slots': a[7], 'dense_bytes': a[8],
                 'dense_kernel': ('k_recount_pipe<3,{}>'.format('true' if a[9] else 'false') if a[14] else
                                  'k_recount_bits<{},{},{},{}>'.format(2 if a[10] == 2 else 3, 'true' if a[9] else 'false', a[10], 'true' if a[12] else 'false')),
                 'dense_nt_loads': bool(a[9]), 'dense_workgroups': a[11], 'dense_listed_units': a[13]}

@@ -143,6 +143,7 @@ void be_recount_hist(VrgBackend* b, const VrgCtx& c, int32_t* rin, int32_t* rout
 // hold an included voxel (all lines of the slab with option skip_excluded = 0); measurement aid for the roofline
 uint64_t be_dense_bytes(VrgBackend* b, const VrgCtx& c);
 void be_dense_info(VrgBackend* b, const VrgCtx& c, int64_t out[5]);
+long long be_slow_flips(VrgBackend* b, const VrgCtx& c);   // four-launch trips of thousands of flips: flips k_mark_compact left to the general kernel (an excluded voxel within their 5x5x5 cube), since the handle was created
 long long be_memo_trips(VrgBackend* b);      // fused trips that kept the per-level memo (a launch of their own behind the sweep; large bands)   // {nt loads, storage mode, workgroups, skip_excluded, k_recount_pipe} of the dense pass
 // (stamp, idx) of every segmented voxel, unordered; returns the count
 uint32_t be_collect_segmented(VrgBackend* b, const VrgCtx& c, uint64_t* stamps, uint32_t* idxs, uint32_t cap);

@@ -883,6 +883,7 @@ __global__ void __launch_bounds__(KM_THREADS * G) KM_STAMP_OCC k_mark_relabel(Vr
     asm volatile("" :: "v"(fidx_first), "v"(st_done), "v"(st_bail), "v"(nf_all), "v"(nlist));     // one wait for the five
     const uint32_t nf = list ? (nlist < nf_all ? nlist : nf_all) : nf_all;
     if (st_done || st_bail) return;
+    if (list && blockIdx.x == 0 && tt == 0 && nf) atomicAdd(&cg.counters[49], nf);       // (diagnostics: flips the compact kernel left to this one, since the handle was created)
     if (st0) { VRG_STAMP_PUT(cg, 16, t_entry); VRG_STAMP(cg, 17); }
 #if defined(VRG_STAMPS)
     if (list) { if (blockIdx.x * G >= nf) return; }                  // (the compact kernel's stamps stay when this launch has nothing to do)
@@ -3300,6 +3301,7 @@ void be_recount_hist(VrgBackend* b, const VrgCtx& c, int32_t* rin, int32_t* rout
 // what the dense pass of this handle is launched as: {non-temporal loads, storage mode (0 fp32, 1 u16 level index, 2 f64),
 // workgroups, skip_excluded, k_recount_pipe instead of k_recount_bits}
 static bool dense_is_pipe(VrgBackend* b, const VrgCtx& c) { return b->dense_pipe && c.I && !c.lev16 && b->skip; }
+long long be_slow_flips(VrgBackend* b, const VrgCtx& c) { use_device(b); uint32_t v = 0; HIP_CHECK(hipMemcpyAsync(&v, c.counters + 49, 4, hipMemcpyDeviceToHost, b->sa)); HIP_CHECK(hipStreamSynchronize(b->sa)); return (long long)v; }
 long long be_memo_trips(VrgBackend* b) { return b->memo_trips; }
 void be_dense_info(VrgBackend* b, const VrgCtx& c, int64_t out[5]) {
     out[0] = dense_nt(b, c) ? 1 : 0; out[1] = c.lev16 ? (c.L <= TAB64_LEVELS ? 3 : 1) : (c.I ? 0 : 2); out[2] = dense_blocks(b, c); out[3] = b->skip ? 1 : 0;

@@ -475,8 +475,12 @@ int API(init)(vrg_handle* h, double H) {
     be_fill(be, c.dIn, 0, (size_t)L * 8); be_fill(be, c.dOut, 0, (size_t)L * 8); be_fill(be, c.dConv, 0, (size_t)L * 8);
     be_fill(be, c.ltouch, 0, (size_t)L * 4);
     // band pool and work arrays: sized by demand (they grow when a trip reports that it needs more)
-    if (!c.p_idx && !size_pool(h, h->band_capacity, 0, 0)) return fail(h, VRG_E_MEM, "vrg_init: band arrays");
-    if (!c.mk_idx && !size_marks(h, 0, false)) return fail(h, VRG_E_MEM, "vrg_init: work arrays");
+    // (unless the caller chose capacities: sized by the volume - a slot costs ~110 bytes, a marked-list entry ~26; re-allocating in the middle of a run costs a
+    // host round trip, a copy and the rest of a batch, and a mask with many vessels grows its band by 10^4 entries per sweep.  880x880x640: 4 M slots = 0.45 GB of 288)
+    const uint64_t auto_pool = (h->band_capacity || h->cap_floor != (1u << 16)) ? h->band_capacity : std::min<uint64_t>(4u << 20, (uint64_t)h->V / 32u);
+    const uint64_t auto_marks = (h->band_capacity || h->cap_floor != (1u << 16)) ? 0 : std::min<uint64_t>(8u << 20, (uint64_t)h->V / 16u);
+    if (!c.p_idx && !size_pool(h, auto_pool, 0, 0)) return fail(h, VRG_E_MEM, "vrg_init: band arrays");
+    if (!c.mk_idx && !size_marks(h, auto_marks, false)) return fail(h, VRG_E_MEM, "vrg_init: work arrays");
     VrgState s;
     for (int attempt = 0;; attempt++) {
         std::memset(&s, 0, sizeof(s));
@@ -761,6 +765,7 @@ int API(get_stats)(vrg_handle* h, int64_t* outp, int64_t cap) {
     if (cap >= 18) outp[17] = h->inited ? h->c.nb : 0;
     if (cap >= 19) outp[18] = be_memo_trips(h->be);
     if (cap >= 20) outp[19] = h->data_nonzero;
+    if (cap >= 23) outp[22] = h->inited ? be_slow_flips(h->be, h->c) : 0;
     // what a large level table costs in device memory: the bin moments (two classes x nb_alloc bins x 9 words) and the per-voxel level index
     if (cap >= 22) {
         outp[20] = (int64_t)h->nb_alloc * (VRG_BIN_K + 1) * 8 * 2;

@@ -215,7 +215,7 @@ def tube_lattice(shape, tubes):
 
 
 def bench_volume_torch(shape, device, seed=3, levels=255, radius=4.0, noise=0.1, seed_planes=3, brain_mask=True, integer_values=False,
-                       tubes=1, seed_mode='planes'):
+                       tubes=1, seed_mode='planes', brain_scale=0.48):
     """The configs 2-4 recipe generated directly in HBM with torch (plumbing only), x-fastest
     layout.  Returns (I, vm) as torch tensors of logical shape (nx,ny,nz) with element strides (1,nx,nx*ny).
     ``levels=None`` keeps the continuous float32 noise (one distinct value per voxel, nearly).
@@ -271,8 +271,10 @@ def bench_volume_torch(shape, device, seed=3, levels=255, radius=4.0, noise=0.1,
         I = torch.round(I * levels)                 # integer_values: what a scanner delivers (the caller scales H by 1 / levels^2: same run)
         if not integer_values:
             I = I / levels
-    ell = (((xs - (nx - 1) / 2.0) / (0.48 * nx)) ** 2 + ((ys - (ny - 1) / 2.0) / (0.48 * ny)) ** 2
-           + ((zs - (nz - 1) / 2.0) / (0.48 * nz)) ** 2) <= 1.0
+    # (brain_scale: the ellipsoid's half axes as a fraction of the volume's - smaller than the tubes' lattice and the vessels cross the brain mask's edge:
+    # excluded voxels right beside the flips, the 4 -> 3 inclusion rule :166-168, :177-179 at work in every sweep)
+    ell = (((xs - (nx - 1) / 2.0) / (brain_scale * nx)) ** 2 + ((ys - (ny - 1) / 2.0) / (brain_scale * ny)) ** 2
+           + ((zs - (nz - 1) / 2.0) / (brain_scale * nz)) ** 2) <= 1.0
     vm = torch.full((nz, ny, nx), 3, dtype=torch.uint8, device=device)
     if brain_mask:
         vm[~ell.expand(nz, ny, nx)] = 4

@@ -79,8 +79,8 @@ void vrg_destroy(vrg_handle* h);
 const char* vrg_last_error(const vrg_handle* h);
 
 /* Options (value 0/1 unless noted; before vrg_init unless "any time"):
- *   "band_capacity"  slots reserved for the narrow band (default 65536; the arrays grow by themselves when a
- *                    sweep needs more, so this only saves the re-allocations)
+ *   "band_capacity"  slots reserved for the narrow band (default: by the volume - one slot per 32 voxels, at least 65536, at most 4 M; the
+ *                    arrays grow by themselves when a sweep needs more, so this only saves the re-allocations)
  *   "capacity_floor" smallest capacity of the pool and of the marked-voxel arrays (default 65536; tests lower it)
  *   "storage16"      (takes effect at the next vrg_init) keep intensities as 16-bit level indices (needs <= 16384 distinct values): the dense
  *                    pass streams 2 B instead of 4 B per voxel; results are bit-identical
@@ -163,7 +163,9 @@ int vrg_get_levels(vrg_handle* h, double* values, int32_t* hist_in, int32_t* his
  * pass is the two-trips-deep kernel k_recount_pipe (option dense_pipe; fp32 storage with skip_excluded), 0 for k_recount_bits.
  * With cap >= 20 also out[19] = the number of non-zero values of dataArray (np.count_nonzero, the reference's closing message :95), counted when the volume was set.
  * With cap >= 22 also what a large level table costs in device memory: out[20] = bytes of the bin moments (L > 2048 distinct values: up to 4 194 304 bins x 9
- * 64-bit words x 2 classes = 604 MB), out[21] = bytes of the per-voxel level index (4 B per voxel; 2 B with 16-bit storage). */
+ * 64-bit words x 2 classes = 604 MB), out[21] = bytes of the per-voxel level index (4 B per voxel; 2 B with 16-bit storage).
+ * With cap >= 23 also out[22] = flips of sweeps with thousands of flips that the compact relabel kernel left to the general one (an excluded voxel
+ * within two voxels of the flip), since the handle was created. */
 int vrg_get_stats(vrg_handle* h, int64_t* out, int64_t cap);
 
 /* Diagnostic builds only (compiled with -DVRG_STAMPS, tools/chain_stamps.py): 64 in-kernel time stamps (100-MHz ticks) of

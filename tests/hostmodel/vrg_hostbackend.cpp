@@ -450,6 +450,7 @@ void be_sweep_batch(VrgBackend* b, VrgCtx& c, int flags, int n, VrgEvents* ev, b
 void be_dense_info(VrgBackend*, const VrgCtx& c, int64_t out[5]) { out[0] = 0; out[1] = c.lev16 ? 1 : (c.I ? 0 : 2); out[2] = 1; out[3] = 1; out[4] = 0; }
 void be_dense_flush(VrgBackend*, const VrgCtx&, be_reduce_fn, void*) {}
 long long be_memo_trips(VrgBackend*) { return 0; }
+long long be_slow_flips(VrgBackend*, const VrgCtx&) { return 0; }
 
 void be_recount_hist(VrgBackend*, const VrgCtx& c, int32_t* rin, int32_t* rout) {
     for_real_voxels(c, [&](uint32_t idx, int, int, int) {

@@ -809,6 +809,48 @@ def test_many_flip_sweeps_vs_oracle(lib):
         o.close()
 
 
+def test_many_flips_beside_excluded_voxels_vs_oracle(lib):
+    """Sweeps of 1 600 flips in a volume whose brain mask is SMALLER than the vessels' lattice (phantoms.bench_volume_torch brain_scale): some
+    tubes grow through excluded voxels - the 4 -> 3 inclusion of :166-168 / :177-179 in every sweep - others inside the mask.  The compact
+    relabel kernel (a flip per half-wave, 1-ring only) must hand exactly the flips with an excluded voxel in their 5x5x5 cube to the general
+    kernel: some, not all (Session.stats()['slow_flips']); labels, band lists and trace equal the oracle's - as they do with the general
+    kernel alone (mark_compact = 0)."""
+    import torch
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session
+    from oracle import vrg_oracle as O
+    shape = (160, 160, 64)
+    I, vm = phantoms.bench_volume_torch(shape, torch.device('cpu'), tubes=16, brain_scale=0.3)
+    d = np.asfortranarray(I.numpy().astype(np.float64)); v = np.asfortranarray(vm.numpy())
+    assert 0.3 < float((v == 4).mean()) < 0.95
+    o = O.Oracle(d, v, 2.25, 1); o.init()
+    k = 0
+    while o.step(12, 10 ** 9, -1.0) == 0:
+        k += 1
+    otr = o.trace()
+    assert k == 12 and int(otr['nflip'][1:].min()) > 1000
+    total = int(otr['nflip'][1:].sum())
+    for opts in ({}, {'mark_compact': 0}, {'fused': 0, 'batch': 5}):
+        s = Session(shape, lib=lib)
+        for kk, vv in opts.items():
+            s.set_option(kk, vv)
+        s.set_volume(d.astype(np.float32)); s.set_labels(v); s.init(2.25)
+        r = s.run(12, 10 ** 9, None)
+        assert r.sweeps == k and r.ties == 0, opts
+        parity.compare_state(s, o, shape, parity.density_rtol(d), 'flips beside excluded voxels, %r' % (opts,))
+        tr = s.trace()
+        for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no'):
+            assert np.array_equal(tr[f], otr[f]), (f, opts)
+        st = s.stats()
+        assert st['host_driven_trips'] == 0
+        if opts.get('mark_compact', 1):
+            assert 0 < st['slow_flips'] < total, (st['slow_flips'], total)     # some flips took the general kernel, some the compact one
+        else:
+            assert st['slow_flips'] == 0
+        s.close()
+    o.close()
+
+
 def test_refine_like_mask_to_convergence_vs_oracle(lib):
     """What the pipeline uses this stage for (the reference's README.md:69-71, :209: VRG smooths an existing vessel mask): the seed is a
     PERTURBED mask of all vessels at once (phantoms.bench_volume_torch seed_mode='noisy-mask': a random half of the mask's surface taken

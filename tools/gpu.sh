@@ -6,6 +6,7 @@
 #   tests            pytest -m gpu (whole suite)            tests:<expr>   pytest -m gpu -k <expr>
 #   bench:<name>:<bench.py args separated by commas>        one bench line -> gpurun_out/<tag>/bench_<name>.json
 #   lines            the round's standard bench lines (headline, driver args, 512, replica role proxies, Z-slabs 80/320, level regimes, 16-bit storage, tubes)
+#   manyflip         ms per sweep against flips per sweep (tools/manyflip.py: 1 .. 512 tubes, both volumes)
 #   slabs            only the slab lines + 512
 #   levels           only the level-regime lines
 #   repeat           rare-race hunt: tools/repeat_case.py 8 seeds x 500, repeat_batched, repeat_stress
@@ -29,6 +30,13 @@ except Exception as e:
 PY
 }
 run() { name=$1; shift; timeout 900 python bench.py "$@" 2> "$out/bench_$name.err" | grep '^{' > "$out/bench_$name.json"; summ "$out/bench_$name.json"; }
+manyflip() { for sh in 512x512x170 880x880x640; do timeout 900 python tools/manyflip.py $sh 1,16,64,128,512 --sweeps 60 2>/dev/null | grep '^{' >> "$out/manyflip_$sh.jsonl"; done; python3 - "$out" <<'PY'
+import json, sys, glob
+for f in sorted(glob.glob(sys.argv[1] + '/manyflip_*.jsonl')):
+    for l in open(f):
+        d = json.loads(l); print('%-14s tubes %4d flips/sweep %8.0f band %8d ms/sweep %.4f dense %.4f host-driven %d' % (d['shape'], d['tubes'], d['flips_mean'] or 0, d['band_end'], d['ms_per_sweep'], d['dense_ms'], d['host_driven_trips']))
+PY
+}
 for step in "$@"; do
   case "$step" in
     smoke) python -c "import __graft_entry__ as g; g.build(); g.smoke()" > "$out/build_smoke.log" 2>&1; echo "build+smoke rc=$?" >> "$out/build_smoke.log"; tail -2 "$out/build_smoke.log" ;;
@@ -38,14 +46,16 @@ for step in "$@"; do
     lines)
       run 880; run 880_driver --steps 20 --warmup 5
       run 512 --shape 512x512x170 --steps 200
-      run proxy8_880 --force-dist --no-cpu-baseline --steps 300                      # replica partition: the roles of an 8-rank group, one GPU
-      run proxy8_512 --force-dist --no-cpu-baseline --steps 300 --shape 512x512x170
-      run proxy4_880 --force-dist --no-cpu-baseline --steps 300 --proxy-world 4
+      run proxy_880 --force-dist --no-cpu-baseline --steps 500                       # replica partition: the roles of 2-, 4- and 8-rank groups, one GPU; whole-run projection
+      run proxy_880_driver_args --force-dist --no-cpu-baseline --steps 20 --warmup 5
+      run proxy_512 --force-dist --no-cpu-baseline --steps 300 --shape 512x512x170
+      run refine_like --refine-like
       for nz in 320 80; do run dist1_zslab_880x880x$nz --force-dist --partition zslab --shape 880x880x$nz --no-cpu-baseline --steps 300; done
       for lv in 4095 65535 0; do run 512_levels$lv --no-cpu-baseline --no-side-lines --shape 512x512x170 --steps 100 --levels $lv; done
       run 880_s16 --storage16 --no-cpu-baseline --no-side-lines
       run 1024_s16 --shape 1024x1024x1024 --storage16 --no-cpu-baseline --no-side-lines --steps 200
       for tb in 16 128; do run 880_tubes$tb --tubes $tb --no-cpu-baseline --no-side-lines --steps 100; done ;;
+    manyflip) manyflip ;;
     slabs)
       run 512 --shape 512x512x170 --steps 200 --no-cpu-baseline
       for nz in 320 160 80; do run dist1_880x880x$nz --force-dist --shape 880x880x$nz --no-cpu-baseline --steps 300; done ;;
