@@ -2426,7 +2426,8 @@ int dense_blocks(const VrgBackend* b, const VrgCtx& c) {
     // (round 4, with the fused band chain beside the pass - fewer dependent round trips for the pass's loads to delay: 80-plane
     // slab 256 -> 0.0419 ms/step, 384 -> 0.0382, 512 -> 0.0392; 160 planes 384 -> 0.0577, 512 -> 0.0552, 768 -> 0.0582; 512x512x170
     // 256 -> 0.0343, 384 -> 0.0347, 512 -> 0.0509: the band kernels then wait for a place on the chip)
-    const uint64_t pick = units <= 50000 ? 256 : units <= 100000 ? 384 : units <= 350000 ? 512 : 768;
+    // (round 6, the chain at 0.031 ms: 512x512x170 - 45 000 units - 256 -> 0.0342-0.0345 ms per step, 320-448 -> 0.0322-0.0331, three repeats each, 512 -> 0.0333, 768 -> 0.035)
+    const uint64_t pick = units <= 100000 ? 384 : units <= 350000 ? 512 : 768;
     return (int)std::min<uint64_t>(pick, std::max<uint64_t>(64, units / 160));
 }
 

@@ -83,7 +83,7 @@ for step in "$@"; do
             timeout 600 python bench.py --shape 512x512x170 --steps 300 --no-cpu-baseline --no-side-lines 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('512x512x170: ms/step', d['ms_per_step'], 'band chain alone', d['config'].get('band_chain_ms'), 'dense', d['config'].get('dense_ms'))" >> "$out/fenced_ab.log" )
         done
         ( export VRG_HIP_LIB=$PWD/arterynetwork_amd/csrc/libvrg_hip_fenced.so
-          ( time timeout 2400 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "many_flip or refine_like or kinds or replica or n_rank or stepwise or golden" ) 2>&1 | tail -5 | cut -c1-200 >> "$out/fenced_ab.log" )
+          timeout 2400 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "many_flip or refine_like or kinds or replica or n_rank or stepwise or golden" 2>&1 | grep -E "passed|failed|error" | tail -3 | cut -c1-200 >> "$out/fenced_ab.log" )
         cat "$out/fenced_ab.log"; } ;;
     stamps*) shp=${step#stamps}; shp=${shp#:}; shp=${shp:-512x512x170}
       bash tools/build_stamps.sh > /dev/null && ( export VRG_HIP_LIB=$PWD/arterynetwork_amd/csrc/libvrg_hip_stamps.so
