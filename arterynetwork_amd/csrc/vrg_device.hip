@@ -806,6 +806,13 @@ __global__ void __launch_bounds__(TPB) k_list_wide(VrgCtx c) {
         vrg_item_list_rec(c, r, c.flist[i], c.fr_idx[i], c.fr_lev[i], !(c.f_key[i] >> 63));
     }
 }
+// ... or, for a sweep with more flips than n^2 comparisons are worth (host-driven trips: the host knows the count and has sized a radix sort): the rank of the flip
+// the sort put at place r is r
+__global__ void __launch_bounds__(TPB) k_rank_scatter(VrgCtx c, const uint32_t* __restrict__ perm, uint32_t nf) {
+    const VrgState& s = *c.st;
+    if (s.done || s.bail || !s.wide) return;
+    ITEM_LOOP(min(nf, c.fcap)) c.rk_part[perm[i]] = i;
+}
 __global__ void __launch_bounds__(TPB) k_prepass_wide(VrgCtx c) {               // phase-A label of the flip-ins (every L bit is in place: a kernel boundary)
     const VrgState& s = *c.st;
     if (s.done || s.bail || !s.wide) return;
@@ -2972,19 +2979,30 @@ static void host_driven_update(VrgBackend* b, const VrgCtx& c, int flags) {
 }
 
 // update() for a sweep with few flips: three launches, nothing from the host in between
-static void small_update(VrgBackend* b, const VrgCtx& c0, bool dense, hipEvent_t e_chain_stop = nullptr) {
+// (host_nf > 0: a host-driven trip - the host has read the flip count: the launches are sized for it, and the flips are ranked by a radix sort instead of k_rank_wide's
+// n^2 comparisons, which at 10^5 flips would take milliseconds)
+static void small_update(VrgBackend* b, const VrgCtx& c0, bool dense, hipEvent_t e_chain_stop = nullptr, uint32_t host_nf = 0) {
     VrgCtx c = c0;
     if (!b->rsv) { HIP_CHECK(hipMalloc((void**)&b->rsv, 64 * sizeof(uint64_t))); if (b->rsv) HIP_CHECK(hipMemsetAsync(b->rsv, 0, 64 * sizeof(uint64_t), b->sa)); }
     c.rsv = b->rsv;                                  // (the relabel kernels' list reservations: lines of their own)
     c.lvl_scan = c.L <= NZ_SORT ? 1 : 0;             // small level table: the touched levels are found by scanning the counters (k_close)
     // (sized by the flips of the last sweep the engine saw: a sweep of thousands of flips gets a workgroup per flip, not a queue of them;
     // a sweep with more flips than its launches can order is handed back - VBAIL_FLIPS - and enqueued again with launches that can)
-    const uint32_t fh = std::max<uint32_t>(b->flip_hint, 1u);
-    const bool wide = 2 * (uint64_t)fh > NF_ORDER;
-    k_order<<<1, KO_THREADS, 0, b->sa>>>(c, wide ? b->small_flips : std::min<uint32_t>(b->small_flips, NF_ORDER));
+    const uint32_t fh = host_nf ? host_nf : std::max<uint32_t>(b->flip_hint, 1u);
+    const bool sorted = host_nf > NF_WIDE;             // (more flips than the device-resident chain takes on its own)
+    const bool wide = sorted || 2 * (uint64_t)fh > NF_ORDER;
+    k_order<<<1, KO_THREADS, 0, b->sa>>>(c, sorted ? host_nf : wide ? b->small_flips : std::min<uint32_t>(b->small_flips, NF_ORDER));
+    if (sorted) {
+        size_t tb = 0;
+        if (!need_keys2(b, host_nf)) { std::snprintf(b->err, sizeof(b->err), "out of device memory (flip sort)"); return; }
+        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, c.f_key, b->keys2, rocprim::counting_iterator<uint32_t>(0u), c.slow, host_nf, 0, 64, b->sa));
+        if (!need_tmp(b, tb)) { std::snprintf(b->err, sizeof(b->err), "out of device memory (flip sort)"); return; }
+        HIP_CHECK(rocprim::radix_sort_pairs(b->tmp, tb, c.f_key, b->keys2, rocprim::counting_iterator<uint32_t>(0u), c.slow, host_nf, 0, 64, b->sa));
+        k_rank_scatter<<<std::min<uint32_t>(1024u, (host_nf + TPB - 1) / TPB), TPB, 0, b->sa>>>(c, c.slow, host_nf);      // (c.slow: free until k_mark_compact fills it)
+    }
     if (wide) {                  // its ordering step chip-wide (no-ops when k_order did the ordering itself)
         const uint64_t nrec = (2 * (uint64_t)fh + KR_THREADS - 1) / KR_THREADS, ntile = (2 * (uint64_t)fh + KR_TILE - 1) / KR_TILE;
-        k_rank_wide<<<(uint32_t)std::min<uint64_t>(16384u, nrec * ntile), KR_THREADS, 0, b->sa>>>(c);
+        if (!sorted) k_rank_wide<<<(uint32_t)std::min<uint64_t>(16384u, nrec * ntile), KR_THREADS, 0, b->sa>>>(c);
         k_list_wide<<<std::min<uint32_t>(1024u, (2 * fh + TPB - 1) / TPB), TPB, 0, b->sa>>>(c);
         k_prepass_wide<<<std::min<uint32_t>(1024u, (2 * fh + TPB - 1) / TPB), TPB, 0, b->sa>>>(c);
         k_fix_wide<<<1, 1024, 0, b->sa>>>(c);
@@ -3088,7 +3106,10 @@ void be_sweep_once(VrgBackend* b, VrgCtx& c, int flags, VrgEvents* ev, be_reduce
         HIP_CHECK(hipMemcpyAsync(&s, c.st, sizeof(s), hipMemcpyDeviceToHost, b->sa));
         HIP_CHECK(hipStreamSynchronize(b->sa));
         if (s.done || s.bail) return;
-        if (s.nf > b->small_flips || (flags & VRG_SWEEP_FULL)) host_driven_update(b, c, flags);
+        // (more flips than the device-resident chain takes - 65 536 - : the same chip-wide kernels with a host-sized radix sort for the ranking; the item kernels
+        // of host_driven_update remain for the full-stencil check variant and for a handle whose "small_flips" was lowered - the tests do that to run them)
+        if (flags & VRG_SWEEP_FULL) host_driven_update(b, c, flags);
+        else if (s.nf > b->small_flips) { if (b->small_flips >= NF_WIDE) small_update(b, c, dense, nullptr, s.nf); else host_driven_update(b, c, flags); }
         else small_update(b, c, dense);
     } else {
         small_update(b, c, dense, e_c1);
