@@ -58,6 +58,8 @@ struct vrg_handle {
     int device = 0;
     bool have_vol = false, have_lab = false, inited = false;
     bool sync_mode = false;              // trips are driven one at a time from the host (many flips per sweep)
+    uint8_t* pool_block = nullptr; uint8_t* marks_block = nullptr;   // the two families of arrays sized by demand: one allocation each (size_pool / size_marks)
+    bool probe = false;                  // the next batch is the first after vrg_init: one trip, to learn the sweep's size
     int verify_every = 1;                // option "verify_every"
     int64_t bin_above = 2048;            // option "bin_above": level tables larger than this evaluate their exact densities through bins
     uint32_t nb_alloc = 0;
@@ -102,16 +104,6 @@ void release(vrg_handle* h, void* p) {
     if (it != h->owned.end()) h->owned.erase(it);
     be_free(h->be, p);
 }
-// a larger array with the first `keep` elements carried over; false: out of memory (the old array stays)
-template <class T> bool grow(vrg_handle* h, T*& p, size_t keep, size_t n) {
-    T* q = alloc<T>(h, n);
-    if (!q) return false;
-    if (p && keep) be_copy(h->be, q, p, keep * sizeof(T));
-    be_sync(h->be);
-    release(h, p);
-    p = q;
-    return true;
-}
 uint64_t pow2_at_least(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
 
 VrgDense get_dense(vrg_handle* h) {     // region sizes as the band side keeps them + the sums of the last dense pass
@@ -153,19 +145,52 @@ int check_state_error(vrg_handle* h, const VrgState& s) {
 }
 
 // ---- arrays sized by demand ------------------------------------------------------------------------------
+// Each family of arrays - the band pool with the flip arrays, the marked-voxel lists - lives in ONE allocation that is carved up: growing a family is one
+// allocation, its copies, one synchronisation and one free (an allocation or a free costs 0.1-0.2 ms and a free synchronises the device: 25 arrays grown one
+// by one were 5 ms in the middle of a run).
+struct Carve {
+    uint8_t* base; size_t off = 0;
+    explicit Carve(uint8_t* b) : base(b) {}
+    template <class T> T* take(size_t n) { off = (off + 255) & ~(size_t)255; T* p = reinterpret_cast<T*>(base + off); off += std::max<size_t>(n, 1) * sizeof(T); return p; }
+};
+struct PoolArrays {
+    uint32_t* p_idx; uint32_t* p_lev; double* p_ip; double* p_op; float* p_err; uint64_t* p_key; uint8_t* p_flag; uint32_t* freel;
+    uint32_t* flist; uint64_t* f_key; uint32_t* fr_idx; uint32_t* fr_lev; uint32_t* f_slot; uint32_t* f_idx; uint32_t* f_lev; uint8_t* f_res;
+    uint32_t* pend; uint32_t* slow; uint32_t* rk_part; uint32_t* fresh; uint64_t* init_key; uint32_t* init_idx;
+    size_t carve(uint8_t* base, size_t cap) {
+        Carve k(base);
+        p_idx = k.take<uint32_t>(cap); p_lev = k.take<uint32_t>(cap); p_ip = k.take<double>(cap); p_op = k.take<double>(cap); p_err = k.take<float>(cap);
+        p_key = k.take<uint64_t>(cap); p_flag = k.take<uint8_t>(cap); freel = k.take<uint32_t>(cap);
+        flist = k.take<uint32_t>(cap); f_key = k.take<uint64_t>(cap); fr_idx = k.take<uint32_t>(cap); fr_lev = k.take<uint32_t>(cap); f_slot = k.take<uint32_t>(cap);
+        f_idx = k.take<uint32_t>(cap); f_lev = k.take<uint32_t>(cap); f_res = k.take<uint8_t>(cap); pend = k.take<uint32_t>(cap); slow = k.take<uint32_t>(cap);
+        rk_part = k.take<uint32_t>(cap); fresh = k.take<uint32_t>(cap); init_key = k.take<uint64_t>(cap); init_idx = k.take<uint32_t>(cap);
+        return k.off + 256;
+    }
+};
 // band pool + flip arrays (capacity bcap = fcap, a power of two); contents of the first `keep` slots survive
 bool size_pool(vrg_handle* h, uint64_t want, uint32_t keep, uint32_t keep_free) {
     VrgCtx& c = h->c;
     uint64_t cap = pow2_at_least(std::max<uint64_t>(want, h->cap_floor));
     if (cap > 0x80000000ull) return false;
-    bool ok = grow(h, c.p_idx, keep, cap) && grow(h, c.p_lev, keep, cap) && grow(h, c.p_ip, keep, cap) && grow(h, c.p_op, keep, cap) && grow(h, c.p_err, keep, cap) &&
-              grow(h, c.p_key, keep, cap) && grow(h, c.p_flag, keep, cap) && grow(h, c.freel, keep_free, cap) &&
-              grow(h, c.flist, 0, cap) && grow(h, c.f_key, 0, cap) && grow(h, c.fr_idx, 0, cap) && grow(h, c.fr_lev, 0, cap) && grow(h, c.f_slot, 0, cap) && grow(h, c.f_idx, 0, cap) && grow(h, c.f_lev, 0, cap) &&
-              grow(h, c.f_res, 0, cap) && grow(h, c.pend, 0, cap) && grow(h, c.slow, 0, cap) && grow(h, c.rk_part, 0, cap) && grow(h, c.fresh, keep, cap) &&
-              grow(h, c.init_key, 0, cap) && grow(h, c.init_idx, 0, cap);
-    if (!ok) return false;
-    if (cap > keep) be_fill(h->be, c.p_flag + keep, 0, cap - keep);
-    be_fill(h->be, c.rk_part, 0, cap * sizeof(uint32_t));
+    PoolArrays n;
+    const size_t bytes = n.carve(nullptr, (size_t)cap);
+    uint8_t* blk = alloc<uint8_t>(h, bytes);
+    if (!blk) return false;
+    n.carve(blk, (size_t)cap);
+    if (c.p_idx && keep) {
+        be_copy(h->be, n.p_idx, c.p_idx, (size_t)keep * 4); be_copy(h->be, n.p_lev, c.p_lev, (size_t)keep * 4); be_copy(h->be, n.p_ip, c.p_ip, (size_t)keep * 8);
+        be_copy(h->be, n.p_op, c.p_op, (size_t)keep * 8); be_copy(h->be, n.p_err, c.p_err, (size_t)keep * 4); be_copy(h->be, n.p_key, c.p_key, (size_t)keep * 8);
+        be_copy(h->be, n.p_flag, c.p_flag, (size_t)keep); be_copy(h->be, n.fresh, c.fresh, (size_t)keep * 4);
+    }
+    if (c.freel && keep_free) be_copy(h->be, n.freel, c.freel, (size_t)keep_free * 4);
+    if (cap > keep) be_fill(h->be, n.p_flag + keep, 0, cap - keep);
+    be_fill(h->be, n.rk_part, 0, cap * sizeof(uint32_t));
+    be_sync(h->be);
+    if (h->pool_block) release(h, h->pool_block);
+    h->pool_block = blk;
+    c.p_idx = n.p_idx; c.p_lev = n.p_lev; c.p_ip = n.p_ip; c.p_op = n.p_op; c.p_err = n.p_err; c.p_key = n.p_key; c.p_flag = n.p_flag; c.freel = n.freel;
+    c.flist = n.flist; c.f_key = n.f_key; c.fr_idx = n.fr_idx; c.fr_lev = n.fr_lev; c.f_slot = n.f_slot; c.f_idx = n.f_idx; c.f_lev = n.f_lev; c.f_res = n.f_res;
+    c.pend = n.pend; c.slow = n.slow; c.rk_part = n.rk_part; c.fresh = n.fresh; c.init_key = n.init_key; c.init_idx = n.init_idx;
     c.bcap = (uint32_t)cap; c.fcap = c.bcap;
     return true;
 }
@@ -175,9 +200,23 @@ bool size_marks(vrg_handle* h, uint64_t want, bool keep) {
     uint64_t cap = pow2_at_least(std::max<uint64_t>(want, h->cap_floor));
     if (cap > 0x80000000ull) return false;
     const size_t k = keep ? c.mcap : 0;
-    bool ok = grow(h, c.mk_idx, 0, cap) && grow(h, c.mk_new, 0, cap + 16) && grow(h, c.mk_old, 0, cap + 16) && grow(h, c.dead, 0, cap);
-    for (int p = 0; p < 2 && ok; p++) ok = grow(h, c.chg_dw[p], k, cap) && grow(h, c.chg_x[p], k, cap);
-    if (!ok) return false;
+    uint32_t* mk_idx; uint8_t* mk_new; uint8_t* mk_old; uint32_t* dead; uint32_t* dw[2]; uint32_t* x[2];
+    auto carve = [&](uint8_t* base) -> size_t {
+        Carve kk(base);
+        mk_idx = kk.take<uint32_t>(cap); mk_new = kk.take<uint8_t>(cap + 16); mk_old = kk.take<uint8_t>(cap + 16); dead = kk.take<uint32_t>(cap);
+        for (int p = 0; p < 2; p++) { dw[p] = kk.take<uint32_t>(cap); x[p] = kk.take<uint32_t>(cap); }
+        return kk.off + 256;
+    };
+    const size_t bytes = carve(nullptr);
+    uint8_t* blk = alloc<uint8_t>(h, bytes);
+    if (!blk) return false;
+    carve(blk);
+    for (int p = 0; p < 2 && k; p++) { be_copy(h->be, dw[p], c.chg_dw[p], k * 4); be_copy(h->be, x[p], c.chg_x[p], k * 4); }
+    be_sync(h->be);
+    if (h->marks_block) release(h, h->marks_block);
+    h->marks_block = blk;
+    c.mk_idx = mk_idx; c.mk_new = mk_new; c.mk_old = mk_old; c.dead = dead;
+    for (int p = 0; p < 2; p++) { c.chg_dw[p] = dw[p]; c.chg_x[p] = x[p]; }
     c.mcap = (uint32_t)cap;
     return true;
 }
@@ -504,7 +543,7 @@ int API(init)(vrg_handle* h, double H) {
     s = get_state(h);
     int rc = check_state_error(h, s);
     if (rc) return rc;
-    h->inited = true; h->sync_mode = false; h->fuse_mode = false;
+    h->inited = true; h->sync_mode = false; h->fuse_mode = false; h->probe = true;
     h->ev.ms_total = 0; h->ev.launches = 0; h->ev.chain_ms_total = 0; h->ev.chain_launches = 0;
     return VRG_OK;
 }
@@ -563,6 +602,8 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
         const bool fuse = h->fuse_mode && !sync;
         int64_t remaining = iterMax - s.iter;
         int nb = sync ? 1 : (int)std::min<int64_t>(h->batch, std::max<int64_t>(remaining, 0) + 1);   // +1: the trip that sets the stop flag
+        if (h->probe) nb = 1;                            // (the first trip after vrg_init: nobody knows how many flips the first sweep lists - a mask of many vessels, 10^5 - and a trip
+                                                         // that is handed back takes the rest of its batch with it)
         if (replicated) { nb = std::min<int>(nb, (int)rp.swcap - 2); rc = repl_open_batch(h, s); if (rc) return abort_group(rc); }   // (the batch's change log: one buffer)
         if (replicated && rp.fault > 0 && (int64_t)rp.seq + 1 == rp.fault) return abort_group(fail(h, VRG_E_MEM, "vrg_run: injected host-side failure (option repl_fault)"));
         if (maxSeconds >= 0 && s.iter < iterMax) {   // wall-clock cap (:97): tested after the no-flip test, before update()
@@ -590,6 +631,7 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
         if (s.bail) {                                // the trip was handed back untouched: make room / change mode, do it again
             const uint64_t nf = s.nf;
             h->bails[std::min(s.bail, 5)]++;
+            h->probe = false;
             // The rest of the batch was enqueued behind the trip that came back: its k_gate + recount pairs may still sit
             // in the dense stream.  They have to run out while the device's stop word (gate[VG_STOP]) is still set -
             // put_state below clears it; a leftover gate would then wait for the NEXT sweep's request and shift which
@@ -608,11 +650,25 @@ int API(run)(vrg_handle* h, int64_t iterMax, int64_t maxSegmentSize, double maxS
             } else {
                 if (!size_pool(h, 2 * ((uint64_t)s.np + nf * 27u), s.np, s.nfree)) return abort_group(fail(h, VRG_E_MEM, "vrg_run: band arrays"));
             }
+            // (whatever the reason, the trip's flip count is known now: everything that count implies is settled in THIS round trip - the kind of trip, the arrays'
+            // sizes - instead of one hand-back per discovery: a first sweep of 2*10^5 flips used to come back four times, each time with the rest of its batch to drain)
+            if (nf > fuse_max) h->fuse_mode = false;
+            if (nf > small) h->sync_mode = true;
+            else if (nf > 0 && !h->sync_mode) be_set_tuning(be, "flip_hint_min", (long long)nf);
+            if (!(base_flags & VRG_SWEEP_FULL) && nf * 125u > c.mcap && nf * 125u <= 0x3fffffffull) {       // (counted as what it is: the marked-voxel arrays grew)
+                if (s.bail != VBAIL_MARKS) h->bails[VBAIL_MARKS]++;
+                if (!size_marks(h, nf * 125u + nf * 32u, true)) return abort_group(fail(h, VRG_E_MEM, "vrg_run: marked-voxel arrays"));
+            }
+            if ((uint64_t)s.np + nf * 27u > c.bcap) {
+                if (s.bail != VBAIL_POOL) h->bails[VBAIL_POOL]++;
+                if (!size_pool(h, 2 * ((uint64_t)s.np + nf * 27u), s.np, s.nfree)) return abort_group(fail(h, VRG_E_MEM, "vrg_run: band arrays"));
+            }
             s.bail = 0; s.nf = 0;
             s.ties = s.ties_filed; s.near_ties = s.near_filed;   // the trip's sign tests are made again: count them once
             put_state(h, s);
             continue;
         }
+        h->probe = false;
         if (h->sync_mode && 2 * (uint64_t)s.last_nf <= small) h->sync_mode = false;   // the flips fit one workgroup again
         if (can_fuse && !h->fuse_mode && !h->sync_mode && 2 * (uint64_t)s.last_nf <= fuse_max) {   // ... or one fused launch
             be_sync(be);

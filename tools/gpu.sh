@@ -67,7 +67,7 @@ for step in "$@"; do
       cat "$out/repeat_case.log" ;;
     chaos)
       bash tools/build_chaos.sh > /dev/null && ( export VRG_HIP_LIB=$PWD/arterynetwork_amd/csrc/libvrg_hip_chaos.so
-        ( time timeout 3000 python -m pytest tests/test_gpu_parity.py tests/test_float32_input.py -m gpu -x -q -k "not event_sampling and not bench and not litmus" ) 2>&1 | tail -6 | cut -c1-200 > "$out/chaos.log"
+        timeout 3000 python -m pytest tests/test_gpu_parity.py tests/test_float32_input.py -m gpu -x -q -k "not event_sampling and not bench and not litmus" 2>&1 | grep -E "passed|failed|FAILED|rror" | tail -4 | cut -c1-200 > "$out/chaos.log"
         for sd in 3 11 19 27 42 77 101 202; do timeout 900 python tools/repeat_case.py $sd 150 2>&1 | grep -v amdgpu.ids | tail -1; done >> "$out/chaos.log" 2>&1
         for sd in 3 11 19 27; do timeout 900 python tools/repeat_batched.py $sd 100 4096 8 2>&1 | grep -v amdgpu.ids | tail -1; done >> "$out/chaos.log" 2>&1
         timeout 900 python tools/repeat_stress.py 10 2>&1 | grep -v amdgpu.ids | tail -2 >> "$out/chaos.log"
