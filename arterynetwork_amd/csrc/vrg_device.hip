@@ -2435,7 +2435,7 @@ int dense_blocks(const VrgBackend* b, const VrgCtx& c) {
     // 256 -> 0.0343, 384 -> 0.0347, 512 -> 0.0509: the band kernels then wait for a place on the chip)
     // (round 6, the chain at 0.031 ms: 512x512x170 - 45 000 units - 256 -> 0.0342-0.0345 ms per step, 320-448 -> 0.0322-0.0331, three repeats each, 512 -> 0.0333, 768 -> 0.035)
     const uint64_t pick = units <= 100000 ? 384 : units <= 350000 ? 512 : 768;
-    return (int)std::min<uint64_t>(pick, std::max<uint64_t>(64, units / 160));
+    return (int)std::min<uint64_t>(pick, std::max<uint64_t>(64, units / 110));      // (512x512x170: 45 000 units -> 384, a whole multiple of half the CUs; not 282)
 }
 
 void use_device(VrgBackend* b) { HIP_CHECK(hipSetDevice(b->device)); }

@@ -218,10 +218,23 @@ def replica_worker(rank, world, port, shape, sweeps, outdir, transport, leader_v
     dist.init_process_group('gloo', rank=rank, world_size=world)
     I, vm = phantoms.bench_volume_torch(shape, dev, tubes=int(os.environ.get('VRG_CHECK_TUBES', '1')))
     torch.cuda.synchronize()
-    s = replica.make_replica_session(shape, rank, world, device=0, transport=transport, leader_verifies=bool(leader_verifies), options={'batch': 16})
+    fault = int(os.environ.get('VRG_CHECK_FAULT', '0'))     # (option repl_fault: a rank fails on the host side in the middle of the run - every rank must return an error)
+    s = replica.make_replica_session(shape, rank, world, device=0, transport=transport, leader_verifies=bool(leader_verifies), options={'batch': 16, 'repl_fault': fault})
     s.set_volume_ptr(I.data_ptr(), np.float32, list(I.stride()))
     s.set_labels_ptr(vm.data_ptr(), np.uint8, list(vm.stride()))
     s.init(2.25)
+    if fault:
+        from arterynetwork_amd._capi import VrgError
+        err = ''
+        try:
+            s.run(sweeps, 10 ** 12, None)
+        except VrgError as e:
+            err = str(e)
+        np.savez(os.path.join(outdir, 'rank%d.npz' % rank), err=np.str_(err))
+        s.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     r = s.run(sweeps // 2, 10 ** 12, None)                  # two calls: the log goes on where the first run ended
     r2 = s.run(sweeps, 10 ** 12, None)
     assert r.sweeps + r2.sweeps == sweeps, (r.sweeps, r2.sweeps, r2.stop_reason)
@@ -263,8 +276,13 @@ def replicas_one_gpu(world, shape, sweeps, transport, leader_verifies):
     outdir = tempfile.mkdtemp(prefix='replicas_')
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--replica-worker', str(rk), str(world), str(port),
                                'x'.join(map(str, shape)), str(sweeps), outdir, transport, str(int(leader_verifies))]) for rk in range(world)]
-    rcs = [p.wait() for p in procs]
+    rcs = [p.wait(timeout=600) for p in procs]
     assert all(rc == 0 for rc in rcs), rcs
+    if int(os.environ.get('VRG_CHECK_FAULT', '0')):
+        errs = [str(np.load(os.path.join(outdir, 'rank%d.npz' % rk))['err']) for rk in range(world)]
+        assert all(errs), 'a rank returned without an error: %r' % (errs,)
+        print('REPLICAS FAIL TOGETHER: %d ranks on one GPU over %s, injected fault %s: every rank returned an error, none hung' % (world, transport, os.environ['VRG_CHECK_FAULT']))
+        return
     counted = 0
     for rk in range(world):
         z = np.load(os.path.join(outdir, 'rank%d.npz' % rk))

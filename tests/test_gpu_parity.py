@@ -1043,6 +1043,18 @@ def test_replicas_n_ranks_one_gpu(world, shape, sweeps, transport, leader_verifi
     assert out.returncode == 0 and 'REPLICAS OK' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+@pytest.mark.parametrize('transport,fault', [('ipc', 2), ('ipc', -3), ('callback', 2), ('callback', -2)])
+def test_replicas_fail_together_one_gpu(transport, fault):
+    """A replicated vrg_run is collective, and so are its failures: three rank processes on GPU 0; the leader fails on the host side when it opens
+    its 2nd batch (fault > 0) or a follower cannot use a chunk (fault < 0) - over hipIpc (polling followers, a control block) and over callbacks
+    (chunks).  Every rank's vrg_run must return an error; none may wait for the others for ever (the parent gives up after ten minutes)."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'full_size_check.py'), '--replicas', '3', '256x192x96', '60', transport, '0'],
+                         capture_output=True, text=True, env=dict(os.environ, VRG_CHECK_FAULT=str(fault)), timeout=900)
+    assert out.returncode == 0 and 'REPLICAS FAIL TOGETHER' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 @pytest.mark.parametrize('transport', ['ipc', 'callback'])
 def test_bench_n_rank_body_on_one_gpu(transport):
     """bench.py --gpus 3 as the driver starts it (torch.distributed.run, one process per rank), its three ranks sharing GPU 0
