@@ -13,7 +13,7 @@
 //       verifiers - with the very dense pass one GPU runs (same kernel, same unit list, same workgroups: the same sums bit for bit),
 //       against the sizes in the sweep's header.  With N - 1 verifiers each counts every (N-1)-th sweep over the WHOLE volume at the
 //       full-volume pass's efficiency (0.77 of peak at 880x880x640 against 0.57 for an 80-plane slab + a gate per sweep).
-//   Small groups (N <= 4) let the leader count its share too (leader_verifies): its chain then runs beside a pass, as on one GPU.
+//   Small groups (N <= 3) let the leader count its share too (leader_verifies): its chain then runs beside a pass, as on one GPU.
 //
 // THE LOG TRAVELS SWEEP BY SWEEP (round 6; it used to move once per batch of trips, so a follower started a batch late and the run ended
 // a batch late).  The trips are still enqueued in batches (option "batch") into one of two buffers, but the leader's band chain PUBLISHES

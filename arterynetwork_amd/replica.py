@@ -14,9 +14,10 @@ from ._capi import Session, VrgError
 
 
 def leader_verifies_default(world):
-    """Small groups let the leader count a share (its chain then runs beside a dense pass, as on one GPU: 0.037 ms per sweep
-    against 0.17 / N for the share); from five ranks on the followers' shares are smaller than that and the leader only leads."""
-    return world <= 4
+    """Groups of up to three ranks let the leader count a share (a rank that counts every n-th sweep over the whole volume needs (0.178 + (n-1) x 0.029) / n
+    ms per sweep at 880x880x640: 2 ranks 0.103, 3 ranks 0.079 - against one verifier 0.178 / two verifiers 0.089 behind a leader that only leads); from four
+    ranks on the followers' shares are the smaller ones and the leader only leads (4 ranks: three verifiers at 0.062 against 0.066 with the leader counting)."""
+    return world <= 3
 
 
 def make_replica_session(shape, rank, world, device=0, lib=None, transport='rccl', group=None, leader_verifies=None, options=None, allow_fallback=False):
@@ -94,7 +95,7 @@ def _setup(s, I, vm, args, configure):
 
 
 def bench_replicas(shape, args, dev, rank, world, roofline, configure, load_traffic):
-    """bench.py body for N > 1 ranks: one leader, N - 1 followers (the leader counts a share when N <= 4).  Every rank generates the
+    """bench.py body for N > 1 ranks: one leader, N - 1 followers (the leader counts a share when N <= 3).  Every rank generates the
     same synthetic volume in its HBM; barrier + synchronize around exactly K sweeps of the collective vrg_run (which ends when
     every sweep has been applied and counted everywhere); MAX over ranks; whole-job throughput."""
     import time
@@ -179,7 +180,7 @@ def bench_proxy(shape, args, dev, roofline, configure, load_traffic):
     whole-run ratio to one GPU those times allow - a PROJECTION (no multi-GPU node has run this), kept under config.scaling_floor.  The
     line's own value / ms_per_step are the ONE-GPU run's (a whole-job throughput that was really measured).  Per group size N:
       leader_step_ms     rank 0's step: band chain + change log + sending it (N = 8: it only leads, log over RCCL with a one-rank
-                         communicator; N <= 4: it also counts every N-th sweep, its chain beside that pass, log through host callbacks)
+                         communicator; N <= 3: it also counts every N-th sweep, its chain beside that pass, log through host callbacks)
       verifier_step_ms   a follower's work per sweep: every sweep's records applied, every n-th sweep counted over the whole volume
                          (n = the group's verifiers) - a follower handle fed the leader's recorded log through the callback transport
       whole_run          steps x max(leader, verifier) + fill + drain for the line's own --steps, for 500 and for 20 (project_whole_run)."""

@@ -421,7 +421,7 @@ def main():
     ap.add_argument('--partition', default='replica', choices=['replica', 'zslab'], help="N > 1: 'replica' = one leader (band chain + change log), the other ranks apply the "
                     "log and count the sweeps round robin over the whole volume (DESIGN.md section 7); 'zslab' = every rank repeats the band chain, the dense pass is cut into Z-slabs")
     ap.add_argument('--transport', default='rccl', choices=['rccl', 'ipc', 'callback'], help='replica partition: how the change log travels')
-    ap.add_argument('--leader-verifies', type=int, default=-1, help='replica partition: 1 / 0 = the leader counts a share of the sweeps / only leads; -1 = by the number of ranks (<= 4: it counts)')
+    ap.add_argument('--leader-verifies', type=int, default=-1, help='replica partition: 1 / 0 = the leader counts a share of the sweeps / only leads; -1 = by the number of ranks (<= 3: it counts)')
     ap.add_argument('--repl-batch', type=int, default=128, help='replica partition: trips per batch of the change log')
     ap.add_argument('--proxy-world', type=int, default=8, help='--force-dist with the replica partition: ranks of the group whose roles are measured')
     args = ap.parse_args()
