@@ -851,6 +851,42 @@ def test_many_flips_beside_excluded_voxels_vs_oracle(lib):
     o.close()
 
 
+@pytest.mark.parametrize('kind', ['bins', 'float64', 'storage16'])
+def test_many_flips_other_storages_vs_oracle(lib, kind):
+    """The compact relabel kernel on the other ways a volume is kept: a level table of thousands of values (12-bit quantisation: exact densities through
+    bins, a per-voxel level index instead of a search), float64 intensities that fp32 cannot hold, 16-bit level storage - 1 600 flips per sweep each,
+    eight sweeps against the oracle (labels, band lists with their densities, trace)."""
+    import torch
+    from arterynetwork_amd import phantoms
+    from arterynetwork_amd._capi import Session
+    from oracle import vrg_oracle as O
+    shape = (160, 160, 64)
+    I, vm = phantoms.bench_volume_torch(shape, torch.device('cpu'), tubes=16, levels=4095 if kind == 'bins' else 255)
+    d = np.asfortranarray(I.numpy().astype(np.float64)); v = np.asfortranarray(vm.numpy())
+    if kind == 'float64':
+        d = np.asfortranarray(d * (1.0 + 2.0 ** -30))          # values float32 cannot hold: the device keeps float64
+    o = O.Oracle(d, v, 2.25, 1); o.init()
+    k = 0
+    while o.step(8, 10 ** 9, -1.0) == 0:
+        k += 1
+    otr = o.trace()
+    assert k == 8 and int(otr['nflip'][1:].min()) > 1000
+    s = Session(shape, lib=lib)
+    if kind == 'storage16':
+        s.set_option('storage16', 1)
+    s.set_volume(d if kind == 'float64' else d.astype(np.float32)); s.set_labels(v); s.init(2.25)
+    if kind == 'bins':
+        assert s.stats()['density_bins'] > 0
+    r = s.run(8, 10 ** 9, None)
+    assert r.sweeps == k and r.ties == 0
+    parity.compare_state(s, o, shape, parity.density_rtol(d), 'many flips, %s' % kind)
+    tr = s.trace()
+    for f in ('nflip', 'nseg', 'n_in', 'n_out', 'ni', 'no'):
+        assert np.array_equal(tr[f], otr[f]), (f, kind)
+    assert s.stats()['host_driven_trips'] == 0
+    s.close(); o.close()
+
+
 def test_refine_like_mask_to_convergence_vs_oracle(lib):
     """What the pipeline uses this stage for (the reference's README.md:69-71, :209: VRG smooths an existing vessel mask): the seed is a
     PERTURBED mask of all vessels at once (phantoms.bench_volume_torch seed_mode='noisy-mask': a random half of the mask's surface taken
