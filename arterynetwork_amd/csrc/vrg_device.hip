@@ -9,12 +9,16 @@
 //   FUSED   k_sweep: ONE launch, one flip per workgroup, for sweeps with at most 128 flips (65 on a large level table) -
 //           every workgroup ranks the flips and resolves the skip rule itself; nothing is applied inside the sweep
 //           (-> k_memo on large bands).  A sweep with more flips hands itself back untouched (VBAIL_FUSE).
-//   CHAIN   k_order -> k_mark_relabel -> k_close: up to 4096 flips; a sweep with more (or one that needs larger arrays) is
-//           handed back untouched (VrgState::bail) and
-//   HOST-DRIVEN (be_sweep_once with VRG_SWEEP_SYNC): the same item functions as device-wide kernels, rocPRIM sorts.
+//   CHAIN   k_order (-> k_rank_wide -> k_list_wide -> k_prepass_wide -> k_fix_wide above 512 flips) -> k_mark_relabel<1> (up to 256 flips) or
+//           k_mark_compact (a flip per half-wave) -> k_mark_relabel<4> over the flips it left -> k_close: up to 65 536 flips without a host
+//           synchronisation; the relabel kernels' workgroups reserve their stretches of the sweep's lists through VrgCtx::rsv (cache lines of their
+//           own: same-address atomics execute one after the other).  A sweep with more flips (or one that needs larger arrays) is handed back
+//           untouched (VrgState::bail) and
+//   HOST-DRIVEN (be_sweep_once with VRG_SWEEP_SYNC): the host reads the flip count - above 65 536 flips a radix sort ranks them and the chain's
+//           chip-wide kernels do the rest; the full-stencil check variant (and a lowered "small_flips") runs the item functions as device-wide kernels.
 //   stream B, the dense pass (enqueued behind the kernel that raises its request: k_close, or the k_band after a fused sweep):
-//     k_recount_bits : the dense kernel (every voxel, HBM-bound, read-only: 4 B intensity + 2 class bits per
-//        voxel): region sizes and intensity sums (:113-116, :249-250), reduced by its last workgroup, checked
+//     k_recount_pipe / k_recount_bits : the dense kernel (every listed 1024-voxel unit, HBM-bound, read-only: 4 B intensity of included
+//        voxels + 2 class bits per voxel): region sizes and intensity sums (:113-116, :249-250), reduced by its last workgroup, checked
 //        against the sizes the band side keeps by increments
 //     -> on several GPUs: slab all-reduce -> k_dense_fin (the same check on the totals, trace sums).
 //   Stream A does not join: it runs up to two sweeps ahead of the dense pass (two copies of the class bits).
@@ -854,8 +858,8 @@ struct KmEvRec { VrgEvent ev; uint32_t m, r1, rf; };    // a buffered event: its
 __device__ __forceinline__ uint32_t km_row(int dy, int dz) { return (uint32_t)((dz + 4) * 9 + (dy + 4)); }
 // G: the flips a workgroup handles side by side, 128 threads each (1: a sweep of up to KM_BLOCKS flips, a workgroup per flip; 4: thousands
 // of flips - every round trip of a flip's chain then serves four, and a workgroup files what ~25 flips add to the lists at once)
-// (126 registers: two 512-thread workgroups - eight flips - per CU.  What bounds the kernel at 10^4 flips per sweep is not known: neither occupancy, nor the number of
-// workgroups, nor its loads' latency or count moved it - DESIGN.md section 4)
+// (136 registers with the list indirection - one 512-thread workgroup per CU; it only takes what k_mark_compact leaves.  At 10^4 flips per sweep the kernel's time was its FILING - six same-address reservations per
+// workgroup, queueing at the memory side - not its rounds: VrgCtx::rsv and k_mark_compact, below; profiles/NOTES_r05.md)
 #if defined(VRG_STAMPS)
 #define KM_STAMP_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))     // (the stamps cost registers: keep the product's two 512-thread workgroups per CU, or the timeline is another kernel's)
 #else
