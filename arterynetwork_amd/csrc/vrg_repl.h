@@ -248,12 +248,10 @@ static int repl_next_chunk(vrg_handle* h, uint64_t n, uint32_t sw_done, uint32_t
     }
     if (r.transport != TR_CALLBACK && r.transport != TR_RCCL) return fail(h, VRG_E_STATE, "replication: no transport set");
     if (r.transport == TR_CALLBACK) r.bcast(&ch, (int64_t)sizeof(ch), 0, r.user);
-    else {
-        VrgLogChunk* slot = repl_chunk_slot(h);
-        if (!slot) return fail(h, VRG_E_MEM, "replication: chunk ring");
-        if (be_repl_bcast(h->be, slot, sizeof(ch), 0)) return fail(h, VRG_E_INTERNAL, "replication: RCCL broadcast failed");
+    else {                                              // (a follower receives into device memory and copies out: only the ROOT's source is host memory - nothing here runs beside a band chain)
+        if (be_repl_bcast(h->be, r.chunk_dev, sizeof(ch), 0)) return fail(h, VRG_E_INTERNAL, "replication: RCCL broadcast failed");
         be_repl_wait(h->be);
-        ch = *slot;
+        be_repl_copy(h->be, &ch, r.chunk_dev, sizeof(ch));
     }
     // (sizes first: whatever else is wrong with the chunk, the broadcasts that follow it have to be matched)
     const size_t sb = (size_t)ch.nsw * sizeof(VrgLogSweep), rb = (size_t)ch.nrec * sizeof(VrgLogRec);

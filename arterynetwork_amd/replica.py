@@ -107,7 +107,15 @@ def bench_replicas(shape, args, dev, rank, world, roofline, configure, load_traf
     torch.cuda.synchronize()
     V = shape[0] * shape[1] * shape[2]
     lv = leader_verifies_default(world) if args.leader_verifies < 0 else bool(args.leader_verifies)
-    s = make_replica_session(shape, rank, world, device=dev.index, transport=args.transport, leader_verifies=lv)
+    try:
+        s = make_replica_session(shape, rank, world, device=dev.index, transport=args.transport, leader_verifies=lv)
+    except VrgError as e:                              # (raised on EVERY rank when the RCCL communicator cannot be set up on some rank: the ranks of one node then map the
+        if args.transport != 'rccl':                   #  leader's log buffers instead - hipIpc, xGMI peer copies - and the line says so: config.transport)
+            raise
+        import sys
+        if rank == 0:
+            sys.stderr.write('bench.py: RCCL transport of the change log not available ({}); using hipIpc\n'.format(e))
+        s = make_replica_session(shape, rank, world, device=dev.index, transport='ipc', leader_verifies=lv)
     _setup(s, I, vm, args, configure)
     s.set_option('batch', args.repl_batch)
     s.set_option('chain_events', 0)
