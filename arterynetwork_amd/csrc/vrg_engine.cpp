@@ -148,10 +148,10 @@ int check_state_error(vrg_handle* h, const VrgState& s) {
 // Each family of arrays - the band pool with the flip arrays, the marked-voxel lists - lives in ONE allocation that is carved up: growing a family is one
 // allocation, its copies, one synchronisation and one free (an allocation or a free costs 0.1-0.2 ms and a free synchronises the device: 25 arrays grown one
 // by one were 5 ms in the middle of a run).
-struct Carve {
-    uint8_t* base; size_t off = 0;
-    explicit Carve(uint8_t* b) : base(b) {}
-    template <class T> T* take(size_t n) { off = (off + 255) & ~(size_t)255; T* p = reinterpret_cast<T*>(base + off); off += std::max<size_t>(n, 1) * sizeof(T); return p; }
+struct Carve {                                       // (base null: a dry run that only adds up the bytes - no arithmetic on a null pointer)
+    uintptr_t base; size_t off = 0;
+    explicit Carve(uint8_t* b) : base(reinterpret_cast<uintptr_t>(b)) {}
+    template <class T> T* take(size_t n) { off = (off + 255) & ~(size_t)255; T* p = base ? reinterpret_cast<T*>(base + off) : nullptr; off += std::max<size_t>(n, 1) * sizeof(T); return p; }
 };
 struct PoolArrays {
     uint32_t* p_idx; uint32_t* p_lev; double* p_ip; double* p_op; float* p_err; uint64_t* p_key; uint8_t* p_flag; uint32_t* freel;
